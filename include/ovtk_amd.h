@@ -1,0 +1,247 @@
+/*
+ * ovtk_amd.h -- C ABI of the MI355X-native tokenizer hot path (libovtk_amd.so).
+ *
+ * Each entry point replaces the evaluate() body of one custom op of openvino_tokenizers
+ * (reference paths are relative to the upstream repository root).  The reference's ops take
+ * ov::TensorVector; an OpenVINO adapter maps tensors onto these plain
+ * pointer + size structs, so no C++ or torch type crosses this boundary.
+ *
+ * Data model = the reference's decomposed tensors (src/utils.cpp:84-102):
+ *   string tensor         begins i32[n], ends i32[n], chars u8[n_chars]
+ *   ragged string tensor  ragged_begins i32[rows], ragged_ends i32[rows] indexing begins/ends
+ *   ragged i32 tensor     begins i32[rows], ends i32[rows], data i32[total]
+ * Offsets need not be ordered or contiguous on input; outputs are ascending and gap-free,
+ * exactly as the reference emits them.
+ *
+ * Conventions
+ *   - every function returns OVTK_OK (0) or a negative OVTK_E_* code; ovtk_last_error() gives
+ *     the message for the calling thread (the adapter turns it into OPENVINO_THROW);
+ *   - "create" copies/compiles the constant inputs + attributes of an op into device tables
+ *     (what the reference builds lazily under call_once / a mutex on first evaluate());
+ *     a handle is immutable afterwards, so "run" may be called concurrently from several
+ *     threads / streams, like evaluate() on a shared node;
+ *   - "run" takes I/O buffers owned by the caller, all in host memory (OVTK_MEM_HOST: staged
+ *     over PCIe by the library) or all in device memory (OVTK_MEM_DEVICE: zero copies), enqueues
+ *     its kernels on `stream` (a hipStream_t, NULL = default stream) and returns after the
+ *     element counts of the variable-length outputs are known (one stream synchronisation);
+ *   - variable-length outputs are written into caller buffers of stated capacity (the reference
+ *     pre-sizes them the same way and shrinks afterwards); a too small buffer is OVTK_E_CAPACITY;
+ *   - there is NO CPU execution path: without a usable HIP device create fails with OVTK_E_HIP.
+ */
+#ifndef OVTK_AMD_H
+#define OVTK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OVTK_OK 0
+#define OVTK_E_ARG (-1)          /* bad attribute / input (reference: OPENVINO_ASSERT in validate_and_infer_types) */
+#define OVTK_E_CAPACITY (-2)     /* output buffer too small (reference: OPENVINO_ASSERT(ragged_offset < size)) */
+#define OVTK_E_VOCAB (-3)        /* merge token missing from vocab (reference: std::out_of_range, bpe_tokenizer.cpp:363-366) */
+#define OVTK_E_UNSUPPORTED (-4)  /* valid for the reference but outside what the device tables can hold / the split patterns compiled for the GPU */
+#define OVTK_E_HIP (-5)          /* HIP runtime failure, or no device */
+#define OVTK_E_RANGE (-6)        /* an index would leave its buffer (undefined behaviour in the reference) */
+
+#define OVTK_MEM_HOST 0
+#define OVTK_MEM_DEVICE 1
+
+const char* ovtk_last_error(void);
+/* ABI version of this header: major*1000 + minor. */
+int ovtk_abi_version(void);
+/* Name of the device the library runs on ("gfx950 ..."), or NULL when no HIP device is usable. */
+const char* ovtk_device_name(void);
+
+/* ---------------------------------------------------------------- tensors */
+typedef struct ovtk_strings {
+    const int32_t* begins;
+    const int32_t* ends;
+    const uint8_t* chars;
+    int64_t n;       /* number of strings */
+    int64_t n_chars; /* size of chars */
+} ovtk_strings;
+
+typedef struct ovtk_ragged_strings {
+    const int32_t* ragged_begins;
+    const int32_t* ragged_ends;
+    int64_t n_rows;
+    ovtk_strings strings;
+} ovtk_ragged_strings;
+
+/* Ragged i32 output: begins/ends sized n_rows by the caller, data sized data_capacity. */
+typedef struct ovtk_ragged_i32_out {
+    int32_t* begins;
+    int32_t* ends;
+    int32_t* data;
+    int64_t data_capacity;
+    int64_t n_data; /* out: elements written */
+    int64_t n_rows; /* out: rows written = input rows, except 1 for the all-empty-batch quirk of RegexSplit (regex_split.cpp:129-143) */
+} ovtk_ragged_i32_out;
+
+/* ---------------------------------------------------------------- RegexSplit
+ * Replaces RegexSplit::evaluate, src/regex_split.cpp:124-324 (+ PCRE2Wrapper::match, src/utils.cpp:396-420).
+ * The pattern is not interpreted by PCRE2 on the device: create() recognises the pattern families the
+ * reference's converter emits (python/openvino_tokenizers/tokenizer_pipeline.py:392-457) and selects a
+ * hand-written gfx950 scanner with identical results; any other pattern is OVTK_E_UNSUPPORTED.
+ * Inputs 0-4 (+5 skips) of the op = `in` (+ `skips`); input "pattern" and attributes = params. */
+typedef struct ovtk_regex_split_params {
+    const char* pattern;
+    int64_t pattern_len;
+    const char* behaviour; /* remove|isolate|contiguous|mergedwithprevious|mergedwithnext (regex_split.cpp:16-22) */
+    int invert;
+    int max_splits; /* -1 or > 0 (regex_split.cpp:114-117) */
+    int device;     /* HIP device ordinal */
+} ovtk_regex_split_params;
+
+typedef struct ovtk_regex_split ovtk_regex_split;
+
+typedef struct ovtk_ragged_strings_out {
+    int32_t* ragged_begins; /* [max(n_rows,1)] */
+    int32_t* ragged_ends;
+    int64_t n_rows;         /* out: n_rows, or 1 for the all-empty batch (regex_split.cpp:129-143) */
+    int32_t* begins;        /* [capacity]; reference bound: n_chars + n strings (regex_split.cpp:182) */
+    int32_t* ends;
+    uint8_t* skips;         /* [capacity] or NULL (6-input form) */
+    int64_t capacity;
+    int64_t n;              /* out: pieces written; -1 = "string outputs alias the inputs" (empty batch) */
+} ovtk_ragged_strings_out;
+
+int ovtk_regex_split_create(const ovtk_regex_split_params* params, ovtk_regex_split** out);
+/* skips: bool[in->strings.n] or NULL.  chars are never copied: output 4 of the op is its input 4 (regex_split.cpp:203). */
+int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, const uint8_t* skips,
+                         ovtk_ragged_strings_out* out, int mem, void* stream);
+void ovtk_regex_split_destroy(ovtk_regex_split* h);
+
+/* ---------------------------------------------------------------- BPETokenizer
+ * Replaces BPETokenizer::evaluate + BPETokenizerImpl, src/bpe_tokenizer.cpp:47-388, src/bpe_tokenizer.hpp:40-131.
+ * Constant inputs 5-7 (vocab), 8-10 (merges: "left right" lines, or left halves), 11-13 (right halves; NULL
+ * for the 11/15-input text form), last four (added tokens + ids; n_added = 0 if absent) and the attributes
+ * unk_token, fuse_unk, suffix_indicator, end_suffix, byte_fallback, cache_capacity (bpe_tokenizer.hpp:220-228).
+ * cache_capacity is accepted for interface parity and ignored: the reference cache is pure memoisation. */
+typedef struct ovtk_bpe_params {
+    ovtk_strings vocab;
+    ovtk_strings merges;       /* text lines or left halves */
+    ovtk_strings merges_right; /* .begins == NULL -> text form */
+    ovtk_strings added_tokens;
+    const int32_t* added_ids;  /* [added_tokens.n] */
+    const char* unk_token;
+    int64_t unk_token_len;
+    int fuse_unk;
+    const char* suffix_indicator;
+    int64_t suffix_indicator_len;
+    const char* end_suffix;
+    int64_t end_suffix_len;
+    int byte_fallback;
+    int64_t cache_capacity;
+    int device;
+} ovtk_bpe_params;
+
+typedef struct ovtk_bpe ovtk_bpe;
+
+int ovtk_bpe_create(const ovtk_bpe_params* params, ovtk_bpe** out);
+/* The op itself: pre-split pieces in, ragged ids out (out->data_capacity: reference uses n_chars). */
+int ovtk_bpe_run(ovtk_bpe* h, const ovtk_ragged_strings* in, ovtk_ragged_i32_out* out, int mem, void* stream);
+void ovtk_bpe_destroy(ovtk_bpe* h);
+
+/* Fused RegexSplit -> BPETokenizer (the sub-graph tokenizer_pipeline.py:1613-1631 builds for byte-level BPE
+ * models): same result as ovtk_regex_split_run followed by ovtk_bpe_run on its outputs, without the piece
+ * begins/ends round trip through HBM.  `skips` as for RegexSplit (skipped strings reach BPE unsplit). */
+int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+                    ovtk_ragged_i32_out* out, int mem, void* stream);
+
+/* ---------------------------------------------------------------- WordpieceTokenizer
+ * Replaces WordpieceTokenizer::evaluate, src/wordpiece_tokenizer.cpp:49-133.  Inputs 5-7 + attributes at
+ * create; input 8 (unk_token_id) is read every call, as in the reference (:74). */
+typedef struct ovtk_wordpiece_params {
+    ovtk_strings vocab;
+    const char* suffix_indicator;
+    int64_t suffix_indicator_len;
+    int max_bytes_per_word;
+    int device;
+} ovtk_wordpiece_params;
+typedef struct ovtk_wordpiece ovtk_wordpiece;
+int ovtk_wordpiece_create(const ovtk_wordpiece_params* params, ovtk_wordpiece** out);
+int ovtk_wordpiece_run(ovtk_wordpiece* h, const ovtk_ragged_strings* in, int32_t unk_token_id,
+                       ovtk_ragged_i32_out* out, int mem, void* stream);
+void ovtk_wordpiece_destroy(ovtk_wordpiece* h);
+
+/* ---------------------------------------------------------------- VocabEncoder
+ * Replaces VocabEncoder::evaluate_impl<T>, src/vocab_encoder.cpp:55-94.  value_size 4 (i32) or 8 (i64). */
+typedef struct ovtk_vocab_encoder_params {
+    ovtk_strings keys;
+    const void* values;
+    int value_size;
+    int device;
+} ovtk_vocab_encoder_params;
+typedef struct ovtk_vocab_encoder ovtk_vocab_encoder;
+int ovtk_vocab_encoder_create(const ovtk_vocab_encoder_params* params, ovtk_vocab_encoder** out);
+/* out: T[in->n]; default_value: pointer to one T in HOST memory (input 7). */
+int ovtk_vocab_encoder_run(ovtk_vocab_encoder* h, const ovtk_strings* in, const void* default_value, void* out,
+                           int mem, void* stream);
+void ovtk_vocab_encoder_destroy(ovtk_vocab_encoder* h);
+
+/* ---------------------------------------------------------------- RaggedToDense
+ * Replaces RaggedToDense::evaluate, src/ragged_to_dense.cpp:70-174.  Stateless.
+ * data: n_data ragged elements of elem_size*inner_elems bytes; out_dense/out_mask: [n_rows, target_dim, inner].
+ * default_value points to one element (elem_size bytes) in HOST memory.  out_mask may be NULL. */
+int ovtk_ragged_to_dense(const int32_t* begins, const int32_t* ends, int64_t n_rows, const void* data,
+                         int64_t n_data, int elem_size, int64_t inner_elems, int32_t target_dim,
+                         const void* default_value, int pad_right, int pad_max_length, void* out_dense,
+                         uint8_t* out_mask, int mem, int device, void* stream);
+
+/* ---------------------------------------------------------------- VocabDecoder / ByteFallback / FuzeRagged
+ * Replace VocabDecoder::evaluate (src/vocab_decoder.cpp:23-87), ByteFallback::evaluate
+ * (src/byte_fallback.cpp:16-50) and FuzeRagged::evaluate (src/fuze.cpp:20-40). */
+typedef struct ovtk_vocab_decoder_params {
+    ovtk_strings vocab;
+    const int32_t* skip_tokens; /* attribute skip_tokens; input 4 overrides it per call */
+    int64_t n_skip_tokens;
+    int device;
+} ovtk_vocab_decoder_params;
+typedef struct ovtk_vocab_decoder ovtk_vocab_decoder;
+
+typedef struct ovtk_strings_out {
+    int32_t* begins; /* [n] */
+    int32_t* ends;
+    uint8_t* chars;  /* [chars_capacity] */
+    int64_t chars_capacity;
+    int64_t n_chars; /* out */
+} ovtk_strings_out;
+
+int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* params, ovtk_vocab_decoder** out);
+/* ids: i32[batch, seq_len].  skip_tokens_input: NULL -> use the attribute; else i32[n] in HOST memory (input 4).
+ * out_ragged_begins/ends: [batch]; out->begins/ends: [batch * max(seq_len,1)]. */
+int ovtk_vocab_decoder_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len,
+                           const int32_t* skip_tokens_input, int64_t n_skip_tokens_input,
+                           int32_t* out_ragged_begins, int32_t* out_ragged_ends, ovtk_strings_out* out,
+                           int mem, void* stream);
+void ovtk_vocab_decoder_destroy(ovtk_vocab_decoder* h);
+
+/* out->begins/ends: [in->n]; out->chars capacity: reference uses in->n_chars (byte_fallback.cpp:24). */
+int ovtk_byte_fallback(const ovtk_strings* in, ovtk_strings_out* out, int mem, int device, void* stream);
+
+int ovtk_fuze_ragged(const int32_t* ragged_begins, const int32_t* ragged_ends, int64_t n_rows,
+                     const int32_t* begins, const int32_t* ends, int64_t n, int32_t* out_begins,
+                     int32_t* out_ends, int mem, int device, void* stream);
+
+/* Fused VocabDecoder -> [ByteFallback] -> FuzeRagged (tokenizer_pipeline.py:1321-1371): one string per row. */
+int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len,
+                        const int32_t* skip_tokens_input, int64_t n_skip_tokens_input, int byte_fallback,
+                        ovtk_strings_out* out, int mem, void* stream);
+
+/* ---------------------------------------------------------------- measurement hooks (bench.py)
+ * With profiling on, every kernel launch of the library is bracketed by hipEvents on the stream it is
+ * launched on; times are accumulated per kernel name after the call's own synchronisation. */
+void ovtk_profile_enable(int on);
+void ovtk_profile_reset(void);
+/* Returns 0 and fills total_ms / launches for `kernel`, or -1 if it has not been launched. */
+int ovtk_profile_get(const char* kernel, double* total_ms, int64_t* launches);
+/* Writes up to `cap` bytes of a '\n'-separated "name total_ms launches" table. Returns bytes needed. */
+int64_t ovtk_profile_dump(char* buf, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,124 @@
+"""ctypes binding of include/ovtk_amd.h.
+
+The product library is `csrc/build/libovtk_amd.so` (HIP, gfx950).  There is no CPU execution
+path: if the library is missing or no HIP device is present, loading / handle creation raises.
+(The test-suite can point `load(path)` at the SIMT-emulator build of the same sources to check
+kernel logic on CPU -- that is test infrastructure and never happens implicitly.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+DEFAULT_LIB = _HERE / "csrc" / "build" / "libovtk_amd.so"
+
+OVTK_OK = 0
+E_ARG, E_CAPACITY, E_VOCAB, E_UNSUPPORTED, E_HIP, E_RANGE = -1, -2, -3, -4, -5, -6
+MEM_HOST, MEM_DEVICE = 0, 1
+
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+
+
+class Strings(C.Structure):
+    _fields_ = [("begins", C.c_void_p), ("ends", C.c_void_p), ("chars", C.c_void_p), ("n", C.c_int64),
+                ("n_chars", C.c_int64)]
+
+
+class RaggedStrings(C.Structure):
+    _fields_ = [("ragged_begins", C.c_void_p), ("ragged_ends", C.c_void_p), ("n_rows", C.c_int64),
+                ("strings", Strings)]
+
+
+class RaggedI32Out(C.Structure):
+    _fields_ = [("begins", C.c_void_p), ("ends", C.c_void_p), ("data", C.c_void_p), ("data_capacity", C.c_int64),
+                ("n_data", C.c_int64), ("n_rows", C.c_int64)]
+
+
+class RegexSplitParams(C.Structure):
+    _fields_ = [("pattern", C.c_char_p), ("pattern_len", C.c_int64), ("behaviour", C.c_char_p), ("invert", C.c_int),
+                ("max_splits", C.c_int), ("device", C.c_int)]
+
+
+class RaggedStringsOut(C.Structure):
+    _fields_ = [("ragged_begins", C.c_void_p), ("ragged_ends", C.c_void_p), ("n_rows", C.c_int64),
+                ("begins", C.c_void_p), ("ends", C.c_void_p), ("skips", C.c_void_p), ("capacity", C.c_int64),
+                ("n", C.c_int64)]
+
+
+class BpeParams(C.Structure):
+    _fields_ = [("vocab", Strings), ("merges", Strings), ("merges_right", Strings), ("added_tokens", Strings),
+                ("added_ids", C.c_void_p), ("unk_token", C.c_char_p), ("unk_token_len", C.c_int64),
+                ("fuse_unk", C.c_int), ("suffix_indicator", C.c_char_p), ("suffix_indicator_len", C.c_int64),
+                ("end_suffix", C.c_char_p), ("end_suffix_len", C.c_int64), ("byte_fallback", C.c_int),
+                ("cache_capacity", C.c_int64), ("device", C.c_int)]
+
+
+class WordpieceParams(C.Structure):
+    _fields_ = [("vocab", Strings), ("suffix_indicator", C.c_char_p), ("suffix_indicator_len", C.c_int64),
+                ("max_bytes_per_word", C.c_int), ("device", C.c_int)]
+
+
+class VocabEncoderParams(C.Structure):
+    _fields_ = [("keys", Strings), ("values", C.c_void_p), ("value_size", C.c_int), ("device", C.c_int)]
+
+
+class VocabDecoderParams(C.Structure):
+    _fields_ = [("vocab", Strings), ("skip_tokens", C.c_void_p), ("n_skip_tokens", C.c_int64), ("device", C.c_int)]
+
+
+class StringsOut(C.Structure):
+    _fields_ = [("begins", C.c_void_p), ("ends", C.c_void_p), ("chars", C.c_void_p), ("chars_capacity", C.c_int64),
+                ("n_chars", C.c_int64)]
+
+
+EXPORTS = [
+    "ovtk_last_error", "ovtk_abi_version", "ovtk_device_name",
+    "ovtk_regex_split_create", "ovtk_regex_split_run", "ovtk_regex_split_destroy",
+    "ovtk_bpe_create", "ovtk_bpe_run", "ovtk_bpe_destroy", "ovtk_encode_run",
+    "ovtk_wordpiece_create", "ovtk_wordpiece_run", "ovtk_wordpiece_destroy",
+    "ovtk_vocab_encoder_create", "ovtk_vocab_encoder_run", "ovtk_vocab_encoder_destroy",
+    "ovtk_ragged_to_dense",
+    "ovtk_vocab_decoder_create", "ovtk_vocab_decoder_run", "ovtk_vocab_decoder_destroy",
+    "ovtk_byte_fallback", "ovtk_fuze_ragged", "ovtk_detokenize_run",
+    "ovtk_profile_enable", "ovtk_profile_reset", "ovtk_profile_get", "ovtk_profile_dump",
+]
+
+
+class OvtkError(RuntimeError):
+    def __init__(self, code, msg):
+        self.code = code
+        super().__init__(f"ovtk error {code}: {msg}")
+
+
+_cache = {}
+
+
+def load(path: os.PathLike | str | None = None) -> C.CDLL:
+    """Loads the HIP library (default) or an explicitly given build.  Raises if it is missing."""
+    p = Path(path) if path is not None else DEFAULT_LIB
+    key = str(p)
+    if key in _cache:
+        return _cache[key]
+    if not p.exists():
+        raise OvtkError(E_HIP, f"{p} not found: build it with `make -C {_HERE / 'csrc'}` "
+                               f"(__graft_entry__.build()); there is no CPU fallback")
+    if path is None:
+        # Share the process' HIP runtime with PyTorch (same SONAME libamdhip64.so.7): import torch first.
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing, not a requirement
+            pass
+    lib = C.CDLL(str(p))
+    lib.ovtk_last_error.restype = C.c_char_p
+    lib.ovtk_device_name.restype = C.c_char_p
+    lib.ovtk_profile_dump.restype = C.c_int64
+    _cache[key] = lib
+    return lib
+
+
+def check(lib, rc):
+    if rc != OVTK_OK:
+        raise OvtkError(rc, lib.ovtk_last_error().decode(errors="replace"))

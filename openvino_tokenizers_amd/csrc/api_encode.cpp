@@ -1,0 +1,444 @@
+// api_encode.cpp -- C-ABI entry points of RegexSplit, BPETokenizer and the fused encode path.
+// Compiled as HIP (hipcc -x hip).  Reference behaviour replaced: src/regex_split.cpp:124-324,
+// src/bpe_tokenizer.cpp:47-164 (evaluate) and :341-388 (table construction).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include "encode_kernels.hpp"
+#include "runtime.hpp"
+#include "tables.hpp"
+#include "unicode_tables.inc"
+
+using namespace ovtk;
+
+namespace {
+
+const char kGpt2Pattern[] = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+const char kGpt2DigitsPattern[] = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+
+// Unicode property tables, one copy per device.
+struct UnicodeTables {
+    DevBuf index, blocks;
+};
+int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks) {
+    static std::mutex mu;
+    static std::map<int, std::unique_ptr<UnicodeTables>> per_device;
+    std::lock_guard<std::mutex> lk(mu);
+    auto& t = per_device[device];
+    if (!t) {
+        auto fresh = std::make_unique<UnicodeTables>();
+        if (int rc = fresh->index.upload(kUcIndex, sizeof kUcIndex)) return rc;
+        if (int rc = fresh->blocks.upload(kUcBlocks, sizeof kUcBlocks)) return rc;
+        OVTK_HIP(hipStreamSynchronize(nullptr));
+        t = std::move(fresh);
+    }
+    *index = t->index.as<uint16_t>();
+    *blocks = t->blocks.as<uint8_t>();
+    return OVTK_OK;
+}
+
+int use_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_error(OVTK_E_HIP, "no HIP device is available; this library has no CPU execution path");
+    if (device < 0 || device >= n) return set_error(OVTK_E_ARG, "device ordinal out of range");
+    OVTK_HIP(hipSetDevice(device));
+    return OVTK_OK;
+}
+
+StringsView view_of(const ovtk_strings& s) { return StringsView{s.begins, s.ends, s.chars, s.n}; }
+
+}  // namespace
+
+struct ovtk_regex_split {
+    int device = 0;
+    SplitDev dev{};
+    int mode = 1;  // 0 removed, 1 isolated, 2 merged-with-previous, 3 merged-with-next
+    bool invert = false;
+    int max_splits = -1;
+};
+
+struct ovtk_bpe {
+    int device = 0;
+    BpeDev dev{};
+    DevBuf root, node, edges, merges, new_id, bf;
+};
+
+extern "C" {
+
+const char* ovtk_last_error(void) { return last_error(); }
+int ovtk_abi_version(void) { return 1000; }
+
+const char* ovtk_device_name(void) {
+    static std::string name;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return nullptr;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return nullptr;
+    name = std::string(prop.gcnArchName) + " " + prop.name;
+    return name.c_str();
+}
+
+void ovtk_profile_enable(int on) { Profiler::get().enable(on != 0); }
+void ovtk_profile_reset(void) { Profiler::get().reset(); }
+int ovtk_profile_get(const char* kernel, double* total_ms, int64_t* launches) {
+    return Profiler::get().lookup(kernel, total_ms, launches) ? 0 : -1;
+}
+int64_t ovtk_profile_dump(char* buf, int64_t cap) {
+    const std::string s = Profiler::get().dump();
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(size_t(cap) - 1, s.size());
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return int64_t(s.size()) + 1;
+}
+
+// ------------------------------------------------------------------------------- RegexSplit
+int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split** out) {
+    if (!p || !out || !p->pattern || !p->behaviour) return set_error(OVTK_E_ARG, "regex_split: null argument");
+    auto h = std::make_unique<ovtk_regex_split>();
+    const std::string beh(p->behaviour), pat(p->pattern, p->pattern + p->pattern_len);
+    // regex_split.cpp:16-22,113-117
+    if (beh == "remove") h->mode = 0;
+    else if (beh == "isolate" || beh == "contiguous") h->mode = 1;
+    else if (beh == "mergedwithprevious") h->mode = 2;
+    else if (beh == "mergedwithnext") h->mode = 3;
+    else return set_error(OVTK_E_ARG, "RegexSplit doesn't support unknown split mode: " + beh);
+    if (!(p->max_splits == -1 || p->max_splits > 0))
+        return set_error(OVTK_E_ARG, "RegexSplit max_splits attribute must be greater then `0` or equal to `-1`");
+    h->invert = p->invert != 0;
+    h->max_splits = p->max_splits;
+    if (pat == kGpt2Pattern) h->dev.kind = kSplitGpt2;
+    else if (pat == kGpt2DigitsPattern) h->dev.kind = kSplitGpt2Digits;
+    else
+        return set_error(OVTK_E_UNSUPPORTED,
+                         "RegexSplit: no gfx950 scanner for this pattern (supported: the byte-level patterns of "
+                         "tokenizer_pipeline.py:448-457); PCRE2 is not executed on the device");
+    if (beh != "isolate")
+        return set_error(OVTK_E_UNSUPPORTED, "RegexSplit: the byte-level patterns are only supported with behaviour=isolate");
+    if (int rc = use_device(p->device)) return rc;
+    h->device = p->device;
+    if (int rc = unicode_tables(p->device, &h->dev.uc_index, &h->dev.uc_blocks)) return rc;
+    *out = h.release();
+    return OVTK_OK;
+}
+
+void ovtk_regex_split_destroy(ovtk_regex_split* h) { delete h; }
+
+// ------------------------------------------------------------------------------- BPETokenizer
+int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
+    if (!p || !out) return set_error(OVTK_E_ARG, "bpe: null argument");
+    if (int rc = use_device(p->device)) return rc;
+    BpeHost host;
+    std::string err;
+    const StringsView right = view_of(p->merges_right);
+    const int rc = build_bpe(view_of(p->vocab), view_of(p->merges), p->merges_right.begins ? &right : nullptr,
+                             view_of(p->added_tokens), p->added_ids,
+                             std::string(p->unk_token ? p->unk_token : "", size_t(p->unk_token ? p->unk_token_len : 0)),
+                             std::string(p->end_suffix ? p->end_suffix : "", size_t(p->end_suffix ? p->end_suffix_len : 0)),
+                             p->byte_fallback != 0, host, err);
+    if (rc) return set_error(rc, err);
+    auto h = std::make_unique<ovtk_bpe>();
+    h->device = p->device;
+    int e = 0;
+    e = e ? e : h->root.upload(host.trie.root.data(), host.trie.root.size() * sizeof(I2));
+    e = e ? e : h->node.upload(host.trie.node.data(), host.trie.node.size() * sizeof(I2));
+    e = e ? e : h->edges.upload(host.trie.edges.data(), host.trie.edges.size() * sizeof(uint64_t));
+    e = e ? e : h->merges.upload(host.merges.data(), host.merges.size() * sizeof(uint64_t));
+    e = e ? e : h->new_id.upload(host.new_id.data(), host.new_id.size() * sizeof(int32_t));
+    e = e ? e : h->bf.upload(host.byte_fallback_id.data(), host.byte_fallback_id.size() * sizeof(int32_t));
+    if (e) return e;
+    OVTK_HIP(hipStreamSynchronize(nullptr));
+    BpeDev& d = h->dev;
+    d.trie.root = h->root.as<I2>();
+    d.trie.node = h->node.as<I2>();
+    d.trie.edges = h->edges.as<uint64_t>();
+    d.trie.edge_mask = host.trie.edge_mask;
+    d.trie.edge_shift = host.trie.edge_shift;
+    d.merges = h->merges.as<uint64_t>();
+    d.bucket_mask = host.bucket_mask;
+    d.bucket_shift = host.bucket_shift;
+    d.new_id = h->new_id.as<int32_t>();
+    d.byte_fallback_id = h->bf.as<int32_t>();
+    d.unk_id = host.unk_id;
+    d.suffix_len = int32_t(host.suffix.size());
+    std::memset(d.suffix, 0, sizeof d.suffix);
+    std::memcpy(d.suffix, host.suffix.data(), host.suffix.size());
+    *out = h.release();
+    return OVTK_OK;
+}
+
+void ovtk_bpe_destroy(ovtk_bpe* h) { delete h; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------- run pipelines
+namespace {
+
+int check_rows(const ovtk_ragged_strings* in) {
+    if (!in) return set_error(OVTK_E_ARG, "null input");
+    if (in->n_rows < 0 || in->strings.n < 0 || in->strings.n_chars < 0) return set_error(OVTK_E_ARG, "negative size");
+    if (in->n_rows >= INT32_MAX || in->strings.n >= INT32_MAX || in->strings.n_chars >= INT32_MAX)
+        return set_error(OVTK_E_ARG, "tensor sizes must fit int32 offsets (the reference's begins/ends are i32)");
+    return OVTK_OK;
+}
+
+// Brings the input ragged string tensor to the device (or wraps device pointers).
+int stage_input(Workspace& ws, const ovtk_ragged_strings* in, const uint8_t* skips, int mem, hipStream_t s, RowsIn& d) {
+    d.n_rows = int32_t(in->n_rows);
+    d.n_strings = int32_t(in->strings.n);
+    d.n_chars = in->strings.n_chars;
+    if (mem == OVTK_MEM_DEVICE) {
+        d.ragged_begins = in->ragged_begins;
+        d.ragged_ends = in->ragged_ends;
+        d.begins = in->strings.begins;
+        d.ends = in->strings.ends;
+        d.chars = in->strings.chars;
+        d.skips = skips;
+        return OVTK_OK;
+    }
+    if (mem != OVTK_MEM_HOST) return set_error(OVTK_E_ARG, "mem must be OVTK_MEM_HOST or OVTK_MEM_DEVICE");
+    int e = 0;
+    e = e ? e : ws.in_rb.upload(in->ragged_begins, size_t(in->n_rows) * 4, s);
+    e = e ? e : ws.in_re.upload(in->ragged_ends, size_t(in->n_rows) * 4, s);
+    e = e ? e : ws.in_begins.upload(in->strings.begins, size_t(in->strings.n) * 4, s);
+    e = e ? e : ws.in_ends.upload(in->strings.ends, size_t(in->strings.n) * 4, s);
+    e = e ? e : ws.in_chars.upload(in->strings.chars, size_t(in->strings.n_chars), s);
+    if (skips) e = e ? e : ws.in_skips.upload(skips, size_t(in->strings.n), s);
+    if (e) return e;
+    d.ragged_begins = ws.in_rb.as<int32_t>();
+    d.ragged_ends = ws.in_re.as<int32_t>();
+    d.begins = ws.in_begins.as<int32_t>();
+    d.ends = ws.in_ends.as<int32_t>();
+    d.chars = ws.in_chars.as<uint8_t>();
+    d.skips = skips ? ws.in_skips.as<uint8_t>() : nullptr;
+    return OVTK_OK;
+}
+
+int grid_for_rows(int n_rows) { return std::max(1, (n_rows + kWavesPerBlock - 1) / kWavesPerBlock); }
+
+int finish_status(Workspace& ws, hipStream_t s) {
+    OVTK_HIP(hipMemcpyAsync(ws.host_status, ws.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s));
+    OVTK_HIP(hipStreamSynchronize(s));
+    Profiler::get().resolve(ws.marks);
+    OVTK_HIP(hipGetLastError());
+    return OVTK_OK;
+}
+
+// RegexSplit [+] BPETokenizer.  split == nullptr: `in` already holds pieces (the BPETokenizer op).
+int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+               ovtk_ragged_i32_out* out, int mem, void* stream) {
+    if (int rc = check_rows(in)) return rc;
+    if (!bpe || !out) return set_error(OVTK_E_ARG, "null argument");
+    if (split && split->device != bpe->device) return set_error(OVTK_E_ARG, "split and bpe handles live on different devices");
+    if (out->data_capacity < 0 || out->data_capacity >= INT32_MAX) return set_error(OVTK_E_ARG, "bad output capacity");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(bpe->device));
+    out->n_data = 0;
+    out->n_rows = in->n_rows;
+    if (split && in->strings.n_chars == 0) {
+        // regex_split.cpp:129-143 quirk: an all-empty batch leaves RegexSplit with ragged shape {1} = [0],[0];
+        // BPETokenizer then emits one empty row (bpe_tokenizer.cpp:129-131,146-161).
+        const int32_t zero = 0;
+        if (mem == OVTK_MEM_HOST) {
+            out->begins[0] = 0;
+            out->ends[0] = 0;
+        } else {
+            OVTK_HIP(hipMemcpyAsync(out->begins, &zero, 4, hipMemcpyHostToDevice, s));
+            OVTK_HIP(hipMemcpyAsync(out->ends, &zero, 4, hipMemcpyHostToDevice, s));
+            OVTK_HIP(hipStreamSynchronize(s));
+        }
+        out->n_rows = 1;
+        return OVTK_OK;
+    }
+    if (in->n_rows == 0) return OVTK_OK;
+
+    WorkspaceLease ws(bpe->device);
+    if (!ws->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
+    RowsIn d_in{};
+    if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
+
+    const int mul = 1 + bpe->dev.suffix_len;
+    const int n_rows = d_in.n_rows;
+    int64_t stage_cap = std::min<int64_t>((in->strings.n_chars + in->strings.n) * mul, INT32_MAX - 1);
+    int64_t deferred_cap = std::max<int64_t>(4096, in->strings.n / 8);
+    int64_t scratch_cap = std::max<int64_t>(ws->scratch.size(), int64_t(16) << 20);
+
+    int32_t *d_begins = out->begins, *d_ends = out->ends, *d_ids = out->data;
+    if (mem == OVTK_MEM_HOST) {
+        if (int rc = ws->out_a.ensure(size_t(n_rows) * 4)) return rc;
+        if (int rc = ws->out_b.ensure(size_t(n_rows) * 4)) return rc;
+        if (int rc = ws->out_c.ensure(size_t(out->data_capacity) * 4)) return rc;
+        d_begins = ws->out_a.as<int32_t>();
+        d_ends = ws->out_b.as<int32_t>();
+        d_ids = ws->out_c.as<int32_t>();
+    }
+
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        int e = 0;
+        e = e ? e : ws->row_stage.ensure(size_t(n_rows + 1) * 4);
+        e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
+        e = e ? e : ws->row_out.ensure(size_t(n_rows + 1) * 4);
+        e = e ? e : ws->row_slotted.ensure(size_t(n_rows));
+        e = e ? e : ws->stage.ensure(size_t(stage_cap) * 4);
+        e = e ? e : ws->deferred.ensure(size_t(deferred_cap) * sizeof(DeferredPiece));
+        e = e ? e : ws->scratch.ensure(size_t(scratch_cap));
+        e = e ? e : ws->status.ensure(sizeof(RunStatus));
+        if (e) return e;
+        EncodeWork w{};
+        w.row_stage = ws->row_stage.as<int32_t>();
+        w.row_cnt = ws->row_cnt.as<int32_t>();
+        w.row_out = ws->row_out.as<int32_t>();
+        w.row_slotted = ws->row_slotted.as<uint8_t>();
+        w.stage = ws->stage.as<int32_t>();
+        w.stage_cap = int32_t(stage_cap);
+        w.deferred = ws->deferred.as<DeferredPiece>();
+        w.deferred_cap = int32_t(deferred_cap);
+        w.scratch = ws->scratch.as<uint8_t>();
+        w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap, 0xFFFFFFF0ll));
+        w.status = ws->status.as<RunStatus>();
+
+        OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
+        OVTK_LAUNCH(ws->marks, "prepare_rows", prepare_rows_kernel, 1, kScanThreads, s, d_in, mul, w);
+        if (split)
+            OVTK_LAUNCH(ws->marks, "encode_fused", encode_kernel<kFused>, grid_for_rows(n_rows), kBlockThreads, s, d_in,
+                        split->dev, bpe->dev, w);
+        else
+            OVTK_LAUNCH(ws->marks, "encode_pieces", encode_kernel<kPieces>, grid_for_rows(n_rows), kBlockThreads, s, d_in,
+                        SplitDev{}, bpe->dev, w);
+        OVTK_LAUNCH(ws->marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
+        OVTK_LAUNCH(ws->marks, "finalize_rows", finalize_rows_kernel, 1, kScanThreads, s, n_rows, w, d_begins, d_ends,
+                    (long long)out->data_capacity);
+        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_for_rows(n_rows), kBlockThreads, s, n_rows, w, d_ids);
+        if (int rc = finish_status(*ws.ws, s)) return rc;
+
+        const RunStatus& st = *ws->host_status;
+        if (st.flags & kFlagRange)
+            return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+        if (st.flags & kFlagStageOverflow) {
+            if (st.stage_need >= INT32_MAX - 1) return set_error(OVTK_E_UNSUPPORTED, "batch needs more than 2^31 staging entries; split the call");
+            stage_cap = st.stage_need;
+            continue;
+        }
+        if (st.flags & kFlagDeferOverflow) {
+            deferred_cap = int64_t(st.n_deferred) + 64;
+            continue;
+        }
+        if (st.flags & kFlagScratchOverflow) {
+            scratch_cap = std::max<int64_t>(scratch_cap * 2, int64_t(st.scratch_used) + (1 << 20));
+            if (scratch_cap > (int64_t(3) << 30)) return set_error(OVTK_E_UNSUPPORTED, "exact-path scratch would exceed 3 GiB; split the call");
+            continue;
+        }
+        if (st.flags & kFlagOutCapacity)
+            return set_error(OVTK_E_CAPACITY, "BPETokenizer: output ids buffer too small (" + std::to_string(st.n_out) +
+                                                  " ids, capacity " + std::to_string(out->data_capacity) + ")");
+        out->n_data = st.n_out;
+        if (mem == OVTK_MEM_HOST) {
+            OVTK_HIP(hipMemcpyAsync(out->begins, d_begins, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
+            OVTK_HIP(hipMemcpyAsync(out->ends, d_ends, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
+            OVTK_HIP(hipMemcpyAsync(out->data, d_ids, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
+            OVTK_HIP(hipStreamSynchronize(s));
+        }
+        return OVTK_OK;
+    }
+    return set_error(OVTK_E_HIP, "workspace sizing did not converge");
+}
+
+}  // namespace
+
+extern "C" {
+
+int ovtk_bpe_run(ovtk_bpe* h, const ovtk_ragged_strings* in, ovtk_ragged_i32_out* out, int mem, void* stream) {
+    return run_encode(nullptr, h, in, nullptr, out, mem, stream);
+}
+
+int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+                    ovtk_ragged_i32_out* out, int mem, void* stream) {
+    if (!split) return set_error(OVTK_E_ARG, "null split handle");
+    return run_encode(split, bpe, in, skips, out, mem, stream);
+}
+
+int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, const uint8_t* skips,
+                         ovtk_ragged_strings_out* out, int mem, void* stream) {
+    if (int rc = check_rows(in)) return rc;
+    if (!h || !out) return set_error(OVTK_E_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(h->device));
+    out->n = 0;
+    out->n_rows = in->n_rows;
+    if (in->strings.n_chars == 0) {  // regex_split.cpp:129-143
+        const int32_t zero = 0;
+        if (mem == OVTK_MEM_HOST) {
+            out->ragged_begins[0] = 0;
+            out->ragged_ends[0] = 0;
+        } else {
+            OVTK_HIP(hipMemcpyAsync(out->ragged_begins, &zero, 4, hipMemcpyHostToDevice, s));
+            OVTK_HIP(hipMemcpyAsync(out->ragged_ends, &zero, 4, hipMemcpyHostToDevice, s));
+            OVTK_HIP(hipStreamSynchronize(s));
+        }
+        out->n_rows = 1;
+        out->n = -1;
+        return OVTK_OK;
+    }
+    if (in->n_rows == 0) return OVTK_OK;
+    WorkspaceLease ws(h->device);
+    if (!ws->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
+    RowsIn d_in{};
+    if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
+    const int n_rows = d_in.n_rows;
+    int e = 0;
+    e = e ? e : ws->row_stage.ensure(size_t(n_rows + 1) * 4);
+    e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
+    e = e ? e : ws->row_out.ensure(size_t(n_rows + 1) * 4);
+    e = e ? e : ws->status.ensure(sizeof(RunStatus));
+    if (e) return e;
+    int32_t *d_rb = out->ragged_begins, *d_re = out->ragged_ends, *d_b = out->begins, *d_e = out->ends;
+    uint8_t* d_sk = out->skips;
+    if (mem == OVTK_MEM_HOST) {
+        e = e ? e : ws->out_a.ensure(size_t(n_rows) * 4);
+        e = e ? e : ws->out_b.ensure(size_t(n_rows) * 4);
+        e = e ? e : ws->out_c.ensure(size_t(out->capacity) * 4);
+        e = e ? e : ws->out_d.ensure(size_t(out->capacity) * 4);
+        e = e ? e : ws->out_e.ensure(size_t(out->capacity));
+        if (e) return e;
+        d_rb = ws->out_a.as<int32_t>();
+        d_re = ws->out_b.as<int32_t>();
+        d_b = ws->out_c.as<int32_t>();
+        d_e = ws->out_d.as<int32_t>();
+        d_sk = out->skips ? ws->out_e.as<uint8_t>() : nullptr;
+    }
+    EncodeWork w{};
+    w.row_stage = ws->row_stage.as<int32_t>();
+    w.row_cnt = ws->row_cnt.as<int32_t>();
+    w.row_out = ws->row_out.as<int32_t>();
+    w.stage_cap = INT32_MAX;
+    w.status = ws->status.as<RunStatus>();
+    OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
+    OVTK_LAUNCH(ws->marks, "prepare_rows", prepare_rows_kernel, 1, kScanThreads, s, d_in, 1, w);
+    OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid_for_rows(n_rows), kBlockThreads, s, d_in, h->dev,
+                h->max_splits, w, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
+    OVTK_LAUNCH(ws->marks, "finalize_rows", finalize_rows_kernel, 1, kScanThreads, s, n_rows, w, d_rb, d_re,
+                (long long)out->capacity);
+    OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid_for_rows(n_rows), kBlockThreads, s, d_in, h->dev,
+                h->max_splits, w, d_b, d_e, d_sk);
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    const RunStatus& st = *ws->host_status;
+    if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+    if (st.flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "RegexSplit: output begins/ends too small");
+    out->n = st.n_out;
+    if (mem == OVTK_MEM_HOST) {
+        OVTK_HIP(hipMemcpyAsync(out->ragged_begins, d_rb, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->ragged_ends, d_re, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->begins, d_b, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->ends, d_e, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
+        if (out->skips) OVTK_HIP(hipMemcpyAsync(out->skips, d_sk, size_t(st.n_out), hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipStreamSynchronize(s));
+    }
+    return OVTK_OK;
+}
+
+}  // extern "C"

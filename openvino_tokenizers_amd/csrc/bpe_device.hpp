@@ -1,0 +1,273 @@
+// bpe_device.hpp -- device side of BPETokenizerImpl::tokenize_into (src/bpe_tokenizer.cpp:196-339).
+//
+// The reference pops merge candidates from a std::priority_queue ordered by (rank, seq), seq being a
+// creation counter (initial pair k has seq k; the two pairs created by the j-th merge share seq
+// n-1+j).  Because stale entries are skipped, "pop" always yields the LIVE adjacent pair with the
+// smallest (rank, seq) -- so as long as that minimum is unique the queue can be replaced by a
+// min-scan over the live pairs, which is what the two fast paths do:
+//   path F  one lane per piece (<= kFastSyms symbols): symbols + pair keys of all 64 pieces of a
+//           batch live in the wave's LDS arrays, each lane scans / compacts its own stretch;
+//   path W  one wave per piece (up to kChunk symbols): lanes scan the piece's pairs in parallel,
+//           wave-min picks the merge, lanes shift the tail cooperatively.
+// A non-unique minimum can only be the two pairs pushed by one merge with equal rank;
+// its pop order is decided by libstdc++'s heap layout, so such a piece (and any piece too long
+// for LDS) is replayed by path X: bpe_exact_piece(), a step-for-step emulation of
+// std::push_heap / std::pop_heap on the same (rank, new_id, a, b, seq) entries, stale ones included.
+//
+// Pair key in LDS: (rank << 10) | seq, 0xFFFFFFFF = "not a merge".  rank < 2^22, seq < 1024 because
+// a piece handled in LDS has at most kChunk = 512 symbols and seq < 2n.
+#pragma once
+
+#include "device_common.hpp"
+#include "tables.hpp"
+
+namespace ovtk {
+
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr int kSeqBits = 10;
+constexpr int kFastSyms = 24;  // pieces with more symbols than this use path W
+
+__device__ __forceinline__ uint32_t merge_rank(const BpeDev& T, uint32_t l, uint32_t r) {
+    const uint64_t key = merge_key(l, r);
+    uint32_t b = uint32_t(hash_u64(key) >> T.bucket_shift) & T.bucket_mask;
+    for (;;) {
+        const ulonglong2 s = reinterpret_cast<const ulonglong2*>(T.merges)[b];
+        if ((s.x >> kMaxRankBits) == key) return uint32_t(s.x) & kNoRank;
+        if ((s.y >> kMaxRankBits) == key) return uint32_t(s.y) & kNoRank;
+        if (s.y == kEmptySlot) return kNoRank;
+        b = (b + 1) & T.bucket_mask;
+    }
+}
+__device__ __forceinline__ uint32_t pair_key(const BpeDev& T, uint32_t l, uint32_t r, uint32_t seq) {
+    const uint32_t rank = merge_rank(T, l, r);
+    return rank == kNoRank ? kNoKey : ((rank << kSeqBits) | seq);
+}
+
+__device__ __forceinline__ int trie_child(const TrieDev& t, int node, uint32_t byte) {
+    const uint32_t key = (uint32_t(node) << 8) | byte;
+    uint32_t p = (hash_u32(key) >> t.edge_shift) & t.edge_mask;
+    for (;;) {
+        const uint64_t e = t.edges[p];
+        if (e == kEmptySlot) return -1;
+        if (uint32_t(e >> 32) == key) return int(uint32_t(e));
+        p = (p + 1) & t.edge_mask;
+    }
+}
+
+// Longest-match walk (src/utils.cpp:517-538) from text position idx; `root` may point to an LDS copy.
+template <class GetByte>
+__device__ __forceinline__ int trie_longest(const TrieDev& t, const I2* root, GetByte&& getb, int n, int& idx) {
+    const I2 r = root[getb(idx)];
+    if (r.y < 0) return -1;
+    int best = r.x, best_end = idx + 1, i = idx + 1;
+    int cur = r.y & ~kLeafBit;
+    bool leaf = (r.y & kLeafBit) != 0;
+    while (!leaf && i < n) {
+        const int child = trie_child(t, cur, getb(i));
+        if (child < 0) break;
+        cur = child;
+        ++i;
+        const I2 nd = t.node[cur];
+        if (nd.x != -1) { best = nd.x; best_end = i; }
+        leaf = nd.y == 0;
+    }
+    if (best == -1) return -1;
+    idx = best_end;
+    return best;
+}
+
+// Initial symbols of one piece (bpe_tokenizer.cpp:230-257): greedy longest trie match, else the
+// byte-fallback token, else unk, else the byte is dropped.  Returns the symbol count.
+template <class GetByte, class Put>
+__device__ __forceinline__ int bpe_symbolize(const BpeDev& T, const I2* root, GetByte&& getb, int n, Put&& put) {
+    int idx = 0, cnt = 0;
+    while (idx < n) {
+        const int tok = trie_longest(T.trie, root, getb, n, idx);
+        if (tok != -1) {
+            put(cnt++, tok);
+            continue;
+        }
+        const int fb = T.byte_fallback_id[getb(idx)];
+        if (fb != -1) put(cnt++, fb);
+        else if (T.unk_id != -1) put(cnt++, T.unk_id);  // fuse_unk never changes this
+        ++idx;
+    }
+    return cnt;
+}
+
+// Path F.  id/key: this lane's private stretch of the wave's LDS arrays, n symbols.
+// Returns the final symbol count, or -1 when the minimum was not unique (replay on path X).
+__device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uint32_t* key, int n) {
+    for (int k = 0; k + 1 < n; ++k) key[k] = pair_key(T, id[k], id[k + 1], uint32_t(k));
+    uint32_t seq = n > 0 ? uint32_t(n - 1) : 0;
+    while (n >= 2) {
+        uint32_t best = kNoKey;
+        int at = 0;
+        bool dup = false;
+        for (int k = 0; k + 1 < n; ++k) {
+            const uint32_t v = key[k];
+            if (v < best) { best = v; at = k; dup = false; }
+            else if (v == best && v != kNoKey) dup = true;
+        }
+        if (best == kNoKey) break;
+        if (dup) return -1;
+        const uint32_t nid = uint32_t(T.new_id[best >> kSeqBits]);
+        id[at] = nid;
+        for (int k = at + 1; k + 1 < n; ++k) {  // close the gap left by the right operand
+            id[k] = id[k + 1];
+            key[k] = key[k + 1];
+        }
+        --n;
+        ++seq;
+        if (at > 0) key[at - 1] = pair_key(T, id[at - 1], nid, seq);
+        if (at + 1 < n) key[at] = pair_key(T, nid, id[at + 1], seq);
+    }
+    return n;
+}
+
+// Path W.  All 64 lanes work on ONE piece of n symbols at id/key (LDS).  Wave-uniform; returns the
+// final count or -1 for a non-unique minimum.
+__device__ __forceinline__ int bpe_merge_wave(const BpeDev& T, uint32_t* id, uint32_t* key, int n) {
+    const int l = lane_id();
+    for (int k = l; k + 1 < n; k += kWave) key[k] = pair_key(T, id[k], id[k + 1], uint32_t(k));
+    wave_sync();
+    uint32_t seq = n > 0 ? uint32_t(n - 1) : 0;
+    while (n >= 2) {
+        // (key, position) minimum; a second pair with the same key shows up as a larger position.
+        unsigned long long mine = ~0ull;
+        int hits = 0;
+        uint32_t local_best = kNoKey;
+        for (int k = l; k + 1 < n; k += kWave) {
+            const uint32_t v = key[k];
+            if (v < local_best) { local_best = v; mine = (uint64_t(v) << 32) | uint32_t(k); hits = 1; }
+            else if (v == local_best && v != kNoKey) ++hits;
+        }
+        const unsigned long long best = wave_min_u64(mine);
+        const uint32_t bkey = uint32_t(best >> 32);
+        if (bkey == kNoKey) break;
+        const int same = wave_sum(local_best == bkey ? hits : 0);
+        if (same > 1) return -1;
+        const int at = int(uint32_t(best));
+        const uint32_t nid = uint32_t(T.new_id[bkey >> kSeqBits]);
+        // cooperative shift-left of (at+1, n)
+        for (int base = at + 1; base + 1 < n; base += kWave) {
+            const int k = base + l;
+            uint32_t a = 0, b = 0;
+            if (k + 1 < n) { a = id[k + 1]; b = key[k + 1]; }
+            wave_sync();
+            if (k + 1 < n) { id[k] = a; key[k] = b; }
+            wave_sync();
+        }
+        --n;
+        ++seq;
+        if (l == 0) {
+            id[at] = nid;
+            if (at > 0) key[at - 1] = pair_key(T, id[at - 1], nid, seq);
+            if (at + 1 < n) key[at] = pair_key(T, nid, id[at + 1], seq);
+        }
+        wave_sync();
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Path X: exact replay with libstdc++'s binary heap (bits/stl_heap.h __push_heap / __adjust_heap,
+// as used by std::priority_queue::emplace / pop) and the reference's symbol list.  One lane per
+// piece, all state in global scratch.  `less(x, y)` is CompareRank(x, y): x has the LARGER
+// (rank, seq) (bpe_tokenizer.cpp:166-172).
+// ---------------------------------------------------------------------------------------------
+struct HeapEntry { int32_t rank, seq, a, b; };  // new_id is a function of rank (T.new_id)
+
+__device__ __forceinline__ bool heap_less(const HeapEntry& x, const HeapEntry& y) {
+    return x.rank != y.rank ? x.rank > y.rank : x.seq > y.seq;
+}
+__device__ __forceinline__ void heap_push(HeapEntry* h, int& size, HeapEntry v) {
+    int hole = size++;
+    int parent = (hole - 1) / 2;
+    while (hole > 0 && heap_less(h[parent], v)) {
+        h[hole] = h[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    h[hole] = v;
+}
+__device__ __forceinline__ HeapEntry heap_pop(HeapEntry* h, int& size) {
+    const HeapEntry top = h[0];
+    if (size > 1) {
+        const HeapEntry v = h[size - 1];  // pop_heap: value = *(last-1); *(last-1) = *first; adjust(0, len-1, value)
+        const int len = size - 1;
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (heap_less(h[child], h[child - 1])) --child;
+            h[hole] = h[child];
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            h[hole] = h[child - 1];
+            hole = child - 1;
+        }
+        int parent = (hole - 1) / 2;
+        while (hole > 0 && heap_less(h[parent], v)) {
+            h[hole] = h[parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        h[hole] = v;
+    }
+    --size;
+    return top;
+}
+
+// Bytes of scratch bpe_exact_piece needs for a text of n bytes (suffix included).
+__host__ __device__ inline uint32_t bpe_exact_scratch_bytes(uint32_t n) {
+    return (3u * 2u * n * 4u) + (3u * n + 1u) * uint32_t(sizeof(HeapEntry)) + 64u;
+}
+
+// Tokenizes one piece exactly as the reference does; writes the ids to out[0..) and returns their
+// number.  scratch: bpe_exact_scratch_bytes(n) bytes, 16-byte aligned.
+template <class GetByte>
+__device__ inline int bpe_exact_piece(const BpeDev& T, GetByte&& getb, int n, void* scratch, int32_t* out) {
+    int32_t* sid = static_cast<int32_t*>(scratch);  // [2n] id
+    int32_t* sprev = sid + 2 * n;                   // [2n]
+    int32_t* snext = sprev + 2 * n;                 // [2n]  (-2 = dead)
+    HeapEntry* heap = reinterpret_cast<HeapEntry*>(
+        (reinterpret_cast<uintptr_t>(snext + 2 * n) + 15) & ~uintptr_t(15));
+    int nsym = bpe_symbolize(T, T.trie.root, getb, n, [&](int k, int tok) {
+        sid[k] = tok;
+        sprev[k] = k - 1;
+        snext[k] = -1;
+        if (k > 0) snext[k - 1] = k;
+    });
+    int live = nsym, hsize = 0, seq = 0, head = nsym ? 0 : -1;
+    auto try_push = [&](int a, int b) {
+        const uint32_t rank = merge_rank(T, uint32_t(sid[a]), uint32_t(sid[b]));
+        if (rank != kNoRank) heap_push(heap, hsize, HeapEntry{int32_t(rank), seq, a, b});
+    };
+    for (int a = head; a != -1 && snext[a] != -1; a = snext[a]) {
+        try_push(a, snext[a]);
+        ++seq;
+    }
+    while (hsize > 0 && live >= 2) {
+        const HeapEntry e = heap_pop(heap, hsize);
+        if (snext[e.a] == -2 || snext[e.b] == -2 || snext[e.a] != e.b) continue;  // stale
+        const int pv = sprev[e.a], nx = snext[e.b], m = nsym++;
+        sid[m] = T.new_id[e.rank];
+        sprev[m] = pv;
+        snext[m] = nx;
+        snext[e.a] = -2;
+        snext[e.b] = -2;
+        if (pv != -1) snext[pv] = m; else head = m;
+        if (nx != -1) sprev[nx] = m;
+        --live;
+        ++seq;
+        if (pv != -1) try_push(pv, m);
+        if (nx != -1) try_push(m, nx);
+    }
+    int cnt = 0;
+    for (int i = head; i != -1; i = snext[i]) out[cnt++] = sid[i];
+    return cnt;
+}
+
+}  // namespace ovtk

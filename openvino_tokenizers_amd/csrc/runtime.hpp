@@ -1,0 +1,108 @@
+// runtime.hpp -- host-side plumbing shared by the op entry points: error reporting, device
+// buffers, per-call workspaces, kernel-launch timing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ovtk_amd.h"
+#include "device_common.hpp"
+
+namespace ovtk {
+
+int set_error(int code, const std::string& msg);
+const char* last_error();
+
+#define OVTK_HIP(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return ::ovtk::set_error(OVTK_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+// Grow-only device buffer.
+class DevBuf {
+public:
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    int ensure(size_t bytes);  // 0 or OVTK_E_HIP
+    int upload(const void* host, size_t bytes, hipStream_t s = nullptr);
+    void release();
+    template <typename T> T* as() const { return static_cast<T*>(p_); }
+    size_t size() const { return cap_; }
+private:
+    void* p_ = nullptr;
+    size_t cap_ = 0;
+};
+
+// Kernel timing for bench.py: hipEvents on the launch stream, resolved after the call's sync.
+class Profiler {
+public:
+    static Profiler& get();
+    bool enabled() const { return on_; }
+    void enable(bool on) { on_ = on; }
+    void reset();
+    bool lookup(const std::string& name, double* ms, int64_t* n);
+    std::string dump();
+    // per call
+    struct Mark { const char* name; hipEvent_t a, b; };
+    void begin(const char* name, hipStream_t s, std::vector<Mark>& marks);
+    void end(hipStream_t s, std::vector<Mark>& marks);
+    void resolve(std::vector<Mark>& marks);
+private:
+    bool on_ = false;
+    std::mutex mu_;
+    std::map<std::string, std::pair<double, int64_t>> acc_;
+    std::vector<hipEvent_t> pool_;
+    hipEvent_t take();
+};
+
+// Launch a kernel, optionally bracketed by profiler events.
+#define OVTK_LAUNCH(marks, name, kernel, grid, block, stream, ...)                   \
+    do {                                                                              \
+        ::ovtk::Profiler& pf_ = ::ovtk::Profiler::get();                              \
+        if (pf_.enabled()) pf_.begin(name, stream, marks);                            \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);  \
+        if (pf_.enabled()) pf_.end(stream, marks);                                    \
+    } while (0)
+
+// Scratch memory of one in-flight run() call.  Handles are immutable; every call checks a
+// workspace out of the per-device pool, so concurrent calls never share mutable state.
+struct Workspace {
+    DevBuf row_stage, row_cnt, row_out, row_slotted, stage, deferred, scratch, status;
+    DevBuf in_rb, in_re, in_begins, in_ends, in_chars, in_skips;  // staging for OVTK_MEM_HOST calls
+    DevBuf out_a, out_b, out_c, out_d, out_e;
+    RunStatus* host_status = nullptr;  // pinned
+    std::vector<Profiler::Mark> marks;
+    ~Workspace();
+};
+
+class WorkspacePool {
+public:
+    static WorkspacePool& get(int device);
+    std::unique_ptr<Workspace> acquire();
+    void release(std::unique_ptr<Workspace> w);
+private:
+    std::mutex mu_;
+    std::vector<std::unique_ptr<Workspace>> free_;
+};
+
+struct WorkspaceLease {
+    explicit WorkspaceLease(int device) : pool(WorkspacePool::get(device)), ws(pool.acquire()) {}
+    ~WorkspaceLease() { pool.release(std::move(ws)); }
+    WorkspacePool& pool;
+    std::unique_ptr<Workspace> ws;
+    Workspace* operator->() { return ws.get(); }
+};
+
+int device_cu_count(int device);
+
+}  // namespace ovtk

@@ -1,0 +1,262 @@
+// tables.cpp -- host-side construction of the device lookup tables (see tables.hpp).
+#include <hip/hip_runtime.h>
+
+#include "tables.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+
+#include "../../include/ovtk_amd.h"
+
+namespace ovtk {
+
+namespace {
+std::string view_str(const StringsView& v, int64_t i) {
+    return std::string(reinterpret_cast<const char*>(v.chars) + v.begins[i],
+                       reinterpret_cast<const char*>(v.chars) + v.ends[i]);
+}
+uint32_t pow2_at_least(uint64_t n) {
+    uint32_t c = 1;
+    while (c < n) c <<= 1;
+    return c;
+}
+int log2u(uint32_t c) {
+    int b = 0;
+    while ((1u << b) < c) ++b;
+    return b;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------- trie
+TrieHost::TrieHost() {
+    b.kids.emplace_back();
+    b.value.push_back(-1);
+}
+
+void TrieHost::add(const uint8_t* s, size_t n, int32_t value) {
+    int cur = 0;
+    for (size_t i = 0; i < n; ++i) {
+        auto& ks = b.kids[cur];
+        auto it = std::lower_bound(ks.begin(), ks.end(), s[i], [](const auto& k, uint8_t c) { return k.first < c; });
+        if (it == ks.end() || it->first != s[i]) {
+            const int fresh = int(b.kids.size());
+            it = ks.insert(it, {s[i], fresh});
+            const int child = it->second;  // read before the vectors below may reallocate b.kids
+            b.kids.emplace_back();
+            b.value.push_back(-1);
+            cur = child;
+        } else {
+            cur = it->second;
+        }
+    }
+    b.value[cur] = value;  // same string added twice: the later value stays (src/utils.cpp:476-478)
+}
+
+void TrieHost::finalize() {
+    const size_t n = b.kids.size();
+    node.assign(n, I2{-1, 0});
+    size_t n_edges = 0;
+    for (size_t i = 0; i < n; ++i) {
+        node[i] = I2{b.value[i], b.kids[i].empty() ? 0 : 1};
+        if (i != 0) n_edges += b.kids[i].size();
+    }
+    root.assign(256, I2{-1, -1});
+    for (const auto& k : b.kids[0]) {
+        const int child = k.second;
+        root[k.first] = I2{b.value[child], child | (b.kids[child].empty() ? kLeafBit : 0)};
+    }
+    const uint32_t cap = std::max<uint32_t>(8, pow2_at_least(uint64_t(n_edges) * 2 + 1));
+    edge_mask = cap - 1;
+    edge_shift = 32 - log2u(cap);
+    edges.assign(cap, kEmptySlot);
+    for (size_t i = 1; i < n; ++i)
+        for (const auto& k : b.kids[i]) {
+            const uint32_t key = (uint32_t(i) << 8) | k.first;
+            uint32_t idx = (hash_u32(key) >> edge_shift) & edge_mask;
+            while (edges[idx] != kEmptySlot) idx = (idx + 1) & edge_mask;
+            edges[idx] = (uint64_t(key) << 32) | uint32_t(k.second);
+        }
+}
+
+int TrieHost::find_longest(const uint8_t* s, int n, int& idx) const {
+    const I2 r = root[s[idx]];
+    if (r.y < 0) return -1;
+    int best = r.x, best_end = idx + 1, i = idx + 1;
+    int cur = r.y & ~kLeafBit;
+    bool leaf = (r.y & kLeafBit) != 0;
+    while (!leaf && i < n) {
+        const uint32_t key = (uint32_t(cur) << 8) | s[i];
+        uint32_t p = (hash_u32(key) >> edge_shift) & edge_mask;
+        int child = -1;
+        while (edges[p] != kEmptySlot) {
+            if (uint32_t(edges[p] >> 32) == key) { child = int(uint32_t(edges[p])); break; }
+            p = (p + 1) & edge_mask;
+        }
+        if (child < 0) break;
+        cur = child;
+        ++i;
+        if (node[cur].x != -1) { best = node[cur].x; best_end = i; }
+        leaf = node[cur].y == 0;
+    }
+    if (best == -1) return -1;
+    idx = best_end;
+    return best;
+}
+
+// ------------------------------------------------------------------------------- BPE
+uint32_t BpeHost::find_merge(uint32_t l, uint32_t r) const {
+    if (merges.empty()) return kNoRank;
+    const uint64_t key = merge_key(l, r);
+    uint32_t bkt = uint32_t(hash_u64(key) >> bucket_shift) & bucket_mask;
+    for (;;) {
+        const uint64_t a = merges[2 * bkt], c = merges[2 * bkt + 1];
+        if ((a >> kMaxRankBits) == key) return uint32_t(a) & kNoRank;
+        if ((c >> kMaxRankBits) == key) return uint32_t(c) & kNoRank;
+        if (c == kEmptySlot) return kNoRank;
+        bkt = (bkt + 1) & bucket_mask;
+    }
+}
+
+int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView* mr, const StringsView& added,
+              const int32_t* added_ids, const std::string& unk_token, const std::string& end_suffix,
+              bool byte_fallback, BpeHost& out, std::string& err) {
+    if (vocab.n >= (int64_t(1) << kMaxVocabBits) - 1) {
+        err = "BPETokenizer: vocabularies of 2^21 or more tokens are not supported by the device tables";
+        return OVTK_E_UNSUPPORTED;
+    }
+    if (ml.n >= int64_t(kNoRank)) {
+        err = "BPETokenizer: 2^22 or more merges are not supported by the device tables";
+        return OVTK_E_UNSUPPORTED;
+    }
+    if (end_suffix.size() > size_t(kMaxSuffix)) {
+        err = "BPETokenizer: end_suffix longer than 6 bytes is not supported on the device";
+        return OVTK_E_UNSUPPORTED;
+    }
+    // Added tokens: ordered map, first occurrence of a string kept (bpe_tokenizer.cpp:51-67).
+    std::map<std::string, int32_t> added_map;
+    for (int64_t i = 0; i < added.n; ++i) {
+        if (added_ids[i] < 0 || added_ids[i] >= (1 << kMaxVocabBits) - 1) {
+            err = "BPETokenizer: added-token id outside [0, 2^21-1) is not supported by the device tables";
+            return OVTK_E_UNSUPPORTED;
+        }
+        added_map.insert({view_str(added, i), added_ids[i]});
+    }
+    // token string -> id, the later id wins (bpe_tokenizer.cpp:79-82); added tokens never overwrite (:110-114).
+    std::unordered_map<std::string, int32_t> tok;
+    tok.reserve(size_t(vocab.n + added.n) * 2);
+    for (int64_t id = 0; id < vocab.n; ++id) tok[view_str(vocab, id)] = int32_t(id);
+    for (const auto& kv : added_map) tok.insert(kv);
+
+    out.unk_id = -1;
+    if (auto it = tok.find(unk_token); it != tok.end()) out.unk_id = it->second;  // :353-355
+
+    // Merges in rank order; a repeated (left,right) pair keeps the LAST rank/new_id (bpe_tokenizer.hpp:58-66).
+    struct Pair { uint32_t l, r; };
+    std::unordered_map<uint64_t, uint32_t> rank_of;
+    rank_of.reserve(size_t(ml.n) * 2);
+    out.new_id.assign(size_t(ml.n), -1);
+    std::vector<std::string> merged;
+    merged.reserve(size_t(ml.n));
+    for (int64_t i = 0; i < ml.n; ++i) {
+        std::string left, right;
+        if (mr) {
+            left = view_str(ml, i);
+            right = view_str(*mr, i);
+        } else {  // "left right" split at the first space (:94-95); no space: substr(npos + 1) == whole line
+            std::string line = view_str(ml, i);
+            const size_t sp = line.find(' ');
+            left = line.substr(0, sp);
+            right = line.substr(sp + 1);
+        }
+        auto l = tok.find(left), r = tok.find(right);
+        std::string both = left + right;
+        auto z = tok.find(both);
+        if (l == tok.end() || r == tok.end() || z == tok.end()) {
+            err = "BPETokenizer: merge " + std::to_string(i) + " references a token that is not in the vocabulary";
+            return OVTK_E_VOCAB;
+        }
+        rank_of[merge_key(uint32_t(l->second), uint32_t(r->second))] = uint32_t(i);
+        out.new_id[size_t(i)] = z->second;
+        merged.push_back(std::move(both));
+    }
+    // Merge results leave the vocabulary; the trie holds what remains (:375-386).
+    for (const auto& m : merged) tok.erase(m);
+    for (const auto& kv : tok)
+        out.trie.add(reinterpret_cast<const uint8_t*>(kv.first.data()), kv.first.size(), kv.second);
+    out.trie.finalize();
+
+    out.byte_fallback_id.assign(256, -1);
+    if (byte_fallback) {  // "<0x%02X>" looked up in the post-erasure vocabulary (:242-248)
+        char buf[8];
+        for (int b = 0; b < 256; ++b) {
+            std::snprintf(buf, sizeof buf, "<0x%02X>", b);
+            if (auto it = tok.find(buf); it != tok.end()) out.byte_fallback_id[size_t(b)] = it->second;
+        }
+    }
+    out.suffix = end_suffix;
+
+    // Bucketised open addressing, load factor <= 0.5 of the slots.
+    const uint32_t buckets = std::max<uint32_t>(4, pow2_at_least(rank_of.size() + 1));
+    out.bucket_mask = buckets - 1;
+    out.bucket_shift = 64 - log2u(buckets);
+    out.merges.assign(size_t(buckets) * 2, kEmptySlot);
+    for (const auto& kv : rank_of) {
+        uint32_t bkt = uint32_t(hash_u64(kv.first) >> out.bucket_shift) & out.bucket_mask;
+        for (;;) {
+            uint64_t* s = &out.merges[size_t(bkt) * 2];
+            if (s[0] == kEmptySlot) { s[0] = (kv.first << kMaxRankBits) | kv.second; break; }
+            if (s[1] == kEmptySlot) { s[1] = (kv.first << kMaxRankBits) | kv.second; break; }
+            bkt = (bkt + 1) & out.bucket_mask;
+        }
+    }
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- WordPiece
+int build_wordpiece(const StringsView& vocab, const std::string& si, TrieHost& root, TrieHost& sub, std::string& err) {
+    (void)err;
+    for (int64_t id = 0; id < vocab.n; ++id) {  // wordpiece_tokenizer.cpp:59-71
+        const uint8_t* p = vocab.chars + vocab.begins[id];
+        const size_t n = size_t(vocab.ends[id] - vocab.begins[id]);
+        if (n >= si.size() && std::memcmp(p, si.data(), si.size()) == 0) sub.add(p + si.size(), n - si.size(), int32_t(id));
+        else root.add(p, n, int32_t(id));
+    }
+    root.finalize();
+    sub.finalize();
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- VocabEncoder
+int build_string_map(const StringsView& keys, StringMapHost& out, std::string& err) {
+    (void)err;
+    const uint32_t cap = std::max<uint32_t>(8, pow2_at_least(uint64_t(keys.n) * 2 + 1));
+    out.mask = cap - 1;
+    out.slots.assign(cap, kEmptySlot);
+    out.key_begins.assign(keys.begins, keys.begins + keys.n);
+    out.key_ends.assign(keys.ends, keys.ends + keys.n);
+    int64_t hi = 0;
+    for (int64_t i = 0; i < keys.n; ++i) hi = std::max<int64_t>(hi, keys.ends[i]);
+    out.key_chars.assign(keys.chars, keys.chars + hi);
+    for (int64_t i = 0; i < keys.n; ++i) {  // insert(): the FIRST occurrence of a key wins (vocab_encoder.cpp:76)
+        const uint8_t* p = keys.chars + keys.begins[i];
+        const int n = keys.ends[i] - keys.begins[i];
+        const uint32_t h = hash_bytes(p, n);
+        uint32_t idx = h & out.mask;
+        bool dup = false;
+        while (out.slots[idx] != kEmptySlot) {
+            if (uint32_t(out.slots[idx] >> 32) == h) {
+                const int64_t j = int64_t(uint32_t(out.slots[idx]));
+                const int m = keys.ends[j] - keys.begins[j];
+                if (m == n && std::memcmp(keys.chars + keys.begins[j], p, size_t(n)) == 0) { dup = true; break; }
+            }
+            idx = (idx + 1) & out.mask;
+        }
+        if (!dup) out.slots[idx] = (uint64_t(h) << 32) | uint32_t(i);
+    }
+    return OVTK_OK;
+}
+
+}  // namespace ovtk

@@ -1,0 +1,121 @@
+// tables.hpp -- read-only lookup tables of the tokenizer ops: host-side builders (plain C++) and
+// the POD views the kernels receive.  Built once per op handle from the op's constant inputs,
+// i.e. what the reference builds lazily on first evaluate():
+//   BPE   vocab map / merges map / trie      src/bpe_tokenizer.cpp:50-120, 341-388
+//   trie  Trie::add / find_longest           src/utils.cpp:464-538
+//   WordPiece root + "##" tries              src/wordpiece_tokenizer.cpp:51-73
+//   VocabEncoder string -> value map         src/vocab_encoder.cpp:62-79
+//
+// Device layouts (all flat arrays, sized for L2 residency, probed with one or two 8/16-byte loads):
+//   trie      root[256] {value, child|leaf bit}; node[n] {value, has_children};
+//             edges: open-addressing table of u64 {key = node<<8|byte : 32, child : 32}
+//   merges    16-byte buckets of two u64 slots {left:21 | right:21 | rank:22}, linear probing by
+//             bucket; new_id[rank] as a dense side array
+//   strings   (VocabEncoder) open-addressing table of {hash32, key index}; keys stay in the
+//             decomposed begins/ends/chars form for the final byte compare
+#pragma once
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace ovtk {
+
+struct I2 { int32_t x, y; };
+
+constexpr uint64_t kEmptySlot = ~0ull;
+constexpr int kMaxVocabBits = 21;            // ids < 2^21 - 1
+constexpr int kMaxRankBits = 22;             // merges < 2^22 - 1
+constexpr uint32_t kNoRank = (1u << kMaxRankBits) - 1;
+constexpr int kMaxSuffix = 6;                // end_suffix bytes supported on the device
+constexpr int32_t kLeafBit = 1 << 30;        // root[b].y / node child field: node has no children
+
+// ---- device views -----------------------------------------------------------------------
+struct TrieDev {
+    const I2* root;          // [256] x = token id ending at this byte or -1; y = node | kLeafBit, or -1 (no child)
+    const I2* node;          // [n_nodes] x = value (-1 none), y = 1 if the node has children
+    const uint64_t* edges;   // [edge_mask+1]
+    uint32_t edge_mask;
+    uint32_t edge_shift;     // 32 - log2(capacity)
+};
+
+struct BpeDev {
+    TrieDev trie;
+    const uint64_t* merges;     // [2 * (bucket_mask+1)]
+    uint32_t bucket_mask;
+    uint32_t bucket_shift;      // 64 - log2(buckets)
+    const int32_t* new_id;      // [n_merges]
+    const int32_t* byte_fallback_id;  // [256], -1 = none (all -1 when byte_fallback is off)
+    int32_t unk_id;
+    int32_t suffix_len;
+    uint8_t suffix[8];
+};
+
+struct StringMapDev {
+    const uint64_t* slots;   // {hash32 : 32 | key index : 32}, kEmptySlot = free
+    uint32_t mask;
+    const int32_t* key_begins;
+    const int32_t* key_ends;
+    const uint8_t* key_chars;
+    const void* values;      // i32 or i64 [n_keys]
+    int32_t value_size;
+};
+
+__host__ __device__ inline uint32_t hash_u32(uint32_t k) { return k * 0x9E3779B1u; }
+__host__ __device__ inline uint64_t hash_u64(uint64_t k) { return k * 0x9E3779B97F4A7C15ull; }
+__host__ __device__ inline uint64_t merge_key(uint32_t l, uint32_t r) { return (uint64_t(l) << kMaxVocabBits) | r; }
+// FNV-1a over the bytes; the same function on host (table build) and device (probe).
+__host__ __device__ inline uint32_t hash_bytes(const uint8_t* p, int n) {
+    uint32_t h = 2166136261u;
+    for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 16777619u;
+    return h;
+}
+
+// ---- host builders ----------------------------------------------------------------------
+struct TrieHost {
+    std::vector<I2> root;
+    std::vector<I2> node;
+    std::vector<uint64_t> edges;
+    uint32_t edge_mask = 0, edge_shift = 32;
+
+    // Incremental form used while inserting.
+    struct Build { std::vector<std::vector<std::pair<uint8_t, int>>> kids; std::vector<int32_t> value; } b;
+    TrieHost();
+    void add(const uint8_t* s, size_t n, int32_t value);  // later add of the same string overwrites
+    void finalize();                                      // flattens b -> root/node/edges
+    // Host mirror of the device walk (unit tests): longest token starting at s[idx], idx advanced.
+    int find_longest(const uint8_t* s, int n, int& idx) const;
+};
+
+struct BpeHost {
+    TrieHost trie;
+    std::vector<uint64_t> merges;
+    uint32_t bucket_mask = 0, bucket_shift = 64;
+    std::vector<int32_t> new_id;
+    std::vector<int32_t> byte_fallback_id;
+    int32_t unk_id = -1;
+    std::string suffix;
+    // Host mirror of the device probe (unit tests): rank or kNoRank.
+    uint32_t find_merge(uint32_t l, uint32_t r) const;
+};
+
+struct StringsView { const int32_t* begins; const int32_t* ends; const uint8_t* chars; int64_t n; };
+
+// Returns 0 or a negative OVTK_E_* code with `err` filled.
+int build_bpe(const StringsView& vocab, const StringsView& merges_left, const StringsView* merges_right,
+              const StringsView& added, const int32_t* added_ids, const std::string& unk_token,
+              const std::string& end_suffix, bool byte_fallback, BpeHost& out, std::string& err);
+
+int build_wordpiece(const StringsView& vocab, const std::string& suffix_indicator, TrieHost& root, TrieHost& sub,
+                    std::string& err);
+
+struct StringMapHost {
+    std::vector<uint64_t> slots;
+    uint32_t mask = 0;
+    std::vector<int32_t> key_begins, key_ends;
+    std::vector<uint8_t> key_chars;
+};
+int build_string_map(const StringsView& keys, StringMapHost& out, std::string& err);
+
+}  // namespace ovtk

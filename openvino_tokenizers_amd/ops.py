@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's custom ops for the tokenizer hot path.
+
+Each class carries the reference op's name, attributes (`visit_attributes` names) and
+`evaluate(inputs) -> outputs` contract with the reference's input order,
+so a test written against the reference's op reads the same here.  Constant inputs (vocab,
+merges, pattern ...) are consumed on the first `evaluate` -- like the reference's lazy
+`call_once` initialisation -- and compiled into device tables by the C-ABI library.
+
+Data inputs may be numpy arrays (host memory: staged over PCIe by the library) or torch CUDA
+tensors (device memory: zero copies; outputs are torch tensors on the same device and the
+kernels run on torch's current stream).  Everything is computed by libovtk_amd.so on the GPU;
+there is no CPU implementation behind these classes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+_NP = {"i32": np.int32, "u8": np.uint8, "i64": np.int64, "bool": np.uint8}
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "device")
+
+
+class _Mem:
+    """Where the data tensors of one call live + how to allocate outputs next to them."""
+
+    def __init__(self, sample):
+        self.torch = _is_torch(sample) and sample.device.type == "cuda"
+        if self.torch:
+            import torch
+            self.t = torch
+            self.device = sample.device
+            self.mem = L.MEM_DEVICE
+            self.stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        else:
+            self.mem = L.MEM_HOST
+            self.stream = C.c_void_p(0)
+        self.keep = []
+
+    def inp(self, x, kind):
+        """-> (array, pointer) of a data input in this call's memory space."""
+        if self.torch:
+            dt = {"i32": self.t.int32, "u8": self.t.uint8, "i64": self.t.int64, "bool": self.t.uint8}[kind]
+            if not _is_torch(x):
+                x = self.t.as_tensor(np.ascontiguousarray(x, dtype=_NP[kind]), device=self.device)
+            if x.dtype == self.t.bool:
+                x = x.view(self.t.uint8)
+            x = x.to(device=self.device, dtype=dt).contiguous()
+            self.keep.append(x)
+            return x, C.c_void_p(x.data_ptr())
+        if _is_torch(x):
+            x = x.cpu().numpy()
+        a = np.ascontiguousarray(x, dtype=_NP[kind])
+        self.keep.append(a)
+        return a, C.c_void_p(a.ctypes.data)
+
+    def alloc(self, n, kind):
+        n = max(int(n), 1)
+        if self.torch:
+            dt = {"i32": self.t.int32, "u8": self.t.uint8, "i64": self.t.int64, "bool": self.t.uint8}[kind]
+            x = self.t.empty(n, dtype=dt, device=self.device)
+            return x, C.c_void_p(x.data_ptr())
+        a = np.empty(n, dtype=_NP[kind])
+        return a, C.c_void_p(a.ctypes.data)
+
+
+def _host(x, dtype):
+    if _is_torch(x):
+        x = x.cpu().numpy()
+    return np.ascontiguousarray(x, dtype=dtype)
+
+
+def _strings_struct(begins, ends, chars, keep):
+    b, e, c = _host(begins, np.int32), _host(ends, np.int32), _host(chars, np.uint8)
+    keep += [b, e, c]
+    return L.Strings(b.ctypes.data, e.ctypes.data, c.ctypes.data if c.size else None, len(b), len(c))
+
+
+def _ragged_in(m: _Mem, inputs):
+    rb, prb = m.inp(inputs[0], "i32")
+    re_, pre = m.inp(inputs[1], "i32")
+    b, pb = m.inp(inputs[2], "i32")
+    e, pe = m.inp(inputs[3], "i32")
+    c, pc = m.inp(inputs[4], "u8")
+    rs = L.RaggedStrings(prb, pre, len(rb), L.Strings(pb, pe, pc, len(b), len(c)))
+    return rs, (rb, re_, b, e, c)
+
+
+def _bytes_of(x):
+    if isinstance(x, str):
+        return x.encode("utf-8")
+    if isinstance(x, (bytes, bytearray)):
+        return bytes(x)
+    return bytes(_host(x, np.uint8))
+
+
+class _Op:
+    def __init__(self, device=0, lib=None):
+        self.device = int(device)
+        self._lib = lib if lib is not None else L.load()
+        self._h = C.c_void_p()
+
+    def _chk(self, rc):
+        L.check(self._lib, rc)
+
+
+class RegexSplit(_Op):
+    """Reference: src/regex_split.cpp (evaluate :124-324).  Inputs: ragged_begins, ragged_ends, begins, ends,
+    chars, [skips], pattern.  Outputs: ragged_begins, ragged_ends, begins, ends, chars (the input tensor), [skips]."""
+
+    def __init__(self, behaviour="remove", invert=False, max_splits=-1, device=0, lib=None):
+        super().__init__(device, lib)
+        self.behaviour, self.invert, self.max_splits = behaviour, bool(invert), int(max_splits)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ovtk_regex_split_destroy(self._h)
+            self._h = None
+
+    def _ensure(self, pattern):
+        if self._h:
+            return
+        pat = _bytes_of(pattern)
+        p = L.RegexSplitParams(pat, len(pat), self.behaviour.encode(), int(self.invert), self.max_splits, self.device)
+        self._chk(self._lib.ovtk_regex_split_create(C.byref(p), C.byref(self._h)))
+
+    def evaluate(self, inputs):
+        if len(inputs) not in (6, 7):
+            raise L.OvtkError(L.E_ARG, f"Incorrect number of inputs passed to RegexSplit: {len(inputs)}")
+        has_skips = len(inputs) == 7
+        self._ensure(inputs[5 + has_skips])
+        m = _Mem(inputs[4])
+        rs, (rb, re_, b, e, c) = _ragged_in(m, inputs)
+        skips, pskips = (m.inp(inputs[5], "bool") if has_skips else (None, None))
+        cap = len(c) + len(b)
+        orb, porb = m.alloc(len(rb), "i32")
+        ore, pore = m.alloc(len(rb), "i32")
+        ob, pob = m.alloc(cap, "i32")
+        oe, poe = m.alloc(cap, "i32")
+        osk, posk = (m.alloc(cap, "bool") if has_skips else (None, None))
+        out = L.RaggedStringsOut(porb, pore, 0, pob, poe, posk, cap, 0)
+        self._chk(self._lib.ovtk_regex_split_run(self._h, C.byref(rs), pskips, C.byref(out), m.mem, m.stream))
+        if out.n < 0:  # regex_split.cpp:129-143: shape {1} ragged dims, string tensors are the inputs
+            res = [orb[:1], ore[:1], b, e, c]
+            if has_skips:
+                res.append(skips)
+            return res
+        res = [orb[:out.n_rows], ore[:out.n_rows], ob[:out.n], oe[:out.n], c]
+        if has_skips:
+            res.append(osk[:out.n])
+        return res
+
+
+class BPETokenizer(_Op):
+    """Reference: src/bpe_tokenizer.cpp (evaluate :47-164).  11/14/15/18 inputs: ragged strings (5), vocab (3),
+    merges (3, or 3 + 3 for left/right halves), [added tokens (3) + ids (1)].  Outputs: begins, ends, ids."""
+
+    def __init__(self, unk_token="", fuse_unk=False, suffix_indicator="", end_suffix="", byte_fallback=False,
+                 cache_capacity=20000, device=0, lib=None):
+        super().__init__(device, lib)
+        self.unk_token, self.fuse_unk = unk_token, bool(fuse_unk)
+        self.suffix_indicator, self.end_suffix = suffix_indicator, end_suffix
+        self.byte_fallback, self.cache_capacity = bool(byte_fallback), int(cache_capacity)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ovtk_bpe_destroy(self._h)
+            self._h = None
+
+    def _ensure(self, inputs):
+        if self._h:
+            return
+        n = len(inputs)
+        if n not in (11, 14, 15, 18):
+            raise L.OvtkError(L.E_ARG, "Incorrect number of inputs passed to BPETokenizer")
+        keep = []
+        vocab = _strings_struct(*inputs[5:8], keep)
+        merges = _strings_struct(*inputs[8:11], keep)
+        right = _strings_struct(*inputs[11:14], keep) if n in (14, 18) else L.Strings(None, None, None, 0, 0)
+        if n in (15, 18):
+            added = _strings_struct(*inputs[n - 4:n - 1], keep)
+            ids = _host(inputs[n - 1], np.int32)
+            keep.append(ids)
+            pids = ids.ctypes.data
+        else:
+            added, pids = L.Strings(None, None, None, 0, 0), None
+        unk, si, es = _bytes_of(self.unk_token), _bytes_of(self.suffix_indicator), _bytes_of(self.end_suffix)
+        p = L.BpeParams(vocab, merges, right, added, pids, unk, len(unk), int(self.fuse_unk), si, len(si), es, len(es),
+                        int(self.byte_fallback), self.cache_capacity, self.device)
+        self._chk(self._lib.ovtk_bpe_create(C.byref(p), C.byref(self._h)))
+
+    def evaluate(self, inputs):
+        self._ensure(inputs)
+        m = _Mem(inputs[4])
+        rs, (rb, _, _, _, c) = _ragged_in(m, inputs)
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        cap = len(c)  # bpe_tokenizer.cpp:135
+        ids, pids = m.alloc(cap, "i32")
+        out = L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
+        self._chk(self._lib.ovtk_bpe_run(self._h, C.byref(rs), C.byref(out), m.mem, m.stream))
+        return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+
+
+class FusedSplitBPE:
+    """RegexSplit -> BPETokenizer in one launch (ovtk_encode_run): the same result as chaining the two ops
+    (what tokenizer_pipeline.py:1613-1631 builds for byte-level BPE models) without materialising the pieces."""
+
+    def __init__(self, split: RegexSplit, bpe: BPETokenizer):
+        self.split, self.bpe = split, bpe
+
+    def evaluate(self, split_inputs, bpe_constant_inputs):
+        """split_inputs: the 6/7 inputs of RegexSplit; bpe_constant_inputs: inputs 5.. of BPETokenizer."""
+        has_skips = len(split_inputs) == 7
+        self.split._ensure(split_inputs[5 + has_skips])
+        self.bpe._ensure(list(split_inputs[:5]) + list(bpe_constant_inputs))
+        m = _Mem(split_inputs[4])
+        rs, (rb, _, _, _, c) = _ragged_in(m, split_inputs)
+        _, pskips = (m.inp(split_inputs[5], "bool") if has_skips else (None, None))
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        cap = len(c)
+        ids, pids = m.alloc(cap, "i32")
+        out = L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
+        lib = self.bpe._lib
+        L.check(lib, lib.ovtk_encode_run(self.split._h, self.bpe._h, C.byref(rs), pskips, C.byref(out), m.mem, m.stream))
+        return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
