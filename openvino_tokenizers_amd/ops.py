@@ -194,13 +194,15 @@ class BPETokenizer(_Op):
                         int(self.byte_fallback), self.cache_capacity, self.device)
         self._chk(self._lib.ovtk_bpe_create(C.byref(p), C.byref(self._h)))
 
-    def evaluate(self, inputs):
+    def evaluate(self, inputs, ids_capacity=None):
+        """ids_capacity: size of the ids buffer; default = number of input chars, as the reference sizes it
+        (bpe_tokenizer.cpp:135) -- only an end_suffix model can need more."""
         self._ensure(inputs)
         m = _Mem(inputs[4])
         rs, (rb, _, _, _, c) = _ragged_in(m, inputs)
         ob, pob = m.alloc(len(rb), "i32")
         oe, poe = m.alloc(len(rb), "i32")
-        cap = len(c)  # bpe_tokenizer.cpp:135
+        cap = len(c) if ids_capacity is None else int(ids_capacity)
         ids, pids = m.alloc(cap, "i32")
         out = L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
         self._chk(self._lib.ovtk_bpe_run(self._h, C.byref(rs), C.byref(out), m.mem, m.stream))

@@ -89,9 +89,12 @@ class RegexSplit:
                                           C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_regex_split_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_regex_split_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def match(self, s: bytes, start: int):
         m = (C.c_int64 * 2)()
@@ -173,9 +176,12 @@ class BPETokenizer:
                                   C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_bpe_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_bpe_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     @property
     def tie_events(self):
@@ -212,9 +218,12 @@ class WordpieceTokenizer:
                                         C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_wordpiece_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_wordpiece_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def __call__(self, rb, re_, begins, ends, chars, unk_id):
         rb, prb = _i32(rb)
@@ -246,9 +255,12 @@ class VocabEncoder:
                                             int(values.dtype.itemsize), C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_vocab_encoder_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_vocab_encoder_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def __call__(self, begins, ends, chars, default):
         begins, pb = _i32(begins)

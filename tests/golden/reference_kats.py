@@ -1,0 +1,75 @@
+"""Known-answer vectors of the reference's own op-level tests (VALUES only, transcribed from
+/root/reference/tests/layer_tests.py).  Patterns are the strings its pipeline steps pass to the ops
+(python/openvino_tokenizers/tokenizer_pipeline.py:388-457).
+
+  REGEX_SPLIT_KATS   tests/layer_tests.py:331-389   (input, expected pieces, pattern, behaviour, invert)
+  RAGGED_TO_DENSE_KATS tests/layer_tests.py:497-573
+"""
+import re
+
+WHITESPACE = (r"\w+|[^\w\s]+", "remove", True)          # RegexSplitStep.whitespace_splitter()
+BERT_WHITESPACE = (r"\s+", "remove", False)             # bert_whitespace_splitter()
+SPLIT_BY_CHARS = (".", "isolate", False)                # split_by_chars()
+METASPACE_NEXT = ("▁", "mergedwithnext", False)
+METASPACE_PREV = ("▁", "mergedwithprevious", False)
+BYTE_LEVEL = (r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+", "isolate", False)
+BYTE_LEVEL_DIGITS = (r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+", "isolate", False)
+
+# The reference builds the expected CLIP pieces with Python's `re` on the same (doubly escaped) pattern.
+CLIP_PATTERN = r"<\\|startoftext\\|>|<\\|endoftext\\|>|'s|'t|'re|'ve|'m|'ll|'d|[\\p{L}]+|[\\p{N}]|[^\\s\\p{L}\\p{N}]+"
+CLIP = (CLIP_PATTERN, "remove", True)
+TEXT2IMAGE_PROMPTS = [
+    "Cinematic, a vibrant Mid-century modern dining area, colorful chairs and a sideboard, ultra realistic, many detail",
+    "colibri flying near a flower, side view, forest background, natural light, photorealistic, 4k",
+    "Illustration of an astronaut sitting in outer space, moon behind him",
+    "A vintage illustration of a retro computer, vaporwave aesthetic, light pink and light blue",
+    "A view from beautiful alien planet, very beautiful, surealism, retro astronaut on the first plane, 8k photo",
+    "red car in snowy forest, epic vista, beautiful landscape, 4k, 8k",
+    "A raccoon trapped inside a glass jar full of colorful candies, the background is steamy with vivid colors",
+    "cute cat 4k, high-res, masterpiece, best quality, soft lighting, dynamic angle",
+    "A cat holding a sign that says hello OpenVINO",
+    "A small cactus with a happy face in the Sahara desert.",
+]
+
+REGEX_SPLIT_KATS = [
+    ("Hello world!", ("Hello", "world", "!"), WHITESPACE),
+    ("Hello     world!", ("Hello", "world!"), BERT_WHITESPACE),
+    ("", ("",), WHITESPACE),
+    *[(p, tuple(re.compile(CLIP_PATTERN).findall(p)), CLIP) for p in TEXT2IMAGE_PROMPTS],
+    ("▁one▁two▁three▁", ("▁one", "▁two", "▁three", "▁"), METASPACE_NEXT),
+    ("▁", ("▁",), METASPACE_NEXT),
+    ("No split pattern", ("No split pattern",), METASPACE_NEXT),
+    ("▁one▁two▁three▁", ("▁", "one▁", "two▁", "three▁"), METASPACE_PREV),
+    ("▁", ("▁",), METASPACE_PREV),
+    ("No split pattern", ("No split pattern",), METASPACE_PREV),
+    ("split", tuple("split"), SPLIT_BY_CHARS),
+    ("split by chars", tuple("split by chars"), SPLIT_BY_CHARS),
+    ("Hello world!", ("Hello", " world", "!"), BYTE_LEVEL),
+    ("test's great", ("test", "'s", " great"), BYTE_LEVEL),
+    ("don't stop", ("don", "'t", " stop"), BYTE_LEVEL),
+    ("hello 123", ("hello", " 123"), BYTE_LEVEL),
+    ("Eng, but with d1gits: 123", ("Eng", ",", " but", " with", " d", "1", "gits", ":", " 123"), BYTE_LEVEL),
+    ("a  b", ("a", " ", " b"), BYTE_LEVEL),
+    ("Hello world!", ("Hello", " world", "!"), BYTE_LEVEL_DIGITS),
+    ("hello 123", ("hello", " ", "1", "2", "3"), BYTE_LEVEL_DIGITS),
+    ("Eng, but with d1gits: 123", ("Eng", ",", " but", " with", " d", "1", "gits", ":", " ", "1", "2", "3"),
+     BYTE_LEVEL_DIGITS),
+    ("If I have 100 million dollars?", ("If", " I", " have", " ", "1", "0", "0", " million", " dollars", "?"),
+     BYTE_LEVEL_DIGITS),
+    ("a1b2c3", ("a", "1", "b", "2", "c", "3"), BYTE_LEVEL_DIGITS),
+    ("test 0987654321 end", ("test", " ", "0", "9", "8", "7", "6", "5", "4", "3", "2", "1", " end"), BYTE_LEVEL_DIGITS),
+]
+
+_R2D = dict(begins=[0, 3], ends=[3, 8], data=[10, 20, 100, 30, 40, 50, 200, 300], value=42)
+RAGGED_TO_DENSE_KATS = [
+    # (inputs, attribute pad_right, optional input pad_right, expected)
+    (dict(_R2D, padding_size=10), True, None,
+     [[10, 20, 100, 42, 42, 42, 42, 42, 42, 42], [30, 40, 50, 200, 300, 42, 42, 42, 42, 42]]),
+    (dict(_R2D, padding_size=10), False, None,
+     [[42, 42, 42, 42, 42, 42, 42, 10, 20, 100], [42, 42, 42, 42, 42, 30, 40, 50, 200, 300]]),
+    (dict(_R2D, padding_size=2), True, None, [[10, 20], [30, 40]]),
+    (dict(_R2D, padding_size=10), True, False,
+     [[42, 42, 42, 42, 42, 42, 42, 10, 20, 100], [42, 42, 42, 42, 42, 30, 40, 50, 200, 300]]),
+    (dict(_R2D, padding_size=10), False, True,
+     [[10, 20, 100, 42, 42, 42, 42, 42, 42, 42], [30, 40, 50, 200, 300, 42, 42, 42, 42, 42]]),
+]

@@ -1,0 +1,248 @@
+"""RegexSplit / BPETokenizer / fused encode: oracle vs HF golden vectors, and the kernels vs the oracle.
+
+`backend` runs every kernel test three ways: "emu" (CPU, the kernel sources under the SIMT emulator -- logic
+only), "hip-host" and "hip-device" (gpu-marked: libovtk_amd.so on the MI355X with host resp. device buffers).
+Bit-exact comparison throughout (integer work).
+"""
+import numpy as np
+import pytest
+
+from openvino_tokenizers_amd import _lib as L
+from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
+from oracle import oracle as O
+from tests.util import BpeTok, assert_same, one_string_per_row
+from tools.make_tokenizers import GPT2_PATTERN
+from tools.workloads import TextModel, ragged_rows
+
+GOLDEN = __import__("pathlib").Path(__file__).parent / "golden"
+DIGITS_PATTERN = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
+
+
+# ------------------------------------------------------------------ oracle pinned by HF golden vectors (CPU)
+def test_oracle_matches_hf_golden():
+    z = np.load(GOLDEN / "golden_bpe_gpt2_small.npz")
+    tok = BpeTok.load("gpt2_small")
+    rb, re_ = ragged_rows(len(z["begins"]))
+    sp = O.RegexSplit(tok.pattern, "isolate")(rb, re_, z["begins"], z["ends"], z["chars"])
+    ob, oe, ids = tok.oracle()(*sp[:5])
+    assert np.array_equal(ob, z["id_begins"]) and np.array_equal(oe, z["id_ends"])
+    assert np.array_equal(ids, z["ids"])
+
+
+def test_oracle_matches_hf_live():
+    """Same check against a live HF tokenizer on fresh seeded text (skipped where `tokenizers` is absent)."""
+    tokenizers = pytest.importorskip("tokenizers")
+    hf = tokenizers.Tokenizer.from_file(str(GOLDEN / "tok_gpt2_small.hf.json"))
+    tok = BpeTok.load("gpt2_small")
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    for kind in ("zipf", "mixed", "uniform"):
+        b, e, c = TextModel(99, kind).batch(300, 150)
+        rb, re_ = ragged_rows(len(b))
+        ob, oe, ids = orc(*rs(rb, re_, b, e, c)[:5])
+        raw = c.tobytes()
+        for i in range(len(b)):
+            assert hf.encode(raw[b[i]:e[i]].decode(), add_special_tokens=False).ids == ids[ob[i]:oe[i]].tolist()
+    assert orc.tie_events == 0
+
+
+# ------------------------------------------------------------------ kernels vs oracle
+def run_all_paths(backend, tok, inputs, skips=None, pattern=None):
+    """Oracle result + the three product paths (split op, BPE op on its pieces, fused) compared bit for bit."""
+    pattern = pattern or tok.pattern
+    pat = np.frombuffer(pattern.encode(), np.uint8)
+    o_in = [np.asarray(x) for x in inputs]
+    sp_ref = O.RegexSplit(pattern, "isolate")(*o_in, skips=skips)
+    ref = tok.oracle()(*sp_ref[:5])
+    data = backend.data(inputs)
+    sk = backend.data([np.asarray(skips, np.uint8)]) if skips is not None else []
+    split = RegexSplit("isolate", lib=backend.lib)
+    sp = split.evaluate(data + sk + [pat])
+    assert_same(sp_ref[:4], sp[:4], backend.host, "RegexSplit")
+    if skips is not None:
+        assert_same([sp_ref[5]], [sp[5]], backend.host, "RegexSplit skips")
+    got = BPETokenizer(**tok.attrs, lib=backend.lib).evaluate(list(sp[:5]) + tok.consts)
+    assert_same(ref, got, backend.host, "BPETokenizer")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    got2 = fused.evaluate(data + sk + [pat], tok.consts)
+    assert_same(ref, got2, backend.host, "fused")
+    return ref
+
+
+def test_golden_strings(backend):
+    z = np.load(GOLDEN / "golden_bpe_gpt2_small.npz")
+    rb, re_ = ragged_rows(len(z["begins"]))
+    ref = run_all_paths(backend, BpeTok.load("gpt2_small"), [rb, re_, z["begins"], z["ends"], z["chars"]])
+    assert np.array_equal(ref[2], z["ids"])  # and therefore equal to HF
+
+
+@pytest.mark.parametrize("kind,n,target", [("zipf", 32, 128), ("mixed", 24, 300), ("uniform", 16, 200)])
+def test_config1_shapes(backend, kind, n, target):
+    """BASELINE.json config 1 (32 x ~128-byte strings) plus mixed-Unicode / stress text."""
+    b, e, c = TextModel(5, kind).batch(n, target)
+    rb, re_ = ragged_rows(n)
+    run_all_paths(backend, BpeTok.load("gpt2_small"), [rb, re_, b, e, c])
+
+
+def test_big_vocab(backend):
+    """GPT-2-shaped tokenizer (V = 50 257, 50 000 merges)."""
+    b, e, c = TextModel(6, "zipf").batch(16, 256)
+    rb, re_ = ragged_rows(16)
+    run_all_paths(backend, BpeTok.load("gpt2"), [rb, re_, b, e, c])
+
+
+def test_digits_pattern(backend):
+    tok = BpeTok.load("gpt2_small")
+    strings = ["hello 123", "If I have 100 million dollars?", "a1b2c3", "test 0987654321 end", " 1 2  3", "x٣٤y ½"]
+    run_all_paths(backend, tok, one_string_per_row(strings), pattern=DIGITS_PATTERN)
+
+
+def test_ragged_layouts(backend):
+    """Empty strings, empty rows, several strings per row, rows sharing strings, gaps and reversed order in chars."""
+    tok = BpeTok.load("gpt2_small")
+    texts = [b"first string here", b"", b"second, with 'quotes' & 42 numbers", b"third\n\nline", b"  ", b"tail"]
+    # lay the strings out back to front with gaps
+    chars = bytearray(b"#" * 200)
+    begins, ends, pos = [], [], 190
+    for t in texts:
+        pos -= len(t) + 3
+        chars[pos:pos + len(t)] = t
+        begins.append(pos)
+        ends.append(pos + len(t))
+    rb = np.array([0, 2, 2, 5, 1, 0], np.int32)   # row 2 is empty, row 4 re-uses strings 1..2, row 5 = row 0
+    re_ = np.array([2, 2, 5, 6, 3, 2], np.int32)
+    run_all_paths(backend, tok, [rb, re_, np.array(begins, np.int32), np.array(ends, np.int32),
+                                 np.frombuffer(bytes(chars), np.uint8)])
+
+
+def test_skips_pass_through(backend):
+    tok = BpeTok.load("gpt2_small")
+    strings = [b"some text", b"<|endoftext|>", b" more text here", b"<|endoftext|>", b"x"]
+    b, e, c = O.pack_strings(strings)
+    rb, re_ = np.array([0, 3], np.int32), np.array([3, 5], np.int32)
+    ref = run_all_paths(backend, tok, [rb, re_, b, e, c], skips=[0, 1, 0, 1, 0])
+    assert (ref[2] == tok.added[b"<|endoftext|>"]).sum() == 2  # the special token reached BPE whole
+
+
+def test_all_empty_batch_quirk(backend):
+    """regex_split.cpp:129-143: zero chars -> ragged dims of shape {1}, whatever the batch size."""
+    tok = BpeTok.load("gpt2_small")
+    inputs = one_string_per_row(["", "", ""])
+    pat = tok.pattern_u8()
+    sp = RegexSplit("isolate", lib=backend.lib).evaluate(backend.data(inputs) + [pat])
+    ref = O.RegexSplit(tok.pattern, "isolate")(*inputs)
+    assert_same(ref[:4], sp[:4], backend.host, "RegexSplit empty batch")
+    got = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib)).evaluate(
+        backend.data(inputs) + [pat], tok.consts)
+    assert_same(tok.oracle()(*ref[:5]), got, backend.host, "fused empty batch")
+
+
+def test_long_strings_and_pieces(backend):
+    """Multi-chunk strings; pieces that need the wave path (> 24 symbols) and the exact path (> 512 bytes)."""
+    tok = BpeTok.load("gpt2_small")
+    m = TextModel(8, "zipf")
+    _, _, c = m.batch(4, 3000)
+    long_text = c.tobytes().decode()
+    strings = [long_text[:2500], "a" * 300, " " * 256 + "x", "ab" * 400, "z" * 2000 + " end", "0" * 700,
+               long_text[2500:4000] + "q" * 530 + long_text[4000:4400], "é" * 400, "short"]
+    run_all_paths(backend, tok, one_string_per_row(strings))
+
+
+def test_max_splits(backend):
+    strings = ["one two three four five", "a b", "single"]
+    inputs = one_string_per_row(strings)
+    pat = np.frombuffer(GPT2_PATTERN.encode(), np.uint8)
+    for ms in (1, 2, 7):
+        ref = O.RegexSplit(GPT2_PATTERN, "isolate", False, ms)(*inputs)
+        got = RegexSplit("isolate", max_splits=ms, lib=backend.lib).evaluate(backend.data(inputs) + [pat])
+        assert_same(ref[:4], got[:4], backend.host, f"max_splits={ms}")
+
+
+# ------------------------------------------------------------------ hand-made vocabularies
+def pieces_inputs(rows):
+    """rows: list of lists of pieces -> the five ragged-string inputs of the BPETokenizer op."""
+    flat = [p for r in rows for p in r]
+    b, e, c = O.pack_strings(flat)
+    counts = np.array([len(r) for r in rows])
+    re_ = np.cumsum(counts).astype(np.int32)
+    return [(re_ - counts).astype(np.int32), re_, b, e, c]
+
+
+def test_heap_tie_vocabulary(backend):
+    """(rank, seq) ties in the merge queue: the two pairs pushed by ONE merge tie when the new
+    symbol and both neighbours carry the same id.  Reachable when an added token's id collides with a merge
+    result's id ("Q" -> id of "ab"): the text Q a b Q merges a+b between two symbols that already are "ab".
+    Which of the tied pairs pops first is decided by libstdc++'s heap layout; the oracle runs the real
+    std::priority_queue, the device replays such pieces on its exact heap path (bpe_exact_piece)."""
+    vocab = [b"a", b"b", b"ab", b"abab", b"ba", b"aa", b"ababab", b"aab", b"bab"]
+    merges = [(b"a", b"b"), (b"ab", b"ab"), (b"b", b"a"), (b"a", b"a"), (b"abab", b"ab"), (b"aa", b"b"), (b"b", b"ab")]
+    tok = BpeTok(vocab, merges, {b"Q": 2, b"R": 5}, None)
+    rng = np.random.default_rng(1)
+    rows = []
+    for _ in range(60):
+        rows.append([bytes(rng.choice(list(b"abQR"), size=int(rng.integers(1, 70)), p=[0.35, 0.3, 0.25, 0.1]))
+                     for _ in range(int(rng.integers(0, 8)))])
+    rows.append([b"QabQ", b"QabQabQabQabQ" * 20, b"RaaR" * 150])  # the last one exceeds the LDS chunk as well
+    inputs = pieces_inputs(rows)
+    orc = tok.oracle()
+    ref = orc(*inputs)
+    assert orc.tie_events > 50, "the vocabulary is meant to produce (rank, seq) ties"
+    got = BPETokenizer(**tok.attrs, lib=backend.lib).evaluate(backend.data(inputs) + tok.consts)
+    assert_same(ref, got, backend.host, "tie vocabulary")
+
+
+def test_unk_byte_fallback_suffix(backend):
+    """Non-byte-level vocabulary: unknown bytes -> <0xHH> byte tokens, then unk, else dropped; end_suffix appended
+    to every piece (also to empty ones); text-form merges ("a b" lines, 11-input form)."""
+    base = [b"<unk>", b"a", b"b", b"c", b"d", b"</w>", b"<0x65>", b"<0x7A>", "é".encode(), b"ab", b"abc", b"c</w>",
+            b"abc</w>", b"d</w>"]
+    merges_text = [b"a b", b"ab c", b"c </w>", b"ab c</w>", b"d </w>"]
+    for attrs in (dict(unk_token="<unk>", byte_fallback=True, end_suffix="</w>"),
+                  dict(unk_token="<unk>", byte_fallback=False, end_suffix="</w>"),
+                  dict(unk_token="", byte_fallback=True, end_suffix=""),
+                  dict(unk_token="", byte_fallback=False, end_suffix="", fuse_unk=True)):
+        tok = BpeTok(base, merges_text, None, None, **attrs)
+        rows = [[b"abc", b"abcd", b"", b"zzz", b"e", "é".encode(), b"xyz"], [], [b"dabc" * 5, b"q"], [b""]]
+        inputs = pieces_inputs(rows)
+        cap = 256  # with an end_suffix an empty piece still yields tokens: size the ids buffer explicitly
+        ref = tok.oracle()(*inputs, cap=cap)
+        got = BPETokenizer(**tok.attrs, lib=backend.lib).evaluate(backend.data(inputs) + tok.consts, ids_capacity=cap)
+        assert_same(ref, got, backend.host, f"attrs {attrs}")
+
+
+def test_errors(backend):
+    tok = BpeTok.load("gpt2_small")
+    lib = backend.lib
+    with pytest.raises(L.OvtkError) as ei:  # unknown behaviour: OPENVINO_ASSERT in the reference (regex_split.cpp:113)
+        RegexSplit("sideways", lib=lib).evaluate(backend.data(one_string_per_row(["x"])) + [tok.pattern_u8()])
+    assert ei.value.code == L.E_ARG
+    with pytest.raises(L.OvtkError) as ei:
+        RegexSplit("isolate", max_splits=0, lib=lib).evaluate(backend.data(one_string_per_row(["x"])) + [tok.pattern_u8()])
+    assert ei.value.code == L.E_ARG
+    with pytest.raises(L.OvtkError) as ei:  # a pattern without a device scanner must fail loudly, not fall back
+        RegexSplit("isolate", lib=lib).evaluate(backend.data(one_string_per_row(["x"])) + [np.frombuffer(b"[a-z]+", np.uint8)])
+    assert ei.value.code == L.E_UNSUPPORTED
+    bad = BpeTok([b"a", b"b"], [(b"a", b"c")], None, None)  # merge token missing: std::out_of_range in the reference
+    with pytest.raises(L.OvtkError) as ei:
+        BPETokenizer(lib=lib).evaluate(backend.data(one_string_per_row(["ab"])) + bad.consts)
+    assert ei.value.code == L.E_VOCAB
+    with pytest.raises(L.OvtkError) as ei:  # wrong input count (bpe_tokenizer.cpp:18-21)
+        BPETokenizer(lib=lib).evaluate(one_string_per_row(["ab"]) + tok.consts[:4])
+    assert ei.value.code == L.E_ARG
+    rb, re_, b, e, c = one_string_per_row(["abc"])
+    with pytest.raises(L.OvtkError) as ei:  # offsets leaving the chars tensor
+        BPETokenizer(**tok.attrs, lib=lib).evaluate(backend.data([rb, re_, b, e + 100, c]) + tok.consts)
+    assert ei.value.code == L.E_RANGE
+
+
+def test_handle_reuse_and_determinism(backend):
+    """One handle, many calls of different sizes (workspace growth), identical results every time."""
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    for n, target in [(4, 64), (40, 400), (2, 16), (40, 400)]:
+        b, e, c = TextModel(n, "zipf").batch(n, target)
+        rb, re_ = ragged_rows(n)
+        ref = orc(*rs(rb, re_, b, e, c)[:5])
+        for _ in range(2):
+            assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [pat], tok.consts), backend.host)

@@ -1,0 +1,28 @@
+"""Pins the oracle against the reference's own known-answer tests (tests/layer_tests.py:331-389, 497-598)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.golden.reference_kats import RAGGED_TO_DENSE_KATS, REGEX_SPLIT_KATS
+from tests.util import one_string_per_row
+
+
+@pytest.mark.parametrize("text, expected, layer", REGEX_SPLIT_KATS)
+def test_regex_split_kat(text, expected, layer):
+    pattern, behaviour, invert = layer
+    out = O.RegexSplit(pattern, behaviour, invert)(*one_string_per_row([text]))
+    # the reference test packs outputs 2..4 back into strings (StringTensorPack) and compares
+    got = tuple(s.decode("utf-8") for s in O.unpack_strings(out[2], out[3], out[4]))
+    assert got == expected
+
+
+@pytest.mark.parametrize("inp, attr_pad_right, input_pad_right, expected", RAGGED_TO_DENSE_KATS)
+def test_ragged_to_dense_kat(inp, attr_pad_right, input_pad_right, expected):
+    pad_right = attr_pad_right if input_pad_right is None else input_pad_right  # input 5 overrides the attribute
+    dense, mask = O.ragged_to_dense(inp["begins"], inp["ends"], np.asarray(inp["data"], np.int32),
+                                    inp["padding_size"], inp["value"], pad_right=pad_right)
+    assert np.array_equal(dense, np.asarray(expected, np.int32))
+    lens = np.minimum(np.asarray(inp["ends"]) - np.asarray(inp["begins"]), inp["padding_size"])
+    for r, n in enumerate(lens):
+        row = mask[r]
+        assert row.sum() == n and (row[:n].all() if pad_right else row[len(row) - n:].all())
