@@ -52,16 +52,16 @@ struct EncodeWork {
 constexpr int kScanThreads = 1024;
 constexpr int kScanPerThread = 4;
 
-// Exclusive scan of f(0..n) by ONE block of kScanThreads threads: put(i, prefix) for every i,
-// returns the total to every thread.  64-bit accumulation (callers clamp / flag).
-template <class F, class Put>
+// Exclusive scan of f(0..n) by ONE block of THREADS threads: put(i, prefix) for every i, returns the
+// total to every thread.  64-bit accumulation (callers clamp / flag).
+template <int THREADS, class F, class Put>
 __device__ __forceinline__ long long block_exclusive_scan(int n, F&& f, Put&& put) {
-    __shared__ long long wave_tot[kScanThreads / kWave];
+    __shared__ long long wave_tot[THREADS / kWave];
     __shared__ long long carry_s;
     const int tid = int(threadIdx.x), l = lane_id(), wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int tile = 0; tile < n; tile += kScanThreads * kScanPerThread) {
+    for (int tile = 0; tile < n; tile += THREADS * kScanPerThread) {
         const int i0 = tile + tid * kScanPerThread;
         long long v[kScanPerThread], s = 0;
 #pragma unroll
@@ -86,7 +86,7 @@ __device__ __forceinline__ long long block_exclusive_scan(int n, F&& f, Put&& pu
             run += v[j];
         }
         __syncthreads();
-        if (tid == kScanThreads - 1) carry_s = run;  // last thread's running sum = total so far
+        if (tid == THREADS - 1) carry_s = run;  // last thread's running sum = total so far
         __syncthreads();
     }
     return carry_s;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kScanThreads) void prepare_rows_kernel(RowsIn in, i
     __shared__ int bad_s;
     if (threadIdx.x == 0) bad_s = 0;
     __syncthreads();
-    const long long total = block_exclusive_scan(
+    const long long total = block_exclusive_scan<kScanThreads>(
         in.n_rows,
         [&](int row) -> long long {
             long long cap = 0;
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, BpeDev 
 __global__ __launch_bounds__(kScanThreads) void finalize_rows_kernel(int n_rows, EncodeWork w, int32_t* out_begins,
                                                                       int32_t* out_ends, long long out_cap) {
     if (w.status->flags & (kFlagRange | kFlagStageOverflow)) return;
-    const long long total = block_exclusive_scan(
+    const long long total = block_exclusive_scan<kScanThreads>(
         n_rows, [&](int row) -> long long { return w.row_cnt[row]; },
         [&](int row, long long off) {
             w.row_out[row] = int32_t(off);

@@ -1,0 +1,384 @@
+// ops_kernels.hpp -- gfx950 kernels of WordpieceTokenizer, VocabEncoder, RaggedToDense, VocabDecoder,
+// ByteFallback, FuzeRagged and the fused detokenizer.  All HBM-bound gather / scan / copy work.
+#pragma once
+
+#include "bpe_device.hpp"
+#include "device_common.hpp"
+#include "encode_kernels.hpp"
+
+namespace ovtk {
+
+// =============================================================================================
+// WordpieceTokenizer (src/wordpiece_tokenizer.cpp:94-130): one wave per row, one lane per word.
+// Every row is staged "slotted" (word w owns staging entries [bytepos, bytepos + max(len,1))).
+// =============================================================================================
+struct WordpieceDev {
+    TrieDev root, sub;
+    int32_t max_bytes;
+};
+
+__global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn in, WordpieceDev T, int32_t unk_id, EncodeWork w) {
+    __shared__ I2 root_lds[256];
+    __shared__ I2 sub_lds[256];
+    for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) {
+        root_lds[i] = T.root.root[i];
+        sub_lds[i] = T.sub.root[i];
+    }
+    __syncthreads();
+    if (w.status->flags & (kFlagRange | kFlagStageOverflow)) return;
+    const int l = lane_id();
+    const int n_waves = int(gridDim.x) * kWavesPerBlock;
+    for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < in.n_rows; row += n_waves) {
+        const int base = w.row_stage[row];
+        const int cb = in.ragged_begins[row], ce = in.ragged_ends[row];
+        int bytepos = 0, emitted = 0;
+        for (int c0 = cb; c0 < ce; c0 += kWave) {
+            const int col = c0 + l;
+            const bool valid = col < ce;
+            int sb = 0, len = 0;
+            if (valid) { sb = in.begins[col]; len = in.ends[col] - sb; }
+            const int units = valid ? (len > 0 ? len : 1) : 0;
+            const int incl = wave_incl_sum(units);
+            int32_t* slot = w.stage + base + bytepos + incl - units;
+            int cnt = 0;
+            if (valid) {
+                const uint8_t* s = in.chars + sb;
+                auto getb = [&](int i) -> uint32_t { return s[i]; };
+                if (len > T.max_bytes || len <= 0) {  // strict > (:100-103); an empty word is undefined in the reference
+                    slot[0] = unk_id;
+                    cnt = 1;
+                } else {
+                    int idx = 0;
+                    int tok = trie_longest(T.root, root_lds, getb, len, idx);
+                    if (tok == -1) {
+                        slot[0] = unk_id;
+                        cnt = 1;
+                    } else {
+                        slot[cnt++] = tok;
+                        while (idx < len) {
+                            tok = trie_longest(T.sub, sub_lds, getb, len, idx);
+                            if (tok == -1) {  // :118-123 the whole word becomes one unk
+                                slot[0] = unk_id;
+                                cnt = 1;
+                                break;
+                            }
+                            slot[cnt++] = tok;
+                        }
+                    }
+                }
+                for (int k = cnt; k < units; ++k) slot[k] = kEmptyId;
+            }
+            emitted += wave_sum(cnt);
+            bytepos += __shfl(incl, kWave - 1);
+        }
+        if (l == 0) {
+            w.row_cnt[row] = emitted;
+            w.row_slotted[row] = 1;
+        }
+    }
+}
+
+// =============================================================================================
+// VocabEncoder (src/vocab_encoder.cpp:88-91): one lane per element, FNV-1a hash, open addressing.
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(kBlockThreads) void vocab_encoder_kernel(const int32_t* begins, const int32_t* ends,
+                                                                      const uint8_t* chars, long long n_chars, int n,
+                                                                      StringMapDev M, T dflt, T* out, RunStatus* status) {
+    const int stride = int(gridDim.x) * kBlockThreads;
+    const T* values = static_cast<const T*>(M.values);
+    for (int i = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); i < n; i += stride) {
+        const long long b = begins[i], e = ends[i];
+        if (b < 0 || e < b || e > n_chars) {
+            atomicOr(&status->flags, kFlagRange);
+            continue;
+        }
+        const uint8_t* s = chars + b;
+        const int len = int(e - b);
+        const uint32_t h = hash_bytes(s, len);
+        uint32_t p = h & M.mask;
+        T val = dflt;
+        for (;;) {
+            const uint64_t slot = M.slots[p];
+            if (slot == kEmptySlot) break;
+            if (uint32_t(slot >> 32) == h) {
+                const int k = int(uint32_t(slot));
+                const int kb = M.key_begins[k];
+                if (M.key_ends[k] - kb == len) {
+                    bool same = true;
+                    for (int j = 0; j < len && same; ++j) same = M.key_chars[kb + j] == s[j];
+                    if (same) { val = values[k]; break; }
+                }
+            }
+            p = (p + 1) & M.mask;
+        }
+        out[i] = val;
+    }
+}
+
+// =============================================================================================
+// RaggedToDense (src/ragged_to_dense.cpp:129-167): one wave per row, byte-granular cells.
+// =============================================================================================
+struct DenseArgs {
+    const int32_t* begins;
+    const int32_t* ends;
+    int32_t n_rows;
+    const uint8_t* data;
+    long long n_data;    // ragged elements
+    int32_t cell;        // bytes per ragged element (elem_size * inner)
+    int32_t elem_size;
+    int32_t inner;
+    int32_t target;
+    int32_t pad_right;
+    int32_t pad_max_length;
+    uint8_t dflt[16];
+    uint8_t* out;
+    uint8_t* mask;       // may be nullptr
+    RunStatus* status;
+};
+
+__global__ __launch_bounds__(kBlockThreads) void ragged_to_dense_kernel(DenseArgs a) {
+    const int l = lane_id();
+    const int n_waves = int(gridDim.x) * kWavesPerBlock;
+    for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < a.n_rows; row += n_waves) {
+        const long long b = a.begins[row];
+        const long long len = (long long)a.ends[row] - b;
+        // :132-133: with pad_max_length the copy is `target` long whatever the row holds
+        const long long take = a.pad_max_length ? a.target : (len < a.target ? (len < 0 ? 0 : len) : a.target);
+        if (b < 0 || b + take > a.n_data) {
+            if (l == 0) atomicOr(&a.status->flags, kFlagRange);
+            continue;
+        }
+        const long long pad = a.target - take;
+        const long long first = a.pad_right ? 0 : pad;  // index of the first copied element in the output row
+        uint8_t* orow = a.out + (long long)row * a.target * a.cell;
+        uint8_t* mrow = a.mask ? a.mask + (long long)row * a.target * a.inner : nullptr;
+        const uint8_t* src = a.data + b * a.cell;
+        if (a.cell == 4) {  // the common case (i32 ids): one dword per lane
+            uint32_t d;
+            d = uint32_t(a.dflt[0]) | uint32_t(a.dflt[1]) << 8 | uint32_t(a.dflt[2]) << 16 | uint32_t(a.dflt[3]) << 24;
+            for (long long k = l; k < a.target; k += kWave) {
+                const bool data = k >= first && k < first + take;
+                reinterpret_cast<uint32_t*>(orow)[k] = data ? reinterpret_cast<const uint32_t*>(src)[k - first] : d;
+                if (mrow) mrow[k] = data ? 1 : 0;
+            }
+        } else {
+            const long long row_bytes = (long long)a.target * a.cell;
+            for (long long byte = l; byte < row_bytes; byte += kWave) {
+                const long long k = byte / a.cell;
+                const bool data = k >= first && k < first + take;
+                orow[byte] = data ? src[byte - first * a.cell] : a.dflt[(byte % a.cell) % a.elem_size];
+            }
+            if (mrow)
+                for (long long m = l; m < (long long)a.target * a.inner; m += kWave) {
+                    const long long k = m / a.inner;
+                    mrow[m] = (k >= first && k < first + take) ? 1 : 0;
+                }
+        }
+    }
+}
+
+// =============================================================================================
+// Large exclusive scans: per-tile sums -> one block scans the tile sums -> per-tile rescan + apply.
+// =============================================================================================
+constexpr int kTileThreads = 256;
+constexpr int kTileElems = kTileThreads * kScanPerThread;  // 1024 elements per block
+
+template <class LenF>
+__global__ __launch_bounds__(kTileThreads) void tile_reduce_kernel(long long n, LenF f, long long* tile_sums) {
+    __shared__ long long part[kTileThreads / kWave];
+    const long long i0 = (long long)blockIdx.x * kTileElems + (long long)threadIdx.x * kScanPerThread;
+    long long s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j)
+        if (i0 + j < n) s += f(i0 + j);
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) s += __shfl_xor(s, d);
+    if (lane_id() == 0) part[wave_in_block()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int k = 0; k < kTileThreads / kWave; ++k) t += part[k];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+// One block: exclusive scan of the tile sums in place; total -> status->n_out (clamped) + capacity flag.
+__global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(int n_tiles, long long* tile_sums, long long cap,
+                                                                  RunStatus* status) {
+    const long long total = block_exclusive_scan<kScanThreads>(
+        n_tiles, [&](int t) -> long long { return tile_sums[t]; }, [&](int t, long long off) { tile_sums[t] = off; });
+    if (threadIdx.x == 0) {
+        status->n_out = total > INT32_MAX ? INT32_MAX : int32_t(total);
+        if (total > cap) atomicOr(&status->flags, kFlagOutCapacity);
+    }
+}
+
+// apply(i, offset, len) is called for every element with its global exclusive offset.
+template <class LenF, class ApplyF>
+__global__ __launch_bounds__(kTileThreads) void tile_apply_kernel(long long n, LenF f, const long long* tile_offs,
+                                                                  ApplyF apply, const RunStatus* status) {
+    __shared__ long long part[kTileThreads / kWave];
+    if (status->flags & (kFlagOutCapacity | kFlagRange)) return;
+    const long long i0 = (long long)blockIdx.x * kTileElems + (long long)threadIdx.x * kScanPerThread;
+    long long v[kScanPerThread], s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) {
+        v[j] = (i0 + j < n) ? (long long)f(i0 + j) : 0;
+        s += v[j];
+    }
+    long long incl = s;
+    const int l = lane_id();
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        long long t = __shfl_up(incl, d);
+        if (l >= d) incl += t;
+    }
+    if (l == kWave - 1) part[wave_in_block()] = incl;
+    __syncthreads();
+    long long run = tile_offs[blockIdx.x] + incl - s;
+    for (int k = 0; k < wave_in_block(); ++k) run += part[k];
+#pragma unroll
+    for (int j = 0; j < kScanPerThread; ++j) {
+        if (i0 + j < n) apply(i0 + j, run, v[j]);
+        run += v[j];
+    }
+}
+
+// =============================================================================================
+// VocabDecoder / ByteFallback / detokenize element functors
+// =============================================================================================
+struct DecodeDev {
+    const int32_t* ids;          // [batch * seq]
+    const int32_t* v_begins;
+    const int32_t* v_ends;
+    const uint8_t* v_chars;
+    int32_t vocab_size;
+    const uint32_t* skip_bits;   // bitmap over [0, vocab_size), may be nullptr
+    const int16_t* fallback_byte;  // per vocab id: byte value of "<0xHH>" style tokens, -1 otherwise, -2 = 0xFF quirk; nullptr = off
+};
+
+// Length in bytes of token i's text (vocab_decoder.cpp:70-81): ids outside [0, V) or in the skip list give "".
+struct DecodeLen {
+    DecodeDev d;
+    __device__ long long operator()(long long i) const {
+        const int32_t id = d.ids[i];
+        if (uint32_t(id) >= uint32_t(d.vocab_size)) return 0;
+        if (d.skip_bits && (d.skip_bits[uint32_t(id) >> 5] >> (id & 31) & 1u)) return 0;
+        if (d.fallback_byte && d.fallback_byte[id] != -1) return 1;
+        return d.v_ends[id] - d.v_begins[id];
+    }
+};
+
+struct DecodeApply {
+    DecodeDev d;
+    int32_t* out_begins;  // per token, or nullptr (fused detokenizer)
+    int32_t* out_ends;
+    uint8_t* out_chars;
+    __device__ void operator()(long long i, long long off, long long len) const {
+        if (out_begins) {
+            out_begins[i] = int32_t(off);
+            out_ends[i] = int32_t(off + len);
+        }
+        if (len == 0) return;
+        const int32_t id = d.ids[i];
+        if (d.fallback_byte && d.fallback_byte[id] != -1) {
+            out_chars[off] = uint8_t(d.fallback_byte[id] == -2 ? 0xFF : d.fallback_byte[id]);
+            return;
+        }
+        const uint8_t* src = d.v_chars + d.v_begins[id];
+        for (long long k = 0; k < len; ++k) out_chars[off + k] = src[k];
+    }
+};
+
+// ByteFallback (src/byte_fallback.cpp:33-46): "<0xHH>" (6 bytes, only '<' at 0, last '>' at 5) -> one byte.
+__device__ __forceinline__ int byte_fallback_value(const uint8_t* s, int len) {
+    // returns -1: copy verbatim; 0..255: the byte; 255 also for the reference's "not in the map -> -1 -> 0xFF" case
+    if (len != 6 || s[0] != '<' || s[5] != '>') return -1;
+    for (int k = 1; k < 6; ++k)
+        if (s[k] == '<') return -1;  // rfind('<') must be 0
+    if (s[1] != '0' || s[2] != 'x') return 255;
+    int v = 0;
+    for (int k = 3; k < 5; ++k) {
+        const uint8_t c = s[k];
+        int h;
+        if (c >= '0' && c <= '9') h = c - '0';
+        else if (c >= 'A' && c <= 'F') h = c - 'A' + 10;  // "%02X": upper-case hex only
+        else return 255;
+        v = v * 16 + h;
+    }
+    return v;
+}
+
+struct FallbackLen {
+    const int32_t* begins;
+    const int32_t* ends;
+    const uint8_t* chars;
+    __device__ long long operator()(long long i) const {
+        const int len = ends[i] - begins[i];
+        return byte_fallback_value(chars + begins[i], len) >= 0 ? 1 : (len > 0 ? len : 0);
+    }
+};
+struct FallbackApply {
+    const int32_t* begins;
+    const int32_t* ends;
+    const uint8_t* chars;
+    int32_t* out_begins;
+    int32_t* out_ends;
+    uint8_t* out_chars;
+    __device__ void operator()(long long i, long long off, long long len) const {
+        out_begins[i] = int32_t(off);
+        out_ends[i] = int32_t(off + len);
+        const uint8_t* s = chars + begins[i];
+        const int v = byte_fallback_value(s, ends[i] - begins[i]);
+        if (v >= 0) { out_chars[off] = uint8_t(v); return; }
+        for (long long k = 0; k < len; ++k) out_chars[off + k] = s[k];
+    }
+};
+
+__global__ __launch_bounds__(kBlockThreads) void check_strings_kernel(const int32_t* begins, const int32_t* ends,
+                                                                      long long n, long long n_chars, RunStatus* status) {
+    const long long stride = (long long)gridDim.x * kBlockThreads;
+    for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
+        const long long b = begins[i], e = ends[i];
+        if (b < 0 || e < b || e > n_chars) atomicOr(&status->flags, kFlagRange);
+    }
+}
+
+// Row offsets of the decoder: ragged_begins[b] = b * S', ragged_ends[b] = (b + 1) * S' (vocab_decoder.cpp:58-59).
+__global__ __launch_bounds__(kBlockThreads) void decoder_rows_kernel(int batch, int sp, int32_t* rb, int32_t* re) {
+    const int stride = int(gridDim.x) * kBlockThreads;
+    for (int b = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); b < batch; b += stride) {
+        rb[b] = b * sp;
+        re[b] = (b + 1) * sp;
+    }
+}
+
+// Fused detokenizer: string of row b = tokens [b*S, (b+1)*S): begins/ends from the token offsets.
+__global__ __launch_bounds__(kBlockThreads) void row_bounds_kernel(int batch, int seq, const int32_t* tok_begins,
+                                                                   const int32_t* tok_ends, int32_t* out_begins,
+                                                                   int32_t* out_ends) {
+    const int stride = int(gridDim.x) * kBlockThreads;
+    for (int b = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); b < batch; b += stride) {
+        out_begins[b] = tok_begins[(long long)b * seq];
+        out_ends[b] = tok_ends[(long long)(b + 1) * seq - 1];
+    }
+}
+
+// FuzeRagged (src/fuze.cpp:35-38).
+__global__ __launch_bounds__(kBlockThreads) void fuze_kernel(const int32_t* rb, const int32_t* re, int n_rows,
+                                                             const int32_t* begins, const int32_t* ends, int n,
+                                                             int32_t* out_begins, int32_t* out_ends, RunStatus* status) {
+    const int stride = int(gridDim.x) * kBlockThreads;
+    for (int r = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); r < n_rows; r += stride) {
+        const int bi = rb[r], ei = re[r] > rb[r] ? re[r] - 1 : re[r];
+        if (bi < 0 || bi >= n || ei < 0 || ei >= n) {  // the reference reads past the tensor here (undefined)
+            atomicOr(&status->flags, kFlagRange);
+            continue;
+        }
+        out_begins[r] = begins[bi];
+        out_ends[r] = ends[ei];
+    }
+}
+
+}  // namespace ovtk

@@ -29,9 +29,9 @@ def all_gather_ragged(begins: torch.Tensor, ends: torch.Tensor, ids: torch.Tenso
     world = dist.get_world_size(group)
     dev = ids.device
     counts = torch.tensor([begins.numel(), ids.numel()], dtype=torch.int64, device=dev)
-    all_counts = torch.empty(world, 2, dtype=torch.int64, device=dev)
+    all_counts = torch.empty(world * 2, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(all_counts, counts, group=group)
-    all_counts = all_counts.cpu()
+    all_counts = all_counts.view(world, 2).cpu()
     max_rows, max_ids = int(all_counts[:, 0].max()), int(all_counts[:, 1].max())
 
     lens_pad = torch.zeros(max_rows, dtype=torch.int32, device=dev)

@@ -1,0 +1,66 @@
+"""The GPU split scanners vs PCRE2 (the oracle runs the real matcher with PCRE2_UTF|PCRE2_UCP, src/utils.cpp:259-261).
+
+The scanners replace regex matching by a local piece-start predicate (csrc/split_device.hpp); this file is the
+evidence that the predicate is equivalent: every string up to 4 symbols over an alphabet with one representative
+per behaviour class (letters incl. the contraction letters, digit, ASCII space, tab, newline, NBSP, apostrophe,
+punctuation, 2/3/4-byte letters/symbols), plus random long strings that cross the 512-byte LDS chunk boundary.
+"""
+import itertools
+
+import numpy as np
+import pytest
+
+from openvino_tokenizers_amd.ops import RegexSplit
+from oracle import oracle as O
+from tests.util import assert_same, one_string_per_row
+from tools.make_tokenizers import GPT2_PATTERN
+
+DIGITS_PATTERN = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
+ALPHABET = ["a", "s", "t", "r", "e", "l", "v", "1", " ", "\t", "\n", " ", "'", "!", "é", "元", "，", "😀", "٣", "　"]
+
+
+def check(backend, pattern, strings):
+    inputs = one_string_per_row(strings)
+    ref = O.RegexSplit(pattern, "isolate")(*inputs)
+    got = RegexSplit("isolate", lib=backend.lib).evaluate(backend.data(inputs) + [np.frombuffer(pattern.encode(), np.uint8)])
+    try:
+        assert_same(ref[:4], got[:4], backend.host, "RegexSplit")
+    except AssertionError:
+        # name the first offending string
+        rb, re_ = ref[0], ref[1]
+        gb, ge = backend.host(got[0]), backend.host(got[1])
+        for i, s in enumerate(strings):
+            r = list(zip(ref[2][rb[i]:re_[i]].tolist(), ref[3][rb[i]:re_[i]].tolist()))
+            g = list(zip(backend.host(got[2])[gb[i]:ge[i]].tolist(), backend.host(got[3])[gb[i]:ge[i]].tolist()))
+            base = int(inputs[2][i])
+            if [(a - base, b - base) for a, b in r] != [(a - base, b - base) for a, b in g]:
+                raise AssertionError(f"{s!r}: PCRE2 {[(a - base, b - base) for a, b in r]} scanner "
+                                     f"{[(a - base, b - base) for a, b in g]}")
+        raise
+
+
+@pytest.mark.parametrize("pattern", [GPT2_PATTERN, DIGITS_PATTERN], ids=["gpt2", "gpt2-digits"])
+def test_exhaustive_short_strings(backend, pattern):
+    n = 3 if backend.name == "emu" else 4
+    strings = ["".join(t) for k in range(1, n + 1) for t in itertools.product(ALPHABET, repeat=k)]
+    check(backend, pattern, strings)
+
+
+@pytest.mark.parametrize("pattern", [GPT2_PATTERN, DIGITS_PATTERN], ids=["gpt2", "gpt2-digits"])
+def test_random_strings(backend, pattern):
+    rng = np.random.default_rng(11)
+    p = np.array([6, 2, 2, 2, 3, 2, 1, 3, 8, 1, 1, 0.5, 3, 2, 1, 1, 0.5, 0.5, 0.5, 0.5])
+    p = p / p.sum()
+    n = 300 if backend.name == "emu" else 6000
+    strings = ["".join(rng.choice(ALPHABET, size=int(rng.integers(1, 60)), p=p)) for _ in range(n)]
+    strings += ["".join(rng.choice(ALPHABET, size=int(rng.integers(400, 1500)), p=p)) for _ in range(12)]
+    check(backend, pattern, strings)
+
+
+def test_chunk_boundaries(backend):
+    """Pieces and special sequences placed right at the 512-byte chunk seams, long single-class runs."""
+    strings = []
+    for k in range(500, 530):
+        strings += ["a" * k + "'s b", "x" * k + "  y", " " * k + "z", "a" * k + " 'll", "é" * (k // 2) + "'t元",
+                    "1" * k + "a" * 600, ("ab " * 200)[:k] + "\t\t" + "c" * 20, "a" * k + "\n\n" + "b" * k + " "]
+    check(backend, GPT2_PATTERN, strings)
