@@ -76,4 +76,113 @@ inline int finish_status(Workspace& ws, hipStream_t s) {
 
 inline int grid_for_elems(long long n) { return int(std::max<long long>(1, std::min<long long>((n + kBlockThreads - 1) / kBlockThreads, 1 << 20))); }
 
+// Device-side destination of a host/device output buffer of `bytes` bytes: the caller's pointer
+// (OVTK_MEM_DEVICE) or a workspace buffer that finish_output() copies back (OVTK_MEM_HOST).
+template <typename T>
+inline int out_target(DevBuf& stage, T* user, size_t bytes, int mem, T** dev) {
+    if (mem == OVTK_MEM_DEVICE) { *dev = user; return OVTK_OK; }
+    if (int rc = stage.ensure(bytes)) return rc;
+    *dev = stage.as<T>();
+    return OVTK_OK;
+}
+inline int copy_back(void* user, const void* dev, size_t bytes, int mem, hipStream_t s) {
+    if (mem == OVTK_MEM_DEVICE || bytes == 0) return OVTK_OK;
+    OVTK_HIP(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, s));
+    return OVTK_OK;
+}
+// Input counterpart: device pointer of an input of `bytes` bytes.
+template <typename T>
+inline int in_source(DevBuf& stage, const T* user, size_t bytes, int mem, hipStream_t s, const T** dev) {
+    if (mem == OVTK_MEM_DEVICE) { *dev = user; return OVTK_OK; }
+    if (int rc = stage.upload(user, bytes, s)) return rc;
+    *dev = stage.as<T>();
+    return OVTK_OK;
+}
+
+// The "ragged strings in -> ragged i32 out" pipeline shared by BPETokenizer, the fused encode and
+// WordpieceTokenizer: prepare_rows (staging offsets) -> middle(ws, d_in, w) (the op's kernels: ids into
+// staging, per-row counts) -> finalize_rows (final offsets) -> compact.  Workspace overflows reported
+// by the kernels are handled by growing the buffer and running again.
+template <class Middle>
+int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
+                    ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle&& middle) {
+    WorkspaceLease ws(device);
+    if (!ws->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
+    RowsIn d_in{};
+    if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
+
+    const int n_rows = d_in.n_rows;
+    int64_t stage_cap = std::min<int64_t>((in->strings.n_chars + in->strings.n) * mul, INT32_MAX - 1);
+    int64_t deferred_cap = std::max<int64_t>(4096, in->strings.n / 8);
+    int64_t scratch_cap = std::max<int64_t>(ws->scratch.size(), int64_t(16) << 20);
+
+    int32_t *d_begins = nullptr, *d_ends = nullptr, *d_ids = nullptr;
+    if (int rc = out_target(ws->out_a, out->begins, size_t(n_rows) * 4, mem, &d_begins)) return rc;
+    if (int rc = out_target(ws->out_b, out->ends, size_t(n_rows) * 4, mem, &d_ends)) return rc;
+    if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_ids)) return rc;
+
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        int e = 0;
+        e = e ? e : ws->row_stage.ensure(size_t(n_rows + 1) * 4);
+        e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
+        e = e ? e : ws->row_out.ensure(size_t(n_rows + 1) * 4);
+        e = e ? e : ws->row_slotted.ensure(size_t(n_rows));
+        e = e ? e : ws->stage.ensure(size_t(stage_cap) * 4);
+        e = e ? e : ws->deferred.ensure(size_t(deferred_cap) * sizeof(DeferredPiece));
+        e = e ? e : ws->scratch.ensure(size_t(scratch_cap));
+        e = e ? e : ws->status.ensure(sizeof(RunStatus));
+        if (e) return e;
+        EncodeWork w{};
+        w.row_stage = ws->row_stage.as<int32_t>();
+        w.row_cnt = ws->row_cnt.as<int32_t>();
+        w.row_out = ws->row_out.as<int32_t>();
+        w.row_slotted = ws->row_slotted.as<uint8_t>();
+        w.stage = ws->stage.as<int32_t>();
+        w.stage_cap = int32_t(stage_cap);
+        w.deferred = ws->deferred.as<DeferredPiece>();
+        w.deferred_cap = int32_t(deferred_cap);
+        w.scratch = ws->scratch.as<uint8_t>();
+        w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap, 0xFFFFFFF0ll));
+        w.status = ws->status.as<RunStatus>();
+
+        OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
+        OVTK_LAUNCH(ws->marks, "prepare_rows", prepare_rows_kernel, 1, kScanThreads, s, d_in, mul, w);
+        middle(*ws.ws, d_in, w);
+        OVTK_LAUNCH(ws->marks, "finalize_rows", finalize_rows_kernel, 1, kScanThreads, s, n_rows, w, d_begins, d_ends,
+                    (long long)out->data_capacity);
+        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_for_rows(n_rows), kBlockThreads, s, n_rows, w, d_ids);
+        if (int rc = finish_status(*ws.ws, s)) return rc;
+
+        const RunStatus& st = *ws->host_status;
+        if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+        if (st.flags & kFlagStageOverflow) {
+            if (st.stage_need >= INT32_MAX - 1)
+                return set_error(OVTK_E_UNSUPPORTED, "batch needs more than 2^31 staging entries; split the call");
+            stage_cap = st.stage_need;
+            continue;
+        }
+        if (st.flags & kFlagDeferOverflow) {
+            deferred_cap = int64_t(st.n_deferred) + 64;
+            continue;
+        }
+        if (st.flags & kFlagScratchOverflow) {
+            scratch_cap = std::max<int64_t>(scratch_cap * 2, int64_t(st.scratch_used) + (1 << 20));
+            if (scratch_cap > (int64_t(3) << 30))
+                return set_error(OVTK_E_UNSUPPORTED, "exact-path scratch would exceed 3 GiB; split the call");
+            continue;
+        }
+        if (st.flags & kFlagOutCapacity)
+            return set_error(OVTK_E_CAPACITY, std::string(op) + ": output ids buffer too small (" +
+                                                  std::to_string(st.n_out) + " ids, capacity " +
+                                                  std::to_string(out->data_capacity) + ")");
+        out->n_data = st.n_out;
+        if (int rc = copy_back(out->begins, d_begins, size_t(n_rows) * 4, mem, s)) return rc;
+        if (int rc = copy_back(out->ends, d_ends, size_t(n_rows) * 4, mem, s)) return rc;
+        if (int rc = copy_back(out->data, d_ids, size_t(st.n_out) * 4, mem, s)) return rc;
+        if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+        return OVTK_OK;
+    }
+    return set_error(OVTK_E_HIP, "workspace sizing did not converge");
+}
+
 }  // namespace ovtk

@@ -197,95 +197,17 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
     }
     if (in->n_rows == 0) return OVTK_OK;
 
-    WorkspaceLease ws(bpe->device);
-    if (!ws->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
-    RowsIn d_in{};
-    if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
-
-    const int mul = 1 + bpe->dev.suffix_len;
-    const int n_rows = d_in.n_rows;
-    int64_t stage_cap = std::min<int64_t>((in->strings.n_chars + in->strings.n) * mul, INT32_MAX - 1);
-    int64_t deferred_cap = std::max<int64_t>(4096, in->strings.n / 8);
-    int64_t scratch_cap = std::max<int64_t>(ws->scratch.size(), int64_t(16) << 20);
-
-    int32_t *d_begins = out->begins, *d_ends = out->ends, *d_ids = out->data;
-    if (mem == OVTK_MEM_HOST) {
-        if (int rc = ws->out_a.ensure(size_t(n_rows) * 4)) return rc;
-        if (int rc = ws->out_b.ensure(size_t(n_rows) * 4)) return rc;
-        if (int rc = ws->out_c.ensure(size_t(out->data_capacity) * 4)) return rc;
-        d_begins = ws->out_a.as<int32_t>();
-        d_ends = ws->out_b.as<int32_t>();
-        d_ids = ws->out_c.as<int32_t>();
-    }
-
-    for (int attempt = 0; attempt < 5; ++attempt) {
-        int e = 0;
-        e = e ? e : ws->row_stage.ensure(size_t(n_rows + 1) * 4);
-        e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
-        e = e ? e : ws->row_out.ensure(size_t(n_rows + 1) * 4);
-        e = e ? e : ws->row_slotted.ensure(size_t(n_rows));
-        e = e ? e : ws->stage.ensure(size_t(stage_cap) * 4);
-        e = e ? e : ws->deferred.ensure(size_t(deferred_cap) * sizeof(DeferredPiece));
-        e = e ? e : ws->scratch.ensure(size_t(scratch_cap));
-        e = e ? e : ws->status.ensure(sizeof(RunStatus));
-        if (e) return e;
-        EncodeWork w{};
-        w.row_stage = ws->row_stage.as<int32_t>();
-        w.row_cnt = ws->row_cnt.as<int32_t>();
-        w.row_out = ws->row_out.as<int32_t>();
-        w.row_slotted = ws->row_slotted.as<uint8_t>();
-        w.stage = ws->stage.as<int32_t>();
-        w.stage_cap = int32_t(stage_cap);
-        w.deferred = ws->deferred.as<DeferredPiece>();
-        w.deferred_cap = int32_t(deferred_cap);
-        w.scratch = ws->scratch.as<uint8_t>();
-        w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap, 0xFFFFFFF0ll));
-        w.status = ws->status.as<RunStatus>();
-
-        OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-        OVTK_LAUNCH(ws->marks, "prepare_rows", prepare_rows_kernel, 1, kScanThreads, s, d_in, mul, w);
-        if (split)
-            OVTK_LAUNCH(ws->marks, "encode_fused", encode_kernel<kFused>, grid_for_rows(n_rows), kBlockThreads, s, d_in,
-                        split->dev, bpe->dev, w);
-        else
-            OVTK_LAUNCH(ws->marks, "encode_pieces", encode_kernel<kPieces>, grid_for_rows(n_rows), kBlockThreads, s, d_in,
-                        SplitDev{}, bpe->dev, w);
-        OVTK_LAUNCH(ws->marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
-        OVTK_LAUNCH(ws->marks, "finalize_rows", finalize_rows_kernel, 1, kScanThreads, s, n_rows, w, d_begins, d_ends,
-                    (long long)out->data_capacity);
-        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_for_rows(n_rows), kBlockThreads, s, n_rows, w, d_ids);
-        if (int rc = finish_status(*ws.ws, s)) return rc;
-
-        const RunStatus& st = *ws->host_status;
-        if (st.flags & kFlagRange)
-            return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
-        if (st.flags & kFlagStageOverflow) {
-            if (st.stage_need >= INT32_MAX - 1) return set_error(OVTK_E_UNSUPPORTED, "batch needs more than 2^31 staging entries; split the call");
-            stage_cap = st.stage_need;
-            continue;
-        }
-        if (st.flags & kFlagDeferOverflow) {
-            deferred_cap = int64_t(st.n_deferred) + 64;
-            continue;
-        }
-        if (st.flags & kFlagScratchOverflow) {
-            scratch_cap = std::max<int64_t>(scratch_cap * 2, int64_t(st.scratch_used) + (1 << 20));
-            if (scratch_cap > (int64_t(3) << 30)) return set_error(OVTK_E_UNSUPPORTED, "exact-path scratch would exceed 3 GiB; split the call");
-            continue;
-        }
-        if (st.flags & kFlagOutCapacity)
-            return set_error(OVTK_E_CAPACITY, "BPETokenizer: output ids buffer too small (" + std::to_string(st.n_out) +
-                                                  " ids, capacity " + std::to_string(out->data_capacity) + ")");
-        out->n_data = st.n_out;
-        if (mem == OVTK_MEM_HOST) {
-            OVTK_HIP(hipMemcpyAsync(out->begins, d_begins, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
-            OVTK_HIP(hipMemcpyAsync(out->ends, d_ends, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
-            OVTK_HIP(hipMemcpyAsync(out->data, d_ids, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
-            OVTK_HIP(hipStreamSynchronize(s));
-        }
-        return OVTK_OK;
-    }
-    return set_error(OVTK_E_HIP, "workspace sizing did not converge");
+    const int n_rows = int(in->n_rows);
+    return run_rows_to_ids(bpe->device, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
+                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w) {
+                               if (split)
+                                   OVTK_LAUNCH(ws.marks, "encode_fused", encode_kernel<kFused>, grid_for_rows(n_rows),
+                                               kBlockThreads, s, d_in, split->dev, bpe->dev, w);
+                               else
+                                   OVTK_LAUNCH(ws.marks, "encode_pieces", encode_kernel<kPieces>, grid_for_rows(n_rows),
+                                               kBlockThreads, s, d_in, SplitDev{}, bpe->dev, w);
+                               OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
+                           });
 }
 
 }  // namespace

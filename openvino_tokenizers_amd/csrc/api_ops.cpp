@@ -1,1 +1,516 @@
-// api_ops.cpp -- placeholder, filled in below.
+// api_ops.cpp -- C-ABI entry points of WordpieceTokenizer, VocabEncoder, RaggedToDense, VocabDecoder,
+// ByteFallback, FuzeRagged and the fused detokenizer.  Compiled as HIP (hipcc -x hip).
+// Reference behaviour replaced: src/wordpiece_tokenizer.cpp:49-133, src/vocab_encoder.cpp:55-94,
+// src/ragged_to_dense.cpp:70-174, src/vocab_decoder.cpp:23-87, src/byte_fallback.cpp:16-50, src/fuze.cpp:20-40.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "api_common.hpp"
+#include "ops_kernels.hpp"
+#include "runtime.hpp"
+#include "tables.hpp"
+
+using namespace ovtk;
+
+namespace {
+
+struct TrieBufs {
+    DevBuf root, node, edges;
+    int upload(const TrieHost& t, TrieDev& d) {
+        int e = 0;
+        e = e ? e : root.upload(t.root.data(), t.root.size() * sizeof(I2));
+        e = e ? e : node.upload(t.node.data(), t.node.size() * sizeof(I2));
+        e = e ? e : edges.upload(t.edges.data(), t.edges.size() * sizeof(uint64_t));
+        if (e) return e;
+        d.root = root.as<I2>();
+        d.node = node.as<I2>();
+        d.edges = edges.as<uint64_t>();
+        d.edge_mask = t.edge_mask;
+        d.edge_shift = t.edge_shift;
+        return OVTK_OK;
+    }
+};
+
+int check_strings_arg(const ovtk_strings* s, const char* what) {
+    if (!s) return set_error(OVTK_E_ARG, std::string(what) + ": null argument");
+    if (s->n < 0 || s->n_chars < 0) return set_error(OVTK_E_ARG, std::string(what) + ": negative size");
+    if (s->n >= INT32_MAX || s->n_chars >= INT32_MAX)
+        return set_error(OVTK_E_ARG, std::string(what) + ": tensor sizes must fit int32 offsets");
+    return OVTK_OK;
+}
+
+// Status block handling of the ops that do not go through run_rows_to_ids.
+int begin_status(Workspace& ws, hipStream_t s, RunStatus** st) {
+    if (!ws.host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
+    if (int rc = ws.status.ensure(sizeof(RunStatus))) return rc;
+    *st = ws.status.as<RunStatus>();
+    OVTK_HIP(hipMemsetAsync(*st, 0, sizeof(RunStatus), s));
+    return OVTK_OK;
+}
+
+// Exclusive scan of len(i), i < n, then apply(i, offset, len): three launches.
+template <class LenF, class ApplyF>
+int scan_and_apply(Workspace& ws, hipStream_t s, long long n, LenF len, ApplyF apply, long long cap, RunStatus* st,
+                   const char* tag) {
+    const long long n_tiles = (n + kTileElems - 1) / kTileElems;
+    if (n_tiles > INT32_MAX) return set_error(OVTK_E_UNSUPPORTED, "too many elements for one call; split it");
+    if (int rc = ws.gen[7].ensure(size_t(std::max<long long>(n_tiles, 1)) * sizeof(long long))) return rc;
+    long long* tiles = ws.gen[7].as<long long>();
+    if (n_tiles > 0) OVTK_LAUNCH(ws.marks, tag, tile_reduce_kernel<LenF>, int(n_tiles), kTileThreads, s, n, len, tiles);
+    OVTK_LAUNCH(ws.marks, "tile_scan", tile_scan_kernel, 1, kScanThreads, s, int(n_tiles), tiles, cap, st);
+    if (n_tiles > 0)
+        OVTK_LAUNCH(ws.marks, tag, (tile_apply_kernel<LenF, ApplyF>), int(n_tiles), kTileThreads, s, n, len,
+                    (const long long*)tiles, apply, (const RunStatus*)st);
+    return OVTK_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- handles
+struct ovtk_wordpiece {
+    int device = 0;
+    WordpieceDev dev{};
+    TrieBufs root, sub;
+};
+
+struct ovtk_vocab_encoder {
+    int device = 0;
+    int value_size = 4;
+    StringMapDev dev{};
+    DevBuf slots, kb, ke, kc, values;
+};
+
+struct ovtk_vocab_decoder {
+    int device = 0;
+    int32_t vocab_size = 0;
+    int32_t max_token_len = 0;
+    DevBuf vb, ve, vc, skip_bits, fallback;
+    std::vector<uint32_t> attr_skip_bits;  // host copy, attribute skip_tokens
+    bool has_attr_skips = false;
+};
+
+extern "C" {
+
+// ------------------------------------------------------------------------------- WordpieceTokenizer
+int ovtk_wordpiece_create(const ovtk_wordpiece_params* p, ovtk_wordpiece** out) {
+    if (!p || !out) return set_error(OVTK_E_ARG, "wordpiece: null argument");
+    if (int rc = check_strings_arg(&p->vocab, "wordpiece vocab")) return rc;
+    if (int rc = use_device(p->device)) return rc;
+    auto h = std::make_unique<ovtk_wordpiece>();
+    h->device = p->device;
+    TrieHost root, sub;
+    std::string err;
+    const std::string si(p->suffix_indicator ? p->suffix_indicator : "", size_t(p->suffix_indicator ? p->suffix_indicator_len : 0));
+    if (int rc = build_wordpiece(view_of(p->vocab), si, root, sub, err)) return set_error(rc, err);
+    if (int rc = h->root.upload(root, h->dev.root)) return rc;
+    if (int rc = h->sub.upload(sub, h->dev.sub)) return rc;
+    OVTK_HIP(hipStreamSynchronize(nullptr));
+    h->dev.max_bytes = p->max_bytes_per_word;
+    *out = h.release();
+    return OVTK_OK;
+}
+
+int ovtk_wordpiece_run(ovtk_wordpiece* h, const ovtk_ragged_strings* in, int32_t unk_token_id, ovtk_ragged_i32_out* out,
+                       int mem, void* stream) {
+    if (int rc = check_rows(in)) return rc;
+    if (!h || !out) return set_error(OVTK_E_ARG, "null argument");
+    if (out->data_capacity < 0 || out->data_capacity >= INT32_MAX) return set_error(OVTK_E_ARG, "bad output capacity");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(h->device));
+    out->n_data = 0;
+    out->n_rows = in->n_rows;
+    if (in->n_rows == 0) return OVTK_OK;
+    const int n_rows = int(in->n_rows);
+    return run_rows_to_ids(h->device, "WordpieceTokenizer", in, nullptr, 1, out, mem, s,
+                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w) {
+                               OVTK_LAUNCH(ws.marks, "wordpiece", wordpiece_kernel, grid_for_rows(n_rows), kBlockThreads, s,
+                                           d_in, h->dev, unk_token_id, w);
+                           });
+}
+
+void ovtk_wordpiece_destroy(ovtk_wordpiece* h) { delete h; }
+
+// ------------------------------------------------------------------------------- VocabEncoder
+int ovtk_vocab_encoder_create(const ovtk_vocab_encoder_params* p, ovtk_vocab_encoder** out) {
+    if (!p || !out) return set_error(OVTK_E_ARG, "vocab_encoder: null argument");
+    if (int rc = check_strings_arg(&p->keys, "vocab_encoder keys")) return rc;
+    if (p->value_size != 4 && p->value_size != 8)  // vocab_encoder.cpp:38-53
+        return set_error(OVTK_E_ARG, "VocabEncoder: unsupported element type (i32 and i64 values only)");
+    if (p->keys.n > 0 && !p->values) return set_error(OVTK_E_ARG, "vocab_encoder: null values");
+    if (int rc = use_device(p->device)) return rc;
+    auto h = std::make_unique<ovtk_vocab_encoder>();
+    h->device = p->device;
+    h->value_size = p->value_size;
+    StringMapHost host;
+    std::string err;
+    if (int rc = build_string_map(view_of(p->keys), host, err)) return set_error(rc, err);
+    int e = 0;
+    e = e ? e : h->slots.upload(host.slots.data(), host.slots.size() * sizeof(uint64_t));
+    e = e ? e : h->kb.upload(host.key_begins.data(), host.key_begins.size() * 4);
+    e = e ? e : h->ke.upload(host.key_ends.data(), host.key_ends.size() * 4);
+    e = e ? e : h->kc.upload(host.key_chars.data(), host.key_chars.size());
+    e = e ? e : h->values.upload(p->values, size_t(p->keys.n) * size_t(p->value_size));
+    if (e) return e;
+    OVTK_HIP(hipStreamSynchronize(nullptr));
+    h->dev.slots = h->slots.as<uint64_t>();
+    h->dev.mask = host.mask;
+    h->dev.key_begins = h->kb.as<int32_t>();
+    h->dev.key_ends = h->ke.as<int32_t>();
+    h->dev.key_chars = h->kc.as<uint8_t>();
+    h->dev.values = h->values.as<void>();
+    h->dev.value_size = p->value_size;
+    *out = h.release();
+    return OVTK_OK;
+}
+
+int ovtk_vocab_encoder_run(ovtk_vocab_encoder* h, const ovtk_strings* in, const void* default_value, void* out, int mem,
+                           void* stream) {
+    if (!h || !default_value) return set_error(OVTK_E_ARG, "null argument");
+    if (int rc = check_strings_arg(in, "vocab_encoder input")) return rc;
+    if (in->n == 0) return OVTK_OK;
+    if (!out) return set_error(OVTK_E_ARG, "null output");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(h->device));
+    WorkspaceLease ws(h->device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    const int32_t *b = nullptr, *e = nullptr;
+    const uint8_t* c = nullptr;
+    if (int rc = in_source(ws->in_begins, in->begins, size_t(in->n) * 4, mem, s, &b)) return rc;
+    if (int rc = in_source(ws->in_ends, in->ends, size_t(in->n) * 4, mem, s, &e)) return rc;
+    if (int rc = in_source(ws->in_chars, in->chars, size_t(in->n_chars), mem, s, &c)) return rc;
+    const size_t out_bytes = size_t(in->n) * size_t(h->value_size);
+    uint8_t* d_out = nullptr;
+    if (int rc = out_target(ws->out_a, static_cast<uint8_t*>(out), out_bytes, mem, &d_out)) return rc;
+    const int n = int(in->n);
+    if (h->value_size == 4) {
+        int32_t d;
+        std::memcpy(&d, default_value, 4);
+        OVTK_LAUNCH(ws->marks, "vocab_encoder", vocab_encoder_kernel<int32_t>, grid_for_elems(n), kBlockThreads, s, b, e, c,
+                    (long long)in->n_chars, n, h->dev, d, reinterpret_cast<int32_t*>(d_out), st);
+    } else {
+        long long d;
+        std::memcpy(&d, default_value, 8);
+        OVTK_LAUNCH(ws->marks, "vocab_encoder", vocab_encoder_kernel<long long>, grid_for_elems(n), kBlockThreads, s, b, e, c,
+                    (long long)in->n_chars, n, h->dev, d, reinterpret_cast<long long*>(d_out), st);
+    }
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside the chars tensor");
+    if (int rc = copy_back(out, d_out, out_bytes, mem, s)) return rc;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+void ovtk_vocab_encoder_destroy(ovtk_vocab_encoder* h) { delete h; }
+
+// ------------------------------------------------------------------------------- RaggedToDense
+int ovtk_ragged_to_dense(const int32_t* begins, const int32_t* ends, int64_t n_rows, const void* data, int64_t n_data,
+                         int elem_size, int64_t inner_elems, int32_t target_dim, const void* default_value, int pad_right,
+                         int pad_max_length, void* out_dense, uint8_t* out_mask, int mem, int device, void* stream) {
+    if (n_rows < 0 || n_data < 0 || inner_elems < 1 || target_dim < 0) return set_error(OVTK_E_ARG, "ragged_to_dense: bad size");
+    if (elem_size != 1 && elem_size != 2 && elem_size != 4 && elem_size != 8)
+        return set_error(OVTK_E_ARG, "ragged_to_dense: element size must be 1, 2, 4 or 8 bytes (POD types)");
+    if (!default_value) return set_error(OVTK_E_ARG, "ragged_to_dense: null default value");
+    if (n_rows >= INT32_MAX || inner_elems * elem_size >= (1 << 20))
+        return set_error(OVTK_E_UNSUPPORTED, "ragged_to_dense: shape too large for one call");
+    if (int rc = use_device(device)) return rc;
+    if (n_rows == 0 || target_dim == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    DenseArgs a{};
+    a.n_rows = int32_t(n_rows);
+    a.n_data = n_data;
+    a.elem_size = elem_size;
+    a.inner = int32_t(inner_elems);
+    a.cell = int32_t(elem_size * inner_elems);
+    a.target = target_dim;
+    a.pad_right = pad_right != 0;
+    a.pad_max_length = pad_max_length != 0;
+    std::memset(a.dflt, 0, sizeof a.dflt);
+    std::memcpy(a.dflt, default_value, size_t(elem_size));
+    a.status = st;
+    const uint8_t* d_data = nullptr;
+    if (int rc = in_source(ws->in_begins, begins, size_t(n_rows) * 4, mem, s, &a.begins)) return rc;
+    if (int rc = in_source(ws->in_ends, ends, size_t(n_rows) * 4, mem, s, &a.ends)) return rc;
+    if (int rc = in_source(ws->in_chars, static_cast<const uint8_t*>(data), size_t(n_data) * size_t(a.cell), mem, s, &d_data)) return rc;
+    a.data = d_data;
+    const size_t dense_bytes = size_t(n_rows) * size_t(target_dim) * size_t(a.cell);
+    const size_t mask_bytes = size_t(n_rows) * size_t(target_dim) * size_t(inner_elems);
+    if (int rc = out_target(ws->out_a, static_cast<uint8_t*>(out_dense), dense_bytes, mem, &a.out)) return rc;
+    a.mask = nullptr;
+    if (out_mask)
+        if (int rc = out_target(ws->out_b, out_mask, mask_bytes, mem, &a.mask)) return rc;
+    OVTK_LAUNCH(ws->marks, "ragged_to_dense", ragged_to_dense_kernel, grid_for_rows(a.n_rows), kBlockThreads, s, a);
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "ragged_to_dense: a row reads past the data tensor");
+    if (int rc = copy_back(out_dense, a.out, dense_bytes, mem, s)) return rc;
+    if (out_mask)
+        if (int rc = copy_back(out_mask, a.mask, mask_bytes, mem, s)) return rc;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- VocabDecoder
+int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_decoder** out) {
+    if (!p || !out) return set_error(OVTK_E_ARG, "vocab_decoder: null argument");
+    if (int rc = check_strings_arg(&p->vocab, "vocab_decoder vocab")) return rc;
+    if (p->n_skip_tokens < 0 || (p->n_skip_tokens > 0 && !p->skip_tokens)) return set_error(OVTK_E_ARG, "vocab_decoder: bad skip_tokens");
+    if (int rc = use_device(p->device)) return rc;
+    auto h = std::make_unique<ovtk_vocab_decoder>();
+    h->device = p->device;
+    const int64_t V = p->vocab.n;
+    h->vocab_size = int32_t(V);
+    std::vector<int16_t> fb(size_t(std::max<int64_t>(V, 1)), int16_t(-1));
+    for (int64_t i = 0; i < V; ++i) {
+        const int64_t b = p->vocab.begins[i], e = p->vocab.ends[i];
+        if (b < 0 || e < b || e > p->vocab.n_chars) return set_error(OVTK_E_RANGE, "vocab_decoder: vocab begins/ends outside chars");
+        h->max_token_len = std::max<int32_t>(h->max_token_len, int32_t(e - b));
+        // ByteFallback applied to this token (byte_fallback.cpp:37-41), precomputed once per vocabulary
+        const uint8_t* t = p->vocab.chars + b;
+        const int len = int(e - b);
+        int v = -1;
+        if (len == 6 && t[0] == '<' && t[5] == '>') {
+            bool only_first = true;
+            for (int k = 1; k < 6; ++k) only_first = only_first && t[k] != '<';
+            if (only_first) {
+                v = 255;  // not a "<0x%02X>" spelling: PieceToByte returns -1, stored as (uint8_t)0xFF
+                auto hex = [](uint8_t c) { return c >= '0' && c <= '9' ? c - '0' : (c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1); };
+                if (t[1] == '0' && t[2] == 'x' && hex(t[3]) >= 0 && hex(t[4]) >= 0) v = hex(t[3]) * 16 + hex(t[4]);
+            }
+        }
+        fb[size_t(i)] = int16_t(v);
+    }
+    h->attr_skip_bits.assign(size_t((V + 31) / 32 + 1), 0u);
+    for (int64_t k = 0; k < p->n_skip_tokens; ++k) {
+        const int32_t t = p->skip_tokens[k];
+        if (t >= 0 && t < V) {
+            h->attr_skip_bits[size_t(t) >> 5] |= 1u << (t & 31);
+            h->has_attr_skips = true;
+        }
+    }
+    int e = 0;
+    e = e ? e : h->vb.upload(p->vocab.begins, size_t(V) * 4);
+    e = e ? e : h->ve.upload(p->vocab.ends, size_t(V) * 4);
+    e = e ? e : h->vc.upload(p->vocab.chars, size_t(p->vocab.n_chars));
+    e = e ? e : h->fallback.upload(fb.data(), fb.size() * sizeof(int16_t));
+    e = e ? e : h->skip_bits.upload(h->attr_skip_bits.data(), h->attr_skip_bits.size() * 4);
+    if (e) return e;
+    OVTK_HIP(hipStreamSynchronize(nullptr));
+    *out = h.release();
+    return OVTK_OK;
+}
+
+void ovtk_vocab_decoder_destroy(ovtk_vocab_decoder* h) { delete h; }
+
+}  // extern "C"
+
+namespace {
+
+// Common front of VocabDecoder and the fused detokenizer: ids on the device + the skip bitmap of this call.
+int decoder_inputs(ovtk_vocab_decoder* h, Workspace& ws, const int32_t* ids, int64_t n_ids, const int32_t* skip_in,
+                   int64_t n_skip_in, int mem, hipStream_t s, DecodeDev& d) {
+    d = DecodeDev{};
+    if (int rc = in_source(ws.gen[0], ids, size_t(n_ids) * 4, mem, s, &d.ids)) return rc;
+    d.v_begins = h->vb.as<int32_t>();
+    d.v_ends = h->ve.as<int32_t>();
+    d.v_chars = h->vc.as<uint8_t>();
+    d.vocab_size = h->vocab_size;
+    if (skip_in) {  // input 4 replaces the attribute for this call (vocab_decoder.cpp:36-41)
+        std::vector<uint32_t> bits(h->attr_skip_bits.size(), 0u);
+        bool any = false;
+        for (int64_t k = 0; k < n_skip_in; ++k) {
+            const int32_t t = skip_in[k];
+            if (t >= 0 && t < h->vocab_size) {
+                bits[size_t(t) >> 5] |= 1u << (t & 31);
+                any = true;
+            }
+        }
+        if (any) {
+            if (int rc = ws.gen[1].upload(bits.data(), bits.size() * 4, s)) return rc;
+            OVTK_HIP(hipStreamSynchronize(s));  // `bits` dies at return
+            d.skip_bits = ws.gen[1].as<uint32_t>();
+        }
+    } else if (h->has_attr_skips) {
+        d.skip_bits = h->skip_bits.as<uint32_t>();
+    }
+    return OVTK_OK;
+}
+
+int check_decoder_args(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len, const int32_t* skip_in,
+                       int64_t n_skip_in, ovtk_strings_out* out) {
+    if (!h || !out) return set_error(OVTK_E_ARG, "null argument");
+    if (batch < 0 || seq_len < 0 || n_skip_in < 0) return set_error(OVTK_E_ARG, "negative size");
+    if (batch * std::max<int64_t>(seq_len, 1) >= INT32_MAX)
+        return set_error(OVTK_E_ARG, "batch * seq_len must fit int32 offsets (vocab_decoder.cpp:45-46); split the call");
+    if (batch * seq_len > 0 && !ids) return set_error(OVTK_E_ARG, "null ids");
+    if (n_skip_in > 0 && !skip_in) return set_error(OVTK_E_ARG, "null skip tokens");
+    if (out->chars_capacity < 0) return set_error(OVTK_E_ARG, "bad output capacity");
+    return OVTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ovtk_vocab_decoder_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len,
+                           const int32_t* skip_in, int64_t n_skip_in, int32_t* out_rb, int32_t* out_re,
+                           ovtk_strings_out* out, int mem, void* stream) {
+    if (int rc = check_decoder_args(h, ids, batch, seq_len, skip_in, n_skip_in, out)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(h->device));
+    out->n_chars = 0;
+    if (batch == 0) return OVTK_OK;
+    const int64_t sp = seq_len > 0 ? seq_len : 1, n_tok = batch * sp;
+    WorkspaceLease ws(h->device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    int32_t *d_rb = nullptr, *d_re = nullptr, *d_b = nullptr, *d_e = nullptr;
+    uint8_t* d_c = nullptr;
+    if (int rc = out_target(ws->out_a, out_rb, size_t(batch) * 4, mem, &d_rb)) return rc;
+    if (int rc = out_target(ws->out_b, out_re, size_t(batch) * 4, mem, &d_re)) return rc;
+    if (int rc = out_target(ws->out_c, out->begins, size_t(n_tok) * 4, mem, &d_b)) return rc;
+    if (int rc = out_target(ws->out_d, out->ends, size_t(n_tok) * 4, mem, &d_e)) return rc;
+    if (int rc = out_target(ws->out_e, out->chars, size_t(out->chars_capacity), mem, &d_c)) return rc;
+    OVTK_LAUNCH(ws->marks, "decoder_rows", decoder_rows_kernel, grid_for_elems(batch), kBlockThreads, s, int(batch), int(sp), d_rb, d_re);
+    if (seq_len == 0) {  // vocab_decoder.cpp:61-65: one empty string per row
+        OVTK_HIP(hipMemsetAsync(d_b, 0, size_t(n_tok) * 4, s));
+        OVTK_HIP(hipMemsetAsync(d_e, 0, size_t(n_tok) * 4, s));
+    } else {
+        DecodeDev d;
+        if (int rc = decoder_inputs(h, *ws.ws, ids, n_tok, skip_in, n_skip_in, mem, s, d)) return rc;
+        if (int rc = scan_and_apply(*ws.ws, s, n_tok, DecodeLen{d}, DecodeApply{d, d_b, d_e, d_c, 0},
+                                    (long long)std::min<int64_t>(out->chars_capacity, INT32_MAX - 1), st, "vocab_decoder"))
+            return rc;
+    }
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagOutCapacity)
+        return set_error(OVTK_E_CAPACITY, "VocabDecoder: output chars buffer too small or beyond int32 offsets (" +
+                                              std::to_string(ws->host_status->n_out) + " bytes needed)");
+    out->n_chars = ws->host_status->n_out;
+    int e = 0;
+    e = e ? e : copy_back(out_rb, d_rb, size_t(batch) * 4, mem, s);
+    e = e ? e : copy_back(out_re, d_re, size_t(batch) * 4, mem, s);
+    e = e ? e : copy_back(out->begins, d_b, size_t(n_tok) * 4, mem, s);
+    e = e ? e : copy_back(out->ends, d_e, size_t(n_tok) * 4, mem, s);
+    e = e ? e : copy_back(out->chars, d_c, size_t(out->n_chars), mem, s);
+    if (e) return e;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len, const int32_t* skip_in,
+                        int64_t n_skip_in, int byte_fallback, ovtk_strings_out* out, int mem, void* stream) {
+    if (int rc = check_decoder_args(h, ids, batch, seq_len, skip_in, n_skip_in, out)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(h->device));
+    out->n_chars = 0;
+    if (batch == 0) return OVTK_OK;
+    WorkspaceLease ws(h->device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    int32_t *d_b = nullptr, *d_e = nullptr;
+    uint8_t* d_c = nullptr;
+    if (int rc = out_target(ws->out_c, out->begins, size_t(batch) * 4, mem, &d_b)) return rc;
+    if (int rc = out_target(ws->out_d, out->ends, size_t(batch) * 4, mem, &d_e)) return rc;
+    if (int rc = out_target(ws->out_e, out->chars, size_t(out->chars_capacity), mem, &d_c)) return rc;
+    if (seq_len == 0) {
+        OVTK_HIP(hipMemsetAsync(d_b, 0, size_t(batch) * 4, s));
+        OVTK_HIP(hipMemsetAsync(d_e, 0, size_t(batch) * 4, s));
+    } else {
+        DecodeDev d;
+        if (int rc = decoder_inputs(h, *ws.ws, ids, batch * seq_len, skip_in, n_skip_in, mem, s, d)) return rc;
+        if (byte_fallback) d.fallback_byte = h->fallback.as<int16_t>();
+        // per-token offsets are not materialised: the apply functor writes the row bounds FuzeRagged would pick
+        if (int rc = scan_and_apply(*ws.ws, s, batch * seq_len, DecodeLen{d}, DecodeApply{d, d_b, d_e, d_c, int32_t(seq_len)},
+                                    (long long)std::min<int64_t>(out->chars_capacity, INT32_MAX - 1), st, "detokenize"))
+            return rc;
+    }
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagOutCapacity)
+        return set_error(OVTK_E_CAPACITY, "detokenize: output chars buffer too small or beyond int32 offsets (" +
+                                              std::to_string(ws->host_status->n_out) + " bytes needed)");
+    out->n_chars = ws->host_status->n_out;
+    int e = 0;
+    e = e ? e : copy_back(out->begins, d_b, size_t(batch) * 4, mem, s);
+    e = e ? e : copy_back(out->ends, d_e, size_t(batch) * 4, mem, s);
+    e = e ? e : copy_back(out->chars, d_c, size_t(out->n_chars), mem, s);
+    if (e) return e;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- ByteFallback
+int ovtk_byte_fallback(const ovtk_strings* in, ovtk_strings_out* out, int mem, int device, void* stream) {
+    if (int rc = check_strings_arg(in, "byte_fallback input")) return rc;
+    if (!out || out->chars_capacity < 0) return set_error(OVTK_E_ARG, "byte_fallback: bad output");
+    if (int rc = use_device(device)) return rc;
+    out->n_chars = 0;
+    if (in->n == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    const int32_t *b = nullptr, *e = nullptr;
+    const uint8_t* c = nullptr;
+    if (int rc = in_source(ws->in_begins, in->begins, size_t(in->n) * 4, mem, s, &b)) return rc;
+    if (int rc = in_source(ws->in_ends, in->ends, size_t(in->n) * 4, mem, s, &e)) return rc;
+    if (int rc = in_source(ws->in_chars, in->chars, size_t(in->n_chars), mem, s, &c)) return rc;
+    int32_t *d_b = nullptr, *d_e = nullptr;
+    uint8_t* d_c = nullptr;
+    if (int rc = out_target(ws->out_c, out->begins, size_t(in->n) * 4, mem, &d_b)) return rc;
+    if (int rc = out_target(ws->out_d, out->ends, size_t(in->n) * 4, mem, &d_e)) return rc;
+    if (int rc = out_target(ws->out_e, out->chars, size_t(out->chars_capacity), mem, &d_c)) return rc;
+    OVTK_LAUNCH(ws->marks, "check_strings", check_strings_kernel, grid_for_elems(in->n), kBlockThreads, s, b, e,
+                (long long)in->n, (long long)in->n_chars, st);
+    if (int rc = scan_and_apply(*ws.ws, s, in->n, FallbackLen{b, e, c, (long long)in->n_chars}, FallbackApply{b, e, c, d_b, d_e, d_c},
+                                (long long)out->chars_capacity, st, "byte_fallback"))
+        return rc;
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside the chars tensor");
+    if (ws->host_status->flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "ByteFallback: output chars buffer too small");
+    out->n_chars = ws->host_status->n_out;
+    int err = 0;
+    err = err ? err : copy_back(out->begins, d_b, size_t(in->n) * 4, mem, s);
+    err = err ? err : copy_back(out->ends, d_e, size_t(in->n) * 4, mem, s);
+    err = err ? err : copy_back(out->chars, d_c, size_t(out->n_chars), mem, s);
+    if (err) return err;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- FuzeRagged
+int ovtk_fuze_ragged(const int32_t* ragged_begins, const int32_t* ragged_ends, int64_t n_rows, const int32_t* begins,
+                     const int32_t* ends, int64_t n, int32_t* out_begins, int32_t* out_ends, int mem, int device, void* stream) {
+    if (n_rows < 0 || n < 0 || n_rows >= INT32_MAX || n >= INT32_MAX) return set_error(OVTK_E_ARG, "fuze: bad size");
+    if (int rc = use_device(device)) return rc;
+    if (n_rows == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    const int32_t *rb = nullptr, *re = nullptr, *b = nullptr, *e = nullptr;
+    if (int rc = in_source(ws->in_rb, ragged_begins, size_t(n_rows) * 4, mem, s, &rb)) return rc;
+    if (int rc = in_source(ws->in_re, ragged_ends, size_t(n_rows) * 4, mem, s, &re)) return rc;
+    if (int rc = in_source(ws->in_begins, begins, size_t(n) * 4, mem, s, &b)) return rc;
+    if (int rc = in_source(ws->in_ends, ends, size_t(n) * 4, mem, s, &e)) return rc;
+    int32_t *d_b = nullptr, *d_e = nullptr;
+    if (int rc = out_target(ws->out_a, out_begins, size_t(n_rows) * 4, mem, &d_b)) return rc;
+    if (int rc = out_target(ws->out_b, out_ends, size_t(n_rows) * 4, mem, &d_e)) return rc;
+    OVTK_LAUNCH(ws->marks, "fuze", fuze_kernel, grid_for_elems(n_rows), kBlockThreads, s, rb, re, int(n_rows), b, e, int(n), d_b, d_e, st);
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "fuze: ragged begins/ends index outside the string tensor");
+    int err = 0;
+    err = err ? err : copy_back(out_begins, d_b, size_t(n_rows) * 4, mem, s);
+    err = err ? err : copy_back(out_ends, d_e, size_t(n_rows) * 4, mem, s);
+    if (err) return err;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+}  // extern "C"

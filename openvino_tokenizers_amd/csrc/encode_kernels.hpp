@@ -93,7 +93,7 @@ __device__ __forceinline__ long long block_exclusive_scan(int n, F&& f, Put&& pu
 }
 
 // ---- K1: per-row staging capacity -> offsets.  cap(row) = mul * sum over its strings of max(len, 1).
-__global__ __launch_bounds__(kScanThreads) void prepare_rows_kernel(RowsIn in, int mul, EncodeWork w) {
+static __global__ __launch_bounds__(kScanThreads) void prepare_rows_kernel(RowsIn in, int mul, EncodeWork w) {
     __shared__ int bad_s;
     if (threadIdx.x == 0) bad_s = 0;
     __syncthreads();
@@ -256,7 +256,7 @@ __device__ __forceinline__ void encode_whole_strings(WaveScratch& ws, const BpeD
 }
 
 template <int MODE>
-__global__ __launch_bounds__(kBlockThreads) void encode_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads) void encode_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
     __shared__ I2 root_lds[256];
     __shared__ uint8_t ascii_cls[128];
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kBlockThreads) void encode_kernel(RowsIn in, SplitD
 }
 
 // ---- K3: path X, one lane per deferred piece.
-__global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, BpeDev T, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, BpeDev T, EncodeWork w) {
     if (w.status->flags & (kFlagRange | kFlagStageOverflow)) return;
     int n = w.status->n_deferred;
     if (n > w.deferred_cap) n = w.deferred_cap;
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, BpeDev 
 }
 
 // ---- K4: final offsets (one block).  out_begins/out_ends may be nullptr.
-__global__ __launch_bounds__(kScanThreads) void finalize_rows_kernel(int n_rows, EncodeWork w, int32_t* out_begins,
+static __global__ __launch_bounds__(kScanThreads) void finalize_rows_kernel(int n_rows, EncodeWork w, int32_t* out_begins,
                                                                       int32_t* out_ends, long long out_cap) {
     if (w.status->flags & (kFlagRange | kFlagStageOverflow)) return;
     const long long total = block_exclusive_scan<kScanThreads>(
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kScanThreads) void finalize_rows_kernel(int n_rows,
 }
 
 // ---- K5: staging -> caller's buffer, one wave per row.
-__global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out) {
+static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out) {
     if (w.status->flags & (kFlagRange | kFlagStageOverflow | kFlagOutCapacity | kFlagDeferOverflow |
                            kFlagScratchOverflow))
         return;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, Enco
 // ---- RegexSplit as its own op: count pass, then write pass (the scan is cheap enough to run twice).
 // mode 0: row_cnt[row] = number of pieces.  mode 1: write begins/ends/skips at row_out[row].
 template <int WRITE>
-__global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, SplitDev sp, int max_splits, EncodeWork w,
+static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, SplitDev sp, int max_splits, EncodeWork w,
                                                               int32_t* out_begins, int32_t* out_ends,
                                                               uint8_t* out_skips) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];

@@ -17,7 +17,7 @@ struct WordpieceDev {
     int32_t max_bytes;
 };
 
-__global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn in, WordpieceDev T, int32_t unk_id, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn in, WordpieceDev T, int32_t unk_id, EncodeWork w) {
     __shared__ I2 root_lds[256];
     __shared__ I2 sub_lds[256];
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn in, Wor
 // VocabEncoder (src/vocab_encoder.cpp:88-91): one lane per element, FNV-1a hash, open addressing.
 // =============================================================================================
 template <typename T>
-__global__ __launch_bounds__(kBlockThreads) void vocab_encoder_kernel(const int32_t* begins, const int32_t* ends,
+static __global__ __launch_bounds__(kBlockThreads) void vocab_encoder_kernel(const int32_t* begins, const int32_t* ends,
                                                                       const uint8_t* chars, long long n_chars, int n,
                                                                       StringMapDev M, T dflt, T* out, RunStatus* status) {
     const int stride = int(gridDim.x) * kBlockThreads;
@@ -137,14 +137,15 @@ struct DenseArgs {
     RunStatus* status;
 };
 
-__global__ __launch_bounds__(kBlockThreads) void ragged_to_dense_kernel(DenseArgs a) {
+static __global__ __launch_bounds__(kBlockThreads) void ragged_to_dense_kernel(DenseArgs a) {
     const int l = lane_id();
     const int n_waves = int(gridDim.x) * kWavesPerBlock;
     for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < a.n_rows; row += n_waves) {
         const long long b = a.begins[row];
         const long long len = (long long)a.ends[row] - b;
         // :132-133: with pad_max_length the copy is `target` long whatever the row holds
-        const long long take = a.pad_max_length ? a.target : (len < a.target ? (len < 0 ? 0 : len) : a.target);
+        // size_t(len) in the reference: a negative length behaves like a huge one
+        const long long take = (a.pad_max_length || len < 0 || len > a.target) ? a.target : len;
         if (b < 0 || b + take > a.n_data) {
             if (l == 0) atomicOr(&a.status->flags, kFlagRange);
             continue;
@@ -185,7 +186,7 @@ constexpr int kTileThreads = 256;
 constexpr int kTileElems = kTileThreads * kScanPerThread;  // 1024 elements per block
 
 template <class LenF>
-__global__ __launch_bounds__(kTileThreads) void tile_reduce_kernel(long long n, LenF f, long long* tile_sums) {
+static __global__ __launch_bounds__(kTileThreads) void tile_reduce_kernel(long long n, LenF f, long long* tile_sums) {
     __shared__ long long part[kTileThreads / kWave];
     const long long i0 = (long long)blockIdx.x * kTileElems + (long long)threadIdx.x * kScanPerThread;
     long long s = 0;
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(kTileThreads) void tile_reduce_kernel(long long n, 
 }
 
 // One block: exclusive scan of the tile sums in place; total -> status->n_out (clamped) + capacity flag.
-__global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(int n_tiles, long long* tile_sums, long long cap,
+static __global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(int n_tiles, long long* tile_sums, long long cap,
                                                                   RunStatus* status) {
     const long long total = block_exclusive_scan<kScanThreads>(
         n_tiles, [&](int t) -> long long { return tile_sums[t]; }, [&](int t, long long off) { tile_sums[t] = off; });
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(int n_tiles, lo
 
 // apply(i, offset, len) is called for every element with its global exclusive offset.
 template <class LenF, class ApplyF>
-__global__ __launch_bounds__(kTileThreads) void tile_apply_kernel(long long n, LenF f, const long long* tile_offs,
+static __global__ __launch_bounds__(kTileThreads) void tile_apply_kernel(long long n, LenF f, const long long* tile_offs,
                                                                   ApplyF apply, const RunStatus* status) {
     __shared__ long long part[kTileThreads / kWave];
     if (status->flags & (kFlagOutCapacity | kFlagRange)) return;
@@ -254,8 +255,8 @@ struct DecodeDev {
     const int32_t* v_ends;
     const uint8_t* v_chars;
     int32_t vocab_size;
-    const uint32_t* skip_bits;   // bitmap over [0, vocab_size), may be nullptr
-    const int16_t* fallback_byte;  // per vocab id: byte value of "<0xHH>" style tokens, -1 otherwise, -2 = 0xFF quirk; nullptr = off
+    const uint32_t* skip_bits;     // bitmap over [0, vocab_size), may be nullptr
+    const int16_t* fallback_byte;  // per vocab id: the byte ByteFallback turns the token into, -1 = copied verbatim; nullptr = op absent
 };
 
 // Length in bytes of token i's text (vocab_decoder.cpp:70-81): ids outside [0, V) or in the skip list give "".
@@ -263,27 +264,35 @@ struct DecodeLen {
     DecodeDev d;
     __device__ long long operator()(long long i) const {
         const int32_t id = d.ids[i];
-        if (uint32_t(id) >= uint32_t(d.vocab_size)) return 0;
+        if (uint32_t(id) >= uint32_t(d.vocab_size)) return 0;  // `token_id < vocab_size` compares as size_t (:71)
         if (d.skip_bits && (d.skip_bits[uint32_t(id) >> 5] >> (id & 31) & 1u)) return 0;
-        if (d.fallback_byte && d.fallback_byte[id] != -1) return 1;
-        return d.v_ends[id] - d.v_begins[id];
+        const int len = d.v_ends[id] - d.v_begins[id];
+        if (len > 0 && d.fallback_byte && d.fallback_byte[id] != -1) return 1;
+        return len;
     }
 };
 
+// seq == 0: the VocabDecoder op, begins/ends per token.  seq > 0: fused detokenizer, out_begins/out_ends hold one
+// entry per row = what FuzeRagged picks (begin of the row's first token, end of its last, fuze.cpp:35-38).
 struct DecodeApply {
     DecodeDev d;
-    int32_t* out_begins;  // per token, or nullptr (fused detokenizer)
+    int32_t* out_begins;
     int32_t* out_ends;
     uint8_t* out_chars;
+    int32_t seq;
     __device__ void operator()(long long i, long long off, long long len) const {
-        if (out_begins) {
+        if (seq == 0) {
             out_begins[i] = int32_t(off);
             out_ends[i] = int32_t(off + len);
+        } else {
+            const long long r = i / seq, c = i - r * seq;
+            if (c == 0) out_begins[r] = int32_t(off);
+            if (c == seq - 1) out_ends[r] = int32_t(off + len);
         }
         if (len == 0) return;
         const int32_t id = d.ids[i];
         if (d.fallback_byte && d.fallback_byte[id] != -1) {
-            out_chars[off] = uint8_t(d.fallback_byte[id] == -2 ? 0xFF : d.fallback_byte[id]);
+            out_chars[off] = uint8_t(d.fallback_byte[id]);
             return;
         }
         const uint8_t* src = d.v_chars + d.v_begins[id];
@@ -291,9 +300,10 @@ struct DecodeApply {
     }
 };
 
-// ByteFallback (src/byte_fallback.cpp:33-46): "<0xHH>" (6 bytes, only '<' at 0, last '>' at 5) -> one byte.
+// ByteFallback (src/byte_fallback.cpp:33-46): a 6-byte token whose only '<' is at 0 and which ends in '>' becomes ONE
+// byte: PieceToByte's value for the spellings "<0x%02X>" (upper-case hex, sentence_piece.cpp:27-46), otherwise
+// PieceToByte's -1 stored into a uint8_t = 0xFF.  Returns -1: copy verbatim; 0..255: the byte.
 __device__ __forceinline__ int byte_fallback_value(const uint8_t* s, int len) {
-    // returns -1: copy verbatim; 0..255: the byte; 255 also for the reference's "not in the map -> -1 -> 0xFF" case
     if (len != 6 || s[0] != '<' || s[5] != '>') return -1;
     for (int k = 1; k < 6; ++k)
         if (s[k] == '<') return -1;  // rfind('<') must be 0
@@ -303,7 +313,7 @@ __device__ __forceinline__ int byte_fallback_value(const uint8_t* s, int len) {
         const uint8_t c = s[k];
         int h;
         if (c >= '0' && c <= '9') h = c - '0';
-        else if (c >= 'A' && c <= 'F') h = c - 'A' + 10;  // "%02X": upper-case hex only
+        else if (c >= 'A' && c <= 'F') h = c - 'A' + 10;
         else return 255;
         v = v * 16 + h;
     }
@@ -314,9 +324,11 @@ struct FallbackLen {
     const int32_t* begins;
     const int32_t* ends;
     const uint8_t* chars;
+    long long n_chars;
     __device__ long long operator()(long long i) const {
-        const int len = ends[i] - begins[i];
-        return byte_fallback_value(chars + begins[i], len) >= 0 ? 1 : (len > 0 ? len : 0);
+        const long long b = begins[i], e = ends[i];
+        if (b < 0 || e < b || e > n_chars) return 0;  // flagged by check_strings_kernel
+        return byte_fallback_value(chars + b, int(e - b)) >= 0 ? 1 : e - b;
     }
 };
 struct FallbackApply {
@@ -329,6 +341,7 @@ struct FallbackApply {
     __device__ void operator()(long long i, long long off, long long len) const {
         out_begins[i] = int32_t(off);
         out_ends[i] = int32_t(off + len);
+        if (len == 0) return;
         const uint8_t* s = chars + begins[i];
         const int v = byte_fallback_value(s, ends[i] - begins[i]);
         if (v >= 0) { out_chars[off] = uint8_t(v); return; }
@@ -336,7 +349,7 @@ struct FallbackApply {
     }
 };
 
-__global__ __launch_bounds__(kBlockThreads) void check_strings_kernel(const int32_t* begins, const int32_t* ends,
+static __global__ __launch_bounds__(kBlockThreads) void check_strings_kernel(const int32_t* begins, const int32_t* ends,
                                                                       long long n, long long n_chars, RunStatus* status) {
     const long long stride = (long long)gridDim.x * kBlockThreads;
     for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n; i += stride) {
@@ -346,7 +359,7 @@ __global__ __launch_bounds__(kBlockThreads) void check_strings_kernel(const int3
 }
 
 // Row offsets of the decoder: ragged_begins[b] = b * S', ragged_ends[b] = (b + 1) * S' (vocab_decoder.cpp:58-59).
-__global__ __launch_bounds__(kBlockThreads) void decoder_rows_kernel(int batch, int sp, int32_t* rb, int32_t* re) {
+static __global__ __launch_bounds__(kBlockThreads) void decoder_rows_kernel(int batch, int sp, int32_t* rb, int32_t* re) {
     const int stride = int(gridDim.x) * kBlockThreads;
     for (int b = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); b < batch; b += stride) {
         rb[b] = b * sp;
@@ -354,19 +367,8 @@ __global__ __launch_bounds__(kBlockThreads) void decoder_rows_kernel(int batch, 
     }
 }
 
-// Fused detokenizer: string of row b = tokens [b*S, (b+1)*S): begins/ends from the token offsets.
-__global__ __launch_bounds__(kBlockThreads) void row_bounds_kernel(int batch, int seq, const int32_t* tok_begins,
-                                                                   const int32_t* tok_ends, int32_t* out_begins,
-                                                                   int32_t* out_ends) {
-    const int stride = int(gridDim.x) * kBlockThreads;
-    for (int b = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); b < batch; b += stride) {
-        out_begins[b] = tok_begins[(long long)b * seq];
-        out_ends[b] = tok_ends[(long long)(b + 1) * seq - 1];
-    }
-}
-
 // FuzeRagged (src/fuze.cpp:35-38).
-__global__ __launch_bounds__(kBlockThreads) void fuze_kernel(const int32_t* rb, const int32_t* re, int n_rows,
+static __global__ __launch_bounds__(kBlockThreads) void fuze_kernel(const int32_t* rb, const int32_t* re, int n_rows,
                                                              const int32_t* begins, const int32_t* ends, int n,
                                                              int32_t* out_begins, int32_t* out_ends, RunStatus* status) {
     const int stride = int(gridDim.x) * kBlockThreads;

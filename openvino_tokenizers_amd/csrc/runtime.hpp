@@ -80,6 +80,7 @@ struct Workspace {
     DevBuf row_stage, row_cnt, row_out, row_slotted, stage, deferred, scratch, status;
     DevBuf in_rb, in_re, in_begins, in_ends, in_chars, in_skips;  // staging for OVTK_MEM_HOST calls
     DevBuf out_a, out_b, out_c, out_d, out_e;
+    DevBuf gen[8];  // op-specific inputs / temporaries (api_ops.cpp)
     RunStatus* host_status = nullptr;  // pinned
     std::vector<Profiler::Mark> marks;
     ~Workspace();

@@ -232,3 +232,234 @@ class FusedSplitBPE:
         lib = self.bpe._lib
         L.check(lib, lib.ovtk_encode_run(self.split._h, self.bpe._h, C.byref(rs), pskips, C.byref(out), m.mem, m.stream))
         return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+
+
+class WordpieceTokenizer(_Op):
+    """Reference: src/wordpiece_tokenizer.cpp (evaluate :49-133).  Inputs: ragged strings (5), vocab (3),
+    unk_token_id (i32 scalar, read every call).  Outputs: begins, ends, ids."""
+
+    def __init__(self, suffix_indicator="##", max_bytes_per_word=100, device=0, lib=None):
+        super().__init__(device, lib)
+        self.suffix_indicator, self.max_bytes_per_word = suffix_indicator, int(max_bytes_per_word)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ovtk_wordpiece_destroy(self._h)
+            self._h = None
+
+    def _ensure(self, inputs):
+        if self._h:
+            return
+        keep = []
+        vocab = _strings_struct(*inputs[5:8], keep)
+        si = _bytes_of(self.suffix_indicator)
+        p = L.WordpieceParams(vocab, si, len(si), self.max_bytes_per_word, self.device)
+        self._chk(self._lib.ovtk_wordpiece_create(C.byref(p), C.byref(self._h)))
+
+    def evaluate(self, inputs, ids_capacity=None):
+        if len(inputs) != 9:
+            raise L.OvtkError(L.E_ARG, f"Incorrect number of inputs passed to WordpieceTokenizer: {len(inputs)}")
+        self._ensure(inputs)
+        unk = int(np.asarray(_host(inputs[8], np.int32)).reshape(-1)[0])
+        m = _Mem(inputs[4])
+        rs, (rb, _, _, _, c) = _ragged_in(m, inputs)
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        cap = len(c) if ids_capacity is None else int(ids_capacity)  # wordpiece_tokenizer.cpp:85
+        ids, pids = m.alloc(cap, "i32")
+        out = L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
+        self._chk(self._lib.ovtk_wordpiece_run(self._h, C.byref(rs), C.c_int32(unk), C.byref(out), m.mem, m.stream))
+        return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+
+
+class VocabEncoder(_Op):
+    """Reference: src/vocab_encoder.cpp (evaluate_impl :55-94).  Inputs: strings (3), key strings (3), values
+    i32/i64[V], default scalar.  Output: values[N]."""
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ovtk_vocab_encoder_destroy(self._h)
+            self._h = None
+
+    def _ensure(self, inputs):
+        if self._h:
+            return
+        keep = []
+        keys = _strings_struct(*inputs[3:6], keep)
+        values = inputs[6].cpu().numpy() if _is_torch(inputs[6]) else np.asarray(inputs[6])
+        if values.dtype not in (np.int32, np.int64):  # vocab_encoder.cpp:38-53
+            raise L.OvtkError(L.E_ARG, f"VocabEncoder: unsupported element type: {values.dtype}")
+        values = np.ascontiguousarray(values)
+        self.dtype = values.dtype
+        p = L.VocabEncoderParams(keys, values.ctypes.data, values.dtype.itemsize, self.device)
+        self._chk(self._lib.ovtk_vocab_encoder_create(C.byref(p), C.byref(self._h)))
+
+    def evaluate(self, inputs):
+        if len(inputs) != 8:
+            raise L.OvtkError(L.E_ARG, f"Incorrect number of inputs passed to VocabEncoder: {len(inputs)}")
+        self._ensure(inputs)
+        m = _Mem(inputs[2])
+        b, pb = m.inp(inputs[0], "i32")
+        e, pe = m.inp(inputs[1], "i32")
+        c, pc = m.inp(inputs[2], "u8")
+        kind = "i32" if self.dtype == np.int32 else "i64"
+        dflt = np.asarray(_host(inputs[7], self.dtype)).reshape(-1)[:1].copy()
+        out, pout = m.alloc(len(b), kind)
+        s = L.Strings(pb, pe, pc, len(b), len(c))
+        self._chk(self._lib.ovtk_vocab_encoder_run(self._h, C.byref(s), C.c_void_p(dflt.ctypes.data), pout, m.mem, m.stream))
+        return [out[:len(b)]]
+
+
+class RaggedToDense(_Op):
+    """Reference: src/ragged_to_dense.cpp (evaluate :70-174).  Inputs: begins, ends, data, target size, default,
+    [pad_right].  Outputs: dense [B, T, ...], mask bool [B, T, ...].  Stateless."""
+
+    def __init__(self, pad_right=True, pad_max_length=False, device=0, lib=None):
+        super().__init__(device, lib)
+        self.pad_right, self.pad_max_length = bool(pad_right), bool(pad_max_length)
+
+    def evaluate(self, inputs):
+        if len(inputs) not in (5, 6):
+            raise L.OvtkError(L.E_ARG, f"Incorrect number of inputs passed to RaggedToDense: {len(inputs)}")
+        data = inputs[2]
+        m = _Mem(data)
+        b, pb = m.inp(inputs[0], "i32")
+        e, pe = m.inp(inputs[1], "i32")
+        if m.torch:
+            d = data.contiguous()
+            np_dtype = np.dtype(str(d.dtype).replace("torch.", "").replace("bool", "uint8"))
+            pd, shape = C.c_void_p(d.data_ptr()), tuple(d.shape)
+        else:
+            d = np.ascontiguousarray(data)
+            np_dtype, pd, shape = d.dtype, C.c_void_p(d.ctypes.data), d.shape
+        m.keep.append(d)
+        inner = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        target = int(np.asarray(_host(inputs[3], np.int32)).reshape(-1)[0])  # read as i32 (:82)
+        dflt = np.asarray(_host(inputs[4], np_dtype)).reshape(-1)[:1].copy()
+        pad_right = self.pad_right if len(inputs) == 5 else bool(np.asarray(_host(inputs[5], np.uint8)).reshape(-1)[0])
+        B = len(b)
+        n_out = B * target * inner
+        if m.torch:
+            dense = m.t.empty((B, target) + shape[1:], dtype=d.dtype, device=m.device)
+            mask = m.t.empty((B, target) + shape[1:], dtype=m.t.uint8, device=m.device)
+            pdense, pmask = C.c_void_p(dense.data_ptr()), C.c_void_p(mask.data_ptr())
+        else:
+            dense = np.empty((B, target) + shape[1:], np_dtype)
+            mask = np.empty((B, target) + shape[1:], np.uint8)
+            pdense, pmask = C.c_void_p(dense.ctypes.data), C.c_void_p(mask.ctypes.data)
+        if n_out:
+            self._chk(self._lib.ovtk_ragged_to_dense(pb, pe, C.c_int64(B), pd, C.c_int64(shape[0] if shape else 0),
+                                                     int(np_dtype.itemsize), C.c_int64(inner), C.c_int32(target),
+                                                     C.c_void_p(dflt.ctypes.data), int(pad_right), int(self.pad_max_length),
+                                                     pdense, pmask, m.mem, self.device, m.stream))
+        return [dense, mask.bool() if m.torch else mask.astype(bool)]
+
+
+class VocabDecoder(_Op):
+    """Reference: src/vocab_decoder.cpp (evaluate :23-87).  Inputs: ids i32[B, S], vocab strings (3), [skip_tokens].
+    Outputs: ragged_begins, ragged_ends, begins, ends, chars."""
+
+    def __init__(self, skip_tokens=(), device=0, lib=None):
+        super().__init__(device, lib)
+        self.skip_tokens = [int(t) for t in skip_tokens]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ovtk_vocab_decoder_destroy(self._h)
+            self._h = None
+
+    def _ensure(self, inputs):
+        if self._h:
+            return
+        keep = []
+        vocab = _strings_struct(*inputs[1:4], keep)
+        lens = keep[1] - keep[0]
+        self.max_token_len = int(lens.max()) if len(lens) else 0
+        skip = np.asarray(self.skip_tokens, np.int32)
+        p = L.VocabDecoderParams(vocab, skip.ctypes.data if len(skip) else None, len(skip), self.device)
+        self._chk(self._lib.ovtk_vocab_decoder_create(C.byref(p), C.byref(self._h)))
+
+    def _prep(self, inputs, chars_capacity):
+        if len(inputs) not in (4, 5):
+            raise L.OvtkError(L.E_ARG, "Too few inputs passed to VocabDecoder, it means it is not converted properly "
+                                       "or it is not used in the supported pattern")
+        self._ensure(inputs)
+        m = _Mem(inputs[0])
+        ids, pids = m.inp(inputs[0], "i32")
+        B, S = int(ids.shape[0]), int(ids.shape[1])
+        if len(inputs) == 5:
+            skip = np.ascontiguousarray(_host(inputs[4], np.int32)).reshape(-1)
+            pskip, nskip = C.c_void_p(skip.ctypes.data if len(skip) else 0), len(skip)
+            if nskip == 0:  # an empty input 4 still overrides the attribute: nothing is skipped
+                skip = np.zeros(1, np.int32)
+                pskip = C.c_void_p(skip.ctypes.data)
+            m.keep.append(skip)
+        else:
+            pskip, nskip = None, 0
+        cap = B * S * self.max_token_len if chars_capacity is None else int(chars_capacity)
+        return m, pids, B, S, pskip, nskip, cap
+
+    def evaluate(self, inputs, chars_capacity=None):
+        m, pids, B, S, pskip, nskip, cap = self._prep(inputs, chars_capacity)
+        sp = max(S, 1)
+        orb, porb = m.alloc(B, "i32")
+        ore, pore = m.alloc(B, "i32")
+        ob, pob = m.alloc(B * sp, "i32")
+        oe, poe = m.alloc(B * sp, "i32")
+        oc, poc = m.alloc(cap, "u8")
+        out = L.StringsOut(pob, poe, poc, cap, 0)
+        self._chk(self._lib.ovtk_vocab_decoder_run(self._h, pids, C.c_int64(B), C.c_int64(S), pskip, C.c_int64(nskip),
+                                                   porb, pore, C.byref(out), m.mem, m.stream))
+        return [orb[:B], ore[:B], ob[:B * sp], oe[:B * sp], oc[:out.n_chars]]
+
+
+class ByteFallback(_Op):
+    """Reference: src/byte_fallback.cpp (evaluate :16-50).  Strings (3) -> strings (3).  Stateless."""
+
+    def evaluate(self, inputs):
+        m = _Mem(inputs[2])
+        b, pb = m.inp(inputs[0], "i32")
+        e, pe = m.inp(inputs[1], "i32")
+        c, pc = m.inp(inputs[2], "u8")
+        ob, pob = m.alloc(len(b), "i32")
+        oe, poe = m.alloc(len(b), "i32")
+        oc, poc = m.alloc(len(c), "u8")  # byte_fallback.cpp:24
+        s = L.Strings(pb, pe, pc, len(b), len(c))
+        out = L.StringsOut(pob, poe, poc, len(c), 0)
+        self._chk(self._lib.ovtk_byte_fallback(C.byref(s), C.byref(out), m.mem, self.device, m.stream))
+        return [ob[:len(b)], oe[:len(b)], oc[:out.n_chars]]
+
+
+class FuzeRagged(_Op):
+    """Reference: src/fuze.cpp (evaluate :20-40).  ragged_begins, ragged_ends, begins, ends -> begins, ends."""
+
+    def evaluate(self, inputs):
+        m = _Mem(inputs[2])
+        rb, prb = m.inp(inputs[0], "i32")
+        re_, pre = m.inp(inputs[1], "i32")
+        b, pb = m.inp(inputs[2], "i32")
+        e, pe = m.inp(inputs[3], "i32")
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        self._chk(self._lib.ovtk_fuze_ragged(prb, pre, C.c_int64(len(rb)), pb, pe, C.c_int64(len(b)), pob, poe, m.mem,
+                                             self.device, m.stream))
+        return [ob[:len(rb)], oe[:len(rb)]]
+
+
+class FusedDetokenizer:
+    """VocabDecoder -> [ByteFallback] -> FuzeRagged in one pass (ovtk_detokenize_run): the same begins/ends/chars as
+    chaining the three ops (tokenizer_pipeline.py:1321-1371) without the per-token offsets going through HBM."""
+
+    def __init__(self, decoder: VocabDecoder, byte_fallback=False):
+        self.decoder, self.byte_fallback = decoder, bool(byte_fallback)
+
+    def evaluate(self, inputs, chars_capacity=None):
+        d = self.decoder
+        m, pids, B, S, pskip, nskip, cap = d._prep(inputs, chars_capacity)
+        ob, pob = m.alloc(B, "i32")
+        oe, poe = m.alloc(B, "i32")
+        oc, poc = m.alloc(cap, "u8")
+        out = L.StringsOut(pob, poe, poc, cap, 0)
+        d._chk(d._lib.ovtk_detokenize_run(d._h, pids, C.c_int64(B), C.c_int64(S), pskip, C.c_int64(nskip),
+                                          int(self.byte_fallback), C.byref(out), m.mem, m.stream))
+        return [ob[:B], oe[:B], oc[:out.n_chars]]

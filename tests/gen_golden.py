@@ -81,5 +81,27 @@ def main():
         print(name, len(strings), "strings", int(tl.sum()), "ids")
 
 
+def main_wordpiece():
+    """WordPiece (bert_small): HF BertPreTokenizer + WordPiece, no normalizer -- lower-cased ASCII/Latin text only
+    (HF handles CJK in its normalizer, the reference in the split pattern; both agree on everything else)."""
+    strings = [s.lower() for s in STRINGS if all(ord(ch) < 0x2E80 for ch in s) and "\x06" not in s]
+    strings += [s.lower() for s in synthetic("zipf", 64, 160, 21)] + ["unaffable", "x" * 120, "a" * 100 + " b", "don't stop-me now!!!"]
+    name = "bert_small"
+    tok = Tokenizer.from_file(str(G / f"tok_{name}.hf.json"))
+    enc = [tok.encode(s, add_special_tokens=False).ids for s in strings]
+    raw = [s.encode("utf-8") for s in strings]
+    lens = np.array([len(r) for r in raw], np.int64)
+    ends = np.cumsum(lens).astype(np.int32)
+    tl = np.array([len(x) for x in enc], np.int64)
+    tends = np.cumsum(tl).astype(np.int32)
+    np.savez_compressed(G / f"golden_wordpiece_{name}.npz", begins=(ends - lens).astype(np.int32), ends=ends,
+                        chars=np.frombuffer(b"".join(raw), np.uint8), id_begins=(tends - tl).astype(np.int32),
+                        id_ends=tends, ids=np.concatenate([np.asarray(x, np.int32) for x in enc if len(x)]),
+                        meta=np.frombuffer(json.dumps(dict(source="tokenizers " + __import__("tokenizers").__version__,
+                                                           tokenizer=f"tok_{name}.hf.json")).encode(), np.uint8))
+    print(name, len(strings), "strings", int(tl.sum()), "ids")
+
+
 if __name__ == "__main__":
     main()
+    main_wordpiece()
