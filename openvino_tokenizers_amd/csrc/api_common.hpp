@@ -99,9 +99,27 @@ inline int in_source(DevBuf& stage, const T* user, size_t bytes, int mem, hipStr
     return OVTK_OK;
 }
 
+// Device-wide exclusive scan (scan_kernels.hpp): three launches on `s`.
+template <class LenF, class ApplyF, class Fin>
+inline void launch_scan(std::vector<Profiler::Mark>& marks, const char* tag, hipStream_t s, long long n, LenF len,
+                        ApplyF apply, Fin fin, long long* tiles, const RunStatus* st, uint32_t skip_flags) {
+    const int n_tiles = int((n + kTileElems - 1) / kTileElems);
+    if (n_tiles > 0) OVTK_LAUNCH(marks, tag, tile_reduce_kernel<LenF>, n_tiles, kTileThreads, s, n, len, tiles);
+    OVTK_LAUNCH(marks, tag, tile_scan_kernel<Fin>, 1, kScanThreads, s, n_tiles, tiles, fin);
+    if (n_tiles > 0)
+        OVTK_LAUNCH(marks, tag, (tile_apply_kernel<LenF, ApplyF>), n_tiles, kTileThreads, s, n, len,
+                    (const long long*)tiles, apply, st, skip_flags);
+}
+inline size_t scan_tiles_bytes(long long n) { return size_t((n + kTileElems - 1) / kTileElems + 1) * sizeof(long long); }
+
+// Persistent grids: enough blocks to fill the chip at the kernel's occupancy, rows / list entries are strided.
+inline int grid_lookup(int device, int n_rows) {
+    return std::max(1, std::min((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, device_cu_count(device) * 6));
+}
+
 // The "ragged strings in -> ragged i32 out" pipeline shared by BPETokenizer, the fused encode and
-// WordpieceTokenizer: prepare_rows (staging offsets) -> middle(ws, d_in, w) (the op's kernels: ids into
-// staging, per-row counts) -> finalize_rows (final offsets) -> compact.  Workspace overflows reported
+// WordpieceTokenizer: scan of row capacities (staging offsets) -> middle(ws, d_in, w) (the op's kernels: ids into
+// staging, per-row counts) -> scan of row counts (final offsets) -> compact.  Workspace overflows reported
 // by the kernels are handled by growing the buffer and running again.
 template <class Middle>
 int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
@@ -113,7 +131,9 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
 
     const int n_rows = d_in.n_rows;
     int64_t stage_cap = std::min<int64_t>((in->strings.n_chars + in->strings.n) * mul, INT32_MAX - 1);
-    int64_t deferred_cap = std::max<int64_t>(4096, in->strings.n / 8);
+    int64_t shard_cap = std::max<int64_t>({4096, (in->strings.n_chars / 16 + in->strings.n / 4) / kShards,
+                                           int64_t(ws->deferred.size() / sizeof(DeferredPiece) / kShards)});
+    int64_t exact_cap = std::max<int64_t>(4096, int64_t(ws->exact.size() / sizeof(ExactPiece)));
     int64_t scratch_cap = std::max<int64_t>(ws->scratch.size(), int64_t(16) << 20);
 
     int32_t *d_begins = nullptr, *d_ends = nullptr, *d_ids = nullptr;
@@ -121,36 +141,42 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
     if (int rc = out_target(ws->out_b, out->ends, size_t(n_rows) * 4, mem, &d_ends)) return rc;
     if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_ids)) return rc;
 
-    for (int attempt = 0; attempt < 5; ++attempt) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
         int e = 0;
         e = e ? e : ws->row_stage.ensure(size_t(n_rows + 1) * 4);
         e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
         e = e ? e : ws->row_out.ensure(size_t(n_rows + 1) * 4);
-        e = e ? e : ws->row_slotted.ensure(size_t(n_rows));
+        e = e ? e : ws->row_used.ensure(size_t(n_rows) * 4);
         e = e ? e : ws->stage.ensure(size_t(stage_cap) * 4);
-        e = e ? e : ws->deferred.ensure(size_t(deferred_cap) * sizeof(DeferredPiece));
+        e = e ? e : ws->deferred.ensure(size_t(shard_cap) * kShards * sizeof(DeferredPiece));
+        e = e ? e : ws->exact.ensure(size_t(exact_cap) * sizeof(ExactPiece));
         e = e ? e : ws->scratch.ensure(size_t(scratch_cap));
+        e = e ? e : ws->tiles.ensure(scan_tiles_bytes(n_rows));
         e = e ? e : ws->status.ensure(sizeof(RunStatus));
         if (e) return e;
         EncodeWork w{};
         w.row_stage = ws->row_stage.as<int32_t>();
         w.row_cnt = ws->row_cnt.as<int32_t>();
         w.row_out = ws->row_out.as<int32_t>();
-        w.row_slotted = ws->row_slotted.as<uint8_t>();
+        w.row_used = ws->row_used.as<int32_t>();
         w.stage = ws->stage.as<int32_t>();
         w.stage_cap = int32_t(stage_cap);
         w.deferred = ws->deferred.as<DeferredPiece>();
-        w.deferred_cap = int32_t(deferred_cap);
+        w.shard_cap = int32_t(std::min<int64_t>(shard_cap, INT32_MAX / kShards));
+        w.exact = ws->exact.as<ExactPiece>();
+        w.exact_cap = int32_t(exact_cap);
         w.scratch = ws->scratch.as<uint8_t>();
         w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap, 0xFFFFFFF0ll));
+        w.tiles = ws->tiles.as<long long>();
         w.status = ws->status.as<RunStatus>();
 
         OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-        OVTK_LAUNCH(ws->marks, "prepare_rows", prepare_rows_kernel, 1, kScanThreads, s, d_in, mul, w);
+        launch_scan(ws->marks, "scan_rows", s, n_rows, RowCapLen{d_in, mul, w.status}, RowCapApply{w.row_stage},
+                    RowCapFin{w, n_rows}, w.tiles, w.status, kFlagRange);
         middle(*ws.ws, d_in, w);
-        OVTK_LAUNCH(ws->marks, "finalize_rows", finalize_rows_kernel, 1, kScanThreads, s, n_rows, w, d_begins, d_ends,
-                    (long long)out->data_capacity);
-        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_for_rows(n_rows), kBlockThreads, s, n_rows, w, d_ids);
+        launch_scan(ws->marks, "scan_rows", s, n_rows, RowCntLen{w.row_cnt}, RowOutApply{w.row_out, d_begins, d_ends},
+                    RowOutFin{w, n_rows, (long long)out->data_capacity}, w.tiles, w.status, kFatalFlags);
+        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_lookup(device, n_rows), kBlockThreads, s, n_rows, w, d_ids);
         if (int rc = finish_status(*ws.ws, s)) return rc;
 
         const RunStatus& st = *ws->host_status;
@@ -162,7 +188,13 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
             continue;
         }
         if (st.flags & kFlagDeferOverflow) {
-            deferred_cap = int64_t(st.n_deferred) + 64;
+            int64_t most = 0;
+            for (int k = 0; k < kShards; ++k) most = std::max<int64_t>(most, st.shard_count[k * kCounterStride]);
+            shard_cap = most + most / 8 + 256;
+            continue;
+        }
+        if (st.flags & kFlagExactOverflow) {
+            exact_cap = int64_t(st.n_exact) + 256;
             continue;
         }
         if (st.flags & kFlagScratchOverflow) {

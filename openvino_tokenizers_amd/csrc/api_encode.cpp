@@ -54,8 +54,42 @@ struct ovtk_regex_split {
 struct ovtk_bpe {
     int device = 0;
     BpeDev dev{};
-    DevBuf root, node, edges, merges, new_id, bf;
+    DevBuf root, node, edges, merges, new_id, bf, pieces;
+    size_t memo_entries = 0;
 };
+
+namespace {
+int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+               ovtk_ragged_i32_out* out, int mem, void* stream);
+
+// The piece memo (tables.hpp PieceEntry): BPE(t) for every vocabulary token t used as a whole piece, computed by the
+// device BPE itself -- the handle (still without memo) encodes its own vocabulary, one token per row.  This is the
+// parallel-machine form of the reference's piece cache (bpe_tokenizer.cpp:197-205,331-338): same pure function
+// piece -> ids, filled from the model constants instead of from previous inputs, so results never depend on history.
+int build_memo(ovtk_bpe* h, const ovtk_strings& vocab) {
+    const int64_t V = vocab.n;
+    if (V == 0) return OVTK_OK;
+    const size_t nv = size_t(V);
+    std::vector<int32_t> rb(nv), re(nv), ob(nv), oe(nv);
+    for (int64_t i = 0; i < V; ++i) {
+        rb[size_t(i)] = int32_t(i);
+        re[size_t(i)] = int32_t(i + 1);
+    }
+    const int64_t cap = (vocab.n_chars + V) * (1 + h->dev.suffix_len);
+    if (cap >= INT32_MAX) return OVTK_OK;  // absurdly large vocabulary text: run without memo
+    std::vector<int32_t> ids(static_cast<size_t>(cap) + 1);
+    ovtk_ragged_strings in{rb.data(), re.data(), V, vocab};
+    ovtk_ragged_i32_out out{ob.data(), oe.data(), ids.data(), cap, 0, 0};
+    if (int rc = run_encode(nullptr, h, &in, nullptr, &out, OVTK_MEM_HOST, nullptr)) return rc;
+    PieceTableHost host;
+    build_piece_table(view_of(vocab), ob.data(), oe.data(), ids.data(), host);
+    if (int rc = h->pieces.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
+    OVTK_HIP(hipStreamSynchronize(nullptr));
+    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.mask, host.shift};
+    h->memo_entries = host.stored;
+    return OVTK_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -138,7 +172,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     e = e ? e : h->root.upload(host.trie.root.data(), host.trie.root.size() * sizeof(I2));
     e = e ? e : h->node.upload(host.trie.node.data(), host.trie.node.size() * sizeof(I2));
     e = e ? e : h->edges.upload(host.trie.edges.data(), host.trie.edges.size() * sizeof(uint64_t));
-    e = e ? e : h->merges.upload(host.merges.data(), host.merges.size() * sizeof(uint64_t));
+    e = e ? e : h->merges.upload(host.merges.data(), host.merges.size() * sizeof(MergeSlot));
     e = e ? e : h->new_id.upload(host.new_id.data(), host.new_id.size() * sizeof(int32_t));
     e = e ? e : h->bf.upload(host.byte_fallback_id.data(), host.byte_fallback_id.size() * sizeof(int32_t));
     if (e) return e;
@@ -149,15 +183,20 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     d.trie.edges = h->edges.as<uint64_t>();
     d.trie.edge_mask = host.trie.edge_mask;
     d.trie.edge_shift = host.trie.edge_shift;
-    d.merges = h->merges.as<uint64_t>();
-    d.bucket_mask = host.bucket_mask;
-    d.bucket_shift = host.bucket_shift;
+    d.merges = h->merges.as<MergeSlot>();
+    d.slot_mask = host.slot_mask;
+    d.slot_shift = host.slot_shift;
+    d.pieces = PieceTableDev{nullptr, 0, 64};
     d.new_id = h->new_id.as<int32_t>();
     d.byte_fallback_id = h->bf.as<int32_t>();
     d.unk_id = host.unk_id;
     d.suffix_len = int32_t(host.suffix.size());
     std::memset(d.suffix, 0, sizeof d.suffix);
     std::memcpy(d.suffix, host.suffix.data(), host.suffix.size());
+    // cache_capacity == 0 disables the reference's piece cache (bpe_tokenizer.cpp:331: size() < capacity); here it
+    // disables the memo the same way.  Results are identical either way.
+    if (p->cache_capacity != 0)
+        if (int rc = build_memo(h.get(), p->vocab)) return rc;
     *out = h.release();
     return OVTK_OK;
 }
@@ -198,14 +237,17 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
     if (in->n_rows == 0) return OVTK_OK;
 
     const int n_rows = int(in->n_rows);
-    return run_rows_to_ids(bpe->device, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
+    const int dev = bpe->device;
+    return run_rows_to_ids(dev, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
                            [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w) {
                                if (split)
-                                   OVTK_LAUNCH(ws.marks, "encode_fused", encode_kernel<kFused>, grid_for_rows(n_rows),
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid_lookup(dev, n_rows),
                                                kBlockThreads, s, d_in, split->dev, bpe->dev, w);
                                else
-                                   OVTK_LAUNCH(ws.marks, "encode_pieces", encode_kernel<kPieces>, grid_for_rows(n_rows),
+                                   OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid_lookup(dev, n_rows),
                                                kBlockThreads, s, d_in, SplitDev{}, bpe->dev, w);
+                               OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(device_cu_count(dev) * 3 / kShards + 1, kShards),
+                                           kBlockThreads, s, d_in, bpe->dev, w);
                                OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
                            });
 }
@@ -221,6 +263,8 @@ int ovtk_bpe_run(ovtk_bpe* h, const ovtk_ragged_strings* in, ovtk_ragged_i32_out
 int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                     ovtk_ragged_i32_out* out, int mem, void* stream) {
     if (!split) return set_error(OVTK_E_ARG, "null split handle");
+    if (split->max_splits != -1)
+        return set_error(OVTK_E_UNSUPPORTED, "fused encode: max_splits is only supported by the RegexSplit op itself");
     return run_encode(split, bpe, in, skips, out, mem, stream);
 }
 
@@ -256,37 +300,35 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     e = e ? e : ws->row_stage.ensure(size_t(n_rows + 1) * 4);
     e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
     e = e ? e : ws->row_out.ensure(size_t(n_rows + 1) * 4);
+    e = e ? e : ws->tiles.ensure(scan_tiles_bytes(n_rows));
     e = e ? e : ws->status.ensure(sizeof(RunStatus));
     if (e) return e;
-    int32_t *d_rb = out->ragged_begins, *d_re = out->ragged_ends, *d_b = out->begins, *d_e = out->ends;
-    uint8_t* d_sk = out->skips;
-    if (mem == OVTK_MEM_HOST) {
-        e = e ? e : ws->out_a.ensure(size_t(n_rows) * 4);
-        e = e ? e : ws->out_b.ensure(size_t(n_rows) * 4);
-        e = e ? e : ws->out_c.ensure(size_t(out->capacity) * 4);
-        e = e ? e : ws->out_d.ensure(size_t(out->capacity) * 4);
-        e = e ? e : ws->out_e.ensure(size_t(out->capacity));
-        if (e) return e;
-        d_rb = ws->out_a.as<int32_t>();
-        d_re = ws->out_b.as<int32_t>();
-        d_b = ws->out_c.as<int32_t>();
-        d_e = ws->out_d.as<int32_t>();
-        d_sk = out->skips ? ws->out_e.as<uint8_t>() : nullptr;
-    }
+    int32_t *d_rb = nullptr, *d_re = nullptr, *d_b = nullptr, *d_e = nullptr;
+    uint8_t* d_sk = nullptr;
+    e = e ? e : out_target(ws->out_a, out->ragged_begins, size_t(n_rows) * 4, mem, &d_rb);
+    e = e ? e : out_target(ws->out_b, out->ragged_ends, size_t(n_rows) * 4, mem, &d_re);
+    e = e ? e : out_target(ws->out_c, out->begins, size_t(out->capacity) * 4, mem, &d_b);
+    e = e ? e : out_target(ws->out_d, out->ends, size_t(out->capacity) * 4, mem, &d_e);
+    if (out->skips) e = e ? e : out_target(ws->out_e, out->skips, size_t(out->capacity), mem, &d_sk);
+    if (e) return e;
     EncodeWork w{};
     w.row_stage = ws->row_stage.as<int32_t>();
     w.row_cnt = ws->row_cnt.as<int32_t>();
     w.row_out = ws->row_out.as<int32_t>();
     w.stage_cap = INT32_MAX;
+    w.tiles = ws->tiles.as<long long>();
     w.status = ws->status.as<RunStatus>();
     OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-    OVTK_LAUNCH(ws->marks, "prepare_rows", prepare_rows_kernel, 1, kScanThreads, s, d_in, 1, w);
-    OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid_for_rows(n_rows), kBlockThreads, s, d_in, h->dev,
-                h->max_splits, w, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
-    OVTK_LAUNCH(ws->marks, "finalize_rows", finalize_rows_kernel, 1, kScanThreads, s, n_rows, w, d_rb, d_re,
-                (long long)out->capacity);
-    OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid_for_rows(n_rows), kBlockThreads, s, d_in, h->dev,
-                h->max_splits, w, d_b, d_e, d_sk);
+    // range validation of the inputs (the capacity offsets themselves are not needed here)
+    launch_scan(ws->marks, "scan_rows", s, n_rows, RowCapLen{d_in, 1, w.status}, RowCapApply{w.row_stage},
+                RowCapFin{w, n_rows}, w.tiles, w.status, kFlagRange);
+    const int grid = grid_lookup(h->device, n_rows);
+    OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
+                (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
+    launch_scan(ws->marks, "scan_rows", s, n_rows, RowCntLen{w.row_cnt}, RowOutApply{w.row_out, d_rb, d_re},
+                RowOutFin{w, n_rows, (long long)out->capacity}, w.tiles, w.status, kFlagRange);
+    OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_b,
+                d_e, d_sk);
     if (int rc = finish_status(*ws.ws, s)) return rc;
     const RunStatus& st = *ws->host_status;
     if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");

@@ -52,19 +52,14 @@ int begin_status(Workspace& ws, hipStream_t s, RunStatus** st) {
     return OVTK_OK;
 }
 
-// Exclusive scan of len(i), i < n, then apply(i, offset, len): three launches.
+// Exclusive scan of len(i), i < n, then apply(i, offset, len).
 template <class LenF, class ApplyF>
 int scan_and_apply(Workspace& ws, hipStream_t s, long long n, LenF len, ApplyF apply, long long cap, RunStatus* st,
                    const char* tag) {
-    const long long n_tiles = (n + kTileElems - 1) / kTileElems;
-    if (n_tiles > INT32_MAX) return set_error(OVTK_E_UNSUPPORTED, "too many elements for one call; split it");
-    if (int rc = ws.gen[7].ensure(size_t(std::max<long long>(n_tiles, 1)) * sizeof(long long))) return rc;
-    long long* tiles = ws.gen[7].as<long long>();
-    if (n_tiles > 0) OVTK_LAUNCH(ws.marks, tag, tile_reduce_kernel<LenF>, int(n_tiles), kTileThreads, s, n, len, tiles);
-    OVTK_LAUNCH(ws.marks, "tile_scan", tile_scan_kernel, 1, kScanThreads, s, int(n_tiles), tiles, cap, st);
-    if (n_tiles > 0)
-        OVTK_LAUNCH(ws.marks, tag, (tile_apply_kernel<LenF, ApplyF>), int(n_tiles), kTileThreads, s, n, len,
-                    (const long long*)tiles, apply, (const RunStatus*)st);
+    if ((n + kTileElems - 1) / kTileElems > INT32_MAX) return set_error(OVTK_E_UNSUPPORTED, "too many elements for one call; split it");
+    if (int rc = ws.tiles.ensure(scan_tiles_bytes(n))) return rc;
+    launch_scan(ws.marks, tag, s, n, len, apply, CharsFin{st, cap}, ws.tiles.as<long long>(), st,
+                kFlagOutCapacity | kFlagRange);
     return OVTK_OK;
 }
 

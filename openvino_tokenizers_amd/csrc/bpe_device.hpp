@@ -5,8 +5,9 @@
 // n-1+j).  Because stale entries are skipped, "pop" always yields the LIVE adjacent pair with the
 // smallest (rank, seq) -- so as long as that minimum is unique the queue can be replaced by a
 // min-scan over the live pairs, which is what the two fast paths do:
-//   path F  one lane per piece (<= kFastSyms symbols): symbols + pair keys of all 64 pieces of a
-//           batch live in the wave's LDS arrays, each lane scans / compacts its own stretch;
+//   path F  one lane per piece (<= kFastSyms symbols): symbols + pair keys of the 64 pieces of a
+//           batch live in the wave's LDS arrays in [symbol][lane] order (bank = lane: conflict-free
+//           when the lanes are at the same symbol index), each lane scans / compacts its own column;
 //   path W  one wave per piece (up to kChunk symbols): lanes scan the piece's pairs in parallel,
 //           wave-min picks the merge, lanes shift the tail cooperatively.
 // A non-unique minimum can only be the two pairs pushed by one merge with equal rank;
@@ -14,8 +15,10 @@
 // for LDS) is replayed by path X: bpe_exact_piece(), a step-for-step emulation of
 // std::push_heap / std::pop_heap on the same (rank, new_id, a, b, seq) entries, stale ones included.
 //
-// Pair key in LDS: (rank << 10) | seq, 0xFFFFFFFF = "not a merge".  rank < 2^22, seq < 1024 because
-// a piece handled in LDS has at most kChunk = 512 symbols and seq < 2n.
+// Pair key in LDS (u64): rank:22 | seq:10 | new_id:21, all ones = "not a merge".  One 16-byte probe of the
+// merge table yields rank and merged id together, so a merge step has ONE dependent global
+// round trip (the two probes for the new neighbour pairs, issued together).  seq < 1024 because a
+// piece handled in LDS has at most kChunk = 512 symbols and seq < 2n.
 #pragma once
 
 #include "device_common.hpp"
@@ -23,24 +26,43 @@
 
 namespace ovtk {
 
-constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr uint64_t kNoKey = ~0ull;
 constexpr int kSeqBits = 10;
-constexpr int kFastSyms = 24;  // pieces with more symbols than this use path W
+constexpr int kIdBits = kMaxVocabBits;                   // 21
+constexpr int kFastSyms = 16;                            // pieces with more symbols than this use path W
+constexpr int kChunkSyms = 512;                          // path W limit (symbols incl. end_suffix)
+constexpr uint32_t kIdMask = (1u << kIdBits) - 1;
 
-__device__ __forceinline__ uint32_t merge_rank(const BpeDev& T, uint32_t l, uint32_t r) {
-    const uint64_t key = merge_key(l, r);
-    uint32_t b = uint32_t(hash_u64(key) >> T.bucket_shift) & T.bucket_mask;
+__device__ __forceinline__ uint32_t merge_slot_of(const BpeDev& T, uint64_t key) {
+    return uint32_t(hash_u64(key) >> T.slot_shift) & T.slot_mask;
+}
+__device__ __forceinline__ uint64_t make_pair_key(const MergeSlot& s, uint32_t seq) {
+    return ((s.kr & kNoRank) << (kSeqBits + kIdBits)) | (uint64_t(seq) << kIdBits) | (s.nid & kIdMask);
+}
+// Continues a probe sequence from slot p whose content s did not match and was not empty.
+__device__ __forceinline__ uint64_t merge_probe_rest(const BpeDev& T, uint64_t key, uint32_t p, uint32_t seq) {
     for (;;) {
-        const ulonglong2 s = reinterpret_cast<const ulonglong2*>(T.merges)[b];
-        if ((s.x >> kMaxRankBits) == key) return uint32_t(s.x) & kNoRank;
-        if ((s.y >> kMaxRankBits) == key) return uint32_t(s.y) & kNoRank;
-        if (s.y == kEmptySlot) return kNoRank;
-        b = (b + 1) & T.bucket_mask;
+        p = (p + 1) & T.slot_mask;
+        const MergeSlot s = T.merges[p];
+        if (s.kr == kEmptySlot) return kNoKey;
+        if ((s.kr >> kMaxRankBits) == key) return make_pair_key(s, seq);
     }
 }
-__device__ __forceinline__ uint32_t pair_key(const BpeDev& T, uint32_t l, uint32_t r, uint32_t seq) {
-    const uint32_t rank = merge_rank(T, l, r);
-    return rank == kNoRank ? kNoKey : ((rank << kSeqBits) | seq);
+__device__ __forceinline__ uint64_t merge_probe_finish(const BpeDev& T, uint64_t key, uint32_t p, const MergeSlot& s,
+                                                       uint32_t seq) {
+    if (s.kr == kEmptySlot) return kNoKey;
+    if ((s.kr >> kMaxRankBits) == key) return make_pair_key(s, seq);
+    return merge_probe_rest(T, key, p, seq);
+}
+__device__ __forceinline__ uint64_t pair_key(const BpeDev& T, uint32_t l, uint32_t r, uint32_t seq) {
+    const uint64_t key = merge_key(l, r);
+    const uint32_t p = merge_slot_of(T, key);
+    return merge_probe_finish(T, key, p, T.merges[p], seq);
+}
+// Rank only (path X).
+__device__ __forceinline__ uint32_t merge_rank(const BpeDev& T, uint32_t l, uint32_t r) {
+    const uint64_t k = pair_key(T, l, r, 0);
+    return k == kNoKey ? kNoRank : uint32_t(k >> (kSeqBits + kIdBits));
 }
 
 __device__ __forceinline__ int trie_child(const TrieDev& t, int node, uint32_t byte) {
@@ -95,64 +117,90 @@ __device__ __forceinline__ int bpe_symbolize(const BpeDev& T, const I2* root, Ge
     return cnt;
 }
 
-// Path F.  id/key: this lane's private stretch of the wave's LDS arrays, n symbols.
-// Returns the final symbol count, or -1 when the minimum was not unique (replay on path X).
-__device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uint32_t* key, int n) {
-    for (int k = 0; k + 1 < n; ++k) key[k] = pair_key(T, id[k], id[k + 1], uint32_t(k));
+// Path F.  id / key: the wave's [kFastSyms][64] LDS arrays; this lane owns column lane_id().  n symbols are in
+// place.  Returns the final symbol count, or -1 when the minimum was not unique (replay on path X).
+__device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uint64_t* key, int n) {
+    const int l = lane_id();
+#define OVTK_AT(k) ((k) * kWave + l)
+    // initial pair keys: the probes of a group of 4 are issued together
+    for (int k0 = 0; k0 + 1 < n; k0 += 4) {
+        uint64_t mk[4];
+        uint32_t p[4];
+        MergeSlot s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + j;
+            const bool on = k + 1 < n;
+            mk[j] = on ? merge_key(id[OVTK_AT(k)], id[OVTK_AT(k + 1)]) : 0;
+            p[j] = merge_slot_of(T, mk[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = T.merges[p[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (k0 + j + 1 < n) key[OVTK_AT(k0 + j)] = merge_probe_finish(T, mk[j], p[j], s[j], uint32_t(k0 + j));
+    }
     uint32_t seq = n > 0 ? uint32_t(n - 1) : 0;
     while (n >= 2) {
-        uint32_t best = kNoKey;
+        uint64_t best = kNoKey;
         int at = 0;
         bool dup = false;
         for (int k = 0; k + 1 < n; ++k) {
-            const uint32_t v = key[k];
+            const uint64_t v = key[OVTK_AT(k)];
             if (v < best) { best = v; at = k; dup = false; }
             else if (v == best && v != kNoKey) dup = true;
         }
         if (best == kNoKey) break;
         if (dup) return -1;
-        const uint32_t nid = uint32_t(T.new_id[best >> kSeqBits]);
-        id[at] = nid;
+        const uint32_t nid = uint32_t(best) & kIdMask;
+        id[OVTK_AT(at)] = nid;
         for (int k = at + 1; k + 1 < n; ++k) {  // close the gap left by the right operand
-            id[k] = id[k + 1];
-            key[k] = key[k + 1];
+            id[OVTK_AT(k)] = id[OVTK_AT(k + 1)];
+            key[OVTK_AT(k)] = key[OVTK_AT(k + 1)];
         }
         --n;
         ++seq;
-        if (at > 0) key[at - 1] = pair_key(T, id[at - 1], nid, seq);
-        if (at + 1 < n) key[at] = pair_key(T, nid, id[at + 1], seq);
+        // the two new neighbour pairs: both probes in flight together
+        const bool has_l = at > 0, has_r = at + 1 < n;
+        const uint64_t kl = has_l ? merge_key(id[OVTK_AT(at - 1)], nid) : 0;
+        const uint64_t kr = has_r ? merge_key(nid, id[OVTK_AT(at + 1)]) : 0;
+        const uint32_t pl = merge_slot_of(T, kl), pr = merge_slot_of(T, kr);
+        const MergeSlot sl = T.merges[pl], sr = T.merges[pr];
+        if (has_l) key[OVTK_AT(at - 1)] = merge_probe_finish(T, kl, pl, sl, seq);
+        if (has_r) key[OVTK_AT(at)] = merge_probe_finish(T, kr, pr, sr, seq);
     }
+#undef OVTK_AT
     return n;
 }
 
-// Path W.  All 64 lanes work on ONE piece of n symbols at id/key (LDS).  Wave-uniform; returns the
+// Path W.  All 64 lanes work on ONE piece of n symbols at id/key (LDS, contiguous).  Wave-uniform; returns the
 // final count or -1 for a non-unique minimum.
-__device__ __forceinline__ int bpe_merge_wave(const BpeDev& T, uint32_t* id, uint32_t* key, int n) {
+__device__ __forceinline__ int bpe_merge_wave(const BpeDev& T, uint32_t* id, uint64_t* key, int n) {
     const int l = lane_id();
     for (int k = l; k + 1 < n; k += kWave) key[k] = pair_key(T, id[k], id[k + 1], uint32_t(k));
     wave_sync();
     uint32_t seq = n > 0 ? uint32_t(n - 1) : 0;
     while (n >= 2) {
-        // (key, position) minimum; a second pair with the same key shows up as a larger position.
-        unsigned long long mine = ~0ull;
-        int hits = 0;
-        uint32_t local_best = kNoKey;
+        // minimum key and its position; a second pair with the same key shows up in `hits`
+        uint64_t local_best = kNoKey;
+        int local_at = 0, hits = 0;
         for (int k = l; k + 1 < n; k += kWave) {
-            const uint32_t v = key[k];
-            if (v < local_best) { local_best = v; mine = (uint64_t(v) << 32) | uint32_t(k); hits = 1; }
+            const uint64_t v = key[k];
+            if (v < local_best) { local_best = v; local_at = k; hits = 1; }
             else if (v == local_best && v != kNoKey) ++hits;
         }
-        const unsigned long long best = wave_min_u64(mine);
-        const uint32_t bkey = uint32_t(best >> 32);
+        const uint64_t bkey = wave_min_u64(local_best);
         if (bkey == kNoKey) break;
         const int same = wave_sum(local_best == bkey ? hits : 0);
         if (same > 1) return -1;
-        const int at = int(uint32_t(best));
-        const uint32_t nid = uint32_t(T.new_id[bkey >> kSeqBits]);
+        const unsigned long long owner = __ballot(local_best == bkey);
+        const int at = __shfl(local_at, __ffsll(owner) - 1);
+        const uint32_t nid = uint32_t(bkey) & kIdMask;
         // cooperative shift-left of (at+1, n)
         for (int base = at + 1; base + 1 < n; base += kWave) {
             const int k = base + l;
-            uint32_t a = 0, b = 0;
+            uint32_t a = 0;
+            uint64_t b = 0;
             if (k + 1 < n) { a = id[k + 1]; b = key[k + 1]; }
             wave_sync();
             if (k + 1 < n) { id[k] = a; key[k] = b; }
@@ -163,6 +211,7 @@ __device__ __forceinline__ int bpe_merge_wave(const BpeDev& T, uint32_t* id, uin
         if (l == 0) {
             id[at] = nid;
             if (at > 0) key[at - 1] = pair_key(T, id[at - 1], nid, seq);
+        } else if (l == 1) {
             if (at + 1 < n) key[at] = pair_key(T, nid, id[at + 1], seq);
         }
         wave_sync();

@@ -16,15 +16,20 @@ constexpr int kWavesPerBlock = kBlockThreads / kWave;
 // Marker for an unused entry of the staging id buffer ("slotted" rows, see encode kernel).
 constexpr int32_t kEmptyId = INT32_MIN;
 
-// Status block of one run, written by the kernels, read by the host after the final sync.
+// Status block of one run, written by the kernels, read by the host after the final sync.  The
+// deferred-piece list is sharded (one region + one counter per shard, each counter on its own 128-byte
+// line: a single device-scope counter saturates at ~90 atomics/us on gfx950).
+constexpr int kShards = 16;
+constexpr int kCounterStride = 32;  // int32 slots between shard counters
 struct RunStatus {
     int32_t n_items;       // (row, string) work items in output order
     int32_t stage_need;    // staging-buffer entries the batch needs
     int32_t n_out;         // final number of output elements (token ids / pieces / chars)
-    int32_t n_deferred;    // pieces handed to the exact-heap kernel
+    int32_t n_exact;       // pieces handed to the exact-heap kernel
     uint32_t scratch_used; // bytes taken from the exact kernel's scratch pool
     uint32_t flags;        // kFlag*
-    int32_t pad[2];
+    int32_t pad[26];
+    int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
 };
 constexpr uint32_t kFlagItemsOverflow = 1u;     // more work items than the workspace holds
 constexpr uint32_t kFlagStageOverflow = 2u;     // staging buffer too small
@@ -32,6 +37,7 @@ constexpr uint32_t kFlagDeferOverflow = 4u;     // deferred-piece list too small
 constexpr uint32_t kFlagScratchOverflow = 8u;   // exact kernel scratch pool too small
 constexpr uint32_t kFlagOutCapacity = 16u;      // caller's output buffer too small
 constexpr uint32_t kFlagRange = 32u;            // an input offset left its buffer
+constexpr uint32_t kFlagExactOverflow = 64u;    // exact-path piece list too small
 
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x) & (kWave - 1); }
 __device__ __forceinline__ int wave_in_block() { return int(threadIdx.x) >> 6; }

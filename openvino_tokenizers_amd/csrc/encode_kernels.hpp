@@ -1,22 +1,24 @@
 // encode_kernels.hpp -- the gfx950 kernels of RegexSplit, BPETokenizer and their fusion.
 //
-// Work decomposition: ONE WAVEFRONT PER RAGGED ROW (= per input string in converted pipelines).
-//   encode_kernel<kFused>   row -> strings -> split scanner -> pieces -> BPE  (RegexSplit + BPETokenizer)
-//   encode_kernel<kPieces>  row -> pre-split pieces -> BPE                    (BPETokenizer op contract)
-// Pieces are processed 64 at a time, one lane per piece (path F), long pieces by the whole wave
-// (path W), ambiguous / oversized pieces are deferred to exact_kernel (path X) -- see bpe_device.hpp.
-//
-// Output placement.  The reference keeps one running `ragged_offset` across rows
-// (bpe_tokenizer.cpp:141-161); here every row first writes into a staging region whose offset
-// comes from an exclusive scan of per-row capacities, a second scan of the per-row token counts
-// gives the final offsets, and compact_kernel moves the ids.  A row is staged "compact" (ids
-// back to back) unless one of its pieces was deferred; from that piece on it is "slotted": each
-// piece owns the stretch [bytepos*mul, (bytepos+len)*mul) of the row's region (mul = 1 +
-// end_suffix length), unused entries hold kEmptyId and compact_kernel squeezes them out.
+// Pipeline of one BPETokenizer / fused encode call (host side: api_common.hpp run_rows_to_ids):
+//   scan(row capacity)          staging offset of every row                        (scan_kernels.hpp)
+//   lookup_kernel<kFused>       ONE WAVE PER ROW: split scanner -> pieces -> piece memo probe
+//   lookup_kernel<kPieces>      same for pre-split pieces (the BPETokenizer op contract)
+//       a piece found in the memo (tables.hpp PieceEntry: BPE(piece) precomputed for every vocabulary
+//       token) writes its ids straight into the row's staging region; any other piece reserves
+//       len + |end_suffix| staging entries and goes to the deferred list (per-wave LDS buffer, flushed 64 at a
+//       time into one of kShards list regions)
+//   merge_kernel                dense batches of 64 deferred pieces: path F (lane per piece), path W (wave
+//                               per piece), ties / oversized pieces -> exact list           (bpe_device.hpp)
+//   exact_kernel                path X, one lane per piece
+//   scan(row token counts)      final offsets = the reference's running `ragged_offset` (bpe_tokenizer.cpp:141-161)
+//   compact_kernel              staging -> caller's ids buffer (rows with deferred pieces have unused entries
+//                               = kEmptyId in their reserved stretches; they are squeezed out by ballot compaction)
 #pragma once
 
 #include "bpe_device.hpp"
 #include "device_common.hpp"
+#include "scan_kernels.hpp"
 #include "split_device.hpp"
 
 namespace ovtk {
@@ -33,300 +35,374 @@ struct RowsIn {
     const uint8_t* skips;  // bool per string, or nullptr
 };
 
-struct DeferredPiece { int32_t begin, len, stage_pos, row; };
+// A piece that missed the memo.  len <= kPieceKeyBytes: k0/k1 hold its bytes (the memo key); always: begin/len
+// locate it in `chars`.
+struct alignas(32) DeferredPiece {
+    uint64_t k0, k1;
+    int32_t stage_pos, row, begin, len;
+};
+struct ExactPiece { int32_t begin, len, stage_pos, row; };
+
+constexpr int kMissBuf = 128;  // per-wave LDS buffer of deferred pieces (flushed when >= 64 are pending)
 
 struct EncodeWork {
     int32_t* row_stage;     // [n_rows + 1] staging offset of each row (exclusive scan of capacities)
-    int32_t* row_cnt;       // [n_rows]     elements produced by each row
+    int32_t* row_cnt;       // [n_rows]     ids produced by each row
+    int32_t* row_used;      // [n_rows]     staging entries the row occupies (> row_cnt: it has unused entries)
     int32_t* row_out;       // [n_rows + 1] final offset of each row
-    uint8_t* row_slotted;   // [n_rows]
     int32_t* stage;
     int32_t stage_cap;
-    DeferredPiece* deferred;
-    int32_t deferred_cap;
+    DeferredPiece* deferred;  // kShards regions of shard_cap entries
+    int32_t shard_cap;
+    ExactPiece* exact;
+    int32_t exact_cap;
     uint8_t* scratch;
     uint32_t scratch_cap;
+    long long* tiles;       // scan temporaries
     RunStatus* status;
 };
 
-constexpr int kScanThreads = 1024;
-constexpr int kScanPerThread = 4;
+constexpr uint32_t kFatalFlags = kFlagRange | kFlagStageOverflow;
 
-// Exclusive scan of f(0..n) by ONE block of THREADS threads: put(i, prefix) for every i, returns the
-// total to every thread.  64-bit accumulation (callers clamp / flag).
-template <int THREADS, class F, class Put>
-__device__ __forceinline__ long long block_exclusive_scan(int n, F&& f, Put&& put) {
-    __shared__ long long wave_tot[THREADS / kWave];
-    __shared__ long long carry_s;
-    const int tid = int(threadIdx.x), l = lane_id(), wv = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int tile = 0; tile < n; tile += THREADS * kScanPerThread) {
-        const int i0 = tile + tid * kScanPerThread;
-        long long v[kScanPerThread], s = 0;
-#pragma unroll
-        for (int j = 0; j < kScanPerThread; ++j) {
-            v[j] = (i0 + j < n) ? (long long)f(i0 + j) : 0;
-            s += v[j];
+// ---- row capacity: mul * sum over the row's strings of max(len, 1), with range validation.
+struct RowCapLen {
+    RowsIn in;
+    int mul;
+    RunStatus* status;
+    __device__ long long operator()(long long row) const {
+        long long cap = 0;
+        const int b = in.ragged_begins[row], e = in.ragged_ends[row];
+        if (b < e && (b < 0 || e > in.n_strings)) {
+            atomicOr(&status->flags, kFlagRange);
+            return 0;
         }
-        long long incl = s;  // inclusive scan of s over the wave
-#pragma unroll
-        for (int d = 1; d < kWave; d <<= 1) {
-            long long t = __shfl_up(incl, d);
-            if (l >= d) incl += t;
-        }
-        if (l == kWave - 1) wave_tot[wv] = incl;
-        __syncthreads();
-        long long before = carry_s;
-        for (int k = 0; k < wv; ++k) before += wave_tot[k];
-        long long run = before + incl - s;
-#pragma unroll
-        for (int j = 0; j < kScanPerThread; ++j) {
-            if (i0 + j < n) put(i0 + j, run);
-            run += v[j];
-        }
-        __syncthreads();
-        if (tid == THREADS - 1) carry_s = run;  // last thread's running sum = total so far
-        __syncthreads();
-    }
-    return carry_s;
-}
-
-// ---- K1: per-row staging capacity -> offsets.  cap(row) = mul * sum over its strings of max(len, 1).
-static __global__ __launch_bounds__(kScanThreads) void prepare_rows_kernel(RowsIn in, int mul, EncodeWork w) {
-    __shared__ int bad_s;
-    if (threadIdx.x == 0) bad_s = 0;
-    __syncthreads();
-    const long long total = block_exclusive_scan<kScanThreads>(
-        in.n_rows,
-        [&](int row) -> long long {
-            long long cap = 0;
-            const int b = in.ragged_begins[row], e = in.ragged_ends[row];
-            if (b < e && (b < 0 || e > in.n_strings)) { bad_s = 1; return 0; }
-            for (int col = b; col < e; ++col) {
-                const long long sb = in.begins[col], se = in.ends[col];
-                if (sb < 0 || se < sb || se > in.n_chars) { bad_s = 1; return 0; }
-                cap += (se - sb > 0 ? se - sb : 1) * mul;
+        for (int col = b; col < e; ++col) {
+            const long long sb = in.begins[col], se = in.ends[col];
+            if (sb < 0 || se < sb || se > in.n_chars) {
+                atomicOr(&status->flags, kFlagRange);
+                return 0;
             }
-            return cap;
-        },
-        [&](int row, long long off) { w.row_stage[row] = off > INT32_MAX ? INT32_MAX : int32_t(off); });
-    if (threadIdx.x == 0) {
-        w.row_stage[in.n_rows] = total > INT32_MAX ? INT32_MAX : int32_t(total);
-        w.status->stage_need = total > INT32_MAX ? INT32_MAX : int32_t(total);
-        uint32_t fl = 0;
-        if (bad_s) fl |= kFlagRange;
-        if (total > (long long)w.stage_cap) fl |= kFlagStageOverflow;
-        if (fl) atomicOr(&w.status->flags, fl);
+            cap += (se - sb > 0 ? se - sb : 1) * mul;
+        }
+        return cap;
+    }
+};
+struct RowCapApply {
+    int32_t* row_stage;
+    __device__ void operator()(long long row, long long off, long long) const {
+        row_stage[row] = off > INT32_MAX ? INT32_MAX : int32_t(off);
+    }
+};
+struct RowCapFin {
+    EncodeWork w;
+    int32_t n_rows;
+    __device__ void operator()(long long total) const {
+        const int32_t t = total > INT32_MAX ? INT32_MAX : int32_t(total);
+        w.row_stage[n_rows] = t;
+        w.status->stage_need = t;
+        if (total > (long long)w.stage_cap) atomicOr(&w.status->flags, kFlagStageOverflow);
+    }
+};
+
+// ---- final offsets from the per-row counts.
+struct RowCntLen {
+    const int32_t* row_cnt;
+    __device__ long long operator()(long long row) const { return row_cnt[row]; }
+};
+struct RowOutApply {
+    int32_t* row_out;
+    int32_t* out_begins;  // may be nullptr
+    int32_t* out_ends;
+    __device__ void operator()(long long row, long long off, long long len) const {
+        row_out[row] = int32_t(off);
+        if (out_begins) out_begins[row] = int32_t(off);
+        if (out_ends) out_ends[row] = int32_t(off + len);
+    }
+};
+struct RowOutFin {
+    EncodeWork w;
+    int32_t n_rows;
+    long long out_cap;
+    __device__ void operator()(long long total) const {
+        w.row_out[n_rows] = total > INT32_MAX ? INT32_MAX : int32_t(total);
+        w.status->n_out = total > INT32_MAX ? INT32_MAX : int32_t(total);
+        if (total > out_cap) atomicOr(&w.status->flags, kFlagOutCapacity);
+    }
+};
+
+// ---- memo probe -------------------------------------------------------------------------------
+// Key of a piece of 1..15 bytes given its first 16 bytes (garbage beyond plen is masked off).
+__device__ __forceinline__ void piece_key(uint64_t raw0, uint64_t raw1, int plen, uint64_t& k0, uint64_t& k1) {
+    if (plen < 8) {
+        k0 = raw0 & ((1ull << (8 * plen)) - 1ull);
+        k1 = 0;
+    } else {
+        k0 = raw0;
+        k1 = raw1 & ((1ull << (8 * (plen - 8))) - 1ull);
+    }
+    k1 |= uint64_t(plen) << 56;
+}
+// 16 bytes at byte offset `off` of a dword array in LDS (aligned reads + funnel shift).
+__device__ __forceinline__ void lds_bytes16(const uint32_t* words, int off, uint64_t& r0, uint64_t& r1) {
+    const int a = off >> 2, sh = (off & 3) * 8;
+    const uint32_t w0 = words[a], w1 = words[a + 1], w2 = words[a + 2], w3 = words[a + 3], w4 = words[a + 4];
+    const uint32_t d0 = uint32_t(((uint64_t(w1) << 32) | w0) >> sh), d1 = uint32_t(((uint64_t(w2) << 32) | w1) >> sh);
+    const uint32_t d2 = uint32_t(((uint64_t(w3) << 32) | w2) >> sh), d3 = uint32_t(((uint64_t(w4) << 32) | w3) >> sh);
+    r0 = (uint64_t(d1) << 32) | d0;
+    r1 = (uint64_t(d3) << 32) | d2;
+}
+// The piece's bytes from global memory (pre-split pieces: any alignment, may end at the buffer's end).
+__device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint64_t& r0, uint64_t& r1) {
+    r0 = 0;
+    r1 = 0;
+    for (int i = 0; i < plen && i < 8; ++i) r0 |= uint64_t(p[i]) << (8 * i);
+    for (int i = 8; i < plen; ++i) r1 |= uint64_t(p[i]) << (8 * (i - 8));
+}
+// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.
+__device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
+    uint32_t p = uint32_t(hash_piece(k0, k1) >> P.shift) & P.mask;
+    for (;;) {
+        const PieceEntry e = P.slots[p];
+        if (e.k1 == 0) return -1;
+        if (e.k0 == k0 && e.k1 == k1) {
+#pragma unroll
+            for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e.tok[k];
+            return e.cnt;
+        }
+        p = (p + 1) & P.mask;
     }
 }
 
-// ---- shared by both encode modes -------------------------------------------------------------
+// ---- lookup kernel ------------------------------------------------------------------------------
 struct RowState {
     int base;      // staging offset of the row
-    int emitted;   // ids produced so far (deferred pieces excluded)
-    int bytepos;   // slot units consumed so far (sum of max(len,1) of the pieces seen)
-    bool slotted;
+    int used;      // staging entries handed out so far
+    int emitted;   // ids written so far (deferred pieces excluded)
     int row;
 };
 
-__device__ __forceinline__ void make_slotted(RowState& st, const EncodeWork& w, int first_bytepos, int mul) {
-    if (st.slotted) return;
-    for (int k = st.emitted + lane_id(); k < first_bytepos * mul; k += kWave) w.stage[st.base + k] = kEmptyId;
-    st.slotted = true;
-}
+struct WaveMiss {
+    DeferredPiece e[kMissBuf];
+};
 
-__device__ __forceinline__ void push_deferred(const EncodeWork& w, int abs_begin, int len, int stage_pos, int row) {
-    const int idx = atomicAdd(&w.status->n_deferred, 1);
-    if (idx < w.deferred_cap) w.deferred[idx] = DeferredPiece{abs_begin, len, stage_pos, row};
-    else atomicOr(&w.status->flags, kFlagDeferOverflow);
-}
-
-// A piece that never enters LDS (longer than the chunk): wave-uniform arguments.
-__device__ __forceinline__ void defer_whole_piece(RowState& st, const EncodeWork& w, int abs_begin, int len, int mul) {
-    make_slotted(st, w, st.bytepos, mul);
-    if (lane_id() == 0) push_deferred(w, abs_begin, len, st.base + st.bytepos * mul, st.row);
-    st.bytepos += len > 0 ? len : 1;
-}
-
-// One batch: lane l owns piece (toff, plen) of the LDS text (valid lanes form a prefix, their
-// symbol needs fit kChunk).  abs_begin: offset of the piece in `chars` (for deferral).
-__device__ __forceinline__ void process_batch(WaveScratch& ws, const BpeDev& T, const I2* root_lds, RowState& st,
-                                              const EncodeWork& w, bool valid, int toff, int plen, int abs_begin) {
+// Writes the first `n` (<= 64) buffered pieces to this block's shard of the deferred list, moves the rest up.
+__device__ __forceinline__ void flush_misses(WaveMiss& mb, int& n_miss, int n, const EncodeWork& w) {
     const int l = lane_id();
-    const int SL = T.suffix_len, mul = 1 + SL;
-    const uint8_t* t = text_bytes(ws);
-    const int need = valid ? plen + SL : 0;
-    const int incl_need = wave_incl_sum(need);
-    const int soff = incl_need - need;
-    const int units = valid ? (plen > 0 ? plen : 1) : 0;
-    const int incl_units = wave_incl_sum(units);
-    const int bpos = st.bytepos + incl_units - units;
-    uint32_t* id = ws.sym_id + soff;
-    uint32_t* key = ws.sym_key + soff;
-
-    int n = 0;
-    if (valid)
-        n = bpe_symbolize(T, root_lds,
-                          [&](int i) -> uint32_t { return i < plen ? t[toff + i] : T.suffix[i - plen]; }, need,
-                          [&](int k, int tok) { id[k] = uint32_t(tok); });
-    const bool is_w = valid && n > kFastSyms;
-    int res = n;
-    if (valid && !is_w) res = bpe_merge_lane(T, id, key, n);
-    unsigned long long wm = __ballot(is_w);
-    while (wm) {
-        const int src = __ffsll(wm) - 1;
-        wm &= wm - 1;
-        const int so = __shfl(soff, src), nn = __shfl(n, src);
-        wave_sync();
-        const int r = bpe_merge_wave(T, ws.sym_id + so, ws.sym_key + so, nn);
-        if (l == src) res = r;
+    const int shard = int(blockIdx.x) % kShards;
+    int idx = 0;
+    if (l == 0) idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
+    idx = __shfl(idx, 0);
+    if (l < n) {
+        if (idx + l < w.shard_cap) w.deferred[(long long)shard * w.shard_cap + idx + l] = mb.e[l];
+        else atomicOr(&w.status->flags, kFlagDeferOverflow);
     }
+    const int rest = n_miss - n;
+    DeferredPiece t{};
+    if (l < rest) t = mb.e[n + l];
     wave_sync();
-    const bool defer = valid && res < 0;
-    const int cnt = (valid && !defer) ? res : 0;
-
-    if (__ballot(defer)) make_slotted(st, w, st.bytepos, mul);
-    const int incl_cnt = wave_incl_sum(cnt);
-    if (!st.slotted) {
-        const int pos = st.base + st.emitted + incl_cnt - cnt;
-        for (int k = 0; k < cnt; ++k) w.stage[pos + k] = int32_t(id[k]);
-    } else if (valid) {
-        const int slot = st.base + bpos * mul;
-        if (defer) {
-            push_deferred(w, abs_begin, plen, slot, st.row);
-        } else {
-            const int slot_len = (plen > 0 ? plen : 1) * mul;
-            for (int k = 0; k < cnt; ++k) w.stage[slot + k] = int32_t(id[k]);
-            for (int k = cnt; k < slot_len; ++k) w.stage[slot + k] = kEmptyId;
-        }
-    }
-    st.emitted += __shfl(incl_cnt, kWave - 1);
-    st.bytepos += __shfl(incl_units, kWave - 1);
+    if (l < rest) mb.e[l] = t;
+    wave_sync();
+    n_miss = rest;
 }
 
-// Number of leading lanes whose symbol needs fit the LDS arrays together (>= 1 when lane 0 is valid
-// and fits; 0 when lane 0 alone does not fit -> caller defers that piece).
-__device__ __forceinline__ int lanes_that_fit(bool valid, int need) {
-    const int incl = wave_incl_sum(valid ? need : 0);
-    const unsigned long long ok = __ballot(valid && incl <= kChunk);
-    // valid lanes are a prefix and incl is monotone, so `ok` is a prefix mask
-    return __popcll(ok);
+// One batch: lane l holds piece (raw bytes r0/r1 if plen <= 15, plen, abs_begin) when `valid`.
+__device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, const EncodeWork& w, WaveMiss& mb, int& n_miss,
+                                             bool valid, uint64_t r0, uint64_t r1, int plen, int abs_begin) {
+    const int SL = T.suffix_len;
+    int32_t tok[kPieceMaxIds] = {0, 0, 0};
+    int cnt = -1;
+    uint64_t k0 = 0, k1 = 0;
+    if (valid && plen >= 1 && plen <= kPieceKeyBytes) {
+        piece_key(r0, r1, plen, k0, k1);
+        if (T.pieces.slots) cnt = memo_lookup(T.pieces, k0, k1, tok);
+    }
+    const bool hit = cnt >= 0;
+    const int need = valid ? (hit ? cnt : plen + SL) : 0;
+    const int incl = wave_incl_sum(need);
+    const int pos = st.base + st.used + incl - need;
+    if (hit) {
+#pragma unroll
+        for (int k = 0; k < kPieceMaxIds; ++k)
+            if (k < cnt) w.stage[pos + k] = tok[k];
+    }
+    const bool miss = valid && !hit;
+    const unsigned long long mm = __ballot(miss);
+    if (mm) {
+        if (miss) mb.e[n_miss + __popcll(mm & lanemask_lt())] = DeferredPiece{k0, k1, pos, st.row, abs_begin, plen};
+        n_miss += __popcll(mm);
+        wave_sync();
+        if (n_miss >= kWave) flush_misses(mb, n_miss, kWave, w);
+    }
+    st.used += __shfl(incl, kWave - 1);
+    st.emitted += wave_sum(hit ? cnt : 0);
 }
 
 enum EncodeMode : int { kFused = 0, kPieces = 1 };
 
 // Whole strings as pieces (kPieces mode, and skipped strings of the fused mode): cols [c_begin, c_end).
-__device__ __forceinline__ void encode_whole_strings(WaveScratch& ws, const BpeDev& T, const I2* root_lds, RowState& st,
-                                                     const EncodeWork& w, const RowsIn& in, int c_begin, int c_end) {
+__device__ __forceinline__ void lookup_whole_strings(const BpeDev& T, RowState& st, const EncodeWork& w, WaveMiss& mb,
+                                                     int& n_miss, const RowsIn& in, int c_begin, int c_end) {
     const int l = lane_id();
-    const int SL = T.suffix_len, mul = 1 + SL;
-    uint8_t* tb = reinterpret_cast<uint8_t*>(ws.text_w);
-    int col = c_begin;
-    while (col < c_end) {
+    for (int col = c_begin; col < c_end; col += kWave) {
         const int my = col + l;
-        const bool cand = my < c_end;
+        const bool valid = my < c_end;
         int sb = 0, plen = 0;
-        if (cand) { sb = in.begins[my]; plen = in.ends[my] - sb; }
-        const int take = lanes_that_fit(cand, plen + SL);
-        if (take == 0) {  // lane 0's piece does not fit LDS: exact path
-            defer_whole_piece(st, w, __shfl(sb, 0), __shfl(plen, 0), mul);
-            col += 1;
-            continue;
+        uint64_t r0 = 0, r1 = 0;
+        if (valid) {
+            sb = in.begins[my];
+            plen = in.ends[my] - sb;
+            if (plen >= 1 && plen <= kPieceKeyBytes) global_bytes16(in.chars + sb, plen, r0, r1);
         }
-        const bool valid = l < take;
-        const int incl = wave_incl_sum(valid ? plen : 0);
-        const int toff = incl - (valid ? plen : 0);
-        wave_sync();  // the previous batch is done with the LDS text
-        // short pieces: the owning lane copies; long ones: the wave copies them one by one
-        const bool big = valid && plen > 32;
-        if (valid && !big)
-            for (int i = 0; i < plen; ++i) tb[toff + i] = in.chars[sb + i];
-        unsigned long long bm = __ballot(big);
-        while (bm) {
-            const int src = __ffsll(bm) - 1;
-            bm &= bm - 1;
-            const int s_sb = __shfl(sb, src), s_len = __shfl(plen, src), s_to = __shfl(toff, src);
-            for (int i = l; i < s_len; i += kWave) tb[s_to + i] = in.chars[s_sb + i];
-        }
-        wave_sync();
-        process_batch(ws, T, root_lds, st, w, valid, toff, plen, sb);
-        col += take;
+        lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, sb);
     }
 }
 
 template <int MODE>
-static __global__ __launch_bounds__(kBlockThreads) void encode_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
-    __shared__ I2 root_lds[256];
+    __shared__ WaveMiss miss_all[kWavesPerBlock];
     __shared__ uint8_t ascii_cls[128];
-    for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
     if (MODE == kFused && threadIdx.x < 128) ascii_cls[threadIdx.x] = uint8_t(uc_nibble(sp, threadIdx.x) & 7);
     __syncthreads();
-    if (w.status->flags & (kFlagRange | kFlagStageOverflow)) return;
+    if (w.status->flags & kFatalFlags) return;
     WaveScratch& ws = ws_all[wave_in_block()];
+    WaveMiss& mb = miss_all[wave_in_block()];
     const int l = lane_id();
-    const int mul = 1 + T.suffix_len;
+    int n_miss = 0;
     const int n_waves = int(gridDim.x) * kWavesPerBlock;
     for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < in.n_rows; row += n_waves) {
-        RowState st{w.row_stage[row], 0, 0, false, row};
+        RowState st{w.row_stage[row], 0, 0, row};
         const int cb = in.ragged_begins[row], ce = in.ragged_ends[row];
         if (MODE == kPieces) {
-            encode_whole_strings(ws, T, root_lds, st, w, in, cb, ce);
+            lookup_whole_strings(T, st, w, mb, n_miss, in, cb, ce);
         } else {
             for (int col = cb; col < ce; ++col) {
                 if (in.skips && in.skips[col]) {  // regex_split.cpp:231-234: passes through unsplit
-                    encode_whole_strings(ws, T, root_lds, st, w, in, col, col + 1);
+                    lookup_whole_strings(T, st, w, mb, n_miss, in, col, col + 1);
                     continue;
                 }
                 const int sb = in.begins[col], slen = in.ends[col] - sb;
-                const int str_unit0 = st.bytepos;
                 scan_string(
                     ws, sp, ascii_cls, in.chars + sb, slen,
                     [&](int np, int c0, int w0, int skew) {
-                        for (int jb = 0; jb < np;) {
+                        for (int jb = 0; jb < np; jb += kWave) {
                             const int j = jb + l;
-                            const bool cand = j < np;
+                            const bool valid = j < np;
                             int ps = 0, plen = 0;
-                            if (cand) { ps = c0 + int(ws.pstart[j]); plen = c0 + int(ws.pstart[j + 1]) - ps; }
-                            const int take = lanes_that_fit(cand, plen + T.suffix_len);
-                            if (take == 0) {
-                                const int b0 = __shfl(ps, 0), n0 = __shfl(plen, 0);
-                                st.bytepos = str_unit0 + b0;
-                                defer_whole_piece(st, w, sb + b0, n0, mul);
-                                jb += 1;
-                                continue;
+                            uint64_t r0 = 0, r1 = 0;
+                            if (valid) {
+                                ps = c0 + int(ws.pstart[j]);
+                                plen = c0 + int(ws.pstart[j + 1]) - ps;
+                                if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, ps - w0 + skew, r0, r1);
                             }
-                            st.bytepos = str_unit0 + __shfl(ps, 0);
-                            process_batch(ws, T, root_lds, st, w, l < take, ps - w0 + skew, plen, sb + ps);
-                            jb += take;
+                            lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, sb + ps);
                         }
                     },
-                    [&](int b, int e) {
-                        st.bytepos = str_unit0 + b;
-                        defer_whole_piece(st, w, sb + b, e - b, mul);
+                    [&](int b, int e) {  // a piece longer than the scan window: straight to the deferred list
+                        lookup_batch(T, st, w, mb, n_miss, l == 0, 0, 0, e - b, sb + b);
                     });
-                if (slen <= 0 && st.slotted)  // an empty string produces no piece but owns one slot unit
-                    for (int k = l; k < mul; k += kWave) w.stage[st.base + str_unit0 * mul + k] = kEmptyId;
-                st.bytepos = str_unit0 + (slen > 0 ? slen : 1);
             }
         }
         if (l == 0) {
             w.row_cnt[row] = st.emitted;
-            w.row_slotted[row] = st.slotted ? 1 : 0;
+            w.row_used[row] = st.used;
+        }
+    }
+    if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
+}
+
+// ---- merge kernel: dense batches of deferred pieces ----------------------------------------------
+static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w) {
+    __shared__ uint32_t id_all[kWavesPerBlock][kFastSyms * kWave];
+    __shared__ uint64_t key_all[kWavesPerBlock][kFastSyms * kWave];
+    __shared__ I2 root_lds[256];
+    for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
+    __syncthreads();
+    if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
+    uint32_t* id = id_all[wave_in_block()];
+    uint64_t* key = key_all[wave_in_block()];
+    const int l = lane_id();
+    const int SL = T.suffix_len;
+    const int shard = int(blockIdx.y);
+    int count = w.status->shard_count[shard * kCounterStride];
+    if (count > w.shard_cap) count = w.shard_cap;
+    const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
+    const int stride = int(gridDim.x) * kBlockThreads;
+    for (int base = (int(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kWave; base < count; base += stride) {
+        const bool valid = base + l < count;
+        DeferredPiece e{};
+        if (valid) e = list[base + l];
+        const int need = e.len + SL;
+        const bool is_f = valid && e.len >= 1 && e.len <= kPieceKeyBytes && need <= kFastSyms;
+        const bool is_w = valid && !is_f && need <= kChunkSyms;
+        bool is_x = valid && !is_f && !is_w;
+        int32_t* out = w.stage + e.stage_pos;
+        wave_sync();  // the previous batch is done with the LDS arrays
+        if (is_f) {
+            const uint64_t k0 = e.k0, k1 = e.k1;
+            const int plen = e.len;
+            const int n = bpe_symbolize(
+                T, root_lds,
+                [&](int i) -> uint32_t {
+                    if (i >= plen) return T.suffix[i - plen];
+                    return uint32_t((i < 8 ? k0 >> (8 * i) : k1 >> (8 * (i - 8))) & 0xFF);
+                },
+                need, [&](int k, int tok) { id[k * kWave + l] = uint32_t(tok); });
+            const int res = bpe_merge_lane(T, id, key, n);
+            if (res < 0) {
+                is_x = true;
+            } else {
+                for (int k = 0; k < res; ++k) out[k] = int32_t(id[k * kWave + l]);
+                for (int k = res; k < need; ++k) out[k] = kEmptyId;
+                if (res) atomicAdd(&w.row_cnt[e.row], res);
+            }
+        }
+        unsigned long long wm = __ballot(is_w);
+        while (wm) {
+            const int src = __ffsll(wm) - 1;
+            wm &= wm - 1;
+            const int s_begin = __shfl(e.begin, src), s_len = __shfl(e.len, src), s_pos = __shfl(e.stage_pos, src);
+            const int s_need = s_len + SL;
+            wave_sync();
+            int n = 0;
+            if (l == src) {
+                const uint8_t* text = in.chars + s_begin;
+                n = bpe_symbolize(
+                    T, root_lds, [&](int i) -> uint32_t { return i < s_len ? text[i] : T.suffix[i - s_len]; }, s_need,
+                    [&](int k, int tok) { id[k] = uint32_t(tok); });
+            }
+            n = __shfl(n, src);
+            wave_sync();
+            const int res = bpe_merge_wave(T, id, key, n);
+            if (res < 0) {
+                if (l == src) is_x = true;
+            } else {
+                int32_t* o = w.stage + s_pos;
+                for (int k = l; k < s_need; k += kWave) o[k] = k < res ? int32_t(id[k]) : kEmptyId;
+                if (l == src && res) atomicAdd(&w.row_cnt[e.row], res);
+            }
+        }
+        const unsigned long long xm = __ballot(is_x);
+        if (xm) {
+            int idx = 0;
+            if (l == 0) idx = atomicAdd(&w.status->n_exact, __popcll(xm));
+            idx = __shfl(idx, 0) + __popcll(xm & lanemask_lt());
+            if (is_x) {
+                if (idx < w.exact_cap) w.exact[idx] = ExactPiece{e.begin, e.len, e.stage_pos, e.row};
+                else atomicOr(&w.status->flags, kFlagExactOverflow);
+            }
         }
     }
 }
 
-// ---- K3: path X, one lane per deferred piece.
+// ---- path X, one lane per piece.
 static __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, BpeDev T, EncodeWork w) {
-    if (w.status->flags & (kFlagRange | kFlagStageOverflow)) return;
-    int n = w.status->n_deferred;
-    if (n > w.deferred_cap) n = w.deferred_cap;
-    const int SL = T.suffix_len, mul = 1 + SL;
+    if (w.status->flags & (kFatalFlags | kFlagDeferOverflow | kFlagExactOverflow)) return;
+    const int n = w.status->n_exact;
+    const int SL = T.suffix_len;
     const int stride = int(gridDim.x) * kBlockThreads;
     for (int i = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); i < n; i += stride) {
-        const DeferredPiece p = w.deferred[i];
+        const ExactPiece p = w.exact[i];
         const int ntext = p.len + SL;
         const uint32_t bytes = (bpe_exact_scratch_bytes(uint32_t(ntext)) + 15u) & ~15u;
         const uint32_t off = atomicAdd(&w.status->scratch_used, bytes);
@@ -338,46 +414,26 @@ static __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, 
         int32_t* out = w.stage + p.stage_pos;
         const int cnt = bpe_exact_piece(
             T, [&](int k) -> uint32_t { return k < p.len ? text[k] : T.suffix[k - p.len]; }, ntext, w.scratch + off, out);
-        const int slot_len = (p.len > 0 ? p.len : 1) * mul;
-        for (int k = cnt; k < slot_len; ++k) out[k] = kEmptyId;
-        atomicAdd(&w.row_cnt[p.row], cnt);
+        for (int k = cnt; k < ntext; ++k) out[k] = kEmptyId;
+        if (cnt) atomicAdd(&w.row_cnt[p.row], cnt);
     }
 }
 
-// ---- K4: final offsets (one block).  out_begins/out_ends may be nullptr.
-static __global__ __launch_bounds__(kScanThreads) void finalize_rows_kernel(int n_rows, EncodeWork w, int32_t* out_begins,
-                                                                      int32_t* out_ends, long long out_cap) {
-    if (w.status->flags & (kFlagRange | kFlagStageOverflow)) return;
-    const long long total = block_exclusive_scan<kScanThreads>(
-        n_rows, [&](int row) -> long long { return w.row_cnt[row]; },
-        [&](int row, long long off) {
-            w.row_out[row] = int32_t(off);
-            if (out_begins) out_begins[row] = int32_t(off);
-            if (out_ends) out_ends[row] = int32_t(off + w.row_cnt[row]);
-        });
-    if (threadIdx.x == 0) {
-        w.row_out[n_rows] = int32_t(total);
-        w.status->n_out = int32_t(total);
-        if (total > out_cap) atomicOr(&w.status->flags, kFlagOutCapacity);
-    }
-}
-
-// ---- K5: staging -> caller's buffer, one wave per row.
+// ---- staging -> caller's buffer, one wave per row.
 static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out) {
-    if (w.status->flags & (kFlagRange | kFlagStageOverflow | kFlagOutCapacity | kFlagDeferOverflow |
-                           kFlagScratchOverflow))
+    if (w.status->flags & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow))
         return;
     const int l = lane_id();
     const int n_waves = int(gridDim.x) * kWavesPerBlock;
     for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < n_rows; row += n_waves) {
-        const int base = w.row_stage[row], cap = w.row_stage[row + 1] - base;
+        const int base = w.row_stage[row], used = w.row_used[row];
         const int cnt = w.row_cnt[row], o = w.row_out[row];
-        if (!w.row_slotted[row]) {
+        if (used == cnt) {
             for (int k = l; k < cnt; k += kWave) out[o + k] = w.stage[base + k];
         } else {
             int run = 0;
-            for (int b = 0; b < cap; b += kWave) {
-                const int v = (b + l < cap) ? w.stage[base + b + l] : kEmptyId;
+            for (int b = 0; b < used; b += kWave) {
+                const int v = (b + l < used) ? w.stage[base + b + l] : kEmptyId;
                 const unsigned long long m = __ballot(v != kEmptyId);
                 if (v != kEmptyId) out[o + run + __popcll(m & lanemask_lt())] = v;
                 run += __popcll(m);
@@ -390,8 +446,8 @@ static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_row
 // mode 0: row_cnt[row] = number of pieces.  mode 1: write begins/ends/skips at row_out[row].
 template <int WRITE>
 static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, SplitDev sp, int max_splits, EncodeWork w,
-                                                              int32_t* out_begins, int32_t* out_ends,
-                                                              uint8_t* out_skips) {
+                                                                     int32_t* out_begins, int32_t* out_ends,
+                                                                     uint8_t* out_skips) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
     __shared__ uint8_t ascii_cls[128];
     if (threadIdx.x < 128) ascii_cls[threadIdx.x] = uint8_t(uc_nibble(sp, threadIdx.x) & 7);

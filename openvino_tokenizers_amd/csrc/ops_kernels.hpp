@@ -10,7 +10,8 @@ namespace ovtk {
 
 // =============================================================================================
 // WordpieceTokenizer (src/wordpiece_tokenizer.cpp:94-130): one wave per row, one lane per word.
-// Every row is staged "slotted" (word w owns staging entries [bytepos, bytepos + max(len,1))).
+// Word w owns staging entries [bytepos, bytepos + max(len,1)) of its row; unused ones hold kEmptyId and are
+// squeezed out by compact_kernel.
 // =============================================================================================
 struct WordpieceDev {
     TrieDev root, sub;
@@ -73,7 +74,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn 
         }
         if (l == 0) {
             w.row_cnt[row] = emitted;
-            w.row_slotted[row] = 1;
+            w.row_used[row] = bytepos;
         }
     }
 }
@@ -179,72 +180,15 @@ static __global__ __launch_bounds__(kBlockThreads) void ragged_to_dense_kernel(D
     }
 }
 
-// =============================================================================================
-// Large exclusive scans: per-tile sums -> one block scans the tile sums -> per-tile rescan + apply.
-// =============================================================================================
-constexpr int kTileThreads = 256;
-constexpr int kTileElems = kTileThreads * kScanPerThread;  // 1024 elements per block
-
-template <class LenF>
-static __global__ __launch_bounds__(kTileThreads) void tile_reduce_kernel(long long n, LenF f, long long* tile_sums) {
-    __shared__ long long part[kTileThreads / kWave];
-    const long long i0 = (long long)blockIdx.x * kTileElems + (long long)threadIdx.x * kScanPerThread;
-    long long s = 0;
-#pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j)
-        if (i0 + j < n) s += f(i0 + j);
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) s += __shfl_xor(s, d);
-    if (lane_id() == 0) part[wave_in_block()] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long t = 0;
-        for (int k = 0; k < kTileThreads / kWave; ++k) t += part[k];
-        tile_sums[blockIdx.x] = t;
-    }
-}
-
-// One block: exclusive scan of the tile sums in place; total -> status->n_out (clamped) + capacity flag.
-static __global__ __launch_bounds__(kScanThreads) void tile_scan_kernel(int n_tiles, long long* tile_sums, long long cap,
-                                                                  RunStatus* status) {
-    const long long total = block_exclusive_scan<kScanThreads>(
-        n_tiles, [&](int t) -> long long { return tile_sums[t]; }, [&](int t, long long off) { tile_sums[t] = off; });
-    if (threadIdx.x == 0) {
+// Finalisation of the char-offset scans of VocabDecoder / ByteFallback: total -> status->n_out + capacity flag.
+struct CharsFin {
+    RunStatus* status;
+    long long cap;
+    __device__ void operator()(long long total) const {
         status->n_out = total > INT32_MAX ? INT32_MAX : int32_t(total);
         if (total > cap) atomicOr(&status->flags, kFlagOutCapacity);
     }
-}
-
-// apply(i, offset, len) is called for every element with its global exclusive offset.
-template <class LenF, class ApplyF>
-static __global__ __launch_bounds__(kTileThreads) void tile_apply_kernel(long long n, LenF f, const long long* tile_offs,
-                                                                  ApplyF apply, const RunStatus* status) {
-    __shared__ long long part[kTileThreads / kWave];
-    if (status->flags & (kFlagOutCapacity | kFlagRange)) return;
-    const long long i0 = (long long)blockIdx.x * kTileElems + (long long)threadIdx.x * kScanPerThread;
-    long long v[kScanPerThread], s = 0;
-#pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) {
-        v[j] = (i0 + j < n) ? (long long)f(i0 + j) : 0;
-        s += v[j];
-    }
-    long long incl = s;
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        long long t = __shfl_up(incl, d);
-        if (l >= d) incl += t;
-    }
-    if (l == kWave - 1) part[wave_in_block()] = incl;
-    __syncthreads();
-    long long run = tile_offs[blockIdx.x] + incl - s;
-    for (int k = 0; k < wave_in_block(); ++k) run += part[k];
-#pragma unroll
-    for (int j = 0; j < kScanPerThread; ++j) {
-        if (i0 + j < n) apply(i0 + j, run, v[j]);
-        run += v[j];
-    }
-}
+};
 
 // =============================================================================================
 // VocabDecoder / ByteFallback / detokenize element functors

@@ -52,8 +52,6 @@ struct WaveScratch {
     uint32_t text_w[kWinBytes / 4];
     uint8_t cls[kWinBytes];
     uint16_t pstart[kChunk + 2];
-    uint32_t sym_id[kChunk];
-    uint32_t sym_key[kChunk];
 };
 
 __device__ __forceinline__ const uint8_t* text_bytes(const WaveScratch& ws) {

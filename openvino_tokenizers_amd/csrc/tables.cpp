@@ -110,13 +110,12 @@ int TrieHost::find_longest(const uint8_t* s, int n, int& idx) const {
 uint32_t BpeHost::find_merge(uint32_t l, uint32_t r) const {
     if (merges.empty()) return kNoRank;
     const uint64_t key = merge_key(l, r);
-    uint32_t bkt = uint32_t(hash_u64(key) >> bucket_shift) & bucket_mask;
+    uint32_t p = uint32_t(hash_u64(key) >> slot_shift) & slot_mask;
     for (;;) {
-        const uint64_t a = merges[2 * bkt], c = merges[2 * bkt + 1];
+        const uint64_t a = merges[p].kr;
+        if (a == kEmptySlot) return kNoRank;
         if ((a >> kMaxRankBits) == key) return uint32_t(a) & kNoRank;
-        if ((c >> kMaxRankBits) == key) return uint32_t(c) & kNoRank;
-        if (c == kEmptySlot) return kNoRank;
-        bkt = (bkt + 1) & bucket_mask;
+        p = (p + 1) & slot_mask;
     }
 }
 
@@ -198,21 +197,53 @@ int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView
     }
     out.suffix = end_suffix;
 
-    // Bucketised open addressing, load factor <= 0.5 of the slots.
-    const uint32_t buckets = std::max<uint32_t>(4, pow2_at_least(rank_of.size() + 1));
-    out.bucket_mask = buckets - 1;
-    out.bucket_shift = 64 - log2u(buckets);
-    out.merges.assign(size_t(buckets) * 2, kEmptySlot);
+    // Open addressing, linear probing, load factor <= 0.5.
+    const uint32_t slots = std::max<uint32_t>(8, pow2_at_least(uint64_t(rank_of.size()) * 2 + 1));
+    out.slot_mask = slots - 1;
+    out.slot_shift = 64 - log2u(slots);
+    out.merges.assign(size_t(slots), MergeSlot{kEmptySlot, 0});
     for (const auto& kv : rank_of) {
-        uint32_t bkt = uint32_t(hash_u64(kv.first) >> out.bucket_shift) & out.bucket_mask;
-        for (;;) {
-            uint64_t* s = &out.merges[size_t(bkt) * 2];
-            if (s[0] == kEmptySlot) { s[0] = (kv.first << kMaxRankBits) | kv.second; break; }
-            if (s[1] == kEmptySlot) { s[1] = (kv.first << kMaxRankBits) | kv.second; break; }
-            bkt = (bkt + 1) & out.bucket_mask;
-        }
+        uint32_t p = uint32_t(hash_u64(kv.first) >> out.slot_shift) & out.slot_mask;
+        while (out.merges[p].kr != kEmptySlot) p = (p + 1) & out.slot_mask;
+        out.merges[p] = MergeSlot{(kv.first << kMaxRankBits) | kv.second, uint64_t(uint32_t(out.new_id[kv.second]))};
     }
     return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- piece memo
+void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
+                       PieceTableHost& out) {
+    size_t eligible = 0;
+    for (int64_t i = 0; i < pieces.n; ++i) {
+        const int len = pieces.ends[i] - pieces.begins[i], cnt = id_ends[i] - id_begins[i];
+        if (len >= 1 && len <= kPieceKeyBytes && cnt >= 0 && cnt <= kPieceMaxIds) ++eligible;
+    }
+    const uint32_t cap = std::max<uint32_t>(8, pow2_at_least(uint64_t(eligible) * 2 + 1));
+    out.mask = cap - 1;
+    out.shift = 64 - log2u(cap);
+    out.slots.assign(size_t(cap), PieceEntry{0, 0, {0, 0, 0}, 0});
+    out.stored = 0;
+    for (int64_t i = 0; i < pieces.n; ++i) {
+        const int len = pieces.ends[i] - pieces.begins[i], cnt = id_ends[i] - id_begins[i];
+        if (!(len >= 1 && len <= kPieceKeyBytes && cnt >= 0 && cnt <= kPieceMaxIds)) continue;
+        uint8_t kb[16] = {0};
+        std::memcpy(kb, pieces.chars + pieces.begins[i], size_t(len));
+        kb[15] = uint8_t(len);
+        uint64_t k0, k1;
+        std::memcpy(&k0, kb, 8);
+        std::memcpy(&k1, kb + 8, 8);
+        uint32_t p = uint32_t(hash_piece(k0, k1) >> out.shift) & out.mask;
+        bool dup = false;
+        while (out.slots[p].k1 != 0) {
+            if (out.slots[p].k0 == k0 && out.slots[p].k1 == k1) { dup = true; break; }
+            p = (p + 1) & out.mask;
+        }
+        if (dup) continue;
+        PieceEntry e{k0, k1, {0, 0, 0}, cnt};
+        for (int k = 0; k < cnt; ++k) e.tok[k] = ids[id_begins[i] + k];
+        out.slots[p] = e;
+        ++out.stored;
+    }
 }
 
 // ------------------------------------------------------------------------------- WordPiece

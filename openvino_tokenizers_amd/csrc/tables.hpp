@@ -9,8 +9,12 @@
 // Device layouts (all flat arrays, sized for L2 residency, probed with one or two 8/16-byte loads):
 //   trie      root[256] {value, child|leaf bit}; node[n] {value, has_children};
 //             edges: open-addressing table of u64 {key = node<<8|byte : 32, child : 32}
-//   merges    16-byte buckets of two u64 slots {left:21 | right:21 | rank:22}, linear probing by
-//             bucket; new_id[rank] as a dense side array
+//   merges    16-byte slots {left:21 | right:21 | rank:22} + {new_id}, linear probing; one
+//             global_load_dwordx4 per probe returns rank AND merged id; new_id[rank] also kept
+//             as a dense side array for the exact-heap path
+//   pieces    the piece memo: 32-byte entries {piece bytes (<= 15) + length : 16 B, ids[3], count}
+//             holding BPE(piece) for every vocabulary token used as a whole piece, computed
+//             once at create time by the device BPE itself (see api_encode.cpp)
 //   strings   (VocabEncoder) open-addressing table of {hash32, key index}; keys stay in the
 //             decomposed begins/ends/chars form for the final byte compare
 #pragma once
@@ -40,12 +44,31 @@ struct TrieDev {
     uint32_t edge_shift;     // 32 - log2(capacity)
 };
 
+struct alignas(16) MergeSlot {
+    uint64_t kr;   // merge_key(left, right) << kMaxRankBits | rank; kEmptySlot = free
+    uint64_t nid;  // id of the merged token
+};
+
+constexpr int kPieceKeyBytes = 15;  // longest piece the memo table can key
+constexpr int kPieceMaxIds = 3;     // longest id sequence it stores
+struct alignas(32) PieceEntry {
+    uint64_t k0, k1;  // piece bytes 0..7 / 8..14 (little endian, zero padded) | length << 56; k1 == 0: free (length >= 1)
+    int32_t tok[kPieceMaxIds];
+    int32_t cnt;
+};
+struct PieceTableDev {
+    const PieceEntry* slots;  // nullptr: no memo (every piece takes the merge path)
+    uint32_t mask;
+    uint32_t shift;           // 64 - log2(capacity)
+};
+
 struct BpeDev {
     TrieDev trie;
-    const uint64_t* merges;     // [2 * (bucket_mask+1)]
-    uint32_t bucket_mask;
-    uint32_t bucket_shift;      // 64 - log2(buckets)
+    const MergeSlot* merges;    // [slot_mask+1]
+    uint32_t slot_mask;
+    uint32_t slot_shift;        // 64 - log2(slots)
     const int32_t* new_id;      // [n_merges]
+    PieceTableDev pieces;
     const int32_t* byte_fallback_id;  // [256], -1 = none (all -1 when byte_fallback is off)
     int32_t unk_id;
     int32_t suffix_len;
@@ -65,6 +88,10 @@ struct StringMapDev {
 __host__ __device__ inline uint32_t hash_u32(uint32_t k) { return k * 0x9E3779B1u; }
 __host__ __device__ inline uint64_t hash_u64(uint64_t k) { return k * 0x9E3779B97F4A7C15ull; }
 __host__ __device__ inline uint64_t merge_key(uint32_t l, uint32_t r) { return (uint64_t(l) << kMaxVocabBits) | r; }
+__host__ __device__ inline uint64_t hash_piece(uint64_t k0, uint64_t k1) {
+    uint64_t h = (k0 ^ (k1 * 0xC2B2AE3D27D4EB4Full)) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
 // FNV-1a over the bytes; the same function on host (table build) and device (probe).
 __host__ __device__ inline uint32_t hash_bytes(const uint8_t* p, int n) {
     uint32_t h = 2166136261u;
@@ -90,8 +117,8 @@ struct TrieHost {
 
 struct BpeHost {
     TrieHost trie;
-    std::vector<uint64_t> merges;
-    uint32_t bucket_mask = 0, bucket_shift = 64;
+    std::vector<MergeSlot> merges;
+    uint32_t slot_mask = 0, slot_shift = 64;
     std::vector<int32_t> new_id;
     std::vector<int32_t> byte_fallback_id;
     int32_t unk_id = -1;
@@ -106,6 +133,16 @@ struct StringsView { const int32_t* begins; const int32_t* ends; const uint8_t* 
 int build_bpe(const StringsView& vocab, const StringsView& merges_left, const StringsView* merges_right,
               const StringsView& added, const int32_t* added_ids, const std::string& unk_token,
               const std::string& end_suffix, bool byte_fallback, BpeHost& out, std::string& err);
+
+// The piece memo from (piece string, its ids) pairs: pieces of 1..kPieceKeyBytes bytes with at most
+// kPieceMaxIds ids are stored (a repeated string keeps its first entry -- all entries of one string are equal).
+struct PieceTableHost {
+    std::vector<PieceEntry> slots;
+    uint32_t mask = 0, shift = 64;
+    size_t stored = 0;
+};
+void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
+                       PieceTableHost& out);
 
 int build_wordpiece(const StringsView& vocab, const std::string& suffix_indicator, TrieHost& root, TrieHost& sub,
                     std::string& err);

@@ -1,0 +1,56 @@
+"""Development probe (run through gpurun): per-kernel times of the split-only, BPE-only and fused paths at config-2
+size, plus piece statistics of the synthetic corpus.  Not part of the product or the test-suite."""
+import ctypes as C
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from openvino_tokenizers_amd import _lib as L
+from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
+from tools.harness import BpeTok
+from tools.workloads import TextModel, ragged_rows
+
+
+def dump(lib):
+    buf = C.create_string_buffer(8192)
+    lib.ovtk_profile_dump(buf, 8192)
+    return {ln.split()[0]: float(ln.split()[1]) / max(int(ln.split()[2]), 1) for ln in buf.value.decode().splitlines() if ln.strip()}
+
+
+def main():
+    lib = L.load()
+    rows = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    tok = BpeTok.load("gpt2")
+    for kind in ("zipf", "uniform"):
+        b, e, c = TextModel(1234, kind).batch(rows, 512, seed=1000)
+        rb, re_ = ragged_rows(rows)
+        d = [torch.as_tensor(x, device="cuda") for x in (rb, re_, b, e, c)]
+        split = RegexSplit("isolate", lib=lib)
+        bpe = BPETokenizer(**tok.attrs, lib=lib)
+        fused = FusedSplitBPE(split, bpe)
+        pat = tok.pattern_u8()
+        for it in range(3):
+            if it == 2:
+                lib.ovtk_profile_reset()
+                lib.ovtk_profile_enable(1)
+            sp = split.evaluate(d + [pat])
+            ids = bpe.evaluate(list(sp[:5]) + tok.consts)
+            ids2 = fused.evaluate(d + [pat], tok.consts)
+        torch.cuda.synchronize()
+        lib.ovtk_profile_enable(0)
+        assert torch.equal(ids[2], ids2[2])
+        plen = (sp[3] - sp[2]).cpu().numpy()
+        tl = (ids[1] - ids[0]).cpu().numpy()
+        print(kind, "bytes", len(c), "pieces", len(plen), "tokens", int(ids[2].numel()),
+              "piece len mean %.2f p50 %d p90 %d p99 %d max %d" % (plen.mean(), *np.percentile(plen, [50, 90, 99]).astype(int), plen.max()),
+              "frac<=15B %.4f" % (plen <= 15).mean())
+        print("   kernel ms:", {k: round(v, 4) for k, v in dump(lib).items()})
+        # how many pieces are exactly one vocab token / tokens per piece
+        pieces_per_row = (sp[1] - sp[0]).cpu().numpy()
+        print("   pieces/row mean %.1f max %d; tokens/piece %.3f" % (pieces_per_row.mean(), pieces_per_row.max(), ids[2].numel() / len(plen)))
+
+
+if __name__ == "__main__":
+    main()
