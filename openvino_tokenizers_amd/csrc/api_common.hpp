@@ -174,6 +174,7 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
         launch_scan(ws->marks, "scan_rows", s, n_rows, RowCapLen{d_in, mul, w.status}, RowCapApply{w.row_stage},
                     RowCapFin{w, n_rows}, w.tiles, w.status, kFlagRange);
         middle(*ws.ws, d_in, w);
+        OVTK_LAUNCH(ws->marks, "count_rows", count_rows_kernel, grid_lookup(device, n_rows), kBlockThreads, s, n_rows, w);
         launch_scan(ws->marks, "scan_rows", s, n_rows, RowCntLen{w.row_cnt}, RowOutApply{w.row_out, d_begins, d_ends},
                     RowOutFin{w, n_rows, (long long)out->data_capacity}, w.tiles, w.status, kFatalFlags);
         OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_lookup(device, n_rows), kBlockThreads, s, n_rows, w, d_ids);

@@ -85,7 +85,7 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab) {
     build_piece_table(view_of(vocab), ob.data(), oe.data(), ids.data(), host);
     if (int rc = h->pieces.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
     OVTK_HIP(hipStreamSynchronize(nullptr));
-    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.mask, host.shift};
+    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift};
     h->memo_entries = host.stored;
     return OVTK_OK;
 }
@@ -172,7 +172,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     e = e ? e : h->root.upload(host.trie.root.data(), host.trie.root.size() * sizeof(I2));
     e = e ? e : h->node.upload(host.trie.node.data(), host.trie.node.size() * sizeof(I2));
     e = e ? e : h->edges.upload(host.trie.edges.data(), host.trie.edges.size() * sizeof(uint64_t));
-    e = e ? e : h->merges.upload(host.merges.data(), host.merges.size() * sizeof(MergeSlot));
+    e = e ? e : h->merges.upload(host.merges.data(), host.merges.size() * sizeof(MergeBucket));
     e = e ? e : h->new_id.upload(host.new_id.data(), host.new_id.size() * sizeof(int32_t));
     e = e ? e : h->bf.upload(host.byte_fallback_id.data(), host.byte_fallback_id.size() * sizeof(int32_t));
     if (e) return e;
@@ -183,10 +183,9 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     d.trie.edges = h->edges.as<uint64_t>();
     d.trie.edge_mask = host.trie.edge_mask;
     d.trie.edge_shift = host.trie.edge_shift;
-    d.merges = h->merges.as<MergeSlot>();
-    d.slot_mask = host.slot_mask;
-    d.slot_shift = host.slot_shift;
-    d.pieces = PieceTableDev{nullptr, 0, 64};
+    d.merges = h->merges.as<MergeBucket>();
+    d.bucket_shift = host.bucket_shift;
+    d.pieces = PieceTableDev{nullptr, 62};
     d.new_id = h->new_id.as<int32_t>();
     d.byte_fallback_id = h->bf.as<int32_t>();
     d.unk_id = host.unk_id;
@@ -246,7 +245,7 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
                                else
                                    OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid_lookup(dev, n_rows),
                                                kBlockThreads, s, d_in, SplitDev{}, bpe->dev, w);
-                               OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(device_cu_count(dev) * 3 / kShards + 1, kShards),
+                               OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(std::max(1, device_cu_count(dev) * 3 / kShards), kShards),
                                            kBlockThreads, s, d_in, bpe->dev, w);
                                OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
                            });

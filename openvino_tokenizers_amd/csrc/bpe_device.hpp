@@ -33,31 +33,26 @@ constexpr int kFastSyms = 16;                            // pieces with more sym
 constexpr int kChunkSyms = 512;                          // path W limit (symbols incl. end_suffix)
 constexpr uint32_t kIdMask = (1u << kIdBits) - 1;
 
-__device__ __forceinline__ uint32_t merge_slot_of(const BpeDev& T, uint64_t key) {
-    return uint32_t(hash_u64(key) >> T.slot_shift) & T.slot_mask;
+// One lookup of the merge table = both candidate buckets, four independent 16-byte loads.
+struct MergeFetch { MergeBucket a, b; };
+__device__ __forceinline__ MergeFetch merge_fetch(const BpeDev& T, uint64_t key) {
+    return MergeFetch{T.merges[merge_h1(key, T.bucket_shift)], T.merges[merge_h2(key, T.bucket_shift)]};
 }
 __device__ __forceinline__ uint64_t make_pair_key(const MergeSlot& s, uint32_t seq) {
     return ((s.kr & kNoRank) << (kSeqBits + kIdBits)) | (uint64_t(seq) << kIdBits) | (s.nid & kIdMask);
 }
-// Continues a probe sequence from slot p whose content s did not match and was not empty.
-__device__ __forceinline__ uint64_t merge_probe_rest(const BpeDev& T, uint64_t key, uint32_t p, uint32_t seq) {
-    for (;;) {
-        p = (p + 1) & T.slot_mask;
-        const MergeSlot s = T.merges[p];
-        if (s.kr == kEmptySlot) return kNoKey;
-        if ((s.kr >> kMaxRankBits) == key) return make_pair_key(s, seq);
-    }
-}
-__device__ __forceinline__ uint64_t merge_probe_finish(const BpeDev& T, uint64_t key, uint32_t p, const MergeSlot& s,
-                                                       uint32_t seq) {
-    if (s.kr == kEmptySlot) return kNoKey;
-    if ((s.kr >> kMaxRankBits) == key) return make_pair_key(s, seq);
-    return merge_probe_rest(T, key, p, seq);
+__device__ __forceinline__ uint64_t merge_resolve(const MergeFetch& f, uint64_t key, uint32_t seq) {
+    // an empty slot holds all ones: its upper 42 bits never equal a key (ids < 2^21 - 1)
+    uint64_t r = kNoKey;
+    if ((f.a.s[0].kr >> kMaxRankBits) == key) r = make_pair_key(f.a.s[0], seq);
+    if ((f.a.s[1].kr >> kMaxRankBits) == key) r = make_pair_key(f.a.s[1], seq);
+    if ((f.b.s[0].kr >> kMaxRankBits) == key) r = make_pair_key(f.b.s[0], seq);
+    if ((f.b.s[1].kr >> kMaxRankBits) == key) r = make_pair_key(f.b.s[1], seq);
+    return r;
 }
 __device__ __forceinline__ uint64_t pair_key(const BpeDev& T, uint32_t l, uint32_t r, uint32_t seq) {
     const uint64_t key = merge_key(l, r);
-    const uint32_t p = merge_slot_of(T, key);
-    return merge_probe_finish(T, key, p, T.merges[p], seq);
+    return merge_resolve(merge_fetch(T, key), key, seq);
 }
 // Rank only (path X).
 __device__ __forceinline__ uint32_t merge_rank(const BpeDev& T, uint32_t l, uint32_t r) {
@@ -118,56 +113,79 @@ __device__ __forceinline__ int bpe_symbolize(const BpeDev& T, const I2* root, Ge
 }
 
 // Path F.  id / key: the wave's [kFastSyms][64] LDS arrays; this lane owns column lane_id().  n symbols are in
-// place.  Returns the final symbol count, or -1 when the minimum was not unique (replay on path X).
+// place.  Symbols never move: a merge writes the new id over its left operand and clears the right operand's bit
+// in the lane's `live` mask; key[k] always describes the pair (k, next live symbol after k).  The min-scan reads
+// all kFastSyms-1 keys with independent, fully unrolled LDS loads (dead / absent positions hold kNoKey).
+// Returns the final symbol count (symbols compacted to the front of the column), or -1 when the minimum was not
+// unique (replay on path X).
 __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uint64_t* key, int n) {
     const int l = lane_id();
 #define OVTK_AT(k) ((k) * kWave + l)
     // initial pair keys: the probes of a group of 4 are issued together
-    for (int k0 = 0; k0 + 1 < n; k0 += 4) {
-        uint64_t mk[4];
-        uint32_t p[4];
-        MergeSlot s[4];
+#pragma unroll
+    for (int k0 = 0; k0 < kFastSyms; k0 += 4) {
+        uint64_t mk[4] = {0, 0, 0, 0};
+        MergeFetch f[4] = {};
+        if (k0 + 1 < n) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j;
+                mk[j] = (k + 1 < n) ? merge_key(id[OVTK_AT(k)], id[OVTK_AT(k + 1)]) : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = merge_fetch(T, mk[j]);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = k0 + j;
-            const bool on = k + 1 < n;
-            mk[j] = on ? merge_key(id[OVTK_AT(k)], id[OVTK_AT(k + 1)]) : 0;
-            p[j] = merge_slot_of(T, mk[j]);
+            if (k < kFastSyms - 1) {
+                uint64_t v = kNoKey;
+                if (k + 1 < n) v = merge_resolve(f[j], mk[j], uint32_t(k));
+                key[OVTK_AT(k)] = v;
+            }
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] = T.merges[p[j]];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (k0 + j + 1 < n) key[OVTK_AT(k0 + j)] = merge_probe_finish(T, mk[j], p[j], s[j], uint32_t(k0 + j));
     }
+    uint32_t live = n >= 32 ? ~0u : ((1u << n) - 1u);
     uint32_t seq = n > 0 ? uint32_t(n - 1) : 0;
+    bool dup = false;
     while (n >= 2) {
+        uint64_t v[kFastSyms - 1];
+#pragma unroll
+        for (int k = 0; k < kFastSyms - 1; ++k) v[k] = key[OVTK_AT(k)];
         uint64_t best = kNoKey;
         int at = 0;
-        bool dup = false;
-        for (int k = 0; k + 1 < n; ++k) {
-            const uint64_t v = key[OVTK_AT(k)];
-            if (v < best) { best = v; at = k; dup = false; }
-            else if (v == best && v != kNoKey) dup = true;
+#pragma unroll
+        for (int k = 0; k < kFastSyms - 1; ++k) {
+            if (v[k] < best) { best = v[k]; at = k; dup = false; }
+            else if (v[k] == best && best != kNoKey) dup = true;
         }
-        if (best == kNoKey) break;
-        if (dup) return -1;
+        if (best == kNoKey || dup) break;
         const uint32_t nid = uint32_t(best) & kIdMask;
+        const uint32_t above = live & ~((2u << at) - 1u);          // live symbols right of `at`
+        const int right = __ffs(above) - 1;                        // the right operand (exists: key[at] was a pair)
+        live &= ~(1u << right);
+        const uint32_t above2 = above & ~(1u << right);
+        const uint32_t below = live & ((1u << at) - 1u);
+        const int nxt = above2 ? __ffs(above2) - 1 : -1;           // new right neighbour
+        const int prv = below ? 31 - __clz(below) : -1;            // left neighbour
         id[OVTK_AT(at)] = nid;
-        for (int k = at + 1; k + 1 < n; ++k) {  // close the gap left by the right operand
-            id[OVTK_AT(k)] = id[OVTK_AT(k + 1)];
-            key[OVTK_AT(k)] = key[OVTK_AT(k + 1)];
-        }
         --n;
         ++seq;
         // the two new neighbour pairs: both probes in flight together
-        const bool has_l = at > 0, has_r = at + 1 < n;
-        const uint64_t kl = has_l ? merge_key(id[OVTK_AT(at - 1)], nid) : 0;
-        const uint64_t kr = has_r ? merge_key(nid, id[OVTK_AT(at + 1)]) : 0;
-        const uint32_t pl = merge_slot_of(T, kl), pr = merge_slot_of(T, kr);
-        const MergeSlot sl = T.merges[pl], sr = T.merges[pr];
-        if (has_l) key[OVTK_AT(at - 1)] = merge_probe_finish(T, kl, pl, sl, seq);
-        if (has_r) key[OVTK_AT(at)] = merge_probe_finish(T, kr, pr, sr, seq);
+        const uint64_t kl = prv >= 0 ? merge_key(id[OVTK_AT(prv >= 0 ? prv : 0)], nid) : 0;
+        const uint64_t kr = nxt >= 0 ? merge_key(nid, id[OVTK_AT(nxt >= 0 ? nxt : 0)]) : 0;
+        const MergeFetch fl = merge_fetch(T, kl), fr = merge_fetch(T, kr);
+        if (prv >= 0) key[OVTK_AT(prv)] = merge_resolve(fl, kl, seq);
+        key[OVTK_AT(at)] = nxt >= 0 ? merge_resolve(fr, kr, seq) : kNoKey;
+        if (right < kFastSyms - 1) key[OVTK_AT(right)] = kNoKey;
+    }
+    if (dup) return -1;
+    // compact the surviving symbols to the front (ascending positions: reads never trail writes)
+    int m = 0;
+    for (uint32_t rest = live; rest; rest &= rest - 1) {
+        const int k = __ffs(rest) - 1;
+        const uint32_t t = id[OVTK_AT(k)];
+        id[OVTK_AT(m++)] = t;
     }
 #undef OVTK_AT
     return n;

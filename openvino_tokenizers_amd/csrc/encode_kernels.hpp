@@ -11,6 +11,7 @@
 //   merge_kernel                dense batches of 64 deferred pieces: path F (lane per piece), path W (wave
 //                               per piece), ties / oversized pieces -> exact list           (bpe_device.hpp)
 //   exact_kernel                path X, one lane per piece
+//   count_rows_kernel           ids per row = non-empty staging entries (rows that had deferred pieces)
 //   scan(row token counts)      final offsets = the reference's running `ragged_offset` (bpe_tokenizer.cpp:141-161)
 //   compact_kernel              staging -> caller's ids buffer (rows with deferred pieces have unused entries
 //                               = kEmptyId in their reserved stretches; they are squeezed out by ballot compaction)
@@ -158,19 +159,30 @@ __device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint6
     for (int i = 0; i < plen && i < 8; ++i) r0 |= uint64_t(p[i]) << (8 * i);
     for (int i = 8; i < plen; ++i) r1 |= uint64_t(p[i]) << (8 * (i - 8));
 }
-// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.
+// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.  Three independent
+// 32-byte loads (cuckoo table), no probe chain.
 __device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
-    uint32_t p = uint32_t(hash_piece(k0, k1) >> P.shift) & P.mask;
-    for (;;) {
-        const PieceEntry e = P.slots[p];
-        if (e.k1 == 0) return -1;
-        if (e.k0 == k0 && e.k1 == k1) {
+    const uint64_t mix = piece_mix(k0, k1);
+    const PieceEntry e0 = P.slots[piece_h(mix, 0, P.shift)];
+    const PieceEntry e1 = P.slots[piece_h(mix, 1, P.shift)];
+    const PieceEntry e2 = P.slots[piece_h(mix, 2, P.shift)];
+    int cnt = -1;
+    if (e0.k0 == k0 && e0.k1 == k1) {
+        cnt = e0.cnt;
 #pragma unroll
-            for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e.tok[k];
-            return e.cnt;
-        }
-        p = (p + 1) & P.mask;
+        for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e0.tok[k];
     }
+    if (e1.k0 == k0 && e1.k1 == k1) {
+        cnt = e1.cnt;
+#pragma unroll
+        for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e1.tok[k];
+    }
+    if (e2.k0 == k0 && e2.k1 == k1) {
+        cnt = e2.cnt;
+#pragma unroll
+        for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e2.tok[k];
+    }
+    return cnt;
 }
 
 // ---- lookup kernel ------------------------------------------------------------------------------
@@ -354,7 +366,6 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
             } else {
                 for (int k = 0; k < res; ++k) out[k] = int32_t(id[k * kWave + l]);
                 for (int k = res; k < need; ++k) out[k] = kEmptyId;
-                if (res) atomicAdd(&w.row_cnt[e.row], res);
             }
         }
         unsigned long long wm = __ballot(is_w);
@@ -379,7 +390,6 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
             } else {
                 int32_t* o = w.stage + s_pos;
                 for (int k = l; k < s_need; k += kWave) o[k] = k < res ? int32_t(id[k]) : kEmptyId;
-                if (l == src && res) atomicAdd(&w.row_cnt[e.row], res);
             }
         }
         const unsigned long long xm = __ballot(is_x);
@@ -415,7 +425,23 @@ static __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, 
         const int cnt = bpe_exact_piece(
             T, [&](int k) -> uint32_t { return k < p.len ? text[k] : T.suffix[k - p.len]; }, ntext, w.scratch + off, out);
         for (int k = cnt; k < ntext; ++k) out[k] = kEmptyId;
-        if (cnt) atomicAdd(&w.row_cnt[p.row], cnt);
+    }
+}
+
+// ---- ids per row once the deferred pieces are in: rows whose staging stretch has unused entries are recounted
+// (coalesced, contention-free -- cheaper than one device-scope atomic per deferred piece).
+static __global__ __launch_bounds__(kBlockThreads) void count_rows_kernel(int n_rows, EncodeWork w) {
+    if (w.status->flags & (kFatalFlags | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow)) return;
+    const int l = lane_id();
+    const int n_waves = int(gridDim.x) * kWavesPerBlock;
+    for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < n_rows; row += n_waves) {
+        const int used = w.row_used[row];
+        if (used == w.row_cnt[row]) continue;  // no deferred piece in this row
+        const int32_t* p = w.stage + w.row_stage[row];
+        int cnt = 0;
+        for (int b = l; b < used; b += kWave) cnt += p[b] != kEmptyId;
+        cnt = wave_sum(cnt);
+        if (l == 0) w.row_cnt[row] = cnt;
     }
 }
 

@@ -110,14 +110,33 @@ int TrieHost::find_longest(const uint8_t* s, int n, int& idx) const {
 uint32_t BpeHost::find_merge(uint32_t l, uint32_t r) const {
     if (merges.empty()) return kNoRank;
     const uint64_t key = merge_key(l, r);
-    uint32_t p = uint32_t(hash_u64(key) >> slot_shift) & slot_mask;
-    for (;;) {
-        const uint64_t a = merges[p].kr;
-        if (a == kEmptySlot) return kNoRank;
-        if ((a >> kMaxRankBits) == key) return uint32_t(a) & kNoRank;
-        p = (p + 1) & slot_mask;
-    }
+    for (uint32_t b : {merge_h1(key, bucket_shift), merge_h2(key, bucket_shift)})
+        for (const MergeSlot& s : merges[b].s)
+            if (s.kr != kEmptySlot && (s.kr >> kMaxRankBits) == key) return uint32_t(s.kr) & kNoRank;
+    return kNoRank;
 }
+
+namespace {
+// Cuckoo insertion by random walk (deterministic xorshift): `choices(item, idx)` fills the candidate slot
+// indices of an item, `empty(slot)` tells a free slot.  Returns false when the walk does not terminate.
+template <class Slot, int N, class Choices, class Empty>
+bool cuckoo_insert(std::vector<Slot>& slots, Slot item, Choices&& choices, Empty&& empty, uint64_t& rng) {
+    for (int kick = 0; kick < 2000; ++kick) {
+        uint32_t idx[N];
+        choices(item, idx);
+        for (int c = 0; c < N; ++c)
+            if (empty(slots[idx[c]])) {
+                slots[idx[c]] = item;
+                return true;
+            }
+        rng ^= rng << 13;
+        rng ^= rng >> 7;
+        rng ^= rng << 17;
+        std::swap(item, slots[idx[rng % N]]);
+    }
+    return false;
+}
+}  // namespace
 
 int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView* mr, const StringsView& added,
               const int32_t* added_ids, const std::string& unk_token, const std::string& end_suffix,
@@ -197,15 +216,29 @@ int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView
     }
     out.suffix = end_suffix;
 
-    // Open addressing, linear probing, load factor <= 0.5.
-    const uint32_t slots = std::max<uint32_t>(8, pow2_at_least(uint64_t(rank_of.size()) * 2 + 1));
-    out.slot_mask = slots - 1;
-    out.slot_shift = 64 - log2u(slots);
-    out.merges.assign(size_t(slots), MergeSlot{kEmptySlot, 0});
-    for (const auto& kv : rank_of) {
-        uint32_t p = uint32_t(hash_u64(kv.first) >> out.slot_shift) & out.slot_mask;
-        while (out.merges[p].kr != kEmptySlot) p = (p + 1) & out.slot_mask;
-        out.merges[p] = MergeSlot{(kv.first << kMaxRankBits) | kv.second, uint64_t(uint32_t(out.new_id[kv.second]))};
+    // Cuckoo table: 2 hash functions x buckets of 2 slots (load <= 0.75 of the slots; grown on the rare failure).
+    for (uint32_t buckets = std::max<uint32_t>(4, pow2_at_least((uint64_t(rank_of.size()) * 4 + 5) / 6));; buckets *= 2) {
+        out.bucket_shift = 64 - log2u(buckets);
+        std::vector<MergeSlot> flat(size_t(buckets) * 2, MergeSlot{kEmptySlot, 0});
+        uint64_t rng = 0x2545F4914F6CDD1Dull;
+        bool ok = true;
+        const uint32_t shift = out.bucket_shift;
+        for (const auto& kv : rank_of) {
+            const MergeSlot item{(kv.first << kMaxRankBits) | kv.second, uint64_t(uint32_t(out.new_id[kv.second]))};
+            ok = cuckoo_insert<MergeSlot, 4>(
+                flat, item,
+                [shift](const MergeSlot& m, uint32_t* idx) {
+                    const uint64_t key = m.kr >> kMaxRankBits;
+                    const uint32_t b1 = merge_h1(key, shift), b2 = merge_h2(key, shift);
+                    idx[0] = 2 * b1; idx[1] = 2 * b1 + 1; idx[2] = 2 * b2; idx[3] = 2 * b2 + 1;
+                },
+                [](const MergeSlot& m) { return m.kr == kEmptySlot; }, rng);
+            if (!ok) break;
+        }
+        if (!ok) continue;
+        out.merges.resize(buckets);
+        std::memcpy(out.merges.data(), flat.data(), flat.size() * sizeof(MergeSlot));
+        break;
     }
     return OVTK_OK;
 }
@@ -213,37 +246,39 @@ int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView
 // ------------------------------------------------------------------------------- piece memo
 void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
                        PieceTableHost& out) {
-    size_t eligible = 0;
-    for (int64_t i = 0; i < pieces.n; ++i) {
-        const int len = pieces.ends[i] - pieces.begins[i], cnt = id_ends[i] - id_begins[i];
-        if (len >= 1 && len <= kPieceKeyBytes && cnt >= 0 && cnt <= kPieceMaxIds) ++eligible;
-    }
-    const uint32_t cap = std::max<uint32_t>(8, pow2_at_least(uint64_t(eligible) * 2 + 1));
-    out.mask = cap - 1;
-    out.shift = 64 - log2u(cap);
-    out.slots.assign(size_t(cap), PieceEntry{0, 0, {0, 0, 0}, 0});
-    out.stored = 0;
+    std::unordered_map<std::string, PieceEntry> uniq;  // a repeated string keeps its first entry
     for (int64_t i = 0; i < pieces.n; ++i) {
         const int len = pieces.ends[i] - pieces.begins[i], cnt = id_ends[i] - id_begins[i];
         if (!(len >= 1 && len <= kPieceKeyBytes && cnt >= 0 && cnt <= kPieceMaxIds)) continue;
         uint8_t kb[16] = {0};
         std::memcpy(kb, pieces.chars + pieces.begins[i], size_t(len));
         kb[15] = uint8_t(len);
-        uint64_t k0, k1;
-        std::memcpy(&k0, kb, 8);
-        std::memcpy(&k1, kb + 8, 8);
-        uint32_t p = uint32_t(hash_piece(k0, k1) >> out.shift) & out.mask;
-        bool dup = false;
-        while (out.slots[p].k1 != 0) {
-            if (out.slots[p].k0 == k0 && out.slots[p].k1 == k1) { dup = true; break; }
-            p = (p + 1) & out.mask;
-        }
-        if (dup) continue;
-        PieceEntry e{k0, k1, {0, 0, 0}, cnt};
+        PieceEntry e{0, 0, {0, 0, 0}, cnt};
+        std::memcpy(&e.k0, kb, 8);
+        std::memcpy(&e.k1, kb + 8, 8);
         for (int k = 0; k < cnt; ++k) e.tok[k] = ids[id_begins[i] + k];
-        out.slots[p] = e;
-        ++out.stored;
+        uniq.emplace(std::string(reinterpret_cast<const char*>(kb), 16), e);
     }
+    // Cuckoo table: 3 hash functions x 1 entry, load <= 0.5.
+    for (uint32_t cap = std::max<uint32_t>(4, pow2_at_least(uint64_t(uniq.size()) * 2 + 1));; cap *= 2) {
+        out.shift = 64 - log2u(cap);
+        out.slots.assign(size_t(cap), PieceEntry{0, 0, {0, 0, 0}, 0});
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        bool ok = true;
+        const uint32_t shift = out.shift;
+        for (const auto& kv : uniq) {
+            ok = cuckoo_insert<PieceEntry, 3>(
+                out.slots, kv.second,
+                [shift](const PieceEntry& e, uint32_t* idx) {
+                    const uint64_t mix = piece_mix(e.k0, e.k1);
+                    for (int c = 0; c < 3; ++c) idx[c] = piece_h(mix, c, shift);
+                },
+                [](const PieceEntry& e) { return e.k1 == 0; }, rng);
+            if (!ok) break;
+        }
+        if (ok) break;
+    }
+    out.stored = uniq.size();
 }
 
 // ------------------------------------------------------------------------------- WordPiece

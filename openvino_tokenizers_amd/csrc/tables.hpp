@@ -9,12 +9,14 @@
 // Device layouts (all flat arrays, sized for L2 residency, probed with one or two 8/16-byte loads):
 //   trie      root[256] {value, child|leaf bit}; node[n] {value, has_children};
 //             edges: open-addressing table of u64 {key = node<<8|byte : 32, child : 32}
-//   merges    16-byte slots {left:21 | right:21 | rank:22} + {new_id}, linear probing; one
-//             global_load_dwordx4 per probe returns rank AND merged id; new_id[rank] also kept
-//             as a dense side array for the exact-heap path
-//   pieces    the piece memo: 32-byte entries {piece bytes (<= 15) + length : 16 B, ids[3], count}
-//             holding BPE(piece) for every vocabulary token used as a whole piece, computed
-//             once at create time by the device BPE itself (see api_encode.cpp)
+//   merges    cuckoo table, 2 hash functions x buckets of two 16-byte slots {left:21 | right:21 |
+//             rank:22} + {new_id}: a lookup is FOUR independent global_load_dwordx4 (both buckets),
+//             never a probe chain -- a wave waits for one round trip, not for its unluckiest lane;
+//             new_id[rank] also kept as a dense side array for the exact-heap path
+//   pieces    the piece memo: cuckoo table, 3 hash functions x one 32-byte entry {piece bytes
+//             (<= 15) + length : 16 B, ids[3], count} holding BPE(piece) for every vocabulary token
+//             used as a whole piece, computed once at create time by the device BPE itself (see
+//             api_encode.cpp); a lookup is three independent 32-byte loads
 //   strings   (VocabEncoder) open-addressing table of {hash32, key index}; keys stay in the
 //             decomposed begins/ends/chars form for the final byte compare
 #pragma once
@@ -58,15 +60,14 @@ struct alignas(32) PieceEntry {
 };
 struct PieceTableDev {
     const PieceEntry* slots;  // nullptr: no memo (every piece takes the merge path)
-    uint32_t mask;
     uint32_t shift;           // 64 - log2(capacity)
 };
+struct alignas(32) MergeBucket { MergeSlot s[2]; };
 
 struct BpeDev {
     TrieDev trie;
-    const MergeSlot* merges;    // [slot_mask+1]
-    uint32_t slot_mask;
-    uint32_t slot_shift;        // 64 - log2(slots)
+    const MergeBucket* merges;  // [1 << (64 - bucket_shift)]
+    uint32_t bucket_shift;      // 64 - log2(buckets)
     const int32_t* new_id;      // [n_merges]
     PieceTableDev pieces;
     const int32_t* byte_fallback_id;  // [256], -1 = none (all -1 when byte_fallback is off)
@@ -88,9 +89,18 @@ struct StringMapDev {
 __host__ __device__ inline uint32_t hash_u32(uint32_t k) { return k * 0x9E3779B1u; }
 __host__ __device__ inline uint64_t hash_u64(uint64_t k) { return k * 0x9E3779B97F4A7C15ull; }
 __host__ __device__ inline uint64_t merge_key(uint32_t l, uint32_t r) { return (uint64_t(l) << kMaxVocabBits) | r; }
-__host__ __device__ inline uint64_t hash_piece(uint64_t k0, uint64_t k1) {
+// Cuckoo hash functions: the top log2(buckets) bits of odd-constant multiplies (shift = 64 - log2(buckets) < 64).
+__host__ __device__ inline uint32_t merge_h1(uint64_t key, uint32_t shift) { return uint32_t((key * 0x9E3779B97F4A7C15ull) >> shift); }
+__host__ __device__ inline uint32_t merge_h2(uint64_t key, uint32_t shift) {
+    return uint32_t(((key ^ (key >> 23)) * 0xD6E8FEB86659FD93ull) >> shift);
+}
+__host__ __device__ inline uint64_t piece_mix(uint64_t k0, uint64_t k1) {
     uint64_t h = (k0 ^ (k1 * 0xC2B2AE3D27D4EB4Full)) * 0x9E3779B97F4A7C15ull;
     return h ^ (h >> 29);
+}
+__host__ __device__ inline uint32_t piece_h(uint64_t mix, int which, uint32_t shift) {
+    const uint64_t c = which == 0 ? 0x9E3779B97F4A7C15ull : (which == 1 ? 0xD6E8FEB86659FD93ull : 0xA0761D6478BD642Full);
+    return uint32_t((mix * c) >> shift);
 }
 // FNV-1a over the bytes; the same function on host (table build) and device (probe).
 __host__ __device__ inline uint32_t hash_bytes(const uint8_t* p, int n) {
@@ -117,8 +127,8 @@ struct TrieHost {
 
 struct BpeHost {
     TrieHost trie;
-    std::vector<MergeSlot> merges;
-    uint32_t slot_mask = 0, slot_shift = 64;
+    std::vector<MergeBucket> merges;
+    uint32_t bucket_shift = 62;
     std::vector<int32_t> new_id;
     std::vector<int32_t> byte_fallback_id;
     int32_t unk_id = -1;
@@ -138,7 +148,7 @@ int build_bpe(const StringsView& vocab, const StringsView& merges_left, const St
 // kPieceMaxIds ids are stored (a repeated string keeps its first entry -- all entries of one string are equal).
 struct PieceTableHost {
     std::vector<PieceEntry> slots;
-    uint32_t mask = 0, shift = 64;
+    uint32_t shift = 62;
     size_t stored = 0;
 };
 void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
