@@ -52,20 +52,40 @@ __device__ __forceinline__ void wave_sync() {
 
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
-// Inclusive prefix sum over the 64 lanes (Hillis-Steele on __shfl_up; 6 steps).
+// ---- DPP building blocks (VALU-speed cross-lane moves; __shfl goes through the LDS crossbar) ----
+constexpr int kDppRowShl = 0x100, kDppRowShr = 0x110, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+template <int CTRL, int ROW_MASK = 0xF, bool BOUND = true>
+__device__ __forceinline__ int dpp_mov0(int v) {  // lanes without a valid source / outside ROW_MASK receive 0
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, BOUND);
+}
+// Inclusive prefix sum over the 64 lanes: Hillis-Steele inside each row of 16, then two row broadcasts.
 __device__ __forceinline__ int wave_incl_sum(int v) {
-    const int l = lane_id();
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        int t = __shfl_up(v, d);
-        if (l >= d) v += t;
-    }
+    v += dpp_mov0<kDppRowShr + 1>(v);
+    v += dpp_mov0<kDppRowShr + 2>(v);
+    v += dpp_mov0<kDppRowShr + 4>(v);
+    v += dpp_mov0<kDppRowShr + 8>(v);
+    v += dpp_mov0<kDppRowBcast15, 0xA, false>(v);
+    v += dpp_mov0<kDppRowBcast31, 0xC, false>(v);
     return v;
 }
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+// Value of lane `src` (wave-uniform index) as a scalar.
+__device__ __forceinline__ int wave_readlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ unsigned long long wave_readlane(unsigned long long v, int src) {
+    const unsigned lo = unsigned(__builtin_amdgcn_readlane(int(unsigned(v)), src));
+    const unsigned hi = unsigned(__builtin_amdgcn_readlane(int(unsigned(v >> 32)), src));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+__device__ __forceinline__ int wave_sum(int v) { return wave_readlane(wave_incl_sum(v), kWave - 1); }
+// 64-bit value of the previous / next lane inside a row of 16 lanes (0 at the row's edge).
+__device__ __forceinline__ unsigned long long row_prev(unsigned long long v) {
+    const unsigned lo = unsigned(dpp_mov0<kDppRowShr + 1>(int(unsigned(v))));
+    const unsigned hi = unsigned(dpp_mov0<kDppRowShr + 1>(int(unsigned(v >> 32))));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long row_next(unsigned long long v) {
+    const unsigned lo = unsigned(dpp_mov0<kDppRowShl + 1>(int(unsigned(v))));
+    const unsigned hi = unsigned(dpp_mov0<kDppRowShl + 1>(int(unsigned(v >> 32))));
+    return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll

@@ -203,7 +203,7 @@ __device__ __forceinline__ void flush_misses(WaveMiss& mb, int& n_miss, int n, c
     const int shard = int(blockIdx.x) % kShards;
     int idx = 0;
     if (l == 0) idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
-    idx = __shfl(idx, 0);
+    idx = wave_readlane(idx, 0);
     if (l < n) {
         if (idx + l < w.shard_cap) w.deferred[(long long)shard * w.shard_cap + idx + l] = mb.e[l];
         else atomicOr(&w.status->flags, kFlagDeferOverflow);
@@ -245,8 +245,10 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
         wave_sync();
         if (n_miss >= kWave) flush_misses(mb, n_miss, kWave, w);
     }
-    st.used += __shfl(incl, kWave - 1);
-    st.emitted += wave_sum(hit ? cnt : 0);
+    st.used += wave_readlane(incl, kWave - 1);
+    // ids written by the hits: cnt is 0..3, summed as two bit-planes of ballots
+    const int c = hit ? cnt : 0;
+    st.emitted += __popcll(__ballot(c & 1)) + 2 * __popcll(__ballot(c & 2));
 }
 
 enum EncodeMode : int { kFused = 0, kPieces = 1 };
@@ -273,9 +275,6 @@ template <int MODE>
 static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
-    __shared__ uint8_t ascii_cls[128];
-    if (MODE == kFused && threadIdx.x < 128) ascii_cls[threadIdx.x] = uint8_t(uc_nibble(sp, threadIdx.x) & 7);
-    __syncthreads();
     if (w.status->flags & kFatalFlags) return;
     WaveScratch& ws = ws_all[wave_in_block()];
     WaveMiss& mb = miss_all[wave_in_block()];
@@ -295,7 +294,7 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
                 }
                 const int sb = in.begins[col], slen = in.ends[col] - sb;
                 scan_string(
-                    ws, sp, ascii_cls, in.chars + sb, slen,
+                    ws, sp, in.chars + sb, slen,
                     [&](int np, int c0, int w0, int skew) {
                         for (int jb = 0; jb < np; jb += kWave) {
                             const int j = jb + l;
@@ -475,9 +474,6 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
                                                                      int32_t* out_begins, int32_t* out_ends,
                                                                      uint8_t* out_skips) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
-    __shared__ uint8_t ascii_cls[128];
-    if (threadIdx.x < 128) ascii_cls[threadIdx.x] = uint8_t(uc_nibble(sp, threadIdx.x) & 7);
-    __syncthreads();
     if (w.status->flags & (kFlagRange | kFlagOutCapacity)) return;
     WaveScratch& ws = ws_all[wave_in_block()];
     const int l = lane_id();
@@ -506,7 +502,7 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
                 if (out_skips) out_skips[o + count + idx] = 0;
             };
             scan_string(
-                ws, sp, ascii_cls, in.chars + sb, se - sb,
+                ws, sp, in.chars + sb, se - sb,
                 [&](int np, int c0, int, int) {
                     for (int j = l; j < np; j += kWave) emit(j, c0 + int(ws.pstart[j]), c0 + int(ws.pstart[j + 1]));
                     in_string += np;

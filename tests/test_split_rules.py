@@ -64,3 +64,14 @@ def test_chunk_boundaries(backend):
         strings += ["a" * k + "'s b", "x" * k + "  y", " " * k + "z", "a" * k + " 'll", "é" * (k // 2) + "'t元",
                     "1" * k + "a" * 600, ("ab " * 200)[:k] + "\t\t" + "c" * 20, "a" * k + "\n\n" + "b" * k + " "]
     check(backend, GPT2_PATTERN, strings)
+
+
+@pytest.mark.parametrize("pattern", [GPT2_PATTERN, DIGITS_PATTERN], ids=["gpt2", "gpt2-digits"])
+def test_every_ascii_byte(backend, pattern):
+    """The scanners classify ASCII arithmetically (split_device.hpp ascii_class): every byte 1..127 in letter, digit,
+    space and string-edge contexts."""
+    strings = []
+    for c in range(1, 128):
+        ch = chr(c)
+        strings += [ch, "a" + ch + "a", " " + ch + " ", "1" + ch + ch + "1", ch + " x", "x " + ch, "'" + ch + "b", "x'" + ch]
+    check(backend, pattern, strings)
