@@ -118,8 +118,9 @@ inline int grid_lookup(int device, int n_rows) {
 }
 
 // The "ragged strings in -> ragged i32 out" pipeline shared by BPETokenizer, the fused encode and
-// WordpieceTokenizer: scan of row capacities (staging offsets) -> middle(ws, d_in, w) (the op's kernels: ids into
-// staging, per-row counts) -> scan of row counts (final offsets) -> compact.  Workspace overflows reported
+// WordpieceTokenizer: prep (validation + per-wave staging arenas) -> middle(ws, d_in, w, grid) (the op's kernels: ids
+// into staging, per-row counts; the first one must be launched with `grid` blocks, the geometry prep summed over) ->
+// count_scan (final offsets) -> compact.  Workspace overflows reported
 // by the kernels are handled by growing the buffer and running again.
 template <class Middle>
 int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
@@ -141,24 +142,28 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
     if (int rc = out_target(ws->out_b, out->ends, size_t(n_rows) * 4, mem, &d_ends)) return rc;
     if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_ids)) return rc;
 
+    const int grid = grid_lookup(device, n_rows);
+    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
     for (int attempt = 0; attempt < 6; ++attempt) {
         int e = 0;
-        e = e ? e : ws->row_stage.ensure(size_t(n_rows + 1) * 4);
+        e = e ? e : ws->row_stage.ensure(size_t(n_rows) * 4);
         e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
-        e = e ? e : ws->row_out.ensure(size_t(n_rows + 1) * 4);
         e = e ? e : ws->row_used.ensure(size_t(n_rows) * 4);
         e = e ? e : ws->stage.ensure(size_t(stage_cap) * 4);
         e = e ? e : ws->deferred.ensure(size_t(shard_cap) * kShards * sizeof(DeferredPiece));
         e = e ? e : ws->exact.ensure(size_t(exact_cap) * sizeof(ExactPiece));
         e = e ? e : ws->scratch.ensure(size_t(scratch_cap));
-        e = e ? e : ws->tiles.ensure(scan_tiles_bytes(n_rows));
+        e = e ? e : ws->wave_off.ensure(size_t(grid * kWavesPerBlock + 1) * sizeof(long long));
+        e = e ? e : ws->tiles.ensure(size_t(n_tiles + 1) * sizeof(long long));
         e = e ? e : ws->status.ensure(sizeof(RunStatus));
         if (e) return e;
         EncodeWork w{};
+        w.n_waves = grid * kWavesPerBlock;
+        w.wave_off = ws->wave_off.as<long long>();
         w.row_stage = ws->row_stage.as<int32_t>();
         w.row_cnt = ws->row_cnt.as<int32_t>();
-        w.row_out = ws->row_out.as<int32_t>();
         w.row_used = ws->row_used.as<int32_t>();
+        w.tile_off = ws->tiles.as<long long>();
         w.stage = ws->stage.as<int32_t>();
         w.stage_cap = int32_t(stage_cap);
         w.deferred = ws->deferred.as<DeferredPiece>();
@@ -167,17 +172,14 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
         w.exact_cap = int32_t(exact_cap);
         w.scratch = ws->scratch.as<uint8_t>();
         w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap, 0xFFFFFFF0ll));
-        w.tiles = ws->tiles.as<long long>();
         w.status = ws->status.as<RunStatus>();
 
         OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-        launch_scan(ws->marks, "scan_rows", s, n_rows, RowCapLen{d_in, mul, w.status}, RowCapApply{w.row_stage},
-                    RowCapFin{w, n_rows}, w.tiles, w.status, kFlagRange);
-        middle(*ws.ws, d_in, w);
-        OVTK_LAUNCH(ws->marks, "count_rows", count_rows_kernel, grid_lookup(device, n_rows), kBlockThreads, s, n_rows, w);
-        launch_scan(ws->marks, "scan_rows", s, n_rows, RowCntLen{w.row_cnt}, RowOutApply{w.row_out, d_begins, d_ends},
-                    RowOutFin{w, n_rows, (long long)out->data_capacity}, w.tiles, w.status, kFatalFlags);
-        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_lookup(device, n_rows), kBlockThreads, s, n_rows, w, d_ids);
+        OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, grid, kBlockThreads, s, d_in, mul, w);
+        middle(*ws.ws, d_in, w, grid);
+        OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, n_tiles, kBlockThreads, s, n_rows, w, 1,
+                    (long long)out->data_capacity);
+        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid, kBlockThreads, s, n_rows, w, d_ids, d_begins, d_ends);
         if (int rc = finish_status(*ws.ws, s)) return rc;
 
         const RunStatus& st = *ws->host_status;

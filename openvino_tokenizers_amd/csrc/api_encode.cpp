@@ -235,16 +235,15 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
     }
     if (in->n_rows == 0) return OVTK_OK;
 
-    const int n_rows = int(in->n_rows);
     const int dev = bpe->device;
     return run_rows_to_ids(dev, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
-                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w) {
+                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                if (split)
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid_lookup(dev, n_rows),
-                                               kBlockThreads, s, d_in, split->dev, bpe->dev, w);
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in,
+                                               split->dev, bpe->dev, w);
                                else
-                                   OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid_lookup(dev, n_rows),
-                                               kBlockThreads, s, d_in, SplitDev{}, bpe->dev, w);
+                                   OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid, kBlockThreads, s, d_in,
+                                               SplitDev{}, bpe->dev, w);
                                OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(std::max(1, device_cu_count(dev) * 3 / kShards), kShards),
                                            kBlockThreads, s, d_in, bpe->dev, w);
                                OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
@@ -295,11 +294,12 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     RowsIn d_in{};
     if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
     const int n_rows = d_in.n_rows;
+    const int grid = grid_lookup(h->device, n_rows);
+    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
     int e = 0;
-    e = e ? e : ws->row_stage.ensure(size_t(n_rows + 1) * 4);
     e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
-    e = e ? e : ws->row_out.ensure(size_t(n_rows + 1) * 4);
-    e = e ? e : ws->tiles.ensure(scan_tiles_bytes(n_rows));
+    e = e ? e : ws->wave_off.ensure(size_t(grid * kWavesPerBlock + 1) * sizeof(long long));
+    e = e ? e : ws->tiles.ensure(size_t(n_tiles + 1) * sizeof(long long));
     e = e ? e : ws->status.ensure(sizeof(RunStatus));
     if (e) return e;
     int32_t *d_rb = nullptr, *d_re = nullptr, *d_b = nullptr, *d_e = nullptr;
@@ -311,23 +311,20 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     if (out->skips) e = e ? e : out_target(ws->out_e, out->skips, size_t(out->capacity), mem, &d_sk);
     if (e) return e;
     EncodeWork w{};
-    w.row_stage = ws->row_stage.as<int32_t>();
+    w.n_waves = grid * kWavesPerBlock;
+    w.wave_off = ws->wave_off.as<long long>();
     w.row_cnt = ws->row_cnt.as<int32_t>();
-    w.row_out = ws->row_out.as<int32_t>();
+    w.tile_off = ws->tiles.as<long long>();
     w.stage_cap = INT32_MAX;
-    w.tiles = ws->tiles.as<long long>();
     w.status = ws->status.as<RunStatus>();
     OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-    // range validation of the inputs (the capacity offsets themselves are not needed here)
-    launch_scan(ws->marks, "scan_rows", s, n_rows, RowCapLen{d_in, 1, w.status}, RowCapApply{w.row_stage},
-                RowCapFin{w, n_rows}, w.tiles, w.status, kFlagRange);
-    const int grid = grid_lookup(h->device, n_rows);
+    // range validation of the inputs (the staging arenas it also computes are not needed here)
+    OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, grid, kBlockThreads, s, d_in, 1, w);
     OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
-                (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
-    launch_scan(ws->marks, "scan_rows", s, n_rows, RowCntLen{w.row_cnt}, RowOutApply{w.row_out, d_rb, d_re},
-                RowOutFin{w, n_rows, (long long)out->capacity}, w.tiles, w.status, kFlagRange);
-    OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_b,
-                d_e, d_sk);
+                (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
+    OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, n_tiles, kBlockThreads, s, n_rows, w, 0, (long long)out->capacity);
+    OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb, d_re,
+                d_b, d_e, d_sk);
     if (int rc = finish_status(*ws.ws, s)) return rc;
     const RunStatus& st = *ws->host_status;
     if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");

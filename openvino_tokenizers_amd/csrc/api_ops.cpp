@@ -119,11 +119,10 @@ int ovtk_wordpiece_run(ovtk_wordpiece* h, const ovtk_ragged_strings* in, int32_t
     out->n_data = 0;
     out->n_rows = in->n_rows;
     if (in->n_rows == 0) return OVTK_OK;
-    const int n_rows = int(in->n_rows);
     return run_rows_to_ids(h->device, "WordpieceTokenizer", in, nullptr, 1, out, mem, s,
-                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w) {
-                               OVTK_LAUNCH(ws.marks, "wordpiece", wordpiece_kernel, grid_for_rows(n_rows), kBlockThreads, s,
-                                           d_in, h->dev, unk_token_id, w);
+                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
+                               OVTK_LAUNCH(ws.marks, "wordpiece", wordpiece_kernel, grid, kBlockThreads, s, d_in, h->dev,
+                                           unk_token_id, w);
                            });
 }
 

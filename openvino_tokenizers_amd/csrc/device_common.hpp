@@ -28,7 +28,8 @@ struct RunStatus {
     int32_t n_exact;       // pieces handed to the exact-heap kernel
     uint32_t scratch_used; // bytes taken from the exact kernel's scratch pool
     uint32_t flags;        // kFlag*
-    int32_t pad[26];
+    uint32_t ticket[2];    // "last block done" tickets of prep_rows_kernel / count_scan_kernel
+    int32_t pad[24];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
 };
 constexpr uint32_t kFlagItemsOverflow = 1u;     // more work items than the workspace holds
@@ -49,6 +50,17 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
+
+// Publishing data to other workgroups of the same launch (MI355X_MICROARCH.md "inter-workgroup visibility"): the
+// producer's plain stores -> __syncthreads() -> ONE lane: agent-scope release + vmcnt drain -> device-scope atomic
+// ticket; the block that draws the last ticket does an agent-scope acquire -> __syncthreads() -> plain loads.
+__device__ __forceinline__ void publish_release() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifndef OVTK_SIMT_EMULATOR
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void publish_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 

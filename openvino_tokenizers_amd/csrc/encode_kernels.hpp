@@ -1,20 +1,23 @@
 // encode_kernels.hpp -- the gfx950 kernels of RegexSplit, BPETokenizer and their fusion.
 //
-// Pipeline of one BPETokenizer / fused encode call (host side: api_common.hpp run_rows_to_ids):
-//   scan(row capacity)          staging offset of every row                        (scan_kernels.hpp)
-//   lookup_kernel<kFused>       ONE WAVE PER ROW: split scanner -> pieces -> piece memo probe
+// Pipeline of one BPETokenizer / fused encode call (host side: api_common.hpp run_rows_to_ids), 6 launches:
+//   prep_rows_kernel            validates the offsets; staging capacity of every wave's rows; the block that finishes
+//                               last scans them into per-wave arena offsets
+//   lookup_kernel<kFused>       ONE WAVE PER ROW (persistent waves, rows strided): split scanner -> pieces -> memo probe
 //   lookup_kernel<kPieces>      same for pre-split pieces (the BPETokenizer op contract)
 //       a piece found in the memo (tables.hpp PieceEntry: BPE(piece) precomputed for every vocabulary
-//       token) writes its ids straight into the row's staging region; any other piece reserves
+//       token) writes its ids straight into the row's staging stretch; any other piece reserves
 //       len + |end_suffix| staging entries and goes to the deferred list (per-wave LDS buffer, flushed 64 at a
 //       time into one of kShards list regions)
 //   merge_kernel                dense batches of 64 deferred pieces: path F (lane per piece), path W (wave
 //                               per piece), ties / oversized pieces -> exact list           (bpe_device.hpp)
 //   exact_kernel                path X, one lane per piece
-//   count_rows_kernel           ids per row = non-empty staging entries (rows that had deferred pieces)
-//   scan(row token counts)      final offsets = the reference's running `ragged_offset` (bpe_tokenizer.cpp:141-161)
-//   compact_kernel              staging -> caller's ids buffer (rows with deferred pieces have unused entries
-//                               = kEmptyId in their reserved stretches; they are squeezed out by ballot compaction)
+//   count_scan_kernel           ids per row (rows that had deferred pieces are recounted: non-empty staging entries),
+//                               per-tile sums, last block scans them = the reference's running `ragged_offset`
+//                               (bpe_tokenizer.cpp:141-161) at tile granularity
+//   compact_kernel              row offset = tile offset + in-tile prefix (rebuilt by the wave), begins/ends, and
+//                               staging -> caller's ids buffer (unused entries = kEmptyId are squeezed out by ballot
+//                               compaction)
 #pragma once
 
 #include "bpe_device.hpp"
@@ -46,11 +49,15 @@ struct ExactPiece { int32_t begin, len, stage_pos, row; };
 
 constexpr int kMissBuf = 128;  // per-wave LDS buffer of deferred pieces (flushed when >= 64 are pending)
 
+constexpr int kRowTile = 64;  // rows per tile of the final offset scan
+
 struct EncodeWork {
-    int32_t* row_stage;     // [n_rows + 1] staging offset of each row (exclusive scan of capacities)
+    int32_t n_waves;        // persistent waves of the prep / lookup launches (wave w owns rows w, w + n_waves, ...)
+    long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities)
+    int32_t* row_stage;     // [n_rows]     staging offset of each row (set by the lookup kernel)
     int32_t* row_cnt;       // [n_rows]     ids produced by each row
     int32_t* row_used;      // [n_rows]     staging entries the row occupies (> row_cnt: it has unused entries)
-    int32_t* row_out;       // [n_rows + 1] final offset of each row
+    long long* tile_off;    // [n_tiles]    output offset of each tile of kRowTile rows
     int32_t* stage;
     int32_t stage_cap;
     DeferredPiece* deferred;  // kShards regions of shard_cap entries
@@ -59,77 +66,76 @@ struct EncodeWork {
     int32_t exact_cap;
     uint8_t* scratch;
     uint32_t scratch_cap;
-    long long* tiles;       // scan temporaries
     RunStatus* status;
 };
 
 constexpr uint32_t kFatalFlags = kFlagRange | kFlagStageOverflow;
 
 // ---- row capacity: mul * sum over the row's strings of max(len, 1), with range validation.
-struct RowCapLen {
-    RowsIn in;
-    int mul;
-    RunStatus* status;
-    __device__ long long operator()(long long row) const {
-        long long cap = 0;
-        const int b = in.ragged_begins[row], e = in.ragged_ends[row];
-        if (b < e && (b < 0 || e > in.n_strings)) {
+__device__ __forceinline__ long long row_capacity(const RowsIn& in, int mul, long long row, RunStatus* status) {
+    long long cap = 0;
+    const int b = in.ragged_begins[row], e = in.ragged_ends[row];
+    if (b < e && (b < 0 || e > in.n_strings)) {
+        atomicOr(&status->flags, kFlagRange);
+        return 0;
+    }
+    for (int col = b; col < e; ++col) {
+        const long long sb = in.begins[col], se = in.ends[col];
+        if (sb < 0 || se < sb || se > in.n_chars) {
             atomicOr(&status->flags, kFlagRange);
             return 0;
         }
-        for (int col = b; col < e; ++col) {
-            const long long sb = in.begins[col], se = in.ends[col];
-            if (sb < 0 || se < sb || se > in.n_chars) {
-                atomicOr(&status->flags, kFlagRange);
-                return 0;
-            }
-            cap += (se - sb > 0 ? se - sb : 1) * mul;
-        }
-        return cap;
+        cap += (se - sb > 0 ? se - sb : 1) * mul;
     }
-};
-struct RowCapApply {
-    int32_t* row_stage;
-    __device__ void operator()(long long row, long long off, long long) const {
-        row_stage[row] = off > INT32_MAX ? INT32_MAX : int32_t(off);
+    return cap;
+}
+
+// True in every thread of the block that draws the last of `n_blocks` tickets; its loads then see what all other
+// blocks stored before taking theirs.
+__device__ __forceinline__ bool last_block_done(uint32_t* ticket, unsigned n_blocks) {
+    __shared__ int is_last_s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        publish_release();
+        const bool last = atomicAdd(ticket, 1u) == n_blocks - 1u;
+        if (last) publish_acquire();
+        is_last_s = last ? 1 : 0;
     }
-};
-struct RowCapFin {
-    EncodeWork w;
-    int32_t n_rows;
-    __device__ void operator()(long long total) const {
-        const int32_t t = total > INT32_MAX ? INT32_MAX : int32_t(total);
-        w.row_stage[n_rows] = t;
-        w.status->stage_need = t;
+    __syncthreads();
+    return is_last_s != 0;
+}
+
+// One launch with the lookup kernel's geometry: wave w sums the capacities of its rows; the last block scans.
+static __global__ __launch_bounds__(kBlockThreads) void prep_rows_kernel(RowsIn in, int mul, EncodeWork w) {
+    const int l = lane_id();
+    const int wave = int(blockIdx.x) * kWavesPerBlock + wave_in_block();
+    long long cap = 0;
+    for (long long row = wave + (long long)l * w.n_waves; row < in.n_rows; row += (long long)kWave * w.n_waves)
+        cap += row_capacity(in, mul, row, w.status);
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) cap += __shfl_xor(cap, d);
+    if (l == 0) w.wave_off[wave] = cap;
+    if (!last_block_done(&w.status->ticket[0], gridDim.x)) return;
+    const long long total = block_exclusive_scan<kBlockThreads>(
+        w.n_waves, [&](int i) -> long long { return w.wave_off[i]; }, [&](int i, long long off) { w.wave_off[i] = off; });
+    if (threadIdx.x == 0) {
+        w.wave_off[w.n_waves] = total;
+        w.status->stage_need = total > INT32_MAX ? INT32_MAX : int32_t(total);
         if (total > (long long)w.stage_cap) atomicOr(&w.status->flags, kFlagStageOverflow);
     }
-};
+}
 
-// ---- final offsets from the per-row counts.
-struct RowCntLen {
-    const int32_t* row_cnt;
-    __device__ long long operator()(long long row) const { return row_cnt[row]; }
-};
-struct RowOutApply {
-    int32_t* row_out;
-    int32_t* out_begins;  // may be nullptr
-    int32_t* out_ends;
-    __device__ void operator()(long long row, long long off, long long len) const {
-        row_out[row] = int32_t(off);
-        if (out_begins) out_begins[row] = int32_t(off);
-        if (out_ends) out_ends[row] = int32_t(off + len);
-    }
-};
-struct RowOutFin {
-    EncodeWork w;
-    int32_t n_rows;
-    long long out_cap;
-    __device__ void operator()(long long total) const {
-        w.row_out[n_rows] = total > INT32_MAX ? INT32_MAX : int32_t(total);
-        w.status->n_out = total > INT32_MAX ? INT32_MAX : int32_t(total);
-        if (total > out_cap) atomicOr(&w.status->flags, kFlagOutCapacity);
-    }
-};
+// Output offset of `row` from the tile offsets: tile offset + prefix of the counts of the rows before it in its tile.
+// Wave-uniform call (row uniform); also returns the row's own count.
+__device__ __forceinline__ long long row_output_offset(const EncodeWork& w, int n_rows, int row, int& cnt) {
+    const int tile = row / kRowTile, first = tile * kRowTile;
+    const int r = first + lane_id();
+    const int c = r < n_rows ? w.row_cnt[r] : 0;
+    const int incl = wave_incl_sum(c);
+    const int j = row - first;
+    cnt = wave_readlane(c, j);
+    return w.tile_off[tile] + (wave_readlane(incl, j) - cnt);
+}
 
 // ---- memo probe -------------------------------------------------------------------------------
 // Key of a piece of 1..15 bytes given its first 16 bytes (garbage beyond plen is masked off).
@@ -280,9 +286,11 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
     WaveMiss& mb = miss_all[wave_in_block()];
     const int l = lane_id();
     int n_miss = 0;
-    const int n_waves = int(gridDim.x) * kWavesPerBlock;
-    for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < in.n_rows; row += n_waves) {
-        RowState st{w.row_stage[row], 0, 0, row};
+    const int n_waves = w.n_waves;  // == gridDim.x * kWavesPerBlock: the geometry prep_rows_kernel summed over
+    const int wave = int(blockIdx.x) * kWavesPerBlock + wave_in_block();
+    int cursor = int(w.wave_off[wave]);  // rows of this wave are staged back to back in its arena
+    for (int row = wave; row < in.n_rows; row += n_waves) {
+        RowState st{cursor, 0, 0, row};
         const int cb = in.ragged_begins[row], ce = in.ragged_ends[row];
         if (MODE == kPieces) {
             lookup_whole_strings(T, st, w, mb, n_miss, in, cb, ce);
@@ -315,9 +323,11 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
             }
         }
         if (l == 0) {
+            w.row_stage[row] = cursor;
             w.row_cnt[row] = st.emitted;
             w.row_used[row] = st.used;
         }
+        cursor += st.used;
     }
     if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
 }
@@ -427,32 +437,61 @@ static __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, 
     }
 }
 
-// ---- ids per row once the deferred pieces are in: rows whose staging stretch has unused entries are recounted
-// (coalesced, contention-free -- cheaper than one device-scope atomic per deferred piece).
-static __global__ __launch_bounds__(kBlockThreads) void count_rows_kernel(int n_rows, EncodeWork w) {
-    if (w.status->flags & (kFatalFlags | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow)) return;
-    const int l = lane_id();
-    const int n_waves = int(gridDim.x) * kWavesPerBlock;
-    for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < n_rows; row += n_waves) {
-        const int used = w.row_used[row];
-        if (used == w.row_cnt[row]) continue;  // no deferred piece in this row
-        const int32_t* p = w.stage + w.row_stage[row];
+// ---- ids per row once the deferred pieces are in + the tile scan of the final offsets.  One block per tile of
+// kRowTile rows: rows whose staging stretch has unused entries are recounted (coalesced, contention-free -- cheaper
+// than one device-scope atomic per deferred piece); the last block scans the tile sums.  recount == 0: row_cnt is
+// final already (RegexSplit piece counts).
+static __global__ __launch_bounds__(kBlockThreads) void count_scan_kernel(int n_rows, EncodeWork w, int recount,
+                                                                         long long out_cap) {
+    __shared__ int tile_cnt[kRowTile];
+    const int l = lane_id(), wv = wave_in_block();
+    const int first = int(blockIdx.x) * kRowTile;
+    const bool bad = (w.status->flags & (kFatalFlags | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow)) != 0;
+    for (int j = wv; j < kRowTile; j += kWavesPerBlock) {
+        const int row = first + j;
         int cnt = 0;
-        for (int b = l; b < used; b += kWave) cnt += p[b] != kEmptyId;
-        cnt = wave_sum(cnt);
-        if (l == 0) w.row_cnt[row] = cnt;
+        if (row < n_rows && !bad) {
+            cnt = w.row_cnt[row];
+            const int used = recount ? w.row_used[row] : cnt;
+            if (used != cnt) {  // the row had deferred pieces
+                const int32_t* p = w.stage + w.row_stage[row];
+                int c = 0;
+                for (int b = l; b < used; b += kWave) c += p[b] != kEmptyId;
+                cnt = wave_sum(c);
+                if (l == 0) w.row_cnt[row] = cnt;
+            }
+        }
+        if (l == 0) tile_cnt[j] = cnt;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const int s = wave_sum(tile_cnt[l]);
+        if (l == 0) w.tile_off[blockIdx.x] = s;
+    }
+    if (!last_block_done(&w.status->ticket[1], gridDim.x)) return;
+    const long long total = block_exclusive_scan<kBlockThreads>(
+        int(gridDim.x), [&](int i) -> long long { return w.tile_off[i]; }, [&](int i, long long off) { w.tile_off[i] = off; });
+    if (threadIdx.x == 0) {
+        w.status->n_out = total > INT32_MAX ? INT32_MAX : int32_t(total);
+        if (total > out_cap) atomicOr(&w.status->flags, kFlagOutCapacity);
     }
 }
 
-// ---- staging -> caller's buffer, one wave per row.
-static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out) {
+// ---- staging -> caller's buffer + the row's begins/ends, one wave per row.
+static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out,
+                                                                       int32_t* out_begins, int32_t* out_ends) {
     if (w.status->flags & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow))
         return;
     const int l = lane_id();
     const int n_waves = int(gridDim.x) * kWavesPerBlock;
     for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < n_rows; row += n_waves) {
+        int cnt = 0;
+        const int o = int(row_output_offset(w, n_rows, row, cnt));
+        if (l == 0) {
+            out_begins[row] = o;
+            out_ends[row] = o + cnt;
+        }
         const int base = w.row_stage[row], used = w.row_used[row];
-        const int cnt = w.row_cnt[row], o = w.row_out[row];
         if (used == cnt) {
             for (int k = l; k < cnt; k += kWave) out[o + k] = w.stage[base + k];
         } else {
@@ -471,6 +510,7 @@ static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_row
 // mode 0: row_cnt[row] = number of pieces.  mode 1: write begins/ends/skips at row_out[row].
 template <int WRITE>
 static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, SplitDev sp, int max_splits, EncodeWork w,
+                                                                     int32_t* out_rb, int32_t* out_re,
                                                                      int32_t* out_begins, int32_t* out_ends,
                                                                      uint8_t* out_skips) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
@@ -480,7 +520,12 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
     const int n_waves = int(gridDim.x) * kWavesPerBlock;
     for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < in.n_rows; row += n_waves) {
         int count = 0;
-        const int o = WRITE ? w.row_out[row] : 0;
+        int total = 0;
+        const int o = WRITE ? int(row_output_offset(w, in.n_rows, row, total)) : 0;
+        if (WRITE && l == 0) {
+            out_rb[row] = o;
+            out_re[row] = o + total;
+        }
         for (int col = in.ragged_begins[row]; col < in.ragged_ends[row]; ++col) {
             const int sb = in.begins[col], se = in.ends[col];
             if (in.skips && in.skips[col]) {

@@ -28,9 +28,11 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn 
     __syncthreads();
     if (w.status->flags & (kFlagRange | kFlagStageOverflow)) return;
     const int l = lane_id();
-    const int n_waves = int(gridDim.x) * kWavesPerBlock;
-    for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < in.n_rows; row += n_waves) {
-        const int base = w.row_stage[row];
+    const int n_waves = w.n_waves;  // the geometry prep_rows_kernel summed the staging arenas over
+    const int wave = int(blockIdx.x) * kWavesPerBlock + wave_in_block();
+    int cursor = int(w.wave_off[wave]);
+    for (int row = wave; row < in.n_rows; row += n_waves) {
+        const int base = cursor;
         const int cb = in.ragged_begins[row], ce = in.ragged_ends[row];
         int bytepos = 0, emitted = 0;
         for (int c0 = cb; c0 < ce; c0 += kWave) {
@@ -73,9 +75,11 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn 
             bytepos += __shfl(incl, kWave - 1);
         }
         if (l == 0) {
+            w.row_stage[row] = base;
             w.row_cnt[row] = emitted;
             w.row_used[row] = bytepos;
         }
+        cursor += bytepos;
     }
 }
 

@@ -77,7 +77,7 @@ private:
 // Scratch memory of one in-flight run() call.  Handles are immutable; every call checks a
 // workspace out of the per-device pool, so concurrent calls never share mutable state.
 struct Workspace {
-    DevBuf row_stage, row_cnt, row_out, row_used, stage, deferred, exact, scratch, tiles, status;
+    DevBuf row_stage, row_cnt, row_used, stage, deferred, exact, scratch, wave_off, tiles, status;
     DevBuf in_rb, in_re, in_begins, in_ends, in_chars, in_skips;  // staging for OVTK_MEM_HOST calls
     DevBuf out_a, out_b, out_c, out_d, out_e;
     DevBuf gen[8];  // op-specific inputs / temporaries (api_ops.cpp)

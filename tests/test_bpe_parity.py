@@ -60,9 +60,10 @@ def run_all_paths(backend, tok, inputs, skips=None, pattern=None):
     assert_same(sp_ref[:4], sp[:4], backend.host, "RegexSplit")
     if skips is not None:
         assert_same([sp_ref[5]], [sp[5]], backend.host, "RegexSplit skips")
-    got = BPETokenizer(**tok.attrs, lib=backend.lib).evaluate(list(sp[:5]) + tok.consts)
+    bpe = BPETokenizer(**tok.attrs, lib=backend.lib)  # one handle (one memo build) serves the op and the fused path
+    got = bpe.evaluate(list(sp[:5]) + tok.consts)
     assert_same(ref, got, backend.host, "BPETokenizer")
-    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), bpe)
     got2 = fused.evaluate(data + sk + [pat], tok.consts)
     assert_same(ref, got2, backend.host, "fused")
     return ref

@@ -41,8 +41,12 @@ def check(backend, pattern, strings):
 
 @pytest.mark.parametrize("pattern", [GPT2_PATTERN, DIGITS_PATTERN], ids=["gpt2", "gpt2-digits"])
 def test_exhaustive_short_strings(backend, pattern):
-    n = 3 if backend.name == "emu" else 4
-    strings = ["".join(t) for k in range(1, n + 1) for t in itertools.product(ALPHABET, repeat=k)]
+    if backend.name == "emu":  # the emulator is slow: all 1- and 2-grams + a seeded sample of the 3- and 4-grams
+        rng = np.random.default_rng(7)
+        strings = ["".join(t) for k in (1, 2) for t in itertools.product(ALPHABET, repeat=k)]
+        strings += ["".join(rng.choice(ALPHABET, size=int(k))) for k in rng.integers(3, 5, size=1200)]
+    else:
+        strings = ["".join(t) for k in range(1, 5) for t in itertools.product(ALPHABET, repeat=k)]
     check(backend, pattern, strings)
 
 

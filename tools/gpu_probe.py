@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, str(__import__("pathlib").Path(__file__).resolve().parent.parent))
 from openvino_tokenizers_amd import _lib as L
 from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
 from tools.harness import BpeTok
