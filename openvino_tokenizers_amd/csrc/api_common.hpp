@@ -112,6 +112,7 @@ inline void launch_scan(std::vector<Profiler::Mark>& marks, const char* tag, hip
 }
 inline size_t scan_tiles_bytes(long long n) { return size_t((n + kTileElems - 1) / kTileElems + 1) * sizeof(long long); }
 
+constexpr int kTicketBlocks = 256;  // blocks of the launches that end with a "last block done" ticket
 // Persistent grids: enough blocks to fill the chip at the kernel's occupancy, rows / list entries are strided.
 inline int grid_lookup(int device, int n_rows) {
     return std::max(1, std::min((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, device_cu_count(device) * 6));
@@ -175,10 +176,10 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
         w.status = ws->status.as<RunStatus>();
 
         OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-        OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, grid, kBlockThreads, s, d_in, mul, w);
+        OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, mul, w);
         middle(*ws.ws, d_in, w, grid);
-        OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, n_tiles, kBlockThreads, s, n_rows, w, 1,
-                    (long long)out->data_capacity);
+        OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s,
+                    n_rows, w, (long long)out->data_capacity);
         OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid, kBlockThreads, s, n_rows, w, d_ids, d_begins, d_ends);
         if (int rc = finish_status(*ws.ws, s)) return rc;
 

@@ -319,10 +319,11 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     w.status = ws->status.as<RunStatus>();
     OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
     // range validation of the inputs (the staging arenas it also computes are not needed here)
-    OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, grid, kBlockThreads, s, d_in, 1, w);
+    OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);
     OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
                 (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
-    OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, n_tiles, kBlockThreads, s, n_rows, w, 0, (long long)out->capacity);
+    OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s, n_rows,
+                w, (long long)out->capacity);
     OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb, d_re,
                 d_b, d_e, d_sk);
     if (int rc = finish_status(*ws.ws, s)) return rc;

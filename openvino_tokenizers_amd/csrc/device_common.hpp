@@ -80,6 +80,17 @@ __device__ __forceinline__ int wave_incl_sum(int v) {
     v += dpp_mov0<kDppRowBcast31, 0xC, false>(v);
     return v;
 }
+// Inclusive prefix maximum over the 64 lanes, non-negative values (0 is the identity the DPP moves fill in).
+__device__ __forceinline__ int wave_incl_max(int v) {
+    int t;
+    t = dpp_mov0<kDppRowShr + 1>(v); v = t > v ? t : v;
+    t = dpp_mov0<kDppRowShr + 2>(v); v = t > v ? t : v;
+    t = dpp_mov0<kDppRowShr + 4>(v); v = t > v ? t : v;
+    t = dpp_mov0<kDppRowShr + 8>(v); v = t > v ? t : v;
+    t = dpp_mov0<kDppRowBcast15, 0xA, false>(v); v = t > v ? t : v;
+    t = dpp_mov0<kDppRowBcast31, 0xC, false>(v); v = t > v ? t : v;
+    return v;
+}
 // Value of lane `src` (wave-uniform index) as a scalar.
 __device__ __forceinline__ int wave_readlane(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ unsigned long long wave_readlane(unsigned long long v, int src) {

@@ -12,9 +12,8 @@
 //   merge_kernel                dense batches of 64 deferred pieces: path F (lane per piece), path W (wave
 //                               per piece), ties / oversized pieces -> exact list           (bpe_device.hpp)
 //   exact_kernel                path X, one lane per piece
-//   count_scan_kernel           ids per row (rows that had deferred pieces are recounted: non-empty staging entries),
-//                               per-tile sums, last block scans them = the reference's running `ragged_offset`
-//                               (bpe_tokenizer.cpp:141-161) at tile granularity
+//   count_scan_kernel           per-tile sums of the row counts, last block scans them = the reference's running
+//                               `ragged_offset` (bpe_tokenizer.cpp:141-161) at tile granularity
 //   compact_kernel              row offset = tile offset + in-tile prefix (rebuilt by the wave), begins/ends, and
 //                               staging -> caller's ids buffer (unused entries = kEmptyId are squeezed out by ballot
 //                               compaction)
@@ -108,15 +107,19 @@ __device__ __forceinline__ bool last_block_done(uint32_t* ticket, unsigned n_blo
 // One launch with the lookup kernel's geometry: wave w sums the capacities of its rows; the last block scans.
 static __global__ __launch_bounds__(kBlockThreads) void prep_rows_kernel(RowsIn in, int mul, EncodeWork w) {
     const int l = lane_id();
-    const int wave = int(blockIdx.x) * kWavesPerBlock + wave_in_block();
-    long long cap = 0;
-    for (long long row = wave + (long long)l * w.n_waves; row < in.n_rows; row += (long long)kWave * w.n_waves)
-        cap += row_capacity(in, mul, row, w.status);
+    // few blocks (every block draws a ticket from ONE counter): each of this launch's waves covers several of the
+    // lookup launch's waves
+    const int my_waves = int(gridDim.x) * kWavesPerBlock;
+    for (int wave = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); wave < w.n_waves; wave += my_waves) {
+        long long cap = 0;
+        for (long long row = wave + (long long)l * w.n_waves; row < in.n_rows; row += (long long)kWave * w.n_waves)
+            cap += row_capacity(in, mul, row, w.status);
 #pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) cap += __shfl_xor(cap, d);
-    if (l == 0) w.wave_off[wave] = cap;
+        for (int d = kWave / 2; d > 0; d >>= 1) cap += __shfl_xor(cap, d);
+        if (l == 0) w.wave_off[wave] = cap;
+    }
     if (!last_block_done(&w.status->ticket[0], gridDim.x)) return;
-    const long long total = block_exclusive_scan<kBlockThreads>(
+    const long long total = block_exclusive_scan<kBlockThreads, 16>(
         w.n_waves, [&](int i) -> long long { return w.wave_off[i]; }, [&](int i, long long off) { w.wave_off[i] = off; });
     if (threadIdx.x == 0) {
         w.wave_off[w.n_waves] = total;
@@ -358,6 +361,7 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
         const bool is_w = valid && !is_f && need <= kChunkSyms;
         bool is_x = valid && !is_f && !is_w;
         int32_t* out = w.stage + e.stage_pos;
+        int f_cnt = 0;
         wave_sync();  // the previous batch is done with the LDS arrays
         if (is_f) {
             const uint64_t k0 = e.k0, k1 = e.k1;
@@ -375,7 +379,18 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
             } else {
                 for (int k = 0; k < res; ++k) out[k] = int32_t(id[k * kWave + l]);
                 for (int k = res; k < need; ++k) out[k] = kEmptyId;
+                f_cnt = res;
             }
+        }
+        // ids of the lane-per-piece results go to row_cnt: the 64 entries of a batch were flushed by ONE wave in
+        // row order, so equal rows are contiguous -- one atomic per run of equal rows instead of one per piece
+        {
+            const int incl = wave_incl_sum(f_cnt);
+            const int my_row = valid ? e.row : -1;
+            const int prev_row = __shfl_up(my_row, 1), next_row = __shfl_down(my_row, 1);
+            const bool head = l == 0 || prev_row != my_row, tail = l == kWave - 1 || next_row != my_row;
+            const int seg_base = wave_incl_max(head ? incl - f_cnt : 0);  // prefix before this lane's run (monotone)
+            if (valid && tail && incl - seg_base > 0) atomicAdd(&w.row_cnt[e.row], incl - seg_base);
         }
         unsigned long long wm = __ballot(is_w);
         while (wm) {
@@ -399,6 +414,7 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
             } else {
                 int32_t* o = w.stage + s_pos;
                 for (int k = l; k < s_need; k += kWave) o[k] = k < res ? int32_t(id[k]) : kEmptyId;
+                if (l == src && res) atomicAdd(&w.row_cnt[e.row], res);
             }
         }
         const unsigned long long xm = __ballot(is_x);
@@ -434,43 +450,24 @@ static __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, 
         const int cnt = bpe_exact_piece(
             T, [&](int k) -> uint32_t { return k < p.len ? text[k] : T.suffix[k - p.len]; }, ntext, w.scratch + off, out);
         for (int k = cnt; k < ntext; ++k) out[k] = kEmptyId;
+        if (cnt) atomicAdd(&w.row_cnt[p.row], cnt);
     }
 }
 
-// ---- ids per row once the deferred pieces are in + the tile scan of the final offsets.  One block per tile of
-// kRowTile rows: rows whose staging stretch has unused entries are recounted (coalesced, contention-free -- cheaper
-// than one device-scope atomic per deferred piece); the last block scans the tile sums.  recount == 0: row_cnt is
-// final already (RegexSplit piece counts).
-static __global__ __launch_bounds__(kBlockThreads) void count_scan_kernel(int n_rows, EncodeWork w, int recount,
-                                                                         long long out_cap) {
-    __shared__ int tile_cnt[kRowTile];
-    const int l = lane_id(), wv = wave_in_block();
-    const int first = int(blockIdx.x) * kRowTile;
-    const bool bad = (w.status->flags & (kFatalFlags | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow)) != 0;
-    for (int j = wv; j < kRowTile; j += kWavesPerBlock) {
-        const int row = first + j;
-        int cnt = 0;
-        if (row < n_rows && !bad) {
-            cnt = w.row_cnt[row];
-            const int used = recount ? w.row_used[row] : cnt;
-            if (used != cnt) {  // the row had deferred pieces
-                const int32_t* p = w.stage + w.row_stage[row];
-                int c = 0;
-                for (int b = l; b < used; b += kWave) c += p[b] != kEmptyId;
-                cnt = wave_sum(c);
-                if (l == 0) w.row_cnt[row] = cnt;
-            }
-        }
-        if (l == 0) tile_cnt[j] = cnt;
-    }
-    __syncthreads();
-    if (wv == 0) {
-        const int s = wave_sum(tile_cnt[l]);
-        if (l == 0) w.tile_off[blockIdx.x] = s;
+// ---- the tile scan of the final offsets: one wave per tile of kRowTile rows sums the row counts, the last block
+// scans the tile sums.
+static __global__ __launch_bounds__(kBlockThreads) void count_scan_kernel(int n_rows, EncodeWork w, long long out_cap) {
+    const int l = lane_id();
+    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
+    const int my_waves = int(gridDim.x) * kWavesPerBlock;
+    for (int tile = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); tile < n_tiles; tile += my_waves) {
+        const int row = tile * kRowTile + l;
+        const int s = wave_sum(row < n_rows ? w.row_cnt[row] : 0);
+        if (l == 0) w.tile_off[tile] = s;
     }
     if (!last_block_done(&w.status->ticket[1], gridDim.x)) return;
-    const long long total = block_exclusive_scan<kBlockThreads>(
-        int(gridDim.x), [&](int i) -> long long { return w.tile_off[i]; }, [&](int i, long long off) { w.tile_off[i] = off; });
+    const long long total = block_exclusive_scan<kBlockThreads, 16>(
+        n_tiles, [&](int i) -> long long { return w.tile_off[i]; }, [&](int i, long long off) { w.tile_off[i] = off; });
     if (threadIdx.x == 0) {
         w.status->n_out = total > INT32_MAX ? INT32_MAX : int32_t(total);
         if (total > out_cap) atomicOr(&w.status->flags, kFlagOutCapacity);

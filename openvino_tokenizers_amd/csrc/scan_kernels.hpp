@@ -14,18 +14,18 @@ constexpr int kTileElems = kTileThreads * kScanPerThread;  // 1024 elements per 
 
 // Exclusive scan of f(0..n) by ONE block of THREADS threads: put(i, prefix) for every i, returns the
 // total to every thread.  64-bit accumulation (callers clamp / flag).
-template <int THREADS, class F, class Put>
+template <int THREADS, int PER = kScanPerThread, class F, class Put>
 __device__ __forceinline__ long long block_exclusive_scan(int n, F&& f, Put&& put) {
     __shared__ long long wave_tot[THREADS / kWave];
     __shared__ long long carry_s;
     const int tid = int(threadIdx.x), l = lane_id(), wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int tile = 0; tile < n; tile += THREADS * kScanPerThread) {
-        const int i0 = tile + tid * kScanPerThread;
-        long long v[kScanPerThread], s = 0;
+    for (int tile = 0; tile < n; tile += THREADS * PER) {
+        const int i0 = tile + tid * PER;
+        long long v[PER], s = 0;
 #pragma unroll
-        for (int j = 0; j < kScanPerThread; ++j) {
+        for (int j = 0; j < PER; ++j) {
             v[j] = (i0 + j < n) ? (long long)f(i0 + j) : 0;
             s += v[j];
         }
@@ -41,7 +41,7 @@ __device__ __forceinline__ long long block_exclusive_scan(int n, F&& f, Put&& pu
         for (int k = 0; k < wv; ++k) before += wave_tot[k];
         long long run = before + incl - s;
 #pragma unroll
-        for (int j = 0; j < kScanPerThread; ++j) {
+        for (int j = 0; j < PER; ++j) {
             if (i0 + j < n) put(i0 + j, run);
             run += v[j];
         }
