@@ -185,7 +185,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     d.trie.edge_shift = host.trie.edge_shift;
     d.merges = h->merges.as<MergeBucket>();
     d.bucket_shift = host.bucket_shift;
-    d.pieces = PieceTableDev{nullptr, 62};
+    d.pieces = PieceTableDev{nullptr, 30};
     d.new_id = h->new_id.as<int32_t>();
     d.byte_fallback_id = h->bf.as<int32_t>();
     d.unk_id = host.unk_id;

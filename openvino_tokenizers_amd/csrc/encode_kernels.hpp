@@ -171,7 +171,7 @@ __device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint6
 // Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.  Three independent
 // 32-byte loads (cuckoo table), no probe chain.
 __device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
-    const uint64_t mix = piece_mix(k0, k1);
+    const uint32_t mix = piece_mix(k0, k1);
     const PieceEntry e0 = P.slots[piece_h(mix, 0, P.shift)];
     const PieceEntry e1 = P.slots[piece_h(mix, 1, P.shift)];
     const PieceEntry e2 = P.slots[piece_h(mix, 2, P.shift)];
@@ -315,7 +315,7 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
                             if (valid) {
                                 ps = c0 + int(ws.pstart[j]);
                                 plen = c0 + int(ws.pstart[j + 1]) - ps;
-                                if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, ps - w0 + skew, r0, r1);
+                                if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps - w0 + skew, r0, r1);
                             }
                             lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, sb + ps);
                         }

@@ -19,13 +19,17 @@
 //   * digits variant (:448-452, `\p{N}` single, no optional space): every N char is its own piece
 //     and a preceding space does not attach to it.
 //
-// Evaluation is bit-parallel.  One wave scans one string: the window (<= 512 bytes + halos) is
-// staged in LDS with coalesced dword loads; for each 64-byte word of the window every lane
-// classifies ONE byte (ASCII arithmetically, other code points through the two-level Unicode
-// property table generated from PCRE2 itself) and the per-byte predicates become 64-bit masks by
-// wave ballot.  Lane w then owns the masks of word w, and the rules above are ~40 AND/OR/shift
-// operations on those masks -- all words of the window at once, neighbouring words reached with
-// one DPP lane shift.  Piece starts are finally turned into positions by popcount ranking.
+// Evaluation is bit-parallel.  One wave scans one string: the window (<= 512 bytes incl. halos) is
+// staged in LDS with coalesced dword loads, then
+//   * ASCII windows (the common case) take the packed-byte path: lane l owns window bytes [8l, 8l+8),
+//     loads the 16 bytes around them and evaluates classes and rules on all of them at once with
+//     SWAR arithmetic (one flag per byte in bit 7) -- ~300 vector instructions per 512-byte window;
+//   * any other window takes the ballot path: for each 64-byte word every lane classifies ONE byte
+//     (non-ASCII code points through the two-level Unicode property table generated from PCRE2
+//     itself), the per-byte predicates become 64-bit masks by wave ballot, lane w owns the masks of
+//     word w and the rules are ~40 AND/OR/shift operations on them, neighbouring words reached with
+//     one DPP lane shift.
+// Piece starts are finally turned into positions by popcount ranking.
 #pragma once
 
 #include "device_common.hpp"
@@ -44,11 +48,11 @@ struct SplitDev {
     const uint8_t* uc_blocks;  // [n_blocks * 64]
 };
 
-constexpr int kChunk = 512;               // text bytes whose piece starts are decided per pass
+constexpr int kChunk = 512;               // window bytes (text whose piece starts are decided per pass + halos)
 constexpr int kLeftHalo = 8;
 constexpr int kRightHalo = 12;
-constexpr int kWinBytes = kChunk + 32;    // halo + alignment skew, multiple of 4
-constexpr int kWinWords = (kChunk + kLeftHalo + kRightHalo + 63) / 64;  // 64-byte mask words per window (9)
+constexpr int kTextPad = 4;               // zero bytes in front of the staged text (the packed-byte path reads 4 bytes back)
+constexpr int kWinBytes = kChunk + 32;    // pad + alignment skew + read-ahead of the 16-byte key loads, multiple of 4
 
 constexpr uint8_t kClsO = 0, kClsL = 1, kClsN = 2, kClsS = 3;
 
@@ -59,7 +63,7 @@ struct WaveScratch {
 };
 
 __device__ __forceinline__ const uint8_t* text_bytes(const WaveScratch& ws) {
-    return reinterpret_cast<const uint8_t*>(ws.text_w);
+    return reinterpret_cast<const uint8_t*>(ws.text_w) + kTextPad;
 }
 
 __device__ __forceinline__ uint32_t uc_nibble(const SplitDev& sp, uint32_t cp) {
@@ -87,6 +91,7 @@ __device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str,
     const uint8_t* ga = g - skew;
     const int nwords = (skew + (w1 - w0) + 3) >> 2;
     const int lo = skew - w0, hi = slen - w0 + skew;  // the string's own bytes, as offsets from ga
+    if (lane_id() == 0) ws.text_w[0] = 0;  // kTextPad
     for (int k = lane_id(); k < nwords; k += kWave) {
         const int b0 = k * 4;
         uint32_t w;
@@ -97,7 +102,7 @@ __device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str,
             for (int j = 0; j < 4; ++j)
                 if (b0 + j >= lo && b0 + j < hi) w |= uint32_t(ga[b0 + j]) << (8 * j);
         }
-        ws.text_w[k] = w;
+        ws.text_w[kTextPad / 4 + k] = w;
     }
     return skew;
 }
@@ -176,6 +181,101 @@ __device__ __forceinline__ Mask gpt2_start_mask(const WaveScratch& ws, const Spl
     return start & cs;
 }
 
+// ---- packed-byte (SWAR) path: ASCII windows of at most 512 bytes --------------------------------
+// All values are 4 packed bytes with one flag per byte in bit 7.  Inputs must be < 0x80 per byte (no carries).
+constexpr uint32_t kB7 = 0x80808080u;
+__device__ __forceinline__ uint32_t swar_eq(uint32_t x, uint32_t c) {  // x == c, per byte
+    return ~((x ^ (c * 0x01010101u)) + 0x7F7F7F7Fu) & kB7;
+}
+__device__ __forceinline__ uint32_t swar_range(uint32_t x, uint32_t lo, uint32_t hi) {  // lo <= x <= hi, per byte
+    return (x + (0x80u - lo) * 0x01010101u) & ~(x + (0x7Fu - hi) * 0x01010101u) & kB7;
+}
+// {hi:lo} >> 8*k, the low dword: bytes shifted towards lower positions ("property of the byte k places after").
+template <int K>
+__device__ __forceinline__ uint32_t swar_after(uint32_t lo, uint32_t hi) { return (lo >> (8 * K)) | (hi << (32 - 8 * K)); }
+// "property of the byte k places before": bytes shifted towards higher positions, `lo` = the dword below.
+template <int K>
+__device__ __forceinline__ uint32_t swar_before(uint32_t lo, uint32_t hi) { return (hi << (8 * K)) | (lo >> (32 - 8 * K)); }
+
+// Piece-start flags of window bytes [8l, 8l+8) for lane l (bit 8k+7 = byte 8l+k), same rules as gpt2_start_mask.
+// Returns false (wave-uniform) when the window holds a non-ASCII byte: the caller then takes the ballot path.
+__device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, int skew, int wlen, bool digits,
+                                                       unsigned long long& flags) {
+    const int l = lane_id();
+    // the 16 bytes around the lane's own: window bytes [8l - 4, 8l + 12) = neighbourhood bytes 0..15
+    const int off = skew + 8 * l;  // byte offset of neighbourhood byte 0 in text_w (kTextPad = 4 bytes back)
+    const int a = off >> 2, sh = (off & 3) * 8;
+    uint32_t raw[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) raw[j] = ws.text_w[a + j];
+    // which neighbourhood bytes exist: window positions q = 8l - 4 + j with 0 <= q < wlen
+    const int first = l == 0 ? 4 : 0;
+    int last = wlen - (8 * l - 4);
+    last = last < 0 ? 0 : (last > 16 ? 16 : last);
+    uint32_t x[4], V[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int nh = last - 4 * j, nl = first - 4 * j;
+        nh = nh < 0 ? 0 : (nh > 4 ? 4 : nh);
+        nl = nl < 0 ? 0 : (nl > 4 ? 4 : nl);
+        const uint32_t mh = nh == 4 ? ~0u : ((1u << (8 * nh)) - 1u), ml = nl == 4 ? ~0u : ((1u << (8 * nl)) - 1u);
+        const uint32_t vf = mh & ~ml;  // 0xFF per existing byte
+        x[j] = uint32_t(((static_cast<unsigned long long>(raw[j + 1]) << 32) | raw[j]) >> sh) & vf;
+        V[j] = vf & kB7;
+    }
+    if (__ballot(((x[0] | x[1] | x[2] | x[3]) & kB7) != 0)) return false;
+    uint32_t L[4], N[4], S[4], SP[4], AP[4], O[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        L[j] = swar_range(x[j] | 0x20202020u, 'a', 'z');
+        N[j] = swar_range(x[j], '0', '9');
+        SP[j] = swar_eq(x[j], 0x20) & V[j];  // a non-existing byte is 0x00: never a letter, digit, apostrophe; mask the rest
+        S[j] = SP[j] | (swar_range(x[j], 9, 13) & V[j]);
+        AP[j] = swar_eq(x[j], 0x27);
+        O[j] = V[j] & ~(L[j] | N[j] | S[j]);
+    }
+    // rules for the lane's own bytes = neighbourhood dwords 1 and 2
+    uint32_t start[2];
+    uint32_t f1[3] = {0, 0, 0}, f2[3] = {0, 0, 0};  // contractions firing at neighbourhood dwords 0..2
+    if (__ballot((AP[0] | AP[1] | AP[2]) != 0)) {
+        uint32_t X1[4], X2[4], XE[4], XL[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            X1[j] = swar_range(x[j], 's', 't') | swar_eq(x[j], 'm') | swar_eq(x[j], 'd');
+            X2[j] = swar_eq(x[j], 'r') | swar_eq(x[j], 'v');
+            XE[j] = swar_eq(x[j], 'e');
+            XL[j] = swar_eq(x[j], 'l');
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t c1 = AP[j] & swar_after<1>(X1[j], X1[j + 1]);
+            const uint32_t c2 = AP[j] & ((swar_after<1>(X2[j], X2[j + 1]) & swar_after<2>(XE[j], XE[j + 1])) |
+                                         (swar_after<1>(XL[j], XL[j + 1]) & swar_after<2>(XL[j], XL[j + 1])));
+            // the apostrophe itself starts a piece unless the previous char is class O or U+0020
+            const uint32_t blocked = j == 0 ? swar_before<1>(0u, O[0] | SP[0]) : swar_before<1>(O[j - 1] | SP[j - 1], O[j] | SP[j]);
+            f1[j] = c1 & ~blocked;
+            f2[j] = c2 & ~blocked;
+        }
+    }
+#pragma unroll
+    for (int j = 1; j <= 2; ++j) {
+        const uint32_t pL = swar_before<1>(L[j - 1], L[j]), pN = swar_before<1>(N[j - 1], N[j]);
+        const uint32_t pS = swar_before<1>(S[j - 1], S[j]), pO = swar_before<1>(O[j - 1], O[j]);
+        const uint32_t pSP = swar_before<1>(SP[j - 1], SP[j]);
+        const uint32_t same = (L[j] & pL) | (N[j] & pN) | (S[j] & pS) | (O[j] & pO);
+        const uint32_t attaches = ~S[j] & (digits ? ~N[j] : ~0u);
+        uint32_t st = ~same & ~(pSP & attaches);
+        const uint32_t next_nonspace = swar_after<1>(V[j] & ~S[j], V[j + 1] & ~S[j + 1]);
+        st |= same & ((S[j] & next_nonspace) | (digits ? N[j] : 0u));
+        const uint32_t f12_lo = f1[j - 1] | f2[j - 1], f12 = f1[j] | f2[j];
+        st |= swar_before<2>(f1[j - 1], f1[j]) | swar_before<3>(f2[j - 1], f2[j]);  // the byte after a contraction
+        st &= ~swar_before<1>(f12_lo, f12);                                           // its first letter stays with it
+        start[j - 1] = st & V[j];
+    }
+    flags = (static_cast<unsigned long long>(start[1]) << 32) | start[0];
+    return true;
+}
+
 // Scans string `str` (slen bytes) and hands complete pieces to the caller chunk by chunk.
 //   on_chunk(np, c0, w0, skew): pstart[0..np] (positions relative to c0, pstart[np] = end of the last piece)
 //                               describe np complete pieces; the LDS text covers them (string byte p at
@@ -190,24 +290,50 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
     int c0 = 0;
     while (c0 < slen) {
         const int w0 = c0 > kLeftHalo ? c0 - kLeftHalo : 0;
-        // Balanced chunks: a 600-byte string is scanned as 2 x 300, not 512 + 88 (fuller lane batches).
-        const int rest = slen - c0;
-        const int nchunks = (rest + kChunk - 1) / kChunk;
-        const int qlim = nchunks <= 1 ? slen : c0 + (rest + nchunks - 1) / nchunks;
+        // The window [w0, w1) never exceeds kChunk bytes.  Balanced chunks: a 600-byte string is scanned as
+        // 2 x 300, not 492 + 108 (fuller lane batches).
+        const int rest = slen - c0, room = kChunk - (c0 - w0);
+        int qlim = slen;
+        if (rest > room) {
+            const int budget = room - kRightHalo;
+            const int nchunks = (rest + budget - 1) / budget;
+            qlim = c0 + (rest + nchunks - 1) / nchunks;
+        }
         const int w1 = (qlim + kRightHalo < slen) ? qlim + kRightHalo : slen;
         wave_sync();  // previous consumers of the LDS window are done
         const int skew = stage_window(ws, str, slen, w0, w1);
         wave_sync();
-        const Mask start = gpt2_start_mask(ws, sp, skew, w1 - w0, digits);
-        // rank the starts of [c0, qlim) (window bits [c0 - w0, qlim - w0)); c0 itself is a start by construction
+        // rank the starts of [c0, qlim) (window bytes [lo, hi)); c0 itself is a start by construction
         const int lo = c0 - w0, hi = qlim - w0;
         int np = 0;
-        for (int w = lo >> 6; w * 64 < hi; ++w) {
-            Mask m = wave_readlane(start, w);
-            if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
-            if (hi - w * 64 < 64) m &= (1ull << (hi - w * 64)) - 1ull;
-            if ((m >> l) & 1ull) ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t(w * 64 + l - lo);
-            np += __popcll(m);
+        unsigned long long fl = 0;
+        if (gpt2_start_flags_ascii(ws, skew, w1 - w0, digits, fl)) {
+            // lane l holds the flags of window bytes [8l, 8l+8) in bit 7 of each byte
+            int k_lo = lo - 8 * l, k_hi = hi - 8 * l;
+            k_lo = k_lo < 0 ? 0 : (k_lo > 8 ? 8 : k_lo);
+            k_hi = k_hi < 0 ? 0 : (k_hi > 8 ? 8 : k_hi);
+            const unsigned long long below_hi = k_hi == 8 ? ~0ull : ((1ull << (8 * k_hi)) - 1ull);
+            const unsigned long long below_lo = k_lo == 8 ? ~0ull : ((1ull << (8 * k_lo)) - 1ull);
+            fl &= below_hi & ~below_lo;
+            if ((lo >> 3) == l) fl |= 0x80ull << (8 * (lo & 7));
+            const int cnt = __popcll(fl);
+            const int incl = wave_incl_sum(cnt);
+            int at = incl - cnt;
+            while (fl) {
+                const int bit = __ffsll(fl) - 1;
+                ws.pstart[at++] = uint16_t(8 * l + (bit >> 3) - lo);
+                fl &= fl - 1;
+            }
+            np = wave_readlane(incl, kWave - 1);
+        } else {
+            const Mask start = gpt2_start_mask(ws, sp, skew, w1 - w0, digits);
+            for (int w = lo >> 6; w * 64 < hi; ++w) {
+                Mask m = wave_readlane(start, w);
+                if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
+                if (hi - w * 64 < 64) m &= (1ull << (hi - w * 64)) - 1ull;
+                if ((m >> l) & 1ull) ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t(w * 64 + l - lo);
+                np += __popcll(m);
+            }
         }
         wave_sync();
         if (qlim == slen) {  // the string ends in this window: every piece is complete
@@ -224,7 +350,8 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
             bool found = false;
             while (!found && e < slen) {
                 const int lw0 = e - kLeftHalo;
-                const int lq = (e + kChunk < slen) ? e + kChunk : slen;
+                const int lspan = kChunk - kLeftHalo - kRightHalo;
+                const int lq = (e + lspan < slen) ? e + lspan : slen;
                 const int lw1 = (lq + kRightHalo < slen) ? lq + kRightHalo : slen;
                 wave_sync();
                 const int lskew = stage_window(ws, str, slen, lw0, lw1);

@@ -261,7 +261,7 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
     }
     // Cuckoo table: 3 hash functions x 1 entry, load <= 0.5.
     for (uint32_t cap = std::max<uint32_t>(4, pow2_at_least(uint64_t(uniq.size()) * 2 + 1));; cap *= 2) {
-        out.shift = 64 - log2u(cap);
+        out.shift = 32 - log2u(cap);
         out.slots.assign(size_t(cap), PieceEntry{0, 0, {0, 0, 0}, 0});
         uint64_t rng = 0x9E3779B97F4A7C15ull;
         bool ok = true;
@@ -270,7 +270,7 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
             ok = cuckoo_insert<PieceEntry, 3>(
                 out.slots, kv.second,
                 [shift](const PieceEntry& e, uint32_t* idx) {
-                    const uint64_t mix = piece_mix(e.k0, e.k1);
+                    const uint32_t mix = piece_mix(e.k0, e.k1);
                     for (int c = 0; c < 3; ++c) idx[c] = piece_h(mix, c, shift);
                 },
                 [](const PieceEntry& e) { return e.k1 == 0; }, rng);
