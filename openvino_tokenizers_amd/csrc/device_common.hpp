@@ -43,12 +43,30 @@ constexpr uint32_t kFlagExactOverflow = 64u;    // exact-path piece list too sma
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x) & (kWave - 1); }
 __device__ __forceinline__ int wave_in_block() { return int(threadIdx.x) >> 6; }
 
-// Orders LDS/global accesses of the lanes of one wave (compiler + hardware) -- the wave-level
-// counterpart of __syncthreads().
+// Orders the LDS accesses of the lanes of one wave -- the wave-level counterpart of __syncthreads() for data handed
+// from lane to lane through LDS.  Deliberately NOT a fence: a wavefront-scope fence makes the compiler drain every
+// outstanding global load and store (s_waitcnt vmcnt(0)) at each hand-off.  LDS operations of one wave execute in
+// issue order; what is needed is that the compiler keeps its memory operations on their side of this point (the asm
+// memory clobber) and that earlier LDS results have landed (lgkmcnt).
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#ifdef OVTK_SIMT_EMULATOR
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }  // tells the compiler too
+// Load of a kernel INPUT (never written during the launch) at a wave-uniform address: through the constant address
+// space, so that it becomes a scalar load (s_load, tracked by lgkmcnt) even after the kernel has issued stores --
+// a vector load here would be waited for with vmcnt(0) and drain every prefetch in flight.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* p) {
+#ifdef OVTK_SIMT_EMULATOR
+    return *p;
+#else
+    return *reinterpret_cast<const __attribute__((address_space(4))) T*>(reinterpret_cast<uintptr_t>(p));
+#endif
 }
 
 // Publishing data to other workgroups of the same launch (MI355X_MICROARCH.md "inter-workgroup visibility"): the

@@ -218,10 +218,15 @@ __device__ __forceinline__ void flush_misses(WaveMiss& mb, int& n_miss, int n, c
         else atomicOr(&w.status->flags, kFlagDeferOverflow);
     }
     const int rest = n_miss - n;
-    DeferredPiece t{};
-    if (l < rest) t = mb.e[n + l];
+    // move the remaining entries up (through scalars: a struct temporary would live in scratch across wave_sync)
+    uint64_t t0 = 0, t1 = 0;
+    int t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    if (l < rest) {
+        const DeferredPiece& src = mb.e[n + l];
+        t0 = src.k0; t1 = src.k1; t2 = src.stage_pos; t3 = src.row; t4 = src.begin; t5 = src.len;
+    }
     wave_sync();
-    if (l < rest) mb.e[l] = t;
+    if (l < rest) mb.e[l] = DeferredPiece{t0, t1, t2, t3, t4, t5};
     wave_sync();
     n_miss = rest;
 }
@@ -280,6 +285,25 @@ __device__ __forceinline__ void lookup_whole_strings(const BpeDev& T, RowState& 
     }
 }
 
+// Header of a row for the software pipeline of the fused lookup kernel.  simple: exactly one string, not skipped, at
+// most kPrefetchBytes long -- its text is prefetched one row ahead; any other row takes the generic path.
+struct RowHdr {
+    int cb, ce, sb, slen;
+    bool simple;
+};
+__device__ __forceinline__ RowHdr load_row_hdr(const RowsIn& in, int row) {
+    RowHdr h{0, 0, 0, 0, false};
+    if (row >= in.n_rows) return h;
+    h.cb = uniform_load(in.ragged_begins + row);
+    h.ce = uniform_load(in.ragged_ends + row);
+    if (h.ce == h.cb + 1 && !(in.skips && uniform_load(in.skips + h.cb))) {
+        h.sb = uniform_load(in.begins + h.cb);
+        h.slen = uniform_load(in.ends + h.cb) - h.sb;
+        h.simple = h.slen > 0 && h.slen <= kPrefetchBytes;
+    }
+    return h;
+}
+
 template <int MODE>
 static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
@@ -290,20 +314,39 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
     const int l = lane_id();
     int n_miss = 0;
     const int n_waves = w.n_waves;  // == gridDim.x * kWavesPerBlock: the geometry prep_rows_kernel summed over
-    const int wave = int(blockIdx.x) * kWavesPerBlock + wave_in_block();
+    const int wave = wave_uniform(int(blockIdx.x) * kWavesPerBlock + wave_in_block());
     int cursor = int(w.wave_off[wave]);  // rows of this wave are staged back to back in its arena
+    // fused mode: headers two rows ahead, text one row ahead
+    RowHdr h_cur{0, 0, 0, 0, false}, h_next{0, 0, 0, 0, false};
+    TextRegs t_cur{{0, 0, 0}};
+    if (MODE == kFused) {
+        h_cur = load_row_hdr(in, wave);
+        h_next = load_row_hdr(in, wave + n_waves);
+        if (h_cur.simple) t_cur = prefetch_text(in.chars + h_cur.sb, h_cur.slen);
+    }
     for (int row = wave; row < in.n_rows; row += n_waves) {
         RowState st{cursor, 0, 0, row};
-        const int cb = in.ragged_begins[row], ce = in.ragged_ends[row];
         if (MODE == kPieces) {
-            lookup_whole_strings(T, st, w, mb, n_miss, in, cb, ce);
+            lookup_whole_strings(T, st, w, mb, n_miss, in, in.ragged_begins[row], in.ragged_ends[row]);
         } else {
-            for (int col = cb; col < ce; ++col) {
-                if (in.skips && in.skips[col]) {  // regex_split.cpp:231-234: passes through unsplit
+            const RowHdr h = h_cur;
+            const TextRegs t = t_cur;
+            h_cur = h_next;
+            if (h_cur.simple) t_cur = prefetch_text(in.chars + h_cur.sb, h_cur.slen);  // lands while this row is processed
+            h_next = load_row_hdr(in, row + 2 * n_waves);
+            int pre_skew = -1;
+            if (h.simple) {
+                wave_sync();  // the previous row is done with the LDS window
+                pre_skew = commit_text(ws, in.chars + h.sb, h.slen, t);
+                wave_sync();
+            }
+            for (int col = h.cb; col < h.ce; ++col) {
+                if (!h.simple && in.skips && in.skips[col]) {  // regex_split.cpp:231-234: passes through unsplit
                     lookup_whole_strings(T, st, w, mb, n_miss, in, col, col + 1);
                     continue;
                 }
-                const int sb = in.begins[col], slen = in.ends[col] - sb;
+                const int sb = h.simple ? h.sb : in.begins[col];
+                const int slen = h.simple ? h.slen : in.ends[col] - sb;
                 scan_string(
                     ws, sp, in.chars + sb, slen,
                     [&](int np, int c0, int w0, int skew) {
@@ -322,7 +365,8 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
                     },
                     [&](int b, int e) {  // a piece longer than the scan window: straight to the deferred list
                         lookup_batch(T, st, w, mb, n_miss, l == 0, 0, 0, e - b, sb + b);
-                    });
+                    },
+                    pre_skew);
             }
         }
         if (l == 0) {

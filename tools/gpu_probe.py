@@ -23,7 +23,7 @@ def main():
     lib = L.load()
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
     tok = BpeTok.load("gpt2")
-    for kind in ("zipf", "uniform"):
+    for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("zipf", "uniform")):
         b, e, c = TextModel(1234, kind).batch(rows, 512, seed=1000)
         rb, re_ = ragged_rows(rows)
         d = [torch.as_tensor(x, device="cuda") for x in (rb, re_, b, e, c)]
