@@ -285,17 +285,23 @@ __device__ __forceinline__ void lookup_whole_strings(const BpeDev& T, RowState& 
     }
 }
 
-// Header of a row for the software pipeline of the fused lookup kernel.  simple: exactly one string, not skipped, at
-// most kPrefetchBytes long -- its text is prefetched one row ahead; any other row takes the generic path.
+// Header of a row for the software pipeline of the fused lookup kernel, fetched in two dependent steps that run in
+// DIFFERENT loop iterations (row range three rows ahead, string offsets two rows ahead, text one row ahead), so no
+// iteration waits for a load it has just issued.  simple: exactly one string, not skipped, at most kPrefetchBytes
+// long -- its text is prefetched; any other row takes the generic path.
 struct RowHdr {
     int cb, ce, sb, slen;
     bool simple;
 };
-__device__ __forceinline__ RowHdr load_row_hdr(const RowsIn& in, int row) {
+__device__ __forceinline__ RowHdr load_row_range(const RowsIn& in, int row) {
     RowHdr h{0, 0, 0, 0, false};
-    if (row >= in.n_rows) return h;
-    h.cb = uniform_load(in.ragged_begins + row);
-    h.ce = uniform_load(in.ragged_ends + row);
+    if (row < in.n_rows) {
+        h.cb = uniform_load(in.ragged_begins + row);
+        h.ce = uniform_load(in.ragged_ends + row);
+    }
+    return h;
+}
+__device__ __forceinline__ RowHdr load_row_string(const RowsIn& in, RowHdr h) {
     if (h.ce == h.cb + 1 && !(in.skips && uniform_load(in.skips + h.cb))) {
         h.sb = uniform_load(in.begins + h.cb);
         h.slen = uniform_load(in.ends + h.cb) - h.sb;
@@ -317,11 +323,12 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
     const int wave = wave_uniform(int(blockIdx.x) * kWavesPerBlock + wave_in_block());
     int cursor = int(w.wave_off[wave]);  // rows of this wave are staged back to back in its arena
     // fused mode: headers two rows ahead, text one row ahead
-    RowHdr h_cur{0, 0, 0, 0, false}, h_next{0, 0, 0, 0, false};
+    RowHdr h_cur{0, 0, 0, 0, false}, h_next{0, 0, 0, 0, false}, h_range{0, 0, 0, 0, false};
     TextRegs t_cur{{0, 0, 0}};
     if (MODE == kFused) {
-        h_cur = load_row_hdr(in, wave);
-        h_next = load_row_hdr(in, wave + n_waves);
+        h_cur = load_row_string(in, load_row_range(in, wave));
+        h_next = load_row_string(in, load_row_range(in, wave + n_waves));
+        h_range = load_row_range(in, wave + 2 * n_waves);
         if (h_cur.simple) t_cur = prefetch_text(in.chars + h_cur.sb, h_cur.slen);
     }
     for (int row = wave; row < in.n_rows; row += n_waves) {
@@ -333,7 +340,8 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
             const TextRegs t = t_cur;
             h_cur = h_next;
             if (h_cur.simple) t_cur = prefetch_text(in.chars + h_cur.sb, h_cur.slen);  // lands while this row is processed
-            h_next = load_row_hdr(in, row + 2 * n_waves);
+            h_next = load_row_string(in, h_range);           // its row range was loaded one iteration ago
+            h_range = load_row_range(in, row + 3 * n_waves);
             int pre_skew = -1;
             if (h.simple) {
                 wave_sync();  // the previous row is done with the LDS window
