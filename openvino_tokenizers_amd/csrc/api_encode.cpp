@@ -19,6 +19,11 @@ namespace {
 
 const char kGpt2Pattern[] = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
 const char kGpt2DigitsPattern[] = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+// tokenizer_pipeline.py:392-426 (bert_whitespace_splitter / bert_keep_delimeters_splitter)
+const char kBertWhitespacePattern[] = "\\s+";
+const char kBertDelimitersPattern[] =
+    "[!-/]|[:-@]|[\\[-`]|[{-~]|[\\p{P}]|[\\x{4E00}-\\x{9FFF}]|[\\x{3400}-\\x{4DBF}]|[\\x{20000}-\\x{2A6DF}]|"
+    "[\\x{2A700}-\\x{2B73F}]|[\\x{2B740}-\\x{2B81F}]|[\\x{2B820}-\\x{2CEAF}]|[\\x{F900}-\\x{FAFF}]|[\\x{2F800}-\\x{2FA1F}]";
 
 // Unicode property tables, one copy per device.
 struct UnicodeTables {
@@ -138,12 +143,21 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
     h->max_splits = p->max_splits;
     if (pat == kGpt2Pattern) h->dev.kind = kSplitGpt2;
     else if (pat == kGpt2DigitsPattern) h->dev.kind = kSplitGpt2Digits;
+    else if (pat == kBertWhitespacePattern) h->dev.kind = kSplitWhitespace;
+    else if (pat == kBertDelimitersPattern) h->dev.kind = kSplitBertPunct;
     else
         return set_error(OVTK_E_UNSUPPORTED,
-                         "RegexSplit: no gfx950 scanner for this pattern (supported: the byte-level patterns of "
-                         "tokenizer_pipeline.py:448-457); PCRE2 is not executed on the device");
-    if (beh != "isolate")
-        return set_error(OVTK_E_UNSUPPORTED, "RegexSplit: the byte-level patterns are only supported with behaviour=isolate");
+                         "RegexSplit: no gfx950 scanner for this pattern (supported: the byte-level and BERT patterns of "
+                         "tokenizer_pipeline.py:392-457); PCRE2 is not executed on the device");
+    if (h->dev.kind <= kSplitGpt2Digits) {
+        if (beh != "isolate")
+            return set_error(OVTK_E_UNSUPPORTED, "RegexSplit: the byte-level patterns are only supported with behaviour=isolate");
+    } else {
+        // regex_split.cpp:244-284: "remove" drops the pieces flagged `invert`: the matches, or the gaps when invert is set
+        if (h->mode == 0) h->dev.drop = h->invert ? 2 : 1;
+        else if (h->mode == 1) h->dev.drop = 0;
+        else return set_error(OVTK_E_UNSUPPORTED, "RegexSplit: merged-with-previous/next is not supported on the device");
+    }
     if (int rc = use_device(p->device)) return rc;
     h->device = p->device;
     if (int rc = unicode_tables(p->device, &h->dev.uc_index, &h->dev.uc_blocks)) return rc;

@@ -360,19 +360,20 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
                     [&](int np, int c0, int w0, int skew) {
                         for (int jb = 0; jb < np; jb += kWave) {
                             const int j = jb + l;
-                            const bool valid = j < np;
+                            bool valid = j < np;
                             int ps = 0, plen = 0;
                             uint64_t r0 = 0, r1 = 0;
                             if (valid) {
-                                ps = c0 + int(ws.pstart[j]);
-                                plen = c0 + int(ws.pstart[j + 1]) - ps;
-                                if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps - w0 + skew, r0, r1);
+                                ps = c0 + int(ws.pstart[j] & kPiecePosMask);
+                                plen = c0 + int(ws.pstart[j + 1] & kPiecePosMask) - ps;
+                                valid = !(ws.pstart[j] & kPieceDropped);
+                                if (valid && plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps - w0 + skew, r0, r1);
                             }
                             lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, sb + ps);
                         }
                     },
-                    [&](int b, int e) {  // a piece longer than the scan window: straight to the deferred list
-                        lookup_batch(T, st, w, mb, n_miss, l == 0, 0, 0, e - b, sb + b);
+                    [&](int b, int e, bool dropped) {  // a piece longer than the scan window: straight to the deferred list
+                        lookup_batch(T, st, w, mb, n_miss, l == 0 && !dropped, 0, 0, e - b, sb + b);
                     },
                     pre_skew);
             }
@@ -587,9 +588,8 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
                 continue;
             }
             int in_string = 0;  // pieces of this string so far (num_splits of regex_split.cpp:241)
-            auto emit = [&](int k, int b, int e) {  // lane-local: k-th piece of the chunk
+            auto emit = [&](int idx, int b, int e) {  // lane-local: idx-th kept piece of the string
                 if (!WRITE) return;
-                const int idx = in_string + k;
                 out_begins[o + count + idx] = sb + b;
                 // regex_split.cpp:278-280: the piece whose index equals max_splits is stretched to the end
                 out_ends[o + count + idx] = (idx == max_splits) ? se : sb + e;
@@ -598,11 +598,19 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
             scan_string(
                 ws, sp, in.chars + sb, se - sb,
                 [&](int np, int c0, int, int) {
-                    for (int j = l; j < np; j += kWave) emit(j, c0 + int(ws.pstart[j]), c0 + int(ws.pstart[j + 1]));
-                    in_string += np;
+                    for (int jb = 0; jb < np; jb += kWave) {
+                        const int j = jb + l;
+                        const bool keep = j < np && !(ws.pstart[j] & kPieceDropped);
+                        const unsigned long long km = __ballot(keep);
+                        if (keep)
+                            emit(in_string + __popcll(km & lanemask_lt()), c0 + int(ws.pstart[j] & kPiecePosMask),
+                                 c0 + int(ws.pstart[j + 1] & kPiecePosMask));
+                        in_string += __popcll(km);
+                    }
                 },
-                [&](int b, int e) {
-                    if (l == 0) emit(0, b, e);
+                [&](int b, int e, bool dropped) {
+                    if (dropped) return;
+                    if (l == 0) emit(in_string, b, e);
                     in_string += 1;
                 });
             count += in_string;

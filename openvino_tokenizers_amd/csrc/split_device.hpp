@@ -40,13 +40,21 @@ namespace ovtk {
 enum SplitKind : int32_t {
     kSplitGpt2 = 0,        // byte_level_splitter()
     kSplitGpt2Digits = 1,  // byte_level_splitter(individual_digits=True)
+    // "class" patterns: a match is a run of chars of one class (X+) or a single char of it; the text between
+    // matches are the gaps; RegexSplit's behaviour / invert decide which of the two kinds of pieces are kept
+    kSplitWhitespace = 2,  // bert_whitespace_splitter(): \s+
+    kSplitBertPunct = 3,   // bert_keep_delimeters_splitter(): one char of [!-/] [:-@] [\[-`] [{-~] \p{P} or the CJK blocks
+    kSplitBertWords = 4,   // both of the above chained (\s+ removed, then delimiters isolated): the fused WordPiece path
 };
 
 struct SplitDev {
     int32_t kind;
     const uint16_t* uc_index;  // [0x110000 >> 7]
     const uint8_t* uc_blocks;  // [n_blocks * 64]
+    int32_t drop;              // class patterns: 0 keep every piece, 1 drop the matches, 2 drop the gaps
 };
+constexpr uint16_t kPieceDropped = 0x8000;  // flag in WaveScratch::pstart: the piece is not emitted
+constexpr uint16_t kPiecePosMask = 0x7FFF;
 
 constexpr int kChunk = 512;               // window bytes (text whose piece starts are decided per pass + halos)
 constexpr int kLeftHalo = 8;
@@ -211,6 +219,67 @@ __device__ __forceinline__ Mask gpt2_start_mask(const WaveScratch& ws, const Spl
     return start & cs;
 }
 
+// ---- class patterns (ballot path) ----------------------------------------------------------------
+// The delimiter class of bert_keep_delimeters_splitter() (tokenizer_pipeline.py:397-426).
+__device__ __forceinline__ bool bert_delimiter(uint32_t cp, uint32_t nibble) {
+    if (cp < 0x80u) return (cp - 0x21u) < 15u || (cp - 0x3Au) < 7u || (cp - 0x5Bu) < 6u || (cp - 0x7Bu) < 4u;
+    if (nibble & 4u) return true;  // \p{P}
+    return (cp - 0x4E00u) < 0x5200u || (cp - 0x3400u) < 0x19C0u || (cp - 0x20000u) < 0xA6E0u || (cp - 0x2A700u) < 0x1040u ||
+           (cp - 0x2B740u) < 0xE0u || (cp - 0x2B820u) < 0x1690u || (cp - 0xF900u) < 0x200u || (cp - 0x2F800u) < 0x220u;
+}
+// Piece starts and "dropped piece" flags of the window for the class patterns; lane w = window bytes [64w, 64w+64).
+__device__ __forceinline__ void class_start_mask(const WaveScratch& ws, const SplitDev& sp, int skew, int wlen, Mask& start,
+                                                 Mask& dropped) {
+    const int l = lane_id();
+    const uint8_t* t = text_bytes(ws) + skew;
+    Mask mS = 0, mP = 0, mCONT = 0;
+    const int nwords = (wlen + 63) >> 6;
+    for (int w = 0; w < nwords; ++w) {
+        const int i = w * 64 + l;
+        const bool valid = i < wlen;
+        const uint32_t b = valid ? t[i] : 0u;
+        bool is_s = false, is_p = false;
+        if (b < 0x80u) {
+            is_s = valid && ascii_class(b) == kClsS;
+            is_p = valid && bert_delimiter(b, 0);
+        } else if (b >= 0xC0u) {
+            int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
+            uint32_t cp = b & (0xFFu >> (n + 1));
+            if (i + n > wlen) n = wlen - i;
+            for (int j = 1; j < n; ++j) cp = (cp << 6) | (t[i + j] & 0x3Fu);
+            const uint32_t nib = uc_nibble(sp, cp);
+            is_s = (nib & 3u) == kClsS;
+            is_p = bert_delimiter(cp, nib);
+        }
+        const Mask bS = __ballot(is_s), bP = __ballot(is_p), bCONT = __ballot((b & 0xC0u) == 0x80u);
+        if (l == w) { mS = bS; mP = bP; mCONT = bCONT; }
+    }
+    const int rem = wlen - l * 64;
+    const Mask mV = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
+    if (__ballot(mCONT != 0)) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            mS |= mask_from_before<1>(mS) & mCONT;
+            mP |= mask_from_before<1>(mP) & mCONT;
+        }
+    }
+    const Mask cs = mV & ~mCONT;
+    const Mask pS = mask_from_before<1>(mS), pP = mask_from_before<1>(mP);
+    Mask m = 0;
+    if (sp.kind == kSplitWhitespace) {
+        m = mS;
+        start = mS ^ pS;                 // a run of whitespace is one match
+    } else if (sp.kind == kSplitBertPunct) {
+        m = mP;
+        start = mP | pP;                 // every delimiter char is a match of its own
+    } else {                             // kSplitBertWords
+        m = mS;
+        start = (mS ^ pS) | mP | pP;
+    }
+    start &= cs;
+    dropped = (sp.drop == 1 ? m : (sp.drop == 2 ? ~m : 0ull)) & cs;
+}
+
 // ---- packed-byte (SWAR) path: ASCII windows of at most 512 bytes --------------------------------
 // All values are 4 packed bytes with one flag per byte in bit 7.  Inputs must be < 0x80 per byte (no carries).
 constexpr uint32_t kB7 = 0x80808080u;
@@ -310,7 +379,9 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
 //   on_chunk(np, c0, w0, skew): pstart[0..np] (positions relative to c0, pstart[np] = end of the last piece)
 //                               describe np complete pieces; the LDS text covers them (string byte p at
 //                               text_bytes(ws)[p - w0 + skew]).
-//   on_long(b, e):              a piece of more than kChunk bytes, not staged in LDS.
+//                               class patterns: entries carry kPieceDropped when the piece is not to be emitted
+//                               (read positions through kPiecePosMask).
+//   on_long(b, e, dropped):     a piece of more than kChunk bytes, not staged in LDS.
 // Wave-uniform; every lane must call it with the same arguments.
 // prestaged_skew >= 0: the caller already staged the whole string (slen <= kChunk) at that skew.
 template <class OnChunk, class OnLong>
@@ -341,7 +412,19 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
         const int lo = c0 - w0, hi = qlim - w0;
         int np = 0;
         unsigned long long fl = 0;
-        if (gpt2_start_flags_ascii(ws, skew, w1 - w0, digits, fl)) {
+        if (sp.kind >= kSplitWhitespace) {
+            Mask start, dropped;
+            class_start_mask(ws, sp, skew, w1 - w0, start, dropped);
+            for (int w = lo >> 6; w * 64 < hi; ++w) {
+                Mask m = wave_readlane(start, w);
+                const Mask d = wave_readlane(dropped, w);
+                if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
+                if (hi - w * 64 < 64) m &= (1ull << (hi - w * 64)) - 1ull;
+                if ((m >> l) & 1ull)
+                    ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t((w * 64 + l - lo) | (((d >> l) & 1ull) ? kPieceDropped : 0));
+                np += __popcll(m);
+            }
+        } else if (gpt2_start_flags_ascii(ws, skew, w1 - w0, digits, fl)) {
             // lane l holds the flags of window bytes [8l, 8l+8) in bit 7 of each byte
             int k_lo = lo - 8 * l, k_hi = hi - 8 * l;
             k_lo = k_lo < 0 ? 0 : (k_lo > 8 ? 8 : k_lo);
@@ -371,15 +454,16 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
         }
         wave_sync();
         if (qlim == slen) {  // the string ends in this window: every piece is complete
-            if (l == 0) ws.pstart[np] = uint16_t(slen - c0);
+            if (l == 0) ws.pstart[np] = uint16_t(slen - c0);  // < 0x8000
             wave_sync();
             on_chunk(np, c0, w0, skew);
             c0 = slen;
         } else if (np >= 2) {  // the last piece may continue: restart the next chunk at its start
             on_chunk(np - 1, c0, w0, skew);
-            c0 += int(ws.pstart[np - 1]);
+            c0 += int(ws.pstart[np - 1] & kPiecePosMask);
         } else {
             // One piece of >= kChunk bytes: look for its end window by window.
+            const bool long_dropped = (ws.pstart[0] & kPieceDropped) != 0;
             int e = qlim;
             bool found = false;
             while (!found && e < slen) {
@@ -390,7 +474,9 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                 wave_sync();
                 const int lskew = stage_window(ws, str, slen, lw0, lw1);
                 wave_sync();
-                const Mask ls = gpt2_start_mask(ws, sp, lskew, lw1 - lw0, digits);
+                Mask ls, ldrop;
+                if (sp.kind >= kSplitWhitespace) class_start_mask(ws, sp, lskew, lw1 - lw0, ls, ldrop);
+                else ls = gpt2_start_mask(ws, sp, lskew, lw1 - lw0, digits);
                 const int llo = e - lw0, lhi = lq - lw0;
                 for (int w = llo >> 6; w * 64 < lhi && !found; ++w) {
                     Mask m = wave_readlane(ls, w);
@@ -403,7 +489,7 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                 }
                 if (!found) e = lq;
             }
-            on_long(c0, e);
+            on_long(c0, e, long_dropped);
             c0 = e;
         }
     }

@@ -19,10 +19,11 @@ DIGITS_PATTERN = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+|\s+
 ALPHABET = ["a", "s", "t", "r", "e", "l", "v", "1", " ", "\t", "\n", " ", "'", "!", "é", "元", "，", "😀", "٣", "　"]
 
 
-def check(backend, pattern, strings):
+def check(backend, pattern, strings, behaviour="isolate", invert=False, max_splits=-1):
     inputs = one_string_per_row(strings)
-    ref = O.RegexSplit(pattern, "isolate")(*inputs)
-    got = RegexSplit("isolate", lib=backend.lib).evaluate(backend.data(inputs) + [np.frombuffer(pattern.encode(), np.uint8)])
+    ref = O.RegexSplit(pattern, behaviour, invert, max_splits)(*inputs)
+    got = RegexSplit(behaviour, invert, max_splits, lib=backend.lib).evaluate(
+        backend.data(inputs) + [np.frombuffer(pattern.encode(), np.uint8)])
     try:
         assert_same(ref[:4], got[:4], backend.host, "RegexSplit")
     except AssertionError:
@@ -79,3 +80,46 @@ def test_every_ascii_byte(backend, pattern):
         ch = chr(c)
         strings += [ch, "a" + ch + "a", " " + ch + " ", "1" + ch + ch + "1", ch + " x", "x " + ch, "'" + ch + "b", "x'" + ch]
     check(backend, pattern, strings)
+
+
+# ------------------------------------------------------------------ BERT patterns (tokenizer_pipeline.py:392-426)
+BERT_WS = r"\s+"
+BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\x{4E00}-\x{9FFF}]", r"[\x{3400}-\x{4DBF}]",
+                       r"[\x{20000}-\x{2A6DF}]", r"[\x{2A700}-\x{2B73F}]", r"[\x{2B740}-\x{2B81F}]",
+                       r"[\x{2B820}-\x{2CEAF}]", r"[\x{F900}-\x{FAFF}]", r"[\x{2F800}-\x{2FA1F}]"])
+BERT_ALPHABET = ["a", "b", "1", " ", "\t", "\n", "\u00a0", "\u3000", "!", "/", ":", "@", "[", "`", "{", "~", "_", "$", "é", "元",
+                 "㐀", "\U00020000", "豈", "，", "«", "😀", "٣"]
+
+
+@pytest.mark.parametrize("pattern,behaviour,invert", [(BERT_WS, "remove", False), (BERT_WS, "isolate", False),
+                                                      (BERT_WS, "remove", True), (BERT_PUNCT, "isolate", False),
+                                                      (BERT_PUNCT, "remove", False), (BERT_PUNCT, "remove", True)])
+def test_bert_patterns(backend, pattern, behaviour, invert):
+    rng = np.random.default_rng(23)
+    strings = ["".join(t) for k in (1, 2) for t in itertools.product(BERT_ALPHABET, repeat=k)]
+    n = 300 if backend.name == "emu" else 5000
+    strings += ["".join(rng.choice(BERT_ALPHABET, size=int(rng.integers(1, 50)))) for _ in range(n)]
+    strings += ["".join(rng.choice(BERT_ALPHABET, size=int(rng.integers(450, 1400)))) for _ in range(8)]
+    strings += ["", " ", "   ", "a" * 600, " " * 700 + "x", "!" * 520, "ab " * 400]
+    check(backend, pattern, strings, behaviour, invert)
+
+
+def test_bert_patterns_max_splits(backend):
+    strings = ["one two  three four", "a,b,c,d", "x", "  lead and trail  ", ",,,"]
+    for ms in (1, 2, 5):
+        check(backend, BERT_WS, strings, "remove", False, ms)
+        check(backend, BERT_PUNCT, strings, "isolate", False, ms)
+
+
+def test_bert_chain_matches_reference_kat(backend):
+    """tests/layer_tests.py:340 ("Hello     world!" -> bert whitespace) and the chained delimiter split on the pieces."""
+    inputs = one_string_per_row(["Hello     world!", "don't stop-me,now", "  多语言 text。"])
+    ws = np.frombuffer(BERT_WS.encode(), np.uint8)
+    pu = np.frombuffer(BERT_PUNCT.encode(), np.uint8)
+    ref1 = O.RegexSplit(BERT_WS, "remove")(*inputs)
+    got1 = RegexSplit("remove", lib=backend.lib).evaluate(backend.data(inputs) + [ws])
+    assert_same(ref1[:4], got1[:4], backend.host, "bert whitespace")
+    assert O.unpack_strings(ref1[2], ref1[3], ref1[4])[:2] == [b"Hello", b"world!"]
+    ref2 = O.RegexSplit(BERT_PUNCT, "isolate")(*ref1[:5])
+    got2 = RegexSplit("isolate", lib=backend.lib).evaluate(list(got1[:5]) + [pu])
+    assert_same(ref2[:4], got2[:4], backend.host, "bert delimiters on the whitespace pieces")
