@@ -3,8 +3,10 @@
 per GPU (config 2), inputs resident in HBM, fused RegexSplit+BPETokenizer through the C ABI.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: launched by torch.distributed.run)
+    python bench.py --config 3      BERT-shaped WordPiece, 65 536 x ~256-byte strings (fused BERT split + WordPiece)
+    python bench.py --config 5      detokenizer (VocabDecoder + ByteFallback + FuzeRagged fused), rows x 2048 ids
 
-One "step" = one pass of the hot path over one batch.  With N > 1 every rank encodes its own 65 536-row shard
+One "step" = one pass of the hot path over one batch.  With N > 1 every rank encodes its own shard of the same size
 (weak scaling) and the step includes the all-gather of the ragged token ids over RCCL/xGMI
 (openvino_tokenizers_amd/distributed.py); `value` = bytes of all ranks / max-over-ranks time.
 Prints ONE JSON line on rank 0.  The oracle is used only for the cpu_baseline leg and a parity spot-check.
@@ -26,14 +28,159 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from openvino_tokenizers_amd import _lib as L  # noqa: E402
-from openvino_tokenizers_amd.ops import BPETokenizer, RegexSplit  # noqa: E402
-from tools.harness import BpeTok  # noqa: E402
+from openvino_tokenizers_amd.ops import (BPETokenizer, RegexSplit, VocabDecoder, WordpieceTokenizer)  # noqa: E402
+from tools.harness import BpeTok, pack_strings  # noqa: E402
+from tools.make_tokenizers import load_tokenizer  # noqa: E402
 from tools.workloads import TextModel, ragged_rows  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 KERNEL_NAMES = {"lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>",
+                "lookup_words": "lookup_kernel<kFused> (BERT words)", "wordpiece_deferred": "wordpiece_deferred_kernel",
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",
-                "scan_rows": "tile_{reduce,scan,apply}_kernel"}
+                "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel",
+                "detokenize": "tile_{reduce,apply}_kernel<DecodeLen,DecodeApply>", "tile_scan": "tile_scan_kernel"}
+BERT_WS = r"\s+"
+BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\x{4E00}-\x{9FFF}]", r"[\x{3400}-\x{4DBF}]",
+                       r"[\x{20000}-\x{2A6DF}]", r"[\x{2A700}-\x{2B73F}]", r"[\x{2B740}-\x{2B81F}]",
+                       r"[\x{2B820}-\x{2CEAF}]", r"[\x{F900}-\x{FAFF}]", r"[\x{2F800}-\x{2FA1F}]"])
+PMC_FILE = ROOT / "profiles" / "latest_pmc.json"  # HBM traffic of the dominant kernels from a separate rocprofv3 --pmc run
+
+
+class Workload:
+    """One BASELINE.json configuration: how to build the inputs, run a step, count units, and check/baseline it."""
+    metric = "input MB/s encoded (GPT-2 BPE, 512-byte strings)"
+    unit = "MB/s"
+
+
+def make_encode_bpe(args, lib, dev, rank):
+    tok = BpeTok.load(args.tokenizer)
+    begins, ends, chars = TextModel(1234, args.text).batch(args.rows, args.bytes, seed=1000 + rank)
+    rb, re_ = ragged_rows(args.rows)
+    n_chars = int(len(chars))
+    d = [torch.as_tensor(x, device=dev) for x in (rb, re_, begins, ends, chars)]
+    split = RegexSplit("isolate", device=dev.index, lib=lib)
+    bpe = BPETokenizer(**dict(tok.attrs, cache_capacity=0 if args.no_memo else tok.attrs.get("cache_capacity", 20000)),
+                       device=dev.index, lib=lib)
+    split._ensure(tok.pattern_u8())
+    bpe._ensure(d + tok.consts)
+    rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), args.rows,
+                         L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), args.rows, n_chars))
+    o_begins = torch.empty(args.rows, dtype=torch.int32, device=dev)
+    o_ends = torch.empty(args.rows, dtype=torch.int32, device=dev)
+    o_ids = torch.empty(n_chars, dtype=torch.int32, device=dev)
+    out = L.RaggedI32Out(o_begins.data_ptr(), o_ends.data_ptr(), o_ids.data_ptr(), n_chars, 0, 0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step():
+        L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(out), L.MEM_DEVICE, stream))
+        return o_begins, o_ends, o_ids[: out.n_data]
+
+    def cpu(n_s):
+        from oracle import oracle as O
+        orc, ors = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+        ref = orc(*ors(rb[:1024], re_[:1024], begins[:1024], ends[:1024], chars)[:5])  # parity prefix + warms the piece cache
+        t1 = time.perf_counter()
+        orc(*ors(rb[:n_s], re_[:n_s], begins[:n_s], ends[:n_s], chars)[:5])
+        return ref, time.perf_counter() - t1, int(ends[n_s - 1] - begins[0]), "RegexSplit(PCRE2 JIT)+BPETokenizer restatement with warm piece cache"
+
+    workload = (f"config 2: GPT-2-shaped byte-level BPE (V=50257, 50000 merges, trained in-process), {args.rows} x "
+                f"~{args.bytes}-byte {args.text} strings per GPU, fused RegexSplit+BPETokenizer, inputs and outputs in HBM"
+                + (", piece memo disabled (cache_capacity=0)" if args.no_memo else ""))
+    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe, o_begins, o_ends, o_ids), workload=workload,
+                metric="input MB/s encoded (GPT-2 BPE, 512-byte strings)", dtype="u8/int32",
+                algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=min(args.rows, 32768))
+
+
+def make_encode_wordpiece(args, lib, dev, rank):
+    tok = load_tokenizer("bert")
+    nbytes = args.bytes if args.bytes != 512 else 256
+    begins, ends, chars = TextModel(1234, "zipf").batch(args.rows, nbytes, seed=2000 + rank)
+    chars = np.frombuffer(chars.tobytes().lower(), np.uint8).copy()  # BERT-uncased normalisation is upstream of this path
+    rb, re_ = ragged_rows(args.rows)
+    n_chars = int(len(chars))
+    d = [torch.as_tensor(x, device=dev) for x in (rb, re_, begins, ends, chars)]
+    ws = RegexSplit("remove", device=dev.index, lib=lib)
+    pu = RegexSplit("isolate", device=dev.index, lib=lib)
+    wp = WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], device=dev.index, lib=lib)
+    ws._ensure(BERT_WS)
+    pu._ensure(BERT_PUNCT)
+    consts = list(pack_strings(tok["vocab"])) + [np.asarray(tok["unk_id"], np.int32)]
+    wp._ensure(d + consts)
+    rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), args.rows,
+                         L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), args.rows, n_chars))
+    o_begins = torch.empty(args.rows, dtype=torch.int32, device=dev)
+    o_ends = torch.empty(args.rows, dtype=torch.int32, device=dev)
+    o_ids = torch.empty(n_chars, dtype=torch.int32, device=dev)
+    out = L.RaggedI32Out(o_begins.data_ptr(), o_ends.data_ptr(), o_ids.data_ptr(), n_chars, 0, 0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    unk = C.c_int32(int(tok["unk_id"]))
+
+    def step():
+        L.check(lib, lib.ovtk_wordpiece_encode_run(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(out), L.MEM_DEVICE, stream))
+        return o_begins, o_ends, o_ids[: out.n_data]
+
+    def cpu(n_s):
+        from oracle import oracle as O
+        s1, s2 = O.RegexSplit(BERT_WS, "remove"), O.RegexSplit(BERT_PUNCT, "isolate")
+        owp = O.WordpieceTokenizer(tok["vocab"], tok["suffix_indicator"], tok["max_bytes_per_word"])
+        chain = lambda n: owp(*s2(*s1(rb[:n], re_[:n], begins[:n], ends[:n], chars)[:5])[:5], tok["unk_id"])
+        ref = chain(1024)
+        t1 = time.perf_counter()
+        chain(n_s)
+        return ref, time.perf_counter() - t1, int(ends[n_s - 1] - begins[0]), "2 x RegexSplit(PCRE2 JIT) + WordpieceTokenizer restatement"
+
+    workload = (f"config 3: BERT-shaped WordPiece (V=30522, trained in-process), {args.rows} x ~{nbytes}-byte lower-cased zipf "
+                f"strings per GPU, fused RegexSplit(\\s+)+RegexSplit(delimiters)+WordpieceTokenizer, inputs and outputs in HBM")
+    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, ws, pu, wp, o_begins, o_ends, o_ids), workload=workload,
+                metric="input MB/s encoded (BERT WordPiece, 256-byte strings)", dtype="u8/int32",
+                algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=min(args.rows, 32768))
+
+
+def make_detokenize(args, lib, dev, rank):
+    tok = BpeTok.load(args.tokenizer)
+    rows = args.rows if args.rows != 65536 else 16384
+    S = 2048
+    V = len(tok.vocab)
+    rng = np.random.default_rng(3000 + rank)
+    ids = rng.integers(0, V - 1, size=(rows, S), dtype=np.int32)
+    pad = V - 1                                   # the special token: 1 % of the positions, skipped by the decoder
+    ids[rng.random((rows, S)) < 0.01] = pad
+    d_ids = torch.as_tensor(ids, device=dev)
+    dec = VocabDecoder(skip_tokens=[pad], device=dev.index, lib=lib)
+    vconst = list(pack_strings(tok.vocab))
+    dec._ensure([d_ids] + vconst)
+    lens = (vconst[1] - vconst[0]).astype(np.int64)
+    n_out = int(lens[ids[ids != pad]].sum())
+    cap = n_out + 64
+    o_begins = torch.empty(rows, dtype=torch.int32, device=dev)
+    o_ends = torch.empty(rows, dtype=torch.int32, device=dev)
+    o_chars = torch.empty(cap, dtype=torch.uint8, device=dev)
+    out = L.StringsOut(o_begins.data_ptr(), o_ends.data_ptr(), o_chars.data_ptr(), cap, 0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    pids = C.c_void_p(d_ids.data_ptr())
+
+    def step():
+        L.check(lib, lib.ovtk_detokenize_run(dec._h, pids, C.c_int64(rows), C.c_int64(S), None, C.c_int64(0), 1, C.byref(out),
+                                             L.MEM_DEVICE, stream))
+        return o_begins, o_ends, o_chars[: out.n_chars]
+
+    def cpu(n_s):
+        from oracle import oracle as O
+        def chain(n):
+            r = O.vocab_decoder(ids[:n], tok.vocab, [pad])
+            bf = O.byte_fallback(*r[2:5])
+            fz = O.fuze(r[0], r[1], bf[0], bf[1])
+            return fz[0], fz[1], bf[2]
+        ref = chain(16)
+        t1 = time.perf_counter()
+        chain(n_s)
+        return ref, time.perf_counter() - t1, n_s * S, "VocabDecoder + ByteFallback + FuzeRagged restatement"
+
+    workload = (f"config 5 chunk: detokenize {rows} x {S} ids (GPT-2-shaped vocabulary, 1 % skipped special ids) per GPU, "
+                f"fused VocabDecoder+ByteFallback+FuzeRagged, inputs and outputs in HBM ({n_out} output bytes < 2^31)")
+    return dict(step=step, cpu=cpu, n_units=rows * S, out=out, keep=(d_ids, dec, o_begins, o_ends, o_chars), workload=workload,
+                metric="token ids/s detokenized (seq 2048)", dtype="int32/u8", unit="Mtok/s", rows=rows,
+                algo=lambda _n: 4 * rows * S + n_out + 8 * rows, sample_rows=min(rows, 1024), is_detok=True, n_out=n_out)
 
 
 def main():
@@ -41,10 +188,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5])
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--bytes", type=int, default=512)
     ap.add_argument("--text", default="zipf", choices=["zipf", "uniform", "mixed"])
     ap.add_argument("--tokenizer", default="gpt2")
+    ap.add_argument("--no-memo", action="store_true", help="config 2: BPETokenizer with cache_capacity=0 (no piece memo)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the all-gather (rank-local consumer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -60,31 +209,14 @@ def main():
         from openvino_tokenizers_amd.distributed import all_gather_ragged
 
     lib = L.load()
-    tok = BpeTok.load(args.tokenizer)
-    begins, ends, chars = TextModel(1234, args.text).batch(args.rows, args.bytes, seed=1000 + rank)
-    rb, re_ = ragged_rows(args.rows)
-    n_chars = int(len(chars))
-    d = [torch.as_tensor(x, device=dev) for x in (rb, re_, begins, ends, chars)]
-
-    split = RegexSplit("isolate", device=local_rank, lib=lib)
-    bpe = BPETokenizer(**tok.attrs, device=local_rank, lib=lib)
-    split._ensure(tok.pattern_u8())
-    bpe._ensure(d + tok.consts)
-
-    # pre-built C-ABI arguments: nothing but the library call is inside a step
-    rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), args.rows,
-                         L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), args.rows, n_chars))
-    o_begins = torch.empty(args.rows, dtype=torch.int32, device=dev)
-    o_ends = torch.empty(args.rows, dtype=torch.int32, device=dev)
-    o_ids = torch.empty(n_chars, dtype=torch.int32, device=dev)
-    out = L.RaggedI32Out(o_begins.data_ptr(), o_ends.data_ptr(), o_ids.data_ptr(), n_chars, 0, 0)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    wl = {2: make_encode_bpe, 3: make_encode_wordpiece, 5: make_detokenize}[args.config](args, lib, dev, rank)
+    is_detok = wl.get("is_detok", False)
 
     def step():
-        L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(out), L.MEM_DEVICE, stream))
-        if world > 1 and not args.no_gather:
-            return all_gather_ragged(o_begins, o_ends, o_ids[: out.n_data])
-        return None
+        res = wl["step"]()
+        if world > 1 and not args.no_gather and not is_detok:
+            return all_gather_ragged(*res)
+        return res
 
     def barrier():
         torch.cuda.synchronize()
@@ -99,23 +231,24 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        res = step()
     barrier()
     dt = time.perf_counter() - t0
     lib.ovtk_profile_enable(0)
+    n_units = wl["n_units"]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        nb = torch.tensor([n_chars], dtype=torch.int64, device=dev)
+        nb = torch.tensor([n_units], dtype=torch.int64, device=dev)
         dist.all_reduce(nb)
-        total_bytes = int(nb.item())
+        total_units = int(nb.item())
     else:
-        total_bytes = n_chars
+        total_units = n_units
 
-    n_tokens = int(out.n_data)
+    n_out = int(wl["out"].n_chars) if is_detok else int(wl["out"].n_data)
     ms_per_step = dt / args.steps * 1e3
-    value = total_bytes * args.steps / dt / 1e6  # MB/s, whole job
+    value = total_units * args.steps / dt / 1e6  # MB/s (or Mtok/s), whole job
 
     # ---- roofline of the dominant kernel (HIP events recorded by the library on the launch stream)
     buf = C.create_string_buffer(8192)
@@ -126,13 +259,18 @@ def main():
     roofline = None
     if per_step:
         dom = max(per_step, key=per_step.get)  # the dominant kernel of the step
+        launches_per_step = max(1, round(prof[dom][1] / args.steps))
         k_ms = prof[dom][0] / max(prof[dom][1], 1)
-        algo_bytes = n_chars + 4 * n_tokens + 16 * args.rows  # A_enc = N_c + 4 N_t + 16 B per launch
-        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        algo_bytes = wl["algo"](n_out)  # algorithmic bytes of one pass
+        achieved = algo_bytes / launches_per_step / (k_ms * 1e-3) / 1e9
+        traffic = None
+        if PMC_FILE.exists():  # per-launch FETCH_SIZE (doubled: gfx950 correction) + WRITE_SIZE of this kernel, see profiles/README.md
+            pmc = json.loads(PMC_FILE.read_text())
+            traffic = pmc.get(f"config{args.config}", {}).get(dom)
         roofline = {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom), "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": None, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
-                    "input_GBps_kernel_only": round(n_chars / (k_ms * 1e-3) / 1e9, 2),
+                    "traffic": traffic, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
+                    "launches_per_step": launches_per_step,
                     "all_kernels_ms_per_step": round(sum(per_step.values()), 4)}
 
     if rank != 0:
@@ -143,34 +281,25 @@ def main():
     # ---- parity spot-check + CPU baseline (oracle = "port" of the reference's algorithm), rank 0 only
     cpu_baseline, parity = None, None
     if not args.no_cpu_baseline:
-        from oracle import oracle as O
-        orc, ors = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
-        n_chk = min(args.rows, 1024)
-        ref = orc(*ors(rb[:n_chk], re_[:n_chk], begins[:n_chk], ends[:n_chk], chars)[:5])  # also warms the piece cache
-        got_ends = o_ends[:n_chk].cpu().numpy()
-        got_ids = o_ids[: int(got_ends[-1])].cpu().numpy()
-        parity = bool(np.array_equal(ref[1], got_ends) and np.array_equal(ref[2], got_ids))
+        n_s = wl["sample_rows"]
+        ref, cdt, sample_units, what = wl["cpu"](n_s)
+        b, e, payload = wl["step"]()
+        n_chk = len(ref[1])
+        got_ends = e[:n_chk].cpu().numpy()
+        got = payload[: int(got_ends[-1])].cpu().numpy()
+        parity = bool(np.array_equal(ref[1], got_ends) and np.array_equal(ref[2], got))
         if world == 1:
-            n_s = min(args.rows, 32768)
-            t1 = time.perf_counter()
-            sp = ors(rb[:n_s], re_[:n_s], begins[:n_s], ends[:n_s], chars)
-            orc(*sp[:5])
-            cdt = time.perf_counter() - t1
-            sample_bytes = int(ends[n_s - 1] - begins[0])
-            cpu_baseline = {"value": round(sample_bytes / cdt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-                            "sample": f"first {n_s} rows ({sample_bytes} bytes) of the same batch, RegexSplit(PCRE2 "
-                                      f"JIT)+BPETokenizer restatement with warm piece cache, {cdt:.2f} s",
+            cpu_baseline = {"value": round(sample_units / cdt / 1e6, 2), "unit": wl.get("unit", "MB/s"), "cores": 1, "kind": "port",
+                            "sample": f"first {n_s} rows ({sample_units} {'ids' if is_detok else 'bytes'}) of the same batch, "
+                                      f"{what}, {cdt:.2f} s",
                             "host_cpus": os.cpu_count()}
 
     line = {
-        "metric": "input MB/s encoded (GPT-2 BPE, 512-byte strings)", "value": round(value, 1), "unit": "MB/s",
+        "metric": wl["metric"], "value": round(value, 1), "unit": wl.get("unit", "MB/s"),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
-        "config": {"workload": f"config 2: GPT-2-shaped byte-level BPE (V=50257, 50000 merges, trained in-process), "
-                               f"{args.rows} x ~{args.bytes}-byte {args.text} strings per GPU, fused RegexSplit+BPETokenizer, "
-                               f"inputs and outputs in HBM",
-                   "rows_per_gpu": args.rows, "bytes_per_gpu": n_chars, "tokens_per_gpu": n_tokens,
-                   "exchange": ("none (1 GPU)" if world == 1 else ("none (--no-gather)" if args.no_gather else
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
+        "config": {"workload": wl["workload"], "rows_per_gpu": wl.get("rows", args.rows), "units_per_gpu": n_units, "outputs_per_gpu": n_out,
+                   "exchange": ("none (1 GPU)" if world == 1 else ("none (rank-local consumer)" if args.no_gather or is_detok else
                                                                     "all-gather of ragged ids over RCCL"))},
         "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_prefix_bit_exact": parity,
         "kernel_ms": kernels,

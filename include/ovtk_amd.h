@@ -165,6 +165,12 @@ typedef struct ovtk_wordpiece ovtk_wordpiece;
 int ovtk_wordpiece_create(const ovtk_wordpiece_params* params, ovtk_wordpiece** out);
 int ovtk_wordpiece_run(ovtk_wordpiece* h, const ovtk_ragged_strings* in, int32_t unk_token_id,
                        ovtk_ragged_i32_out* out, int mem, void* stream);
+/* Fused RegexSplit(\s+, remove) -> RegexSplit(BERT delimiters, isolate) -> WordpieceTokenizer: the sub-graph
+ * tokenizer_pipeline.py:392-435 (bert_splitter) + :641-659 builds for BERT models; same result as chaining the three ops,
+ * without the word begins/ends round trips through HBM.  Any other pair of split handles is OVTK_E_UNSUPPORTED. */
+int ovtk_wordpiece_encode_run(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
+                              const ovtk_ragged_strings* in, int32_t unk_token_id, ovtk_ragged_i32_out* out, int mem,
+                              void* stream);
 void ovtk_wordpiece_destroy(ovtk_wordpiece* h);
 
 /* ---------------------------------------------------------------- VocabEncoder

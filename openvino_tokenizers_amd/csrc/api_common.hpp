@@ -10,6 +10,15 @@
 #include "runtime.hpp"
 #include "tables.hpp"
 
+// Handle of RegexSplit (shared by api_encode.cpp and the fused WordPiece path in api_ops.cpp).
+struct ovtk_regex_split {
+    int device = 0;
+    ovtk::SplitDev dev{};
+    int mode = 1;  // 0 removed, 1 isolated, 2 merged-with-previous, 3 merged-with-next
+    bool invert = false;
+    int max_splits = -1;
+};
+
 namespace ovtk {
 
 inline int use_device(int device) {

@@ -48,13 +48,6 @@ int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks) {
 
 }  // namespace
 
-struct ovtk_regex_split {
-    int device = 0;
-    SplitDev dev{};
-    int mode = 1;  // 0 removed, 1 isolated, 2 merged-with-previous, 3 merged-with-next
-    bool invert = false;
-    int max_splits = -1;
-};
 
 struct ovtk_bpe {
     int device = 0;

@@ -70,6 +70,8 @@ struct ovtk_wordpiece {
     int device = 0;
     WordpieceDev dev{};
     TrieBufs root, sub;
+    DevBuf memo_buf;
+    PieceTableDev memo{nullptr, 30};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
 };
 
 struct ovtk_vocab_encoder {
@@ -105,6 +107,30 @@ int ovtk_wordpiece_create(const ovtk_wordpiece_params* p, ovtk_wordpiece** out) 
     if (int rc = h->sub.upload(sub, h->dev.sub)) return rc;
     OVTK_HIP(hipStreamSynchronize(nullptr));
     h->dev.max_bytes = p->max_bytes_per_word;
+    // Word memo for ovtk_wordpiece_encode_run: WordPiece(t) of every vocabulary string t taken as a word, computed by the
+    // device op itself (one word per row).  No entry depends on unk_token_id: a word that needs unk is simply not stored.
+    if (p->vocab.n > 0) {
+        const size_t V = size_t(p->vocab.n);
+        std::vector<int32_t> rb(V), re(V), ob(V), oe(V);
+        for (size_t i = 0; i < V; ++i) {
+            rb[i] = int32_t(i);
+            re[i] = int32_t(i + 1);
+        }
+        const int64_t cap = p->vocab.n_chars + p->vocab.n;
+        std::vector<int32_t> ids(static_cast<size_t>(cap) + 1);
+        ovtk_ragged_strings in{rb.data(), re.data(), p->vocab.n, p->vocab};
+        ovtk_ragged_i32_out o{ob.data(), oe.data(), ids.data(), cap, 0, 0};
+        const int32_t marker = INT32_MIN + 1;  // stands for unk while the memo is built
+        if (int rc = ovtk_wordpiece_run(h.get(), &in, marker, &o, OVTK_MEM_HOST, nullptr)) return rc;
+        for (size_t i = 0; i < V; ++i)  // drop the words that produced unk (an entry with 4+ ids is never stored)
+            for (int32_t k = ob[i]; k < oe[i]; ++k)
+                if (ids[size_t(k)] == marker) { oe[i] = ob[i] + kPieceMaxIds + 1; break; }
+        PieceTableHost host;
+        build_piece_table(view_of(p->vocab), ob.data(), oe.data(), ids.data(), host);
+        if (int rc = h->memo_buf.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
+        OVTK_HIP(hipStreamSynchronize(nullptr));
+        h->memo = PieceTableDev{h->memo_buf.as<PieceEntry>(), host.shift};
+    }
     *out = h.release();
     return OVTK_OK;
 }
@@ -123,6 +149,53 @@ int ovtk_wordpiece_run(ovtk_wordpiece* h, const ovtk_ragged_strings* in, int32_t
                            [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                OVTK_LAUNCH(ws.marks, "wordpiece", wordpiece_kernel, grid, kBlockThreads, s, d_in, h->dev,
                                            unk_token_id, w);
+                           });
+}
+
+int ovtk_wordpiece_encode_run(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
+                              const ovtk_ragged_strings* in, int32_t unk_token_id, ovtk_ragged_i32_out* out, int mem,
+                              void* stream) {
+    if (int rc = check_rows(in)) return rc;
+    if (!h || !whitespace || !delimiters || !out) return set_error(OVTK_E_ARG, "null argument");
+    if (whitespace->dev.kind != kSplitWhitespace || whitespace->dev.drop != 1 || whitespace->max_splits != -1 ||
+        delimiters->dev.kind != kSplitBertPunct || delimiters->dev.drop != 0 || delimiters->max_splits != -1)
+        return set_error(OVTK_E_UNSUPPORTED,
+                         "fused WordPiece encode needs RegexSplit(\\s+, remove) followed by RegexSplit(BERT delimiters, isolate)");
+    if (whitespace->device != h->device || delimiters->device != h->device)
+        return set_error(OVTK_E_ARG, "split and wordpiece handles live on different devices");
+    if (out->data_capacity < 0 || out->data_capacity >= INT32_MAX) return set_error(OVTK_E_ARG, "bad output capacity");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(h->device));
+    out->n_data = 0;
+    out->n_rows = in->n_rows;
+    if (in->strings.n_chars == 0) {  // regex_split.cpp:129-143: the first split leaves one empty row
+        const int32_t zero = 0;
+        if (mem == OVTK_MEM_HOST) {
+            out->begins[0] = 0;
+            out->ends[0] = 0;
+        } else {
+            OVTK_HIP(hipMemcpyAsync(out->begins, &zero, 4, hipMemcpyHostToDevice, s));
+            OVTK_HIP(hipMemcpyAsync(out->ends, &zero, 4, hipMemcpyHostToDevice, s));
+            OVTK_HIP(hipStreamSynchronize(s));
+        }
+        out->n_rows = 1;
+        return OVTK_OK;
+    }
+    if (in->n_rows == 0) return OVTK_OK;
+    SplitDev sp = whitespace->dev;
+    sp.kind = kSplitBertWords;  // whitespace runs dropped, every delimiter char its own word
+    sp.drop = 1;
+    BpeDev memo_only{};        // the lookup kernel reads nothing but the memo and the (absent) end suffix
+    memo_only.pieces = h->memo;
+    memo_only.suffix_len = 0;
+    const int dev = h->device;
+    return run_rows_to_ids(dev, "WordpieceTokenizer", in, nullptr, 1, out, mem, s,
+                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
+                               OVTK_LAUNCH(ws.marks, "lookup_words", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp,
+                                           memo_only, w);
+                               OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel,
+                                           dim3(std::max(1, device_cu_count(dev) * 8 / kShards), kShards), kBlockThreads, s, d_in,
+                                           h->dev, unk_token_id, w);
                            });
 }
 

@@ -18,6 +18,32 @@ struct WordpieceDev {
     int32_t max_bytes;
 };
 
+// WordPiece of one word (wordpiece_tokenizer.cpp:100-126) into slot[0..): returns the id count (>= 1).
+template <class GetByte>
+__device__ __forceinline__ int wordpiece_word(const WordpieceDev& T, const I2* root_lds, const I2* sub_lds, GetByte&& getb,
+                                              int len, int32_t unk_id, int32_t* slot) {
+    if (len > T.max_bytes || len <= 0) {  // strict > (:100-103); an empty word is undefined in the reference
+        slot[0] = unk_id;
+        return 1;
+    }
+    int idx = 0, cnt = 0;
+    int tok = trie_longest(T.root, root_lds, getb, len, idx);
+    if (tok == -1) {
+        slot[0] = unk_id;
+        return 1;
+    }
+    slot[cnt++] = tok;
+    while (idx < len) {
+        tok = trie_longest(T.sub, sub_lds, getb, len, idx);
+        if (tok == -1) {  // :118-123 the whole word becomes one unk
+            slot[0] = unk_id;
+            return 1;
+        }
+        slot[cnt++] = tok;
+    }
+    return cnt;
+}
+
 static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn in, WordpieceDev T, int32_t unk_id, EncodeWork w) {
     __shared__ I2 root_lds[256];
     __shared__ I2 sub_lds[256];
@@ -46,29 +72,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn 
             int cnt = 0;
             if (valid) {
                 const uint8_t* s = in.chars + sb;
-                auto getb = [&](int i) -> uint32_t { return s[i]; };
-                if (len > T.max_bytes || len <= 0) {  // strict > (:100-103); an empty word is undefined in the reference
-                    slot[0] = unk_id;
-                    cnt = 1;
-                } else {
-                    int idx = 0;
-                    int tok = trie_longest(T.root, root_lds, getb, len, idx);
-                    if (tok == -1) {
-                        slot[0] = unk_id;
-                        cnt = 1;
-                    } else {
-                        slot[cnt++] = tok;
-                        while (idx < len) {
-                            tok = trie_longest(T.sub, sub_lds, getb, len, idx);
-                            if (tok == -1) {  // :118-123 the whole word becomes one unk
-                                slot[0] = unk_id;
-                                cnt = 1;
-                                break;
-                            }
-                            slot[cnt++] = tok;
-                        }
-                    }
-                }
+                cnt = wordpiece_word(T, root_lds, sub_lds, [&](int i) -> uint32_t { return s[i]; }, len, unk_id, slot);
                 for (int k = cnt; k < units; ++k) slot[k] = kEmptyId;
             }
             emitted += wave_sum(cnt);
@@ -80,6 +84,52 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn 
             w.row_used[row] = bytepos;
         }
         cursor += bytepos;
+    }
+}
+
+// The words the fused BERT path could not resolve through the memo (encode_kernels.hpp lookup_kernel with the
+// kSplitBertWords scanner): dense batches of 64 deferred words, one lane per word.
+static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kernel(RowsIn in, WordpieceDev T, int32_t unk_id,
+                                                                                 EncodeWork w) {
+    __shared__ I2 root_lds[256];
+    __shared__ I2 sub_lds[256];
+    for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) {
+        root_lds[i] = T.root.root[i];
+        sub_lds[i] = T.sub.root[i];
+    }
+    __syncthreads();
+    if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
+    const int l = lane_id();
+    const int shard = int(blockIdx.y);
+    int count = w.status->shard_count[shard * kCounterStride];
+    if (count > w.shard_cap) count = w.shard_cap;
+    const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
+    const int stride = int(gridDim.x) * kBlockThreads;
+    for (int base = (int(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kWave; base < count; base += stride) {
+        const bool valid = base + l < count;
+        DeferredPiece e{};
+        if (valid) e = list[base + l];
+        int cnt = 0;
+        if (valid) {
+            int32_t* out = w.stage + e.stage_pos;
+            if (e.len >= 1 && e.len <= kPieceKeyBytes) {
+                const uint64_t k0 = e.k0, k1 = e.k1;
+                cnt = wordpiece_word(
+                    T, root_lds, sub_lds,
+                    [&](int i) -> uint32_t { return uint32_t((i < 8 ? k0 >> (8 * i) : k1 >> (8 * (i - 8))) & 0xFF); }, e.len,
+                    unk_id, out);
+            } else {
+                const uint8_t* s = in.chars + e.begin;
+                cnt = wordpiece_word(T, root_lds, sub_lds, [&](int i) -> uint32_t { return s[i]; }, e.len, unk_id, out);
+            }
+            for (int k = cnt; k < e.len; ++k) out[k] = kEmptyId;
+        }
+        const int incl = wave_incl_sum(cnt);
+        const int my_row = valid ? e.row : -1;
+        const int prev_row = __shfl_up(my_row, 1), next_row = __shfl_down(my_row, 1);
+        const bool head = l == 0 || prev_row != my_row, tail = l == kWave - 1 || next_row != my_row;
+        const int seg_base = wave_incl_max(head ? incl - cnt : 0);
+        if (valid && tail && incl - seg_base > 0) atomicAdd(&w.row_cnt[e.row], incl - seg_base);
     }
 }
 

@@ -463,3 +463,30 @@ class FusedDetokenizer:
         d._chk(d._lib.ovtk_detokenize_run(d._h, pids, C.c_int64(B), C.c_int64(S), pskip, C.c_int64(nskip),
                                           int(self.byte_fallback), C.byref(out), m.mem, m.stream))
         return [ob[:B], oe[:B], oc[:out.n_chars]]
+
+
+class FusedSplitWordpiece:
+    """RegexSplit(\\s+, remove) -> RegexSplit(BERT delimiters, isolate) -> WordpieceTokenizer in one pass
+    (ovtk_wordpiece_encode_run): the same result as chaining the three ops (what tokenizer_pipeline.py:392-435 and
+    :641-659 build for BERT models) without materialising the words."""
+
+    def __init__(self, whitespace: RegexSplit, delimiters: RegexSplit, wordpiece: WordpieceTokenizer):
+        self.whitespace, self.delimiters, self.wordpiece = whitespace, delimiters, wordpiece
+
+    def evaluate(self, ragged_inputs, whitespace_pattern, delimiters_pattern, wordpiece_constant_inputs):
+        """ragged_inputs: inputs 0-4 of the first RegexSplit; wordpiece_constant_inputs: inputs 5-8 of WordpieceTokenizer."""
+        self.whitespace._ensure(whitespace_pattern)
+        self.delimiters._ensure(delimiters_pattern)
+        wp = self.wordpiece
+        wp._ensure(list(ragged_inputs[:5]) + list(wordpiece_constant_inputs))
+        unk = int(np.asarray(_host(wordpiece_constant_inputs[3], np.int32)).reshape(-1)[0])
+        m = _Mem(ragged_inputs[4])
+        rs, (rb, _, _, _, c) = _ragged_in(m, ragged_inputs)
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        cap = len(c)
+        ids, pids = m.alloc(cap, "i32")
+        out = L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
+        L.check(wp._lib, wp._lib.ovtk_wordpiece_encode_run(wp._h, self.whitespace._h, self.delimiters._h, C.byref(rs),
+                                                           C.c_int32(unk), C.byref(out), m.mem, m.stream))
+        return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]

@@ -7,8 +7,8 @@ import numpy as np
 import pytest
 
 from openvino_tokenizers_amd import _lib as L
-from openvino_tokenizers_amd.ops import (ByteFallback, FusedDetokenizer, FuzeRagged, RaggedToDense, VocabDecoder,
-                                         VocabEncoder, WordpieceTokenizer)
+from openvino_tokenizers_amd.ops import (ByteFallback, FusedDetokenizer, FusedSplitWordpiece, FuzeRagged, RaggedToDense,
+                                         RegexSplit, VocabDecoder, VocabEncoder, WordpieceTokenizer)
 from oracle import oracle as O
 from tests.golden.reference_kats import RAGGED_TO_DENSE_KATS
 from tests.util import assert_same, one_string_per_row, pack_strings
@@ -69,6 +69,59 @@ def test_wordpiece(backend, name, n, target):
     got = op.evaluate(backend.data(words) + wp_consts(tok))
     assert_same(ref, got, backend.host, "WordpieceTokenizer")
     assert (ref[2] == tok["unk_id"]).sum() < len(ref[2]) // 2
+
+
+@pytest.mark.parametrize("name,kind,n,target", [("bert_small", "zipf", 40, 200), ("bert_small", "mixed", 24, 300),
+                                                 ("bert", "zipf", 12, 256)])
+def test_fused_split_wordpiece(backend, name, kind, n, target):
+    """The three-op BERT chain on the device (two RegexSplit scanners + WordpieceTokenizer) and the fused path, both
+    against the oracle chain (PCRE2 splits + trie WordPiece)."""
+    tok = load_tokenizer(name)
+    b, e, c = TextModel(31, kind).batch(n, target)
+    c = np.frombuffer(c.tobytes().decode().lower().encode(), np.uint8) if kind == "zipf" else c
+    if kind == "mixed":  # lower() may change byte lengths of non-ASCII text: keep the original bytes
+        pass
+    rb, re_ = ragged_rows(n)
+    inputs = [rb, re_, b, e, c]
+    words = bert_words(inputs)
+    ref = O.WordpieceTokenizer(tok["vocab"], tok["suffix_indicator"], tok["max_bytes_per_word"])(*words, tok["unk_id"])
+    ws_pat, pu_pat = np.frombuffer(BERT_WS.encode(), np.uint8), np.frombuffer(BERT_PUNCT.encode(), np.uint8)
+    data = backend.data(inputs)
+    ws = RegexSplit("remove", lib=backend.lib)
+    pu = RegexSplit("isolate", lib=backend.lib)
+    wp = WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], lib=backend.lib)
+    s1 = ws.evaluate(data + [ws_pat])
+    s2 = pu.evaluate(list(s1[:5]) + [pu_pat])
+    assert_same(words[:4], s2[:4], backend.host, "BERT split chain")
+    got = wp.evaluate(list(s2[:5]) + wp_consts(tok))
+    assert_same(ref, got, backend.host, "WordpieceTokenizer on device-split words")
+    fused = FusedSplitWordpiece(ws, pu, wp).evaluate(data, ws_pat, pu_pat, wp_consts(tok)[0:3] + [np.asarray(tok["unk_id"], np.int32)])
+    assert_same(ref, fused, backend.host, "fused split + WordPiece")
+
+
+def test_fused_split_wordpiece_edge_cases(backend):
+    """Unknown / over-long words, > 15-byte words (memo misses), empty rows, the all-empty batch, > 512-byte strings."""
+    vocab = [b"[UNK]", b"un", b"##aff", b"##able", b"aff", b"a", b"##b", b"able", b"unaffable", b"x" * 20, b"##" + b"x" * 20,
+             b",", b"!", "é".encode(), "##é".encode(), "元".encode()]
+    strings = ["unaffable, unaffablez! a ab abz", "", "   ", "x" * 20 + " " + "x" * 40 + "," + "x" * 41, "éé éz 元元 a元b",
+               "a " * 400, "able" * 200, ",,,,", " lead", "trail "]
+    inputs = one_string_per_row(strings)
+    ws_pat, pu_pat = np.frombuffer(BERT_WS.encode(), np.uint8), np.frombuffer(BERT_PUNCT.encode(), np.uint8)
+    consts = list(pack_strings(vocab)) + [np.asarray(0, np.int32)]
+    for max_bytes in (100, 40, 3):
+        ref = O.WordpieceTokenizer(vocab, "##", max_bytes)(*bert_words(inputs), 0)
+        fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
+                                    WordpieceTokenizer("##", max_bytes, lib=backend.lib))
+        assert_same(ref, fused.evaluate(backend.data(inputs), ws_pat, pu_pat, consts), backend.host, f"max_bytes={max_bytes}")
+    empty = one_string_per_row(["", ""])
+    ref = O.WordpieceTokenizer(vocab, "##", 100)(*bert_words(empty), 0)
+    fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
+                                WordpieceTokenizer("##", 100, lib=backend.lib))
+    assert_same(ref, fused.evaluate(backend.data(empty), ws_pat, pu_pat, consts), backend.host, "all-empty batch")
+    with pytest.raises(L.OvtkError) as ei:  # any other split pair is refused, never approximated
+        FusedSplitWordpiece(RegexSplit("isolate", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
+                            WordpieceTokenizer("##", 100, lib=backend.lib)).evaluate(backend.data(inputs), ws_pat, pu_pat, consts)
+    assert ei.value.code == L.E_UNSUPPORTED
 
 
 def test_wordpiece_edge_cases(backend):
