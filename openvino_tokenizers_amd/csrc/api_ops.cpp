@@ -63,6 +63,26 @@ int scan_and_apply(Workspace& ws, hipStream_t s, long long n, LenF len, ApplyF a
     return OVTK_OK;
 }
 
+// VocabDecoder / fused detokenizer: count pass -> scan -> write pass over (row, segment) units.
+int decode_passes(Workspace& ws, hipStream_t s, int device, const DecodeDev& d, int64_t batch, int64_t seq, int32_t* tok_begins,
+                  int32_t* tok_ends, int32_t* row_begins, int32_t* row_ends, uint8_t* chars, long long cap, RunStatus* st,
+                  const char* tag) {
+    const int n_seg = int((seq + kSegTokens - 1) / kSegTokens);
+    const long long n_units = batch * n_seg;
+    if (int rc = ws.gen[2].ensure(size_t(n_units) * sizeof(long long))) return rc;
+    if (int rc = ws.gen[3].ensure(size_t(n_units) * sizeof(long long))) return rc;
+    if (int rc = ws.tiles.ensure(scan_tiles_bytes(n_units))) return rc;
+    long long* unit_bytes = ws.gen[2].as<long long>();
+    long long* unit_off = ws.gen[3].as<long long>();
+    const int grid = int(std::min<long long>((n_units + kWavesPerBlock - 1) / kWavesPerBlock, (long long)device_cu_count(device) * 8));
+    OVTK_LAUNCH(ws.marks, "decode_count", decode_count_kernel, grid, kBlockThreads, s, d, int(seq), n_seg, n_units, unit_bytes);
+    launch_scan(ws.marks, "decode_scan", s, n_units, UnitLen{unit_bytes}, UnitApply{unit_off, n_seg, row_begins, row_ends},
+                CharsFin{st, cap}, ws.tiles.as<long long>(), st, kFlagOutCapacity | kFlagRange);
+    OVTK_LAUNCH(ws.marks, tag, decode_write_kernel, grid, kBlockThreads, s, d, int(seq), n_seg, n_units,
+                (const long long*)unit_off, (const long long*)unit_bytes, tok_begins, tok_ends, chars, (const RunStatus*)st);
+    return OVTK_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------- handles
@@ -85,7 +105,7 @@ struct ovtk_vocab_decoder {
     int device = 0;
     int32_t vocab_size = 0;
     int32_t max_token_len = 0;
-    DevBuf vb, ve, vc, skip_bits, fallback;
+    DevBuf vb, vc, skip_bits, len_plain, pack_plain, len_bf, pack_bf;
     std::vector<uint32_t> attr_skip_bits;  // host copy, attribute skip_tokens
     bool has_attr_skips = false;
 };
@@ -333,14 +353,20 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
     h->device = p->device;
     const int64_t V = p->vocab.n;
     h->vocab_size = int32_t(V);
-    std::vector<int16_t> fb(size_t(std::max<int64_t>(V, 1)), int16_t(-1));
+    if (V > 0 && (!p->vocab.begins || !p->vocab.ends)) return set_error(OVTK_E_ARG, "vocab_decoder: null vocab offsets");
+    const size_t nv = size_t(std::max<int64_t>(V, 1));
+    std::vector<uint16_t> len_plain(nv, 0), len_bf(nv, 0);
+    std::vector<TokenPack> pack_plain(nv, TokenPack{{0, 0, 0, 0}}), pack_bf(nv, TokenPack{{0, 0, 0, 0}});
     for (int64_t i = 0; i < V; ++i) {
         const int64_t b = p->vocab.begins[i], e = p->vocab.ends[i];
         if (b < 0 || e < b || e > p->vocab.n_chars) return set_error(OVTK_E_RANGE, "vocab_decoder: vocab begins/ends outside chars");
+        if (e - b > 0xFFFF) return set_error(OVTK_E_UNSUPPORTED, "vocab_decoder: tokens longer than 65535 bytes are not supported");
         h->max_token_len = std::max<int32_t>(h->max_token_len, int32_t(e - b));
-        // ByteFallback applied to this token (byte_fallback.cpp:37-41), precomputed once per vocabulary
         const uint8_t* t = p->vocab.chars + b;
         const int len = int(e - b);
+        len_plain[size_t(i)] = uint16_t(len);
+        std::memcpy(pack_plain[size_t(i)].w, t, size_t(std::min(len, 16)));
+        // ByteFallback applied to this token (byte_fallback.cpp:37-41), precomputed once per vocabulary
         int v = -1;
         if (len == 6 && t[0] == '<' && t[5] == '>') {
             bool only_first = true;
@@ -351,7 +377,13 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
                 if (t[1] == '0' && t[2] == 'x' && hex(t[3]) >= 0 && hex(t[4]) >= 0) v = hex(t[3]) * 16 + hex(t[4]);
             }
         }
-        fb[size_t(i)] = int16_t(v);
+        if (v >= 0) {
+            len_bf[size_t(i)] = 1;
+            pack_bf[size_t(i)].w[0] = uint32_t(v);
+        } else {
+            len_bf[size_t(i)] = len_plain[size_t(i)];
+            pack_bf[size_t(i)] = pack_plain[size_t(i)];
+        }
     }
     h->attr_skip_bits.assign(size_t((V + 31) / 32 + 1), 0u);
     for (int64_t k = 0; k < p->n_skip_tokens; ++k) {
@@ -363,9 +395,11 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
     }
     int e = 0;
     e = e ? e : h->vb.upload(p->vocab.begins, size_t(V) * 4);
-    e = e ? e : h->ve.upload(p->vocab.ends, size_t(V) * 4);
     e = e ? e : h->vc.upload(p->vocab.chars, size_t(p->vocab.n_chars));
-    e = e ? e : h->fallback.upload(fb.data(), fb.size() * sizeof(int16_t));
+    e = e ? e : h->len_plain.upload(len_plain.data(), nv * sizeof(uint16_t));
+    e = e ? e : h->pack_plain.upload(pack_plain.data(), nv * sizeof(TokenPack));
+    e = e ? e : h->len_bf.upload(len_bf.data(), nv * sizeof(uint16_t));
+    e = e ? e : h->pack_bf.upload(pack_bf.data(), nv * sizeof(TokenPack));
     e = e ? e : h->skip_bits.upload(h->attr_skip_bits.data(), h->attr_skip_bits.size() * 4);
     if (e) return e;
     OVTK_HIP(hipStreamSynchronize(nullptr));
@@ -381,12 +415,13 @@ namespace {
 
 // Common front of VocabDecoder and the fused detokenizer: ids on the device + the skip bitmap of this call.
 int decoder_inputs(ovtk_vocab_decoder* h, Workspace& ws, const int32_t* ids, int64_t n_ids, const int32_t* skip_in,
-                   int64_t n_skip_in, int mem, hipStream_t s, DecodeDev& d) {
+                   int64_t n_skip_in, int mem, hipStream_t s, bool byte_fallback, DecodeDev& d) {
     d = DecodeDev{};
     if (int rc = in_source(ws.gen[0], ids, size_t(n_ids) * 4, mem, s, &d.ids)) return rc;
     d.v_begins = h->vb.as<int32_t>();
-    d.v_ends = h->ve.as<int32_t>();
     d.v_chars = h->vc.as<uint8_t>();
+    d.v_len = (byte_fallback ? h->len_bf : h->len_plain).as<uint16_t>();
+    d.v_pack = (byte_fallback ? h->pack_bf : h->pack_plain).as<TokenPack>();
     d.vocab_size = h->vocab_size;
     if (skip_in) {  // input 4 replaces the attribute for this call (vocab_decoder.cpp:36-41)
         std::vector<uint32_t> bits(h->attr_skip_bits.size(), 0u);
@@ -450,9 +485,9 @@ int ovtk_vocab_decoder_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t ba
         OVTK_HIP(hipMemsetAsync(d_e, 0, size_t(n_tok) * 4, s));
     } else {
         DecodeDev d;
-        if (int rc = decoder_inputs(h, *ws.ws, ids, n_tok, skip_in, n_skip_in, mem, s, d)) return rc;
-        if (int rc = scan_and_apply(*ws.ws, s, n_tok, DecodeLen{d}, DecodeApply{d, d_b, d_e, d_c, 0},
-                                    (long long)std::min<int64_t>(out->chars_capacity, INT32_MAX - 1), st, "vocab_decoder"))
+        if (int rc = decoder_inputs(h, *ws.ws, ids, n_tok, skip_in, n_skip_in, mem, s, false, d)) return rc;
+        if (int rc = decode_passes(*ws.ws, s, h->device, d, batch, seq_len, d_b, d_e, nullptr, nullptr, d_c,
+                                   (long long)std::min<int64_t>(out->chars_capacity, INT32_MAX - 1), st, "vocab_decoder"))
             return rc;
     }
     if (int rc = finish_status(*ws.ws, s)) return rc;
@@ -491,11 +526,10 @@ int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch
         OVTK_HIP(hipMemsetAsync(d_e, 0, size_t(batch) * 4, s));
     } else {
         DecodeDev d;
-        if (int rc = decoder_inputs(h, *ws.ws, ids, batch * seq_len, skip_in, n_skip_in, mem, s, d)) return rc;
-        if (byte_fallback) d.fallback_byte = h->fallback.as<int16_t>();
-        // per-token offsets are not materialised: the apply functor writes the row bounds FuzeRagged would pick
-        if (int rc = scan_and_apply(*ws.ws, s, batch * seq_len, DecodeLen{d}, DecodeApply{d, d_b, d_e, d_c, int32_t(seq_len)},
-                                    (long long)std::min<int64_t>(out->chars_capacity, INT32_MAX - 1), st, "detokenize"))
+        if (int rc = decoder_inputs(h, *ws.ws, ids, batch * seq_len, skip_in, n_skip_in, mem, s, byte_fallback != 0, d)) return rc;
+        // per-token offsets are not materialised: the scan writes the row bounds FuzeRagged would pick
+        if (int rc = decode_passes(*ws.ws, s, h->device, d, batch, seq_len, nullptr, nullptr, d_b, d_e, d_c,
+                                   (long long)std::min<int64_t>(out->chars_capacity, INT32_MAX - 1), st, "detokenize"))
             return rc;
     }
     if (int rc = finish_status(*ws.ws, s)) return rc;

@@ -247,56 +247,184 @@ struct CharsFin {
 // =============================================================================================
 // VocabDecoder / ByteFallback / detokenize element functors
 // =============================================================================================
+// Per-vocabulary decode tables (built at create): v_len[id] = bytes token id contributes, v_pack[id] = its first 16
+// bytes.  Two flavours per handle: plain VocabDecoder, and VocabDecoder followed by ByteFallback ("<0xHH>" -> one byte).
+struct alignas(16) TokenPack { uint32_t w[4]; };
 struct DecodeDev {
     const int32_t* ids;          // [batch * seq]
     const int32_t* v_begins;
-    const int32_t* v_ends;
     const uint8_t* v_chars;
+    const uint16_t* v_len;       // output bytes of the token (after ByteFallback in that flavour)
+    const TokenPack* v_pack;     // its first min(len, 16) output bytes, zero padded
     int32_t vocab_size;
-    const uint32_t* skip_bits;     // bitmap over [0, vocab_size), may be nullptr
-    const int16_t* fallback_byte;  // per vocab id: the byte ByteFallback turns the token into, -1 = copied verbatim; nullptr = op absent
+    const uint32_t* skip_bits;   // bitmap over [0, vocab_size), may be nullptr
 };
 
-// Length in bytes of token i's text (vocab_decoder.cpp:70-81): ids outside [0, V) or in the skip list give "".
-struct DecodeLen {
-    DecodeDev d;
-    __device__ long long operator()(long long i) const {
-        const int32_t id = d.ids[i];
-        if (uint32_t(id) >= uint32_t(d.vocab_size)) return 0;  // `token_id < vocab_size` compares as size_t (:71)
-        if (d.skip_bits && (d.skip_bits[uint32_t(id) >> 5] >> (id & 31) & 1u)) return 0;
-        const int len = d.v_ends[id] - d.v_begins[id];
-        if (len > 0 && d.fallback_byte && d.fallback_byte[id] != -1) return 1;
-        return len;
+// Length in bytes of a token's text (vocab_decoder.cpp:70-81): ids outside [0, V) or in the skip list give "".
+__device__ __forceinline__ int decode_len(const DecodeDev& d, int32_t id) {
+    if (uint32_t(id) >= uint32_t(d.vocab_size)) return 0;  // `token_id < vocab_size` compares as size_t (:71)
+    if (d.skip_bits && (d.skip_bits[uint32_t(id) >> 5] >> (id & 31) & 1u)) return 0;
+    return d.v_len[id];
+}
+
+// VocabDecoder / fused detokenizer as two wave-per-segment passes around one scan: a segment = up to kSegTokens
+// consecutive tokens of one row.  Pass 1 sums the segment's output bytes; the scan (scan_kernels.hpp) turns them
+// into offsets (and, for the fused form, into the row's begin / end = what FuzeRagged picks, fuze.cpp:35-38);
+// pass 2 re-reads the ids (16 B per lane), ranks the token lengths with a wave prefix sum, gathers each token's
+// packed bytes with ONE 16-byte load, assembles the segment's text in LDS and writes it out with coalesced dword stores.
+constexpr int kSegTokens = 512;
+constexpr int kSegLdsBytes = 4096;  // segments whose text is longer are copied token by token
+
+// The 4 ids of lane l in the group of 256 tokens starting at token g of the row (ids beyond t1 read as -1 = "no text").
+__device__ __forceinline__ void load_ids4(const DecodeDev& d, long long row_base, int g, int t1, int32_t (&id)[4]) {
+    const int t = g + 4 * lane_id();
+    const int32_t* p = d.ids + row_base + t;
+    if (t + 4 <= t1 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const int4 v = *reinterpret_cast<const int4*>(p);
+        id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) id[j] = t + j < t1 ? p[j] : -1;
+    }
+}
+
+static __global__ __launch_bounds__(kBlockThreads) void decode_count_kernel(DecodeDev d, int seq, int n_seg, long long n_units,
+                                                                            long long* unit_bytes) {
+    const int l = lane_id();
+    const long long my_waves = (long long)gridDim.x * kWavesPerBlock;
+    for (long long u = (long long)blockIdx.x * kWavesPerBlock + wave_in_block(); u < n_units; u += my_waves) {
+        const long long row = u / n_seg;
+        const int seg = int(u - row * n_seg);
+        const int t0 = seg * kSegTokens, t1 = t0 + kSegTokens < seq ? t0 + kSegTokens : seq;
+        int s = 0;
+        for (int g = t0; g < t1; g += 4 * kWave) {
+            int32_t id[4];
+            load_ids4(d, row * seq, g, t1, id);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += decode_len(d, id[j]);
+        }
+        s = wave_sum(s);
+        if (l == 0) unit_bytes[u] = s;
+    }
+}
+
+struct UnitLen {
+    const long long* unit_bytes;
+    __device__ long long operator()(long long u) const { return unit_bytes[u]; }
+};
+// unit_off[u] = offset; fused form (row_begins != nullptr): first / last segment of a row give its begin / end.
+struct UnitApply {
+    long long* unit_off;
+    int n_seg;
+    int32_t* row_begins;
+    int32_t* row_ends;
+    __device__ void operator()(long long u, long long off, long long len) const {
+        unit_off[u] = off;
+        if (!row_begins) return;
+        const long long row = u / n_seg;
+        const int seg = int(u - row * n_seg);
+        if (seg == 0) row_begins[row] = int32_t(off);
+        if (seg == n_seg - 1) row_ends[row] = int32_t(off + len);
     }
 };
 
-// seq == 0: the VocabDecoder op, begins/ends per token.  seq > 0: fused detokenizer, out_begins/out_ends hold one
-// entry per row = what FuzeRagged picks (begin of the row's first token, end of its last, fuze.cpp:35-38).
-struct DecodeApply {
-    DecodeDev d;
-    int32_t* out_begins;
-    int32_t* out_ends;
-    uint8_t* out_chars;
-    int32_t seq;
-    __device__ void operator()(long long i, long long off, long long len) const {
-        if (seq == 0) {
-            out_begins[i] = int32_t(off);
-            out_ends[i] = int32_t(off + len);
-        } else {
-            const long long r = i / seq, c = i - r * seq;
-            if (c == 0) out_begins[r] = int32_t(off);
-            if (c == seq - 1) out_ends[r] = int32_t(off + len);
+static __global__ __launch_bounds__(kBlockThreads) void decode_write_kernel(DecodeDev d, int seq, int n_seg, long long n_units,
+                                                                            const long long* unit_off,
+                                                                            const long long* unit_bytes, int32_t* tok_begins,
+                                                                            int32_t* tok_ends, uint8_t* out_chars,
+                                                                            const RunStatus* status) {
+    __shared__ uint32_t seg_all[kWavesPerBlock][kSegLdsBytes / 4 + 2];
+    if (status->flags & (kFlagOutCapacity | kFlagRange)) return;
+    const int l = lane_id();
+    uint8_t* buf = reinterpret_cast<uint8_t*>(seg_all[wave_in_block()]);
+    const long long my_waves = (long long)gridDim.x * kWavesPerBlock;
+    for (long long u = (long long)blockIdx.x * kWavesPerBlock + wave_in_block(); u < n_units; u += my_waves) {
+        const long long row = u / n_seg;
+        const int seg = int(u - row * n_seg);
+        const int t0 = seg * kSegTokens, t1 = t0 + kSegTokens < seq ? t0 + kSegTokens : seq;
+        const long long base = unit_off[u];
+        const int total = int(unit_bytes[u]);
+        const int skew = int((reinterpret_cast<uintptr_t>(out_chars) + base) & 3);  // LDS byte skew + k <-> output byte base + k: dwords line up
+        const bool staged = total + skew <= kSegLdsBytes;
+        int run = 0;
+        uint32_t* wbuf = seg_all[wave_in_block()];
+        wave_sync();  // the previous segment's flush is done with the buffer
+        if (staged) {
+            for (int q = l; q < ((skew + total + 3) >> 2) + 1; q += kWave) wbuf[q] = 0;
+            wave_sync();
         }
-        if (len == 0) return;
-        const int32_t id = d.ids[i];
-        if (d.fallback_byte && d.fallback_byte[id] != -1) {
-            out_chars[off] = uint8_t(d.fallback_byte[id]);
-            return;
+        for (int g = t0; g < t1; g += 4 * kWave) {
+            int32_t id[4];
+            load_ids4(d, row * seq, g, t1, id);
+            int n[4];
+            TokenPack pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                n[j] = decode_len(d, id[j]);
+                if (n[j] > 0) pk[j] = d.v_pack[id[j]];
+            }
+            const int mine = n[0] + n[1] + n[2] + n[3];
+            const int incl = wave_incl_sum(mine);
+            int off = run + incl - mine;
+            if (tok_begins) {
+                const int t = g + 4 * l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (t + j < t1) {
+                        tok_begins[row * seq + t + j] = int32_t(base + off + (j > 0 ? n[0] : 0) + (j > 1 ? n[1] : 0) + (j > 2 ? n[2] : 0));
+                        tok_ends[row * seq + t + j] = int32_t(base + off + n[0] + (j > 0 ? n[1] : 0) + (j > 1 ? n[2] : 0) + (j > 2 ? n[3] : 0));
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n[j] > 0) {
+                    if (staged) {
+                        // the token's (zero padded) first 16 bytes, shifted to its byte position, are OR-ed dword by
+                        // dword into the zeroed buffer: ~2 LDS operations per token instead of one per byte
+                        const int o = skew + off, sh = (o & 3) * 8, dw = o >> 2;
+                        const int m = n[j] < 16 ? n[j] : 16;
+                        const int nd = (((o & 3) + m) + 3) >> 2;  // dwords touched, 1..5
+                        uint32_t prev = 0;
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) {
+                            const uint32_t cur = q < 4 ? pk[j].w[q] : 0u;
+                            const uint32_t v = sh ? ((cur << sh) | (prev >> (32 - sh))) : cur;
+                            if (q < nd && v) atomicOr(&wbuf[dw + q], v);
+                            prev = cur;
+                        }
+                        if (n[j] > 16) {
+                            uint8_t* dst = buf + o;
+                            const uint8_t* src = d.v_chars + d.v_begins[id[j]];
+                            for (int k = 16; k < n[j]; ++k) dst[k] = src[k];
+                        }
+                    } else {  // oversized segment: straight to the output, byte by byte
+                        const uint8_t* src = d.v_chars + d.v_begins[id[j]];
+                        uint8_t* dst = out_chars + base + off;
+                        if (n[j] == 1) dst[0] = uint8_t(pk[j].w[0]);  // (also the ByteFallback byte)
+                        else for (int k = 0; k < n[j]; ++k) dst[k] = src[k];
+                    }
+                    off += n[j];
+                }
+            }
+            run += wave_readlane(incl, kWave - 1);
         }
-        const uint8_t* src = d.v_chars + d.v_begins[id];
-        for (long long k = 0; k < len; ++k) out_chars[off + k] = src[k];
+        if (!staged) continue;
+        wave_sync();
+        // flush: output bytes [base, base + total) = buffer bytes [skew, skew + total); whole dwords inside that range
+        // go out as dwords (the buffer's dword grid is the output's), the ragged ends byte by byte
+        uint8_t* gout = out_chars + base - skew;
+        const int lo = skew, hi = skew + total;
+        const int d0 = (lo + 3) >> 2, d1 = hi >> 2;  // dwords [d0, d1) lie inside
+        for (int k = d0 + l; k < d1; k += kWave) reinterpret_cast<uint32_t*>(gout)[k] = wbuf[k];
+        if (d0 <= d1) {
+            if (l < 4 * d0 - lo) gout[lo + l] = buf[lo + l];                   // head: bytes [lo, 4*d0)
+            if (l < hi - 4 * d1) gout[4 * d1 + l] = buf[4 * d1 + l];           // tail: bytes [4*d1, hi)
+        } else if (l < total) {                                                // the whole text sits inside one dword
+            gout[lo + l] = buf[lo + l];
+        }
     }
-};
+}
 
 // ByteFallback (src/byte_fallback.cpp:33-46): a 6-byte token whose only '<' is at 0 and which ends in '>' becomes ONE
 // byte: PieceToByte's value for the spellings "<0x%02X>" (upper-case hex, sentence_piece.cpp:27-46), otherwise
