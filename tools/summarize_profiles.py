@@ -1,0 +1,67 @@
+"""Turns the raw rocprofv3 output of a gpurun call (gpurun_out/prof_c*, pmc_fetch_c*, pmc_write_c*) into the small
+summaries committed under profiles/ and into profiles/latest_pmc.json (read by bench.py for roofline.traffic).
+
+    python tools/summarize_profiles.py r01/c            # writes profiles/r01/c_config{2,3,5}_*.csv + latest_pmc.json
+
+HBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes): MI355X_MICROARCH.md "HBM" -- on gfx950 FETCH_SIZE
+reports half of the bytes of a wide coalesced streaming read; WRITE_SIZE is taken as reported.  Separate --pmc passes.
+"""
+import glob
+import json
+import sys
+from pathlib import Path
+
+import pandas as pd
+
+ROOT = Path(__file__).resolve().parent.parent
+TAG = {"lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "merge_kernel": "bpe_merge",
+       "exact_kernel": "bpe_exact", "compact_kernel": "compact", "prep_rows_kernel": "prep_rows",
+       "count_scan_kernel": "count_scan", "wordpiece_deferred_kernel": "wordpiece_deferred",
+       "decode_count_kernel": "decode_count", "decode_write_kernel": "detokenize"}
+
+
+def short(name):
+    n = name.replace("void ", "").split("(")[0].replace("ovtk::", "")
+    return n
+
+
+def main(prefix):
+    out_dir = ROOT / "profiles" / Path(prefix).parent
+    out_dir.mkdir(parents=True, exist_ok=True)
+    stem = Path(prefix).name
+    pmc_json = {}
+    for cfg in (2, 3, 5):
+        st = glob.glob(str(ROOT / f"gpurun_out/prof_c{cfg}/*/*kernel_stats.csv"))
+        if st:
+            d = pd.read_csv(st[0])
+            d = d[d["Name"].str.contains("ovtk")]
+            d.to_csv(out_dir / f"{stem}_config{cfg}_kernel_stats.csv", index=False)
+        rows = []
+        for ctr in ("fetch", "write"):
+            f = glob.glob(str(ROOT / f"gpurun_out/pmc_{ctr}_c{cfg}/*/*counter_collection.csv"))
+            if not f:
+                continue
+            d = pd.read_csv(f[0])
+            d = d[d["Kernel_Name"].str.contains("ovtk")]
+            d["kernel"] = d["Kernel_Name"].map(short)
+            g = d.groupby(["kernel", "Counter_Name"]).agg(dispatches=("Counter_Value", "size"), mean_KB=("Counter_Value", "mean"),
+                                                         vgpr=("VGPR_Count", "first"), sgpr=("SGPR_Count", "first"),
+                                                         lds=("LDS_Block_Size", "first")).reset_index()
+            rows.append(g)
+        if rows:
+            t = pd.concat(rows)
+            t.to_csv(out_dir / f"{stem}_config{cfg}_pmc_summary.csv", index=False)
+            per = {}
+            for k, g in t.groupby("kernel"):
+                fetch = float(g[g.Counter_Name == "FETCH_SIZE"].mean_KB.sum())
+                write = float(g[g.Counter_Name == "WRITE_SIZE"].mean_KB.sum())
+                base = k.split("<")[0] + ("<" + k.split("<")[1] if "<" in k and k.startswith("lookup") else "")
+                tag = TAG.get(base, TAG.get(k, k))
+                per[tag] = int((2 * fetch + write) * 1024)
+            pmc_json[f"config{cfg}"] = per
+    (ROOT / "profiles" / "latest_pmc.json").write_text(json.dumps(pmc_json, indent=1, sort_keys=True) + "\n")
+    print(json.dumps(pmc_json, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01/x")
