@@ -19,6 +19,9 @@ namespace {
 
 const char kGpt2Pattern[] = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+| ?\\p{N}+| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
 const char kGpt2DigitsPattern[] = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+|\\s+(?!\\S)|\\s+";
+// the split pattern of Llama-3's tokenizer.json (tiktoken cl100k family); reaches RegexSplit through hf_parser's Split step
+const char kLlama3Pattern[] =
+    "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
 // tokenizer_pipeline.py:392-426 (bert_whitespace_splitter / bert_keep_delimeters_splitter)
 const char kBertWhitespacePattern[] = "\\s+";
 const char kBertDelimitersPattern[] =
@@ -138,11 +141,12 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
     else if (pat == kGpt2DigitsPattern) h->dev.kind = kSplitGpt2Digits;
     else if (pat == kBertWhitespacePattern) h->dev.kind = kSplitWhitespace;
     else if (pat == kBertDelimitersPattern) h->dev.kind = kSplitBertPunct;
+    else if (pat == kLlama3Pattern) h->dev.kind = kSplitLlama3;
     else
         return set_error(OVTK_E_UNSUPPORTED,
                          "RegexSplit: no gfx950 scanner for this pattern (supported: the byte-level and BERT patterns of "
                          "tokenizer_pipeline.py:392-457); PCRE2 is not executed on the device");
-    if (h->dev.kind <= kSplitGpt2Digits) {
+    if (h->dev.kind <= kSplitGpt2Digits || h->dev.kind == kSplitLlama3) {
         if (beh != "isolate")
             return set_error(OVTK_E_UNSUPPORTED, "RegexSplit: the byte-level patterns are only supported with behaviour=isolate");
     } else {
@@ -270,6 +274,8 @@ int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_st
     if (!split) return set_error(OVTK_E_ARG, "null split handle");
     if (split->max_splits != -1)
         return set_error(OVTK_E_UNSUPPORTED, "fused encode: max_splits is only supported by the RegexSplit op itself");
+    if (split->dev.kind > kSplitGpt2Digits)
+        return set_error(OVTK_E_UNSUPPORTED, "fused encode: this pattern is only supported as RegexSplit followed by BPETokenizer");
     return run_encode(split, bpe, in, skips, out, mem, stream);
 }
 
@@ -327,12 +333,22 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
     // range validation of the inputs (the staging arenas it also computes are not needed here)
     OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);
-    OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
-                (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
+    const bool seq = h->dev.kind == kSplitLlama3;  // sequential matcher: one lane per row
+    const int seq_grid = (n_rows + kBlockThreads - 1) / kBlockThreads;
+    if (seq)
+        OVTK_LAUNCH(ws->marks, "split_count", split_seq_kernel<0>, seq_grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
+                    (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
+    else
+        OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
+                    (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
     OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s, n_rows,
                 w, (long long)out->capacity);
-    OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb, d_re,
-                d_b, d_e, d_sk);
+    if (seq)
+        OVTK_LAUNCH(ws->marks, "split_write", split_seq_kernel<1>, seq_grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb,
+                    d_re, d_b, d_e, d_sk);
+    else
+        OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb, d_re,
+                    d_b, d_e, d_sk);
     if (int rc = finish_status(*ws.ws, s)) return rc;
     const RunStatus& st = *ws->host_status;
     if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");

@@ -102,6 +102,27 @@ def main_wordpiece():
     print(name, len(strings), "strings", int(tl.sum()), "ids")
 
 
+def main_llama3():
+    """Llama-3-shaped byte-level BPE (tiktoken-style split pattern, trained in-process): HF ids for mixed-script text."""
+    strings = STRINGS + synthetic("zipf", 32, 160, 31) + synthetic("mixed", 48, 200, 32) + synthetic("uniform", 8, 96, 33)
+    strings += ["it's IT'S don'T we'LL 'ſ 12345 6,789.10\r\n\r\n  end  ", "a\tb \n c\n\n  d", "x\u00a0y !\n\nz"]
+    name = "llama3_small"
+    tok = Tokenizer.from_file(str(G / f"tok_{name}.hf.json"))
+    enc = [tok.encode(s, add_special_tokens=False).ids for s in strings]
+    raw = [s.encode("utf-8") for s in strings]
+    lens = np.array([len(r) for r in raw], np.int64)
+    ends = np.cumsum(lens).astype(np.int32)
+    tl = np.array([len(x) for x in enc], np.int64)
+    tends = np.cumsum(tl).astype(np.int32)
+    np.savez_compressed(G / f"golden_bpe_{name}.npz", begins=(ends - lens).astype(np.int32), ends=ends,
+                        chars=np.frombuffer(b"".join(raw), np.uint8), id_begins=(tends - tl).astype(np.int32),
+                        id_ends=tends, ids=np.concatenate([np.asarray(x, np.int32) for x in enc if len(x)]),
+                        meta=np.frombuffer(json.dumps(dict(source="tokenizers " + __import__("tokenizers").__version__,
+                                                           tokenizer=f"tok_{name}.hf.json")).encode(), np.uint8))
+    print(name, len(strings), "strings", int(tl.sum()), "ids")
+
+
 if __name__ == "__main__":
     main()
     main_wordpiece()
+    main_llama3()

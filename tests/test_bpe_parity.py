@@ -45,6 +45,35 @@ def test_oracle_matches_hf_live():
     assert orc.tie_events == 0
 
 
+def test_oracle_matches_hf_golden_llama3():
+    z = np.load(GOLDEN / "golden_bpe_llama3_small.npz")
+    tok = BpeTok.load("llama3_small")
+    rb, re_ = ragged_rows(len(z["begins"]))
+    sp = O.RegexSplit(tok.pattern, "isolate")(rb, re_, z["begins"], z["ends"], z["chars"])
+    ob, oe, ids = tok.oracle()(*sp[:5])
+    assert np.array_equal(ob, z["id_begins"]) and np.array_equal(oe, z["id_ends"]) and np.array_equal(ids, z["ids"])
+
+
+def test_llama3_chain(backend):
+    """Llama-3-shaped tokenizer: RegexSplit (sequential matcher) -> BPETokenizer on the device vs the oracle chain and
+    the HF golden ids; the fused entry point refuses this pattern (it is only supported as the two-op chain)."""
+    z = np.load(GOLDEN / "golden_bpe_llama3_small.npz")
+    tok = BpeTok.load("llama3_small")
+    rb, re_ = ragged_rows(len(z["begins"]))
+    inputs = [rb, re_, z["begins"], z["ends"], z["chars"]]
+    pat = tok.pattern_u8()
+    sp_ref = O.RegexSplit(tok.pattern, "isolate")(*inputs)
+    split = RegexSplit("isolate", lib=backend.lib)
+    sp = split.evaluate(backend.data(inputs) + [pat])
+    assert_same(sp_ref[:4], sp[:4], backend.host, "RegexSplit llama3")
+    bpe = BPETokenizer(**tok.attrs, lib=backend.lib)
+    got = bpe.evaluate(list(sp[:5]) + tok.consts)
+    assert np.array_equal(backend.host(got[2]), z["ids"]) and np.array_equal(backend.host(got[1]), z["id_ends"])
+    with pytest.raises(L.OvtkError) as ei:
+        FusedSplitBPE(split, bpe).evaluate(backend.data(inputs) + [pat], tok.consts)
+    assert ei.value.code == L.E_UNSUPPORTED
+
+
 # ------------------------------------------------------------------ kernels vs oracle
 def run_all_paths(backend, tok, inputs, skips=None, pattern=None):
     """Oracle result + the three product paths (split op, BPE op on its pieces, fused) compared bit for bit."""

@@ -13,7 +13,7 @@ import pytest
 from openvino_tokenizers_amd.ops import RegexSplit
 from oracle import oracle as O
 from tests.util import assert_same, one_string_per_row
-from tools.make_tokenizers import GPT2_PATTERN
+from tools.make_tokenizers import GPT2_PATTERN, LLAMA3_PATTERN
 
 DIGITS_PATTERN = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
 ALPHABET = ["a", "s", "t", "r", "e", "l", "v", "1", " ", "\t", "\n", " ", "'", "!", "é", "元", "，", "😀", "٣", "　"]
@@ -123,3 +123,42 @@ def test_bert_chain_matches_reference_kat(backend):
     ref2 = O.RegexSplit(BERT_PUNCT, "isolate")(*ref1[:5])
     got2 = RegexSplit("isolate", lib=backend.lib).evaluate(list(got1[:5]) + [pu])
     assert_same(ref2[:4], got2[:4], backend.host, "bert delimiters on the whitespace pieces")
+
+
+# ------------------------------------------------------------------ Llama-3 pattern (sequential matcher, lane per row)
+LLAMA3_ALPHABET = ["a", "s", "S", "t", "r", "E", "l", "L", "v", "m", "d", "ſ", "1", "٣", " ", "\t", "\n", "\r", "\u00a0", "'", "!",
+                   "é", "元", "😀"]
+
+
+def test_llama3_exhaustive_short_strings(backend):
+    rng = np.random.default_rng(5)
+    if backend.name == "emu":
+        strings = ["".join(t) for k in (1, 2) for t in itertools.product(LLAMA3_ALPHABET, repeat=k)]
+        strings += ["".join(rng.choice(LLAMA3_ALPHABET, size=int(k))) for k in rng.integers(3, 6, size=1500)]
+    else:
+        strings = ["".join(t) for k in range(1, 4) for t in itertools.product(LLAMA3_ALPHABET, repeat=k)]
+        strings += ["".join(rng.choice(LLAMA3_ALPHABET, size=int(k))) for k in rng.integers(4, 7, size=60000)]
+    check(backend, LLAMA3_PATTERN, strings)
+
+
+def test_llama3_random_and_long(backend):
+    rng = np.random.default_rng(17)
+    p = np.array([6, 2, 1, 2, 2, 1, 2, 1, 1, 1, 1, 0.3, 4, 1, 8, 1, 1.5, 0.7, 0.5, 2.5, 2, 1, 1, 0.5])
+    p = p / p.sum()
+    n = 300 if backend.name == "emu" else 6000
+    strings = ["".join(rng.choice(LLAMA3_ALPHABET, size=int(rng.integers(1, 80)), p=p)) for _ in range(n)]
+    strings += ["".join(rng.choice(LLAMA3_ALPHABET, size=int(rng.integers(400, 1500)), p=p)) for _ in range(10)]
+    strings += ["", "1" * 700, " " * 300 + "x", "\n" * 20 + " a", "it's IT'S 'Tis don'T we'LL 12345 6,789.10\r\n\r\n  end  "]
+    check(backend, LLAMA3_PATTERN, strings)
+    check(backend, LLAMA3_PATTERN, strings[:50], max_splits=3)
+
+
+def test_llama3_rows_with_several_strings_and_skips(backend):
+    strings = [b"Hello world's 1234", b"<|begin_of_text|>", b"  two  spaces\n\nnew", b"", b"x"]
+    b, e, c = O.pack_strings(strings)
+    rb, re_ = np.array([0, 2, 2], np.int32), np.array([2, 2, 5], np.int32)
+    skips = np.array([0, 1, 0, 0, 0], np.uint8)
+    pat = np.frombuffer(LLAMA3_PATTERN.encode(), np.uint8)
+    ref = O.RegexSplit(LLAMA3_PATTERN, "isolate")(rb, re_, b, e, c, skips=skips)
+    got = RegexSplit("isolate", lib=backend.lib).evaluate(backend.data([rb, re_, b, e, c, skips]) + [pat])
+    assert_same(ref[:4] + [ref[5]], list(got[:4]) + [got[5]], backend.host, "llama3 ragged rows + skips")
