@@ -4,6 +4,7 @@ per GPU (config 2), inputs resident in HBM, fused RegexSplit+BPETokenizer throug
 
     python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: launched by torch.distributed.run)
     python bench.py --config 3      BERT-shaped WordPiece, 65 536 x ~256-byte strings (fused BERT split + WordPiece)
+    python bench.py --config 4      one 8-GPU shard of the Llama-3-shaped config (RegexSplit -> BPETokenizer chain, mixed scripts)
     python bench.py --config 5      detokenizer (VocabDecoder + ByteFallback + FuzeRagged fused), rows x 2048 ids
 
 One "step" = one pass of the hot path over one batch.  With N > 1 every rank encodes its own shard of the same size
@@ -37,7 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 KERNEL_NAMES = {"lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>",
                 "lookup_words": "lookup_kernel<kFused> (BERT words)", "wordpiece_deferred": "wordpiece_deferred_kernel",
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",
-                "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel",
+                "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel", "split_count": "split_seq_kernel<0>",
+                "split_write": "split_seq_kernel<1>",
                 "detokenize": "tile_{reduce,apply}_kernel<DecodeLen,DecodeApply>", "tile_scan": "tile_scan_kernel"}
 BERT_WS = r"\s+"
 BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\x{4E00}-\x{9FFF}]", r"[\x{3400}-\x{4DBF}]",
@@ -89,6 +91,55 @@ def make_encode_bpe(args, lib, dev, rank):
     return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe, o_begins, o_ends, o_ids), workload=workload,
                 metric="input MB/s encoded (GPT-2 BPE, 512-byte strings)", dtype="u8/int32",
                 algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=min(args.rows, 32768))
+
+
+def make_encode_llama3(args, lib, dev, rank):
+    """Config 4 shard: Llama-3-shaped byte-level BPE (tiktoken-style split pattern, 128k merges) on mixed-script text,
+    as the two-op chain RegexSplit -> BPETokenizer (the sequential split matcher has no fused form)."""
+    tok = BpeTok.load("llama3")
+    rows = args.rows if args.rows != 65536 else 131072  # 1 M rows / 8 GPUs
+    begins, ends, chars = TextModel(1234, "mixed").batch(rows, args.bytes, seed=4000 + rank)
+    rb, re_ = ragged_rows(rows)
+    n_chars = int(len(chars))
+    d = [torch.as_tensor(x, device=dev) for x in (rb, re_, begins, ends, chars)]
+    split = RegexSplit("isolate", device=dev.index, lib=lib)
+    bpe = BPETokenizer(**tok.attrs, device=dev.index, lib=lib)
+    split._ensure(tok.pattern_u8())
+    bpe._ensure(d + tok.consts)
+    cap = n_chars + rows
+    rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), rows, L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), rows, n_chars))
+    p_rb = torch.empty(rows, dtype=torch.int32, device=dev)
+    p_re = torch.empty(rows, dtype=torch.int32, device=dev)
+    p_b = torch.empty(cap, dtype=torch.int32, device=dev)
+    p_e = torch.empty(cap, dtype=torch.int32, device=dev)
+    sp_out = L.RaggedStringsOut(p_rb.data_ptr(), p_re.data_ptr(), 0, p_b.data_ptr(), p_e.data_ptr(), None, cap, 0)
+    o_begins = torch.empty(rows, dtype=torch.int32, device=dev)
+    o_ends = torch.empty(rows, dtype=torch.int32, device=dev)
+    o_ids = torch.empty(n_chars, dtype=torch.int32, device=dev)
+    out = L.RaggedI32Out(o_begins.data_ptr(), o_ends.data_ptr(), o_ids.data_ptr(), n_chars, 0, 0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def step():
+        L.check(lib, lib.ovtk_regex_split_run(split._h, C.byref(rs), None, C.byref(sp_out), L.MEM_DEVICE, stream))
+        pieces = L.RaggedStrings(p_rb.data_ptr(), p_re.data_ptr(), rows,
+                                 L.Strings(p_b.data_ptr(), p_e.data_ptr(), d[4].data_ptr(), sp_out.n, n_chars))
+        L.check(lib, lib.ovtk_bpe_run(bpe._h, C.byref(pieces), C.byref(out), L.MEM_DEVICE, stream))
+        return o_begins, o_ends, o_ids[: out.n_data]
+
+    def cpu(n_s):
+        from oracle import oracle as O
+        orc, ors = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+        ref = orc(*ors(rb[:1024], re_[:1024], begins[:1024], ends[:1024], chars)[:5])
+        t1 = time.perf_counter()
+        orc(*ors(rb[:n_s], re_[:n_s], begins[:n_s], ends[:n_s], chars)[:5])
+        return ref, time.perf_counter() - t1, int(ends[n_s - 1] - begins[0]), "RegexSplit(PCRE2 JIT)+BPETokenizer restatement with warm piece cache"
+
+    workload = (f"config 4 shard: Llama-3-shaped byte-level BPE (V=128256, 127999 merges, trained in-process), {rows} x "
+                f"~{args.bytes}-byte mixed-script strings per GPU, RegexSplit (tiktoken-style pattern) -> BPETokenizer, "
+                f"inputs and outputs in HBM")
+    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe, p_rb, p_re, p_b, p_e, o_begins, o_ends, o_ids),
+                workload=workload, metric="input MB/s encoded (Llama-3 BPE, 512-byte mixed-script strings)", dtype="u8/int32",
+                rows=rows, algo=lambda n_tok: n_chars + 4 * n_tok + 16 * rows, sample_rows=min(rows, 16384))
 
 
 def make_encode_wordpiece(args, lib, dev, rank):
@@ -188,7 +239,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5])
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--bytes", type=int, default=512)
     ap.add_argument("--text", default="zipf", choices=["zipf", "uniform", "mixed"])
@@ -209,7 +260,7 @@ def main():
         from openvino_tokenizers_amd.distributed import all_gather_ragged
 
     lib = L.load()
-    wl = {2: make_encode_bpe, 3: make_encode_wordpiece, 5: make_detokenize}[args.config](args, lib, dev, rank)
+    wl = {2: make_encode_bpe, 3: make_encode_wordpiece, 4: make_encode_llama3, 5: make_detokenize}[args.config](args, lib, dev, rank)
     is_detok = wl.get("is_detok", False)
 
     def step():
