@@ -15,10 +15,10 @@
 // for LDS) is replayed by path X: bpe_exact_piece(), a step-for-step emulation of
 // std::push_heap / std::pop_heap on the same (rank, new_id, a, b, seq) entries, stale ones included.
 //
-// Pair key in LDS (u64): rank:22 | seq:10 | new_id:21, all ones = "not a merge".  One 16-byte probe of the
-// merge table yields rank and merged id together, so a merge step has ONE dependent global
-// round trip (the two probes for the new neighbour pairs, issued together).  seq < 1024 because a
-// piece handled in LDS has at most kChunk = 512 symbols and seq < 2n.
+// Pair key (u64): rank:22 | seq:10 | new_id:21, all ones = "not a merge"; path F keeps its upper half (rank | seq,
+// exactly 32 bits: the order) and the merged id in two u32 LDS arrays.  One lookup of the merge table yields rank
+// and merged id together, so a merge step has ONE dependent global round trip (the two lookups for the new
+// neighbour pairs, issued together).  seq < 1024 because a piece handled in LDS has at most 512 symbols and seq < 2n.
 #pragma once
 
 #include "device_common.hpp"
@@ -112,16 +112,21 @@ __device__ __forceinline__ int bpe_symbolize(const BpeDev& T, const I2* root, Ge
     return cnt;
 }
 
-// Path F.  id / key: the wave's [kFastSyms][64] LDS arrays; this lane owns column lane_id().  n symbols are in
-// place.  Symbols never move: a merge writes the new id over its left operand and clears the right operand's bit
-// in the lane's `live` mask; key[k] always describes the pair (k, next live symbol after k).  The min-scan reads
-// all kFastSyms-1 keys with independent, fully unrolled LDS loads (dead / absent positions hold kNoKey).
-// Returns the final symbol count (symbols compacted to the front of the column), or -1 when the minimum was not
-// unique (replay on path X).
-__device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uint64_t* key, int n) {
+// Path F.  id / key / nid: the wave's [kFastSyms][64] u32 LDS arrays; this lane owns column lane_id().  n symbols are
+// in place.  Symbols never move: a merge writes the new id over its left operand and clears the right operand's bit
+// in the lane's `live` mask; key[k] = rank << 10 | seq and nid[k] = merged id describe the pair (k, next live symbol
+// after k), key 0xFFFFFFFF = "not a merge" (dead / absent positions too).  The min-scan reads all kFastSyms-1 keys with
+// independent, fully unrolled LDS loads.  Returns the final symbol count (symbols compacted to the front of the
+// column), or -1 when the minimum was not unique (replay on path X).
+constexpr uint32_t kNoKey32 = 0xFFFFFFFFu;
+__device__ __forceinline__ void split_pair_key(uint64_t k64, uint32_t& key, uint32_t& nid) {
+    key = k64 == kNoKey ? kNoKey32 : uint32_t(k64 >> kIdBits);
+    nid = uint32_t(k64) & kIdMask;
+}
+__device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uint32_t* key, uint32_t* nid, int n) {
     const int l = lane_id();
 #define OVTK_AT(k) ((k) * kWave + l)
-    // initial pair keys: the probes of a group of 4 are issued together
+    // initial pair keys: the lookups of a group of 4 are issued together
 #pragma unroll
     for (int k0 = 0; k0 < kFastSyms; k0 += 4) {
         uint64_t mk[4] = {0, 0, 0, 0};
@@ -139,9 +144,10 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uin
         for (int j = 0; j < 4; ++j) {
             const int k = k0 + j;
             if (k < kFastSyms - 1) {
-                uint64_t v = kNoKey;
-                if (k + 1 < n) v = merge_resolve(f[j], mk[j], uint32_t(k));
-                key[OVTK_AT(k)] = v;
+                uint32_t kk = kNoKey32, nn = 0;
+                if (k + 1 < n) split_pair_key(merge_resolve(f[j], mk[j], uint32_t(k)), kk, nn);
+                key[OVTK_AT(k)] = kk;
+                nid[OVTK_AT(k)] = nn;
             }
         }
     }
@@ -149,18 +155,18 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uin
     uint32_t seq = n > 0 ? uint32_t(n - 1) : 0;
     bool dup = false;
     while (n >= 2) {
-        uint64_t v[kFastSyms - 1];
+        uint32_t v[kFastSyms - 1];
 #pragma unroll
         for (int k = 0; k < kFastSyms - 1; ++k) v[k] = key[OVTK_AT(k)];
-        uint64_t best = kNoKey;
+        uint32_t best = kNoKey32;
         int at = 0;
 #pragma unroll
         for (int k = 0; k < kFastSyms - 1; ++k) {
             if (v[k] < best) { best = v[k]; at = k; dup = false; }
-            else if (v[k] == best && best != kNoKey) dup = true;
+            else if (v[k] == best && best != kNoKey32) dup = true;
         }
-        if (best == kNoKey || dup) break;
-        const uint32_t nid = uint32_t(best) & kIdMask;
+        if (best == kNoKey32 || dup) break;
+        const uint32_t merged = nid[OVTK_AT(at)];
         const uint32_t above = live & ~((2u << at) - 1u);          // live symbols right of `at`
         const int right = __ffs(above) - 1;                        // the right operand (exists: key[at] was a pair)
         live &= ~(1u << right);
@@ -168,16 +174,24 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uin
         const uint32_t below = live & ((1u << at) - 1u);
         const int nxt = above2 ? __ffs(above2) - 1 : -1;           // new right neighbour
         const int prv = below ? 31 - __clz(below) : -1;            // left neighbour
-        id[OVTK_AT(at)] = nid;
+        id[OVTK_AT(at)] = merged;
         --n;
         ++seq;
-        // the two new neighbour pairs: both probes in flight together
-        const uint64_t kl = prv >= 0 ? merge_key(id[OVTK_AT(prv >= 0 ? prv : 0)], nid) : 0;
-        const uint64_t kr = nxt >= 0 ? merge_key(nid, id[OVTK_AT(nxt >= 0 ? nxt : 0)]) : 0;
+        // the two new neighbour pairs: both lookups in flight together
+        const uint64_t kl = prv >= 0 ? merge_key(id[OVTK_AT(prv >= 0 ? prv : 0)], merged) : 0;
+        const uint64_t kr = nxt >= 0 ? merge_key(merged, id[OVTK_AT(nxt >= 0 ? nxt : 0)]) : 0;
         const MergeFetch fl = merge_fetch(T, kl), fr = merge_fetch(T, kr);
-        if (prv >= 0) key[OVTK_AT(prv)] = merge_resolve(fl, kl, seq);
-        key[OVTK_AT(at)] = nxt >= 0 ? merge_resolve(fr, kr, seq) : kNoKey;
-        if (right < kFastSyms - 1) key[OVTK_AT(right)] = kNoKey;
+        if (prv >= 0) {
+            uint32_t kk, nn;
+            split_pair_key(merge_resolve(fl, kl, seq), kk, nn);
+            key[OVTK_AT(prv)] = kk;
+            nid[OVTK_AT(prv)] = nn;
+        }
+        uint32_t kk = kNoKey32, nn = 0;
+        if (nxt >= 0) split_pair_key(merge_resolve(fr, kr, seq), kk, nn);
+        key[OVTK_AT(at)] = kk;
+        nid[OVTK_AT(at)] = nn;
+        if (right < kFastSyms - 1) key[OVTK_AT(right)] = kNoKey32;
     }
     if (dup) return -1;
     // compact the surviving symbols to the front (ascending positions: reads never trail writes)

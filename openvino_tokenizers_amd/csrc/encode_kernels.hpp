@@ -392,13 +392,15 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
 // ---- merge kernel: dense batches of deferred pieces ----------------------------------------------
 static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w) {
     __shared__ uint32_t id_all[kWavesPerBlock][kFastSyms * kWave];
-    __shared__ uint64_t key_all[kWavesPerBlock][kFastSyms * kWave];
+    __shared__ uint64_t key_all[kWavesPerBlock][kFastSyms * kWave];  // path F: u32 key[] | u32 nid[]; path W: u64 key[512]
     __shared__ I2 root_lds[256];
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
     __syncthreads();
     if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
     uint32_t* id = id_all[wave_in_block()];
     uint64_t* key = key_all[wave_in_block()];
+    uint32_t* fkey = reinterpret_cast<uint32_t*>(key);
+    uint32_t* fnid = fkey + kFastSyms * kWave;
     const int l = lane_id();
     const int SL = T.suffix_len;
     const int shard = int(blockIdx.y);
@@ -427,7 +429,7 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
                     return uint32_t((i < 8 ? k0 >> (8 * i) : k1 >> (8 * (i - 8))) & 0xFF);
                 },
                 need, [&](int k, int tok) { id[k * kWave + l] = uint32_t(tok); });
-            const int res = bpe_merge_lane(T, id, key, n);
+            const int res = bpe_merge_lane(T, id, fkey, fnid, n);
             if (res < 0) {
                 is_x = true;
             } else {

@@ -218,7 +218,7 @@ int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView
 
     // Cuckoo table: 2 hash functions x buckets of 2 slots (load <= 0.75 of the slots; grown on the rare failure).
     for (uint32_t buckets = std::max<uint32_t>(4, pow2_at_least((uint64_t(rank_of.size()) * 4 + 5) / 6));; buckets *= 2) {
-        out.bucket_shift = 64 - log2u(buckets);
+        out.bucket_shift = 32 - log2u(buckets);
         std::vector<MergeSlot> flat(size_t(buckets) * 2, MergeSlot{kEmptySlot, 0});
         uint64_t rng = 0x2545F4914F6CDD1Dull;
         bool ok = true;

@@ -66,8 +66,8 @@ struct alignas(32) MergeBucket { MergeSlot s[2]; };
 
 struct BpeDev {
     TrieDev trie;
-    const MergeBucket* merges;  // [1 << (64 - bucket_shift)]
-    uint32_t bucket_shift;      // 64 - log2(buckets)
+    const MergeBucket* merges;  // [1 << (32 - bucket_shift)]
+    uint32_t bucket_shift;      // 32 - log2(buckets)
     const int32_t* new_id;      // [n_merges]
     PieceTableDev pieces;
     const int32_t* byte_fallback_id;  // [256], -1 = none (all -1 when byte_fallback is off)
@@ -90,10 +90,13 @@ __host__ __device__ inline uint32_t hash_u32(uint32_t k) { return k * 0x9E3779B1
 __host__ __device__ inline uint64_t hash_u64(uint64_t k) { return k * 0x9E3779B97F4A7C15ull; }
 __host__ __device__ inline uint64_t merge_key(uint32_t l, uint32_t r) { return (uint64_t(l) << kMaxVocabBits) | r; }
 // Cuckoo hash functions: the top log2(buckets) bits of odd-constant multiplies (shift = 64 - log2(buckets) < 64).
-__host__ __device__ inline uint32_t merge_h1(uint64_t key, uint32_t shift) { return uint32_t((key * 0x9E3779B97F4A7C15ull) >> shift); }
-__host__ __device__ inline uint32_t merge_h2(uint64_t key, uint32_t shift) {
-    return uint32_t(((key ^ (key >> 23)) * 0xD6E8FEB86659FD93ull) >> shift);
+// (32-bit arithmetic: a 64-bit multiply costs ~5 vector instructions at a quarter of the rate; key < 2^42)
+__host__ __device__ inline uint32_t merge_mix(uint64_t key) {
+    uint32_t h = uint32_t(key) * 0x9E3779B1u + uint32_t(key >> 32) * 0x85EBCA77u;
+    return h ^ (h >> 15);
 }
+__host__ __device__ inline uint32_t merge_h1(uint64_t key, uint32_t shift) { return (merge_mix(key) * 0x2C1B3C6Du) >> shift; }
+__host__ __device__ inline uint32_t merge_h2(uint64_t key, uint32_t shift) { return (merge_mix(key) * 0xD6E8FEB9u) >> shift; }
 // Memo hashing in 32-bit arithmetic (64-bit multiplies cost ~5x on the vector ALU): one multiply per key word, a
 // finalising multiply, then one multiply per cuckoo function.
 __host__ __device__ inline uint32_t piece_mix(uint64_t k0, uint64_t k1) {
@@ -133,7 +136,7 @@ struct TrieHost {
 struct BpeHost {
     TrieHost trie;
     std::vector<MergeBucket> merges;
-    uint32_t bucket_shift = 62;
+    uint32_t bucket_shift = 30;
     std::vector<int32_t> new_id;
     std::vector<int32_t> byte_fallback_id;
     int32_t unk_id = -1;
