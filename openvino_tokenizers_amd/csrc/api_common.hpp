@@ -122,19 +122,32 @@ inline void launch_scan(std::vector<Profiler::Mark>& marks, const char* tag, hip
 inline size_t scan_tiles_bytes(long long n) { return size_t((n + kTileElems - 1) / kTileElems + 1) * sizeof(long long); }
 
 constexpr int kTicketBlocks = 256;  // blocks of the launches that end with a "last block done" ticket
-// Persistent grids: enough blocks to fill the chip at the kernel's occupancy, rows / list entries are strided.
-inline int grid_lookup(int device, int n_rows) {
-    return std::max(1, std::min((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, device_cu_count(device) * 6));
+// Persistent grids: exactly the blocks that are resident at the kernel's occupancy (a larger grid runs its surplus as a
+// second, poorly filled round: every block carries the same share of the rows); rows / list entries are strided.
+// The occupancy API over-reports by one block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md "Residency"), hence
+// the cap at 6 (100+ SGPRs).
+template <class Kernel>
+inline int resident_blocks_per_cu(Kernel kernel, int cap = 6) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlockThreads, 0) != hipSuccess || n <= 0) n = 4;
+    return std::min(n, cap);
 }
+inline int grid_rows(int device, int n_rows, int blocks_per_cu) {
+    return std::max(1, std::min((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, device_cu_count(device) * blocks_per_cu));
+}
+inline int grid_lookup(int device, int n_rows) { return grid_rows(device, n_rows, 6); }
 
 // The "ragged strings in -> ragged i32 out" pipeline shared by BPETokenizer, the fused encode and
 // WordpieceTokenizer: prep (validation + per-wave staging arenas) -> middle(ws, d_in, w, grid) (the op's kernels: ids
 // into staging, per-row counts; the first one must be launched with `grid` blocks, the geometry prep summed over) ->
 // count_scan (final offsets) -> compact.  Workspace overflows reported
 // by the kernels are handled by growing the buffer and running again.
+// self_alloc: the middle's first kernel (lookup_kernel) validates the offsets and takes its staging from bump allocators
+// itself, so no prep launch is needed.
 template <class Middle>
 int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
-                    ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle&& middle) {
+                    ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle&& middle, bool self_alloc = false,
+                    int blocks_per_cu = 6) {
     WorkspaceLease ws(device);
     if (!ws->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
     RowsIn d_in{};
@@ -152,8 +165,10 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
     if (int rc = out_target(ws->out_b, out->ends, size_t(n_rows) * 4, mem, &d_ends)) return rc;
     if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_ids)) return rc;
 
-    const int grid = grid_lookup(device, n_rows);
+    const int grid = grid_rows(device, n_rows, blocks_per_cu);
     const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
+    if (self_alloc)  // every wave may leave one chunk partly unused
+        stage_cap = std::min<int64_t>(stage_cap + int64_t(grid * kWavesPerBlock + kShards) * kStageChunk, INT32_MAX - 1);
     for (int attempt = 0; attempt < 6; ++attempt) {
         int e = 0;
         e = e ? e : ws->row_stage.ensure(size_t(n_rows) * 4);
@@ -169,7 +184,8 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
         if (e) return e;
         EncodeWork w{};
         w.n_waves = grid * kWavesPerBlock;
-        w.wave_off = ws->wave_off.as<long long>();
+        w.wave_off = self_alloc ? nullptr : ws->wave_off.as<long long>();
+        w.stage_region = int32_t(stage_cap / kShards);
         w.row_stage = ws->row_stage.as<int32_t>();
         w.row_cnt = ws->row_cnt.as<int32_t>();
         w.row_used = ws->row_used.as<int32_t>();
@@ -185,19 +201,21 @@ int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, c
         w.status = ws->status.as<RunStatus>();
 
         OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-        OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, mul, w);
+        if (!self_alloc)
+            OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, mul, w);
         middle(*ws.ws, d_in, w, grid);
         OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s,
                     n_rows, w, (long long)out->data_capacity);
-        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid, kBlockThreads, s, n_rows, w, d_ids, d_begins, d_ends);
+        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_lookup(device, n_rows), kBlockThreads, s, n_rows, w, d_ids, d_begins, d_ends);
         if (int rc = finish_status(*ws.ws, s)) return rc;
 
         const RunStatus& st = *ws->host_status;
         if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
         if (st.flags & kFlagStageOverflow) {
-            if (st.stage_need >= INT32_MAX - 1)
+            const int64_t need = self_alloc ? stage_cap * 2 : int64_t(st.stage_need);  // the allocators do not know the total
+            if (need >= INT32_MAX - 1)
                 return set_error(OVTK_E_UNSUPPORTED, "batch needs more than 2^31 staging entries; split the call");
-            stage_cap = st.stage_need;
+            stage_cap = need;
             continue;
         }
         if (st.flags & kFlagDeferOverflow) {

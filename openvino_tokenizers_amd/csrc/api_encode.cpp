@@ -258,7 +258,9 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
                                OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(std::max(1, device_cu_count(dev) * 3 / kShards), kShards),
                                            kBlockThreads, s, d_in, bpe->dev, w);
                                OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
-                           });
+                           },
+                           /*self_alloc=*/true,
+                           split ? resident_blocks_per_cu(lookup_kernel<kFused>) : resident_blocks_per_cu(lookup_kernel<kPieces>));
 }
 
 }  // namespace

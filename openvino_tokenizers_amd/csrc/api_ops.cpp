@@ -216,7 +216,8 @@ int ovtk_wordpiece_encode_run(ovtk_wordpiece* h, ovtk_regex_split* whitespace, o
                                OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel,
                                            dim3(std::max(1, device_cu_count(dev) * 8 / kShards), kShards), kBlockThreads, s, d_in,
                                            h->dev, unk_token_id, w);
-                           });
+                           },
+                           /*self_alloc=*/true, resident_blocks_per_cu(lookup_kernel<kFused>));
 }
 
 void ovtk_wordpiece_destroy(ovtk_wordpiece* h) { delete h; }

@@ -31,6 +31,7 @@ struct RunStatus {
     uint32_t ticket[2];    // "last block done" tickets of prep_rows_kernel / count_scan_kernel
     int32_t pad[24];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
+    int32_t stage_top[kShards * kCounterStride];    // [s * kCounterStride] = staging entries handed out in region s
 };
 constexpr uint32_t kFlagItemsOverflow = 1u;     // more work items than the workspace holds
 constexpr uint32_t kFlagStageOverflow = 2u;     // staging buffer too small

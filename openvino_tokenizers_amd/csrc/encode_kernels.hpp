@@ -53,7 +53,9 @@ constexpr int kRowTile = 64;  // rows per tile of the final offset scan
 
 struct EncodeWork {
     int32_t n_waves;        // persistent waves of the prep / lookup launches (wave w owns rows w, w + n_waves, ...)
-    long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities)
+    long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities), or
+                            // nullptr: the lookup kernel takes staging chunks from kShards bump allocators itself
+    int32_t stage_region;   // allocator mode: entries per allocator region (stage_cap / kShards)
     int32_t* row_stage;     // [n_rows]     staging offset of each row (set by the lookup kernel)
     int32_t* row_cnt;       // [n_rows]     ids produced by each row
     int32_t* row_used;      // [n_rows]     staging entries the row occupies (> row_cnt: it has unused entries)
@@ -286,10 +288,9 @@ __device__ __forceinline__ void lookup_whole_strings(const BpeDev& T, RowState& 
     }
 }
 
-// Header of a row for the software pipeline of the fused lookup kernel, fetched in two dependent steps that run in
-// DIFFERENT loop iterations (row range three rows ahead, string offsets two rows ahead, text one row ahead), so no
-// iteration waits for a load it has just issued.  simple: exactly one string, not skipped, at most kPrefetchBytes
-// long -- its text is prefetched; any other row takes the generic path.
+// Header of a row (scalar loads).  simple: exactly one string, not skipped, at most kChunk bytes long, offsets inside
+// the chars tensor.  (A software pipeline that fetched the next row's header and text into registers while the
+// current row was processed was measured: it cost 25 VGPRs = one wave per SIMD and was a net loss.)
 struct RowHdr {
     int cb, ce, sb, slen;
     bool simple;
@@ -303,16 +304,45 @@ __device__ __forceinline__ RowHdr load_row_range(const RowsIn& in, int row) {
     return h;
 }
 __device__ __forceinline__ RowHdr load_row_string(const RowsIn& in, RowHdr h) {
-    if (h.ce == h.cb + 1 && !(in.skips && uniform_load(in.skips + h.cb))) {
+    if (h.ce == h.cb + 1 && h.cb >= 0 && h.cb < in.n_strings && !(in.skips && uniform_load(in.skips + h.cb))) {
         h.sb = uniform_load(in.begins + h.cb);
         h.slen = uniform_load(in.ends + h.cb) - h.sb;
-        h.simple = h.slen > 0 && h.slen <= kPrefetchBytes;
+        // (offsets that leave the chars tensor make the row "not simple": the generic path reports them)
+        h.simple = h.slen > 0 && h.slen <= kChunk && h.sb >= 0 && (long long)h.sb + h.slen <= in.n_chars;
     }
     return h;
 }
 
+constexpr int kStageChunk = 4096;  // staging entries a wave takes from its allocator at a time
+// Staging capacity of a row (mul * sum of max(len, 1)) with the offset validation prep_rows_kernel does otherwise;
+// -1 (and kFlagRange) for offsets that leave their tensors.  Wave-uniform result.
+__device__ __forceinline__ int row_capacity_checked(const RowsIn& in, const RowHdr& h, int mul, RunStatus* status) {
+    const int l = lane_id();
+    bool bad = h.cb < h.ce && (h.cb < 0 || h.ce > in.n_strings);
+    long long cap = 0;
+    if (!bad) {
+        if (h.simple) {
+            bad = h.sb < 0 || (long long)h.sb + h.slen > in.n_chars;
+            cap = (long long)h.slen * mul;
+        } else {
+            for (int col = h.cb + l; col < h.ce; col += kWave) {
+                const long long sb = in.begins[col], se = in.ends[col];
+                if (sb < 0 || se < sb || se > in.n_chars) bad = true;
+                else cap += (se - sb > 0 ? se - sb : 1) * mul;
+            }
+#pragma unroll
+            for (int d = kWave / 2; d > 0; d >>= 1) cap += __shfl_xor(cap, d);
+        }
+    }
+    if (__ballot(bad) || cap > INT32_MAX / 2) {
+        if (l == 0) atomicOr(&status->flags, kFlagRange);
+        return -1;
+    }
+    return int(cap);
+}
+
 template <int MODE>
-static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
     if (w.status->flags & kFatalFlags) return;
@@ -322,33 +352,39 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
     int n_miss = 0;
     const int n_waves = w.n_waves;  // == gridDim.x * kWavesPerBlock: the geometry prep_rows_kernel summed over
     const int wave = wave_uniform(int(blockIdx.x) * kWavesPerBlock + wave_in_block());
-    int cursor = int(w.wave_off[wave]);  // rows of this wave are staged back to back in its arena
-    // fused mode: headers two rows ahead, text one row ahead
-    RowHdr h_cur{0, 0, 0, 0, false}, h_next{0, 0, 0, 0, false}, h_range{0, 0, 0, 0, false};
-    TextRegs t_cur{{0, 0, 0}};
-    if (MODE == kFused) {
-        h_cur = load_row_string(in, load_row_range(in, wave));
-        h_next = load_row_string(in, load_row_range(in, wave + n_waves));
-        h_range = load_row_range(in, wave + 2 * n_waves);
-        if (h_cur.simple) t_cur = prefetch_text(in.chars + h_cur.sb, h_cur.slen);
-    }
+    // rows of this wave are staged back to back: in its arena (prep_rows_kernel ran), or in chunks it takes from one
+    // of kShards bump allocators (no prep launch; offsets are validated here)
+    const bool alloc = w.wave_off == nullptr;
+    int cursor = alloc ? 0 : int(w.wave_off[wave]), limit = alloc ? 0 : INT32_MAX;
+    bool dead = false;  // allocator mode: staging exhausted or bad offsets -- the host reruns / reports
     for (int row = wave; row < in.n_rows; row += n_waves) {
-        RowState st{cursor, 0, 0, row};
-        if (MODE == kPieces) {
-            lookup_whole_strings(T, st, w, mb, n_miss, in, in.ragged_begins[row], in.ragged_ends[row]);
-        } else {
-            const RowHdr h = h_cur;
-            const TextRegs t = t_cur;
-            h_cur = h_next;
-            if (h_cur.simple) t_cur = prefetch_text(in.chars + h_cur.sb, h_cur.slen);  // lands while this row is processed
-            h_next = load_row_string(in, h_range);           // its row range was loaded one iteration ago
-            h_range = load_row_range(in, row + 3 * n_waves);
-            int pre_skew = -1;
-            if (h.simple) {
-                wave_sync();  // the previous row is done with the LDS window
-                pre_skew = commit_text(ws, in.chars + h.sb, h.slen, t);
-                wave_sync();
+        RowHdr h{0, 0, 0, 0, false};
+        if (MODE == kFused) h = load_row_string(in, load_row_range(in, row));
+        else h = load_row_range(in, row);
+        if (alloc) {
+            const int cap = dead ? 0 : row_capacity_checked(in, h, T.suffix_len + 1, w.status);
+            if (cap < 0) dead = true;
+            if (!dead && cursor + cap > limit) {
+                const int size = cap > kStageChunk ? cap : kStageChunk;
+                const int shard = wave % kShards;
+                int base = 0;
+                if (l == 0) base = atomicAdd(&w.status->stage_top[shard * kCounterStride], size);
+                base = wave_readlane(base, 0);
+                if (base < 0 || base > w.stage_region - size) {
+                    if (l == 0) atomicOr(&w.status->flags, kFlagStageOverflow);
+                    dead = true;
+                } else {
+                    cursor = shard * w.stage_region + base;
+                    limit = cursor + size;
+                }
             }
+        }
+        RowState st{cursor, 0, 0, row};
+        if (dead) {
+            // nothing is staged for this row
+        } else if (MODE == kPieces) {
+            lookup_whole_strings(T, st, w, mb, n_miss, in, h.cb, h.ce);
+        } else {
             for (int col = h.cb; col < h.ce; ++col) {
                 if (!h.simple && in.skips && in.skips[col]) {  // regex_split.cpp:231-234: passes through unsplit
                     lookup_whole_strings(T, st, w, mb, n_miss, in, col, col + 1);
@@ -375,8 +411,7 @@ static __global__ __launch_bounds__(kBlockThreads) void lookup_kernel(RowsIn in,
                     },
                     [&](int b, int e, bool dropped) {  // a piece longer than the scan window: straight to the deferred list
                         lookup_batch(T, st, w, mb, n_miss, l == 0 && !dropped, 0, 0, e - b, sb + b);
-                    },
-                    pre_skew);
+                    });
             }
         }
         if (l == 0) {

@@ -116,36 +116,6 @@ __device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str,
     return skew;
 }
 
-// Software-pipelined staging of a whole string of at most kChunk bytes: the aligned dwords that cover it are
-// fetched into registers one row ahead (prefetch_text) and written to LDS when the row's turn comes
-// (commit_text).  Reads whole aligned dwords: up to 3 bytes on either side of the string are fetched too (same
-// dword as a byte of the string, so the same page) and ignored by the scanners.
-struct TextRegs { uint32_t d[3]; };
-constexpr int kPrefetchBytes = kChunk;
-__device__ __forceinline__ TextRegs prefetch_text(const uint8_t* str, int slen) {
-    const int skew = int(reinterpret_cast<uintptr_t>(str) & 3);
-    const uint32_t* ga = reinterpret_cast<const uint32_t*>(str - skew);
-    const int nwords = (skew + slen + 3) >> 2;  // <= 129
-    TextRegs r{{0, 0, 0}};
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int k = lane_id() + j * kWave;
-        if (k < nwords) r.d[j] = ga[k];
-    }
-    return r;
-}
-__device__ __forceinline__ int commit_text(WaveScratch& ws, const uint8_t* str, int slen, const TextRegs& r) {
-    const int skew = int(reinterpret_cast<uintptr_t>(str) & 3);
-    const int nwords = (skew + slen + 3) >> 2;
-    if (lane_id() == 0) ws.text_w[0] = 0;  // kTextPad
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int k = lane_id() + j * kWave;
-        if (k < nwords) ws.text_w[kTextPad / 4 + k] = r.d[j];
-    }
-    return skew;
-}
-
 // ---- 64-bit masks, lane w = window bytes [64w, 64w + 64) ---------------------------------------
 using Mask = unsigned long long;
 // Bit i of the result = bit (i - k) of the window-wide mask (k in 1..4): "property of the byte k places before".
@@ -384,10 +354,9 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
 //                               (read positions through kPiecePosMask).
 //   on_long(b, e, dropped):     a piece of more than kChunk bytes, not staged in LDS.
 // Wave-uniform; every lane must call it with the same arguments.
-// prestaged_skew >= 0: the caller already staged the whole string (slen <= kChunk) at that skew.
 template <class OnChunk, class OnLong>
 __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp, const uint8_t* str, int slen,
-                                            OnChunk&& on_chunk, OnLong&& on_long, int prestaged_skew = -1) {
+                                            OnChunk&& on_chunk, OnLong&& on_long) {
     const bool digits = sp.kind == kSplitGpt2Digits;
     const int l = lane_id();
     int c0 = 0;
@@ -403,12 +372,9 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
             qlim = c0 + (rest + nchunks - 1) / nchunks;
         }
         const int w1 = (qlim + kRightHalo < slen) ? qlim + kRightHalo : slen;
-        int skew = prestaged_skew;
-        if (skew < 0) {
-            wave_sync();  // previous consumers of the LDS window are done
-            skew = stage_window(ws, str, slen, w0, w1);
-            wave_sync();
-        }
+        wave_sync();  // previous consumers of the LDS window are done
+        const int skew = stage_window(ws, str, slen, w0, w1);
+        wave_sync();
         // rank the starts of [c0, qlim) (window bytes [lo, hi)); c0 itself is a start by construction
         const int lo = c0 - w0, hi = qlim - w0;
         int np = 0;

@@ -297,6 +297,7 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memse
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
