@@ -40,7 +40,7 @@ KERNEL_NAMES = {"lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "looku
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",
                 "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel", "split_count": "split_seq_kernel<0>",
                 "split_write": "split_seq_kernel<1>",
-                "detokenize": "tile_{reduce,apply}_kernel<DecodeLen,DecodeApply>", "tile_scan": "tile_scan_kernel"}
+                "detokenize": "decode_write_kernel", "decode_count": "decode_count_kernel", "decode_scan": "tile_{reduce,scan,apply}_kernel<UnitLen>"}
 BERT_WS = r"\s+"
 BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\x{4E00}-\x{9FFF}]", r"[\x{3400}-\x{4DBF}]",
                        r"[\x{20000}-\x{2A6DF}]", r"[\x{2A700}-\x{2B73F}]", r"[\x{2B740}-\x{2B81F}]",

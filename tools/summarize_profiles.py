@@ -31,17 +31,17 @@ def main(prefix):
     stem = Path(prefix).name
     pmc_json = {}
     for cfg in (2, 3, 5):
-        st = glob.glob(str(ROOT / f"gpurun_out/prof_c{cfg}/*/*kernel_stats.csv"))
+        st = sorted(glob.glob(str(ROOT / f"gpurun_out/prof_c{cfg}/*/*kernel_stats.csv")))
         if st:
-            d = pd.read_csv(st[0])
+            d = pd.read_csv(st[-1])
             d = d[d["Name"].str.contains("ovtk")]
             d.to_csv(out_dir / f"{stem}_config{cfg}_kernel_stats.csv", index=False)
         rows = []
         for ctr in ("fetch", "write"):
-            f = glob.glob(str(ROOT / f"gpurun_out/pmc_{ctr}_c{cfg}/*/*counter_collection.csv"))
+            f = sorted(glob.glob(str(ROOT / f"gpurun_out/pmc_{ctr}_c{cfg}/*/*counter_collection.csv")))
             if not f:
                 continue
-            d = pd.read_csv(f[0])
+            d = pd.read_csv(f[-1])
             d = d[d["Kernel_Name"].str.contains("ovtk")]
             d["kernel"] = d["Kernel_Name"].map(short)
             g = d.groupby(["kernel", "Counter_Name"]).agg(dispatches=("Counter_Value", "size"), mean_KB=("Counter_Value", "mean"),
@@ -58,6 +58,8 @@ def main(prefix):
                 base = k.split("<")[0] + ("<" + k.split("<")[1] if "<" in k and k.startswith("lookup") else "")
                 tag = TAG.get(base, TAG.get(k, k))
                 per[tag] = int((2 * fetch + write) * 1024)
+            if cfg == 3 and "lookup_fused" in per:
+                per["lookup_words"] = per["lookup_fused"]  # bench.py's name for the same kernel run with the BERT scanner
             pmc_json[f"config{cfg}"] = per
     (ROOT / "profiles" / "latest_pmc.json").write_text(json.dumps(pmc_json, indent=1, sort_keys=True) + "\n")
     print(json.dumps(pmc_json, indent=1))
