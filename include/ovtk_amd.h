@@ -114,6 +114,19 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
                          ovtk_ragged_strings_out* out, int mem, void* stream);
 void ovtk_regex_split_destroy(ovtk_regex_split* h);
 
+/* ---------------------------------------------------------------- SpecialTokensSplit
+ * Replaces SpecialTokensSplit::evaluate, src/special_tokens_split.cpp:61-162 (+ PCRE2Wrapper::match_and_find_group,
+ * src/utils.cpp:423-461): the op in front of RegexSplit that cuts the added / special tokens out of the text and
+ * produces the `skips` flags.  The pattern (input 5 / 6) is the alternation of quoted token lists that
+ * SpecialTokensSplitStep generates (python/openvino_tokenizers/tokenizer_pipeline.py:138-159); create() parses it back
+ * into literal tokens and strip flags, anything else is OVTK_E_UNSUPPORTED.  `skips` (7-input form) may be NULL;
+ * out->skips is mandatory (output 5).  Capacity: the reference sizes the outputs to n_chars (:88-92). */
+typedef struct ovtk_special_tokens_split ovtk_special_tokens_split;
+int ovtk_special_tokens_split_create(const char* pattern, int64_t pattern_len, int device, ovtk_special_tokens_split** out);
+int ovtk_special_tokens_split_run(ovtk_special_tokens_split* h, const ovtk_ragged_strings* in, const uint8_t* skips,
+                                  ovtk_ragged_strings_out* out, int mem, void* stream);
+void ovtk_special_tokens_split_destroy(ovtk_special_tokens_split* h);
+
 /* ---------------------------------------------------------------- BPETokenizer
  * Replaces BPETokenizer::evaluate + BPETokenizerImpl, src/bpe_tokenizer.cpp:47-388, src/bpe_tokenizer.hpp:40-131.
  * Constant inputs 5-7 (vocab), 8-10 (merges: "left right" lines, or left halves), 11-13 (right halves; NULL

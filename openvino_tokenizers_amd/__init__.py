@@ -6,4 +6,4 @@ include/ovtk_amd.h; see DESIGN.md and INTEGRATION.md.
 """
 from ._lib import OvtkError, load  # noqa: F401
 from .ops import (BPETokenizer, ByteFallback, FusedDetokenizer, FusedSplitBPE, FusedSplitWordpiece, FuzeRagged, RaggedToDense,  # noqa: F401
-                  RegexSplit, VocabDecoder, VocabEncoder, WordpieceTokenizer)
+                  RegexSplit, SpecialTokensSplit, VocabDecoder, VocabEncoder, WordpieceTokenizer)

@@ -77,6 +77,7 @@ class StringsOut(C.Structure):
 EXPORTS = [
     "ovtk_last_error", "ovtk_abi_version", "ovtk_device_name",
     "ovtk_regex_split_create", "ovtk_regex_split_run", "ovtk_regex_split_destroy",
+    "ovtk_special_tokens_split_create", "ovtk_special_tokens_split_run", "ovtk_special_tokens_split_destroy",
     "ovtk_bpe_create", "ovtk_bpe_run", "ovtk_bpe_destroy", "ovtk_encode_run",
     "ovtk_wordpiece_create", "ovtk_wordpiece_run", "ovtk_wordpiece_encode_run", "ovtk_wordpiece_destroy",
     "ovtk_vocab_encoder_create", "ovtk_vocab_encoder_run", "ovtk_vocab_encoder_destroy",

@@ -5,7 +5,9 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cctype>
 #include <string>
+#include <vector>
 
 #include "api_common.hpp"
 #include "encode_kernels.hpp"
@@ -92,6 +94,65 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab) {
 }
 }  // namespace
 
+struct ovtk_special_tokens_split {
+    int device = 0;
+    SpecialDev dev{};
+    DevBuf tb, te, tc, gf, gfl;
+};
+
+namespace {
+// Parses the pattern SpecialTokensSplitStep generates (tokenizer_pipeline.py:138-159):
+//   alt ( "|" alt )*,  alt = ["(?:\\s*)"] "(" token ( "|" token )* ")" ["(?:\\s*)"],  token = quote_meta(text).
+// Returns false for anything else.
+bool parse_special_pattern(const std::string& pat, std::vector<std::string>& tokens, std::vector<int32_t>& group_first,
+                           std::vector<uint8_t>& group_flags) {
+    static const std::string kStrip = "(?:\\s*)";
+    size_t i = 0;
+    group_first.clear();
+    group_flags.clear();
+    tokens.clear();
+    if (pat.empty()) return false;
+    while (true) {
+        uint8_t flags = 0;
+        if (pat.compare(i, kStrip.size(), kStrip) == 0) { flags |= 1; i += kStrip.size(); }
+        if (i >= pat.size() || pat[i] != '(' || pat.compare(i, 2, "(?") == 0) return false;
+        ++i;
+        group_first.push_back(int32_t(tokens.size()));
+        std::string tok;
+        bool closed = false;
+        while (i < pat.size()) {
+            const char c = pat[i];
+            if (c == '\\') {
+                if (i + 1 >= pat.size()) return false;
+                const unsigned char n = static_cast<unsigned char>(pat[i + 1]);
+                if (n < 0x80 && std::isalnum(n)) return false;  // an escape sequence, not a quoted literal
+                tok.push_back(char(n));
+                i += 2;
+            } else if (c == '|' || c == ')') {
+                if (tok.empty()) return false;
+                tokens.push_back(tok);
+                tok.clear();
+                ++i;
+                if (c == ')') { closed = true; break; }
+            } else if (c == '(' || c == '[' || c == '*' || c == '+' || c == '?' || c == '.' || c == '^' || c == '$' || c == '{') {
+                return false;  // quote_meta would have escaped it: not a literal token list
+            } else {
+                tok.push_back(c);
+                ++i;
+            }
+        }
+        if (!closed) return false;
+        if (pat.compare(i, kStrip.size(), kStrip) == 0) { flags |= 2; i += kStrip.size(); }
+        group_flags.push_back(flags);
+        if (i == pat.size()) break;
+        if (pat[i] != '|') return false;
+        ++i;
+    }
+    group_first.push_back(int32_t(tokens.size()));
+    return true;
+}
+}  // namespace
+
 extern "C" {
 
 const char* ovtk_last_error(void) { return last_error(); }
@@ -163,6 +224,55 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
 }
 
 void ovtk_regex_split_destroy(ovtk_regex_split* h) { delete h; }
+
+// ------------------------------------------------------------------------------- SpecialTokensSplit
+int ovtk_special_tokens_split_create(const char* pattern, int64_t pattern_len, int device, ovtk_special_tokens_split** out) {
+    if (!pattern || !out || pattern_len < 0) return set_error(OVTK_E_ARG, "special_tokens_split: null argument");
+    std::vector<std::string> tokens;
+    std::vector<int32_t> group_first;
+    std::vector<uint8_t> group_flags;
+    if (!parse_special_pattern(std::string(pattern, pattern + pattern_len), tokens, group_first, group_flags))
+        return set_error(OVTK_E_UNSUPPORTED,
+                         "SpecialTokensSplit: the pattern is not a list of quoted special tokens as "
+                         "tokenizer_pipeline.py:138-159 generates it; PCRE2 is not executed on the device");
+    if (int rc = use_device(device)) return rc;
+    auto h = std::make_unique<ovtk_special_tokens_split>();
+    h->device = device;
+    std::vector<int32_t> tb, te;
+    std::string chars;
+    bool any_strip_left = false;
+    for (uint8_t f : group_flags) any_strip_left = any_strip_left || (f & 1);
+    for (const auto& t : tokens) {
+        tb.push_back(int32_t(chars.size()));
+        chars += t;
+        te.push_back(int32_t(chars.size()));
+        const uint8_t b = uint8_t(t[0]);
+        h->dev.first_bytes[b >> 5] |= 1u << (b & 31);
+    }
+    if (any_strip_left)  // a match may start with \\s (PCRE2_UCP): tab..CR, space, and the lead bytes of U+0085, U+00A0, U+1680,
+                         // U+2000-200A / 2028 / 2029 / 202F / 205F, U+3000
+        for (uint8_t b : {9, 10, 11, 12, 13, 32, 0xC2, 0xE1, 0xE2, 0xE3}) h->dev.first_bytes[b >> 5] |= 1u << (b & 31);
+    int e = 0;
+    e = e ? e : h->tb.upload(tb.data(), tb.size() * 4);
+    e = e ? e : h->te.upload(te.data(), te.size() * 4);
+    e = e ? e : h->tc.upload(chars.data(), chars.size());
+    e = e ? e : h->gf.upload(group_first.data(), group_first.size() * 4);
+    e = e ? e : h->gfl.upload(group_flags.data(), group_flags.size());
+    if (e) return e;
+    OVTK_HIP(hipStreamSynchronize(nullptr));
+    h->dev.tok_begins = h->tb.as<int32_t>();
+    h->dev.tok_ends = h->te.as<int32_t>();
+    h->dev.tok_chars = h->tc.as<uint8_t>();
+    h->dev.group_first = h->gf.as<int32_t>();
+    h->dev.group_flags = h->gfl.as<uint8_t>();
+    h->dev.n_groups = int32_t(group_flags.size());
+    h->dev.uc.kind = kSplitWhitespace;
+    if (int rc = unicode_tables(device, &h->dev.uc.uc_index, &h->dev.uc.uc_blocks)) return rc;
+    *out = h.release();
+    return OVTK_OK;
+}
+
+void ovtk_special_tokens_split_destroy(ovtk_special_tokens_split* h) { delete h; }
 
 // ------------------------------------------------------------------------------- BPETokenizer
 int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
@@ -362,6 +472,68 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
         OVTK_HIP(hipMemcpyAsync(out->begins, d_b, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
         OVTK_HIP(hipMemcpyAsync(out->ends, d_e, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
         if (out->skips) OVTK_HIP(hipMemcpyAsync(out->skips, d_sk, size_t(st.n_out), hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipStreamSynchronize(s));
+    }
+    return OVTK_OK;
+}
+
+int ovtk_special_tokens_split_run(ovtk_special_tokens_split* h, const ovtk_ragged_strings* in, const uint8_t* skips,
+                                  ovtk_ragged_strings_out* out, int mem, void* stream) {
+    if (int rc = check_rows(in)) return rc;
+    if (!h || !out || !out->skips) return set_error(OVTK_E_ARG, "special_tokens_split: null argument (the skips output is mandatory)");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(h->device));
+    out->n = 0;
+    out->n_rows = in->n_rows;
+    if (in->n_rows == 0) return OVTK_OK;
+    WorkspaceLease ws(h->device);
+    if (!ws->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
+    RowsIn d_in{};
+    if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
+    const int n_rows = d_in.n_rows;
+    const int grid = grid_lookup(h->device, n_rows);
+    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
+    int e = 0;
+    e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
+    e = e ? e : ws->wave_off.ensure(size_t(grid * kWavesPerBlock + 1) * sizeof(long long));
+    e = e ? e : ws->tiles.ensure(size_t(n_tiles + 1) * sizeof(long long));
+    e = e ? e : ws->status.ensure(sizeof(RunStatus));
+    if (e) return e;
+    int32_t *d_rb = nullptr, *d_re = nullptr, *d_b = nullptr, *d_e = nullptr;
+    uint8_t* d_sk = nullptr;
+    e = e ? e : out_target(ws->out_a, out->ragged_begins, size_t(n_rows) * 4, mem, &d_rb);
+    e = e ? e : out_target(ws->out_b, out->ragged_ends, size_t(n_rows) * 4, mem, &d_re);
+    e = e ? e : out_target(ws->out_c, out->begins, size_t(out->capacity) * 4, mem, &d_b);
+    e = e ? e : out_target(ws->out_d, out->ends, size_t(out->capacity) * 4, mem, &d_e);
+    e = e ? e : out_target(ws->out_e, out->skips, size_t(out->capacity), mem, &d_sk);
+    if (e) return e;
+    EncodeWork w{};
+    w.n_waves = grid * kWavesPerBlock;
+    w.wave_off = ws->wave_off.as<long long>();
+    w.row_cnt = ws->row_cnt.as<int32_t>();
+    w.tile_off = ws->tiles.as<long long>();
+    w.stage_cap = INT32_MAX;
+    w.status = ws->status.as<RunStatus>();
+    OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
+    OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);  // offset validation
+    const int seq_grid = (n_rows + kBlockThreads - 1) / kBlockThreads;
+    OVTK_LAUNCH(ws->marks, "special_count", special_split_kernel<0>, seq_grid, kBlockThreads, s, d_in, h->dev, w, (int32_t*)nullptr,
+                (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
+    OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s, n_rows,
+                w, (long long)out->capacity);
+    OVTK_LAUNCH(ws->marks, "special_write", special_split_kernel<1>, seq_grid, kBlockThreads, s, d_in, h->dev, w, d_rb, d_re, d_b, d_e,
+                d_sk);
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    const RunStatus& st = *ws->host_status;
+    if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+    if (st.flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "SpecialTokensSplit: output begins/ends too small");
+    out->n = st.n_out;
+    if (mem == OVTK_MEM_HOST) {
+        OVTK_HIP(hipMemcpyAsync(out->ragged_begins, d_rb, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->ragged_ends, d_re, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->begins, d_b, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->ends, d_e, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->skips, d_sk, size_t(st.n_out), hipMemcpyDeviceToHost, s));
         OVTK_HIP(hipStreamSynchronize(s));
     }
     return OVTK_OK;

@@ -708,4 +708,52 @@ static __global__ __launch_bounds__(kBlockThreads) void split_seq_kernel(RowsIn 
     if (!WRITE) w.row_cnt[row] = count;
 }
 
+// ---- SpecialTokensSplit: one LANE per row, count pass then write pass.
+template <int WRITE>
+static __global__ __launch_bounds__(kBlockThreads) void special_split_kernel(RowsIn in, SpecialDev T, EncodeWork w,
+                                                                             int32_t* out_rb, int32_t* out_re,
+                                                                             int32_t* out_begins, int32_t* out_ends,
+                                                                             uint8_t* out_skips) {
+    if (w.status->flags & (kFlagRange | kFlagOutCapacity)) return;
+    const int row = int(blockIdx.x) * kBlockThreads + int(threadIdx.x);
+    const bool valid = row < in.n_rows;
+    int o = 0;
+    if (WRITE) {
+        const int cnt = valid ? w.row_cnt[row] : 0;
+        const int incl = wave_incl_sum(cnt);
+        o = int(w.tile_off[row / kRowTile < (in.n_rows + kRowTile - 1) / kRowTile ? row / kRowTile : 0]) + incl - cnt;
+        if (valid) {
+            out_rb[row] = o;
+            out_re[row] = o + cnt;
+        }
+    }
+    if (!valid) return;
+    int count = 0;
+    auto put = [&](int b, int e, int skip) {
+        if (WRITE) {
+            out_begins[o + count] = b;
+            out_ends[o + count] = e;
+            out_skips[o + count] = uint8_t(skip);
+        }
+        ++count;
+    };
+    for (int col = in.ragged_begins[row]; col < in.ragged_ends[row]; ++col) {
+        const int sb = in.begins[col], se = in.ends[col];
+        if (in.skips && in.skips[col]) {  // special_tokens_split.cpp:110-113
+            put(sb, se, 1);
+            continue;
+        }
+        const uint8_t* s = in.chars + sb;
+        const int slen = se - sb;
+        int start = 0, mb = 0, gb = 0, ge = 0, me = 0;
+        while (start < slen && special_next_match(T, s, slen, start, mb, gb, ge, me)) {  // :127-141
+            if (start < mb) put(sb + start, sb + mb, 0);
+            put(sb + gb, sb + ge, 1);
+            start = me;
+        }
+        if (start < slen) put(sb + start, sb + slen, 0);  // :143-147
+    }
+    if (!WRITE) w.row_cnt[row] = count;
+}
+
 }  // namespace ovtk

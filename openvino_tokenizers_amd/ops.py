@@ -156,6 +156,41 @@ class RegexSplit(_Op):
         return res
 
 
+class SpecialTokensSplit(_Op):
+    """Reference: src/special_tokens_split.cpp (evaluate :61-162).  Inputs: ragged_begins, ragged_ends, begins, ends,
+    chars, [skips], pattern.  Outputs: ragged_begins, ragged_ends, begins, ends, chars (the input tensor), skips."""
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ovtk_special_tokens_split_destroy(self._h)
+            self._h = None
+
+    def _ensure(self, pattern):
+        if self._h:
+            return
+        pat = _bytes_of(pattern)
+        self._chk(self._lib.ovtk_special_tokens_split_create(pat, C.c_int64(len(pat)), self.device, C.byref(self._h)))
+
+    def evaluate(self, inputs):
+        if len(inputs) not in (6, 7):
+            raise L.OvtkError(L.E_ARG, f"Incorrect number of inputs passed to SpecialTokensSplit: {len(inputs)}; try to "
+                                       f"reconvert tokenizer with newer version of OpenVINO Tokenizers")
+        has_skips = len(inputs) == 7
+        self._ensure(inputs[5 + has_skips])
+        m = _Mem(inputs[4])
+        rs, (rb, re_, b, e, c) = _ragged_in(m, inputs)
+        _, pskips = (m.inp(inputs[5], "bool") if has_skips else (None, None))
+        cap = len(c) + len(b)  # the reference sizes to n_chars (:88-92); + n for skipped empty strings
+        orb, porb = m.alloc(len(rb), "i32")
+        ore, pore = m.alloc(len(rb), "i32")
+        ob, pob = m.alloc(cap, "i32")
+        oe, poe = m.alloc(cap, "i32")
+        osk, posk = m.alloc(cap, "bool")
+        out = L.RaggedStringsOut(porb, pore, 0, pob, poe, posk, cap, 0)
+        self._chk(self._lib.ovtk_special_tokens_split_run(self._h, C.byref(rs), pskips, C.byref(out), m.mem, m.stream))
+        return [orb[:out.n_rows], ore[:out.n_rows], ob[:out.n], oe[:out.n], c, osk[:out.n]]
+
+
 class BPETokenizer(_Op):
     """Reference: src/bpe_tokenizer.cpp (evaluate :47-164).  11/14/15/18 inputs: ragged strings (5), vocab (3),
     merges (3, or 3 + 3 for left/right halves), [added tokens (3) + ids (1)].  Outputs: begins, ends, ids."""

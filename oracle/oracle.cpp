@@ -49,6 +49,7 @@ struct Pcre2 {
     int (*match)(const code*, const uint8_t*, size_t, size_t, uint32_t, match_data*, void*) = nullptr;
     int (*jit_match)(const code*, const uint8_t*, size_t, size_t, uint32_t, match_data*, void*) = nullptr;
     size_t* (*ovector)(match_data*) = nullptr;
+    uint32_t (*ovector_count)(match_data*) = nullptr;
     void (*md_free)(match_data*) = nullptr;
     void (*code_free)(code*) = nullptr;
     bool ok = false;
@@ -69,9 +70,10 @@ struct Pcre2 {
             q.match = reinterpret_cast<decltype(q.match)>(sym("pcre2_match_8"));
             q.jit_match = reinterpret_cast<decltype(q.jit_match)>(sym("pcre2_jit_match_8"));
             q.ovector = reinterpret_cast<decltype(q.ovector)>(sym("pcre2_get_ovector_pointer_8"));
+            q.ovector_count = reinterpret_cast<decltype(q.ovector_count)>(sym("pcre2_get_ovector_count_8"));
             q.md_free = reinterpret_cast<decltype(q.md_free)>(sym("pcre2_match_data_free_8"));
             q.code_free = reinterpret_cast<decltype(q.code_free)>(sym("pcre2_code_free_8"));
-            q.ok = q.compile && q.jit_compile && q.md_create && q.match && q.jit_match && q.ovector &&
+            q.ok = q.compile && q.jit_compile && q.md_create && q.match && q.jit_match && q.ovector && q.ovector_count &&
                    q.md_free && q.code_free;
             return q;
         }();
@@ -283,6 +285,64 @@ extern "C" int orc_regex_split_run(const orc_regex* r, const int32_t* rb, const 
         out_re[row] = int32_t(off);
     }
     *n_rows_out = B;
+    *n_out = off;
+    return ORC_OK;
+}
+
+// =======================================================================================
+// SpecialTokensSplit : src/special_tokens_split.cpp:61-162, PCRE2Wrapper::match_and_find_group src/utils.cpp:423-461
+// =======================================================================================
+extern "C" int orc_special_tokens_split_run(const orc_regex* r, const int32_t* rb, const int32_t* re, int64_t B,
+                                            const int32_t* begins, const int32_t* ends, const uint8_t* chars,
+                                            const uint8_t* skips, int32_t* out_rb, int32_t* out_re,
+                                            int32_t* out_begins, int32_t* out_ends, uint8_t* out_skips, int64_t cap,
+                                            int64_t* n_out) {
+    const Pcre2& P = Pcre2::get();
+    MatchData md(r);
+    int64_t off = 0;
+    auto put = [&](int32_t b, int32_t e, bool skip) -> bool {
+        if (off >= cap) return false;
+        out_begins[off] = b;
+        out_ends[off] = e;
+        out_skips[off] = skip ? 1 : 0;
+        ++off;
+        return true;
+    };
+    for (int64_t row = 0; row < B; ++row) {
+        out_rb[row] = int32_t(off);
+        for (int32_t col = rb[row]; col < re[row]; ++col) {
+            const int32_t sb = begins[col];
+            const uint8_t* s = chars + sb;
+            const size_t len = size_t(ends[col] - sb);
+            bool ok = true;
+            if (skips && skips[col]) {  // :110-113
+                ok = put(sb, ends[col], true);
+            } else {
+                size_t start = 0;
+                while (r->code && md.md) {  // :127-141
+                    const int rc = (r->jit ? P.jit_match : P.match)(r->code, s, len, start, 0, md.md, nullptr);
+                    if (rc < 0) break;
+                    const size_t* ov = P.ovector(md.md);
+                    const size_t mb = ov[0], me = ov[1];
+                    if (mb == me) break;  // "match.first != match.second" (:119)
+                    // utils.cpp:452-457: the capture group that lies inside the full match (the last such one)
+                    size_t gb = size_t(-1), ge = size_t(-1);
+                    const uint32_t n = P.ovector_count(md.md);
+                    for (uint32_t g = 1; g < n; ++g)
+                        if (mb <= ov[2 * g] && ov[2 * g] <= me && ov[2 * g + 1] <= me) { gb = ov[2 * g]; ge = ov[2 * g + 1]; }
+                    const bool empty_group = gb == size_t(-1) || gb == ge;
+                    const size_t group_start = empty_group ? mb : gb;
+                    const size_t group_end = (ge == size_t(-1) || empty_group) ? me : ge;
+                    if (start < mb) ok = ok && put(sb + int32_t(start), sb + int32_t(mb), false);
+                    ok = ok && put(sb + int32_t(group_start), sb + int32_t(group_end), true);
+                    start = me;
+                }
+                if (start < len) ok = ok && put(sb + int32_t(start), sb + int32_t(len), false);  // :143-147
+            }
+            if (!ok) return fail(ORC_E_CAPACITY, "special_tokens_split: output overflow");
+        }
+        out_re[row] = int32_t(off);
+    }
     *n_out = off;
     return ORC_OK;
 }

@@ -57,6 +57,14 @@ int orc_regex_split_run(const orc_regex*, const int32_t* rb, const int32_t* re, 
  * Returns 1 and fills m[2] on a match, 0 on no match. */
 int orc_regex_match(const orc_regex*, const uint8_t* s, int64_t len, int64_t start, int64_t* m);
 
+/* ---- SpecialTokensSplit : src/special_tokens_split.cpp:61-162 (the pattern is compiled with orc_regex_split_create;
+ * behaviour / invert / max_splits are not used).  skips may be NULL (6-input form); out_skips is always written.
+ * Output buffers sized `cap` (reference bound: nchars). */
+int orc_special_tokens_split_run(const orc_regex*, const int32_t* rb, const int32_t* re, int64_t B,
+                                 const int32_t* begins, const int32_t* ends, const uint8_t* chars,
+                                 const uint8_t* skips, int32_t* out_rb, int32_t* out_re,
+                                 int32_t* out_begins, int32_t* out_ends, uint8_t* out_skips, int64_t cap, int64_t* n_out);
+
 /* ---- BPETokenizer : src/bpe_tokenizer.cpp:47-388, src/bpe_tokenizer.hpp:40-131 ---- */
 typedef struct orc_bpe orc_bpe;
 /* merges: if mr_begins == NULL the merges are "left right" text lines in (ml_*), split at the

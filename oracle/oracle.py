@@ -139,6 +139,43 @@ class RegexSplit:
         return out
 
 
+# --------------------------------------------------------------------------- SpecialTokensSplit
+def special_tokens_pattern(tokens):
+    """tokens: list of (text, strip_left, strip_right) -> the pattern SpecialTokensSplitStep builds
+    (python/openvino_tokenizers/tokenizer_pipeline.py:138-159, utils.py:421-429 quote_meta)."""
+    def quote_meta(t):
+        return "".join(("\\" if not ch.isalnum() and ch not in ("_", "\u2581", "\uff5c") else "") + ch for ch in t)
+    groups = {}
+    for text, sl, sr in tokens:
+        groups.setdefault((bool(sl), bool(sr)), []).append(text)
+    return "|".join(r"(?:\s*)" * sl + "(" + "|".join(quote_meta(t) for t in toks) + ")" + r"(?:\s*)" * sr
+                    for (sl, sr), toks in groups.items())
+
+
+class SpecialTokensSplit:
+    def __init__(self, pattern):
+        self._re = RegexSplit(pattern, "isolate")
+
+    def __call__(self, rb, re_, begins, ends, chars, skips=None):
+        rb, prb = _i32(rb)
+        re_, pre = _i32(re_)
+        begins, pb = _i32(begins)
+        ends, pe = _i32(ends)
+        chars, pc = _u8(chars)
+        B, cap = len(rb), len(chars) + len(begins) + 1
+        ps = None
+        if skips is not None:
+            skips, ps = _u8(np.asarray(skips, dtype=np.uint8))
+        orb, ore = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        ob, oe, osk = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.uint8)
+        n = C.c_int64()
+        _chk(lib().orc_special_tokens_split_run(self._re._h, prb, pre, C.c_int64(B), pb, pe, pc, ps,
+                                                orb.ctypes.data_as(i32p), ore.ctypes.data_as(i32p),
+                                                ob.ctypes.data_as(i32p), oe.ctypes.data_as(i32p),
+                                                osk.ctypes.data_as(u8p), C.c_int64(cap), C.byref(n)))
+        return [orb, ore, ob[:n.value].copy(), oe[:n.value].copy(), chars, osk[:n.value].copy()]
+
+
 # --------------------------------------------------------------------------- BPETokenizer
 class BPETokenizer:
     """vocab: list[bytes]; merges: list[(bytes,bytes)] or list[bytes] ("a b" text form);

@@ -73,3 +73,21 @@ RAGGED_TO_DENSE_KATS = [
     (dict(_R2D, padding_size=10), False, True,
      [[10, 20, 100, 42, 42, 42, 42, 42, 42, 42], [30, 40, 50, 200, 300, 42, 42, 42, 42, 42]]),
 ]
+
+
+# tests/layer_tests.py:405-457 (SpecialTokensSplit): (tokens [(text, strip_left, strip_right)], text, pieces, skips)
+SPECIAL_TOKENS_KATS = [
+    ([("<｜begin▁of▁sentence｜>", False, False)], "<｜begin▁of▁sentence｜> the user's <</SYS>>",
+     ("<｜begin▁of▁sentence｜>", " the user's <</SYS>>"), [1, 0]),
+    ([("<｜begin▁of▁sentence｜>", False, True)], "<｜begin▁of▁sentence｜>   the user's <</SYS>>",
+     ("<｜begin▁of▁sentence｜>", "the user's <</SYS>>"), [1, 0]),
+    ([("<|eot_id|>", True, False)], "    the user's <</SYS>>    <|eot_id|>", ("    the user's <</SYS>>", "<|eot_id|>"), [0, 1]),
+    ([("    ", False, False)], "    def", ("    ", "def"), [1, 0]),
+    ([("    ", False, False)], "    def  ", ("    ", "def  "), [1, 0]),
+    ([("    ", False, False)], "    def    ", ("    ", "def", "    "), [1, 0, 1]),
+    ([("def", True, False)], "_    def  _", ("_", "def", "  _"), [0, 1, 0]),
+    ([("def", False, True)], "_    def  _", ("_    ", "def", "_"), [0, 1, 0]),
+    ([("def", True, True)], "_    def  _def", ("_", "def", "_", "def"), [0, 1, 0, 1]),
+    ([("def", True, True)], "def_    def  _def", ("def", "_", "def", "_", "def"), [1, 0, 1, 0, 1]),
+    ([("def", True, True)], "defdef_    def  _def", ("def", "def", "_", "def", "_", "def"), [1, 1, 0, 1, 0, 1]),
+]

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.golden.reference_kats import RAGGED_TO_DENSE_KATS, REGEX_SPLIT_KATS
+from tests.golden.reference_kats import RAGGED_TO_DENSE_KATS, REGEX_SPLIT_KATS, SPECIAL_TOKENS_KATS
 from tests.util import one_string_per_row
 
 
@@ -26,3 +26,10 @@ def test_ragged_to_dense_kat(inp, attr_pad_right, input_pad_right, expected):
     for r, n in enumerate(lens):
         row = mask[r]
         assert row.sum() == n and (row[:n].all() if pad_right else row[len(row) - n:].all())
+
+
+@pytest.mark.parametrize("tokens, text, expected, expected_skips", SPECIAL_TOKENS_KATS)
+def test_special_tokens_split_kat(tokens, text, expected, expected_skips):
+    out = O.SpecialTokensSplit(O.special_tokens_pattern(tokens))(*one_string_per_row([text]))
+    got = tuple(s.decode("utf-8") for s in O.unpack_strings(out[2], out[3], out[4]))
+    assert got == expected and out[5].tolist() == expected_skips
