@@ -245,6 +245,37 @@ int ovtk_fuze_ragged(const int32_t* ragged_begins, const int32_t* ragged_ends, i
                      const int32_t* begins, const int32_t* ends, int64_t n, int32_t* out_begins,
                      int32_t* out_ends, int mem, int device, void* stream);
 
+/* ---------------------------------------------------------------- UTF8Validate
+ * Replaces UTF8Validate::evaluate, src/utf8_validate.cpp:18-143.  replace_mode 0: drop invalid bytes, 1: U+FFFD.
+ * out->begins/ends: [in->n]; out->chars capacity: the reference allocates 3 * in->n_chars (:31-33).  Offsets start
+ * at in->begins[0] like the reference's (:46); out->n_chars = last offset (bytes before begins[0] are not written). */
+int ovtk_utf8_validate(const ovtk_strings* in, int replace_mode, ovtk_strings_out* out, int mem, int device,
+                       void* stream);
+
+/* ---------------------------------------------------------------- Truncate / CombineSegments
+ * ovtk_truncate replaces Truncate::evaluate, src/truncate.cpp:37-150 (the reference edits begins/ends in place; here
+ * out_* may alias the inputs).  n_inputs 1: begins1/ends1/out_*1 and mode are ignored.  side: "left"|"right";
+ * mode: "only_first"|"only_second"|"longest_first". */
+int ovtk_truncate(int n_inputs, const int32_t* begins0, const int32_t* ends0, const int32_t* begins1,
+                  const int32_t* ends1, int64_t n, int32_t max_length, const char* side, const char* mode,
+                  int32_t* out_begins0, int32_t* out_ends0, int32_t* out_begins1, int32_t* out_ends1, int mem,
+                  int device, void* stream);
+
+/* ovtk_combine_segments replaces CombineSegments::evaluate, src/combine_segments.cpp:36-134, for i32 elements (token
+ * ids, the only element type tokenizer_pipeline.py builds it with).  segs[j]: begins/ends [n], data [n_data]; n == 1
+ * is broadcast over the rows.  segment_ids: i32[n_segs] in HOST memory (the op's last input).
+ * out_begins/out_ends: [max n]; out_data/out_ids: capacity out_capacity, *n_out elements written. */
+typedef struct {
+    const int32_t* begins;
+    const int32_t* ends;
+    const int32_t* data;
+    int64_t n;
+    int64_t n_data;
+} ovtk_ragged_i32;
+int ovtk_combine_segments(const ovtk_ragged_i32* segs, int n_segs, const int32_t* segment_ids, int32_t* out_begins,
+                          int32_t* out_ends, int32_t* out_data, int32_t* out_ids, int64_t out_capacity,
+                          int64_t* n_out, int mem, int device, void* stream);
+
 /* Fused VocabDecoder -> [ByteFallback] -> FuzeRagged (tokenizer_pipeline.py:1321-1371): one string per row. */
 int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len,
                         const int32_t* skip_tokens_input, int64_t n_skip_tokens_input, int byte_fallback,

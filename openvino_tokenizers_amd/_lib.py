@@ -74,6 +74,11 @@ class StringsOut(C.Structure):
                 ("n_chars", C.c_int64)]
 
 
+class RaggedI32(C.Structure):
+    _fields_ = [("begins", C.c_void_p), ("ends", C.c_void_p), ("data", C.c_void_p), ("n", C.c_int64),
+                ("n_data", C.c_int64)]
+
+
 EXPORTS = [
     "ovtk_last_error", "ovtk_abi_version", "ovtk_device_name",
     "ovtk_regex_split_create", "ovtk_regex_split_run", "ovtk_regex_split_destroy",
@@ -84,6 +89,7 @@ EXPORTS = [
     "ovtk_ragged_to_dense",
     "ovtk_vocab_decoder_create", "ovtk_vocab_decoder_run", "ovtk_vocab_decoder_destroy",
     "ovtk_byte_fallback", "ovtk_fuze_ragged", "ovtk_detokenize_run",
+    "ovtk_utf8_validate", "ovtk_truncate", "ovtk_combine_segments",
     "ovtk_profile_enable", "ovtk_profile_reset", "ovtk_profile_get", "ovtk_profile_dump",
 ]
 

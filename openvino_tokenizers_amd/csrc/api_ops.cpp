@@ -615,4 +615,169 @@ int ovtk_fuze_ragged(const int32_t* ragged_begins, const int32_t* ragged_ends, i
     return OVTK_OK;
 }
 
+// ------------------------------------------------------------------------------- UTF8Validate
+int ovtk_utf8_validate(const ovtk_strings* in, int replace_mode, ovtk_strings_out* out, int mem, int device, void* stream) {
+    if (int rc = check_strings_arg(in, "utf8_validate input")) return rc;
+    if (!out || out->chars_capacity < 0) return set_error(OVTK_E_ARG, "utf8_validate: bad output");
+    if (int rc = use_device(device)) return rc;
+    out->n_chars = 0;
+    if (in->n == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    const int32_t *b = nullptr, *e = nullptr;
+    const uint8_t* c = nullptr;
+    if (int rc = in_source(ws->in_begins, in->begins, size_t(in->n) * 4, mem, s, &b)) return rc;
+    if (int rc = in_source(ws->in_ends, in->ends, size_t(in->n) * 4, mem, s, &e)) return rc;
+    if (int rc = in_source(ws->in_chars, in->chars, size_t(in->n_chars), mem, s, &c)) return rc;
+    int32_t base = 0;  // begins[0]
+    if (mem == OVTK_MEM_HOST) base = in->begins[0];
+    else {
+        OVTK_HIP(hipMemcpyAsync(&base, b, 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipStreamSynchronize(s));
+    }
+    if (base < 0 || base > in->n_chars) return set_error(OVTK_E_RANGE, "input begins/ends index outside the chars tensor");
+    int32_t *d_b = nullptr, *d_e = nullptr;
+    uint8_t* d_c = nullptr;
+    if (int rc = out_target(ws->out_c, out->begins, size_t(in->n) * 4, mem, &d_b)) return rc;
+    if (int rc = out_target(ws->out_d, out->ends, size_t(in->n) * 4, mem, &d_e)) return rc;
+    if (int rc = out_target(ws->out_e, out->chars, size_t(out->chars_capacity), mem, &d_c)) return rc;
+    OVTK_LAUNCH(ws->marks, "check_strings", check_strings_kernel, grid_for_elems(in->n), kBlockThreads, s, b, e,
+                (long long)in->n, (long long)in->n_chars, st);
+    const long long cap = std::min<long long>(out->chars_capacity, INT32_MAX - 1) - base;
+    if (int rc = scan_and_apply(*ws.ws, s, in->n, Utf8Len{b, e, c, (long long)in->n_chars, replace_mode != 0},
+                                Utf8Apply{b, e, c, d_b, d_e, d_c, (long long)base, replace_mode != 0}, cap, st, "utf8_validate"))
+        return rc;
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside the chars tensor");
+    if (ws->host_status->flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "UTF8Validate: output chars buffer too small");
+    out->n_chars = base + ws->host_status->n_out;
+    int err = 0;
+    err = err ? err : copy_back(out->begins, d_b, size_t(in->n) * 4, mem, s);
+    err = err ? err : copy_back(out->ends, d_e, size_t(in->n) * 4, mem, s);
+    err = err ? err : copy_back(out->chars, d_c, size_t(out->n_chars), mem, s);
+    if (err) return err;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- Truncate
+int ovtk_truncate(int n_inputs, const int32_t* begins0, const int32_t* ends0, const int32_t* begins1, const int32_t* ends1,
+                  int64_t n, int32_t max_length, const char* side, const char* mode, int32_t* out_begins0,
+                  int32_t* out_ends0, int32_t* out_begins1, int32_t* out_ends1, int mem, int device, void* stream) {
+    if (n_inputs != 1 && n_inputs != 2)
+        return set_error(OVTK_E_ARG, "Only single or pair inputs are supported in Truncation op");  // truncate.cpp:147
+    if (n < 0 || n >= INT32_MAX || !side) return set_error(OVTK_E_ARG, "truncate: bad size");
+    const std::string sd(side), md(mode ? mode : "");
+    if (sd != "left" && sd != "right") return set_error(OVTK_E_ARG, "Unknown truncation side: " + sd);
+    int m = 2;
+    if (n_inputs == 2) {
+        if (md == "only_first") m = 0;
+        else if (md == "only_second") m = 1;
+        else if (md == "longest_first") m = 2;
+        else return set_error(OVTK_E_ARG, "Unknown truncation mode: " + md);  // truncate.cpp:129
+    }
+    if (int rc = use_device(device)) return rc;
+    if (n == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    TruncateArgs a{};
+    a.n = n; a.max_length = max_length; a.left = sd == "left"; a.mode = m;
+    const size_t bytes = size_t(n) * 4;
+    if (int rc = in_source(ws->in_begins, begins0, bytes, mem, s, &a.b0)) return rc;
+    if (int rc = in_source(ws->in_ends, ends0, bytes, mem, s, &a.e0)) return rc;
+    if (int rc = out_target(ws->out_a, out_begins0, bytes, mem, &a.ob0)) return rc;
+    if (int rc = out_target(ws->out_b, out_ends0, bytes, mem, &a.oe0)) return rc;
+    if (n_inputs == 2) {
+        if (int rc = in_source(ws->in_rb, begins1, bytes, mem, s, &a.b1)) return rc;
+        if (int rc = in_source(ws->in_re, ends1, bytes, mem, s, &a.e1)) return rc;
+        if (int rc = out_target(ws->out_c, out_begins1, bytes, mem, &a.ob1)) return rc;
+        if (int rc = out_target(ws->out_d, out_ends1, bytes, mem, &a.oe1)) return rc;
+    }
+    OVTK_LAUNCH(ws->marks, "truncate", truncate_kernel, grid_for_elems(n), kBlockThreads, s, a);
+    int err = 0;
+    err = err ? err : copy_back(out_begins0, a.ob0, bytes, mem, s);
+    err = err ? err : copy_back(out_ends0, a.oe0, bytes, mem, s);
+    if (n_inputs == 2) {
+        err = err ? err : copy_back(out_begins1, a.ob1, bytes, mem, s);
+        err = err ? err : copy_back(out_ends1, a.oe1, bytes, mem, s);
+    }
+    if (err) return err;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    Profiler::get().resolve(ws->marks);  // empty unless profiling (then it waits for the kernel)
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- CombineSegments
+int ovtk_combine_segments(const ovtk_ragged_i32* segs, int n_segs, const int32_t* segment_ids, int32_t* out_begins,
+                          int32_t* out_ends, int32_t* out_data, int32_t* out_ids, int64_t out_capacity, int64_t* n_out,
+                          int mem, int device, void* stream) {
+    if (!segs || !segment_ids || !n_out || n_segs < 1 || out_capacity < 0) return set_error(OVTK_E_ARG, "combine_segments: bad arguments");
+    if (n_segs > kMaxSegments) return set_error(OVTK_E_UNSUPPORTED, "combine_segments: more than 16 inputs");
+    int64_t rows = 0;
+    for (int j = 0; j < n_segs; ++j) {
+        if (segs[j].n < 0 || segs[j].n_data < 0 || segs[j].n >= INT32_MAX || segs[j].n_data >= INT32_MAX)
+            return set_error(OVTK_E_ARG, "combine_segments: bad size");
+        rows = std::max(rows, segs[j].n);
+    }
+    for (int j = 0; j < n_segs; ++j)  // combine_segments.cpp:110-116 indexes row i of every non-scalar input
+        if (segs[j].n != 1 && segs[j].n != rows)
+            return set_error(OVTK_E_ARG, "combine_segments: inputs must have one row or the common number of rows");
+    if (int rc = use_device(device)) return rc;
+    *n_out = 0;
+    if (rows == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    CombineDev d{};
+    d.n_segs = n_segs;
+    if (mem == OVTK_MEM_HOST) {  // one staging buffer for all segments
+        size_t total = 0;
+        for (int j = 0; j < n_segs; ++j) total += (size_t(segs[j].n) * 2 + size_t(segs[j].n_data)) * 4;
+        if (int rc = ws->in_chars.ensure(total)) return rc;
+    }
+    size_t cur = 0;
+    auto place = [&](const int32_t* src, int64_t count, const int32_t** dst) -> int {
+        if (mem != OVTK_MEM_HOST) { *dst = src; return OVTK_OK; }
+        int32_t* p = reinterpret_cast<int32_t*>(ws->in_chars.as<uint8_t>() + cur);
+        if (count) OVTK_HIP(hipMemcpyAsync(p, src, size_t(count) * 4, hipMemcpyHostToDevice, s));
+        cur += size_t(count) * 4;
+        *dst = p;
+        return OVTK_OK;
+    };
+    for (int j = 0; j < n_segs; ++j) {
+        if (int rc = place(segs[j].begins, segs[j].n, &d.begins[j])) return rc;
+        if (int rc = place(segs[j].ends, segs[j].n, &d.ends[j])) return rc;
+        if (int rc = place(segs[j].data, segs[j].n_data, &d.data[j])) return rc;
+        d.n_rows[j] = int32_t(segs[j].n);
+        d.n_data[j] = int32_t(segs[j].n_data);
+        d.ids[j] = segment_ids[j];
+    }
+    int32_t *d_b = nullptr, *d_e = nullptr, *d_d = nullptr, *d_i = nullptr;
+    if (int rc = out_target(ws->out_a, out_begins, size_t(rows) * 4, mem, &d_b)) return rc;
+    if (int rc = out_target(ws->out_b, out_ends, size_t(rows) * 4, mem, &d_e)) return rc;
+    if (int rc = out_target(ws->out_c, out_data, size_t(out_capacity) * 4, mem, &d_d)) return rc;
+    if (int rc = out_target(ws->out_d, out_ids, size_t(out_capacity) * 4, mem, &d_i)) return rc;
+    if (int rc = scan_and_apply(*ws.ws, s, rows, CombineLen{d, st}, CombineApply{d_b, d_e},
+                                (long long)std::min<int64_t>(out_capacity, INT32_MAX - 1), st, "combine_rows"))
+        return rc;
+    const int grid = int(std::min<long long>((rows + kWavesPerBlock - 1) / kWavesPerBlock, (long long)device_cu_count(device) * 8));
+    OVTK_LAUNCH(ws->marks, "combine_segments", combine_copy_kernel, grid, kBlockThreads, s, d, (long long)rows,
+                (const int32_t*)d_b, d_d, d_i, (const RunStatus*)st);
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "combine_segments: a row reads past its data tensor");
+    if (ws->host_status->flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "combine_segments: output buffer too small");
+    *n_out = ws->host_status->n_out;
+    int err = 0;
+    err = err ? err : copy_back(out_begins, d_b, size_t(rows) * 4, mem, s);
+    err = err ? err : copy_back(out_ends, d_e, size_t(rows) * 4, mem, s);
+    err = err ? err : copy_back(out_data, d_d, size_t(*n_out) * 4, mem, s);
+    err = err ? err : copy_back(out_ids, d_i, size_t(*n_out) * 4, mem, s);
+    if (err) return err;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
 }  // extern "C"

@@ -509,4 +509,185 @@ static __global__ __launch_bounds__(kBlockThreads) void fuze_kernel(const int32_
     }
 }
 
+// ------------------------------------------------------------------------------- UTF8Validate
+// src/utf8_validate.cpp:18-143 walked symbol by symbol instead of byte by byte: a lead byte promises `need`
+// continuation bytes; when one is missing (or the string ends) the symbol is replaced once and the offending byte
+// is read again as a lead (:93-104, :134-137); a complete but overlong symbol is replaced once per byte (:111-121).
+// sink.copy(j, k): k input bytes from offset j are kept; sink.bad(times): `times` U+FFFD (replace mode only).
+template <class Sink>
+__device__ __forceinline__ void utf8_walk(const uint8_t* s, int len, Sink& sink) {
+    int j = 0;
+    while (j < len) {
+        const uint32_t c = s[j];
+        if (c < 0x80) { sink.copy(j, 1); ++j; continue; }
+        const int need = (c >> 5) == 0x6 ? 1 : (c >> 4) == 0xE ? 2 : (c >> 3) == 0x1E ? 3 : 0;
+        if (need == 0) { sink.bad(1); ++j; continue; }
+        uint32_t cp = c & (0x3Fu >> need);
+        int t = 1;
+        for (; t <= need && j + t < len && (s[j + t] >> 6) == 0x2; ++t) cp = (cp << 6) | (s[j + t] & 0x3Fu);
+        if (t <= need) { sink.bad(1); j += t; continue; }
+        const uint32_t min_cp = need == 1 ? 0x80u : need == 2 ? 0x800u : 0x10000u;
+        if (cp < min_cp) sink.bad(need + 1); else sink.copy(j, need + 1);
+        j += need + 1;
+    }
+}
+
+struct Utf8Count {
+    long long n = 0;
+    int replace;
+    __device__ void copy(int, int k) { n += k; }
+    __device__ void bad(int times) { n += replace ? 3 * times : 0; }
+};
+struct Utf8Write {
+    const uint8_t* src;
+    uint8_t* dst;
+    int replace;
+    __device__ void copy(int j, int k) {
+        for (int t = 0; t < k; ++t) dst[t] = src[j + t];
+        dst += k;
+    }
+    __device__ void bad(int times) {
+        if (!replace) return;
+        for (int t = 0; t < times; ++t) { dst[0] = 0xEF; dst[1] = 0xBF; dst[2] = 0xBD; dst += 3; }
+    }
+};
+
+struct Utf8Len {
+    const int32_t* begins;
+    const int32_t* ends;
+    const uint8_t* chars;
+    long long n_chars;
+    int replace;
+    __device__ long long operator()(long long i) const {
+        const long long b = begins[i], e = ends[i];
+        if (b < 0 || e < b || e > n_chars) return 0;  // flagged by check_strings_kernel
+        Utf8Count sink{0, replace};
+        utf8_walk(chars + b, int(e - b), sink);
+        return sink.n;
+    }
+};
+struct Utf8Apply {
+    const int32_t* begins;
+    const int32_t* ends;
+    const uint8_t* chars;
+    int32_t* out_begins;
+    int32_t* out_ends;
+    uint8_t* out_chars;
+    long long base;  // begins[0]: the reference's offsets start there (:46)
+    int replace;
+    __device__ void operator()(long long i, long long off, long long len) const {
+        out_begins[i] = int32_t(base + off);
+        out_ends[i] = int32_t(base + off + len);
+        if (len == 0) return;
+        Utf8Write sink{chars + begins[i], out_chars + base + off, replace};
+        utf8_walk(chars + begins[i], ends[i] - begins[i], sink);
+    }
+};
+
+// ------------------------------------------------------------------------------- Truncate
+// src/truncate.cpp:37-150, one lane per row.  side: 0 right / 1 left; mode: 0 only_first, 1 only_second,
+// 2 longest_first.  b1/e1 == nullptr -> single input (:42-60).
+struct TruncateArgs {
+    const int32_t *b0, *e0, *b1, *e1;
+    int32_t *ob0, *oe0, *ob1, *oe1;
+    long long n;
+    int32_t max_length;
+    int left, mode;
+};
+
+static __global__ __launch_bounds__(kBlockThreads) void truncate_kernel(TruncateArgs a) {
+    const long long stride = (long long)gridDim.x * kBlockThreads;
+    for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < a.n; i += stride) {
+        int32_t fb = a.b0[i], fe = a.e0[i];
+        if (!a.b1) {
+            const int32_t len = fe - fb, t = len < a.max_length ? len : a.max_length;
+            if (a.left) fb = fe - t; else fe = fb + t;
+            a.ob0[i] = fb;
+            a.oe0[i] = fe;
+            continue;
+        }
+        int32_t sb = a.b1[i], se = a.e1[i];
+        const int32_t fl = fe - fb, sl = se - sb, m = a.max_length;
+        int32_t keep_f = fl, keep_s = sl;  // lengths kept
+        if (fl + sl > m) {
+            const int32_t half = m / 2, half_up = m / 2 + m % 2;
+            if (a.mode == 0) keep_f = fl > m ? m : fl;
+            else if (a.mode == 1) keep_s = sl > m ? m : sl;
+            else if (fl >= half_up && sl <= half) keep_f = m - sl;
+            else if (fl < half_up && sl > half) keep_s = m - fl;
+            else {
+                keep_f = half + (m % 2) * (fl >= sl);
+                keep_s = half + (m % 2) * (fl < sl);
+            }
+        }
+        if (a.left) { fb = fe - keep_f; sb = se - keep_s; } else { fe = fb + keep_f; se = sb + keep_s; }
+        a.ob0[i] = fb; a.oe0[i] = fe;
+        a.ob1[i] = sb; a.oe1[i] = se;
+    }
+}
+
+// ------------------------------------------------------------------------------- CombineSegments
+// src/combine_segments.cpp:36-134: row i of the result is the concatenation of row i of every input
+// (a one-row input is broadcast, :110-116) with a parallel tensor naming the source input.  The
+// reference's running `flat_out_size` becomes a device scan of the row totals; then one wave copies
+// a row, segment after segment, lanes on consecutive elements (coalesced both sides).
+constexpr int kMaxSegments = 16;
+struct CombineDev {
+    const int32_t* begins[kMaxSegments];
+    const int32_t* ends[kMaxSegments];
+    const int32_t* data[kMaxSegments];
+    int32_t n_rows[kMaxSegments];
+    int32_t n_data[kMaxSegments];
+    int32_t ids[kMaxSegments];
+    int n_segs;
+};
+
+struct CombineLen {
+    CombineDev d;
+    RunStatus* status;
+    __device__ long long operator()(long long i) const {
+        long long tot = 0;
+        for (int j = 0; j < d.n_segs; ++j) {
+            const long long r = d.n_rows[j] == 1 ? 0 : i;
+            const int32_t b = d.begins[j][r], e = d.ends[j][r];
+            if (b < 0 || e < b || e > d.n_data[j]) {
+                atomicOr(&status->flags, kFlagRange);
+                continue;
+            }
+            tot += e - b;
+        }
+        return tot;
+    }
+};
+struct CombineApply {
+    int32_t* out_begins;
+    int32_t* out_ends;
+    __device__ void operator()(long long i, long long off, long long len) const {
+        out_begins[i] = int32_t(off);
+        out_ends[i] = int32_t(off + len);
+    }
+};
+
+static __global__ __launch_bounds__(kBlockThreads) void combine_copy_kernel(CombineDev d, long long n_rows,
+                                                                            const int32_t* out_begins, int32_t* out_data,
+                                                                            int32_t* out_ids, const RunStatus* status) {
+    if (status->flags & (kFlagRange | kFlagOutCapacity)) return;
+    const int l = lane_id();
+    const long long stride = (long long)gridDim.x * kWavesPerBlock;
+    for (long long i = (long long)blockIdx.x * kWavesPerBlock + wave_in_block(); i < n_rows; i += stride) {
+        long long off = out_begins[i];
+        for (int j = 0; j < d.n_segs; ++j) {
+            const long long r = d.n_rows[j] == 1 ? 0 : i;
+            const int32_t b = d.begins[j][r], len = d.ends[j][r] - b;
+            const int32_t id = d.ids[j];
+            const int32_t* src = d.data[j] + b;
+            for (int32_t k = l; k < len; k += kWave) {
+                out_data[off + k] = src[k];
+                out_ids[off + k] = id;
+            }
+            off += len;
+        }
+    }
+}
+
 }  // namespace ovtk

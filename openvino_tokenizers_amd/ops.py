@@ -465,6 +465,28 @@ class ByteFallback(_Op):
         return [ob[:len(b)], oe[:len(b)], oc[:out.n_chars]]
 
 
+class UTF8Validate(_Op):
+    """Reference: src/utf8_validate.cpp (evaluate :18-143).  Strings (3) -> strings (3); attribute replace_mode."""
+
+    def __init__(self, replace_mode=False, device=0, lib=None):
+        super().__init__(device, lib)
+        self.replace_mode = bool(replace_mode)
+
+    def evaluate(self, inputs):
+        m = _Mem(inputs[2])
+        b, pb = m.inp(inputs[0], "i32")
+        e, pe = m.inp(inputs[1], "i32")
+        c, pc = m.inp(inputs[2], "u8")
+        ob, pob = m.alloc(len(b), "i32")
+        oe, poe = m.alloc(len(b), "i32")
+        cap = 3 * len(c)  # utf8_validate.cpp:31-33
+        oc, poc = m.alloc(cap, "u8")
+        s = L.Strings(pb, pe, pc, len(b), len(c))
+        out = L.StringsOut(pob, poe, poc, cap, 0)
+        self._chk(self._lib.ovtk_utf8_validate(C.byref(s), int(self.replace_mode), C.byref(out), m.mem, self.device, m.stream))
+        return [ob[:len(b)], oe[:len(b)], oc[:out.n_chars]]
+
+
 class FuzeRagged(_Op):
     """Reference: src/fuze.cpp (evaluate :20-40).  ragged_begins, ragged_ends, begins, ends -> begins, ends."""
 
@@ -479,6 +501,66 @@ class FuzeRagged(_Op):
         self._chk(self._lib.ovtk_fuze_ragged(prb, pre, C.c_int64(len(rb)), pb, pe, C.c_int64(len(b)), pob, poe, m.mem,
                                              self.device, m.stream))
         return [ob[:len(rb)], oe[:len(rb)]]
+
+
+class Truncate(_Op):
+    """Reference: src/truncate.cpp (evaluate :37-150).  Inputs: (begins, ends, data) x 1 or 2, max_length,
+    trunc_side, [trunc_mode].  Outputs: (begins, ends, data) per input; data is the input tensor."""
+
+    def evaluate(self, inputs):
+        k = 1 if len(inputs) < 8 else 2
+        max_length = int(np.asarray(_host(inputs[3 * k], np.int32)).reshape(-1)[0])
+        side = _bytes_of(inputs[3 * k + 1])
+        mode = _bytes_of(inputs[3 * k + 2]) if len(inputs) > 3 * k + 2 else b"longest_first"
+        m = _Mem(inputs[0])
+        n = len(inputs[0])
+        ins, outs = [], []
+        for j in range(2):
+            if j < k:
+                ins += [m.inp(inputs[3 * j], "i32")[1], m.inp(inputs[3 * j + 1], "i32")[1]]
+                outs += [m.alloc(n, "i32"), m.alloc(n, "i32")]
+            else:
+                ins += [None, None]
+                outs += [(None, None), (None, None)]
+        self._chk(self._lib.ovtk_truncate(k, ins[0], ins[1], ins[2], ins[3], C.c_int64(n), C.c_int32(max_length), side,
+                                          mode, outs[0][1], outs[1][1], outs[2][1], outs[3][1], m.mem, self.device,
+                                          m.stream))
+        res = []
+        for j in range(k):
+            res += [outs[2 * j][0][:n], outs[2 * j + 1][0][:n], inputs[3 * j + 2]]
+        return res
+
+
+class CombineSegments(_Op):
+    """Reference: src/combine_segments.cpp (evaluate :36-134).  Inputs: (begins, ends, data) x k, segment_ids[k].
+    Outputs: begins, ends, data, begins, ends, segment ids (the two ragged outputs share their offsets)."""
+
+    def evaluate(self, inputs, capacity=None):
+        k = (len(inputs) - 1) // 3
+        ids = _host(inputs[-1], np.int32).reshape(-1)
+        if len(ids) != k or (len(inputs) - 1) % 3:
+            raise L.OvtkError(L.E_ARG, "CombineSegments: expected 3*k + 1 inputs with k segment ids")
+        m = _Mem(inputs[2])
+        segs = (L.RaggedI32 * k)()
+        rows = 0
+        bound = 0
+        for j in range(k):
+            b, pb = m.inp(np.atleast_1d(inputs[3 * j]) if not _is_torch(inputs[3 * j]) else inputs[3 * j].reshape(-1), "i32")
+            e, pe = m.inp(np.atleast_1d(inputs[3 * j + 1]) if not _is_torch(inputs[3 * j + 1]) else inputs[3 * j + 1].reshape(-1), "i32")
+            d, pd = m.inp(inputs[3 * j + 2], "i32")
+            segs[j] = L.RaggedI32(pb, pe, pd, len(b), len(d))
+            rows = max(rows, len(b))
+        for j in range(k):
+            bound += int(segs[j].n_data) * (rows if segs[j].n == 1 else 1)
+        cap = int(capacity) if capacity is not None else bound
+        ob, pob = m.alloc(rows, "i32")
+        oe, poe = m.alloc(rows, "i32")
+        od, pod = m.alloc(cap, "i32")
+        oi, poi = m.alloc(cap, "i32")
+        n_out = C.c_int64(0)
+        self._chk(self._lib.ovtk_combine_segments(segs, k, ids.ctypes.data_as(C.c_void_p), pob, poe, pod, poi,
+                                                  C.c_int64(cap), C.byref(n_out), m.mem, self.device, m.stream))
+        return [ob[:rows], oe[:rows], od[:n_out.value], ob[:rows], oe[:rows], oi[:n_out.value]]
 
 
 class FusedDetokenizer:

@@ -729,6 +729,123 @@ extern "C" int orc_ragged_to_dense(const int32_t* begins, const int32_t* ends, i
 }
 
 // =======================================================================================
+// UTF8Validate : src/utf8_validate.cpp:18-143.  A byte-at-a-time automaton: `pending` continuation bytes
+// are still owed to a symbol of `width` bytes whose code point is being assembled in `cp`.
+// Output offsets start at begins[0] like the reference's `out_idx` (:46).
+// =======================================================================================
+extern "C" int orc_utf8_validate(const int32_t* begins, const int32_t* ends, const uint8_t* chars, int64_t n,
+                                 int replace_mode, int32_t* out_begins, int32_t* out_ends, uint8_t* out_chars,
+                                 int64_t cap, int64_t* n_chars_out) {
+    static const uint8_t kRepl[3] = {0xEF, 0xBF, 0xBD};
+    static const uint32_t kMinCp[4] = {0x0, 0x80, 0x800, 0x10000};
+    int64_t o = n ? begins[0] : 0;
+    const int64_t o0 = o;
+    bool overflow = false;
+    auto put = [&](const uint8_t* src, int k) {
+        if (o + k > cap) { overflow = true; return; }
+        std::memcpy(out_chars + o, src, size_t(k));
+        o += k;
+    };
+    auto bad = [&](int times) { if (replace_mode) for (int t = 0; t < times; ++t) put(kRepl, 3); };
+    for (int64_t i = 0; i < n; ++i) {
+        uint32_t pending = 0, width = 0, cp = 0;
+        out_begins[i] = int32_t(o);
+        for (int64_t j = begins[i]; j < ends[i]; ++j) {
+            const uint8_t c = chars[j];
+            if (pending == 0) {
+                if (c < 0x80) put(&c, 1);
+                else if ((c >> 5) == 0x6) { width = 2; pending = 1; cp = uint32_t(c & 0x1F) << 6; }
+                else if ((c >> 4) == 0xE) { width = 3; pending = 2; cp = uint32_t(c & 0x0F) << 12; }
+                else if ((c >> 3) == 0x1E) { width = 4; pending = 3; cp = uint32_t(c & 0x07) << 18; }
+                else bad(1);
+                continue;
+            }
+            if ((c >> 6) != 0x2) {  // not a continuation: the symbol is broken, this byte starts over (:93-104)
+                pending = 0;
+                bad(1);
+                --j;
+                continue;
+            }
+            --pending;
+            cp |= uint32_t(c & 0x3F) << (6 * pending);
+            if (pending) continue;
+            if (cp < kMinCp[width - 1]) bad(int(width));  // overlong form: one replacement per byte (:111-121)
+            else put(chars + j + 1 - width, int(width));
+        }
+        if (pending) bad(1);  // unfinished symbol at the end of the string (:134-137)
+        out_ends[i] = int32_t(o);
+        if (overflow) return fail(ORC_E_CAPACITY, "utf8_validate: output overflow");
+    }
+    *n_chars_out = o - o0;
+    return ORC_OK;
+}
+
+// =======================================================================================
+// Truncate : src/truncate.cpp:37-150 (begins/ends are modified in place there; here in/out arrays)
+// =======================================================================================
+extern "C" int orc_truncate(int n_inputs, int32_t* b0, int32_t* e0, int32_t* b1, int32_t* e1, int64_t n,
+                            int32_t max_length, const char* side, const char* mode) {
+    const std::string trunc_side(side), trunc_mode(mode ? mode : "");
+    if (trunc_side != "left" && trunc_side != "right") return fail(ORC_E_ARG, "Unknown truncation side: " + trunc_side);
+    if (n_inputs == 1) {
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t t = std::min(e0[i] - b0[i], max_length);
+            if (trunc_side == "right") e0[i] = b0[i] + t; else b0[i] = e0[i] - t;
+        }
+        return ORC_OK;
+    }
+    if (n_inputs != 2) return fail(ORC_E_ARG, "Only single or pair inputs are supported in Truncation op");
+    if (trunc_mode != "only_first" && trunc_mode != "only_second" && trunc_mode != "longest_first")
+        return fail(ORC_E_ARG, "Unknown truncation mode: " + trunc_mode);
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t fl = e0[i] - b0[i], sl = e1[i] - b1[i];
+        if (fl + sl <= max_length) continue;
+        const int32_t fr = (max_length % 2) * (fl >= sl), sr = (max_length % 2) * (fl < sl);
+        const int32_t half = max_length / 2, half_up = max_length / 2 + max_length % 2;
+        if (trunc_side == "right") {
+            if (trunc_mode == "only_first") { if (fl > max_length) e0[i] = b0[i] + max_length; }
+            else if (trunc_mode == "only_second") { if (sl > max_length) e1[i] = b1[i] + max_length; }
+            else if (fl >= half_up && sl <= half) e0[i] = b0[i] + (max_length - sl);
+            else if (fl < half_up && sl > half) e1[i] = b1[i] + (max_length - fl);
+            else { e0[i] = b0[i] + half + fr; e1[i] = b1[i] + half + sr; }
+        } else {
+            if (trunc_mode == "only_first") { if (fl > max_length) b0[i] = e0[i] - max_length; }
+            else if (trunc_mode == "only_second") { if (sl > max_length) b1[i] = e1[i] - max_length; }
+            else if (fl >= half_up && sl <= half) b0[i] = e0[i] - (max_length - sl);
+            else if (fl < half_up && sl > half) b1[i] = e1[i] - (max_length - fl);
+            else { b0[i] = e0[i] - (half + fr); b1[i] = e1[i] - (half + sr); }
+        }
+    }
+    return ORC_OK;
+}
+
+// =======================================================================================
+// CombineSegments : src/combine_segments.cpp:36-134 (i32 elements and ids)
+// =======================================================================================
+extern "C" int orc_combine_segments(int n_segs, const int32_t* const* begins, const int32_t* const* ends,
+                                    const int32_t* const* data, const int64_t* n_rows, const int32_t* seg_ids,
+                                    int64_t max_rows, int32_t* out_begins, int32_t* out_ends, int32_t* out_data,
+                                    int32_t* out_ids, int64_t cap, int64_t* n_out) {
+    int64_t off = 0;
+    for (int64_t i = 0; i < max_rows; ++i) {
+        out_begins[i] = int32_t(off);
+        for (int j = 0; j < n_segs; ++j) {
+            const int64_t r = n_rows[j] == 1 ? 0 : i;  // a single-row segment is broadcast (:110-116)
+            const int32_t b = begins[j][r], len = ends[j][r] - b;
+            if (off + len > cap) return fail(ORC_E_CAPACITY, "combine_segments: output overflow");
+            for (int32_t k = 0; k < len; ++k) {
+                out_data[off + k] = data[j][b + k];
+                out_ids[off + k] = seg_ids[j];
+            }
+            off += len > 0 ? len : 0;
+        }
+        out_ends[i] = int32_t(off);
+    }
+    *n_out = off;
+    return ORC_OK;
+}
+
+// =======================================================================================
 // VocabDecoder / ByteFallback / FuzeRagged
 // =======================================================================================
 extern "C" int orc_vocab_decoder(const int32_t* ids, int64_t B, int64_t S,

@@ -112,6 +112,21 @@ int orc_ragged_to_dense(const int32_t* begins, const int32_t* ends, int64_t B,
                         int32_t target_dim, const void* default_value,
                         int pad_right, int pad_max_length, void* out_dense, uint8_t* out_mask);
 
+/* ---- UTF8Validate : src/utf8_validate.cpp:18-143.  out_chars capacity: the reference allocates 3 * n_chars (:31-33);
+ * offsets start at begins[0] (:46), *n_chars_out = last offset - begins[0] (:140). ---- */
+int orc_utf8_validate(const int32_t* begins, const int32_t* ends, const uint8_t* chars, int64_t n, int replace_mode,
+                      int32_t* out_begins, int32_t* out_ends, uint8_t* out_chars, int64_t cap, int64_t* n_chars_out);
+
+/* ---- Truncate : src/truncate.cpp:37-150 (in place, like the reference); n_inputs 1 or 2, mode NULL for 1 ---- */
+int orc_truncate(int n_inputs, int32_t* b0, int32_t* e0, int32_t* b1, int32_t* e1, int64_t n, int32_t max_length,
+                 const char* side, const char* mode);
+
+/* ---- CombineSegments : src/combine_segments.cpp:36-134 (i32 elements / ids; a 1-row segment is broadcast) ---- */
+int orc_combine_segments(int n_segs, const int32_t* const* begins, const int32_t* const* ends,
+                         const int32_t* const* data, const int64_t* n_rows, const int32_t* seg_ids, int64_t max_rows,
+                         int32_t* out_begins, int32_t* out_ends, int32_t* out_data, int32_t* out_ids, int64_t cap,
+                         int64_t* n_out);
+
 /* ---- VocabDecoder : src/vocab_decoder.cpp:23-87 ---- */
 int orc_vocab_decoder(const int32_t* ids, int64_t B, int64_t S,
                       const int32_t* v_begins, const int32_t* v_ends, const uint8_t* v_chars, int64_t V,

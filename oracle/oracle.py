@@ -327,6 +327,50 @@ def ragged_to_dense(begins, ends, data, target_dim, default, pad_right=True, pad
     return out, mask.astype(bool)
 
 
+# --------------------------------------------------------------------------- UTF8Validate
+def utf8_validate(begins, ends, chars, replace_mode):
+    (b, pb), (e, pe), (c, pc) = _i32(begins), _i32(ends), _u8(chars)
+    cap = 3 * len(c) + 3
+    ob, oe, oc = np.zeros(len(b), np.int32), np.zeros(len(b), np.int32), np.zeros(cap, np.uint8)
+    n = C.c_int64()
+    _chk(lib().orc_utf8_validate(pb, pe, pc, C.c_int64(len(b)),
+                                 int(bool(replace_mode)), ob.ctypes.data_as(i32p), oe.ctypes.data_as(i32p),
+                                 oc.ctypes.data_as(u8p), C.c_int64(cap), C.byref(n)))
+    first = int(b[0]) if len(b) else 0
+    return ob, oe, oc[:first + n.value].copy()
+
+
+# --------------------------------------------------------------------------- Truncate / CombineSegments
+def truncate(pairs, max_length, side="right", mode="longest_first"):
+    """pairs: [(begins, ends)] or [(b0, e0), (b1, e1)] -> list of truncated (begins, ends)."""
+    arrs = [(np.array(b, dtype=np.int32), np.array(e, dtype=np.int32)) for b, e in pairs]
+    n = len(arrs[0][0])
+    ptr = [a.ctypes.data_as(i32p) for pair in arrs for a in pair] + [None, None]
+    _chk(lib().orc_truncate(len(arrs), ptr[0], ptr[1], ptr[2], ptr[3], C.c_int64(n), C.c_int32(int(max_length)),
+                            side.encode(), mode.encode() if len(arrs) == 2 else None))
+    return arrs
+
+
+def combine_segments(segments, seg_ids):
+    """segments: list of (begins, ends, data) i32 -> (begins, ends, data, ids)."""
+    segs = [tuple(np.ascontiguousarray(x, dtype=np.int32) for x in s) for s in segments]
+    k = len(segs)
+    max_rows = max(len(s[0]) for s in segs)
+    cap = sum((max_rows if len(s[0]) == 1 else 1) * len(s[2]) for s in segs) + 1
+    PB = (i32p * k)(*[s[0].ctypes.data_as(i32p) for s in segs])
+    PE = (i32p * k)(*[s[1].ctypes.data_as(i32p) for s in segs])
+    PD = (i32p * k)(*[s[2].ctypes.data_as(i32p) for s in segs])
+    NR = (C.c_int64 * k)(*[len(s[0]) for s in segs])
+    ids = np.ascontiguousarray(seg_ids, dtype=np.int32)
+    ob, oe = np.zeros(max_rows, np.int32), np.zeros(max_rows, np.int32)
+    od, oi = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+    n = C.c_int64()
+    _chk(lib().orc_combine_segments(k, PB, PE, PD, NR, ids.ctypes.data_as(i32p), C.c_int64(max_rows),
+                                    ob.ctypes.data_as(i32p), oe.ctypes.data_as(i32p), od.ctypes.data_as(i32p),
+                                    oi.ctypes.data_as(i32p), C.c_int64(cap), C.byref(n)))
+    return ob, oe, od[:n.value].copy(), oi[:n.value].copy()
+
+
 # --------------------------------------------------------------------------- detokenize trio
 def vocab_decoder(ids, vocab, skip_tokens=()):
     ids = np.ascontiguousarray(ids, dtype=np.int32)

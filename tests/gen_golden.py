@@ -122,7 +122,36 @@ def main_llama3():
     print(name, len(strings), "strings", int(tl.sum()), "ids")
 
 
+def main_truncate():
+    """Pair truncation known answers from HF tokenizers (WordLevel vocabulary, no post-processor so max_length
+    counts only the two sequences): kept lengths for every (len_a, len_b, max_length, side), longest_first -- the mode
+    tokenizer_pipeline.py:955 always builds."""
+    from tokenizers import Tokenizer as T
+    from tokenizers.models import WordLevel
+    from tokenizers.pre_tokenizers import WhitespaceSplit
+    tok = T(WordLevel({"a": 0, "b": 1, "[UNK]": 2}, unk_token="[UNK]"))
+    tok.pre_tokenizer = WhitespaceSplit()
+    rows = []
+    for strategy in ("longest_first",):  # the reference's only_first / only_second deliberately differ from HF (truncate.cpp:92,97)
+        for side in ("right", "left"):
+            for max_length in (1, 2, 5, 8, 9):
+                tok.enable_truncation(max_length, strategy=strategy, direction=side)
+                for la in range(0, 13):
+                    for lb in range(0, 13):
+                        try:
+                            enc = tok.encode(" ".join(["a"] * la), " ".join(["b"] * lb))
+                        except Exception:  # HF refuses when the sequence to truncate cannot absorb the excess
+                            continue
+                        ka = sum(1 for s in enc.sequence_ids if s == 0)
+                        kb = sum(1 for s in enc.sequence_ids if s == 1)
+                        rows.append((["only_first", "only_second", "longest_first"].index(strategy), side == "left",
+                                     max_length, la, lb, ka, kb))
+    np.savez_compressed(G / "golden_truncate_hf.npz", rows=np.array(rows, np.int32))
+    print("truncate rows", len(rows))
+
+
 if __name__ == "__main__":
+    main_truncate()
     main()
     main_wordpiece()
     main_llama3()

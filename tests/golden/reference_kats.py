@@ -91,3 +91,42 @@ SPECIAL_TOKENS_KATS = [
     ([("def", True, True)], "def_    def  _def", ("def", "_", "def", "_", "def"), [1, 0, 1, 0, 1]),
     ([("def", True, True)], "defdef_    def  _def", ("def", "def", "_", "def", "_", "def"), [1, 1, 0, 1, 0, 1]),
 ]
+
+# tests/layer_tests.py:601-644 (CombineSegments): (segments, expected begins/ends/data); segment ids = arange(n)
+COMBINE_SEGMENTS_KATS = [
+    ([{"begins": [0, 2], "ends": [2, 5], "data": [10, 20, 30, 40, 50]}, {"begins": [0, 1], "ends": [1, 3], "data": [100, 200, 300]}],
+     {"begins": [0, 3], "ends": [3, 8], "data": [10, 20, 100, 30, 40, 50, 200, 300]}),
+    ([{"begins": [0, 2], "ends": [2, 5], "data": [10, 20, 30, 40, 50]}, {"begins": [0, 1], "ends": [1, 3], "data": [100, 200, 300]},
+      {"begins": [0, 2], "ends": [2, 3], "data": [1000, 2000, 3000]}],
+     {"begins": [0, 5], "ends": [5, 11], "data": [10, 20, 100, 1000, 2000, 30, 40, 50, 200, 300, 3000]}),
+]
+
+# tests/layer_tests.py:84-139 (UTF8Validate): expected = bytes.decode(errors="ignore" | "replace")
+UTF8_VALIDATE_KATS = [
+    b"Eng... test, string?!",
+    b"\xe2\x82\xac",
+    "Проверка, как работает кириллица Љ љ Ђ ђ".encode(),
+    "測試字符串".encode(),
+    "Tester, la chaîne...".encode(),
+    "سلسلة الاختبار".encode(),
+    "מחרוזת בדיקה".encode(),
+    "Сынақ жолы á".encode(),
+    "😁😁".encode(),
+    "🤣🤣🤣😁😁😁😁".encode(),
+    "🫠".encode(),
+    "介绍下清华大学".encode(),
+    "折纸的过程看似简单，其实想要做好，还是需要一套很复杂的工艺。以折一支玫瑰花为例，我们可以将整个折纸过程分成三个阶段，即：创建栅格折痕，制作立体基座，完成花瓣修饰。".encode(),
+    b"\x81First byte is invalid utf8",
+    b"\x80\x80\x80",
+    bytes([0b11000000, 0b11000000, 0b11000000]),
+    bytes([0b11110000, 0b10010011, 0b10000001, 0b11101000, 0b11110000, 0b10010011, 0b10000001, 0b10101000]),
+    bytes([0b11110000, 0b10011111, 0b10011000, 0b11000001, 0b11110000, 0b10011111, 0b10011000, 0b10000001]),
+    b"\xc0\x80",
+    b"\xe0\x81\x81",
+    b"\xf0\x80\x80\x80",
+    b"\xe2\x28\xa1",
+    b"the following block is invalid \xe2\x28\xa1 but this text is valid",
+    b"A\xc3\x28B",
+    b"\xe2\x82",
+    b"A\xc3\xa9\xe2\x82\xac\xf0\x90\x8d\x88",
+]

@@ -3,7 +3,8 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.golden.reference_kats import RAGGED_TO_DENSE_KATS, REGEX_SPLIT_KATS, SPECIAL_TOKENS_KATS
+from tests.golden.reference_kats import (COMBINE_SEGMENTS_KATS, RAGGED_TO_DENSE_KATS, REGEX_SPLIT_KATS,
+                                         SPECIAL_TOKENS_KATS, UTF8_VALIDATE_KATS)
 from tests.util import one_string_per_row
 
 
@@ -33,3 +34,19 @@ def test_special_tokens_split_kat(tokens, text, expected, expected_skips):
     out = O.SpecialTokensSplit(O.special_tokens_pattern(tokens))(*one_string_per_row([text]))
     got = tuple(s.decode("utf-8") for s in O.unpack_strings(out[2], out[3], out[4]))
     assert got == expected and out[5].tolist() == expected_skips
+
+
+@pytest.mark.parametrize("segments, expected", COMBINE_SEGMENTS_KATS)
+def test_combine_segments_kat(segments, expected):
+    ob, oe, od, oi = O.combine_segments([(s["begins"], s["ends"], s["data"]) for s in segments], np.arange(len(segments)))
+    assert ob.tolist() == expected["begins"] and oe.tolist() == expected["ends"] and od.tolist() == expected["data"]
+
+
+@pytest.mark.parametrize("mode", ["ignore", "replace"])
+@pytest.mark.parametrize("raw", UTF8_VALIDATE_KATS)
+def test_utf8_validate_kat(raw, mode):
+    """tests/layer_tests.py:131-139: the op's output equals Python's bytes.decode(errors=mode)."""
+    b, e, c = O.pack_strings([raw, b"", raw])
+    ob, oe, oc = O.utf8_validate(b, e, c, mode == "replace")
+    want = raw.decode(errors=mode).encode()
+    assert O.unpack_strings(ob, oe, oc) == [want, b"", want]
