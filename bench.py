@@ -48,6 +48,30 @@ BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\
 PMC_FILE = ROOT / "profiles" / "latest_pmc.json"  # HBM traffic of the dominant kernels from a separate rocprofv3 --pmc run
 
 
+class IdOut:
+    """Four sets of ragged-id output buffers used in turn: with N > 1 up to three batches are with the exchange
+    (queued / gathering / unpacking -- a shard that outgrew the agreed pad is packed again) while the next is encoded."""
+
+    def __init__(self, rows, cap, dev):
+        self.sets = []
+        for _ in range(4):
+            b = torch.empty(rows, dtype=torch.int32, device=dev)
+            e = torch.empty(rows, dtype=torch.int32, device=dev)
+            ids = torch.empty(cap, dtype=torch.int32, device=dev)
+            self.sets.append((b, e, ids, L.RaggedI32Out(b.data_ptr(), e.data_ptr(), ids.data_ptr(), cap, 0, 0)))
+        self.k = 0
+        self.last = self.sets[0]
+
+    def take(self):
+        self.last = self.sets[self.k % 4]
+        self.k += 1
+        return self.last
+
+    @property
+    def n_data(self):
+        return self.last[3].n_data
+
+
 class Workload:
     """One BASELINE.json configuration: how to build the inputs, run a step, count units, and check/baseline it."""
     metric = "input MB/s encoded (GPT-2 BPE, 512-byte strings)"
@@ -67,15 +91,24 @@ def make_encode_bpe(args, lib, dev, rank):
     bpe._ensure(d + tok.consts)
     rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), args.rows,
                          L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), args.rows, n_chars))
-    o_begins = torch.empty(args.rows, dtype=torch.int32, device=dev)
-    o_ends = torch.empty(args.rows, dtype=torch.int32, device=dev)
-    o_ids = torch.empty(n_chars, dtype=torch.int32, device=dev)
-    out = L.RaggedI32Out(o_begins.data_ptr(), o_ends.data_ptr(), o_ids.data_ptr(), n_chars, 0, 0)
+    out = IdOut(args.rows, n_chars, dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def step():
-        L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(out), L.MEM_DEVICE, stream))
-        return o_begins, o_ends, o_ids[: out.n_data]
+        o_begins, o_ends, o_ids, o = out.take()
+        L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, stream))
+        return o_begins, o_ends, o_ids[: o.n_data]
+
+    def enqueue():
+        """The same step in two halves (ovtk_encode_enqueue / ovtk_encode_finish): -> finish() -> (begins, ends, ids)."""
+        o_begins, o_ends, o_ids, o = out.take()
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_encode_enqueue(split._h, bpe._h, C.byref(rs), None, C.byref(o), stream, C.byref(pending)))
+
+        def finish():
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
+            return o_begins, o_ends, o_ids[: o.n_data]
+        return finish
 
     def cpu(n_s):
         from oracle import oracle as O
@@ -88,7 +121,7 @@ def make_encode_bpe(args, lib, dev, rank):
     workload = (f"config 2: GPT-2-shaped byte-level BPE (V=50257, 50000 merges, trained in-process), {args.rows} x "
                 f"~{args.bytes}-byte {args.text} strings per GPU, fused RegexSplit+BPETokenizer, inputs and outputs in HBM"
                 + (", piece memo disabled (cache_capacity=0)" if args.no_memo else ""))
-    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe, o_begins, o_ends, o_ids), workload=workload,
+    return dict(step=step, enqueue=enqueue, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe), workload=workload, vocab=len(tok.vocab),
                 metric="input MB/s encoded (GPT-2 BPE, 512-byte strings)", dtype="u8/int32",
                 algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=min(args.rows, 32768))
 
@@ -113,18 +146,16 @@ def make_encode_llama3(args, lib, dev, rank):
     p_b = torch.empty(cap, dtype=torch.int32, device=dev)
     p_e = torch.empty(cap, dtype=torch.int32, device=dev)
     sp_out = L.RaggedStringsOut(p_rb.data_ptr(), p_re.data_ptr(), 0, p_b.data_ptr(), p_e.data_ptr(), None, cap, 0)
-    o_begins = torch.empty(rows, dtype=torch.int32, device=dev)
-    o_ends = torch.empty(rows, dtype=torch.int32, device=dev)
-    o_ids = torch.empty(n_chars, dtype=torch.int32, device=dev)
-    out = L.RaggedI32Out(o_begins.data_ptr(), o_ends.data_ptr(), o_ids.data_ptr(), n_chars, 0, 0)
+    out = IdOut(rows, n_chars, dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def step():
+        o_begins, o_ends, o_ids, o = out.take()
         L.check(lib, lib.ovtk_regex_split_run(split._h, C.byref(rs), None, C.byref(sp_out), L.MEM_DEVICE, stream))
         pieces = L.RaggedStrings(p_rb.data_ptr(), p_re.data_ptr(), rows,
                                  L.Strings(p_b.data_ptr(), p_e.data_ptr(), d[4].data_ptr(), sp_out.n, n_chars))
-        L.check(lib, lib.ovtk_bpe_run(bpe._h, C.byref(pieces), C.byref(out), L.MEM_DEVICE, stream))
-        return o_begins, o_ends, o_ids[: out.n_data]
+        L.check(lib, lib.ovtk_bpe_run(bpe._h, C.byref(pieces), C.byref(o), L.MEM_DEVICE, stream))
+        return o_begins, o_ends, o_ids[: o.n_data]
 
     def cpu(n_s):
         from oracle import oracle as O
@@ -137,7 +168,7 @@ def make_encode_llama3(args, lib, dev, rank):
     workload = (f"config 4 shard: Llama-3-shaped byte-level BPE (V=128256, 127999 merges, trained in-process), {rows} x "
                 f"~{args.bytes}-byte mixed-script strings per GPU, RegexSplit (tiktoken-style pattern) -> BPETokenizer, "
                 f"inputs and outputs in HBM")
-    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe, p_rb, p_re, p_b, p_e, o_begins, o_ends, o_ids),
+    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe, p_rb, p_re, p_b, p_e), vocab=len(tok.vocab),
                 workload=workload, metric="input MB/s encoded (Llama-3 BPE, 512-byte mixed-script strings)", dtype="u8/int32",
                 rows=rows, algo=lambda n_tok: n_chars + 4 * n_tok + 16 * rows, sample_rows=min(rows, 16384))
 
@@ -159,16 +190,14 @@ def make_encode_wordpiece(args, lib, dev, rank):
     wp._ensure(d + consts)
     rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), args.rows,
                          L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), args.rows, n_chars))
-    o_begins = torch.empty(args.rows, dtype=torch.int32, device=dev)
-    o_ends = torch.empty(args.rows, dtype=torch.int32, device=dev)
-    o_ids = torch.empty(n_chars, dtype=torch.int32, device=dev)
-    out = L.RaggedI32Out(o_begins.data_ptr(), o_ends.data_ptr(), o_ids.data_ptr(), n_chars, 0, 0)
+    out = IdOut(args.rows, n_chars, dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     unk = C.c_int32(int(tok["unk_id"]))
 
     def step():
-        L.check(lib, lib.ovtk_wordpiece_encode_run(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(out), L.MEM_DEVICE, stream))
-        return o_begins, o_ends, o_ids[: out.n_data]
+        o_begins, o_ends, o_ids, o = out.take()
+        L.check(lib, lib.ovtk_wordpiece_encode_run(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(o), L.MEM_DEVICE, stream))
+        return o_begins, o_ends, o_ids[: o.n_data]
 
     def cpu(n_s):
         from oracle import oracle as O
@@ -182,7 +211,7 @@ def make_encode_wordpiece(args, lib, dev, rank):
 
     workload = (f"config 3: BERT-shaped WordPiece (V=30522, trained in-process), {args.rows} x ~{nbytes}-byte lower-cased zipf "
                 f"strings per GPU, fused RegexSplit(\\s+)+RegexSplit(delimiters)+WordpieceTokenizer, inputs and outputs in HBM")
-    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, ws, pu, wp, o_begins, o_ends, o_ids), workload=workload,
+    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, ws, pu, wp), workload=workload, vocab=len(tok["vocab"]),
                 metric="input MB/s encoded (BERT WordPiece, 256-byte strings)", dtype="u8/int32",
                 algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=min(args.rows, 32768))
 
@@ -247,6 +276,12 @@ def main():
     ap.add_argument("--no-memo", action="store_true", help="config 2: BPETokenizer with cache_capacity=0 (no piece memo)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the all-gather (rank-local consumer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hog", type=int, default=0, help="debug: occupy CU slots with N idle 512-thread blocks on a side stream during "
+                                                        "every step (stands in for RCCL's all-gather kernel; tools/cu_hog.hip)")
+    ap.add_argument("--row-tickets", type=int, default=-1, help="ovtk_set_row_tickets(n); default: 0 at N = 1, 2 with an exchange")
+    ap.add_argument("--hog-lds", type=int, default=0, help="debug: dynamic LDS bytes per hog block")
+    ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
+    ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -254,20 +289,53 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_exchange
+    if dist_on:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
-        from openvino_tokenizers_amd.distributed import all_gather_ragged
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from openvino_tokenizers_amd.distributed import ShardExchange
 
     lib = L.load()
     wl = {2: make_encode_bpe, 3: make_encode_wordpiece, 4: make_encode_llama3, 5: make_detokenize}[args.config](args, lib, dev, rank)
     is_detok = wl.get("is_detok", False)
+    # N > 1: every rank's ragged ids are all-gathered (RCCL), one batch behind the encode so that the gather of batch k
+    # travels over xGMI while batch k + 1 is encoded; flush() completes the last one inside the timed region.
+    exchange = None
+    if (world > 1 or args.force_exchange) and not args.no_gather and not is_detok:
+        exchange = ShardExchange(wl.get("rows", args.rows) * world, wl["vocab"], dev, lib=lib)
+
+    # A step = one batch through the hot path.  Where the op has the two-half form (config 2) the host launches batch k,
+    # then completes batch k-1 (status check, and with N > 1 its exchange) while the GPU works on k: the reference's
+    # evaluate() semantics per batch, without the GPU idling while the host reads a status word.  --sync: one blocking
+    # ovtk_encode_run per step.
+    row_tickets = args.row_tickets if args.row_tickets >= 0 else (2 if exchange is not None else 0)
+    L.check(lib, lib.ovtk_set_row_tickets(row_tickets))
+    inflight = []
+    hog = None
+    if args.hog:
+        hog_lib = C.CDLL(str(ROOT / "tools" / "build" / "libcuhog.so"))
+        hog_stream = torch.cuda.Stream(dev)
+        hog = lambda: hog_lib.cu_hog(args.hog, 512, args.hog_lds, C.c_double(300.0), C.c_void_p(hog_stream.cuda_stream))  # noqa: E731
+
+    def complete(finish):
+        res = finish()
+        return exchange.submit(*res) if exchange is not None else res
 
     def step():
-        res = wl["step"]()
-        if world > 1 and not args.no_gather and not is_detok:
-            return all_gather_ragged(*res)
-        return res
+        if hog is not None:
+            hog()
+        if "enqueue" in wl and not args.sync:
+            inflight.append(wl["enqueue"]())
+            return complete(inflight.pop(0)) if len(inflight) > 1 else None
+        return complete(wl["step"])
+
+    def drain():
+        while inflight:
+            complete(inflight.pop(0))
+        if exchange is not None:
+            exchange.flush()
 
     def barrier():
         torch.cuda.synchronize()
@@ -277,12 +345,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     lib.ovtk_profile_reset()
     lib.ovtk_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        step()
+    drain()   # every one of the K batches is complete (and, N > 1, gathered on every rank) before the clock stops
     barrier()
     dt = time.perf_counter() - t0
     lib.ovtk_profile_enable(0)
@@ -325,7 +395,9 @@ def main():
                     "all_kernels_ms_per_step": round(sum(per_step.values()), 4)}
 
     if rank != 0:
-        if world > 1:
+        if exchange is not None:
+            exchange.close()
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -349,14 +421,21 @@ def main():
         "metric": wl["metric"], "value": round(value, 1), "unit": wl.get("unit", "MB/s"),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
-        "config": {"workload": wl["workload"], "rows_per_gpu": wl.get("rows", args.rows), "units_per_gpu": n_units, "outputs_per_gpu": n_out,
-                   "exchange": ("none (1 GPU)" if world == 1 else ("none (rank-local consumer)" if args.no_gather or is_detok else
-                                                                    "all-gather of ragged ids over RCCL"))},
+        "config": {"workload": wl["workload"],
+                   "row_tickets": row_tickets,
+                   "host_loop": ("launch batch k, then complete batch k-1 (ovtk_encode_enqueue/finish)" if "enqueue" in wl and not args.sync
+                                 else "one blocking call per batch"),
+                   "rows_per_gpu": wl.get("rows", args.rows), "units_per_gpu": n_units, "outputs_per_gpu": n_out,
+                   "exchange": ("none (1 GPU)" if exchange is None and world == 1 else ("none (rank-local consumer)" if exchange is None else
+                                                                    f"all-gather of ragged ids over RCCL, {exchange.id_bytes}-byte ids on the wire, "
+                                                                    f"gather overlapped with the next encode, unpack one batch later ({exchange.regathers} re-gathers)"))},
         "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_prefix_bit_exact": parity,
         "kernel_ms": kernels,
     }
     print(json.dumps(line))
-    if world > 1:
+    if exchange is not None:
+        exchange.close()
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -164,6 +164,23 @@ void ovtk_bpe_destroy(ovtk_bpe* h);
 int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                     ovtk_ragged_i32_out* out, int mem, void* stream);
 
+/* The same call in two halves, for device-resident batches (OVTK_MEM_DEVICE): enqueue launches the kernels on `stream`
+ * and returns; finish waits for them -- for their own event, not for work the caller put on the stream afterwards --
+ * repeats the launch if a workspace proved too small, fills *out (n_data, n_rows) and frees the pending call, also on
+ * error.  The buffers named by `in`, `skips` and `out` must stay valid until finish; the structs themselves are
+ * copied.  Lets a host keep the next batch's launches (or an exchange, see the row-shard section) behind the GPU
+ * instead of idling in evaluate() as the reference's synchronous ops do. */
+/* How the BPE kernels share rows among their (persistent) waves, process-wide: 0 (default) -- every wave owns a fixed
+ * share, fastest when the GPU runs nothing else; n > 0 -- rows are handed out n at a time, so that blocks which become
+ * resident late because another stream's kernel (RCCL's all-gather during the row-shard exchange) holds their CU take
+ * less work instead of finishing last.  Results are identical either way. */
+int ovtk_set_row_tickets(int rows_per_ticket);
+
+typedef struct ovtk_pending ovtk_pending;
+int ovtk_encode_enqueue(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+                        const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending);
+int ovtk_encode_finish(ovtk_pending* pending, ovtk_ragged_i32_out* out);
+
 /* ---------------------------------------------------------------- WordpieceTokenizer
  * Replaces WordpieceTokenizer::evaluate, src/wordpiece_tokenizer.cpp:49-133.  Inputs 5-7 + attributes at
  * create; input 8 (unk_token_id) is read every call, as in the reference (:74). */
@@ -244,6 +261,37 @@ int ovtk_byte_fallback(const ovtk_strings* in, ovtk_strings_out* out, int mem, i
 int ovtk_fuze_ragged(const int32_t* ragged_begins, const int32_t* ragged_ends, int64_t n_rows,
                      const int32_t* begins, const int32_t* ends, int64_t n, int32_t* out_begins,
                      int32_t* out_ends, int mem, int device, void* stream);
+
+/* ---------------------------------------------------------------- row-shard exchange
+ * No reference counterpart (the reference is single-process).  Rows shard contiguously over the ranks of one node
+ * (rank r owns rows first(r) .. first(r+1), balanced like numpy.array_split); the one exchange step is an all-gather
+ * of fixed-size "wires": i32 lens[max_rows] then pad_ids ids of id_bytes (2 when every id < 65536, else 4) bytes.
+ *   ovtk_shard_pack    builds this rank's wire from the ragged ids an encode call returned (ascending, gap-free
+ *                      from 0).  Device memory: only enqueues work on `stream`.
+ *   (the caller all-gathers the wires: RCCL)
+ *   ovtk_shard_unpack  rebuilds the global ragged tensor from the `world` wires: begins/ends [n_rows], ids widened to
+ *                      i32.  Device memory: only enqueues work on `stream` -- the handle owns the scratch, so calls
+ *                      on one handle must be ordered on one stream -- and `result` (device memory) is written last.
+ *                      Host memory: synchronous, `result` in host memory.
+ * result->status: OVTK_OK; OVTK_E_CAPACITY with max_shard_ids > pad_ids when some shard held more ids than the wire
+ * has room for (identical on every rank: repeat the exchange with a larger pad); OVTK_E_RANGE when out_capacity is
+ * too small; OVTK_E_UNSUPPORTED beyond 2^31 ids. */
+typedef struct {
+    int64_t n_ids;          /* ids in the global tensor */
+    int64_t max_shard_ids;  /* largest shard */
+    int64_t status;
+    int64_t reserved;
+} ovtk_shard_result;
+typedef struct ovtk_shard_exchange ovtk_shard_exchange;
+int ovtk_shard_exchange_create(int world, int64_t n_rows, int id_bytes, int device, ovtk_shard_exchange** out);
+int64_t ovtk_shard_max_rows(const ovtk_shard_exchange* h);                    /* lens slots per wire */
+int64_t ovtk_shard_wire_bytes(const ovtk_shard_exchange* h, int64_t pad_ids); /* pad_ids: multiple of 8 */
+int ovtk_shard_pack(ovtk_shard_exchange* h, const int32_t* begins, const int32_t* ends, const int32_t* ids,
+                    int64_t rows, int64_t n_ids, int64_t pad_ids, void* wire, int mem, void* stream);
+int ovtk_shard_unpack(ovtk_shard_exchange* h, const void* wires, int64_t pad_ids, int32_t* out_begins,
+                      int32_t* out_ends, int32_t* out_ids, int64_t out_capacity, ovtk_shard_result* result,
+                      int mem, void* stream);
+void ovtk_shard_exchange_destroy(ovtk_shard_exchange* h);
 
 /* ---------------------------------------------------------------- UTF8Validate
  * Replaces UTF8Validate::evaluate, src/utf8_validate.cpp:18-143.  replace_mode 0: drop invalid bytes, 1: U+FFFD.

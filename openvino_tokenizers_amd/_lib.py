@@ -79,17 +79,23 @@ class RaggedI32(C.Structure):
                 ("n_data", C.c_int64)]
 
 
+class ShardResult(C.Structure):
+    _fields_ = [("n_ids", C.c_int64), ("max_shard_ids", C.c_int64), ("status", C.c_int64), ("reserved", C.c_int64)]
+
+
 EXPORTS = [
     "ovtk_last_error", "ovtk_abi_version", "ovtk_device_name",
     "ovtk_regex_split_create", "ovtk_regex_split_run", "ovtk_regex_split_destroy",
     "ovtk_special_tokens_split_create", "ovtk_special_tokens_split_run", "ovtk_special_tokens_split_destroy",
-    "ovtk_bpe_create", "ovtk_bpe_run", "ovtk_bpe_destroy", "ovtk_encode_run",
+    "ovtk_bpe_create", "ovtk_bpe_run", "ovtk_bpe_destroy", "ovtk_encode_run", "ovtk_encode_enqueue", "ovtk_encode_finish", "ovtk_set_row_tickets",
     "ovtk_wordpiece_create", "ovtk_wordpiece_run", "ovtk_wordpiece_encode_run", "ovtk_wordpiece_destroy",
     "ovtk_vocab_encoder_create", "ovtk_vocab_encoder_run", "ovtk_vocab_encoder_destroy",
     "ovtk_ragged_to_dense",
     "ovtk_vocab_decoder_create", "ovtk_vocab_decoder_run", "ovtk_vocab_decoder_destroy",
     "ovtk_byte_fallback", "ovtk_fuze_ragged", "ovtk_detokenize_run",
     "ovtk_utf8_validate", "ovtk_truncate", "ovtk_combine_segments",
+    "ovtk_shard_exchange_create", "ovtk_shard_max_rows", "ovtk_shard_wire_bytes", "ovtk_shard_pack", "ovtk_shard_unpack",
+    "ovtk_shard_exchange_destroy",
     "ovtk_profile_enable", "ovtk_profile_reset", "ovtk_profile_get", "ovtk_profile_dump",
 ]
 
@@ -122,6 +128,8 @@ def load(path: os.PathLike | str | None = None) -> C.CDLL:
     lib.ovtk_last_error.restype = C.c_char_p
     lib.ovtk_device_name.restype = C.c_char_p
     lib.ovtk_profile_dump.restype = C.c_int64
+    lib.ovtk_shard_wire_bytes.restype = C.c_int64
+    lib.ovtk_shard_max_rows.restype = C.c_int64
     _cache[key] = lib
     return lib
 

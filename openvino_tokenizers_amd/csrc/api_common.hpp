@@ -1,6 +1,8 @@
 // api_common.hpp -- helpers shared by the C-ABI translation units.
 #pragma once
 
+#include <atomic>
+
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -144,108 +146,169 @@ inline int grid_lookup(int device, int n_rows) { return grid_rows(device, n_rows
 // by the kernels are handled by growing the buffer and running again.
 // self_alloc: the middle's first kernel (lookup_kernel) validates the offsets and takes its staging from bump allocators
 // itself, so no prep launch is needed.
+//
+// A run is an object so that a call can be split in two (ovtk_encode_enqueue / ovtk_encode_finish): start() stages the
+// inputs and launches one attempt without waiting; finish() waits for that attempt's event (not for whatever the
+// caller put on the stream afterwards), repeats it while a workspace was too small, and reports.
+// ovtk_set_row_tickets(): 0 = every wave owns a fixed share of the rows; n > 0 = rows are handed out n at a time.
+inline std::atomic<int>& row_tickets() {
+    static std::atomic<int> v{0};
+    return v;
+}
+
+struct PendingRun {
+    virtual ~PendingRun() = default;
+    virtual int finish(ovtk_ragged_i32_out* out) = 0;
+};
+
+template <class Middle>
+class RowsRun final : public PendingRun {
+public:
+    RowsRun(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
+            const ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle middle, bool self_alloc, int blocks_per_cu)
+        : device_(device), op_(op), in_(*in), skips_(skips), mul_(mul), out_(*out), mem_(mem), s_(s),
+          middle_(std::move(middle)), self_alloc_(self_alloc), blocks_per_cu_(blocks_per_cu), ws_(device) {}
+
+    int start() {
+        if (!ws_->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
+        if (!ws_->done) OVTK_HIP(hipEventCreateWithFlags(&ws_->done, hipEventDisableTiming));
+        if (int rc = stage_input(*ws_.ws, &in_, skips_, mem_, s_, d_in_)) return rc;
+        n_rows_ = d_in_.n_rows;
+        stage_cap_ = std::min<int64_t>((in_.strings.n_chars + in_.strings.n) * mul_, INT32_MAX - 1);
+        shard_cap_ = std::max<int64_t>({4096, (in_.strings.n_chars / 16 + in_.strings.n / 4) / kShards,
+                                        int64_t(ws_->deferred.size() / sizeof(DeferredPiece) / kShards)});
+        exact_cap_ = std::max<int64_t>(4096, int64_t(ws_->exact.size() / sizeof(ExactPiece)));
+        scratch_cap_ = std::max<int64_t>(ws_->scratch.size(), int64_t(16) << 20);
+        if (int rc = out_target(ws_->out_a, out_.begins, size_t(n_rows_) * 4, mem_, &d_begins_)) return rc;
+        if (int rc = out_target(ws_->out_b, out_.ends, size_t(n_rows_) * 4, mem_, &d_ends_)) return rc;
+        if (int rc = out_target(ws_->out_c, out_.data, size_t(out_.data_capacity) * 4, mem_, &d_ids_)) return rc;
+        grid_ = grid_rows(device_, n_rows_, blocks_per_cu_);
+        n_tiles_ = (n_rows_ + kRowTile - 1) / kRowTile;
+        if (self_alloc_)  // every wave may leave one chunk partly unused
+            stage_cap_ = std::min<int64_t>(stage_cap_ + int64_t(grid_ * kWavesPerBlock + kShards) * kStageChunk, INT32_MAX - 1);
+        return launch();
+    }
+
+    int finish(ovtk_ragged_i32_out* out) override {
+        for (int attempt = 0; attempt < 6; ++attempt) {
+            OVTK_HIP(hipEventSynchronize(ws_->done));
+            Profiler::get().resolve(ws_->marks);
+            OVTK_HIP(hipGetLastError());
+            const RunStatus& st = *ws_->host_status;
+            if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+            if (st.flags & kFlagStageOverflow) {
+                const int64_t need = self_alloc_ ? stage_cap_ * 2 : int64_t(st.stage_need);  // the allocators do not know the total
+                if (need >= INT32_MAX - 1)
+                    return set_error(OVTK_E_UNSUPPORTED, "batch needs more than 2^31 staging entries; split the call");
+                stage_cap_ = need;
+            } else if (st.flags & kFlagDeferOverflow) {
+                int64_t most = 0;
+                for (int k = 0; k < kShards; ++k) most = std::max<int64_t>(most, st.shard_count[k * kCounterStride]);
+                shard_cap_ = most + most / 8 + 256;
+            } else if (st.flags & kFlagExactOverflow) {
+                exact_cap_ = int64_t(st.n_exact) + 256;
+            } else if (st.flags & kFlagScratchOverflow) {
+                scratch_cap_ = std::max<int64_t>(scratch_cap_ * 2, int64_t(st.scratch_used) + (1 << 20));
+                if (scratch_cap_ > (int64_t(3) << 30))
+                    return set_error(OVTK_E_UNSUPPORTED, "exact-path scratch would exceed 3 GiB; split the call");
+            } else {
+                if (st.flags & kFlagOutCapacity)
+                    return set_error(OVTK_E_CAPACITY, op_ + ": output ids buffer too small (" + std::to_string(st.n_out) +
+                                                          " ids, capacity " + std::to_string(out_.data_capacity) + ")");
+                out->n_data = st.n_out;
+                if (int rc = copy_back(out_.begins, d_begins_, size_t(n_rows_) * 4, mem_, s_)) return rc;
+                if (int rc = copy_back(out_.ends, d_ends_, size_t(n_rows_) * 4, mem_, s_)) return rc;
+                if (int rc = copy_back(out_.data, d_ids_, size_t(st.n_out) * 4, mem_, s_)) return rc;
+                if (mem_ == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s_));
+                return OVTK_OK;
+            }
+            if (int rc = launch()) return rc;  // a workspace was too small: once more with the size the kernels asked for
+        }
+        return set_error(OVTK_E_HIP, "workspace sizing did not converge");
+    }
+
+private:
+    int launch() {
+        Workspace& ws = *ws_.ws;
+        int e = 0;
+        e = e ? e : ws.row_stage.ensure(size_t(n_rows_) * 4);
+        e = e ? e : ws.row_cnt.ensure(size_t(n_rows_) * 4);
+        e = e ? e : ws.row_used.ensure(size_t(n_rows_) * 4);
+        e = e ? e : ws.stage.ensure(size_t(stage_cap_) * 4);
+        e = e ? e : ws.deferred.ensure(size_t(shard_cap_) * kShards * sizeof(DeferredPiece));
+        e = e ? e : ws.exact.ensure(size_t(exact_cap_) * sizeof(ExactPiece));
+        e = e ? e : ws.scratch.ensure(size_t(scratch_cap_));
+        e = e ? e : ws.wave_off.ensure(size_t(grid_ * kWavesPerBlock + 1) * sizeof(long long));
+        e = e ? e : ws.tiles.ensure(size_t(n_tiles_ + 1) * sizeof(long long));
+        e = e ? e : ws.status.ensure(sizeof(RunStatus));
+        if (e) return e;
+        EncodeWork w{};
+        w.n_waves = grid_ * kWavesPerBlock;
+        w.rows_per_ticket = self_alloc_ ? row_tickets().load(std::memory_order_relaxed) : 0;
+        w.wave_off = self_alloc_ ? nullptr : ws.wave_off.as<long long>();
+        w.stage_region = int32_t(stage_cap_ / kShards);
+        w.row_stage = ws.row_stage.as<int32_t>();
+        w.row_cnt = ws.row_cnt.as<int32_t>();
+        w.row_used = ws.row_used.as<int32_t>();
+        w.tile_off = ws.tiles.as<long long>();
+        w.stage = ws.stage.as<int32_t>();
+        w.stage_cap = int32_t(stage_cap_);
+        w.deferred = ws.deferred.as<DeferredPiece>();
+        w.shard_cap = int32_t(std::min<int64_t>(shard_cap_, INT32_MAX / kShards));
+        w.exact = ws.exact.as<ExactPiece>();
+        w.exact_cap = int32_t(exact_cap_);
+        w.scratch = ws.scratch.as<uint8_t>();
+        w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap_, 0xFFFFFFF0ll));
+        w.status = ws.status.as<RunStatus>();
+
+        OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s_));
+        if (!self_alloc_)
+            OVTK_LAUNCH(ws.marks, "prep_rows", prep_rows_kernel, std::min(grid_, kTicketBlocks), kBlockThreads, s_, d_in_, mul_, w);
+        middle_(ws, d_in_, w, grid_);
+        OVTK_LAUNCH(ws.marks, "count_scan", count_scan_kernel, std::min((n_tiles_ + 3) / 4, kTicketBlocks), kBlockThreads, s_,
+                    n_rows_, w, (long long)out_.data_capacity);
+        OVTK_LAUNCH(ws.marks, "compact", compact_kernel, grid_lookup(device_, n_rows_), kBlockThreads, s_, n_rows_, w, d_ids_,
+                    d_begins_, d_ends_);
+        OVTK_HIP(hipMemcpyAsync(ws.host_status, ws.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s_));
+        OVTK_HIP(hipEventRecord(ws.done, s_));
+        return OVTK_OK;
+    }
+
+    int device_;
+    std::string op_;
+    ovtk_ragged_strings in_;
+    const uint8_t* skips_;
+    int mul_;
+    ovtk_ragged_i32_out out_;
+    int mem_;
+    hipStream_t s_;
+    Middle middle_;
+    bool self_alloc_;
+    int blocks_per_cu_;
+    WorkspaceLease ws_;
+    RowsIn d_in_{};
+    int n_rows_ = 0, grid_ = 0, n_tiles_ = 0;
+    int64_t stage_cap_ = 0, shard_cap_ = 0, exact_cap_ = 0, scratch_cap_ = 0;
+    int32_t *d_begins_ = nullptr, *d_ends_ = nullptr, *d_ids_ = nullptr;
+};
+
+template <class Middle>
+std::unique_ptr<RowsRun<std::decay_t<Middle>>> make_rows_run(int device, const char* op, const ovtk_ragged_strings* in,
+                                                             const uint8_t* skips, int mul, const ovtk_ragged_i32_out* out, int mem,
+                                                             hipStream_t s, Middle&& middle, bool self_alloc = false,
+                                                             int blocks_per_cu = 6) {
+    return std::make_unique<RowsRun<std::decay_t<Middle>>>(device, op, in, skips, mul, out, mem, s, std::forward<Middle>(middle),
+                                                           self_alloc, blocks_per_cu);
+}
+
+// The synchronous form every *_run entry point uses.  `middle` is copied: capture by value.
 template <class Middle>
 int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
                     ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle&& middle, bool self_alloc = false,
                     int blocks_per_cu = 6) {
-    WorkspaceLease ws(device);
-    if (!ws->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
-    RowsIn d_in{};
-    if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
-
-    const int n_rows = d_in.n_rows;
-    int64_t stage_cap = std::min<int64_t>((in->strings.n_chars + in->strings.n) * mul, INT32_MAX - 1);
-    int64_t shard_cap = std::max<int64_t>({4096, (in->strings.n_chars / 16 + in->strings.n / 4) / kShards,
-                                           int64_t(ws->deferred.size() / sizeof(DeferredPiece) / kShards)});
-    int64_t exact_cap = std::max<int64_t>(4096, int64_t(ws->exact.size() / sizeof(ExactPiece)));
-    int64_t scratch_cap = std::max<int64_t>(ws->scratch.size(), int64_t(16) << 20);
-
-    int32_t *d_begins = nullptr, *d_ends = nullptr, *d_ids = nullptr;
-    if (int rc = out_target(ws->out_a, out->begins, size_t(n_rows) * 4, mem, &d_begins)) return rc;
-    if (int rc = out_target(ws->out_b, out->ends, size_t(n_rows) * 4, mem, &d_ends)) return rc;
-    if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_ids)) return rc;
-
-    const int grid = grid_rows(device, n_rows, blocks_per_cu);
-    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
-    if (self_alloc)  // every wave may leave one chunk partly unused
-        stage_cap = std::min<int64_t>(stage_cap + int64_t(grid * kWavesPerBlock + kShards) * kStageChunk, INT32_MAX - 1);
-    for (int attempt = 0; attempt < 6; ++attempt) {
-        int e = 0;
-        e = e ? e : ws->row_stage.ensure(size_t(n_rows) * 4);
-        e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
-        e = e ? e : ws->row_used.ensure(size_t(n_rows) * 4);
-        e = e ? e : ws->stage.ensure(size_t(stage_cap) * 4);
-        e = e ? e : ws->deferred.ensure(size_t(shard_cap) * kShards * sizeof(DeferredPiece));
-        e = e ? e : ws->exact.ensure(size_t(exact_cap) * sizeof(ExactPiece));
-        e = e ? e : ws->scratch.ensure(size_t(scratch_cap));
-        e = e ? e : ws->wave_off.ensure(size_t(grid * kWavesPerBlock + 1) * sizeof(long long));
-        e = e ? e : ws->tiles.ensure(size_t(n_tiles + 1) * sizeof(long long));
-        e = e ? e : ws->status.ensure(sizeof(RunStatus));
-        if (e) return e;
-        EncodeWork w{};
-        w.n_waves = grid * kWavesPerBlock;
-        w.wave_off = self_alloc ? nullptr : ws->wave_off.as<long long>();
-        w.stage_region = int32_t(stage_cap / kShards);
-        w.row_stage = ws->row_stage.as<int32_t>();
-        w.row_cnt = ws->row_cnt.as<int32_t>();
-        w.row_used = ws->row_used.as<int32_t>();
-        w.tile_off = ws->tiles.as<long long>();
-        w.stage = ws->stage.as<int32_t>();
-        w.stage_cap = int32_t(stage_cap);
-        w.deferred = ws->deferred.as<DeferredPiece>();
-        w.shard_cap = int32_t(std::min<int64_t>(shard_cap, INT32_MAX / kShards));
-        w.exact = ws->exact.as<ExactPiece>();
-        w.exact_cap = int32_t(exact_cap);
-        w.scratch = ws->scratch.as<uint8_t>();
-        w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap, 0xFFFFFFF0ll));
-        w.status = ws->status.as<RunStatus>();
-
-        OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-        if (!self_alloc)
-            OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, mul, w);
-        middle(*ws.ws, d_in, w, grid);
-        OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s,
-                    n_rows, w, (long long)out->data_capacity);
-        OVTK_LAUNCH(ws->marks, "compact", compact_kernel, grid_lookup(device, n_rows), kBlockThreads, s, n_rows, w, d_ids, d_begins, d_ends);
-        if (int rc = finish_status(*ws.ws, s)) return rc;
-
-        const RunStatus& st = *ws->host_status;
-        if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
-        if (st.flags & kFlagStageOverflow) {
-            const int64_t need = self_alloc ? stage_cap * 2 : int64_t(st.stage_need);  // the allocators do not know the total
-            if (need >= INT32_MAX - 1)
-                return set_error(OVTK_E_UNSUPPORTED, "batch needs more than 2^31 staging entries; split the call");
-            stage_cap = need;
-            continue;
-        }
-        if (st.flags & kFlagDeferOverflow) {
-            int64_t most = 0;
-            for (int k = 0; k < kShards; ++k) most = std::max<int64_t>(most, st.shard_count[k * kCounterStride]);
-            shard_cap = most + most / 8 + 256;
-            continue;
-        }
-        if (st.flags & kFlagExactOverflow) {
-            exact_cap = int64_t(st.n_exact) + 256;
-            continue;
-        }
-        if (st.flags & kFlagScratchOverflow) {
-            scratch_cap = std::max<int64_t>(scratch_cap * 2, int64_t(st.scratch_used) + (1 << 20));
-            if (scratch_cap > (int64_t(3) << 30))
-                return set_error(OVTK_E_UNSUPPORTED, "exact-path scratch would exceed 3 GiB; split the call");
-            continue;
-        }
-        if (st.flags & kFlagOutCapacity)
-            return set_error(OVTK_E_CAPACITY, std::string(op) + ": output ids buffer too small (" +
-                                                  std::to_string(st.n_out) + " ids, capacity " +
-                                                  std::to_string(out->data_capacity) + ")");
-        out->n_data = st.n_out;
-        if (int rc = copy_back(out->begins, d_begins, size_t(n_rows) * 4, mem, s)) return rc;
-        if (int rc = copy_back(out->ends, d_ends, size_t(n_rows) * 4, mem, s)) return rc;
-        if (int rc = copy_back(out->data, d_ids, size_t(st.n_out) * 4, mem, s)) return rc;
-        if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
-        return OVTK_OK;
-    }
-    return set_error(OVTK_E_HIP, "workspace sizing did not converge");
+    auto run = make_rows_run(device, op, in, skips, mul, out, mem, s, std::forward<Middle>(middle), self_alloc, blocks_per_cu);
+    if (int rc = run->start()) return rc;
+    return run->finish(out);
 }
 
 }  // namespace ovtk

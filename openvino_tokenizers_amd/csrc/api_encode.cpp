@@ -329,8 +329,9 @@ void ovtk_bpe_destroy(ovtk_bpe* h) { delete h; }
 namespace {
 
 // RegexSplit [+] BPETokenizer.  split == nullptr: `in` already holds pieces (the BPETokenizer op).
-int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
-               ovtk_ragged_i32_out* out, int mem, void* stream) {
+// Launches the kernels; `run` stays empty when the result was complete without any (empty batches).
+int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+                 ovtk_ragged_i32_out* out, int mem, void* stream, std::unique_ptr<PendingRun>& run) {
     if (int rc = check_rows(in)) return rc;
     if (!bpe || !out) return set_error(OVTK_E_ARG, "null argument");
     if (split && split->device != bpe->device) return set_error(OVTK_E_ARG, "split and bpe handles live on different devices");
@@ -357,20 +358,46 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
     if (in->n_rows == 0) return OVTK_OK;
 
     const int dev = bpe->device;
-    return run_rows_to_ids(dev, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
-                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
-                               if (split)
+    auto r = make_rows_run(dev, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
+                           [=](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
+                               const bool tickets = w.rows_per_ticket != 0;
+                               if (split && tickets)
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFused, true>), grid, kBlockThreads, s, d_in,
+                                               split->dev, bpe->dev, w);
+                               else if (split)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in,
                                                split->dev, bpe->dev, w);
+                               else if (tickets)
+                                   OVTK_LAUNCH(ws.marks, "lookup_pieces", (lookup_kernel<kPieces, true>), grid, kBlockThreads, s, d_in,
+                                               SplitDev{}, bpe->dev, w);
                                else
                                    OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid, kBlockThreads, s, d_in,
                                                SplitDev{}, bpe->dev, w);
-                               OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(std::max(1, device_cu_count(dev) * 3 / kShards), kShards),
+                               OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(kShards, std::max(1, device_cu_count(dev) * 3 / kShards)),
                                            kBlockThreads, s, d_in, bpe->dev, w);
                                OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
                            },
                            /*self_alloc=*/true,
                            split ? resident_blocks_per_cu(lookup_kernel<kFused>) : resident_blocks_per_cu(lookup_kernel<kPieces>));
+    if (int rc = r->start()) return rc;
+    run = std::move(r);
+    return OVTK_OK;
+}
+
+int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+               ovtk_ragged_i32_out* out, int mem, void* stream) {
+    std::unique_ptr<PendingRun> run;
+    if (int rc = start_encode(split, bpe, in, skips, out, mem, stream, run)) return rc;
+    return run ? run->finish(out) : OVTK_OK;
+}
+
+int check_fused(const ovtk_regex_split* split) {
+    if (!split) return set_error(OVTK_E_ARG, "null split handle");
+    if (split->max_splits != -1)
+        return set_error(OVTK_E_UNSUPPORTED, "fused encode: max_splits is only supported by the RegexSplit op itself");
+    if (split->dev.kind > kSplitGpt2Digits)
+        return set_error(OVTK_E_UNSUPPORTED, "fused encode: this pattern is only supported as RegexSplit followed by BPETokenizer");
+    return OVTK_OK;
 }
 
 }  // namespace
@@ -383,12 +410,38 @@ int ovtk_bpe_run(ovtk_bpe* h, const ovtk_ragged_strings* in, ovtk_ragged_i32_out
 
 int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                     ovtk_ragged_i32_out* out, int mem, void* stream) {
-    if (!split) return set_error(OVTK_E_ARG, "null split handle");
-    if (split->max_splits != -1)
-        return set_error(OVTK_E_UNSUPPORTED, "fused encode: max_splits is only supported by the RegexSplit op itself");
-    if (split->dev.kind > kSplitGpt2Digits)
-        return set_error(OVTK_E_UNSUPPORTED, "fused encode: this pattern is only supported as RegexSplit followed by BPETokenizer");
+    if (int rc = check_fused(split)) return rc;
     return run_encode(split, bpe, in, skips, out, mem, stream);
+}
+
+int ovtk_set_row_tickets(int rows_per_ticket) {
+    if (rows_per_ticket < 0 || rows_per_ticket > 64) return set_error(OVTK_E_ARG, "row tickets: 0 (static) .. 64 rows per ticket");
+    row_tickets().store(rows_per_ticket, std::memory_order_relaxed);
+    return OVTK_OK;
+}
+
+struct ovtk_pending {
+    std::unique_ptr<PendingRun> run;  // empty: nothing was launched, `out` was complete at enqueue
+    ovtk_ragged_i32_out out{};
+};
+
+int ovtk_encode_enqueue(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+                        const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending) {
+    if (!pending || !out) return set_error(OVTK_E_ARG, "null argument");
+    if (int rc = check_fused(split)) return rc;
+    auto p = std::make_unique<ovtk_pending>();
+    p->out = *out;
+    if (int rc = start_encode(split, bpe, in, skips, &p->out, OVTK_MEM_DEVICE, stream, p->run)) return rc;
+    *pending = p.release();
+    return OVTK_OK;
+}
+
+int ovtk_encode_finish(ovtk_pending* pending, ovtk_ragged_i32_out* out) {
+    if (!pending) return set_error(OVTK_E_ARG, "null argument");
+    std::unique_ptr<ovtk_pending> p(pending);  // released whatever happens
+    const int rc = p->run ? p->run->finish(&p->out) : OVTK_OK;
+    if (out) *out = p->out;
+    return rc;
 }
 
 int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, const uint8_t* skips,

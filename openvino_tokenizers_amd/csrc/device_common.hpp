@@ -29,9 +29,12 @@ struct RunStatus {
     uint32_t scratch_used; // bytes taken from the exact kernel's scratch pool
     uint32_t flags;        // kFlag*
     uint32_t ticket[2];    // "last block done" tickets of prep_rows_kernel / count_scan_kernel
-    int32_t pad[24];
+    uint32_t rows_done;    // bit s: row-ticket shard s is exhausted (lookup_kernel)
+    int32_t pad[23];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
     int32_t stage_top[kShards * kCounterStride];    // [s * kCounterStride] = staging entries handed out in region s
+    int32_t row_ticket[kShards * kCounterStride];   // [s * kCounterStride] = rows of range s handed to waves (lookup_kernel)
+    int32_t batch_ticket[kShards * kCounterStride]; // [s * kCounterStride] = 64-piece batches of shard s handed out (merge_kernel)
 };
 constexpr uint32_t kFlagItemsOverflow = 1u;     // more work items than the workspace holds
 constexpr uint32_t kFlagStageOverflow = 2u;     // staging buffer too small

@@ -52,6 +52,7 @@ constexpr int kMissBuf = 128;  // per-wave LDS buffer of deferred pieces (flushe
 constexpr int kRowTile = 64;  // rows per tile of the final offset scan
 
 struct EncodeWork {
+    int32_t rows_per_ticket;  // lookup_kernel, allocator mode: 0 = static rows per wave, else rows handed out per ticket
     int32_t n_waves;        // persistent waves of the prep / lookup launches (wave w owns rows w, w + n_waves, ...)
     long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities), or
                             // nullptr: the lookup kernel takes staging chunks from kShards bump allocators itself
@@ -341,7 +342,7 @@ __device__ __forceinline__ int row_capacity_checked(const RowsIn& in, const RowH
     return int(cap);
 }
 
-template <int MODE>
+template <int MODE, bool TICKETS = false>
 static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
@@ -357,7 +358,52 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
     const bool alloc = w.wave_off == nullptr;
     int cursor = alloc ? 0 : int(w.wave_off[wave]), limit = alloc ? 0 : INT32_MAX;
     bool dead = false;  // allocator mode: staging exhausted or bad offsets -- the host reruns / reports
-    for (int row = wave; row < in.n_rows; row += n_waves) {
+    // Which rows a wave takes.  Static (w.rows_per_ticket == 0): rows wave, wave + n_waves, ... -- the share
+    // prep_rows_kernel sized its arena for, and the cheapest when the GPU is ours alone.  Dynamic (allocator mode
+    // only): rows are handed out rows_per_ticket at a time -- a block that becomes resident late (another stream's
+    // kernel, e.g. RCCL's all-gather, sits on its CU) then simply takes fewer, instead of running its whole share
+    // after everybody else (+30 % kernel time measured with 16 CUs taken; the tickets cost +5 %).  The tickets
+    // form kShards ranges with one counter each (a single device-scope counter saturates at ~90 atomics/us); a wave
+    // works through its home range, then through the ranges not yet marked done.  The NEXT ticket is requested
+    // before the current rows' header loads are issued, so most of its latency is paid together with theirs.
+    const int rpt = TICKETS ? w.rows_per_ticket : 0;  // a template flag: the static kernel carries none of this
+    const int n_tickets = rpt ? (in.n_rows + rpt - 1) / rpt : 0;
+    const int per = (n_tickets + kShards - 1) / kShards;
+    int tk_shard = wave % kShards, tk_pend = 0;
+    uint32_t tk_seen = 0;  // ranges this wave found empty
+    auto tk_issue = [&]() {
+        if (l == 0) tk_pend = atomicAdd(&w.status->row_ticket[tk_shard * kCounterStride], 1);
+    };
+    auto tk_resolve = [&]() -> int {  // -> first row of the ticket, or -1
+        for (;;) {
+            const int idx = wave_readlane(tk_pend, 0);
+            const int base = tk_shard * per;
+            const int size = n_tickets - base < per ? n_tickets - base : per;
+            if (idx < size) return (base + idx) * rpt;
+            if (idx == size || idx == size + 1) {  // the first waves to find the range empty say so
+                if (l == 0) atomicOr(&w.status->rows_done, 1u << tk_shard);
+            }
+            tk_seen |= 1u << tk_shard;
+            uint32_t done = __hip_atomic_load(&w.status->rows_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | tk_seen;
+            done = uint32_t(wave_uniform(int(done)));
+            int next = -1;
+            for (int k = 1; k < kShards && next < 0; ++k) {
+                const int cand = (tk_shard + k) % kShards;
+                if (!(done >> cand & 1u)) next = cand;
+            }
+            if (next < 0) return -1;
+            tk_shard = next;
+            tk_issue();
+        }
+    };
+    int row = wave, chunk_end = 0;
+    if (rpt) {
+        tk_issue();
+        row = tk_resolve();
+        chunk_end = row + rpt;
+    }
+    while (row >= 0 && row < in.n_rows) {
+        if (rpt && row + rpt == chunk_end) tk_issue();  // first row of a ticket
         RowHdr h{0, 0, 0, 0, false};
         if (MODE == kFused) h = load_row_string(in, load_row_range(in, row));
         else h = load_row_range(in, row);
@@ -420,6 +466,12 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
             w.row_used[row] = st.used;
         }
         cursor += st.used;
+        if (!rpt) {
+            row += n_waves;
+        } else if (++row == chunk_end) {
+            row = tk_resolve();
+            chunk_end = row + rpt;
+        }
     }
     if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
 }
@@ -438,12 +490,25 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
     uint32_t* fnid = fkey + kFastSyms * kWave;
     const int l = lane_id();
     const int SL = T.suffix_len;
-    const int shard = int(blockIdx.y);
+    const int shard = int(blockIdx.x);  // fastest-varying: blocks that become resident late are spread over all shards
     int count = w.status->shard_count[shard * kCounterStride];
     if (count > w.shard_cap) count = w.shard_cap;
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
-    const int stride = int(gridDim.x) * kBlockThreads;
-    for (int base = (int(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kWave; base < count; base += stride) {
+    // 64-piece batches of the shard: strided over its waves, or (w.rows_per_ticket != 0, see lookup_kernel: late blocks
+    // take fewer) handed out by a per-shard ticket, the next one requested before this batch's entries are loaded.
+    const bool dyn = w.rows_per_ticket != 0;
+    const int stride = int(gridDim.y) * kBlockThreads;
+    int bt_pend = 0, base = (int(blockIdx.y) * kWavesPerBlock + wave_in_block()) * kWave;
+    auto bt_issue = [&]() {
+        if (l == 0) bt_pend = atomicAdd(&w.status->batch_ticket[shard * kCounterStride], 1);
+    };
+    if (dyn) bt_issue();
+    for (;; base += stride) {
+        if (dyn) {
+            base = wave_readlane(bt_pend, 0) * kWave;
+            if (base < count) bt_issue();
+        }
+        if (base >= count) break;
         const bool valid = base + l < count;
         DeferredPiece e{};
         if (valid) e = list[base + l];

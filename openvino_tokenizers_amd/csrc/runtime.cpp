@@ -94,6 +94,7 @@ void Profiler::resolve(std::vector<Mark>& marks) {
 }
 
 Workspace::~Workspace() {
+    if (done) (void)hipEventDestroy(done);
     if (host_status) (void)hipHostFree(host_status);
 }
 

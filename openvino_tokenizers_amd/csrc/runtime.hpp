@@ -82,6 +82,7 @@ struct Workspace {
     DevBuf out_a, out_b, out_c, out_d, out_e;
     DevBuf gen[8];  // op-specific inputs / temporaries (api_ops.cpp)
     RunStatus* host_status = nullptr;  // pinned
+    hipEvent_t done = nullptr;         // end of the call in flight (RowsRun)
     std::vector<Profiler::Mark> marks;
     ~Workspace();
 };

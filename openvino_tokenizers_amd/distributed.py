@@ -5,14 +5,23 @@ running output offset, src/bpe_tokenizer.cpp:141-161), so each rank encodes a co
 replica of the read-only tables and there is exactly ONE exchange step: an all-gather of the per-shard ragged
 token-id tensors (RCCL over xGMI; `torch.distributed` backend "nccl" on ROCm).  The reference has no counterpart.
 
-RCCL has no all-gather-v, so shards are padded to the largest one: first the (rows, tokens) counts are gathered
-(16 bytes per rank), then row lengths and ids with `all_gather_into_tensor`; every rank rebuilds the global
-begins/ends with one cumulative sum.  At config-4 sizes a shard is ~60 MB of ids: one bucket, no chunking.
+RCCL has no all-gather-v, so every rank sends one fixed-size *wire* (include/ovtk_amd.h, "row-shard exchange"):
+its row lengths, then its ids narrowed to 2 bytes when the vocabulary allows and padded to a size all ranks agreed
+on.  One collective per batch, no counts exchange and no host round trip: the receiver's scan over the global row
+lengths locates every shard.  `ShardExchange` keeps two wires in flight so the gather of batch k (RCCL's own
+stream, xGMI) overlaps the encode of batch k+1: xGMI is point-to-point, 7 links x ~50 GB/s each way per GPU, so an
+8-rank gather of 4-byte ids would take longer than the encode itself.  (Measured on one MI355X: driving the exchange
+from a second thread / stream does not help -- the encode kernels are persistent grids that fill every CU, so
+side-stream kernels only start at kernel boundaries and a dependent chain of them falls behind.)
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
 import torch.distributed as dist
+
+from . import _lib as L
 
 
 def shard_rows(n_rows: int, rank: int, world: int):
@@ -23,27 +32,178 @@ def shard_rows(n_rows: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def all_gather_ragged(begins: torch.Tensor, ends: torch.Tensor, ids: torch.Tensor, group=None):
-    """Local ragged ids (begins/ends i32[rows_local], ids i32[n_local]) of every rank -> the global ragged tensor
-    (begins, ends, ids) in rank order, identical on all ranks."""
-    world = dist.get_world_size(group)
-    dev = ids.device
-    counts = torch.tensor([begins.numel(), ids.numel()], dtype=torch.int64, device=dev)
-    all_counts = torch.empty(world * 2, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_counts, counts, group=group)
-    all_counts = all_counts.view(world, 2).cpu()
-    max_rows, max_ids = int(all_counts[:, 0].max()), int(all_counts[:, 1].max())
+def _round_up(x, m):
+    return (int(x) + m - 1) // m * m
 
-    lens_pad = torch.zeros(max_rows, dtype=torch.int32, device=dev)
-    lens_pad[: begins.numel()] = ends - begins
-    ids_pad = torch.zeros(max(max_ids, 1), dtype=torch.int32, device=dev)
-    ids_pad[: ids.numel()] = ids
-    all_lens = torch.empty(world * max_rows, dtype=torch.int32, device=dev)
-    all_ids = torch.empty(world * ids_pad.numel(), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(all_lens, lens_pad, group=group)
-    dist.all_gather_into_tensor(all_ids, ids_pad, group=group)
 
-    lens = torch.cat([all_lens[r * max_rows: r * max_rows + int(all_counts[r, 0])] for r in range(world)])
-    out_ids = torch.cat([all_ids[r * ids_pad.numel(): r * ids_pad.numel() + int(all_counts[r, 1])] for r in range(world)])
-    g_ends = torch.cumsum(lens, 0, dtype=torch.int64).to(torch.int32)
-    return g_ends - lens, g_ends, out_ids
+class ShardExchange:
+    """All-gather of ragged token ids over the ranks of `group`, pipelined with the encode.
+
+        ex = ShardExchange(n_rows_global, vocab_size, device)
+        for batch in batches:
+            done = ex.submit(begins, ends, ids)      # local shard -> an EARLIER batch's global (begins, ends, ids), or None
+        rest = ex.flush()                            # list of the batches still in flight, oldest first
+
+    submit(k) enqueues, on the caller's stream and without waiting for the GPU: the pack of batch k (HIP kernel); its
+    all-gather (asynchronous: RCCL's own stream, so the wires travel over xGMI while the caller encodes batch k+1);
+    and the unpack of batch k-1, whose gather had the whole encode of batch k to finish.  It hands back batch k-2,
+    reading a 32-byte verdict the unpack left in pinned memory.  Up to three batches are with the exchange; the local
+    tensors of a batch must stay untouched until that batch is handed back (a shard that outgrew the agreed pad is
+    packed again from them), so a caller cycling output buffers needs four sets.
+    Tensors may be CUDA (RCCL) or CPU (gloo; the kernels then go through the library's host-memory path -- the CPU
+    tests run that with the emulator build).
+    """
+
+    def __init__(self, n_rows: int, vocab_size: int, device, group=None, lib=None, pad_ids: int = 0, headroom: float = 1.125):
+        self.lib = lib if lib is not None else L.load()
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_rows = int(n_rows)
+        self.device = torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        self.id_bytes = 2 if int(vocab_size) <= 65536 else 4
+        self.headroom = float(headroom)
+        self.pad_ids = _round_up(pad_ids, 8)
+        self._h = C.c_void_p()
+        L.check(self.lib, self.lib.ovtk_shard_exchange_create(self.world, C.c_int64(self.n_rows), self.id_bytes,
+                                                              (self.device.index or 0) if self.cuda else 0, C.byref(self._h)))
+        self.max_rows = int(self.lib.ovtk_shard_max_rows(self._h))
+        self._wires = {}          # slot -> (send, recv); two slots: a wire is free again once its batch is unpacked
+        self._verdicts = [self._verdict_slot() for _ in range(2)]
+        self._k = 0
+        self._gathering = None    # batch whose all-gather is in flight
+        self._unpacking = None    # batch whose unpack is enqueued
+        self.regathers = 0
+
+    def _verdict_slot(self):
+        if not self.cuda:
+            return torch.zeros(4, dtype=torch.int64), torch.zeros(4, dtype=torch.int64), None
+        return (torch.zeros(4, dtype=torch.int64, device=self.device), torch.zeros(4, dtype=torch.int64).pin_memory(),
+                torch.cuda.Event())
+
+    def close(self):
+        if self._h:
+            if self.cuda:
+                torch.cuda.synchronize(self.device)
+            self.lib.ovtk_shard_exchange_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown
+            pass
+
+    # -- plumbing
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr())
+
+    def _stream_ptr(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream) if self.cuda else C.c_void_p(0)
+
+    @property
+    def _mem(self):
+        return L.MEM_DEVICE if self.cuda else L.MEM_HOST
+
+    def _buffers(self, slot):
+        nbytes = int(self.lib.ovtk_shard_wire_bytes(self._h, C.c_int64(self.pad_ids)))
+        w = self._wires.get(slot)
+        if w is None or w[0].numel() != nbytes:
+            w = (torch.empty(nbytes, dtype=torch.uint8, device=self.device),
+                 torch.empty(nbytes * self.world, dtype=torch.uint8, device=self.device))
+            self._wires[slot] = w
+        return w
+
+    def _agree_pad(self, n_local: int):
+        """First batch: one MAX all-reduce fixes the pad for the batches that follow."""
+        t = torch.tensor([n_local], dtype=torch.int64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        self.pad_ids = max(self.pad_ids, _round_up(int(t.item()) * self.headroom + 8, 8))
+
+    def _start_gather(self, local, slot):
+        begins, ends, ids = local
+        send, recv = self._buffers(slot)
+        L.check(self.lib, self.lib.ovtk_shard_pack(self._h, self._ptr(begins), self._ptr(ends), self._ptr(ids), C.c_int64(begins.numel()),
+                                                   C.c_int64(ids.numel()), C.c_int64(self.pad_ids), self._ptr(send), self._mem,
+                                                   self._stream_ptr()))
+        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)  # RCCL's stream waits for the pack
+        return dict(local=local, slot=slot, work=work, recv=recv, pad=self.pad_ids)
+
+    def _start_unpack(self, b):
+        """Gathered wires -> global ragged tensor; only enqueues (CUDA)."""
+        pad, cap = b["pad"], b["pad"] * self.world
+        b["work"].wait()   # CUDA: the caller's stream waits for RCCL's stream; the host does not block
+        begins = torch.empty(max(self.n_rows, 1), dtype=torch.int32, device=self.device)
+        ends = torch.empty(max(self.n_rows, 1), dtype=torch.int32, device=self.device)
+        ids = torch.empty(max(cap, 1), dtype=torch.int32, device=self.device)
+        res, host, done = self._verdicts[b["slot"]]
+        L.check(self.lib, self.lib.ovtk_shard_unpack(self._h, self._ptr(b["recv"]), C.c_int64(pad), self._ptr(begins), self._ptr(ends),
+                                                     self._ptr(ids), C.c_int64(cap), self._ptr(res), self._mem, self._stream_ptr()))
+        if self.cuda:
+            host.copy_(res, non_blocking=True)
+            done.record()
+        else:
+            host = res
+        b.update(out=(begins, ends, ids), res=host, done=done)
+        return b
+
+    def _collect(self, b):
+        """Verdict of an unpack (waits for it if need be) -> the global tensor, or the exchange again with a larger pad."""
+        while True:
+            if b["done"] is not None:
+                b["done"].synchronize()
+            n_ids, biggest, status = b["res"][:3].tolist()
+            if status == L.E_CAPACITY and biggest > b["pad"]:
+                # Every rank sees the same lens, so every rank takes this branch together.
+                self.regathers += 1
+                self.pad_ids = max(self.pad_ids, _round_up(biggest * self.headroom + 8, 8))
+                b = self._start_unpack(self._start_gather(b["local"], b["slot"]))
+                continue
+            if status != L.OVTK_OK:
+                raise L.OvtkError(status, "shard exchange failed (see ovtk_shard_result in include/ovtk_amd.h)")
+            begins, ends, ids = b["out"]
+            return begins[: self.n_rows], ends[: self.n_rows], ids[:n_ids]
+
+    # -- API
+    def submit(self, begins: torch.Tensor, ends: torch.Tensor, ids: torch.Tensor):
+        local = (begins.contiguous(), ends.contiguous(), ids.contiguous())
+        if self.pad_ids == 0:
+            self._agree_pad(ids.numel())
+        done = self._collect(self._unpacking) if self._unpacking is not None else None   # frees the slot reused below
+        self._unpacking = None
+        started = self._start_gather(local, self._k & 1)
+        self._k += 1
+        if self._gathering is not None:
+            self._unpacking = self._start_unpack(self._gathering)
+        self._gathering = started
+        return done
+
+    def flush(self):
+        out = []
+        if self._unpacking is not None:
+            out.append(self._collect(self._unpacking))
+        if self._gathering is not None:
+            out.append(self._collect(self._start_unpack(self._gathering)))
+        self._unpacking = self._gathering = None
+        return out
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def all_gather_ragged(begins: torch.Tensor, ends: torch.Tensor, ids: torch.Tensor, n_rows: int, vocab_size: int = 1 << 31,
+                      group=None, lib=None):
+    """Unpipelined form: local ragged ids of every rank -> the global ragged tensor (begins, ends, ids) in rank
+    order, identical on all ranks.  n_rows: global row count (shard_rows() decides who owns what)."""
+    ex = ShardExchange(n_rows, vocab_size, ids.device, group=group, lib=lib)
+    ex.submit(begins, ends, ids)
+    out = ex.flush()[-1]
+    ex.close()
+    return out

@@ -268,6 +268,32 @@ class FusedSplitBPE:
         L.check(lib, lib.ovtk_encode_run(self.split._h, self.bpe._h, C.byref(rs), pskips, C.byref(out), m.mem, m.stream))
         return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
 
+    def enqueue(self, split_inputs, bpe_constant_inputs):
+        """evaluate() in two halves for CUDA tensors (ovtk_encode_enqueue / ovtk_encode_finish): launches the kernels
+        and returns a ticket; `ticket()` waits for them and returns evaluate()'s outputs.  The host is free in between
+        (to launch the next batch, or a ShardExchange step)."""
+        has_skips = len(split_inputs) == 7
+        self.split._ensure(split_inputs[5 + has_skips])
+        self.bpe._ensure(list(split_inputs[:5]) + list(bpe_constant_inputs))
+        m = _Mem(split_inputs[4])
+        if not m.torch:
+            raise L.OvtkError(L.E_ARG, "enqueue() needs device-resident (torch CUDA) inputs")
+        rs, (rb, _, _, _, c) = _ragged_in(m, split_inputs)
+        _, pskips = (m.inp(split_inputs[5], "bool") if has_skips else (None, None))
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        cap = len(c)
+        ids, pids = m.alloc(cap, "i32")
+        out = L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
+        lib = self.bpe._lib
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_encode_enqueue(self.split._h, self.bpe._h, C.byref(rs), pskips, C.byref(out), m.stream, C.byref(pending)))
+
+        def ticket(_keep=m):
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(out)))
+            return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+        return ticket
+
 
 class WordpieceTokenizer(_Op):
     """Reference: src/wordpiece_tokenizer.cpp (evaluate :49-133).  Inputs: ragged strings (5), vocab (3),

@@ -269,6 +269,8 @@ static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int b
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T> static inline T __hip_atomic_load(T* p, int, int) { return *p; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
@@ -303,6 +305,8 @@ static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }

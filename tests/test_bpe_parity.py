@@ -276,3 +276,44 @@ def test_handle_reuse_and_determinism(backend):
         ref = orc(*rs(rb, re_, b, e, c)[:5])
         for _ in range(2):
             assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [pat], tok.consts), backend.host)
+
+
+def test_enqueue_finish_overlapped(gpu_backend):
+    """ovtk_encode_enqueue / ovtk_encode_finish: three batches launched back to back, finished afterwards in order --
+    each equals the oracle, workspaces do not bleed into each other (every call in flight leases its own)."""
+    backend = gpu_backend
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    batches, refs, tickets = [], [], []
+    for i, (n, target, kind) in enumerate([(3000, 300, "zipf"), (500, 900, "mixed"), (3000, 120, "uniform")]):
+        b, e, c = TextModel(n + i, kind).batch(n, target)
+        rb, re_ = ragged_rows(n)
+        refs.append(orc(*rs(rb, re_, b, e, c)[:5]))
+        batches.append(backend.data([rb, re_, b, e, c]))
+    for data in batches:
+        tickets.append(fused.enqueue(data + [pat], tok.consts))
+    for ref, ticket in zip(refs, tickets):
+        assert_same(ref, ticket(), backend.host, "enqueue/finish")
+    with pytest.raises(L.OvtkError):   # host arrays have no asynchronous form
+        fused.enqueue([np.asarray(x.cpu()) for x in batches[0]] + [pat], tok.consts)
+
+
+@pytest.mark.parametrize("rows_per_ticket", [1, 2, 5])
+def test_row_tickets_same_result(backend, rows_per_ticket):
+    """ovtk_set_row_tickets: rows handed out dynamically (for a GPU shared with a collective) -- identical output."""
+    tok = BpeTok.load("gpt2_small")
+    n = 70 if backend.name == "emu" else 20000
+    b, e, c = TextModel(99, "mixed").batch(n, 200)
+    rb, re_ = ragged_rows(n)
+    ref = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(rb, re_, b, e, c)[:5])
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    L.check(backend.lib, backend.lib.ovtk_set_row_tickets(rows_per_ticket))
+    try:
+        for _ in range(2):
+            assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [tok.pattern_u8()], tok.consts), backend.host)
+    finally:
+        L.check(backend.lib, backend.lib.ovtk_set_row_tickets(0))
+    with pytest.raises(L.OvtkError):
+        L.check(backend.lib, backend.lib.ovtk_set_row_tickets(-1))

@@ -1,13 +1,19 @@
-"""N > 1 path on CPU: gloo, world_size 2 -- the row-shard + all-gather exchange of openvino_tokenizers_amd.distributed."""
+"""N > 1 path: the row-shard exchange of openvino_tokenizers_amd.distributed.
+CPU: gloo, world_size 2 and 3, pack/unpack kernels through the emulator build.  GPU: the same exchange over RCCL
+("nccl") in a one-rank group on the box's single MI355X -- streams, async work handles and the HIP kernels for real."""
 import os
 import socket
+from pathlib import Path
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from openvino_tokenizers_amd.distributed import all_gather_ragged, shard_rows
+from openvino_tokenizers_amd.distributed import ShardExchange, all_gather_ragged, shard_rows
+
+EMU = Path(__file__).parent / "emu" / "build" / "libovtk_emu.so"
 
 
 def _free_port():
@@ -16,21 +22,49 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, lens_all, ids_all, q):
+def _local_shard(lens_all, ids_all, rank, world, device="cpu"):
+    """What a rank's local encode returns: offsets relative to its own ids."""
+    lo, hi = shard_rows(len(lens_all), rank, world)
+    ends_all = np.cumsum(lens_all)
+    begins_all = ends_all - lens_all
+    t0 = int(begins_all[lo]) if lo < len(lens_all) else int(ends_all[-1] if len(ends_all) else 0)
+    t1 = int(ends_all[hi - 1]) if hi > lo else t0
+    b = torch.as_tensor((begins_all[lo:hi] - t0).astype(np.int32), device=device)
+    e = torch.as_tensor((ends_all[lo:hi] - t0).astype(np.int32), device=device)
+    ids = torch.as_tensor(ids_all[t0:t1].astype(np.int32), device=device)
+    return b, e, ids
+
+
+def _batches(seed, n_rows, vocab, n_batches=4):
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n_batches):
+        lens = rng.integers(0, 9 + 6 * k, size=n_rows).astype(np.int64)   # later batches outgrow the first pad
+        out.append((lens, rng.integers(0, vocab, size=int(lens.sum())).astype(np.int64)))
+    return out
+
+
+def _worker(rank, world, port, n_rows, vocab, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        lo, hi = shard_rows(len(lens_all), rank, world)
-        ends_all = np.cumsum(lens_all)
-        begins_all = ends_all - lens_all
-        t0 = int(begins_all[lo]) if lo < len(lens_all) else int(ends_all[-1])
-        t1 = int(ends_all[hi - 1]) if hi > lo else t0
-        # what a rank's local encode returns: offsets relative to its own ids
-        b = torch.as_tensor((begins_all[lo:hi] - t0).astype(np.int32))
-        e = torch.as_tensor((ends_all[lo:hi] - t0).astype(np.int32))
-        ids = torch.as_tensor(ids_all[t0:t1].astype(np.int32))
-        gb, ge, gi = all_gather_ragged(b, e, ids)
-        q.put((rank, gb.numpy(), ge.numpy(), gi.numpy()))
+        from openvino_tokenizers_amd import _lib as L
+        lib = L.load(EMU)
+        batches = _batches(7, n_rows, vocab)
+        ex = ShardExchange(n_rows, vocab, "cpu", lib=lib)
+        got = []
+        for lens, ids in batches:
+            done = ex.submit(*_local_shard(lens, ids, rank, world))
+            if done is not None:
+                got.append([t.numpy().copy() for t in done])
+        got += [[t.numpy().copy() for t in b] for b in ex.flush()]
+        regathers = ex.regathers
+        ex.close()
+        one = all_gather_ragged(*_local_shard(*batches[0], rank, world), n_rows=n_rows, vocab_size=vocab, lib=lib)
+        q.put((rank, got, [t.numpy().copy() for t in one], regathers, ex.id_bytes))
+    except BaseException as exc:  # the parent fails on this instead of waiting for its timeout
+        q.put((rank, repr(exc), None, 0, 0))
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -45,21 +79,50 @@ def test_shard_rows_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_all_gather_ragged_gloo_world2():
-    rng = np.random.default_rng(0)
-    lens = rng.integers(0, 9, size=37).astype(np.int64)  # uneven shards, some empty rows
-    ids = rng.integers(0, 50000, size=int(lens.sum())).astype(np.int64)
+@pytest.mark.parametrize("world, n_rows, vocab", [(2, 37, 50000), (3, 10, 130000), (2, 1, 100)])
+def test_shard_exchange_gloo(emu_lib, world, n_rows, vocab):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, lens, ids, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, vocab, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=120) for _ in procs]
+    results = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-        assert p.exitcode == 0
-    ends = np.cumsum(lens).astype(np.int32)
-    for _, gb, ge, gi in results:
-        assert np.array_equal(ge, ends) and np.array_equal(gb, ends - lens.astype(np.int32))
-        assert np.array_equal(gi, ids.astype(np.int32))
+    assert all(isinstance(r[1], list) for r in results), [r[1] for r in results]
+    assert all(p.exitcode == 0 for p in procs)
+    batches = _batches(7, n_rows, vocab)
+    for _, got, one, regathers, id_bytes in results:
+        assert len(got) == len(batches) and id_bytes == (2 if vocab <= 65536 else 4)
+        for (lens, ids), (gb, ge, gi) in zip(batches, got):
+            ends = np.cumsum(lens).astype(np.int32)
+            assert np.array_equal(ge, ends) and np.array_equal(gb, ends - lens.astype(np.int32))
+            assert np.array_equal(gi, ids.astype(np.int32))
+        assert np.array_equal(one[2], batches[0][1].astype(np.int32))
+        assert regathers >= 1 or n_rows == 1   # the growing batches must have forced a larger pad at least once
+
+
+@pytest.mark.gpu
+def test_shard_exchange_rccl_one_rank(hip_lib):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n_rows, vocab = 5000, 50257
+        batches = _batches(11, n_rows, vocab, n_batches=5)
+        ex = ShardExchange(n_rows, vocab, dev, lib=hip_lib)
+        got = []
+        for lens, ids in batches:
+            done = ex.submit(*_local_shard(lens, ids, 0, 1, device=dev))
+            if done is not None:
+                got.append([t.cpu().numpy() for t in done])
+        got += [[t.cpu().numpy() for t in b] for b in ex.flush()]
+        assert len(got) == len(batches) and ex.regathers >= 1
+        ex.close()
+        for (lens, ids), (gb, ge, gi) in zip(batches, got):
+            ends = np.cumsum(lens).astype(np.int32)
+            assert np.array_equal(ge, ends) and np.array_equal(gb, ends - lens.astype(np.int32))
+            assert np.array_equal(gi, ids.astype(np.int32))
+    finally:
+        dist.destroy_process_group()
