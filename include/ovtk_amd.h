@@ -262,6 +262,22 @@ int ovtk_fuze_ragged(const int32_t* ragged_begins, const int32_t* ragged_ends, i
                      const int32_t* begins, const int32_t* ends, int64_t n, int32_t* out_begins,
                      int32_t* out_ends, int mem, int device, void* stream);
 
+/* ---------------------------------------------------------------- string tensor wire format
+ * The packed u8 form of a string tensor, [i32 n][i32 begin_0][i32 end_i x n][bytes] (parse_packed_strings,
+ * src/utils.cpp:18-29): the staging step either side of the path -- ONE buffer crosses PCIe, the decomposed tensors
+ * the ops consume (begins / ends / chars) exist only in HBM.
+ * ovtk_string_tensor_unpack replaces the u8 branch of StringTensorUnpack::evaluate, src/string_tensor_unpack.cpp:53-71:
+ * `packed` lives in packed_mem (host or device), the outputs are DEVICE buffers (out->begins/ends: capacity
+ * rows_capacity; out->chars: chars_capacity); *n = strings, out->n_chars = bytes.
+ * ovtk_string_tensor_pack is the inverse (what StringTensorPack + the Python pack_strings helper produce,
+ * python/openvino_tokenizers/utils.py): device strings, gaps and order as they are -> gap-free packed buffer in
+ * packed_mem of ovtk_string_tensor_packed_bytes(n, sum of lengths) bytes. */
+int64_t ovtk_string_tensor_packed_bytes(int64_t n, int64_t n_chars);
+int ovtk_string_tensor_unpack(const uint8_t* packed, int64_t n_bytes, int packed_mem, ovtk_strings_out* out,
+                              int64_t rows_capacity, int64_t* n, int device, void* stream);
+int ovtk_string_tensor_pack(const ovtk_strings* in, uint8_t* packed, int64_t capacity, int packed_mem,
+                            int64_t* n_bytes, int device, void* stream);
+
 /* ---------------------------------------------------------------- row-shard exchange
  * No reference counterpart (the reference is single-process).  Rows shard contiguously over the ranks of one node
  * (rank r owns rows first(r) .. first(r+1), balanced like numpy.array_split); the one exchange step is an all-gather
@@ -292,6 +308,17 @@ int ovtk_shard_unpack(ovtk_shard_exchange* h, const void* wires, int64_t pad_ids
                       int32_t* out_ends, int32_t* out_ids, int64_t out_capacity, ovtk_shard_result* result,
                       int mem, void* stream);
 void ovtk_shard_exchange_destroy(ovtk_shard_exchange* h);
+
+/* ---------------------------------------------------------------- TrieTokenizer (RWKV)
+ * Replaces TrieTokenizer::evaluate, src/trie_tokenizer.cpp:23-81: greedy longest match over a trie of vocab[i] ->
+ * indices[i] (inputs 5-8, consumed at create like the reference's lazy init :27-45).  Where no entry matches at some
+ * byte the reference's loop never terminates (:72-75); this library returns OVTK_E_VOCAB instead.
+ * out->data capacity: the reference allocates in->strings.n_chars ids (:60). */
+typedef struct ovtk_trie_tokenizer ovtk_trie_tokenizer;
+int ovtk_trie_tokenizer_create(const ovtk_strings* vocab, const int32_t* indices, int device, ovtk_trie_tokenizer** out);
+int ovtk_trie_tokenizer_run(ovtk_trie_tokenizer* h, const ovtk_ragged_strings* in, ovtk_ragged_i32_out* out, int mem,
+                            void* stream);
+void ovtk_trie_tokenizer_destroy(ovtk_trie_tokenizer* h);
 
 /* ---------------------------------------------------------------- UTF8Validate
  * Replaces UTF8Validate::evaluate, src/utf8_validate.cpp:18-143.  replace_mode 0: drop invalid bytes, 1: U+FFFD.

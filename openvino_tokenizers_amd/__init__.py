@@ -7,4 +7,4 @@ include/ovtk_amd.h; see DESIGN.md and INTEGRATION.md.
 """
 from ._lib import OvtkError, load  # noqa: F401
 from .ops import (BPETokenizer, ByteFallback, CombineSegments, FusedDetokenizer, FusedSplitBPE, FusedSplitWordpiece, FuzeRagged, RaggedToDense,  # noqa: F401
-                  RegexSplit, SpecialTokensSplit, Truncate, UTF8Validate, VocabDecoder, VocabEncoder, WordpieceTokenizer)
+                  RegexSplit, SpecialTokensSplit, StringTensorPack, StringTensorUnpack, TrieTokenizer, Truncate, UTF8Validate, VocabDecoder, VocabEncoder, WordpieceTokenizer)

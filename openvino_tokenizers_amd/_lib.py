@@ -94,6 +94,8 @@ EXPORTS = [
     "ovtk_vocab_decoder_create", "ovtk_vocab_decoder_run", "ovtk_vocab_decoder_destroy",
     "ovtk_byte_fallback", "ovtk_fuze_ragged", "ovtk_detokenize_run",
     "ovtk_utf8_validate", "ovtk_truncate", "ovtk_combine_segments",
+    "ovtk_trie_tokenizer_create", "ovtk_trie_tokenizer_run", "ovtk_trie_tokenizer_destroy",
+    "ovtk_string_tensor_packed_bytes", "ovtk_string_tensor_unpack", "ovtk_string_tensor_pack",
     "ovtk_shard_exchange_create", "ovtk_shard_max_rows", "ovtk_shard_wire_bytes", "ovtk_shard_pack", "ovtk_shard_unpack",
     "ovtk_shard_exchange_destroy",
     "ovtk_profile_enable", "ovtk_profile_reset", "ovtk_profile_get", "ovtk_profile_dump",
@@ -129,6 +131,7 @@ def load(path: os.PathLike | str | None = None) -> C.CDLL:
     lib.ovtk_device_name.restype = C.c_char_p
     lib.ovtk_profile_dump.restype = C.c_int64
     lib.ovtk_shard_wire_bytes.restype = C.c_int64
+    lib.ovtk_string_tensor_packed_bytes.restype = C.c_int64
     lib.ovtk_shard_max_rows.restype = C.c_int64
     _cache[key] = lib
     return lib

@@ -615,6 +615,149 @@ int ovtk_fuze_ragged(const int32_t* ragged_begins, const int32_t* ragged_ends, i
     return OVTK_OK;
 }
 
+// ------------------------------------------------------------------------------- TrieTokenizer
+struct ovtk_trie_tokenizer {
+    int device = 0;
+    TrieDev dev{};
+    TrieBufs bufs;
+};
+
+int ovtk_trie_tokenizer_create(const ovtk_strings* vocab, const int32_t* indices, int device, ovtk_trie_tokenizer** out) {
+    if (int rc = check_strings_arg(vocab, "trie tokenizer vocab")) return rc;
+    if (!indices || !out) return set_error(OVTK_E_ARG, "trie tokenizer: null argument");
+    if (int rc = use_device(device)) return rc;
+    auto h = std::make_unique<ovtk_trie_tokenizer>();
+    h->device = device;
+    TrieHost t;
+    for (int64_t i = 0; i < vocab->n; ++i) {  // trie_tokenizer.cpp:40-43: a later entry with the same bytes overwrites
+        const int64_t b = vocab->begins[i], e = vocab->ends[i];
+        if (b < 0 || e < b || e > vocab->n_chars) return set_error(OVTK_E_RANGE, "trie tokenizer: vocab begins/ends outside the chars tensor");
+        t.add(vocab->chars + b, size_t(e - b), indices[i]);
+    }
+    t.finalize();
+    if (int rc = h->bufs.upload(t, h->dev)) return rc;
+    OVTK_HIP(hipStreamSynchronize(nullptr));
+    *out = h.release();
+    return OVTK_OK;
+}
+
+void ovtk_trie_tokenizer_destroy(ovtk_trie_tokenizer* h) { delete h; }
+
+int ovtk_trie_tokenizer_run(ovtk_trie_tokenizer* h, const ovtk_ragged_strings* in, ovtk_ragged_i32_out* out, int mem, void* stream) {
+    if (!h || !in || !out) return set_error(OVTK_E_ARG, "null argument");
+    if (int rc = check_strings_arg(&in->strings, "trie tokenizer input")) return rc;
+    if (in->n_rows < 0 || in->n_rows >= INT32_MAX || out->data_capacity < 0) return set_error(OVTK_E_ARG, "trie tokenizer: bad size");
+    if (int rc = use_device(h->device)) return rc;
+    out->n_rows = in->n_rows;
+    out->n_data = 0;
+    if (in->n_rows == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(h->device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    TrieRows r{};
+    if (int rc = in_source(ws->in_rb, in->ragged_begins, size_t(in->n_rows) * 4, mem, s, &r.ragged_begins)) return rc;
+    if (int rc = in_source(ws->in_re, in->ragged_ends, size_t(in->n_rows) * 4, mem, s, &r.ragged_ends)) return rc;
+    if (int rc = in_source(ws->in_begins, in->strings.begins, size_t(in->strings.n) * 4, mem, s, &r.begins)) return rc;
+    if (int rc = in_source(ws->in_ends, in->strings.ends, size_t(in->strings.n) * 4, mem, s, &r.ends)) return rc;
+    if (int rc = in_source(ws->in_chars, in->strings.chars, size_t(in->strings.n_chars), mem, s, &r.chars)) return rc;
+    r.n_strings = in->strings.n;
+    r.n_chars = in->strings.n_chars;
+    r.trie = h->dev;
+    r.status = st;
+    int32_t *d_b = nullptr, *d_e = nullptr, *d_i = nullptr;
+    if (int rc = out_target(ws->out_a, out->begins, size_t(in->n_rows) * 4, mem, &d_b)) return rc;
+    if (int rc = out_target(ws->out_b, out->ends, size_t(in->n_rows) * 4, mem, &d_e)) return rc;
+    if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_i)) return rc;
+    if (int rc = scan_and_apply(*ws.ws, s, in->n_rows, TrieLen{r}, TrieApply{r, d_b, d_e, d_i},
+                                (long long)std::min<int64_t>(out->data_capacity, INT32_MAX - 1), st, "trie_tokenizer"))
+        return rc;
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    const uint32_t f = ws->host_status->flags;
+    if (f & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+    if (f & kFlagItemsOverflow)
+        return set_error(OVTK_E_VOCAB, "TrieTokenizer: no vocabulary entry matches at some byte (the reference does not terminate on this input)");
+    if (f & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "TrieTokenizer: output ids buffer too small");
+    out->n_data = ws->host_status->n_out;
+    int err = 0;
+    err = err ? err : copy_back(out->begins, d_b, size_t(in->n_rows) * 4, mem, s);
+    err = err ? err : copy_back(out->ends, d_e, size_t(in->n_rows) * 4, mem, s);
+    err = err ? err : copy_back(out->data, d_i, size_t(out->n_data) * 4, mem, s);
+    if (err) return err;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- string tensor wire format
+int64_t ovtk_string_tensor_packed_bytes(int64_t n, int64_t n_chars) { return 8 + 4 * n + n_chars; }
+
+int ovtk_string_tensor_unpack(const uint8_t* packed, int64_t n_bytes, int packed_mem, ovtk_strings_out* out,
+                              int64_t rows_capacity, int64_t* n, int device, void* stream) {
+    if (!packed || !out || !n || rows_capacity < 0 || out->chars_capacity < 0) return set_error(OVTK_E_ARG, "string_tensor_unpack: bad arguments");
+    if (int rc = use_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto peek = [&](int64_t byte_off, int32_t* v) -> int {  // one header word
+        if (packed_mem == OVTK_MEM_HOST) { std::memcpy(v, packed + byte_off, 4); return OVTK_OK; }
+        OVTK_HIP(hipMemcpyAsync(v, packed + byte_off, 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipStreamSynchronize(s));
+        return OVTK_OK;
+    };
+    // the reference's format checks (src/utils.cpp:21-25)
+    if (n_bytes < 4) return set_error(OVTK_E_ARG, "Incorrect packed string tensor format: no batch size in the packed string tensor");
+    int32_t batch = 0, total = 0;
+    if (int rc = peek(0, &batch)) return rc;
+    if (batch < 0 || n_bytes < 8 + 4 * int64_t(batch))
+        return set_error(OVTK_E_ARG, "Incorrect packed string tensor format: the packed string tensor must contain first string offset and end indices");
+    *n = batch;
+    out->n_chars = 0;
+    if (batch == 0) return OVTK_OK;
+    if (int rc = peek(4 + 4 * int64_t(batch), &total)) return rc;  // end_ids[batch - 1] (string_tensor_unpack.cpp:59)
+    if (total < 0 || 8 + 4 * int64_t(batch) + total > n_bytes) return set_error(OVTK_E_RANGE, "packed string tensor: end offsets exceed the buffer");
+    if (batch > rows_capacity || total > out->chars_capacity) return set_error(OVTK_E_CAPACITY, "string_tensor_unpack: output buffers too small");
+    const hipMemcpyKind kind = packed_mem == OVTK_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    OVTK_HIP(hipMemcpyAsync(out->begins, packed + 4, size_t(batch) * 4, kind, s));  // begin_ids = words 1.., end_ids = words 2.. (:26-27)
+    OVTK_HIP(hipMemcpyAsync(out->ends, packed + 8, size_t(batch) * 4, kind, s));
+    if (total) OVTK_HIP(hipMemcpyAsync(out->chars, packed + 8 + 4 * size_t(batch), size_t(total), kind, s));
+    if (packed_mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));  // the host buffer may be reused on return
+    out->n_chars = total;
+    return OVTK_OK;
+}
+
+int ovtk_string_tensor_pack(const ovtk_strings* in, uint8_t* packed, int64_t capacity, int packed_mem, int64_t* n_bytes,
+                            int device, void* stream) {
+    if (int rc = check_strings_arg(in, "string_tensor_pack input")) return rc;
+    if (!packed || !n_bytes || capacity < 8 + 4 * in->n) return set_error(OVTK_E_CAPACITY, "string_tensor_pack: packed buffer too small for the header");
+    if (int rc = use_device(device)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    uint8_t* d_packed = packed;
+    if (packed_mem == OVTK_MEM_HOST) {
+        if (int rc = ws->out_e.ensure(size_t(capacity))) return rc;
+        d_packed = ws->out_e.as<uint8_t>();
+    }
+    int32_t* header = reinterpret_cast<int32_t*>(d_packed);
+    const long long cap = std::min<long long>(capacity - 8 - 4 * in->n, INT32_MAX - 1);
+    OVTK_LAUNCH(ws->marks, "pack_header", pack_header_kernel, 1, kWave, s, header, int32_t(in->n));
+    if (in->n) {
+        OVTK_LAUNCH(ws->marks, "check_strings", check_strings_kernel, grid_for_elems(in->n), kBlockThreads, s, in->begins, in->ends,
+                    (long long)in->n, (long long)in->n_chars, st);
+        if (int rc = scan_and_apply(*ws.ws, s, in->n, PackLen{in->begins, in->ends, (long long)in->n_chars},
+                                    PackApply{in->begins, in->chars, header, d_packed + 8 + 4 * in->n}, cap, st, "string_pack"))
+            return rc;
+    }
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside the chars tensor");
+    if (ws->host_status->flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "string_tensor_pack: packed buffer too small");
+    *n_bytes = 8 + 4 * in->n + ws->host_status->n_out;
+    if (packed_mem == OVTK_MEM_HOST) {
+        OVTK_HIP(hipMemcpyAsync(packed, d_packed, size_t(*n_bytes), hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipStreamSynchronize(s));
+    }
+    return OVTK_OK;
+}
+
 // ------------------------------------------------------------------------------- row-shard exchange
 struct ovtk_shard_exchange {
     int device = 0;

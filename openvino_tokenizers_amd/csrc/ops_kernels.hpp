@@ -510,6 +510,67 @@ static __global__ __launch_bounds__(kBlockThreads) void fuze_kernel(const int32_
     }
 }
 
+// ------------------------------------------------------------------------------- TrieTokenizer
+// src/trie_tokenizer.cpp:66-78, one lane per ragged row: a counting walk sizes the row (device scan = the reference's
+// running ragged_offset), a second walk writes the ids.  emit(token) per match; returns false where nothing matches.
+struct TrieRows {
+    const int32_t* ragged_begins;
+    const int32_t* ragged_ends;
+    const int32_t* begins;
+    const int32_t* ends;
+    const uint8_t* chars;
+    long long n_strings, n_chars;
+    TrieDev trie;
+    RunStatus* status;
+
+    template <class Emit>
+    __device__ void walk(long long row, Emit&& emit) const {
+        const long long cb = ragged_begins[row], ce = ragged_ends[row];
+        if (cb < 0 || ce < cb || ce > n_strings) {
+            atomicOr(&status->flags, kFlagRange);
+            return;
+        }
+        for (long long col = cb; col < ce; ++col) {
+            const long long b = begins[col], e = ends[col];
+            if (b < 0 || e < b || e > n_chars) {
+                atomicOr(&status->flags, kFlagRange);
+                return;
+            }
+            const uint8_t* s = chars + b;
+            const int n = int(e - b);
+            int idx = 0;
+            while (idx < n) {
+                const int tok = trie_longest(trie, trie.root, [&](int i) -> uint32_t { return s[i]; }, n, idx);
+                if (tok == -1) {  // the reference spins here forever (:72-75)
+                    atomicOr(&status->flags, kFlagItemsOverflow);
+                    return;
+                }
+                emit(tok);
+            }
+        }
+    }
+};
+struct TrieLen {
+    TrieRows r;
+    __device__ long long operator()(long long row) const {
+        long long n = 0;
+        r.walk(row, [&](int) { ++n; });
+        return n;
+    }
+};
+struct TrieApply {
+    TrieRows r;
+    int32_t* out_begins;
+    int32_t* out_ends;
+    int32_t* out_ids;
+    __device__ void operator()(long long row, long long off, long long len) const {
+        out_begins[row] = int32_t(off);
+        out_ends[row] = int32_t(off + len);
+        int32_t* dst = out_ids + off;
+        r.walk(row, [&](int tok) { *dst++ = tok; });
+    }
+};
+
 // ------------------------------------------------------------------------------- UTF8Validate
 // src/utf8_validate.cpp:18-143 walked symbol by symbol instead of byte by byte: a lead byte promises `need`
 // continuation bytes; when one is missing (or the string ends) the symbol is replaced once and the offending byte
@@ -688,6 +749,37 @@ static __global__ __launch_bounds__(kBlockThreads) void combine_copy_kernel(Comb
             }
             off += len;
         }
+    }
+}
+
+// ------------------------------------------------------------------------------- string tensor wire format
+// Pack (the inverse of parse_packed_strings, src/utils.cpp:18-29): string i goes to bytes[off_i, off_i + len_i) and
+// its end offset to header word 2 + i; off = exclusive scan of the lengths.
+struct PackLen {
+    const int32_t* begins;
+    const int32_t* ends;
+    long long n_chars;
+    __device__ long long operator()(long long i) const {
+        const long long b = begins[i], e = ends[i];
+        return (b < 0 || e < b || e > n_chars) ? 0 : e - b;  // flagged by check_strings_kernel
+    }
+};
+struct PackApply {
+    const int32_t* begins;
+    const uint8_t* chars;
+    int32_t* header;  // [n, begin_0, end_0 .. end_{n-1}]
+    uint8_t* bytes;
+    __device__ void operator()(long long i, long long off, long long len) const {
+        header[2 + i] = int32_t(off + len);
+        const uint8_t* src = chars + begins[i];
+        uint8_t* dst = bytes + off;
+        for (long long k = 0; k < len; ++k) dst[k] = src[k];
+    }
+};
+static __global__ __launch_bounds__(kWave) void pack_header_kernel(int32_t* header, int32_t n) {
+    if (threadIdx.x == 0) {
+        header[0] = n;
+        header[1] = 0;
     }
 }
 

@@ -491,6 +491,117 @@ class ByteFallback(_Op):
         return [ob[:len(b)], oe[:len(b)], oc[:out.n_chars]]
 
 
+class TrieTokenizer(_Op):
+    """Reference: src/trie_tokenizer.cpp (evaluate :23-81).  Inputs: ragged strings (5), vocab (3), indices i32.
+    Outputs: begins, ends, ids."""
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.ovtk_trie_tokenizer_destroy(self._h)
+            self._h = None
+
+    def _ensure(self, inputs):
+        if self._h:
+            return
+        keep = []
+        vocab = _strings_struct(inputs[5], inputs[6], inputs[7], keep)
+        idx = _host(inputs[8], np.int32).reshape(-1)
+        if len(idx) != vocab.n:
+            raise L.OvtkError(L.E_ARG, "Vocab size must be equal to Indices size")   # trie_tokenizer.cpp:38
+        self._chk(self._lib.ovtk_trie_tokenizer_create(C.byref(vocab), idx.ctypes.data_as(C.c_void_p), self.device, C.byref(self._h)))
+
+    def evaluate(self, inputs):
+        self._ensure(inputs)
+        m = _Mem(inputs[4])
+        rs, (rb, _, _, _, c) = _ragged_in(m, inputs)
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        cap = len(c)   # trie_tokenizer.cpp:60
+        ids, pids = m.alloc(cap, "i32")
+        out = L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
+        self._chk(self._lib.ovtk_trie_tokenizer_run(self._h, C.byref(rs), C.byref(out), m.mem, m.stream))
+        return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+
+
+def _device_alloc(n, kind, device):
+    """Device-side output of the staging ops: a torch CUDA tensor, or -- no GPU in the process: the emulator build,
+    whose "device" memory is host memory -- a numpy array."""
+    n = max(int(n), 1)
+    try:
+        import torch
+        if torch.cuda.is_available():
+            dt = {"i32": torch.int32, "u8": torch.uint8}[kind]
+            t = torch.empty(n, dtype=dt, device=torch.device("cuda", device))
+            return t, C.c_void_p(t.data_ptr()), C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    except ImportError:  # pragma: no cover
+        pass
+    a = np.empty(n, dtype=_NP[kind])
+    return a, C.c_void_p(a.ctypes.data), C.c_void_p(0)
+
+
+class StringTensorUnpack(_Op):
+    """Reference: src/string_tensor_unpack.cpp (evaluate :45-78, the packed-u8 branch; the element::string branch is a
+    host container and stays with the caller).  Input: packed u8 [i32 n][i32 begin_0][i32 end_i x n][bytes] in HOST
+    (numpy) or device (torch CUDA) memory.  Outputs: begins, ends, chars in DEVICE memory -- the H2D staging step."""
+
+    def __init__(self, mode="begins_ends", device=0, lib=None):
+        super().__init__(device, lib)
+        if mode != "begins_ends":
+            raise L.OvtkError(L.E_ARG, f"StringTensorUnpack supporst only 'begins_ends' mode, but get {mode}")
+
+    def evaluate(self, inputs):
+        packed = inputs[0]
+        on_dev = _is_torch(packed) and packed.device.type == "cuda"
+        if on_dev:
+            packed = packed.contiguous()
+            ptr, nbytes, mem = C.c_void_p(packed.data_ptr()), packed.numel(), L.MEM_DEVICE
+        else:
+            packed = _host(packed, np.uint8)
+            ptr, nbytes, mem = C.c_void_p(packed.ctypes.data), packed.size, L.MEM_HOST
+        rows = max((nbytes - 8) // 4, 0)
+        ob, pob, stream = _device_alloc(rows, "i32", self.device)
+        oe, poe, _ = _device_alloc(rows, "i32", self.device)
+        oc, poc, _ = _device_alloc(nbytes, "u8", self.device)
+        out = L.StringsOut(pob, poe, poc, nbytes, 0)
+        n = C.c_int64(0)
+        self._chk(self._lib.ovtk_string_tensor_unpack(ptr, C.c_int64(nbytes), mem, C.byref(out), C.c_int64(rows), C.byref(n),
+                                                      self.device, stream))
+        return [ob[:n.value], oe[:n.value], oc[:out.n_chars]]
+
+
+class StringTensorPack(_Op):
+    """Inverse of StringTensorUnpack (OpenVINO's opset15 StringTensorPack followed by the packed-u8 serialisation of
+    python/openvino_tokenizers/utils.py): begins, ends, chars in DEVICE memory -> one packed u8 buffer, returned in
+    host memory (`to_host=True`, the D2H staging step) or left on the device."""
+
+    def evaluate(self, inputs, to_host=True):
+        m = _Mem(inputs[2])
+        if not m.torch:
+            try:  # host arrays are uploaded first; without a GPU (emulator build) host memory IS device memory
+                import torch
+                if torch.cuda.is_available():
+                    dev = torch.device("cuda", self.device)
+                    kinds = (np.int32, np.int32, np.uint8)
+                    return self.evaluate([torch.as_tensor(_host(x, k), device=dev) for x, k in zip(inputs, kinds)], to_host)
+            except ImportError:  # pragma: no cover
+                pass
+        b, pb = m.inp(inputs[0], "i32")
+        e, pe = m.inp(inputs[1], "i32")
+        c, pc = m.inp(inputs[2], "u8")
+        s = L.Strings(pb, pe, pc, len(b), len(c))
+        total = int((e - b).clamp(min=0).sum()) if m.torch else int(np.maximum(e.astype(np.int64) - b, 0).sum())
+        cap = int(self._lib.ovtk_string_tensor_packed_bytes(C.c_int64(len(b)), C.c_int64(total)))
+        if to_host or not m.torch:
+            buf = np.empty(cap, np.uint8)
+            ptr, mem = C.c_void_p(buf.ctypes.data), L.MEM_HOST
+        else:
+            buf = m.t.empty(cap, dtype=m.t.uint8, device=m.device)
+            ptr, mem = C.c_void_p(buf.data_ptr()), L.MEM_DEVICE
+        n = C.c_int64(0)
+        self._chk(self._lib.ovtk_string_tensor_pack(C.byref(s), ptr, C.c_int64(cap), mem, C.byref(n), self.device, m.stream))
+        return [buf[:n.value]]
+
+
 class UTF8Validate(_Op):
     """Reference: src/utf8_validate.cpp (evaluate :18-143).  Strings (3) -> strings (3); attribute replace_mode."""
 

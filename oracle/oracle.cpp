@@ -729,6 +729,45 @@ extern "C" int orc_ragged_to_dense(const int32_t* begins, const int32_t* ends, i
 }
 
 // =======================================================================================
+// TrieTokenizer : src/trie_tokenizer.cpp:23-81 (RWKV).  Greedy longest match from a trie of vocab[i] -> indices[i];
+// where nothing matches the reference's loop never advances (:72-75) -- reported as ORC_E_VOCAB here.
+// =======================================================================================
+struct orc_trie_tokenizer { TrieNode trie; };
+
+extern "C" int orc_trie_tokenizer_create(const int32_t* v_begins, const int32_t* v_ends, const uint8_t* v_chars, int64_t V,
+                                         const int32_t* indices, orc_trie_tokenizer** out) {
+    auto t = std::make_unique<orc_trie_tokenizer>();
+    for (int64_t i = 0; i < V; ++i) t->trie.add(v_chars + v_begins[i], size_t(v_ends[i] - v_begins[i]), indices[i]);
+    *out = t.release();
+    return ORC_OK;
+}
+extern "C" void orc_trie_tokenizer_destroy(orc_trie_tokenizer* t) { delete t; }
+
+extern "C" int orc_trie_tokenizer_run(const orc_trie_tokenizer* t, const int32_t* rb, const int32_t* re, int64_t B,
+                                      const int32_t* begins, const int32_t* ends, const uint8_t* chars, int32_t* out_begins,
+                                      int32_t* out_ends, int32_t* out_ids, int64_t cap, int64_t* n_ids) {
+    int64_t off = 0;
+    for (int64_t row = 0; row < B; ++row) {
+        out_begins[row] = int32_t(off);
+        for (int32_t col = rb[row]; col < re[row]; ++col) {
+            const uint8_t* s = chars + begins[col];
+            const int n = ends[col] - begins[col];
+            int idx = 0;
+            while (idx < n) {
+                const int before = idx;
+                const int tok = t->trie.find_longest(s, n, idx);
+                if (idx == before) return fail(ORC_E_VOCAB, "trie tokenizer: no vocabulary entry matches (the reference loops forever)");
+                if (off >= cap) return fail(ORC_E_CAPACITY, "trie tokenizer: ids overflow");
+                out_ids[off++] = tok;
+            }
+        }
+        out_ends[row] = int32_t(off);
+    }
+    *n_ids = off;
+    return ORC_OK;
+}
+
+// =======================================================================================
 // UTF8Validate : src/utf8_validate.cpp:18-143.  A byte-at-a-time automaton: `pending` continuation bytes
 // are still owed to a symbol of `width` bytes whose code point is being assembled in `cp`.
 // Output offsets start at begins[0] like the reference's `out_idx` (:46).

@@ -112,6 +112,15 @@ int orc_ragged_to_dense(const int32_t* begins, const int32_t* ends, int64_t B,
                         int32_t target_dim, const void* default_value,
                         int pad_right, int pad_max_length, void* out_dense, uint8_t* out_mask);
 
+/* ---- TrieTokenizer : src/trie_tokenizer.cpp:23-81 ---- */
+typedef struct orc_trie_tokenizer orc_trie_tokenizer;
+int orc_trie_tokenizer_create(const int32_t* v_begins, const int32_t* v_ends, const uint8_t* v_chars, int64_t V,
+                              const int32_t* indices, orc_trie_tokenizer** out);
+int orc_trie_tokenizer_run(const orc_trie_tokenizer* t, const int32_t* rb, const int32_t* re, int64_t B,
+                           const int32_t* begins, const int32_t* ends, const uint8_t* chars, int32_t* out_begins,
+                           int32_t* out_ends, int32_t* out_ids, int64_t cap, int64_t* n_ids);
+void orc_trie_tokenizer_destroy(orc_trie_tokenizer* t);
+
 /* ---- UTF8Validate : src/utf8_validate.cpp:18-143.  out_chars capacity: the reference allocates 3 * n_chars (:31-33);
  * offsets start at begins[0] (:46), *n_chars_out = last offset - begins[0] (:140). ---- */
 int orc_utf8_validate(const int32_t* begins, const int32_t* ends, const uint8_t* chars, int64_t n, int replace_mode,

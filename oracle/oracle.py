@@ -279,6 +279,37 @@ class WordpieceTokenizer:
         return ob, oe, ids[:n.value].copy()
 
 
+# --------------------------------------------------------------------------- TrieTokenizer
+class TrieTokenizer:
+    def __init__(self, vocab, indices):
+        vb, ve, vc = pack_strings(vocab)
+        idx, pidx = _i32(indices)
+        self._h = C.c_void_p()
+        _chk(lib().orc_trie_tokenizer_create(vb.ctypes.data_as(i32p), ve.ctypes.data_as(i32p), _u8(vc)[1], C.c_int64(len(vb)),
+                                             pidx, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_trie_tokenizer_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
+
+    def __call__(self, rb, re_, begins, ends, chars):
+        rb, prb = _i32(rb)
+        re_, pre = _i32(re_)
+        begins, pb = _i32(begins)
+        ends, pe = _i32(ends)
+        chars, pc = _u8(chars)
+        B, cap = len(rb), max(len(chars), 1)
+        ob, oe, ids = np.zeros(B, np.int32), np.zeros(B, np.int32), np.zeros(cap, np.int32)
+        n = C.c_int64()
+        _chk(lib().orc_trie_tokenizer_run(self._h, prb, pre, C.c_int64(B), pb, pe, pc, ob.ctypes.data_as(i32p),
+                                          oe.ctypes.data_as(i32p), ids.ctypes.data_as(i32p), C.c_int64(cap), C.byref(n)))
+        return ob, oe, ids[:n.value].copy()
+
+
 # --------------------------------------------------------------------------- VocabEncoder
 class VocabEncoder:
     def __init__(self, keys, values):

@@ -1,0 +1,86 @@
+"""TrieTokenizer (src/trie_tokenizer.cpp, RWKV world tokenizer): greedy longest match; kernel vs oracle, and the oracle
+vs a ten-line pure-Python statement of the same rule."""
+import numpy as np
+import pytest
+
+from openvino_tokenizers_amd import _lib as L
+from openvino_tokenizers_amd.ops import TrieTokenizer
+from oracle import oracle as O
+from tests.util import assert_same
+
+
+def rwkv_like_vocab(rng, n_extra=3000):
+    """All 256 single bytes (ids 1..256, like the RWKV vocabulary file) + random multi-byte entries, some of them
+    prefixes of others, one duplicate string (the later id wins, trie_tokenizer.cpp:40-43)."""
+    vocab = [bytes([b]) for b in range(256)]
+    alphabet = list(b"abcdeft \n") + [0xE4, 0xB8, 0xAD, 0xE6, 0x96, 0x87]
+    seen = set(vocab)
+    while len(vocab) < 256 + n_extra:
+        w = bytes(rng.choice(alphabet, size=int(rng.integers(2, 9))).tolist())
+        if w not in seen:
+            seen.add(w)
+            vocab.append(w)
+    vocab.append(vocab[300])
+    indices = np.arange(1, len(vocab) + 1, dtype=np.int32)
+    return vocab, indices
+
+
+def py_greedy(vocab, indices, s):
+    table = {}
+    for w, i in zip(vocab, indices.tolist()):
+        table[w] = i
+    longest = max(map(len, table))
+    out, i = [], 0
+    while i < len(s):
+        for ln in range(min(longest, len(s) - i), 0, -1):
+            if s[i:i + ln] in table:
+                out.append(table[s[i:i + ln]])
+                i += ln
+                break
+        else:
+            raise ValueError("no match")
+    return out
+
+
+def test_oracle_against_plain_python():
+    rng = np.random.default_rng(1)
+    vocab, indices = rwkv_like_vocab(rng, 500)
+    strings = [bytes(rng.choice(list(b"abcdeft \n\xe4\xb8\xad\xe6\x96\x87xyz"), size=int(rng.integers(0, 60))).tolist()) for _ in range(200)]
+    b, e, c = O.pack_strings(strings)
+    rb = np.arange(len(strings), dtype=np.int32)
+    ob, oe, ids = O.TrieTokenizer(vocab, indices)(rb, rb + 1, b, e, c)
+    for i, s in enumerate(strings):
+        assert ids[ob[i]:oe[i]].tolist() == py_greedy(vocab, indices, s)
+
+
+def test_kernel_matches_oracle(backend):
+    rng = np.random.default_rng(2)
+    vocab, indices = rwkv_like_vocab(rng)
+    n = 120 if backend.name == "emu" else 20000
+    strings = [bytes(rng.choice(list(b"abcdeft \n\xe4\xb8\xad\xe6\x96\x87xyz\x00\xff"), size=int(rng.integers(0, 90))).tolist()) for _ in range(n)]
+    strings[3] = b""
+    b, e, c = O.pack_strings(strings)
+    # ragged rows: 0, 1 or 2 strings per row
+    cuts = np.unique(np.concatenate([[0, len(strings)], rng.integers(0, len(strings), len(strings) // 2)])).astype(np.int32)
+    rb, re_ = cuts[:-1], cuts[1:]
+    rb, re_ = np.concatenate([rb, [5]]).astype(np.int32), np.concatenate([re_, [5]]).astype(np.int32)   # + an empty row
+    ref = O.TrieTokenizer(vocab, indices)(rb, re_, b, e, c)
+    vb, ve, vc = O.pack_strings(vocab)
+    got = TrieTokenizer(lib=backend.lib).evaluate(backend.data([rb, re_, b, e, c]) + [vb, ve, vc, indices])
+    assert_same(list(ref), got, backend.host, "TrieTokenizer")
+
+
+def test_errors(backend):
+    vb, ve, vc = O.pack_strings([b"a", b"ab"])
+    idx = np.array([7, 9], np.int32)
+    b, e, c = O.pack_strings([b"abz"])
+    one = np.array([0], np.int32)
+    with pytest.raises(L.OvtkError) as ei:   # 'z' matches nothing: the reference would never return
+        TrieTokenizer(lib=backend.lib).evaluate([one, one + 1, b, e, c, vb, ve, vc, idx])
+    assert ei.value.code == L.E_VOCAB
+    with pytest.raises(O.OracleError):
+        O.TrieTokenizer([b"a", b"ab"], idx)(one, one + 1, b, e, c)
+    with pytest.raises(L.OvtkError, match="Vocab size must be equal to Indices size"):
+        TrieTokenizer(lib=backend.lib).evaluate([one, one + 1, b, e, c, vb, ve, vc, idx[:1]])
+    ok = TrieTokenizer(lib=backend.lib).evaluate([one, one + 1, b, np.array([2], np.int32), c, vb, ve, vc, idx])
+    assert backend.host(ok[2]).tolist() == [9]
