@@ -156,6 +156,10 @@ inline std::atomic<int>& row_tickets() {
     return v;
 }
 
+// Up to this many rows the last block of merge_kernel sums the row counts itself (one block reads 4 bytes per row);
+// larger batches keep the parallel count_scan_kernel.
+constexpr int kFoldTailRows = 1 << 18;
+
 struct PendingRun {
     virtual ~PendingRun() = default;
     virtual int finish(ovtk_ragged_i32_out* out) = 0;
@@ -165,9 +169,11 @@ template <class Middle>
 class RowsRun final : public PendingRun {
 public:
     RowsRun(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
-            const ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle middle, bool self_alloc, int blocks_per_cu)
+            const ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle middle, bool self_alloc, int blocks_per_cu,
+            bool tail_in_middle)
         : device_(device), op_(op), in_(*in), skips_(skips), mul_(mul), out_(*out), mem_(mem), s_(s),
-          middle_(std::move(middle)), self_alloc_(self_alloc), blocks_per_cu_(blocks_per_cu), ws_(device) {}
+          middle_(std::move(middle)), self_alloc_(self_alloc), blocks_per_cu_(blocks_per_cu), ws_(device),
+          fold_tail_(tail_in_middle) {}
 
     int start() {
         if (!ws_->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
@@ -211,6 +217,8 @@ public:
                 scratch_cap_ = std::max<int64_t>(scratch_cap_ * 2, int64_t(st.scratch_used) + (1 << 20));
                 if (scratch_cap_ > (int64_t(3) << 30))
                     return set_error(OVTK_E_UNSUPPORTED, "exact-path scratch would exceed 3 GiB; split the call");
+            } else if (st.flags & kFlagTailPending) {
+                fold_tail_ = false;  // more exact pieces than the folded tail takes: once more with their own launches
             } else {
                 if (st.flags & kFlagOutCapacity)
                     return set_error(OVTK_E_CAPACITY, op_ + ": output ids buffer too small (" + std::to_string(st.n_out) +
@@ -240,10 +248,17 @@ private:
         e = e ? e : ws.scratch.ensure(size_t(scratch_cap_));
         e = e ? e : ws.wave_off.ensure(size_t(grid_ * kWavesPerBlock + 1) * sizeof(long long));
         e = e ? e : ws.tiles.ensure(size_t(n_tiles_ + 1) * sizeof(long long));
-        e = e ? e : ws.status.ensure(sizeof(RunStatus));
+        const bool fold = fold_tail_ && n_rows_ <= kFoldTailRows;
+        const size_t status_bytes = sizeof(RunStatus) + (fold ? size_t(n_tiles_) * 4 : 0);  // + tile_cnt, zeroed with the status
+        e = e ? e : ws.status.ensure(status_bytes);
+        if (fold) e = e ? e : ws.gen[4].ensure(size_t(n_rows_) * 4);
         if (e) return e;
         EncodeWork w{};
         w.n_waves = grid_ * kWavesPerBlock;
+        w.fold_tail = fold;
+        w.tile_cnt = fold ? reinterpret_cast<int32_t*>(ws.status.as<uint8_t>() + sizeof(RunStatus)) : nullptr;
+        w.row_emit = fold ? ws.gen[4].as<int32_t>() : nullptr;
+        w.out_cap = out_.data_capacity;
         w.rows_per_ticket = self_alloc_ ? row_tickets().load(std::memory_order_relaxed) : 0;
         w.wave_off = self_alloc_ ? nullptr : ws.wave_off.as<long long>();
         w.stage_region = int32_t(stage_cap_ / kShards);
@@ -261,12 +276,13 @@ private:
         w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap_, 0xFFFFFFF0ll));
         w.status = ws.status.as<RunStatus>();
 
-        OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s_));
+        OVTK_HIP(hipMemsetAsync(w.status, 0, status_bytes, s_));
         if (!self_alloc_)
             OVTK_LAUNCH(ws.marks, "prep_rows", prep_rows_kernel, std::min(grid_, kTicketBlocks), kBlockThreads, s_, d_in_, mul_, w);
         middle_(ws, d_in_, w, grid_);
-        OVTK_LAUNCH(ws.marks, "count_scan", count_scan_kernel, std::min((n_tiles_ + 3) / 4, kTicketBlocks), kBlockThreads, s_,
-                    n_rows_, w, (long long)out_.data_capacity);
+        if (!w.fold_tail)
+            OVTK_LAUNCH(ws.marks, "count_scan", count_scan_kernel, std::min((n_tiles_ + 3) / 4, kTicketBlocks), kBlockThreads, s_,
+                        n_rows_, w, (long long)out_.data_capacity);
         OVTK_LAUNCH(ws.marks, "compact", compact_kernel, grid_lookup(device_, n_rows_), kBlockThreads, s_, n_rows_, w, d_ids_,
                     d_begins_, d_ends_);
         OVTK_HIP(hipMemcpyAsync(ws.host_status, ws.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s_));
@@ -286,6 +302,7 @@ private:
     bool self_alloc_;
     int blocks_per_cu_;
     WorkspaceLease ws_;
+    bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
     RowsIn d_in_{};
     int n_rows_ = 0, grid_ = 0, n_tiles_ = 0;
     int64_t stage_cap_ = 0, shard_cap_ = 0, exact_cap_ = 0, scratch_cap_ = 0;
@@ -296,9 +313,9 @@ template <class Middle>
 std::unique_ptr<RowsRun<std::decay_t<Middle>>> make_rows_run(int device, const char* op, const ovtk_ragged_strings* in,
                                                              const uint8_t* skips, int mul, const ovtk_ragged_i32_out* out, int mem,
                                                              hipStream_t s, Middle&& middle, bool self_alloc = false,
-                                                             int blocks_per_cu = 6) {
+                                                             int blocks_per_cu = 6, bool tail_in_middle = false) {
     return std::make_unique<RowsRun<std::decay_t<Middle>>>(device, op, in, skips, mul, out, mem, s, std::forward<Middle>(middle),
-                                                           self_alloc, blocks_per_cu);
+                                                           self_alloc, blocks_per_cu, tail_in_middle);
 }
 
 // The synchronous form every *_run entry point uses.  `middle` is copied: capture by value.

@@ -374,11 +374,12 @@ int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_
                                    OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid, kBlockThreads, s, d_in,
                                                SplitDev{}, bpe->dev, w);
                                OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(kShards, std::max(1, device_cu_count(dev) * 3 / kShards)),
-                                           kBlockThreads, s, d_in, bpe->dev, w);
-                               OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
+                                           kBlockThreads, s, d_in, bpe->dev, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
+                               if (!w.fold_tail) OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
                            },
                            /*self_alloc=*/true,
-                           split ? resident_blocks_per_cu(lookup_kernel<kFused>) : resident_blocks_per_cu(lookup_kernel<kPieces>));
+                           split ? resident_blocks_per_cu(lookup_kernel<kFused>) : resident_blocks_per_cu(lookup_kernel<kPieces>),
+                           /*tail_in_middle=*/true);
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;

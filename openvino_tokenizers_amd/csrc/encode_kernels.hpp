@@ -52,6 +52,8 @@ constexpr int kMissBuf = 128;  // per-wave LDS buffer of deferred pieces (flushe
 constexpr int kRowTile = 64;  // rows per tile of the final offset scan
 
 struct EncodeWork {
+    int32_t fold_tail;      // merge_kernel's last block also runs exact pieces + the row scan (no exact / count_scan launches)
+    long long out_cap;      // caller's ids capacity (the folded tail's capacity check)
     int32_t rows_per_ticket;  // lookup_kernel, allocator mode: 0 = static rows per wave, else rows handed out per ticket
     int32_t n_waves;        // persistent waves of the prep / lookup launches (wave w owns rows w, w + n_waves, ...)
     long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities), or
@@ -59,6 +61,10 @@ struct EncodeWork {
     int32_t stage_region;   // allocator mode: entries per allocator region (stage_cap / kShards)
     int32_t* row_stage;     // [n_rows]     staging offset of each row (set by the lookup kernel)
     int32_t* row_cnt;       // [n_rows]     ids produced by each row
+    int32_t* tile_cnt;      // [n_tiles] or nullptr: the counts summed per tile of kRowTile rows while merge_kernel runs
+                            //           (atomics into the zeroed tail of the status buffer) -- what the folded tail scans
+    int32_t* row_emit;      // [n_rows] (with tile_cnt): ids the lookup kernel itself wrote for the row, i.e. row_cnt
+                            //           before merge_kernel's additions (a copy: merge blocks sum it while others add)
     int32_t* row_used;      // [n_rows]     staging entries the row occupies (> row_cnt: it has unused entries)
     long long* tile_off;    // [n_tiles]    output offset of each tile of kRowTile rows
     int32_t* stage;
@@ -95,11 +101,13 @@ __device__ __forceinline__ long long row_capacity(const RowsIn& in, int mul, lon
 
 // True in every thread of the block that draws the last of `n_blocks` tickets; its loads then see what all other
 // blocks stored before taking theirs.
-__device__ __forceinline__ bool last_block_done(uint32_t* ticket, unsigned n_blocks) {
+// release = false: the block made nothing but device-scope atomics visible to the last block (an agent-scope release
+// writes the XCD's dirty L2 lines back -- hundreds of blocks doing that at the end of a kernel cost tens of us).
+__device__ __forceinline__ bool last_block_done(uint32_t* ticket, unsigned n_blocks, bool release = true) {
     __shared__ int is_last_s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        publish_release();
+        if (release) publish_release();
         const bool last = atomicAdd(ticket, 1u) == n_blocks - 1u;
         if (last) publish_acquire();
         is_last_s = last ? 1 : 0;
@@ -367,7 +375,7 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
     // works through its home range, then through the ranges not yet marked done.  The NEXT ticket is requested
     // before the current rows' header loads are issued, so most of its latency is paid together with theirs.
     const int rpt = TICKETS ? w.rows_per_ticket : 0;  // a template flag: the static kernel carries none of this
-    const int n_tickets = rpt ? (in.n_rows + rpt - 1) / rpt : 0;
+    const int n_tickets = rpt ? (in.n_rows + rpt - 1) / (rpt ? rpt : 1) : 0;
     const int per = (n_tickets + kShards - 1) / kShards;
     int tk_shard = wave % kShards, tk_pend = 0;
     uint32_t tk_seen = 0;  // ranges this wave found empty
@@ -463,6 +471,7 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
         if (l == 0) {
             w.row_stage[row] = cursor;
             w.row_cnt[row] = st.emitted;
+            if (w.row_emit) w.row_emit[row] = st.emitted;  // (an atomic into tile_cnt here would stall every row: vmcnt is in order)
             w.row_used[row] = st.used;
         }
         cursor += st.used;
@@ -476,14 +485,63 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
     if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
 }
 
+// ---- path X, one lane per piece.
+__device__ __forceinline__ void exact_one(const RowsIn& in, const BpeDev& T, const EncodeWork& w, int i) {
+    const int SL = T.suffix_len;
+    const ExactPiece p = w.exact[i];
+    const int ntext = p.len + SL;
+    const uint32_t bytes = (bpe_exact_scratch_bytes(uint32_t(ntext)) + 15u) & ~15u;
+    const uint32_t off = atomicAdd(&w.status->scratch_used, bytes);
+    if (off > w.scratch_cap || bytes > w.scratch_cap - off) {
+        atomicOr(&w.status->flags, kFlagScratchOverflow);
+        return;
+    }
+    const uint8_t* text = in.chars + p.begin;
+    int32_t* out = w.stage + p.stage_pos;
+    const int cnt = bpe_exact_piece(
+        T, [&](int k) -> uint32_t { return k < p.len ? text[k] : T.suffix[k - p.len]; }, ntext, w.scratch + off, out);
+    for (int k = cnt; k < ntext; ++k) out[k] = kEmptyId;
+    if (cnt) {
+        atomicAdd(&w.row_cnt[p.row], cnt);
+        if (w.tile_cnt) atomicAdd(&w.tile_cnt[p.row / kRowTile], cnt);
+    }
+}
+
+// Final offsets by ONE block (the folded tail of merge_kernel) -- count_scan_kernel without its launch: the per-tile
+// sums were accumulated in w.tile_cnt while the ids were produced, so only their scan is left.
+__device__ __forceinline__ void scan_tiles_one_block(int n_rows, const EncodeWork& w, long long out_cap) {
+    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
+    const long long total = block_exclusive_scan<kBlockThreads, 16>(
+        n_tiles, [&](int i) -> long long { return w.tile_cnt[i]; }, [&](int i, long long off) { w.tile_off[i] = off; });
+    if (threadIdx.x == 0) {
+        w.status->n_out = total > INT32_MAX ? INT32_MAX : int32_t(total);
+        if (total > out_cap) atomicOr(&w.status->flags, kFlagOutCapacity);
+    }
+}
+
 // ---- merge kernel: dense batches of deferred pieces ----------------------------------------------
-static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w) {
+// tail_rows > 0: the block that finishes last also runs the exact pieces (when few) and the scan of the row counts, so
+// that exact_kernel and count_scan_kernel need no launches of their own (tail_rows = n_rows, out_cap as for count_scan).
+static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w, int tail_rows,
+                                                                     long long out_cap) {
     __shared__ uint32_t id_all[kWavesPerBlock][kFastSyms * kWave];
     __shared__ uint64_t key_all[kWavesPerBlock][kFastSyms * kWave];  // path F: u32 key[] | u32 nid[]; path W: u64 key[512]
     __shared__ I2 root_lds[256];
+    __shared__ int pushed_exact;  // this block stored exact-list entries (plain stores the tail block must see)
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
+    if (threadIdx.x == 0) pushed_exact = 0;
     __syncthreads();
     if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
+    if (tail_rows > 0) {  // tile sums of what the lookup kernel emitted: one wave per tile, spread over the whole grid
+        const int n_tiles = (tail_rows + kRowTile - 1) / kRowTile;
+        const int wave = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
+        const int n_waves = int(gridDim.x) * int(gridDim.y) * kWavesPerBlock;
+        for (int tile = wave; tile < n_tiles; tile += n_waves) {
+            const int row = tile * kRowTile + lane_id();
+            const int s0 = wave_sum(row < tail_rows ? w.row_emit[row] : 0);
+            if (lane_id() == 0 && s0) atomicAdd(&w.tile_cnt[tile], s0);
+        }
+    }
     uint32_t* id = id_all[wave_in_block()];
     uint64_t* key = key_all[wave_in_block()];
     uint32_t* fkey = reinterpret_cast<uint32_t*>(key);
@@ -546,7 +604,10 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
             const int prev_row = __shfl_up(my_row, 1), next_row = __shfl_down(my_row, 1);
             const bool head = l == 0 || prev_row != my_row, tail = l == kWave - 1 || next_row != my_row;
             const int seg_base = wave_incl_max(head ? incl - f_cnt : 0);  // prefix before this lane's run (monotone)
-            if (valid && tail && incl - seg_base > 0) atomicAdd(&w.row_cnt[e.row], incl - seg_base);
+            if (valid && tail && incl - seg_base > 0) {
+                atomicAdd(&w.row_cnt[e.row], incl - seg_base);
+                if (w.tile_cnt) atomicAdd(&w.tile_cnt[e.row / kRowTile], incl - seg_base);
+            }
         }
         unsigned long long wm = __ballot(is_w);
         while (wm) {
@@ -570,7 +631,10 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
             } else {
                 int32_t* o = w.stage + s_pos;
                 for (int k = l; k < s_need; k += kWave) o[k] = k < res ? int32_t(id[k]) : kEmptyId;
-                if (l == src && res) atomicAdd(&w.row_cnt[e.row], res);
+                if (l == src && res) {
+                    atomicAdd(&w.row_cnt[e.row], res);
+                    if (w.tile_cnt) atomicAdd(&w.tile_cnt[e.row / kRowTile], res);
+                }
             }
         }
         const unsigned long long xm = __ballot(is_x);
@@ -582,32 +646,34 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
                 if (idx < w.exact_cap) w.exact[idx] = ExactPiece{e.begin, e.len, e.stage_pos, e.row};
                 else atomicOr(&w.status->flags, kFlagExactOverflow);
             }
+            if (l == 0) pushed_exact = 1;
         }
     }
+    if (tail_rows <= 0) return;
+    // ---- folded tail: every block takes a ticket when its batches are done; the last one is alone on the data
+    __syncthreads();
+    if (!last_block_done(&w.status->ticket[0], gridDim.x * gridDim.y, pushed_exact != 0)) return;
+    const int n_exact = w.status->n_exact;
+    if (n_exact > kBlockThreads || (w.status->flags & kFlagExactOverflow)) {  // too many for one block: separate launches
+        if (threadIdx.x == 0) atomicOr(&w.status->flags, kFlagTailPending);
+        return;
+    }
+    if (n_exact > 0) {
+        if (int(threadIdx.x) < n_exact) exact_one(in, T, w, int(threadIdx.x));
+        publish_release();  // the exact pieces' count atomics before the scan below
+        __syncthreads();
+        publish_acquire();
+        if (w.status->flags & kFlagScratchOverflow) return;
+    }
+    scan_tiles_one_block(tail_rows, w, out_cap);
 }
 
-// ---- path X, one lane per piece.
+// ---- path X as its own launch.
 static __global__ __launch_bounds__(kBlockThreads) void exact_kernel(RowsIn in, BpeDev T, EncodeWork w) {
     if (w.status->flags & (kFatalFlags | kFlagDeferOverflow | kFlagExactOverflow)) return;
     const int n = w.status->n_exact;
-    const int SL = T.suffix_len;
     const int stride = int(gridDim.x) * kBlockThreads;
-    for (int i = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); i < n; i += stride) {
-        const ExactPiece p = w.exact[i];
-        const int ntext = p.len + SL;
-        const uint32_t bytes = (bpe_exact_scratch_bytes(uint32_t(ntext)) + 15u) & ~15u;
-        const uint32_t off = atomicAdd(&w.status->scratch_used, bytes);
-        if (off > w.scratch_cap || bytes > w.scratch_cap - off) {
-            atomicOr(&w.status->flags, kFlagScratchOverflow);
-            continue;
-        }
-        const uint8_t* text = in.chars + p.begin;
-        int32_t* out = w.stage + p.stage_pos;
-        const int cnt = bpe_exact_piece(
-            T, [&](int k) -> uint32_t { return k < p.len ? text[k] : T.suffix[k - p.len]; }, ntext, w.scratch + off, out);
-        for (int k = cnt; k < ntext; ++k) out[k] = kEmptyId;
-        if (cnt) atomicAdd(&w.row_cnt[p.row], cnt);
-    }
+    for (int i = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); i < n; i += stride) exact_one(in, T, w, i);
 }
 
 // ---- the tile scan of the final offsets: one wave per tile of kRowTile rows sums the row counts, the last block

@@ -260,7 +260,7 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
         uniq.emplace(std::string(reinterpret_cast<const char*>(kb), 16), e);
     }
     // Cuckoo table: 3 hash functions x 1 entry, load <= 0.5.
-    for (uint32_t cap = std::max<uint32_t>(4, pow2_at_least(uint64_t(uniq.size()) * 2 + 1));; cap *= 2) {
+    for (uint32_t cap = std::max<uint32_t>(4, pow2_at_least(uint64_t(uniq.size()) + uniq.size() / 5 + 1));; cap *= 2) {
         out.shift = 32 - log2u(cap);
         out.slots.assign(size_t(cap), PieceEntry{0, 0, {0, 0, 0}, 0});
         uint64_t rng = 0x9E3779B97F4A7C15ull;
