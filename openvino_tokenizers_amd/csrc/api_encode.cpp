@@ -59,6 +59,7 @@ struct ovtk_bpe {
     BpeDev dev{};
     DevBuf root, node, edges, merges, new_id, bf, pieces;
     size_t memo_entries = 0;
+    bool narrow_ids = false;  // every token id < 65536: merge_kernel keeps ids as u16 in LDS
 };
 
 namespace {
@@ -289,6 +290,9 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     if (rc) return set_error(rc, err);
     auto h = std::make_unique<ovtk_bpe>();
     h->device = p->device;
+    h->narrow_ids = p->vocab.n <= 65536;
+    for (int64_t i = 0; i < p->added_tokens.n && p->added_ids; ++i)
+        if (p->added_ids[i] < 0 || p->added_ids[i] > 65535) h->narrow_ids = false;
     int e = 0;
     e = e ? e : h->root.upload(host.trie.root.data(), host.trie.root.size() * sizeof(I2));
     e = e ? e : h->node.upload(host.trie.node.data(), host.trie.node.size() * sizeof(I2));
@@ -373,8 +377,16 @@ int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_
                                else
                                    OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid, kBlockThreads, s, d_in,
                                                SplitDev{}, bpe->dev, w);
-                               OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel, dim3(kShards, std::max(1, device_cu_count(dev) * 3 / kShards)),
-                                           kBlockThreads, s, d_in, bpe->dev, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
+                               const int tail_rows = w.fold_tail ? d_in.n_rows : 0;
+                               if (bpe->narrow_ids) {
+                                   static const int per_cu = resident_blocks_per_cu(merge_kernel<true>);
+                                   OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<true>, dim3(kShards, std::max(1, device_cu_count(dev) * per_cu / kShards)),
+                                               kBlockThreads, s, d_in, bpe->dev, w, tail_rows, w.out_cap);
+                               } else {
+                                   static const int per_cu = resident_blocks_per_cu(merge_kernel<false>);
+                                   OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<false>, dim3(kShards, std::max(1, device_cu_count(dev) * per_cu / kShards)),
+                                               kBlockThreads, s, d_in, bpe->dev, w, tail_rows, w.out_cap);
+                               }
                                if (!w.fold_tail) OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
                            },
                            /*self_alloc=*/true,

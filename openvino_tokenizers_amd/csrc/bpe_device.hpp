@@ -123,7 +123,10 @@ __device__ __forceinline__ void split_pair_key(uint64_t k64, uint32_t& key, uint
     key = k64 == kNoKey ? kNoKey32 : uint32_t(k64 >> kIdBits);
     nid = uint32_t(k64) & kIdMask;
 }
-__device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uint32_t* key, uint32_t* nid, int n) {
+// IdT: uint32_t, or uint16_t when every id of the vocabulary is below 65536 (8 instead of 12 bytes of LDS per symbol:
+// merge_kernel is occupancy-bound by its LDS).
+template <typename IdT>
+__device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t* key, IdT* nid, int n) {
     const int l = lane_id();
 #define OVTK_AT(k) ((k) * kWave + l)
     // initial pair keys: the lookups of a group of 4 are issued together
@@ -147,7 +150,7 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uin
                 uint32_t kk = kNoKey32, nn = 0;
                 if (k + 1 < n) split_pair_key(merge_resolve(f[j], mk[j], uint32_t(k)), kk, nn);
                 key[OVTK_AT(k)] = kk;
-                nid[OVTK_AT(k)] = nn;
+                nid[OVTK_AT(k)] = IdT(nn);
             }
         }
     }
@@ -174,7 +177,7 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uin
         const uint32_t below = live & ((1u << at) - 1u);
         const int nxt = above2 ? __ffs(above2) - 1 : -1;           // new right neighbour
         const int prv = below ? 31 - __clz(below) : -1;            // left neighbour
-        id[OVTK_AT(at)] = merged;
+        id[OVTK_AT(at)] = IdT(merged);
         --n;
         ++seq;
         // the two new neighbour pairs: both lookups in flight together
@@ -185,12 +188,12 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uin
             uint32_t kk, nn;
             split_pair_key(merge_resolve(fl, kl, seq), kk, nn);
             key[OVTK_AT(prv)] = kk;
-            nid[OVTK_AT(prv)] = nn;
+            nid[OVTK_AT(prv)] = IdT(nn);
         }
         uint32_t kk = kNoKey32, nn = 0;
         if (nxt >= 0) split_pair_key(merge_resolve(fr, kr, seq), kk, nn);
         key[OVTK_AT(at)] = kk;
-        nid[OVTK_AT(at)] = nn;
+        nid[OVTK_AT(at)] = IdT(nn);
         if (right < kFastSyms - 1) key[OVTK_AT(right)] = kNoKey32;
     }
     if (dup) return -1;
@@ -198,7 +201,7 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, uint32_t* id, uin
     int m = 0;
     for (uint32_t rest = live; rest; rest &= rest - 1) {
         const int k = __ffs(rest) - 1;
-        const uint32_t t = id[OVTK_AT(k)];
+        const IdT t = id[OVTK_AT(k)];
         id[OVTK_AT(m++)] = t;
     }
 #undef OVTK_AT

@@ -19,6 +19,8 @@
 //                               compaction)
 #pragma once
 
+#include <type_traits>
+
 #include "bpe_device.hpp"
 #include "device_common.hpp"
 #include "scan_kernels.hpp"
@@ -522,10 +524,16 @@ __device__ __forceinline__ void scan_tiles_one_block(int n_rows, const EncodeWor
 // ---- merge kernel: dense batches of deferred pieces ----------------------------------------------
 // tail_rows > 0: the block that finishes last also runs the exact pieces (when few) and the scan of the row counts, so
 // that exact_kernel and count_scan_kernel need no launches of their own (tail_rows = n_rows, out_cap as for count_scan).
+// NARROW: every id < 65536 -- path F keeps ids and merged ids as u16 (8 KB of LDS per wave instead of 12: 4 resident
+// blocks per CU instead of 3, and the kernel's time follows its occupancy).
+// A wave's LDS: path F  key u32[16*64] | id IdT[16*64] | nid IdT[16*64];  path W  key u64[512] | id u32[512].
+template <bool NARROW>
 static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w, int tail_rows,
                                                                      long long out_cap) {
-    __shared__ uint32_t id_all[kWavesPerBlock][kFastSyms * kWave];
-    __shared__ uint64_t key_all[kWavesPerBlock][kFastSyms * kWave];  // path F: u32 key[] | u32 nid[]; path W: u64 key[512]
+    using IdT = typename std::conditional<NARROW, uint16_t, uint32_t>::type;
+    constexpr int kWaveLdsBytes = kFastSyms * kWave * (4 + 2 * int(sizeof(IdT)));
+    static_assert(kWaveLdsBytes >= kChunkSyms * 12, "path W's key u64[] + id u32[] must fit the wave's LDS");
+    __shared__ uint64_t lds_all[kWavesPerBlock][kWaveLdsBytes / 8];
     __shared__ I2 root_lds[256];
     __shared__ int pushed_exact;  // this block stored exact-list entries (plain stores the tail block must see)
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
@@ -542,10 +550,11 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
             if (lane_id() == 0 && s0) atomicAdd(&w.tile_cnt[tile], s0);
         }
     }
-    uint32_t* id = id_all[wave_in_block()];
-    uint64_t* key = key_all[wave_in_block()];
-    uint32_t* fkey = reinterpret_cast<uint32_t*>(key);
-    uint32_t* fnid = fkey + kFastSyms * kWave;
+    uint64_t* key = lds_all[wave_in_block()];                                 // path W
+    uint32_t* id = reinterpret_cast<uint32_t*>(key + kChunkSyms);             // path W
+    uint32_t* fkey = reinterpret_cast<uint32_t*>(key);                        // path F
+    IdT* fid = reinterpret_cast<IdT*>(fkey + kFastSyms * kWave);              // path F
+    IdT* fnid = fid + kFastSyms * kWave;                                      // path F
     const int l = lane_id();
     const int SL = T.suffix_len;
     const int shard = int(blockIdx.x);  // fastest-varying: blocks that become resident late are spread over all shards
@@ -586,12 +595,12 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
                     if (i >= plen) return T.suffix[i - plen];
                     return uint32_t((i < 8 ? k0 >> (8 * i) : k1 >> (8 * (i - 8))) & 0xFF);
                 },
-                need, [&](int k, int tok) { id[k * kWave + l] = uint32_t(tok); });
-            const int res = bpe_merge_lane(T, id, fkey, fnid, n);
+                need, [&](int k, int tok) { fid[k * kWave + l] = IdT(tok); });
+            const int res = bpe_merge_lane<IdT>(T, fid, fkey, fnid, n);
             if (res < 0) {
                 is_x = true;
             } else {
-                for (int k = 0; k < res; ++k) out[k] = int32_t(id[k * kWave + l]);
+                for (int k = 0; k < res; ++k) out[k] = int32_t(fid[k * kWave + l]);
                 for (int k = res; k < need; ++k) out[k] = kEmptyId;
                 f_cnt = res;
             }
