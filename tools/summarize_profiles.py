@@ -15,6 +15,7 @@ import pandas as pd
 
 ROOT = Path(__file__).resolve().parent.parent
 TAG = {"lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "merge_kernel": "bpe_merge",
+       "split_seq_kernel<0>": "split_count", "split_seq_kernel<1>": "split_write",
        "exact_kernel": "bpe_exact", "compact_kernel": "compact", "prep_rows_kernel": "prep_rows",
        "count_scan_kernel": "count_scan", "wordpiece_deferred_kernel": "wordpiece_deferred",
        "decode_count_kernel": "decode_count", "decode_write_kernel": "detokenize"}
@@ -25,23 +26,36 @@ def short(name):
     return n
 
 
+def newest(pattern):
+    files = glob.glob(pattern)
+    return max(files, key=lambda f: Path(f).stat().st_mtime) if files else None
+
+
+def tag_of(kernel):
+    """bench.py's name of a kernel: template arguments matter only for the first one of lookup / split kernels."""
+    base, _, args = kernel.partition("<")
+    first = args.split(",")[0].rstrip(">").strip() if args else ""
+    keyed = f"{base}<{first}>" if base in ("lookup_kernel", "split_seq_kernel", "split_kernel") and first else base
+    return TAG.get(keyed, TAG.get(base, kernel))
+
+
 def main(prefix):
     out_dir = ROOT / "profiles" / Path(prefix).parent
     out_dir.mkdir(parents=True, exist_ok=True)
     stem = Path(prefix).name
     pmc_json = {}
-    for cfg in (2, 3, 5):
-        st = sorted(glob.glob(str(ROOT / f"gpurun_out/prof_c{cfg}/*/*kernel_stats.csv")))
+    for cfg in (2, 3, 4, 5):
+        st = newest(str(ROOT / f"gpurun_out/prof_c{cfg}/*/*kernel_stats.csv"))
         if st:
-            d = pd.read_csv(st[-1])
+            d = pd.read_csv(st)
             d = d[d["Name"].str.contains("ovtk")]
             d.to_csv(out_dir / f"{stem}_config{cfg}_kernel_stats.csv", index=False)
         rows = []
         for ctr in ("fetch", "write"):
-            f = sorted(glob.glob(str(ROOT / f"gpurun_out/pmc_{ctr}_c{cfg}/*/*counter_collection.csv")))
+            f = newest(str(ROOT / f"gpurun_out/pmc_{ctr}_c{cfg}/*/*counter_collection.csv"))
             if not f:
                 continue
-            d = pd.read_csv(f[-1])
+            d = pd.read_csv(f)
             d = d[d["Kernel_Name"].str.contains("ovtk")]
             d["kernel"] = d["Kernel_Name"].map(short)
             g = d.groupby(["kernel", "Counter_Name"]).agg(dispatches=("Counter_Value", "size"), mean_KB=("Counter_Value", "mean"),
@@ -55,9 +69,7 @@ def main(prefix):
             for k, g in t.groupby("kernel"):
                 fetch = float(g[g.Counter_Name == "FETCH_SIZE"].mean_KB.sum())
                 write = float(g[g.Counter_Name == "WRITE_SIZE"].mean_KB.sum())
-                base = k.split("<")[0] + ("<" + k.split("<")[1] if "<" in k and k.startswith("lookup") else "")
-                tag = TAG.get(base, TAG.get(k, k))
-                per[tag] = int((2 * fetch + write) * 1024)
+                per[tag_of(k)] = int((2 * fetch + write) * 1024)
             if cfg == 3 and "lookup_fused" in per:
                 per["lookup_words"] = per["lookup_fused"]  # bench.py's name for the same kernel run with the BERT scanner
             pmc_json[f"config{cfg}"] = per
