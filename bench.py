@@ -281,6 +281,7 @@ def main():
                                                         "every step (stands in for RCCL's all-gather kernel; tools/cu_hog.hip)")
     ap.add_argument("--row-tickets", type=int, default=-1, help="ovtk_set_row_tickets(n); default: 0 at N = 1, 2 with an exchange")
     ap.add_argument("--hog-lds", type=int, default=0, help="debug: dynamic LDS bytes per hog block")
+    ap.add_argument("--lib", default=None, help="debug: load this build of libovtk_amd.so")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
     args = ap.parse_args()
@@ -298,7 +299,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from openvino_tokenizers_amd.distributed import ShardExchange
 
-    lib = L.load()
+    lib = L.load(args.lib)
     wl = {2: make_encode_bpe, 3: make_encode_wordpiece, 4: make_encode_llama3, 5: make_detokenize}[args.config](args, lib, dev, rank)
     is_detok = wl.get("is_detok", False)
     # N > 1: every rank's ragged ids are all-gathered (RCCL), one batch behind the encode so that the gather of batch k

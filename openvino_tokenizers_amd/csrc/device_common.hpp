@@ -133,6 +133,10 @@ __device__ __forceinline__ unsigned long long row_next(unsigned long long v) {
     const unsigned hi = unsigned(dpp_mov0<kDppRowShl + 1>(int(unsigned(v >> 32))));
     return (static_cast<unsigned long long>(hi) << 32) | lo;
 }
+// Value of lane l-1 / l+1 of the whole wavefront (0 for lane 0 / lane 63): GFX9's DPP wavefront shifts.
+constexpr int kDppWaveShl1 = 0x130, kDppWaveShr1 = 0x138;
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v) { return uint32_t(dpp_mov0<kDppWaveShr1>(int(v))); }
+__device__ __forceinline__ uint32_t lane_next(uint32_t v) { return uint32_t(dpp_mov0<kDppWaveShl1>(int(v))); }
 __device__ __forceinline__ int wave_max(int v) {
 #pragma unroll
     for (int d = kWave / 2; d > 0; d >>= 1) {

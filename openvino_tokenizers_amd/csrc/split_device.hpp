@@ -269,34 +269,29 @@ __device__ __forceinline__ uint32_t swar_before(uint32_t lo, uint32_t hi) { retu
 
 // Piece-start flags of window bytes [8l, 8l+8) for lane l (bit 8k+7 = byte 8l+k), same rules as gpt2_start_mask.
 // Returns false (wave-uniform) when the window holds a non-ASCII byte: the caller then takes the ballot path.
+// A lane classifies only its own two dwords; what the rules need from the bytes before and after them (the classes
+// of the previous byte, "next byte is not a space", the contraction letters after an apostrophe, contractions that
+// fired up to three bytes back) comes from the neighbouring lanes with one DPP wavefront shift per value.
+// Index convention below: [0] = last dword of lane l-1, [1], [2] = own dwords, [3] = first dword of lane l+1.
 __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, int skew, int wlen, bool digits,
                                                        unsigned long long& flags) {
     const int l = lane_id();
-    // the 16 bytes around the lane's own: window bytes [8l - 4, 8l + 12) = neighbourhood bytes 0..15
-    const int off = skew + 8 * l;  // byte offset of neighbourhood byte 0 in text_w (kTextPad = 4 bytes back)
+    const int off = kTextPad + skew + 8 * l;  // byte offset of the lane's first byte in text_w
     const int a = off >> 2, sh = (off & 3) * 8;
-    uint32_t raw[5];
+    const uint32_t r0 = ws.text_w[a], r1 = ws.text_w[a + 1], r2 = ws.text_w[a + 2];
+    int nv = wlen - 8 * l;  // how many of the lane's 8 bytes exist
+    nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
+    const uint32_t m1 = nv >= 4 ? ~0u : ((1u << (8 * nv)) - 1u);
+    const uint32_t m2 = nv >= 8 ? ~0u : (nv <= 4 ? 0u : ((1u << (8 * (nv - 4))) - 1u));
+    uint32_t x[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
+    x[1] = uint32_t(((static_cast<unsigned long long>(r1) << 32) | r0) >> sh) & m1;
+    x[2] = uint32_t(((static_cast<unsigned long long>(r2) << 32) | r1) >> sh) & m2;
+    V[1] = m1 & kB7;
+    V[2] = m2 & kB7;
+    if (__ballot(((x[1] | x[2]) & kB7) != 0)) return false;
+    uint32_t L[3], N[3], S[3], SP[3], AP[3], O[3];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) raw[j] = ws.text_w[a + j];
-    // which neighbourhood bytes exist: window positions q = 8l - 4 + j with 0 <= q < wlen
-    const int first = l == 0 ? 4 : 0;
-    int last = wlen - (8 * l - 4);
-    last = last < 0 ? 0 : (last > 16 ? 16 : last);
-    uint32_t x[4], V[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int nh = last - 4 * j, nl = first - 4 * j;
-        nh = nh < 0 ? 0 : (nh > 4 ? 4 : nh);
-        nl = nl < 0 ? 0 : (nl > 4 ? 4 : nl);
-        const uint32_t mh = nh == 4 ? ~0u : ((1u << (8 * nh)) - 1u), ml = nl == 4 ? ~0u : ((1u << (8 * nl)) - 1u);
-        const uint32_t vf = mh & ~ml;  // 0xFF per existing byte
-        x[j] = uint32_t(((static_cast<unsigned long long>(raw[j + 1]) << 32) | raw[j]) >> sh) & vf;
-        V[j] = vf & kB7;
-    }
-    if (__ballot(((x[0] | x[1] | x[2] | x[3]) & kB7) != 0)) return false;
-    uint32_t L[4], N[4], S[4], SP[4], AP[4], O[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 1; j <= 2; ++j) {
         L[j] = swar_range(x[j] | 0x20202020u, 'a', 'z');
         N[j] = swar_range(x[j], '0', '9');
         SP[j] = swar_eq(x[j], 0x20) & V[j];  // a non-existing byte is 0x00: never a letter, digit, apostrophe; mask the rest
@@ -304,29 +299,43 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
         AP[j] = swar_eq(x[j], 0x27);
         O[j] = V[j] & ~(L[j] | N[j] | S[j]);
     }
-    // rules for the lane's own bytes = neighbourhood dwords 1 and 2
-    uint32_t start[2];
-    uint32_t f1[3] = {0, 0, 0}, f2[3] = {0, 0, 0};  // contractions firing at neighbourhood dwords 0..2
-    if (__ballot((AP[0] | AP[1] | AP[2]) != 0)) {
+    L[0] = lane_prev(L[2]);
+    N[0] = lane_prev(N[2]);
+    S[0] = lane_prev(S[2]);
+    O[0] = lane_prev(O[2]);
+    SP[0] = lane_prev(SP[2]);
+    uint32_t NS[4];  // "exists and is not white space"
+    NS[1] = V[1] & ~S[1];
+    NS[2] = V[2] & ~S[2];
+    NS[3] = lane_next(NS[1]);
+    uint32_t f1[3] = {0, 0, 0}, f2[3] = {0, 0, 0};  // contractions ('x / 'xx) firing at an apostrophe
+    if (__ballot((AP[1] | AP[2]) != 0)) {
         uint32_t X1[4], X2[4], XE[4], XL[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 1; j <= 2; ++j) {
             X1[j] = swar_range(x[j], 's', 't') | swar_eq(x[j], 'm') | swar_eq(x[j], 'd');
             X2[j] = swar_eq(x[j], 'r') | swar_eq(x[j], 'v');
             XE[j] = swar_eq(x[j], 'e');
             XL[j] = swar_eq(x[j], 'l');
         }
+        X1[3] = lane_next(X1[1]);
+        X2[3] = lane_next(X2[1]);
+        XE[3] = lane_next(XE[1]);
+        XL[3] = lane_next(XL[1]);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 1; j <= 2; ++j) {
             const uint32_t c1 = AP[j] & swar_after<1>(X1[j], X1[j + 1]);
             const uint32_t c2 = AP[j] & ((swar_after<1>(X2[j], X2[j + 1]) & swar_after<2>(XE[j], XE[j + 1])) |
                                          (swar_after<1>(XL[j], XL[j + 1]) & swar_after<2>(XL[j], XL[j + 1])));
             // the apostrophe itself starts a piece unless the previous char is class O or U+0020
-            const uint32_t blocked = j == 0 ? swar_before<1>(0u, O[0] | SP[0]) : swar_before<1>(O[j - 1] | SP[j - 1], O[j] | SP[j]);
+            const uint32_t blocked = swar_before<1>(O[j - 1] | SP[j - 1], O[j] | SP[j]);
             f1[j] = c1 & ~blocked;
             f2[j] = c2 & ~blocked;
         }
+        f1[0] = lane_prev(f1[2]);
+        f2[0] = lane_prev(f2[2]);
     }
+    uint32_t start[2];
 #pragma unroll
     for (int j = 1; j <= 2; ++j) {
         const uint32_t pL = swar_before<1>(L[j - 1], L[j]), pN = swar_before<1>(N[j - 1], N[j]);
@@ -335,7 +344,7 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
         const uint32_t same = (L[j] & pL) | (N[j] & pN) | (S[j] & pS) | (O[j] & pO);
         const uint32_t attaches = ~S[j] & (digits ? ~N[j] : ~0u);
         uint32_t st = ~same & ~(pSP & attaches);
-        const uint32_t next_nonspace = swar_after<1>(V[j] & ~S[j], V[j + 1] & ~S[j + 1]);
+        const uint32_t next_nonspace = swar_after<1>(NS[j], NS[j + 1]);
         st |= same & ((S[j] & next_nonspace) | (digits ? N[j] : 0u));
         const uint32_t f12_lo = f1[j - 1] | f2[j - 1], f12 = f1[j] | f2[j];
         st |= swar_before<2>(f1[j - 1], f1[j]) | swar_before<3>(f2[j - 1], f2[j]);  // the byte after a contraction

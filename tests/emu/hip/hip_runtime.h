@@ -246,13 +246,15 @@ static inline unsigned __lane_id() { return unsigned(::emu::lane()); }
 template <typename T> static inline T emu_readfirstlane(T v) { return ::emu::shfl(v, 0); }
 #define __builtin_amdgcn_readlane(v, src) ::emu::shfl(v, src)
 // DPP (gfx9 semantics) for the controls the kernels use: row_shl:n 0x100+n, row_shr:n 0x110+n, row_bcast15 0x142,
-// row_bcast31 0x143.  A lane whose row is not in row_mask / whose bank is not in bank_mask keeps `old`; a lane with
+// row_bcast31 0x143, wave_shl:1 0x130, wave_shr:1 0x138.  A lane whose row is not in row_mask / whose bank is not in bank_mask keeps `old`; a lane with
 // no valid source gets 0 when bound_ctrl is set, `old` otherwise.  Collective: every lane of the wave must call it.
 static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     const int l = ::emu::lane(), row = l >> 4, in_row = l & 15;
     int from = -1;
     if (ctrl >= 0x101 && ctrl <= 0x10F) { const int n = ctrl - 0x100; if (in_row + n <= 15) from = l + n; }
     else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; if (in_row - n >= 0) from = l - n; }
+    else if (ctrl == 0x130) { if (l + 1 < 64) from = l + 1; }   // wave_shl:1
+    else if (ctrl == 0x138) { if (l >= 1) from = l - 1; }        // wave_shr:1
     else if (ctrl == 0x142) { if (row >= 1) from = row * 16 - 1; }
     else if (ctrl == 0x143) { if (row >= 2) from = 31; }
     else { std::fprintf(stderr, "emu: unsupported DPP control 0x%x\n", ctrl); std::abort(); }
