@@ -405,7 +405,7 @@ def main():
 
     # ---- parity spot-check + CPU baseline (oracle = "port" of the reference's algorithm), rank 0 only
     cpu_baseline, parity = None, None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # N > 1: the ranks are done once the line is printed
         n_s = wl["sample_rows"]
         ref, cdt, sample_units, what = wl["cpu"](n_s)
         b, e, payload = wl["step"]()

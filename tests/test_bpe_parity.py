@@ -317,3 +317,25 @@ def test_row_tickets_same_result(backend, rows_per_ticket):
         L.check(backend.lib, backend.lib.ovtk_set_row_tickets(0))
     with pytest.raises(L.OvtkError):
         L.check(backend.lib, backend.lib.ovtk_set_row_tickets(-1))
+
+
+@pytest.mark.parametrize("shift", [1, 2, 3])
+def test_unaligned_chars_tensor(backend, shift):
+    """The chars tensor itself starts at an address that is not a multiple of 4, and strings touch both of its ends:
+    the window staging fetches whole dwords only inside the tensor."""
+    tok = BpeTok.load("gpt2_small")
+    strings = ["it's", "a b", "x" * 700 + " y's", "", "tail isn't"]
+    b, e, c = O.pack_strings(strings)
+    rb, re_ = ragged_rows(len(strings))
+    ref = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(rb, re_, b, e, c)[:5])
+    padded = np.concatenate([np.full(shift, 0x41, np.uint8), c])
+    if backend.name == "hip-device":
+        import torch
+        chars = torch.as_tensor(padded, device="cuda")[shift:]
+        assert chars.data_ptr() % 4 == shift
+        data = backend.data([rb, re_, b, e]) + [chars]
+    else:
+        chars = padded[shift:]
+        data = [rb, re_, b, e, chars]
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    assert_same(ref, fused.evaluate(data + [tok.pattern_u8()], tok.consts), backend.host, "unaligned tensor")
