@@ -124,7 +124,7 @@ def make_encode_bpe(args, lib, dev, rank):
                 + (", piece memo disabled (cache_capacity=0)" if args.no_memo else ""))
     return dict(step=step, enqueue=enqueue, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe), workload=workload, vocab=len(tok.vocab),
                 metric="input MB/s encoded (GPT-2 BPE, 512-byte strings)", dtype="u8/int32",
-                algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=min(args.rows, 32768))
+                algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=args.rows)
 
 
 def make_encode_llama3(args, lib, dev, rank):
@@ -214,7 +214,7 @@ def make_encode_wordpiece(args, lib, dev, rank):
                 f"strings per GPU, fused RegexSplit(\\s+)+RegexSplit(delimiters)+WordpieceTokenizer, inputs and outputs in HBM")
     return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, ws, pu, wp), workload=workload, vocab=len(tok["vocab"]),
                 metric="input MB/s encoded (BERT WordPiece, 256-byte strings)", dtype="u8/int32",
-                algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=min(args.rows, 32768))
+                algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=args.rows)
 
 
 def make_detokenize(args, lib, dev, rank):
