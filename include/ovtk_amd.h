@@ -281,14 +281,15 @@ int ovtk_string_tensor_pack(const ovtk_strings* in, uint8_t* packed, int64_t cap
 /* ---------------------------------------------------------------- row-shard exchange
  * No reference counterpart (the reference is single-process).  Rows shard contiguously over the ranks of one node
  * (rank r owns rows first(r) .. first(r+1), balanced like numpy.array_split); the one exchange step is an all-gather
- * of fixed-size "wires": i32 lens[max_rows] then pad_ids ids of id_bytes (2 when every id < 65536, else 4) bytes.
+ * of fixed-size "wires": a 16-byte header (n_ids, n_rows), i32 ends[max_rows] (the shard's own end offsets), then
+ * pad_ids ids of id_bytes (2 when every id < 65536, else 4) bytes.
  *   ovtk_shard_pack    builds this rank's wire from the ragged ids an encode call returned (ascending, gap-free
  *                      from 0).  Device memory: only enqueues work on `stream`.
  *   (the caller all-gathers the wires: RCCL)
- *   ovtk_shard_unpack  rebuilds the global ragged tensor from the `world` wires: begins/ends [n_rows], ids widened to
- *                      i32.  Device memory: only enqueues work on `stream` -- the handle owns the scratch, so calls
- *                      on one handle must be ordered on one stream -- and `result` (device memory) is written last.
- *                      Host memory: synchronous, `result` in host memory.
+ *   ovtk_shard_unpack  rebuilds the global ragged tensor from the `world` wires in one kernel (rank r's ids start at the
+ *                      sum of the n_ids before it, its rows' offsets are that base plus the local ones): begins/ends
+ *                      [n_rows], ids widened to i32.  Device memory: only enqueues work on `stream`; `result` lives
+ *                      in device memory.  Host memory: synchronous, `result` in host memory.
  * result->status: OVTK_OK; OVTK_E_CAPACITY with max_shard_ids > pad_ids when some shard held more ids than the wire
  * has room for (identical on every rank: repeat the exchange with a larger pad); OVTK_E_RANGE when out_capacity is
  * too small; OVTK_E_UNSUPPORTED beyond 2^31 ids. */

@@ -762,7 +762,7 @@ int ovtk_string_tensor_pack(const ovtk_strings* in, uint8_t* packed, int64_t cap
 struct ovtk_shard_exchange {
     int device = 0;
     ShardGeom g{};
-    DevBuf tiles, status, in_a, in_b, in_c, out_a, out_b, out_c;  // scratch of the calls in flight on the caller's stream
+    DevBuf in_a, in_b, in_c, out_a, out_b, out_c;  // staging of host-memory calls (the CPU tests)
     std::vector<Profiler::Mark> marks;
 };
 
@@ -776,15 +776,13 @@ int ovtk_shard_exchange_create(int world, int64_t n_rows, int id_bytes, int devi
     g.n_rows = n_rows; g.world = world; g.id_bytes = id_bytes;
     g.base = n_rows / world; g.rem = n_rows % world;
     g.max_rows = (g.base + (g.rem ? 1 : 0) + 3) / 4 * 4;  // ids start 16-byte aligned in the wire
-    if (int rc = h->status.ensure(sizeof(RunStatus))) return rc;
-    if (int rc = h->tiles.ensure(scan_tiles_bytes(std::max<int64_t>(n_rows, 1)))) return rc;
     *out = h.release();
     return OVTK_OK;
 }
 
 int64_t ovtk_shard_max_rows(const ovtk_shard_exchange* h) { return h ? h->g.max_rows : -1; }
 int64_t ovtk_shard_wire_bytes(const ovtk_shard_exchange* h, int64_t pad_ids) {
-    return h ? h->g.max_rows * 4 + pad_ids * int64_t(h->g.id_bytes) : -1;
+    return h ? kShardHeaderBytes + h->g.max_rows * 4 + pad_ids * int64_t(h->g.id_bytes) : -1;
 }
 void ovtk_shard_exchange_destroy(ovtk_shard_exchange* h) { delete h; }
 
@@ -794,7 +792,7 @@ int shard_pad(ovtk_shard_exchange* h, int64_t pad_ids, ShardGeom* g) {
     if (pad_ids < 0 || pad_ids % 8 || pad_ids >= INT32_MAX) return set_error(OVTK_E_ARG, "shard exchange: pad_ids must be a multiple of 8");
     *g = h->g;
     g->pad_ids = pad_ids;
-    g->stride = g->max_rows * 4 + pad_ids * g->id_bytes;
+    g->stride = kShardHeaderBytes + g->max_rows * 4 + pad_ids * g->id_bytes;
     return use_device(h->device);
 }
 }  // namespace
@@ -803,7 +801,7 @@ int ovtk_shard_pack(ovtk_shard_exchange* h, const int32_t* begins, const int32_t
                     int64_t n_ids, int64_t pad_ids, void* wire, int mem, void* stream) {
     ShardGeom g{};
     if (int rc = shard_pad(h, pad_ids, &g)) return rc;
-    if (rows < 0 || rows > g.max_rows || n_ids < 0 || !wire) return set_error(OVTK_E_ARG, "shard_pack: bad arguments");
+    if (rows < 0 || rows > g.max_rows || n_ids < 0 || n_ids >= INT32_MAX || !wire) return set_error(OVTK_E_ARG, "shard_pack: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Profiler::get().resolve(h->marks);  // marks of earlier calls (complete once the caller consumed their results)
     const int32_t *b = nullptr, *e = nullptr, *d = nullptr;
@@ -827,26 +825,20 @@ int ovtk_shard_unpack(ovtk_shard_exchange* h, const void* wires, int64_t pad_ids
     if (!wires || !result || out_capacity < 0) return set_error(OVTK_E_ARG, "shard_unpack: bad arguments");
     hipStream_t s = static_cast<hipStream_t>(stream);
     Profiler::get().resolve(h->marks);
-    RunStatus* st = h->status.as<RunStatus>();
-    OVTK_HIP(hipMemsetAsync(st, 0, sizeof(RunStatus), s));
     const uint8_t* w = nullptr;
     if (int rc = in_source(h->in_c, static_cast<const uint8_t*>(wires), size_t(g.stride) * g.world, mem, s, &w)) return rc;
     int32_t *d_b = nullptr, *d_e = nullptr, *d_i = nullptr;
-    ovtk_shard_result* d_res = nullptr;
     const size_t rows_bytes = size_t(std::max<int64_t>(g.n_rows, 1)) * 4;
     if (int rc = out_target(h->out_a, out_begins, rows_bytes, mem, &d_b)) return rc;
     if (int rc = out_target(h->out_b, out_ends, rows_bytes, mem, &d_e)) return rc;
     if (int rc = out_target(h->out_c, out_ids, size_t(out_capacity) * 4 + sizeof(ovtk_shard_result), mem, &d_i)) return rc;
-    d_res = mem == OVTK_MEM_HOST ? reinterpret_cast<ovtk_shard_result*>(h->out_c.as<uint8_t>() + size_t(out_capacity) * 4) : result;
-    // Offsets are always produced (only the 2^31 limit stops them): a shard that outgrew the pad must be reported
-    // with its size even when the caller's ids buffer, sized from the pad, is too small as well.
-    launch_scan(h->marks, "shard_rows", s, g.n_rows, ShardLen{w, g}, ShardApply{d_b, d_e}, CharsFin{st, (long long)INT32_MAX - 1},
-                h->tiles.as<long long>(), st, kFlagOutCapacity);
-    const int chunks = int(std::max<long long>(1, std::min<long long>((pad_ids + kBlockThreads * 8 - 1) / (kBlockThreads * 8),
+    ovtk_shard_result* d_res =
+        mem == OVTK_MEM_HOST ? reinterpret_cast<ovtk_shard_result*>(h->out_c.as<uint8_t>() + size_t(out_capacity) * 4) : result;
+    const long long share = std::max<long long>(pad_ids, g.max_rows);
+    const int chunks = int(std::max<long long>(1, std::min<long long>((share + kBlockThreads * 8 - 1) / (kBlockThreads * 8),
                                                                        (long long)device_cu_count(h->device) * 8 / g.world + 1)));
-    OVTK_LAUNCH(h->marks, "shard_unpack", shard_unpack_kernel, dim3(chunks, g.world), kBlockThreads, s, w, g,
-                (const int32_t*)d_b, d_i, (long long)out_capacity, st);
-    OVTK_LAUNCH(h->marks, "shard_result", shard_result_kernel, 1, kWave, s, (const RunStatus*)st, d_res);
+    OVTK_LAUNCH(h->marks, "shard_unpack", shard_unpack_kernel, dim3(chunks, g.world), kBlockThreads, s, w, g, d_b, d_e, d_i,
+                (long long)out_capacity, d_res);
     if (mem == OVTK_MEM_HOST) {
         OVTK_HIP(hipMemcpyAsync(result, d_res, sizeof(ovtk_shard_result), hipMemcpyDeviceToHost, s));
         OVTK_HIP(hipStreamSynchronize(s));

@@ -784,103 +784,87 @@ static __global__ __launch_bounds__(kWave) void pack_header_kernel(int32_t* head
 }
 
 // ------------------------------------------------------------------------------- row-shard exchange
-// Wire format of one rank's ragged ids for the RCCL all-gather (no reference counterpart): every rank sends the same
-// number of bytes -- i32 lens[max_rows] (rows past the shard: 0) then pad_ids ids of 2 or 4 bytes -- because RCCL has
-// no all-gather-v.  The receiver needs no counts: a scan over the global row lengths gives every row's offset, and
-// the ids of rank r are the contiguous run between the offsets of its first row and of the next rank's first row.
+// Wire format of one rank's ragged ids for the RCCL all-gather (no reference counterpart).  Every rank sends the same
+// number of bytes because RCCL has no all-gather-v:
+//     i32 n_ids, i32 n_rows, 2 x i32 0 | i32 ends[max_rows] (the shard's own end offsets) | pad_ids ids of 2 or 4 bytes
+// The receiver needs no scan and no counts exchange: rank r's ids go to the sum of the n_ids of the ranks before it,
+// and a row's global offsets are that base plus its local ones.  One kernel packs, one kernel unpacks.
+constexpr int kShardHeaderBytes = 16;
 struct ShardGeom {
     long long n_rows;    // global rows
-    long long max_rows;  // lens slots per wire
+    long long max_rows;  // ends slots per wire
     long long pad_ids;   // id slots per wire
     long long stride;    // bytes per wire
     int world, id_bytes;
     long long base, rem;  // shard_rows(): ranks < rem own base + 1 rows
 
     __host__ __device__ long long first_row(long long r) const { return r * base + (r < rem ? r : rem); }
-    __host__ __device__ long long rank_of(long long g, long long* local) const {
-        const long long cut = rem * (base + 1);
-        long long r;
-        if (g < cut) { r = g / (base + 1); *local = g - r * (base + 1); }
-        else { r = rem + (g - cut) / base; *local = g - cut - (r - rem) * base; }
-        return r;
-    }
 };
 
 static __global__ __launch_bounds__(kBlockThreads) void shard_pack_kernel(const int32_t* begins, const int32_t* ends,
                                                                           const int32_t* ids, long long rows, long long n_ids,
                                                                           ShardGeom g, uint8_t* wire) {
-    int32_t* lens = reinterpret_cast<int32_t*>(wire);
-    uint8_t* wid = wire + g.max_rows * 4;
+    int32_t* hdr = reinterpret_cast<int32_t*>(wire);
+    int32_t* w_ends = hdr + kShardHeaderBytes / 4;
+    uint8_t* wid = wire + kShardHeaderBytes + g.max_rows * 4;
     const long long stride = (long long)gridDim.x * kBlockThreads, t0 = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
-    for (long long i = t0; i < g.max_rows; i += stride) lens[i] = i < rows ? ends[i] - begins[i] : 0;
-    const long long n = n_ids < g.pad_ids ? n_ids : g.pad_ids;  // a shard larger than the pad is cut; the receiver sees it in lens
+    if (t0 == 0) {
+        hdr[0] = int32_t(n_ids);
+        hdr[1] = int32_t(rows);
+        hdr[2] = hdr[3] = 0;
+    }
+    const int32_t origin = rows > 0 ? begins[0] : 0;  // offsets travel relative to the shard's first id
+    for (long long i = t0; i < g.max_rows; i += stride) w_ends[i] = i < rows ? ends[i] - origin : 0;
+    const long long n = n_ids < g.pad_ids ? n_ids : g.pad_ids;  // a shard larger than the pad is cut; n_ids in the header says so
     if (g.id_bytes == 2) {
         uint16_t* w = reinterpret_cast<uint16_t*>(wid);
-        for (long long i = t0; i < n; i += stride) w[i] = uint16_t(ids[i]);
+        for (long long i = t0; i < n; i += stride) w[i] = uint16_t(ids[origin + i]);
     } else {
         int32_t* w = reinterpret_cast<int32_t*>(wid);
-        for (long long i = t0; i < n; i += stride) w[i] = ids[i];
+        for (long long i = t0; i < n; i += stride) w[i] = ids[origin + i];
     }
 }
 
-struct ShardLen {
-    const uint8_t* wires;
-    ShardGeom g;
-    __device__ long long operator()(long long row) const {
-        long long local;
-        const long long r = g.rank_of(row, &local);
-        const int32_t v = reinterpret_cast<const int32_t*>(wires + r * g.stride)[local];
-        return v > 0 ? v : 0;
-    }
-};
-struct ShardApply {
-    int32_t* out_begins;
-    int32_t* out_ends;
-    __device__ void operator()(long long i, long long off, long long len) const {
-        out_begins[i] = int32_t(off);
-        out_ends[i] = int32_t(off + len);
-    }
-};
-
-// grid (chunks, world): rank r's ids are widened and moved to out_ids[begin of its first row ...).
-static __global__ __launch_bounds__(kBlockThreads) void shard_unpack_kernel(const uint8_t* wires, ShardGeom g,
-                                                                            const int32_t* out_begins, int32_t* out_ids,
-                                                                            long long out_cap, RunStatus* status) {
-    if (status->flags & kFlagOutCapacity) return;  // more than 2^31 ids in total: no offsets were written
+// grid (chunks, world): block (x, r) handles rank r's wire -- rows r's offsets and a share of its ids; block (0, 0)
+// also writes the verdict (ovtk_shard_result, include/ovtk_amd.h).
+static __global__ __launch_bounds__(kBlockThreads) void shard_unpack_kernel(const uint8_t* wires, ShardGeom g, int32_t* out_begins,
+                                                                            int32_t* out_ends, int32_t* out_ids, long long out_cap,
+                                                                            ovtk_shard_result* res) {
     const long long r = blockIdx.y;
-    const long long row0 = g.first_row(r), row1 = g.first_row(r + 1);
-    if (row0 >= g.n_rows) return;
-    const long long off = out_begins[row0];
-    const long long cnt = (row1 < g.n_rows ? (long long)out_begins[row1] : (long long)status->n_out) - off;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&status->stage_need, int32_t(cnt));
-    if (cnt > g.pad_ids) {  // the sender had to cut this shard: the caller repeats the exchange with a larger pad
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status->flags, kFlagStageOverflow);
-        return;
+    long long off = 0, total = 0, biggest = 0;
+    for (int q = 0; q < g.world; ++q) {  // the world's headers: a few scalar loads per block
+        const long long c = reinterpret_cast<const int32_t*>(wires + q * g.stride)[0];
+        if (q < r) off += c;
+        total += c;
+        biggest = c > biggest ? c : biggest;
     }
-    if (off + cnt > out_cap) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status->flags, kFlagRange);
-        return;
+    const bool cut = biggest > g.pad_ids, too_big = total > INT32_MAX - 1, no_room = total > out_cap;
+    if (blockIdx.x == 0 && r == 0 && threadIdx.x == 0) {
+        res->n_ids = total;
+        res->max_shard_ids = biggest;
+        res->reserved = 0;
+        res->status = too_big ? OVTK_E_UNSUPPORTED : cut ? OVTK_E_CAPACITY : no_room ? OVTK_E_RANGE : OVTK_OK;
     }
-    const uint8_t* wid = wires + r * g.stride + g.max_rows * 4;
+    if (cut || too_big || no_room) return;
+    const uint8_t* wire = wires + r * g.stride;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(wire);
+    const int32_t* w_ends = hdr + kShardHeaderBytes / 4;
+    const long long cnt = hdr[0], rows = g.first_row(r + 1) - g.first_row(r), row0 = g.first_row(r);
+    const long long stride = (long long)gridDim.x * kBlockThreads, t0 = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
+    for (long long i = t0; i < rows; i += stride) {
+        const long long e = w_ends[i], b = i ? w_ends[i - 1] : 0;
+        out_begins[row0 + i] = int32_t(off + b);
+        out_ends[row0 + i] = int32_t(off + e);
+    }
+    const uint8_t* wid = wire + kShardHeaderBytes + g.max_rows * 4;
     int32_t* dst = out_ids + off;
-    const long long stride = (long long)gridDim.x * kBlockThreads;
     if (g.id_bytes == 2) {
         const uint16_t* w = reinterpret_cast<const uint16_t*>(wid);
-        for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < cnt; i += stride) dst[i] = w[i];
+        for (long long i = t0; i < cnt; i += stride) dst[i] = w[i];
     } else {
         const int32_t* w = reinterpret_cast<const int32_t*>(wid);
-        for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < cnt; i += stride) dst[i] = w[i];
+        for (long long i = t0; i < cnt; i += stride) dst[i] = w[i];
     }
-}
-
-// Last launch of an unpack: the verdict the caller reads whenever it wants (ovtk_shard_result, include/ovtk_amd.h).
-static __global__ __launch_bounds__(kWave) void shard_result_kernel(const RunStatus* status, ovtk_shard_result* res) {
-    if (threadIdx.x != 0) return;
-    res->n_ids = status->n_out;
-    res->max_shard_ids = status->stage_need;
-    res->reserved = 0;
-    const uint32_t f = status->flags;
-    res->status = (f & kFlagOutCapacity) ? OVTK_E_UNSUPPORTED : (f & kFlagStageOverflow) ? OVTK_E_CAPACITY : (f & kFlagRange) ? OVTK_E_RANGE : OVTK_OK;
 }
 
 }  // namespace ovtk
