@@ -1,0 +1,174 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties (the oracle needs minutes for
+these batches): lossless encode -> decode round trip, independence of how the rows are sharded ("linearity": the
+result of a batch is the concatenation of the results of its halves), determinism, offsets that are ascending and
+gap-free, agreement of the fused paths with the op-by-op chains, a byte checksum of the detokenizer output against the
+per-token checksums -- plus the oracle on a prefix of every batch."""
+import numpy as np
+import pytest
+
+from openvino_tokenizers_amd.ops import (BPETokenizer, ByteFallback, FusedDetokenizer, FusedSplitBPE, FusedSplitWordpiece,
+                                         FuzeRagged, RaggedToDense, RegexSplit, VocabDecoder, WordpieceTokenizer)
+from oracle import oracle as O
+from tests.util import BpeTok
+from tools.harness import pack_strings
+from tools.make_tokenizers import load_tokenizer
+from tools.workloads import TextModel, ragged_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(arrays):
+    import torch
+    return [torch.as_tensor(a, device="cuda") for a in arrays]
+
+
+def check_offsets(begins, ends, n_ids):
+    import torch
+    assert int(begins[0]) == 0 and int(ends[-1]) == n_ids
+    assert bool(torch.all(ends[:-1] == begins[1:])) and bool(torch.all(ends >= begins))
+
+
+def halves_equal_whole(run, rb, re_, b, e, c, whole):
+    """Rows [0, h) and [h, n) encoded on their own give the whole batch's ids back to back."""
+    import torch
+    n = len(rb)
+    h = n // 2 + 17
+    parts = []
+    for lo, hi in ((0, h), (h, n)):
+        rb2 = (rb[lo:hi] - rb[lo]).astype(np.int32)
+        re2 = (re_[lo:hi] - rb[lo]).astype(np.int32)
+        s0, s1 = int(rb[lo]), int(re_[hi - 1])
+        parts.append(run(rb2, re2, b[s0:s1], e[s0:s1], c))
+    ids = torch.cat([p[2] for p in parts])
+    ends = torch.cat([parts[0][1], parts[1][1] + parts[0][2].numel()])
+    assert torch.equal(ids, whole[2]) and torch.equal(ends, whole[1])
+
+
+def decode_rows(tok_vocab, begins, ends, ids, pad, lib):
+    """Ragged ids -> RaggedToDense (pad id, skipped) -> fused VocabDecoder + FuzeRagged: one string per row."""
+    import torch
+    assert not bool((ids == pad).any()), "the pad id occurs in the encoding"
+    width = int((ends - begins).max())
+    dense, _ = RaggedToDense(lib=lib).evaluate([begins, ends, ids, np.int32(width), np.int32(pad)])
+    dec = VocabDecoder(skip_tokens=[pad], lib=lib)
+    return FusedDetokenizer(dec).evaluate([dense] + list(pack_strings(tok_vocab)))
+
+
+def same_text(out, b, e, c):
+    import torch
+    ob, oe, oc = out
+    lens = torch.as_tensor(e - b, device="cuda")
+    assert torch.equal(oe - ob, lens), "decoded row lengths differ from the input"
+    assert int(b[0]) == 0 and np.array_equal(e[:-1], b[1:]), "test text is laid out back to back"
+    assert torch.equal(oc, torch.as_tensor(c, device="cuda")), "decode(encode(text)) != text"
+
+
+@pytest.mark.parametrize("name, kind, rows", [("gpt2", "zipf", 65536), ("llama3", "mixed", 131072)])
+def test_bpe_full_size(hip_lib, name, kind, rows):
+    """Config 2 (GPT-2-shaped, fused) and one config-4 shard (Llama-3-shaped, chain)."""
+    import torch
+    tok = BpeTok.load(name)
+    b, e, c = TextModel(1234, kind).batch(rows, 512, seed=77)
+    rb, re_ = ragged_rows(rows)
+    pat = tok.pattern_u8()
+    split = RegexSplit("isolate", lib=hip_lib)
+    bpe = BPETokenizer(**tok.attrs, lib=hip_lib)
+    fused = FusedSplitBPE(split, bpe) if name == "gpt2" else None
+
+    def chain(rb_, re2, b_, e_, c_):
+        sp = split.evaluate(dev([rb_, re2, b_, e_]) + [c_, pat])
+        return bpe.evaluate(list(sp[:5]) + tok.consts)
+
+    def run(rb_, re2, b_, e_, c_):
+        if fused is None:
+            return chain(rb_, re2, b_, e_, c_)
+        return fused.evaluate(dev([rb_, re2, b_, e_]) + [c_, pat], tok.consts)
+
+    d_c = torch.as_tensor(c, device="cuda")
+    whole = run(rb, re_, b, e, d_c)
+    n_ids = whole[2].numel()
+    check_offsets(whole[0], whole[1], n_ids)
+    again = run(rb, re_, b, e, d_c)
+    assert all(torch.equal(x, y) for x, y in zip(whole, again)), "two runs differ"
+    if fused is not None:
+        ch = chain(rb, re_, b, e, d_c)
+        assert all(torch.equal(x, y) for x, y in zip(whole, ch)), "fused encode differs from RegexSplit -> BPETokenizer"
+    halves_equal_whole(run, rb, re_, b, e, d_c, whole)
+    # byte-level BPE is lossless: the ids decode to exactly the input bytes
+    pad = len(tok.vocab) - 1
+    same_text(decode_rows(tok.vocab, whole[0], whole[1], whole[2], pad, hip_lib), b, e, c)
+    # the oracle on the first rows
+    k = 1500
+    ref = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(rb[:k], re_[:k], b[:k], e[:k], c)[:5])
+    assert np.array_equal(ref[1], whole[1][:k].cpu().numpy()) and np.array_equal(ref[2], whole[2][: int(ref[1][-1])].cpu().numpy())
+
+
+def test_wordpiece_full_size(hip_lib):
+    """Config 3: BERT-shaped WordPiece, 65 536 x ~256-byte rows."""
+    import torch
+    tok = load_tokenizer("bert")
+    rows = 65536
+    b, e, c = TextModel(1234, "zipf").batch(rows, 256, seed=78)
+    c = np.frombuffer(c.tobytes().lower(), np.uint8).copy()
+    rb, re_ = ragged_rows(rows)
+    from bench import BERT_PUNCT, BERT_WS
+    ws = RegexSplit("remove", lib=hip_lib)
+    pu = RegexSplit("isolate", lib=hip_lib)
+    wp = WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], lib=hip_lib)
+    consts = list(pack_strings(tok["vocab"])) + [np.asarray(tok["unk_id"], np.int32)]
+    fused = FusedSplitWordpiece(ws, pu, wp)
+    u8 = lambda s: np.frombuffer(s.encode(), np.uint8)  # noqa: E731
+
+    def run(rb_, re2, b_, e_, c_):
+        return fused.evaluate(dev([rb_, re2, b_, e_]) + [c_], u8(BERT_WS), u8(BERT_PUNCT), consts)
+
+    d_c = torch.as_tensor(c, device="cuda")
+    whole = run(rb, re_, b, e, d_c)
+    check_offsets(whole[0], whole[1], whole[2].numel())
+    s1 = ws.evaluate(dev([rb, re_, b, e]) + [d_c, u8(BERT_WS)])
+    s2 = pu.evaluate(list(s1[:5]) + [u8(BERT_PUNCT)])
+    ch = wp.evaluate(list(s2[:5]) + consts)
+    assert all(torch.equal(x, y) for x, y in zip(whole, ch)), "fused WordPiece differs from the three-op chain"
+    halves_equal_whole(run, rb, re_, b, e, d_c, whole)
+    k = 1500
+    o1 = O.RegexSplit(BERT_WS, "remove")(rb[:k], re_[:k], b[:k], e[:k], c)
+    o2 = O.RegexSplit(BERT_PUNCT, "isolate")(*o1[:5])
+    ref = O.WordpieceTokenizer(tok["vocab"], tok["suffix_indicator"], tok["max_bytes_per_word"])(*o2[:5], tok["unk_id"])
+    assert np.array_equal(ref[1], whole[1][:k].cpu().numpy()) and np.array_equal(ref[2], whole[2][: int(ref[1][-1])].cpu().numpy())
+
+
+def test_detokenize_full_size(hip_lib):
+    """Config 5 chunk: 16 384 x 2 048 ids (< 2^31 output bytes per call)."""
+    import torch
+    tok = BpeTok.load("gpt2")
+    rows, S, V = 16384, 2048, len(tok.vocab)
+    rng = np.random.default_rng(5)
+    ids = rng.integers(0, V - 1, size=(rows, S), dtype=np.int32)
+    pad = V - 1
+    ids[rng.random((rows, S)) < 0.01] = pad
+    vconst = list(pack_strings(tok.vocab))
+    d_ids = torch.as_tensor(ids, device="cuda")
+    dec = VocabDecoder(skip_tokens=[pad], lib=hip_lib)
+    fused = FusedDetokenizer(dec, byte_fallback=True).evaluate([d_ids] + vconst)
+    r = dec.evaluate([d_ids] + vconst)
+    bf = ByteFallback(lib=hip_lib).evaluate(list(r[2:5]))
+    fz = FuzeRagged(lib=hip_lib).evaluate([r[0], r[1], bf[0], bf[1]])
+    assert torch.equal(fused[0], fz[0]) and torch.equal(fused[1], fz[1]) and torch.equal(fused[2], bf[2]), "fused != chain"
+    # length and byte checksum of every row = sums over its tokens (GPT-2-shaped vocabularies hold no <0xNN> tokens,
+    # so ByteFallback changes nothing here)
+    lens = (vconst[1] - vconst[0]).astype(np.int64)
+    sums = np.add.reduceat(np.concatenate([vconst[2].astype(np.int64), [0]]), vconst[0].astype(np.int64)) * (lens > 0)
+    lens[pad] = 0
+    sums[pad] = 0
+    want_len = lens[ids].sum(axis=1)
+    got_len = (fused[1] - fused[0]).cpu().numpy().astype(np.int64)
+    assert np.array_equal(got_len, want_len)
+    csum = torch.cumsum(fused[2].to(torch.int64), 0)
+    csum = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), csum])
+    got_sum = (csum[fused[1].long()] - csum[fused[0].long()]).cpu().numpy()
+    assert np.array_equal(got_sum, sums[ids].sum(axis=1))
+    k = 8
+    o = O.vocab_decoder(ids[:k], tok.vocab, [pad])
+    obf = O.byte_fallback(*o[2:5])
+    ofz = O.fuze(o[0], o[1], obf[0], obf[1])
+    assert np.array_equal(ofz[1], fused[1][:k].cpu().numpy()) and np.array_equal(obf[2][: int(ofz[1][-1])], fused[2][: int(ofz[1][-1])].cpu().numpy())
