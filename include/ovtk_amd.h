@@ -352,6 +352,29 @@ int ovtk_combine_segments(const ovtk_ragged_i32* segs, int n_segs, const int32_t
                           int32_t* out_ends, int32_t* out_data, int32_t* out_ids, int64_t out_capacity,
                           int64_t* n_out, int mem, int device, void* stream);
 
+/* Fused Truncate -> CombineSegments -> RaggedToDense x 2 (tokenizer_pipeline.py TruncationStep, CombineSegmentsStep,
+ * PaddingStep): input_ids / attention_mask / token_type_ids straight from the ragged segments, same values as chaining
+ * ovtk_truncate, ovtk_combine_segments and ovtk_ragged_to_dense.  trunc_a / trunc_b: indices into segs of the truncated
+ * segment(s) (-1: none; both >= 0: pair truncation with `mode`).  target_dim < 0: the longest combined row, as the
+ * PaddingStep's ReduceMax computes it (one extra kernel and host wait); with pad_max_length the larger of max_length...
+ * is the caller's business: pass the target you want.  *out_target_dim = the row width used; outputs are [n_rows, width]
+ * with capacity out_capacity elements each (out_mask / out_type_ids may be NULL). */
+typedef struct {
+    const ovtk_ragged_i32* segs;
+    int n_segs;
+    const int32_t* segment_ids;   /* i32[n_segs], HOST memory */
+    int trunc_a, trunc_b;
+    int32_t max_length;
+    const char* trunc_side;       /* "left" | "right" */
+    const char* trunc_mode;       /* "only_first" | "only_second" | "longest_first" (pair truncation) */
+    int32_t target_dim;
+    int32_t pad_value;            /* input_ids padding */
+    int32_t type_pad_value;       /* token_type_ids padding */
+    int pad_right;
+} ovtk_encode_tail_params;
+int ovtk_encode_tail_run(const ovtk_encode_tail_params* p, int32_t* out_ids, uint8_t* out_mask, int32_t* out_type_ids,
+                         int64_t out_capacity, int32_t* out_target_dim, int mem, int device, void* stream);
+
 /* Fused VocabDecoder -> [ByteFallback] -> FuzeRagged (tokenizer_pipeline.py:1321-1371): one string per row. */
 int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len,
                         const int32_t* skip_tokens_input, int64_t n_skip_tokens_input, int byte_fallback,

@@ -79,6 +79,12 @@ class RaggedI32(C.Structure):
                 ("n_data", C.c_int64)]
 
 
+class EncodeTailParams(C.Structure):
+    _fields_ = [("segs", C.c_void_p), ("n_segs", C.c_int), ("segment_ids", C.c_void_p), ("trunc_a", C.c_int), ("trunc_b", C.c_int),
+                ("max_length", C.c_int32), ("trunc_side", C.c_char_p), ("trunc_mode", C.c_char_p), ("target_dim", C.c_int32),
+                ("pad_value", C.c_int32), ("type_pad_value", C.c_int32), ("pad_right", C.c_int)]
+
+
 class ShardResult(C.Structure):
     _fields_ = [("n_ids", C.c_int64), ("max_shard_ids", C.c_int64), ("status", C.c_int64), ("reserved", C.c_int64)]
 
@@ -93,7 +99,7 @@ EXPORTS = [
     "ovtk_ragged_to_dense",
     "ovtk_vocab_decoder_create", "ovtk_vocab_decoder_run", "ovtk_vocab_decoder_destroy",
     "ovtk_byte_fallback", "ovtk_fuze_ragged", "ovtk_detokenize_run",
-    "ovtk_utf8_validate", "ovtk_truncate", "ovtk_combine_segments",
+    "ovtk_utf8_validate", "ovtk_truncate", "ovtk_combine_segments", "ovtk_encode_tail_run",
     "ovtk_trie_tokenizer_create", "ovtk_trie_tokenizer_run", "ovtk_trie_tokenizer_destroy",
     "ovtk_string_tensor_packed_bytes", "ovtk_string_tensor_unpack", "ovtk_string_tensor_pack",
     "ovtk_shard_exchange_create", "ovtk_shard_max_rows", "ovtk_shard_wire_bytes", "ovtk_shard_pack", "ovtk_shard_unpack",

@@ -949,38 +949,35 @@ int ovtk_truncate(int n_inputs, const int32_t* begins0, const int32_t* ends0, co
 }
 
 // ------------------------------------------------------------------------------- CombineSegments
-int ovtk_combine_segments(const ovtk_ragged_i32* segs, int n_segs, const int32_t* segment_ids, int32_t* out_begins,
-                          int32_t* out_ends, int32_t* out_data, int32_t* out_ids, int64_t out_capacity, int64_t* n_out,
-                          int mem, int device, void* stream) {
-    if (!segs || !segment_ids || !n_out || n_segs < 1 || out_capacity < 0) return set_error(OVTK_E_ARG, "combine_segments: bad arguments");
-    if (n_segs > kMaxSegments) return set_error(OVTK_E_UNSUPPORTED, "combine_segments: more than 16 inputs");
-    int64_t rows = 0;
+namespace {
+// Validation + (host memory) staging shared by the ops that take k ragged i32 segments.
+int check_segments(const ovtk_ragged_i32* segs, int n_segs, const int32_t* segment_ids, const char* op, int64_t* rows) {
+    if (!segs || !segment_ids || n_segs < 1) return set_error(OVTK_E_ARG, std::string(op) + ": bad arguments");
+    if (n_segs > kMaxSegments) return set_error(OVTK_E_UNSUPPORTED, std::string(op) + ": more than 16 inputs");
+    *rows = 0;
     for (int j = 0; j < n_segs; ++j) {
         if (segs[j].n < 0 || segs[j].n_data < 0 || segs[j].n >= INT32_MAX || segs[j].n_data >= INT32_MAX)
-            return set_error(OVTK_E_ARG, "combine_segments: bad size");
-        rows = std::max(rows, segs[j].n);
+            return set_error(OVTK_E_ARG, std::string(op) + ": bad size");
+        *rows = std::max(*rows, segs[j].n);
     }
     for (int j = 0; j < n_segs; ++j)  // combine_segments.cpp:110-116 indexes row i of every non-scalar input
-        if (segs[j].n != 1 && segs[j].n != rows)
-            return set_error(OVTK_E_ARG, "combine_segments: inputs must have one row or the common number of rows");
-    if (int rc = use_device(device)) return rc;
-    *n_out = 0;
-    if (rows == 0) return OVTK_OK;
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    WorkspaceLease ws(device);
-    RunStatus* st = nullptr;
-    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
-    CombineDev d{};
+        if (segs[j].n != 1 && segs[j].n != *rows)
+            return set_error(OVTK_E_ARG, std::string(op) + ": inputs must have one row or the common number of rows");
+    return OVTK_OK;
+}
+
+int stage_segments(Workspace& ws, const ovtk_ragged_i32* segs, int n_segs, const int32_t* segment_ids, int mem, hipStream_t s,
+                   CombineDev& d) {
     d.n_segs = n_segs;
     if (mem == OVTK_MEM_HOST) {  // one staging buffer for all segments
         size_t total = 0;
         for (int j = 0; j < n_segs; ++j) total += (size_t(segs[j].n) * 2 + size_t(segs[j].n_data)) * 4;
-        if (int rc = ws->in_chars.ensure(total)) return rc;
+        if (int rc = ws.in_chars.ensure(total)) return rc;
     }
     size_t cur = 0;
     auto place = [&](const int32_t* src, int64_t count, const int32_t** dst) -> int {
         if (mem != OVTK_MEM_HOST) { *dst = src; return OVTK_OK; }
-        int32_t* p = reinterpret_cast<int32_t*>(ws->in_chars.as<uint8_t>() + cur);
+        int32_t* p = reinterpret_cast<int32_t*>(ws.in_chars.as<uint8_t>() + cur);
         if (count) OVTK_HIP(hipMemcpyAsync(p, src, size_t(count) * 4, hipMemcpyHostToDevice, s));
         cur += size_t(count) * 4;
         *dst = p;
@@ -994,6 +991,25 @@ int ovtk_combine_segments(const ovtk_ragged_i32* segs, int n_segs, const int32_t
         d.n_data[j] = int32_t(segs[j].n_data);
         d.ids[j] = segment_ids[j];
     }
+    return OVTK_OK;
+}
+}  // namespace
+
+int ovtk_combine_segments(const ovtk_ragged_i32* segs, int n_segs, const int32_t* segment_ids, int32_t* out_begins,
+                          int32_t* out_ends, int32_t* out_data, int32_t* out_ids, int64_t out_capacity, int64_t* n_out,
+                          int mem, int device, void* stream) {
+    if (!n_out || out_capacity < 0) return set_error(OVTK_E_ARG, "combine_segments: bad arguments");
+    int64_t rows = 0;
+    if (int rc = check_segments(segs, n_segs, segment_ids, "combine_segments", &rows)) return rc;
+    if (int rc = use_device(device)) return rc;
+    *n_out = 0;
+    if (rows == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    CombineDev d{};
+    if (int rc = stage_segments(*ws.ws, segs, n_segs, segment_ids, mem, s, d)) return rc;
     int32_t *d_b = nullptr, *d_e = nullptr, *d_d = nullptr, *d_i = nullptr;
     if (int rc = out_target(ws->out_a, out_begins, size_t(rows) * 4, mem, &d_b)) return rc;
     if (int rc = out_target(ws->out_b, out_ends, size_t(rows) * 4, mem, &d_e)) return rc;
@@ -1014,6 +1030,73 @@ int ovtk_combine_segments(const ovtk_ragged_i32* segs, int n_segs, const int32_t
     err = err ? err : copy_back(out_ends, d_e, size_t(rows) * 4, mem, s);
     err = err ? err : copy_back(out_data, d_d, size_t(*n_out) * 4, mem, s);
     err = err ? err : copy_back(out_ids, d_i, size_t(*n_out) * 4, mem, s);
+    if (err) return err;
+    if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    return OVTK_OK;
+}
+
+// ------------------------------------------------------------------------------- Truncate + CombineSegments + RaggedToDense
+int ovtk_encode_tail_run(const ovtk_encode_tail_params* p, int32_t* out_ids, uint8_t* out_mask, int32_t* out_type_ids,
+                         int64_t out_capacity, int32_t* out_target_dim, int mem, int device, void* stream) {
+    if (!p || !out_ids || !out_target_dim || out_capacity < 0) return set_error(OVTK_E_ARG, "encode_tail: bad arguments");
+    int64_t rows = 0;
+    if (int rc = check_segments(p->segs, p->n_segs, p->segment_ids, "encode_tail", &rows)) return rc;
+    if (p->trunc_a >= p->n_segs || p->trunc_b >= p->n_segs || (p->trunc_b >= 0 && (p->trunc_a < 0 || p->trunc_a == p->trunc_b)))
+        return set_error(OVTK_E_ARG, "encode_tail: bad truncated segment indices");
+    TailDev t{};
+    t.trunc_a = p->trunc_a < 0 ? -1 : p->trunc_a;
+    t.trunc_b = p->trunc_b < 0 ? -1 : p->trunc_b;
+    t.max_length = p->max_length;
+    t.mode = 2;
+    if (t.trunc_a >= 0) {
+        const std::string sd(p->trunc_side ? p->trunc_side : ""), md(p->trunc_mode ? p->trunc_mode : "");
+        if (sd != "left" && sd != "right") return set_error(OVTK_E_ARG, "Unknown truncation side: " + sd);
+        t.left = sd == "left";
+        if (t.trunc_b >= 0) {
+            if (md == "only_first") t.mode = 0;
+            else if (md == "only_second") t.mode = 1;
+            else if (md == "longest_first") t.mode = 2;
+            else return set_error(OVTK_E_ARG, "Unknown truncation mode: " + md);
+        }
+    }
+    t.pad_value = p->pad_value;
+    t.type_pad = p->type_pad_value;
+    t.pad_right = p->pad_right != 0;
+    if (int rc = use_device(device)) return rc;
+    *out_target_dim = p->target_dim < 0 ? 0 : p->target_dim;
+    if (rows == 0) return OVTK_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    WorkspaceLease ws(device);
+    RunStatus* st = nullptr;
+    if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+    if (int rc = stage_segments(*ws.ws, p->segs, p->n_segs, p->segment_ids, mem, s, t.c)) return rc;
+    int32_t T = p->target_dim;
+    if (T < 0) {  // the PaddingStep's ReduceMax: the longest combined row
+        OVTK_LAUNCH(ws->marks, "tail_measure", tail_measure_kernel, grid_for_elems(rows), kBlockThreads, s, t, (long long)rows, st);
+        if (int rc = finish_status(*ws.ws, s)) return rc;
+        if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "encode_tail: a row reads past its data tensor");
+        T = ws->host_status->n_out;
+    }
+    *out_target_dim = T;
+    const int64_t need = rows * int64_t(T);
+    if (need > out_capacity) return set_error(OVTK_E_CAPACITY, "encode_tail: output buffers too small for [rows, " + std::to_string(T) + "]");
+    if (need == 0) return OVTK_OK;
+    t.target = T;
+    int32_t *d_ids = nullptr, *d_types = nullptr;
+    uint8_t* d_mask = nullptr;
+    if (int rc = out_target(ws->out_a, out_ids, size_t(need) * 4, mem, &d_ids)) return rc;
+    if (out_mask)
+        if (int rc = out_target(ws->out_b, out_mask, size_t(need), mem, &d_mask)) return rc;
+    if (out_type_ids)
+        if (int rc = out_target(ws->out_c, out_type_ids, size_t(need) * 4, mem, &d_types)) return rc;
+    const int grid = int(std::min<long long>((rows + kWavesPerBlock - 1) / kWavesPerBlock, (long long)device_cu_count(device) * 8));
+    OVTK_LAUNCH(ws->marks, "encode_tail", tail_dense_kernel, grid, kBlockThreads, s, t, (long long)rows, d_ids, d_mask, d_types, st);
+    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "encode_tail: a row reads past its data tensor");
+    int err = 0;
+    err = err ? err : copy_back(out_ids, d_ids, size_t(need) * 4, mem, s);
+    if (out_mask) err = err ? err : copy_back(out_mask, d_mask, size_t(need), mem, s);
+    if (out_type_ids) err = err ? err : copy_back(out_type_ids, d_types, size_t(need) * 4, mem, s);
     if (err) return err;
     if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
     return OVTK_OK;

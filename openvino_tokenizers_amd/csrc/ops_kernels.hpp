@@ -752,6 +752,120 @@ static __global__ __launch_bounds__(kBlockThreads) void combine_copy_kernel(Comb
     }
 }
 
+// ------------------------------------------------------------------------------- Truncate + CombineSegments + RaggedToDense
+// The tail of every encode pipeline (tokenizer_pipeline.py TruncationStep -> CombineSegmentsStep -> PaddingStep) in one
+// kernel: a wave owns a row, cuts the one or two truncated segments (src/truncate.cpp:37-150), lays the segments out
+// back to back (src/combine_segments.cpp:36-134) and writes the padded rows of input_ids / attention_mask /
+// token_type_ids directly (src/ragged_to_dense.cpp:70-174) -- the combined ragged tensor never exists.
+struct TailDev {
+    CombineDev c;
+    int trunc_a, trunc_b;  // indices of the truncated segments (-1: none); trunc_b only for pair truncation
+    int32_t max_length;
+    int left, mode;        // as truncate_kernel
+    int32_t target, pad_value, type_pad;
+    int pad_right;
+};
+
+// Kept range [b, e) of segment j in row i after truncation; false when the offsets leave the data tensor.
+__device__ __forceinline__ bool tail_segment(const TailDev& t, long long i, int j, int32_t& b, int32_t& e) {
+    const CombineDev& c = t.c;
+    const long long r = c.n_rows[j] == 1 ? 0 : i;
+    b = c.begins[j][r];
+    e = c.ends[j][r];
+    if (b < 0 || e < b || e > c.n_data[j]) return false;
+    if (j != t.trunc_a && j != t.trunc_b) return true;
+    int32_t keep = e - b;
+    const int32_t m = t.max_length;
+    if (t.trunc_b < 0) {
+        keep = keep < m ? keep : m;  // single input (:42-60)
+    } else {
+        const int o = j == t.trunc_a ? t.trunc_b : t.trunc_a;
+        const long long ro = c.n_rows[o] == 1 ? 0 : i;
+        const int32_t other = c.ends[o][ro] - c.begins[o][ro];
+        const int32_t fl = j == t.trunc_a ? keep : other, sl = j == t.trunc_a ? other : keep;
+        if (fl + sl > m) {
+            const int32_t half = m / 2, half_up = m / 2 + m % 2;
+            int32_t keep_f = fl, keep_s = sl;
+            if (t.mode == 0) keep_f = fl > m ? m : fl;
+            else if (t.mode == 1) keep_s = sl > m ? m : sl;
+            else if (fl >= half_up && sl <= half) keep_f = m - sl;
+            else if (fl < half_up && sl > half) keep_s = m - fl;
+            else {
+                keep_f = half + (m % 2) * (fl >= sl);
+                keep_s = half + (m % 2) * (fl < sl);
+            }
+            keep = j == t.trunc_a ? keep_f : keep_s;
+        }
+    }
+    if (t.left) b = e - keep; else e = b + keep;
+    return true;
+}
+
+// Longest combined row (the PaddingStep's ReduceMax) -> status->n_out.
+static __global__ __launch_bounds__(kBlockThreads) void tail_measure_kernel(TailDev t, long long n_rows, RunStatus* status) {
+    const long long stride = (long long)gridDim.x * kBlockThreads;
+    int longest = 0;
+    for (long long i = (long long)blockIdx.x * kBlockThreads + threadIdx.x; i < n_rows; i += stride) {
+        int tot = 0;
+        for (int j = 0; j < t.c.n_segs; ++j) {
+            int32_t b, e;
+            if (!tail_segment(t, i, j, b, e)) atomicOr(&status->flags, kFlagRange);
+            else tot += e - b;
+        }
+        longest = tot > longest ? tot : longest;
+    }
+    longest = wave_max(longest);
+    if (lane_id() == 0 && longest) atomicMax(&status->n_out, longest);
+}
+
+static __global__ __launch_bounds__(kBlockThreads) void tail_dense_kernel(TailDev t, long long n_rows, int32_t* out_ids,
+                                                                          uint8_t* out_mask, int32_t* out_types, RunStatus* status) {
+    const int l = lane_id();
+    const long long stride = (long long)gridDim.x * kWavesPerBlock;
+    const int T = t.target;
+    for (long long i = (long long)blockIdx.x * kWavesPerBlock + wave_in_block(); i < n_rows; i += stride) {
+        int total = 0;
+        bool ok = true;
+        for (int j = 0; j < t.c.n_segs; ++j) {
+            int32_t b, e;
+            ok = tail_segment(t, i, j, b, e) && ok;
+            total += ok ? e - b : 0;
+        }
+        if (!ok) {
+            if (l == 0) atomicOr(&status->flags, kFlagRange);
+            continue;
+        }
+        const int used = total < T ? total : T;                 // ragged_to_dense.cpp: a longer row is cut at the target
+        const int first = t.pad_right ? 0 : T - used;            // where the row's elements start in the dense row
+        int32_t* ids = out_ids + i * T;
+        uint8_t* mask = out_mask ? out_mask + i * T : nullptr;
+        int32_t* types = out_types ? out_types + i * T : nullptr;
+        for (int p = l; p < T; p += kWave) {
+            const bool in_row = p >= first && p < first + used;
+            if (!in_row) {
+                ids[p] = t.pad_value;
+                if (mask) mask[p] = 0;
+                if (types) types[p] = t.type_pad;
+            }
+        }
+        int at = 0;
+        for (int j = 0; j < t.c.n_segs && at < used; ++j) {
+            int32_t b, e;
+            tail_segment(t, i, j, b, e);
+            int len = e - b;
+            if (at + len > used) len = used - at;
+            const int32_t* src = t.c.data[j] + b;
+            const int32_t sid = t.c.ids[j];
+            for (int k = l; k < len; k += kWave) {
+                ids[first + at + k] = src[k];
+                if (mask) mask[first + at + k] = 1;
+                if (types) types[first + at + k] = sid;
+            }
+            at += len;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------- string tensor wire format
 // Pack (the inverse of parse_packed_strings, src/utils.cpp:18-29): string i goes to bytes[off_i, off_i + len_i) and
 // its end offset to header word 2 + i; off = exclusive scan of the lengths.

@@ -700,6 +700,54 @@ class CombineSegments(_Op):
         return [ob[:rows], oe[:rows], od[:n_out.value], ob[:rows], oe[:rows], oi[:n_out.value]]
 
 
+class FusedEncodeTail(_Op):
+    """Truncate -> CombineSegments -> RaggedToDense (input_ids + mask) -> RaggedToDense (token_type_ids) in one kernel
+    (ovtk_encode_tail_run): what tokenizer_pipeline.py's TruncationStep, CombineSegmentsStep and PaddingStep build, without
+    the combined ragged tensor.  segments: [(begins, ends, data)] i32; truncated: indices of the one or two segments
+    Truncate applies to; target_dim None = the longest combined row (the PaddingStep's ReduceMax)."""
+
+    def __init__(self, max_length=2**31 - 1, trunc_side="right", trunc_mode="longest_first", pad_right=True, device=0, lib=None):
+        super().__init__(device, lib)
+        self.max_length, self.trunc_side, self.trunc_mode, self.pad_right = int(max_length), trunc_side, trunc_mode, bool(pad_right)
+
+    def evaluate(self, segments, segment_ids, truncated=(), pad_value=0, type_pad_value=0, target_dim=None):
+        k = len(segments)
+        ids = _host(segment_ids, np.int32).reshape(-1)
+        m = _Mem(next((s[2] for s in segments if _is_torch(s[2])), segments[0][2]))
+        segs = (L.RaggedI32 * k)()
+        rows = 0
+        for j, (b, e, d) in enumerate(segments):
+            b = b.reshape(-1) if _is_torch(b) else np.atleast_1d(b)
+            e = e.reshape(-1) if _is_torch(e) else np.atleast_1d(e)
+            bb, pb = m.inp(b, "i32")
+            ee, pe = m.inp(e, "i32")
+            dd, pd = m.inp(d, "i32")
+            segs[j] = L.RaggedI32(pb, pe, pd, len(bb), len(dd))
+            rows = max(rows, len(bb))
+        tr = list(truncated) + [-1, -1]
+        p = L.EncodeTailParams(C.cast(segs, C.c_void_p), k, ids.ctypes.data_as(C.c_void_p), int(tr[0]), int(tr[1]),
+                               C.c_int32(min(self.max_length, 2**31 - 1)), _bytes_of(self.trunc_side), _bytes_of(self.trunc_mode),
+                               -1 if target_dim is None else int(target_dim), int(pad_value), int(type_pad_value), int(self.pad_right))
+        T = C.c_int32(0)
+        if target_dim is None:   # measure first: the width decides the output shapes
+            one, pone = m.alloc(1, "i32")
+            rc = self._lib.ovtk_encode_tail_run(C.byref(p), pone, None, None, C.c_int64(0), C.byref(T), m.mem, self.device, m.stream)
+            if rc not in (L.OVTK_OK, L.E_CAPACITY):
+                self._chk(rc)
+            p.target_dim = T.value
+        width = int(p.target_dim)
+        n = rows * width
+        out_ids, pids = m.alloc(n, "i32")
+        mask, pmask = m.alloc(n, "bool")
+        types, ptypes = m.alloc(n, "i32")
+        self._chk(self._lib.ovtk_encode_tail_run(C.byref(p), pids, pmask, ptypes, C.c_int64(max(n, 1)), C.byref(T), m.mem, self.device,
+                                                 m.stream))
+        shape = (rows, width)
+        if m.torch:
+            return [out_ids[:n].reshape(shape), mask[:n].reshape(shape).bool(), types[:n].reshape(shape)]
+        return [out_ids[:n].reshape(shape), mask[:n].reshape(shape).astype(bool), types[:n].reshape(shape)]
+
+
 class FusedDetokenizer:
     """VocabDecoder -> [ByteFallback] -> FuzeRagged in one pass (ovtk_detokenize_run): the same begins/ends/chars as
     chaining the three ops (tokenizer_pipeline.py:1321-1371) without the per-token offsets going through HBM."""

@@ -154,3 +154,34 @@ def test_combine_segments_errors(backend):
         CombineSegments(lib=backend.lib).evaluate([b, ok, d, b[:1], ok[:1], d, np.zeros(3, np.int32), np.zeros(3, np.int32), d,
                                                    np.array([0, 1, 2], np.int32)])
     assert ei.value.code == L.E_ARG
+
+
+@pytest.mark.parametrize("shape", ["single", "pair_longest", "pair_left_only_first", "no_trunc_padleft", "fixed_width"])
+def test_fused_encode_tail(backend, shape):
+    """ovtk_encode_tail_run = Truncate -> CombineSegments -> RaggedToDense (ids, mask) + RaggedToDense (segment ids),
+    compared with that chain of the oracle's restatements."""
+    from openvino_tokenizers_amd.ops import FusedEncodeTail
+    rng = np.random.default_rng(len(shape))
+    n = 120 if backend.name == "emu" else 6000
+    one = lambda v: (np.array([0], np.int32), np.array([1], np.int32), np.array([v], np.int32))  # noqa: E731
+    a, b2 = ragged(rng, n, 70), ragged(rng, n, 50)
+    cfg = dict(single=dict(segs=[one(101), a, one(102)], ids=[0, 0, 0], trunc=[1], m=40, side="right", mode="longest_first", pad_right=True, T=None),
+               pair_longest=dict(segs=[one(101), a, one(102), b2, one(102)], ids=[0, 0, 0, 1, 1], trunc=[1, 3], m=61, side="right", mode="longest_first", pad_right=True, T=None),
+               pair_left_only_first=dict(segs=[a, one(5), b2], ids=[0, 0, 1], trunc=[0, 2], m=30, side="left", mode="only_first", pad_right=True, T=None),
+               no_trunc_padleft=dict(segs=[one(1), a], ids=[7, 3], trunc=[], m=2**31 - 1, side="right", mode="longest_first", pad_right=False, T=None),
+               fixed_width=dict(segs=[one(101), a, one(102)], ids=[0, 0, 0], trunc=[1], m=64, side="right", mode="longest_first", pad_right=True, T=48))[shape]
+    segs = [tuple(x.copy() for x in s) for s in cfg["segs"]]
+    # the chain, with the oracle's restatements
+    cut = [list(s) for s in segs]
+    if cfg["trunc"]:
+        res = O.truncate([(segs[j][0], segs[j][1]) for j in cfg["trunc"]], cfg["m"], cfg["side"], cfg["mode"])
+        for j, (tb, te) in zip(cfg["trunc"], res):
+            cut[j][0], cut[j][1] = tb, te
+    cb, ce, cd, ci = O.combine_segments([tuple(s) for s in cut], cfg["ids"])
+    width = int((ce - cb).max()) if cfg["T"] is None else cfg["T"]
+    want_ids, want_mask = O.ragged_to_dense(cb, ce, cd, width, 9, cfg["pad_right"])
+    want_types, _ = O.ragged_to_dense(cb, ce, ci, width, 4, cfg["pad_right"])
+    op = FusedEncodeTail(cfg["m"], cfg["side"], cfg["mode"], cfg["pad_right"], lib=backend.lib)
+    dsegs = [tuple(backend.data(list(s))) for s in segs]
+    got = op.evaluate(dsegs, cfg["ids"], truncated=cfg["trunc"], pad_value=9, type_pad_value=4, target_dim=cfg["T"])
+    assert_same([want_ids, want_mask.astype(bool), want_types], got, backend.host, "FusedEncodeTail")
