@@ -129,7 +129,7 @@ def make_encode_bpe(args, lib, dev, rank):
 
 def make_encode_llama3(args, lib, dev, rank):
     """Config 4 shard: Llama-3-shaped byte-level BPE (tiktoken-style split pattern, 128k merges) on mixed-script text,
-    as the two-op chain RegexSplit -> BPETokenizer (the sequential split matcher has no fused form)."""
+    fused RegexSplit + BPETokenizer (bit-parallel Llama-3 scanner)."""
     tok = BpeTok.load("llama3")
     rows = args.rows if args.rows != 65536 else 131072  # 1 M rows / 8 GPUs
     begins, ends, chars = TextModel(1234, "mixed").batch(rows, args.bytes, seed=4000 + rank)
@@ -140,23 +140,24 @@ def make_encode_llama3(args, lib, dev, rank):
     bpe = BPETokenizer(**tok.attrs, device=dev.index, lib=lib)
     split._ensure(tok.pattern_u8())
     bpe._ensure(d + tok.consts)
-    cap = n_chars + rows
     rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), rows, L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), rows, n_chars))
-    p_rb = torch.empty(rows, dtype=torch.int32, device=dev)
-    p_re = torch.empty(rows, dtype=torch.int32, device=dev)
-    p_b = torch.empty(cap, dtype=torch.int32, device=dev)
-    p_e = torch.empty(cap, dtype=torch.int32, device=dev)
-    sp_out = L.RaggedStringsOut(p_rb.data_ptr(), p_re.data_ptr(), 0, p_b.data_ptr(), p_e.data_ptr(), None, cap, 0)
     out = IdOut(rows, n_chars, dev)
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
     def step():
         o_begins, o_ends, o_ids, o = out.take()
-        L.check(lib, lib.ovtk_regex_split_run(split._h, C.byref(rs), None, C.byref(sp_out), L.MEM_DEVICE, stream))
-        pieces = L.RaggedStrings(p_rb.data_ptr(), p_re.data_ptr(), rows,
-                                 L.Strings(p_b.data_ptr(), p_e.data_ptr(), d[4].data_ptr(), sp_out.n, n_chars))
-        L.check(lib, lib.ovtk_bpe_run(bpe._h, C.byref(pieces), C.byref(o), L.MEM_DEVICE, stream))
+        L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, stream))
         return o_begins, o_ends, o_ids[: o.n_data]
+
+    def enqueue():
+        o_begins, o_ends, o_ids, o = out.take()
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_encode_enqueue(split._h, bpe._h, C.byref(rs), None, C.byref(o), stream, C.byref(pending)))
+
+        def finish():
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
+            return o_begins, o_ends, o_ids[: o.n_data]
+        return finish
 
     def cpu(n_s):
         from oracle import oracle as O
@@ -167,9 +168,9 @@ def make_encode_llama3(args, lib, dev, rank):
         return ref, time.perf_counter() - t1, int(ends[n_s - 1] - begins[0]), "RegexSplit(PCRE2 JIT)+BPETokenizer restatement with warm piece cache"
 
     workload = (f"config 4 shard: Llama-3-shaped byte-level BPE (V=128256, 127999 merges, trained in-process), {rows} x "
-                f"~{args.bytes}-byte mixed-script strings per GPU, RegexSplit (tiktoken-style pattern) -> BPETokenizer, "
+                f"~{args.bytes}-byte mixed-script strings per GPU, fused RegexSplit (tiktoken-style pattern) + BPETokenizer, "
                 f"inputs and outputs in HBM")
-    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe, p_rb, p_re, p_b, p_e), vocab=len(tok.vocab),
+    return dict(step=step, enqueue=enqueue, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe), vocab=len(tok.vocab),
                 workload=workload, metric="input MB/s encoded (Llama-3 BPE, 512-byte mixed-script strings)", dtype="u8/int32",
                 rows=rows, algo=lambda n_tok: n_chars + 4 * n_tok + 16 * rows, sample_rows=min(rows, 16384))
 

@@ -365,7 +365,14 @@ int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_
     auto r = make_rows_run(dev, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
                            [=](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                const bool tickets = w.rows_per_ticket != 0;
-                               if (split && tickets)
+                               const bool llama3 = split && split->dev.kind == kSplitLlama3;
+                               if (llama3 && tickets)
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFusedLlama3, true>), grid, kBlockThreads, s, d_in,
+                                               split->dev, bpe->dev, w);
+                               else if (llama3)
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in,
+                                               split->dev, bpe->dev, w);
+                               else if (split && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFused, true>), grid, kBlockThreads, s, d_in,
                                                split->dev, bpe->dev, w);
                                else if (split)
@@ -390,7 +397,9 @@ int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_
                                if (!w.fold_tail) OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
                            },
                            /*self_alloc=*/true,
-                           split ? resident_blocks_per_cu(lookup_kernel<kFused>) : resident_blocks_per_cu(lookup_kernel<kPieces>),
+                           !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
+                                  : split->dev.kind == kSplitLlama3 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>)
+                                                                    : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (int rc = r->start()) return rc;
     run = std::move(r);
@@ -408,7 +417,7 @@ int check_fused(const ovtk_regex_split* split) {
     if (!split) return set_error(OVTK_E_ARG, "null split handle");
     if (split->max_splits != -1)
         return set_error(OVTK_E_UNSUPPORTED, "fused encode: max_splits is only supported by the RegexSplit op itself");
-    if (split->dev.kind > kSplitGpt2Digits)
+    if (split->dev.kind > kSplitGpt2Digits && split->dev.kind != kSplitLlama3)
         return set_error(OVTK_E_UNSUPPORTED, "fused encode: this pattern is only supported as RegexSplit followed by BPETokenizer");
     return OVTK_OK;
 }
@@ -511,10 +520,13 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
     // range validation of the inputs (the staging arenas it also computes are not needed here)
     OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);
-    const bool seq = h->dev.kind == kSplitLlama3;  // sequential matcher: one lane per row
+    const bool seq = false;  // (split_seq_kernel: the lane-per-row form of the Llama-3 matcher, superseded by the bit-parallel scanner)
     const int seq_grid = (n_rows + kBlockThreads - 1) / kBlockThreads;
     if (seq)
         OVTK_LAUNCH(ws->marks, "split_count", split_seq_kernel<0>, seq_grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
+                    (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
+    else if (h->dev.kind == kSplitLlama3)
+        OVTK_LAUNCH(ws->marks, "split_count", (split_kernel<0, true>), grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
                     (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
     else
         OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
@@ -523,6 +535,9 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
                 w, (long long)out->capacity);
     if (seq)
         OVTK_LAUNCH(ws->marks, "split_write", split_seq_kernel<1>, seq_grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb,
+                    d_re, d_b, d_e, d_sk);
+    else if (h->dev.kind == kSplitLlama3)
+        OVTK_LAUNCH(ws->marks, "split_write", (split_kernel<1, true>), grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb,
                     d_re, d_b, d_e, d_sk);
     else
         OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb, d_re,

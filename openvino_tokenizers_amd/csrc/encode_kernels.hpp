@@ -279,7 +279,7 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     st.emitted += __popcll(__ballot(c & 1)) + 2 * __popcll(__ballot(c & 2));
 }
 
-enum EncodeMode : int { kFused = 0, kPieces = 1 };
+enum EncodeMode : int { kFused = 0, kPieces = 1, kFusedLlama3 = 2 };  // kFusedLlama3: kFused compiled for the Llama-3 scanner
 
 // Whole strings as pieces (kPieces mode, and skipped strings of the fused mode): cols [c_begin, c_end).
 __device__ __forceinline__ void lookup_whole_strings(const BpeDev& T, RowState& st, const EncodeWork& w, WaveMiss& mb,
@@ -415,7 +415,7 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
     while (row >= 0 && row < in.n_rows) {
         if (rpt && row + rpt == chunk_end) tk_issue();  // first row of a ticket
         RowHdr h{0, 0, 0, 0, false};
-        if (MODE == kFused) h = load_row_string(in, load_row_range(in, row));
+        if (MODE != kPieces) h = load_row_string(in, load_row_range(in, row));
         else h = load_row_range(in, row);
         if (alloc) {
             const int cap = dead ? 0 : row_capacity_checked(in, h, T.suffix_len + 1, w.status);
@@ -448,7 +448,7 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
                 }
                 const int sb = h.simple ? h.sb : in.begins[col];
                 const int slen = h.simple ? h.slen : in.ends[col] - sb;
-                scan_string(
+                scan_string<MODE == kFusedLlama3>(
                     ws, sp, in.chars + sb, slen,
                     [&](int np, int c0, int w0, int skew) {
                         for (int jb = 0; jb < np; jb += kWave) {
@@ -736,7 +736,7 @@ static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_row
 
 // ---- RegexSplit as its own op: count pass, then write pass (the scan is cheap enough to run twice).
 // mode 0: row_cnt[row] = number of pieces.  mode 1: write begins/ends/skips at row_out[row].
-template <int WRITE>
+template <int WRITE, bool LLAMA3 = false>
 static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, SplitDev sp, int max_splits, EncodeWork w,
                                                                      int32_t* out_rb, int32_t* out_re,
                                                                      int32_t* out_begins, int32_t* out_ends,
@@ -773,7 +773,7 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
                 out_ends[o + count + idx] = (idx == max_splits) ? se : sb + e;
                 if (out_skips) out_skips[o + count + idx] = 0;
             };
-            scan_string(
+            scan_string<LLAMA3>(
                 ws, sp, in.chars + sb, se - sb,
                 [&](int np, int c0, int, int) {
                     for (int jb = 0; jb < np; jb += kWave) {

@@ -91,6 +91,107 @@ __device__ __forceinline__ uint32_t ascii_class(uint32_t b) {
     return kClsO;
 }
 
+// ---- the Llama-3 pattern, matched literally (one position at a time) ------------------------------
+// (?i:'s|'t|'re|'ve|'m|'ll|'d) | [^\r\n\p{L}\p{N}]?\p{L}+ | \p{N}{1,3} | ?[^\s\p{L}\p{N}]+[\r\n]* | \s*[\r\n]+ | \s+(?!\S) | \s+
+// The alternatives are tried in PCRE2's order, each with its greedy / back-off behaviour.  Used by the lane-per-row
+// kernels of split_seq_device.hpp and as the fallback of the bit-parallel Llama-3 scanner below.
+struct SeqChar {
+    uint32_t cp;
+    int len;   // bytes
+    int cls;   // kClsO / kClsL / kClsN / kClsS (line breaks are kClsS)
+};
+
+__device__ __forceinline__ SeqChar seq_char(const SplitDev& sp, const uint8_t* s, int pos, int slen) {
+    const uint32_t b = s[pos];
+    if (b < 0x80u) return SeqChar{b, 1, int(ascii_class(b))};
+    if (b < 0xC0u) return SeqChar{b, 1, kClsO};  // stray continuation byte (invalid UTF-8: parity is undefined)
+    int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
+    if (pos + n > slen) n = slen - pos;
+    uint32_t cp = b & (0xFFu >> (n + 1));
+    int len = 1;
+    for (; len < n && (s[pos + len] & 0xC0u) == 0x80u; ++len) cp = (cp << 6) | (s[pos + len] & 0x3Fu);
+    return SeqChar{cp, len, int(uc_nibble(sp, cp) & 3u)};
+}
+// Unicode simple case folding restricted to what can equal one of s t r e v m l d (PCRE2_UCP caseless matching):
+// ASCII upper case, and U+017F LATIN SMALL LETTER LONG S which folds to 's'.
+__device__ __forceinline__ uint32_t fold_contraction_letter(uint32_t cp) {
+    if (cp - 'A' < 26u) return cp + 32u;
+    if (cp == 0x17Fu) return 's';
+    return cp;
+}
+__device__ __forceinline__ bool is_line_break(uint32_t cp) { return cp == '\r' || cp == '\n'; }
+
+// End of the match that starts at p (p < slen).
+__device__ __forceinline__ int llama3_match_end(const SplitDev& sp, const uint8_t* s, int slen, int p) {
+    const SeqChar c0 = seq_char(sp, s, p, slen);
+    // (?i:'s|'t|'re|'ve|'m|'ll|'d)
+    if (c0.cp == '\'' && p + 1 < slen) {
+        const SeqChar c1 = seq_char(sp, s, p + 1, slen);
+        const uint32_t f1 = fold_contraction_letter(c1.cp);
+        const int p2 = p + 1 + c1.len;
+        if (f1 == 's' || f1 == 't' || f1 == 'm' || f1 == 'd') return p2;
+        if ((f1 == 'r' || f1 == 'v' || f1 == 'l') && p2 < slen) {
+            const SeqChar c2 = seq_char(sp, s, p2, slen);
+            const uint32_t f2 = fold_contraction_letter(c2.cp);
+            if ((f1 == 'l' && f2 == 'l') || (f1 != 'l' && f2 == 'e')) return p2 + c2.len;
+        }
+    }
+    // [^\r\n\p{L}\p{N}]?\p{L}+   (the optional char is tried first; without it \p{L}+ must start at p)
+    {
+        int q = -1;
+        if (c0.cls == kClsL) q = p;
+        else if (c0.cls != kClsN && !is_line_break(c0.cp) && p + c0.len < slen && seq_char(sp, s, p + c0.len, slen).cls == kClsL)
+            q = p + c0.len;
+        if (q >= 0) {
+            while (q < slen) {
+                const SeqChar c = seq_char(sp, s, q, slen);
+                if (c.cls != kClsL) break;
+                q += c.len;
+            }
+            return q;
+        }
+    }
+    // \p{N}{1,3}
+    if (c0.cls == kClsN) {
+        int q = p + c0.len;
+        for (int k = 1; k < 3 && q < slen; ++k) {
+            const SeqChar c = seq_char(sp, s, q, slen);
+            if (c.cls != kClsN) break;
+            q += c.len;
+        }
+        return q;
+    }
+    //  ?[^\s\p{L}\p{N}]+[\r\n]*
+    {
+        int q = -1;
+        if (c0.cls == kClsO) q = p;
+        else if (c0.cp == ' ' && p + 1 < slen && seq_char(sp, s, p + 1, slen).cls == kClsO) q = p + 1;
+        if (q >= 0) {
+            while (q < slen) {
+                const SeqChar c = seq_char(sp, s, q, slen);
+                if (c.cls != kClsO) break;
+                q += c.len;
+            }
+            while (q < slen && is_line_break(s[q])) ++q;
+            return q;
+        }
+    }
+    // whitespace run [p, e): \s*[\r\n]+ (up to its last line break) | \s+(?!\S) (all but the last char, or all of it
+    // at the end of the string) | \s+
+    int e = p, after_last_break = -1, last_char = p;
+    while (e < slen) {
+        const SeqChar c = seq_char(sp, s, e, slen);
+        if (c.cls != kClsS) break;
+        last_char = e;
+        e += c.len;
+        if (is_line_break(c.cp)) after_last_break = e;
+    }
+    if (after_last_break >= 0) return after_last_break;
+    if (e == slen) return e;
+    if (last_char > p) return last_char;
+    return e;
+}
+
 // Stage bytes [w0, w1) of the string at `str` (global) into ws.text_w.  Returns the skew: string
 // byte p lives at text_bytes(ws)[p - w0 + skew].  Whole dwords are fetched where they lie inside
 // the string's own buffer range [0, slen); edge dwords are assembled from byte loads.
@@ -188,6 +289,176 @@ __device__ __forceinline__ Mask gpt2_start_mask(const WaveScratch& ws, const Spl
     start |= mask_from_before<2>(f1) | mask_from_before<3>(f2);      // the byte after a contraction
     start &= ~mask_from_before<1>(f1 | f2);                          // the contraction's first letter stays with it
     return start & cs;
+}
+
+// ---- the Llama-3 pattern, bit-parallel ------------------------------------------------------------
+// Derived from the matcher above (no look-behind in the pattern: what matches at a piece start depends only on the
+// text from there on).  With byte-run masks L / N / W (white space) / O, NL = line breaks, SP = U+0020:
+//   * a run start is a piece start, except: an L run takes ONE char in front of it when that char is white space other
+//     than a line break, or an O run of a single char that is neither preceded by U+0020 nor a contraction;
+//     an O run hands its start to a U+0020 directly in front of it; a W run that follows an O char hands its leading
+//     line breaks to that piece (the next start is after them);
+//   * digits: every third position of an N run (ASCII digits; other \p{N} chars make the window fall back);
+//   * inside a W run: after its LAST line break, and in front of its last char when at least two chars follow the last
+//     line break and the run is followed by something;
+//   * an apostrophe that starts a piece and is followed by s|t|m|d or re|ve|ll (any case; U+017F falls back) is a
+//     piece of its own with those letters, and the next piece starts right behind them.
+// The three non-local parts (digit phase, "a line break follows in this run", "these line breaks follow an O char")
+// are carry ripples over the at most nine 64-byte words of the window, done on the scalar unit, forward and backward.
+__device__ __forceinline__ Mask readlane_mask(Mask v, int w) {
+    const unsigned lo = unsigned(wave_readlane(int(unsigned(v)), w)), hi = unsigned(wave_readlane(int(unsigned(v >> 32)), w));
+    return (static_cast<Mask>(hi) << 32) | lo;
+}
+// Bits of `run` reached from `seed` (a subset of run) going up through contiguous run bits; carry: the ripple entered
+// through bit 0 / left through bit 63.
+__device__ __forceinline__ Mask ripple_up(Mask run, Mask seed, bool& carry) {
+    const Mask x = seed | ((carry && (run & 1ull)) ? 1ull : 0ull);
+    const Mask sum = run + x;
+    carry = sum < run;
+    return (run & ~sum) | x;
+}
+// lead byte of the char whose LAST byte is flagged in `at_last` (chars are at most 4 bytes)
+__device__ __forceinline__ Mask to_lead(Mask at_last, Mask cont) {
+    const Mask a1 = mask_from_after<1>(cont), a2 = mask_from_after<2>(cont), a3 = mask_from_after<3>(cont);
+    return ~cont & (at_last | (a1 & mask_from_after<1>(at_last)) | (a1 & a2 & mask_from_after<2>(at_last)) |
+                    (a1 & a2 & a3 & mask_from_after<3>(at_last)));
+}
+
+// Piece starts of the window [w0, w1) (wlen bytes, staged at `skew`); lo = window position of the chunk start (a piece
+// start by construction).  at_end: the window reaches the end of the string.  undecided: starts at window positions
+// >= undecided may depend on text behind the window.  fallback (wave-uniform): the window holds something only the
+// literal matcher handles.
+__device__ __forceinline__ Mask llama3_start_mask(const WaveScratch& ws, const SplitDev& sp, int skew, int wlen, int lo, bool at_end,
+                                                  int& undecided, bool& fallback) {
+    const int l = lane_id();
+    const uint8_t* t = text_bytes(ws) + skew;
+    Mask mL = 0, mN = 0, mW = 0, mNL = 0, mSP = 0, mCONT = 0, mAP = 0, mX1 = 0, mX2 = 0, mXE = 0, mXL = 0;
+    bool odd = false;
+    const int nwords = (wlen + 63) >> 6;
+    for (int w = 0; w < nwords; ++w) {
+        const int i = w * 64 + l;
+        const bool valid = i < wlen;
+        const uint32_t b = valid ? t[i] : 0u;
+        uint32_t cls = kClsO;
+        if (b < 0x80u) {
+            cls = valid ? ascii_class(b) : kClsO;
+        } else if (b >= 0xC0u) {
+            int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
+            uint32_t cp = b & (0xFFu >> (n + 1));
+            if (i + n > wlen) n = wlen - i;
+            for (int j = 1; j < n; ++j) cp = (cp << 6) | (t[i + j] & 0x3Fu);
+            cls = uc_nibble(sp, cp) & 3u;
+            if (cls == kClsN || cp == 0x17Fu) odd = true;  // a non-ASCII digit; LATIN SMALL LETTER LONG S folds to 's'
+        }
+        const uint32_t f = b | 0x20u;  // ASCII letters folded to lower case
+        const Mask bL = __ballot(cls == kClsL), bN = __ballot(cls == kClsN), bW = __ballot(cls == kClsS);
+        const Mask bNL = __ballot(b == '\r' || b == '\n'), bSP = __ballot(b == 0x20u), bCONT = __ballot((b & 0xC0u) == 0x80u);
+        const Mask bAP = __ballot(b == 0x27u), bX1 = __ballot(f == 's' || f == 't' || f == 'm' || f == 'd');
+        const Mask bX2 = __ballot(f == 'r' || f == 'v'), bXE = __ballot(f == 'e'), bXL = __ballot(f == 'l');
+        if (l == w) {
+            mL = bL; mN = bN; mW = bW; mNL = bNL; mSP = bSP; mCONT = bCONT;
+            mAP = bAP; mX1 = bX1; mX2 = bX2; mXE = bXE; mXL = bXL;
+        }
+    }
+    fallback = __ballot(odd) != 0;
+    const int rem = wlen - l * 64;
+    const Mask mV = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
+    if (__ballot(mCONT != 0)) {  // continuation bytes take the class of their lead byte
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            mL |= mask_from_before<1>(mL) & mCONT;
+            mW |= mask_from_before<1>(mW) & mCONT;
+        }
+    }
+    const Mask mO = mV & ~(mL | mN | mW);
+    const Mask cs = mV & ~mCONT;
+    const Mask pL = mask_from_before<1>(mL), pW = mask_from_before<1>(mW), pO = mask_from_before<1>(mO);
+    const Mask pSP = mask_from_before<1>(mSP), pNL = mask_from_before<1>(mNL);
+    // the chunk start is a piece start: digit groups count from it
+    Mask mNd = mN;
+    if (lo > 0 && l == ((lo - 1) >> 6)) mNd &= ~(1ull << ((lo - 1) & 63));
+    const Mask seedN = mNd & ~mask_from_before<1>(mNd);            // N run starts
+    const Mask seedA = mNL & ~pNL & pO;                             // line breaks right behind an O char
+    // ---- forward ripples: digit groups G, absorbed line breaks F
+    Mask G = 0, F = 0;
+    {
+        bool cF = false;
+        int k_prev = 0;  // digits in the last group of the previous word when its run reaches the word's end, else 0
+        for (int w = 0; w < nwords; ++w) {
+            const Mask Nw = readlane_mask(mNd, w), Sw = readlane_mask(seedN, w), NLw = readlane_mask(mNL, w);
+            const Mask Aw = readlane_mask(seedA, w);
+            Mask g = Sw;
+            if (k_prev && (Nw & 1ull)) {  // the run continues from the previous word: its next group starts 3 - k_prev digits in
+                const Mask head = Nw & ~(Nw + 1ull);  // the run of ones that starts at bit 0
+                g |= (1ull << (3 - k_prev)) & head;
+            }
+            const Mask a3 = Nw & (Nw << 1) & (Nw << 2) & (Nw << 3);
+            for (;;) {
+                const Mask ng = ((g << 3) & a3) & ~g;
+                if (!ng) break;
+                g |= ng;
+            }
+            k_prev = 0;
+            if (Nw >> 63) {  // digits of the group still open at the end of this word (3: the next digit starts a group)
+                const Mask top = ~Nw ? (~0ull << (64 - __clzll(~Nw))) : ~0ull;  // the run of ones that ends at bit 63
+                const Mask gt = g & top;                                        // never empty: a run has a start every 3 digits
+                k_prev = __clzll(gt) % 3 + 1;
+            }
+            const Mask f = ripple_up(NLw, Aw, cF);
+            if (l == w) { G = g; F = f; }
+        }
+    }
+    // ---- backward ripple: D = "a line break follows (or is here) in this white-space run"
+    Mask D = 0;
+    {
+        bool c = false;
+        for (int w = nwords - 1; w >= 0; --w) {
+            const Mask Ww = readlane_mask(mW, w), NLw = readlane_mask(mNL, w);
+            const Mask r = __brevll(ripple_up(__brevll(Ww), __brevll(NLw), c));
+            if (l == w) D = r;
+        }
+    }
+    // ---- local rules
+    const Mask sL = mL & ~pL, sO = mO & ~pO, sW = mW & ~pW;
+    const Mask endO = mO & ~mask_from_after<1>(mO), endW = mW & ~mask_from_after<1>(mW);
+    const Mask single_o = sO & to_lead(endO, mCONT);                       // O runs of one char
+    const Mask c1 = mAP & mask_from_after<1>(mX1);
+    const Mask c2 = mAP & ((mask_from_after<1>(mX2) & mask_from_after<2>(mXE)) | (mask_from_after<1>(mXL) & mask_from_after<2>(mXL)));
+    const Mask fire1 = c1 & sO & ~pSP, fire2 = c2 & sO & ~pSP & ~fire1;
+    Mask takes = single_o & ~pSP & ~(fire1 | fire2);                       // this O char goes in front of the letters behind it
+    if (__ballot(mCONT != 0)) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) takes |= mask_from_before<1>(takes) & mCONT;
+    }
+    const Mask supL = sL & (mask_from_before<1>(mW & ~mNL) | mask_from_before<1>(takes) | mask_from_before<1>(fire1 | fire2));
+    const Mask supO = sO & pSP;
+    const Mask supW = sW & pO & mNL;
+    const Mask endNL = mNL & ~mask_from_after<1>(mNL);
+    const Mask b_abs = mask_from_before<1>(F & endNL) & mW;                // behind the line breaks an O piece took
+    const Mask b_ln = mask_from_before<1>(mNL & ~mask_from_after<1>(D)) & mW;  // behind the run's last line break
+    const Mask last_w = to_lead(endW & mask_from_after<1>(mV), mCONT);     // last char of a W run that is followed by a char
+    const Mask b_last = last_w & mW & ~mNL & pW & ~pNL;
+    const Mask b_con = mask_from_before<2>(fire1) | mask_from_before<3>(fire2);
+    const Mask start = ((sL & ~supL) | G | (sO & ~supO) | (sW & ~supW) | b_abs | b_ln | b_last | b_con) & cs;
+    // ---- how far the window decides
+    undecided = 0x7FFFFFFF;
+    if (!at_end) {
+        undecided = wlen > 8 ? wlen - 8 : 0;
+        const int v = wlen - 1;
+        if ((readlane_mask(mW, v >> 6) >> (v & 63)) & 1ull) {  // the window ends inside a white-space run: where does it start?
+            int a = 0;
+            for (int w = v >> 6; w >= 0; --w) {
+                Mask nonw = ~readlane_mask(mW, w);
+                if (w == (v >> 6) && (v & 63) != 63) nonw &= (1ull << ((v & 63) + 1)) - 1ull;
+                if (nonw) {
+                    a = w * 64 + (63 - __clzll(nonw)) + 1;
+                    break;
+                }
+            }
+            if (a + 1 < undecided) undecided = a + 1;
+        }
+    }
+    return start;
 }
 
 // ---- class patterns (ballot path) ----------------------------------------------------------------
@@ -363,7 +634,9 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
 //                               (read positions through kPiecePosMask).
 //   on_long(b, e, dropped):     a piece of more than kChunk bytes, not staged in LDS.
 // Wave-uniform; every lane must call it with the same arguments.
-template <class OnChunk, class OnLong>
+// LLAMA3: the kernel is compiled for the Llama-3 pattern only / for every other pattern (the two families share no
+// scanner code, and either one alone fits the register budget of the lookup kernel).
+template <bool LLAMA3, class OnChunk, class OnLong>
 __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp, const uint8_t* str, int slen,
                                             OnChunk&& on_chunk, OnLong&& on_long) {
     const bool digits = sp.kind == kSplitGpt2Digits;
@@ -388,6 +661,55 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
         const int lo = c0 - w0, hi = qlim - w0;
         int np = 0;
         unsigned long long fl = 0;
+        if constexpr (LLAMA3) {
+            int und = 0;
+            bool seq = false;
+            const Mask start = llama3_start_mask(ws, sp, skew, w1 - w0, lo, w1 == slen, und, seq);
+            const int hi2 = hi < und ? hi : und;
+            const bool whole = qlim == slen && hi2 == hi;  // every piece that starts in the window also ends in it
+            if (!seq && hi2 > lo) {
+                for (int w = lo >> 6; w * 64 < hi2; ++w) {
+                    Mask m = wave_readlane(start, w);
+                    if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
+                    if (hi2 - w * 64 < 64) m &= (1ull << (hi2 - w * 64)) - 1ull;
+                    if ((m >> l) & 1ull) ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t(w * 64 + l - lo);
+                    np += __popcll(m);
+                }
+                wave_sync();
+                if (whole) {
+                    if (l == 0) ws.pstart[np] = uint16_t(slen - c0);
+                    wave_sync();
+                    on_chunk(np, c0, w0, skew);
+                    c0 = slen;
+                    continue;
+                }
+                if (np >= 2) {  // the last piece may continue behind the window: the next chunk starts with it
+                    on_chunk(np - 1, c0, w0, skew);
+                    c0 += int(ws.pstart[np - 1] & kPiecePosMask);
+                    continue;
+                }
+            }
+            // Nothing the masks could decide (a window the bit-parallel rules do not cover, or one piece that fills
+            // it): lane 0 matches literally from the chunk start, as far as the pieces stay inside the staged text.
+            int n_seq = 0, p = c0;
+            if (l == 0) {
+                while (p < slen && n_seq < kChunk) {
+                    const int e = llama3_match_end(sp, str, slen, p);
+                    if (e > w1) break;
+                    ws.pstart[n_seq++] = uint16_t(p - c0);
+                    p = e;
+                }
+                ws.pstart[n_seq] = uint16_t(p - c0);
+                if (n_seq == 0) p = llama3_match_end(sp, str, slen, c0);  // a piece longer than the window
+            }
+            n_seq = wave_readlane(n_seq, 0);
+            p = wave_readlane(p, 0);
+            wave_sync();
+            if (n_seq) on_chunk(n_seq, c0, w0, skew);
+            else on_long(c0, p, false);
+            c0 = p;
+            continue;
+        }
         if (sp.kind >= kSplitWhitespace) {
             Mask start, dropped;
             class_start_mask(ws, sp, skew, w1 - w0, start, dropped);

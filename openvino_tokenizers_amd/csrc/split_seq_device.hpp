@@ -18,103 +18,6 @@
 
 namespace ovtk {
 
-struct SeqChar {
-    uint32_t cp;
-    int len;   // bytes
-    int cls;   // kClsO / kClsL / kClsN / kClsS (line breaks are kClsS)
-};
-
-__device__ __forceinline__ SeqChar seq_char(const SplitDev& sp, const uint8_t* s, int pos, int slen) {
-    const uint32_t b = s[pos];
-    if (b < 0x80u) return SeqChar{b, 1, int(ascii_class(b))};
-    if (b < 0xC0u) return SeqChar{b, 1, kClsO};  // stray continuation byte (invalid UTF-8: parity is undefined)
-    int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
-    if (pos + n > slen) n = slen - pos;
-    uint32_t cp = b & (0xFFu >> (n + 1));
-    int len = 1;
-    for (; len < n && (s[pos + len] & 0xC0u) == 0x80u; ++len) cp = (cp << 6) | (s[pos + len] & 0x3Fu);
-    return SeqChar{cp, len, int(uc_nibble(sp, cp) & 3u)};
-}
-// Unicode simple case folding restricted to what can equal one of s t r e v m l d (PCRE2_UCP caseless matching):
-// ASCII upper case, and U+017F LATIN SMALL LETTER LONG S which folds to 's'.
-__device__ __forceinline__ uint32_t fold_contraction_letter(uint32_t cp) {
-    if (cp - 'A' < 26u) return cp + 32u;
-    if (cp == 0x17Fu) return 's';
-    return cp;
-}
-__device__ __forceinline__ bool is_line_break(uint32_t cp) { return cp == '\r' || cp == '\n'; }
-
-// End of the match that starts at p (p < slen).
-__device__ __forceinline__ int llama3_match_end(const SplitDev& sp, const uint8_t* s, int slen, int p) {
-    const SeqChar c0 = seq_char(sp, s, p, slen);
-    // (?i:'s|'t|'re|'ve|'m|'ll|'d)
-    if (c0.cp == '\'' && p + 1 < slen) {
-        const SeqChar c1 = seq_char(sp, s, p + 1, slen);
-        const uint32_t f1 = fold_contraction_letter(c1.cp);
-        const int p2 = p + 1 + c1.len;
-        if (f1 == 's' || f1 == 't' || f1 == 'm' || f1 == 'd') return p2;
-        if ((f1 == 'r' || f1 == 'v' || f1 == 'l') && p2 < slen) {
-            const SeqChar c2 = seq_char(sp, s, p2, slen);
-            const uint32_t f2 = fold_contraction_letter(c2.cp);
-            if ((f1 == 'l' && f2 == 'l') || (f1 != 'l' && f2 == 'e')) return p2 + c2.len;
-        }
-    }
-    // [^\r\n\p{L}\p{N}]?\p{L}+   (the optional char is tried first; without it \p{L}+ must start at p)
-    {
-        int q = -1;
-        if (c0.cls == kClsL) q = p;
-        else if (c0.cls != kClsN && !is_line_break(c0.cp) && p + c0.len < slen && seq_char(sp, s, p + c0.len, slen).cls == kClsL)
-            q = p + c0.len;
-        if (q >= 0) {
-            while (q < slen) {
-                const SeqChar c = seq_char(sp, s, q, slen);
-                if (c.cls != kClsL) break;
-                q += c.len;
-            }
-            return q;
-        }
-    }
-    // \p{N}{1,3}
-    if (c0.cls == kClsN) {
-        int q = p + c0.len;
-        for (int k = 1; k < 3 && q < slen; ++k) {
-            const SeqChar c = seq_char(sp, s, q, slen);
-            if (c.cls != kClsN) break;
-            q += c.len;
-        }
-        return q;
-    }
-    //  ?[^\s\p{L}\p{N}]+[\r\n]*
-    {
-        int q = -1;
-        if (c0.cls == kClsO) q = p;
-        else if (c0.cp == ' ' && p + 1 < slen && seq_char(sp, s, p + 1, slen).cls == kClsO) q = p + 1;
-        if (q >= 0) {
-            while (q < slen) {
-                const SeqChar c = seq_char(sp, s, q, slen);
-                if (c.cls != kClsO) break;
-                q += c.len;
-            }
-            while (q < slen && is_line_break(s[q])) ++q;
-            return q;
-        }
-    }
-    // whitespace run [p, e): \s*[\r\n]+ (up to its last line break) | \s+(?!\S) (all but the last char, or all of it
-    // at the end of the string) | \s+
-    int e = p, after_last_break = -1, last_char = p;
-    while (e < slen) {
-        const SeqChar c = seq_char(sp, s, e, slen);
-        if (c.cls != kClsS) break;
-        last_char = e;
-        e += c.len;
-        if (is_line_break(c.cp)) after_last_break = e;
-    }
-    if (after_last_break >= 0) return after_last_break;
-    if (e == slen) return e;
-    if (last_char > p) return last_char;
-    return e;
-}
-
 __device__ __forceinline__ int seq_match_end(const SplitDev& sp, const uint8_t* s, int slen, int p) {
     return llama3_match_end(sp, s, slen, p);  // the only sequential pattern so far (kSplitLlama3)
 }

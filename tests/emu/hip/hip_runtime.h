@@ -238,6 +238,11 @@ static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
 static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }
 static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+static inline unsigned long long __brevll(unsigned long long x) {
+    unsigned long long r = 0;
+    for (int i = 0; i < 64; ++i) r |= ((x >> i) & 1ull) << (63 - i);
+    return r;
+}
 static inline int __clz(unsigned x) { return x ? __builtin_clz(x) : 32; }
 static inline unsigned __lane_id() { return unsigned(::emu::lane()); }
 #define __builtin_amdgcn_wave_barrier() ::emu::wave_barrier()

@@ -55,8 +55,8 @@ def test_oracle_matches_hf_golden_llama3():
 
 
 def test_llama3_chain(backend):
-    """Llama-3-shaped tokenizer: RegexSplit (sequential matcher) -> BPETokenizer on the device vs the oracle chain and
-    the HF golden ids; the fused entry point refuses this pattern (it is only supported as the two-op chain)."""
+    """Llama-3-shaped tokenizer: RegexSplit -> BPETokenizer on the device vs the oracle chain and the HF golden ids;
+    the fused entry point gives the same ids."""
     z = np.load(GOLDEN / "golden_bpe_llama3_small.npz")
     tok = BpeTok.load("llama3_small")
     rb, re_ = ragged_rows(len(z["begins"]))
@@ -69,12 +69,27 @@ def test_llama3_chain(backend):
     bpe = BPETokenizer(**tok.attrs, lib=backend.lib)
     got = bpe.evaluate(list(sp[:5]) + tok.consts)
     assert np.array_equal(backend.host(got[2]), z["ids"]) and np.array_equal(backend.host(got[1]), z["id_ends"])
-    with pytest.raises(L.OvtkError) as ei:
-        FusedSplitBPE(split, bpe).evaluate(backend.data(inputs) + [pat], tok.consts)
-    assert ei.value.code == L.E_UNSUPPORTED
+    fused = FusedSplitBPE(split, bpe).evaluate(backend.data(inputs) + [pat], tok.consts)
+    assert np.array_equal(backend.host(fused[2]), z["ids"]) and np.array_equal(backend.host(fused[1]), z["id_ends"])
 
 
 # ------------------------------------------------------------------ kernels vs oracle
+def test_llama3_fused(backend):
+    """The Llama-3 pattern through the fused RegexSplit + BPETokenizer kernel (bit-parallel scanner) = the oracle."""
+    tok = BpeTok.load("llama3_small")
+    n = 40 if backend.name == "emu" else 4000
+    b, e, c = TextModel(5, "mixed").batch(n, 300)
+    strings = ["it's IT'S don'T we'LL 12345 6,789.10\r\n\r\n  end  ", "a\tb \n c\n\n  d", "x\u00a0y !\n\nz", "", "1234567 " * 90, " " * 700 + "x"]
+    b2, e2, c2 = O.pack_strings(strings)
+    b = np.concatenate([b, b2 + len(c)]).astype(np.int32)
+    e = np.concatenate([e, e2 + len(c)]).astype(np.int32)
+    c = np.concatenate([c, c2])
+    rb, re_ = ragged_rows(len(b))
+    ref = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(rb, re_, b, e, c)[:5])
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [tok.pattern_u8()], tok.consts), backend.host, "fused llama3")
+
+
 def run_all_paths(backend, tok, inputs, skips=None, pattern=None):
     """Oracle result + the three product paths (split op, BPE op on its pieces, fused) compared bit for bit."""
     pattern = pattern or tok.pattern

@@ -153,6 +153,26 @@ def test_llama3_random_and_long(backend):
     check(backend, LLAMA3_PATTERN, strings[:50], max_splits=3)
 
 
+def test_llama3_bitparallel_paths(backend):
+    """Strings without the chars that send a window to the literal matcher (non-ASCII digits, U+017F): the bit-parallel
+    rules and their ripples across 64-byte words -- digit groups at every phase and offset, white-space runs with line
+    breaks at every place, line breaks behind an O char, contractions, multi-byte chars next to all of them, chunk seams."""
+    rng = np.random.default_rng(23)
+    alpha = [a for a in LLAMA3_ALPHABET if a not in ("ſ", "٣")] + ["é", "元", "😀", "\u3000", ".", "-"]
+    n = 150 if backend.name == "emu" else 20000
+    strings = ["".join(rng.choice(alpha, size=int(rng.integers(1, 40)))) for _ in range(n)]
+    strings += ["".join(rng.choice(alpha, size=int(rng.integers(300, 1600)))) for _ in range(6 if backend.name == "emu" else 300)]
+    for pre in (0, 1, 2, 61, 62, 63, 64, 65, 127, 500, 509, 510, 511, 512):       # digit runs / white space across word and chunk borders
+        for k in (1, 2, 3, 4, 7, 130):
+            strings.append("x" * pre + "1" * k + "y")
+            strings.append("x" * pre + " " * k + "y")
+            strings.append("x" * pre + "!" + "\n" * k + " " * (k % 3) + "y")
+            strings.append("x" * pre + " " * k + "\n" + " " * k + "y")
+            strings.append("x" * pre + "é" * k + "'LL" + "元" * k + " " + "😀" * k + "\r\n")
+    strings += [" " * 2000, "\n" * 1200 + "a", "a" + " \n" * 400, "1" * 1300 + " " + "2" * 5, "!" * 900 + "\n" * 700 + "?", "x" * 3000 + "'s"]
+    check(backend, LLAMA3_PATTERN, strings)
+
+
 def test_llama3_rows_with_several_strings_and_skips(backend):
     strings = [b"Hello world's 1234", b"<|begin_of_text|>", b"  two  spaces\n\nnew", b"", b"x"]
     b, e, c = O.pack_strings(strings)
