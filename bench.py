@@ -39,8 +39,8 @@ KERNEL_NAMES = {"lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "looku
                 "shard_unpack": "shard_unpack_kernel",
                 "lookup_words": "lookup_kernel<kFused> (BERT words)", "wordpiece_deferred": "wordpiece_deferred_kernel",
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",
-                "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel", "split_count": "split_seq_kernel<0>",
-                "split_write": "split_seq_kernel<1>",
+                "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel", "split_count": "split_kernel<0>",
+                "split_write": "split_kernel<1>",
                 "detokenize": "decode_write_kernel", "decode_count": "decode_count_kernel", "decode_scan": "tile_{reduce,scan,apply}_kernel<UnitLen>"}
 BERT_WS = r"\s+"
 BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\x{4E00}-\x{9FFF}]", r"[\x{3400}-\x{4DBF}]",

@@ -520,12 +520,7 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
     // range validation of the inputs (the staging arenas it also computes are not needed here)
     OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);
-    const bool seq = false;  // (split_seq_kernel: the lane-per-row form of the Llama-3 matcher, superseded by the bit-parallel scanner)
-    const int seq_grid = (n_rows + kBlockThreads - 1) / kBlockThreads;
-    if (seq)
-        OVTK_LAUNCH(ws->marks, "split_count", split_seq_kernel<0>, seq_grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
-                    (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
-    else if (h->dev.kind == kSplitLlama3)
+    if (h->dev.kind == kSplitLlama3)
         OVTK_LAUNCH(ws->marks, "split_count", (split_kernel<0, true>), grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
                     (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
     else
@@ -533,10 +528,7 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
                     (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
     OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s, n_rows,
                 w, (long long)out->capacity);
-    if (seq)
-        OVTK_LAUNCH(ws->marks, "split_write", split_seq_kernel<1>, seq_grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb,
-                    d_re, d_b, d_e, d_sk);
-    else if (h->dev.kind == kSplitLlama3)
+    if (h->dev.kind == kSplitLlama3)
         OVTK_LAUNCH(ws->marks, "split_write", (split_kernel<1, true>), grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb,
                     d_re, d_b, d_e, d_sk);
     else

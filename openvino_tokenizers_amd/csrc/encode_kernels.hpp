@@ -797,57 +797,6 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
     }
 }
 
-// ---- RegexSplit for the sequential patterns: one LANE per row (a wave = one tile of kRowTile rows), count pass then
-// write pass like split_kernel.
-template <int WRITE>
-static __global__ __launch_bounds__(kBlockThreads) void split_seq_kernel(RowsIn in, SplitDev sp, int max_splits, EncodeWork w,
-                                                                         int32_t* out_rb, int32_t* out_re, int32_t* out_begins,
-                                                                         int32_t* out_ends, uint8_t* out_skips) {
-    static_assert(kRowTile == kWave, "a wave is one tile of the offset scan");
-    if (w.status->flags & (kFlagRange | kFlagOutCapacity)) return;
-    const int row = int(blockIdx.x) * kBlockThreads + int(threadIdx.x);
-    const bool valid = row < in.n_rows;
-    int o = 0;
-    if (WRITE) {
-        const int cnt = valid ? w.row_cnt[row] : 0;
-        const int incl = wave_incl_sum(cnt);
-        o = int(w.tile_off[row / kRowTile < (in.n_rows + kRowTile - 1) / kRowTile ? row / kRowTile : 0]) + incl - cnt;
-        if (valid) {
-            out_rb[row] = o;
-            out_re[row] = o + cnt;
-        }
-    }
-    if (!valid) return;
-    int count = 0;
-    for (int col = in.ragged_begins[row]; col < in.ragged_ends[row]; ++col) {
-        const int sb = in.begins[col], se = in.ends[col];
-        if (in.skips && in.skips[col]) {
-            if (WRITE) {
-                out_begins[o + count] = sb;
-                out_ends[o + count] = se;
-                if (out_skips) out_skips[o + count] = 1;
-            }
-            ++count;
-            continue;
-        }
-        const uint8_t* s = in.chars + sb;
-        const int slen = se - sb;
-        int idx = 0;
-        for (int p = 0; p < slen;) {
-            const int e = seq_match_end(sp, s, slen, p);
-            if (WRITE) {
-                out_begins[o + count + idx] = sb + p;
-                out_ends[o + count + idx] = (idx == max_splits) ? se : sb + e;  // regex_split.cpp:278-280
-                if (out_skips) out_skips[o + count + idx] = 0;
-            }
-            ++idx;
-            p = e;
-        }
-        count += idx;
-    }
-    if (!WRITE) w.row_cnt[row] = count;
-}
-
 // ---- SpecialTokensSplit: one LANE per row, count pass then write pass.
 template <int WRITE>
 static __global__ __launch_bounds__(kBlockThreads) void special_split_kernel(RowsIn in, SpecialDev T, EncodeWork w,

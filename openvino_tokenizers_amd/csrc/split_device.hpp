@@ -45,7 +45,7 @@ enum SplitKind : int32_t {
     kSplitWhitespace = 2,  // bert_whitespace_splitter(): \s+
     kSplitBertPunct = 3,   // bert_keep_delimeters_splitter(): one char of [!-/] [:-@] [\[-`] [{-~] \p{P} or the CJK blocks
     kSplitBertWords = 4,   // both of the above chained (\s+ removed, then delimiters isolated): the fused WordPiece path
-    kSplitLlama3 = 5,      // tiktoken-style pattern of Llama-3: sequential matcher, one lane per row (split_seq_device.hpp)
+    kSplitLlama3 = 5,      // tiktoken-style pattern of Llama-3 (llama3_start_mask; its kernels are separate instantiations)
 };
 
 struct SplitDev {

@@ -1,26 +1,12 @@
-// split_seq_device.hpp -- sequential pre-tokenizer matchers: ONE LANE PER ROW.
-//
-// Some patterns are not decided by a bounded neighbourhood (Llama-3: digits in groups of three from the start of
-// their run, whitespace runs cut after their LAST line break), so they are not evaluated with the bit-parallel
-// scanners of split_device.hpp but by a hand-compiled matcher that follows PCRE2's semantics literally: at the
-// current position the alternatives are tried in order, each with its greedy / back-off behaviour.  Every position
-// matches something, so RegexSplit's "next match from start" (regex_split.cpp:286-299) is "the match at start" and
-// isolate-mode pieces are consecutive matches.  A lane walks its own row; the 64 rows of a wave are one tile of the
-// final offset scan.  Lane-instructions per byte are about those of the bit-parallel scanners; what is lost is
-// coalescing (each lane streams its own string through L1) and uniform control flow.
-//
-// Llama-3 (tiktoken cl100k-style) pattern, tools/make_tokenizers.py LLAMA3_PATTERN:
-//   (?i:'s|'t|'re|'ve|'m|'ll|'d) | [^\r\n\p{L}\p{N}]?\p{L}+ | \p{N}{1,3} | ?[^\s\p{L}\p{N}]+[\r\n]* | \s*[\r\n]+ | \s+(?!\S) | \s+
+// split_seq_device.hpp -- matchers that walk a string position by position, ONE LANE PER ROW: SpecialTokensSplit.
+// (The Llama-3 pattern used to live here in the same form; it is a bit-parallel scanner now, split_device.hpp, with its
+// literal matcher llama3_match_end() kept there as the fallback.)
 #pragma once
 
 #include "device_common.hpp"
 #include "split_device.hpp"
 
 namespace ovtk {
-
-__device__ __forceinline__ int seq_match_end(const SplitDev& sp, const uint8_t* s, int slen, int p) {
-    return llama3_match_end(sp, s, slen, p);  // the only sequential pattern so far (kSplitLlama3)
-}
 
 // ---------------------------------------------------------------------------------------------
 // SpecialTokensSplit (src/special_tokens_split.cpp:61-162).  Its pattern is generated
