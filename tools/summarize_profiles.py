@@ -14,7 +14,8 @@ from pathlib import Path
 import pandas as pd
 
 ROOT = Path(__file__).resolve().parent.parent
-TAG = {"lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "merge_kernel": "bpe_merge",
+TAG = {"lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "lookup_kernel<2>": "lookup_fused",
+       "merge_kernel": "bpe_merge",
        "split_seq_kernel<0>": "split_count", "split_seq_kernel<1>": "split_write",
        "exact_kernel": "bpe_exact", "compact_kernel": "compact", "prep_rows_kernel": "prep_rows",
        "count_scan_kernel": "count_scan", "wordpiece_deferred_kernel": "wordpiece_deferred",
