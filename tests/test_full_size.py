@@ -172,3 +172,27 @@ def test_detokenize_full_size(hip_lib):
     obf = O.byte_fallback(*o[2:5])
     ofz = O.fuze(o[0], o[1], obf[0], obf[1])
     assert np.array_equal(ofz[1], fused[1][:k].cpu().numpy()) and np.array_equal(obf[2][: int(ofz[1][-1])], fused[2][: int(ofz[1][-1])].cpu().numpy())
+
+
+def test_many_short_rows(hip_lib):
+    """300 000 rows (more than the folded tail of merge_kernel takes: the separate exact / count_scan launches run)
+    of ~24 bytes: halves back to back = the whole batch, offsets gap-free, the oracle on a prefix."""
+    import torch
+    tok = BpeTok.load("gpt2")
+    rows = 300000
+    b, e, c = TextModel(99, "zipf").batch(rows, 24, seed=5)
+    rb, re_ = ragged_rows(rows)
+    pat = tok.pattern_u8()
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=hip_lib), BPETokenizer(**tok.attrs, lib=hip_lib))
+
+    def run(rb_, re2, b_, e_, c_):
+        return fused.evaluate(dev([rb_, re2, b_, e_]) + [c_, pat], tok.consts)
+
+    d_c = torch.as_tensor(c, device="cuda")
+    whole = run(rb, re_, b, e, d_c)
+    check_offsets(whole[0], whole[1], whole[2].numel())
+    halves_equal_whole(run, rb, re_, b, e, d_c, whole)
+    same_text(decode_rows(tok.vocab, whole[0], whole[1], whole[2], len(tok.vocab) - 1, hip_lib), b, e, c)
+    k = 3000
+    ref = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(rb[:k], re_[:k], b[:k], e[:k], c)[:5])
+    assert np.array_equal(ref[1], whole[1][:k].cpu().numpy()) and np.array_equal(ref[2], whole[2][: int(ref[1][-1])].cpu().numpy())
