@@ -75,7 +75,12 @@ int decode_passes(Workspace& ws, hipStream_t s, int device, const DecodeDev& d, 
     long long* unit_bytes = ws.gen[2].as<long long>();
     long long* unit_off = ws.gen[3].as<long long>();
     const int grid = int(std::min<long long>((n_units + kWavesPerBlock - 1) / kWavesPerBlock, (long long)device_cu_count(device) * 8));
-    OVTK_LAUNCH(ws.marks, "decode_count", decode_count_kernel, grid, kBlockThreads, s, d, int(seq), n_seg, n_units, unit_bytes);
+    if (d.vocab_size <= kLenLdsTokens)
+        OVTK_LAUNCH(ws.marks, "decode_count", decode_count_lds_kernel,
+                    int(std::min<long long>((n_units + kCountLdsThreads / kWave - 1) / (kCountLdsThreads / kWave), (long long)device_cu_count(device))),
+                    kCountLdsThreads, s, d, int(seq), n_seg, n_units, unit_bytes);
+    else
+        OVTK_LAUNCH(ws.marks, "decode_count", decode_count_kernel, grid, kBlockThreads, s, d, int(seq), n_seg, n_units, unit_bytes);
     launch_scan(ws.marks, "decode_scan", s, n_units, UnitLen{unit_bytes}, UnitApply{unit_off, n_seg, row_begins, row_ends},
                 CharsFin{st, cap}, ws.tiles.as<long long>(), st, kFlagOutCapacity | kFlagRange);
     OVTK_LAUNCH(ws.marks, tag, decode_write_kernel, grid, kBlockThreads, s, d, int(seq), n_seg, n_units,
@@ -105,9 +110,8 @@ struct ovtk_vocab_decoder {
     int device = 0;
     int32_t vocab_size = 0;
     int32_t max_token_len = 0;
-    DevBuf vb, vc, skip_bits, len_plain, pack_plain, len_bf, pack_bf;
-    std::vector<uint32_t> attr_skip_bits;  // host copy, attribute skip_tokens
-    bool has_attr_skips = false;
+    DevBuf vb, vc, len_plain, pack_plain, len_bf, pack_bf;  // len_*: output bytes per token, 0 for the attribute's skip_tokens
+    std::vector<uint16_t> len_plain_host, len_bf_host;      // without any skips: input 4 of a call replaces the attribute
 };
 
 extern "C" {
@@ -355,7 +359,7 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
     const int64_t V = p->vocab.n;
     h->vocab_size = int32_t(V);
     if (V > 0 && (!p->vocab.begins || !p->vocab.ends)) return set_error(OVTK_E_ARG, "vocab_decoder: null vocab offsets");
-    const size_t nv = size_t(std::max<int64_t>(V, 1));
+    const size_t nv = (size_t(std::max<int64_t>(V, 1)) + 1) & ~size_t(1);  // even: the length tables are also read as dwords
     std::vector<uint16_t> len_plain(nv, 0), len_bf(nv, 0);
     std::vector<TokenPack> pack_plain(nv, TokenPack{{0, 0, 0, 0}}), pack_bf(nv, TokenPack{{0, 0, 0, 0}});
     for (int64_t i = 0; i < V; ++i) {
@@ -386,13 +390,11 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
             pack_bf[size_t(i)] = pack_plain[size_t(i)];
         }
     }
-    h->attr_skip_bits.assign(size_t((V + 31) / 32 + 1), 0u);
-    for (int64_t k = 0; k < p->n_skip_tokens; ++k) {
+    h->len_plain_host = len_plain;
+    h->len_bf_host = len_bf;
+    for (int64_t k = 0; k < p->n_skip_tokens; ++k) {  // a skipped token decodes to "" (vocab_decoder.cpp:70-81): length 0 in the tables
         const int32_t t = p->skip_tokens[k];
-        if (t >= 0 && t < V) {
-            h->attr_skip_bits[size_t(t) >> 5] |= 1u << (t & 31);
-            h->has_attr_skips = true;
-        }
+        if (t >= 0 && t < V) len_plain[size_t(t)] = len_bf[size_t(t)] = 0;
     }
     int e = 0;
     e = e ? e : h->vb.upload(p->vocab.begins, size_t(V) * 4);
@@ -401,7 +403,6 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
     e = e ? e : h->pack_plain.upload(pack_plain.data(), nv * sizeof(TokenPack));
     e = e ? e : h->len_bf.upload(len_bf.data(), nv * sizeof(uint16_t));
     e = e ? e : h->pack_bf.upload(pack_bf.data(), nv * sizeof(TokenPack));
-    e = e ? e : h->skip_bits.upload(h->attr_skip_bits.data(), h->attr_skip_bits.size() * 4);
     if (e) return e;
     OVTK_HIP(hipStreamSynchronize(nullptr));
     *out = h.release();
@@ -424,23 +425,15 @@ int decoder_inputs(ovtk_vocab_decoder* h, Workspace& ws, const int32_t* ids, int
     d.v_len = (byte_fallback ? h->len_bf : h->len_plain).as<uint16_t>();
     d.v_pack = (byte_fallback ? h->pack_bf : h->pack_plain).as<TokenPack>();
     d.vocab_size = h->vocab_size;
-    if (skip_in) {  // input 4 replaces the attribute for this call (vocab_decoder.cpp:36-41)
-        std::vector<uint32_t> bits(h->attr_skip_bits.size(), 0u);
-        bool any = false;
+    if (skip_in) {  // input 4 replaces the attribute for this call (vocab_decoder.cpp:36-41): its own length table
+        std::vector<uint16_t> lens = byte_fallback ? h->len_bf_host : h->len_plain_host;
         for (int64_t k = 0; k < n_skip_in; ++k) {
             const int32_t t = skip_in[k];
-            if (t >= 0 && t < h->vocab_size) {
-                bits[size_t(t) >> 5] |= 1u << (t & 31);
-                any = true;
-            }
+            if (t >= 0 && t < h->vocab_size) lens[size_t(t)] = 0;
         }
-        if (any) {
-            if (int rc = ws.gen[1].upload(bits.data(), bits.size() * 4, s)) return rc;
-            OVTK_HIP(hipStreamSynchronize(s));  // `bits` dies at return
-            d.skip_bits = ws.gen[1].as<uint32_t>();
-        }
-    } else if (h->has_attr_skips) {
-        d.skip_bits = h->skip_bits.as<uint32_t>();
+        if (int rc = ws.gen[1].upload(lens.data(), lens.size() * sizeof(uint16_t), s)) return rc;
+        OVTK_HIP(hipStreamSynchronize(s));  // `lens` dies at return
+        d.v_len = ws.gen[1].as<uint16_t>();
     }
     return OVTK_OK;
 }

@@ -255,17 +255,16 @@ struct DecodeDev {
     const int32_t* ids;          // [batch * seq]
     const int32_t* v_begins;
     const uint8_t* v_chars;
-    const uint16_t* v_len;       // output bytes of the token (after ByteFallback in that flavour)
+    const uint16_t* v_len;       // output bytes of the token (after ByteFallback in that flavour; 0 when it is skipped)
     const TokenPack* v_pack;     // its first min(len, 16) output bytes, zero padded
     int32_t vocab_size;
-    const uint32_t* skip_bits;   // bitmap over [0, vocab_size), may be nullptr
 };
 
 // Length in bytes of a token's text (vocab_decoder.cpp:70-81): ids outside [0, V) or in the skip list give "".
 __device__ __forceinline__ int decode_len(const DecodeDev& d, int32_t id) {
-    if (uint32_t(id) >= uint32_t(d.vocab_size)) return 0;  // `token_id < vocab_size` compares as size_t (:71)
-    if (d.skip_bits && (d.skip_bits[uint32_t(id) >> 5] >> (id & 31) & 1u)) return 0;
-    return d.v_len[id];
+    const bool in_vocab = uint32_t(id) < uint32_t(d.vocab_size);  // `token_id < vocab_size` compares as size_t (:71)
+    const int len = d.v_len[in_vocab ? uint32_t(id) : 0u];        // ONE lookup per token: skipped tokens have length 0 in the table
+    return in_vocab ? len : 0;
 }
 
 // VocabDecoder / fused detokenizer as two wave-per-segment passes around one scan: a segment = up to kSegTokens
@@ -297,13 +296,66 @@ static __global__ __launch_bounds__(kBlockThreads) void decode_count_kernel(Deco
         const long long row = u / n_seg;
         const int seg = int(u - row * n_seg);
         const int t0 = seg * kSegTokens, t1 = t0 + kSegTokens < seq ? t0 + kSegTokens : seq;
-        int s = 0;
-        for (int g = t0; g < t1; g += 4 * kWave) {
-            int32_t id[4];
-            load_ids4(d, row * seq, g, t1, id);
+        // a segment is two groups of 256 tokens: both id loads are issued before the first length lookup, and all eight
+        // lookups of a lane before the first sum (the kernel was bound by dependent round trips, not by bandwidth)
+        static_assert(kSegTokens == 8 * kWave, "two groups of 4 ids per lane");
+        int32_t id[2][4];
+        load_ids4(d, row * seq, t0, t1, id[0]);
+        if (t0 + 4 * kWave < t1) {
+            load_ids4(d, row * seq, t0 + 4 * kWave, t1, id[1]);
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += decode_len(d, id[j]);
+            for (int j = 0; j < 4; ++j) id[1][j] = -1;
         }
+        int n[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) n[h][j] = decode_len(d, id[h][j]);
+        int s = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += n[h][j];
+        s = wave_sum(s);
+        if (l == 0) unit_bytes[u] = s;
+    }
+}
+
+// The same pass for vocabularies of at most 65 536 tokens: every block first copies the length table (2 bytes per token)
+// into LDS, so the per-token lookup is an LDS read instead of an address-divergent global gather (the texture
+// addresser, not HBM, bounded the kernel above: 64 cache lines per wave-instruction).  One 1024-thread block per CU.
+constexpr int kLenLdsTokens = 65536;
+constexpr int kCountLdsThreads = 1024;
+static __global__ __launch_bounds__(kCountLdsThreads) void decode_count_lds_kernel(DecodeDev d, int seq, int n_seg, long long n_units,
+                                                                                   long long* unit_bytes) {
+    __shared__ uint16_t len_lds[kLenLdsTokens];
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(d.v_len);  // tables are padded to an even token count
+        uint32_t* dst = reinterpret_cast<uint32_t*>(len_lds);
+        for (int i = int(threadIdx.x); i < (d.vocab_size + 1) / 2; i += kCountLdsThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int l = lane_id();
+    const long long my_waves = (long long)gridDim.x * (kCountLdsThreads / kWave);
+    for (long long u = (long long)blockIdx.x * (kCountLdsThreads / kWave) + wave_in_block(); u < n_units; u += my_waves) {
+        const long long row = u / n_seg;
+        const int seg = int(u - row * n_seg);
+        const int t0 = seg * kSegTokens, t1 = t0 + kSegTokens < seq ? t0 + kSegTokens : seq;
+        int32_t id[2][4];
+        load_ids4(d, row * seq, t0, t1, id[0]);
+        if (t0 + 4 * kWave < t1) {
+            load_ids4(d, row * seq, t0 + 4 * kWave, t1, id[1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) id[1][j] = -1;
+        }
+        int s = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                s += uint32_t(id[h][j]) < uint32_t(d.vocab_size) ? int(len_lds[id[h][j]]) : 0;
         s = wave_sum(s);
         if (l == 0) unit_bytes[u] = s;
     }
