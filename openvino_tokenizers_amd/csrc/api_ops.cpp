@@ -370,7 +370,8 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
         const uint8_t* t = p->vocab.chars + b;
         const int len = int(e - b);
         len_plain[size_t(i)] = uint16_t(len);
-        std::memcpy(pack_plain[size_t(i)].w, t, size_t(std::min(len, 16)));
+        std::memcpy(pack_plain[size_t(i)].w, t, size_t(std::min(len, 15)));
+        pack_plain[size_t(i)].w[3] |= uint32_t(len <= 15 ? len : 0xFF) << 24;  // byte 15: the length
         // ByteFallback applied to this token (byte_fallback.cpp:37-41), precomputed once per vocabulary
         int v = -1;
         if (len == 6 && t[0] == '<' && t[5] == '>') {
@@ -385,6 +386,7 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
         if (v >= 0) {
             len_bf[size_t(i)] = 1;
             pack_bf[size_t(i)].w[0] = uint32_t(v);
+            pack_bf[size_t(i)].w[3] = 1u << 24;
         } else {
             len_bf[size_t(i)] = len_plain[size_t(i)];
             pack_bf[size_t(i)] = pack_plain[size_t(i)];
@@ -394,7 +396,11 @@ int ovtk_vocab_decoder_create(const ovtk_vocab_decoder_params* p, ovtk_vocab_dec
     h->len_bf_host = len_bf;
     for (int64_t k = 0; k < p->n_skip_tokens; ++k) {  // a skipped token decodes to "" (vocab_decoder.cpp:70-81): length 0 in the tables
         const int32_t t = p->skip_tokens[k];
-        if (t >= 0 && t < V) len_plain[size_t(t)] = len_bf[size_t(t)] = 0;
+        if (t >= 0 && t < V) {
+            len_plain[size_t(t)] = len_bf[size_t(t)] = 0;
+            pack_plain[size_t(t)].w[3] &= 0x00FFFFFFu;  // length byte 0; the text stays (a call's own skip list may keep the token)
+            pack_bf[size_t(t)].w[3] &= 0x00FFFFFFu;
+        }
     }
     int e = 0;
     e = e ? e : h->vb.upload(p->vocab.begins, size_t(V) * 4);
@@ -425,6 +431,7 @@ int decoder_inputs(ovtk_vocab_decoder* h, Workspace& ws, const int32_t* ids, int
     d.v_len = (byte_fallback ? h->len_bf : h->len_plain).as<uint16_t>();
     d.v_pack = (byte_fallback ? h->pack_bf : h->pack_plain).as<TokenPack>();
     d.vocab_size = h->vocab_size;
+    d.len_in_pack = skip_in ? 0 : 1;
     if (skip_in) {  // input 4 replaces the attribute for this call (vocab_decoder.cpp:36-41): its own length table
         std::vector<uint16_t> lens = byte_fallback ? h->len_bf_host : h->len_plain_host;
         for (int64_t k = 0; k < n_skip_in; ++k) {

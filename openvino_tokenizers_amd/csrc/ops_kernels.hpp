@@ -256,7 +256,8 @@ struct DecodeDev {
     const int32_t* v_begins;
     const uint8_t* v_chars;
     const uint16_t* v_len;       // output bytes of the token (after ByteFallback in that flavour; 0 when it is skipped)
-    const TokenPack* v_pack;     // its first min(len, 16) output bytes, zero padded
+    const TokenPack* v_pack;     // its first min(len, 15) output bytes, zero padded; byte 15 = len (0xFF: 16 or more, see v_len)
+    int32_t len_in_pack;         // 0: a call's own skip list is in force, lengths come from v_len only
     int32_t vocab_size;
 };
 
@@ -413,8 +414,14 @@ static __global__ __launch_bounds__(kBlockThreads) void decode_write_kernel(Deco
             TokenPack pk[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                n[j] = decode_len(d, id[j]);
-                if (n[j] > 0) pk[j] = d.v_pack[id[j]];
+                // ONE address-divergent load per token (the pack carries the length): the pass is bound by the texture
+                // addresser (TA busy 80 %), not by bandwidth
+                const bool in_vocab = uint32_t(id[j]) < uint32_t(d.vocab_size);
+                pk[j] = in_vocab ? d.v_pack[id[j]] : TokenPack{{0, 0, 0, 0}};
+                const int code = int(pk[j].w[3] >> 24);
+                pk[j].w[3] &= 0x00FFFFFFu;
+                if (d.len_in_pack) n[j] = code == 0xFF ? int(d.v_len[id[j]]) : code;
+                else n[j] = decode_len(d, id[j]);
             }
             const int mine = n[0] + n[1] + n[2] + n[3];
             const int incl = wave_incl_sum(mine);
@@ -436,7 +443,7 @@ static __global__ __launch_bounds__(kBlockThreads) void decode_write_kernel(Deco
                         // the token's (zero padded) first 16 bytes, shifted to its byte position, are OR-ed dword by
                         // dword into the zeroed buffer: ~2 LDS operations per token instead of one per byte
                         const int o = skew + off, sh = (o & 3) * 8, dw = o >> 2;
-                        const int m = n[j] < 16 ? n[j] : 16;
+                        const int m = n[j] < 15 ? n[j] : 15;
                         const int nd = (((o & 3) + m) + 3) >> 2;  // dwords touched, 1..5
                         uint32_t prev = 0;
 #pragma unroll
@@ -446,10 +453,10 @@ static __global__ __launch_bounds__(kBlockThreads) void decode_write_kernel(Deco
                             if (q < nd && v) atomicOr(&wbuf[dw + q], v);
                             prev = cur;
                         }
-                        if (n[j] > 16) {
+                        if (n[j] > 15) {
                             uint8_t* dst = buf + o;
                             const uint8_t* src = d.v_chars + d.v_begins[id[j]];
-                            for (int k = 16; k < n[j]; ++k) dst[k] = src[k];
+                            for (int k = 15; k < n[j]; ++k) dst[k] = src[k];
                         }
                     } else {  // oversized segment: straight to the output, byte by byte
                         const uint8_t* src = d.v_chars + d.v_begins[id[j]];
