@@ -201,6 +201,16 @@ def make_encode_wordpiece(args, lib, dev, rank):
         L.check(lib, lib.ovtk_wordpiece_encode_run(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(o), L.MEM_DEVICE, stream))
         return o_begins, o_ends, o_ids[: o.n_data]
 
+    def enqueue():
+        o_begins, o_ends, o_ids, o = out.take()
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_wordpiece_encode_enqueue(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(o), stream, C.byref(pending)))
+
+        def finish():
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
+            return o_begins, o_ends, o_ids[: o.n_data]
+        return finish
+
     def cpu(n_s):
         from oracle import oracle as O
         s1, s2 = O.RegexSplit(BERT_WS, "remove"), O.RegexSplit(BERT_PUNCT, "isolate")
@@ -213,7 +223,7 @@ def make_encode_wordpiece(args, lib, dev, rank):
 
     workload = (f"config 3: BERT-shaped WordPiece (V=30522, trained in-process), {args.rows} x ~{nbytes}-byte lower-cased zipf "
                 f"strings per GPU, fused RegexSplit(\\s+)+RegexSplit(delimiters)+WordpieceTokenizer, inputs and outputs in HBM")
-    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, keep=(d, ws, pu, wp), workload=workload, vocab=len(tok["vocab"]),
+    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, enqueue=enqueue, keep=(d, ws, pu, wp), workload=workload, vocab=len(tok["vocab"]),
                 metric="input MB/s encoded (BERT WordPiece, 256-byte strings)", dtype="u8/int32",
                 algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=args.rows)
 

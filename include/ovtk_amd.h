@@ -201,6 +201,10 @@ int ovtk_wordpiece_run(ovtk_wordpiece* h, const ovtk_ragged_strings* in, int32_t
 int ovtk_wordpiece_encode_run(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
                               const ovtk_ragged_strings* in, int32_t unk_token_id, ovtk_ragged_i32_out* out, int mem,
                               void* stream);
+/* ovtk_wordpiece_encode_run in two halves (device memory; see ovtk_encode_enqueue): finish with ovtk_encode_finish. */
+int ovtk_wordpiece_encode_enqueue(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
+                                  const ovtk_ragged_strings* in, int32_t unk_token_id, const ovtk_ragged_i32_out* out,
+                                  void* stream, ovtk_pending** pending);
 void ovtk_wordpiece_destroy(ovtk_wordpiece* h);
 
 /* ---------------------------------------------------------------- VocabEncoder

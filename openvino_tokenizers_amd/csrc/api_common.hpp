@@ -156,14 +156,22 @@ inline std::atomic<int>& row_tickets() {
     return v;
 }
 
-// Up to this many rows the last block of merge_kernel sums the row counts itself (one block reads 4 bytes per row);
-// larger batches keep the parallel count_scan_kernel.
-constexpr int kFoldTailRows = 1 << 18;
-
 struct PendingRun {
     virtual ~PendingRun() = default;
     virtual int finish(ovtk_ragged_i32_out* out) = 0;
 };
+}  // namespace ovtk
+// A call in flight (ovtk_encode_enqueue / ovtk_wordpiece_encode_enqueue -> ovtk_encode_finish).
+struct ovtk_pending {
+    std::unique_ptr<ovtk::PendingRun> run;  // empty: nothing was launched, `out` was complete at enqueue
+    ovtk_ragged_i32_out out{};
+};
+namespace ovtk {
+
+// Up to this many rows the last block of merge_kernel sums the row counts itself (one block reads 4 bytes per row);
+// larger batches keep the parallel count_scan_kernel.
+constexpr int kFoldTailRows = 1 << 18;
+
 
 template <class Middle>
 class RowsRun final : public PendingRun {
@@ -322,8 +330,9 @@ std::unique_ptr<RowsRun<std::decay_t<Middle>>> make_rows_run(int device, const c
 template <class Middle>
 int run_rows_to_ids(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
                     ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle&& middle, bool self_alloc = false,
-                    int blocks_per_cu = 6) {
-    auto run = make_rows_run(device, op, in, skips, mul, out, mem, s, std::forward<Middle>(middle), self_alloc, blocks_per_cu);
+                    int blocks_per_cu = 6, bool tail_in_middle = false) {
+    auto run = make_rows_run(device, op, in, skips, mul, out, mem, s, std::forward<Middle>(middle), self_alloc, blocks_per_cu,
+                             tail_in_middle);
     if (int rc = run->start()) return rc;
     return run->finish(out);
 }

@@ -442,11 +442,6 @@ int ovtk_set_row_tickets(int rows_per_ticket) {
     return OVTK_OK;
 }
 
-struct ovtk_pending {
-    std::unique_ptr<PendingRun> run;  // empty: nothing was launched, `out` was complete at enqueue
-    ovtk_ragged_i32_out out{};
-};
-
 int ovtk_encode_enqueue(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                         const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending) {
     if (!pending || !out) return set_error(OVTK_E_ARG, "null argument");

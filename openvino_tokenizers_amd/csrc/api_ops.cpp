@@ -176,9 +176,12 @@ int ovtk_wordpiece_run(ovtk_wordpiece* h, const ovtk_ragged_strings* in, int32_t
                            });
 }
 
-int ovtk_wordpiece_encode_run(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
-                              const ovtk_ragged_strings* in, int32_t unk_token_id, ovtk_ragged_i32_out* out, int mem,
-                              void* stream) {
+}  // extern "C"
+namespace {
+// Launches the fused BERT split + WordPiece kernels; `run` stays empty when the result was complete without any.
+int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
+                           const ovtk_ragged_strings* in, int32_t unk_token_id, ovtk_ragged_i32_out* out, int mem,
+                           void* stream, std::unique_ptr<PendingRun>& run) {
     if (int rc = check_rows(in)) return rc;
     if (!h || !whitespace || !delimiters || !out) return set_error(OVTK_E_ARG, "null argument");
     if (whitespace->dev.kind != kSplitWhitespace || whitespace->dev.drop != 1 || whitespace->max_splits != -1 ||
@@ -213,15 +216,40 @@ int ovtk_wordpiece_encode_run(ovtk_wordpiece* h, ovtk_regex_split* whitespace, o
     memo_only.pieces = h->memo;
     memo_only.suffix_len = 0;
     const int dev = h->device;
-    return run_rows_to_ids(dev, "WordpieceTokenizer", in, nullptr, 1, out, mem, s,
-                           [&](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
+    const WordpieceDev wdev = h->dev;
+    auto r = make_rows_run(dev, "WordpieceTokenizer", in, nullptr, 1, out, mem, s,
+                           [=](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                OVTK_LAUNCH(ws.marks, "lookup_words", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp,
                                            memo_only, w);
                                OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel,
                                            dim3(std::max(1, device_cu_count(dev) * 8 / kShards), kShards), kBlockThreads, s, d_in,
-                                           h->dev, unk_token_id, w);
+                                           wdev, unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
                            },
-                           /*self_alloc=*/true, resident_blocks_per_cu(lookup_kernel<kFused>));
+                           /*self_alloc=*/true, resident_blocks_per_cu(lookup_kernel<kFused>), /*tail_in_middle=*/true);
+    if (int rc = r->start()) return rc;
+    run = std::move(r);
+    return OVTK_OK;
+}
+}  // namespace
+extern "C" {
+
+int ovtk_wordpiece_encode_run(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
+                              const ovtk_ragged_strings* in, int32_t unk_token_id, ovtk_ragged_i32_out* out, int mem,
+                              void* stream) {
+    std::unique_ptr<PendingRun> run;
+    if (int rc = start_wordpiece_encode(h, whitespace, delimiters, in, unk_token_id, out, mem, stream, run)) return rc;
+    return run ? run->finish(out) : OVTK_OK;
+}
+
+int ovtk_wordpiece_encode_enqueue(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
+                                  const ovtk_ragged_strings* in, int32_t unk_token_id, const ovtk_ragged_i32_out* out,
+                                  void* stream, ovtk_pending** pending) {
+    if (!pending || !out) return set_error(OVTK_E_ARG, "null argument");
+    auto p = std::make_unique<ovtk_pending>();
+    p->out = *out;
+    if (int rc = start_wordpiece_encode(h, whitespace, delimiters, in, unk_token_id, &p->out, OVTK_MEM_DEVICE, stream, p->run)) return rc;
+    *pending = p.release();
+    return OVTK_OK;
 }
 
 void ovtk_wordpiece_destroy(ovtk_wordpiece* h) { delete h; }

@@ -521,6 +521,19 @@ __device__ __forceinline__ void scan_tiles_one_block(int n_rows, const EncodeWor
     }
 }
 
+// Start of a kernel that folds the row scan into its end (merge_kernel, wordpiece_deferred_kernel): tile sums of what the
+// lookup kernel emitted, one wave per tile, spread over the whole grid (2-D grids: x fastest).
+__device__ __forceinline__ void fold_emitted_tile_sums(const EncodeWork& w, int tail_rows) {
+    const int n_tiles = (tail_rows + kRowTile - 1) / kRowTile;
+    const int wave = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
+    const int n_waves = int(gridDim.x) * int(gridDim.y) * kWavesPerBlock;
+    for (int tile = wave; tile < n_tiles; tile += n_waves) {
+        const int row = tile * kRowTile + lane_id();
+        const int s0 = wave_sum(row < tail_rows ? w.row_emit[row] : 0);
+        if (lane_id() == 0 && s0) atomicAdd(&w.tile_cnt[tile], s0);
+    }
+}
+
 // ---- merge kernel: dense batches of deferred pieces ----------------------------------------------
 // tail_rows > 0: the block that finishes last also runs the exact pieces (when few) and the scan of the row counts, so
 // that exact_kernel and count_scan_kernel need no launches of their own (tail_rows = n_rows, out_cap as for count_scan).
@@ -540,16 +553,7 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
     if (threadIdx.x == 0) pushed_exact = 0;
     __syncthreads();
     if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
-    if (tail_rows > 0) {  // tile sums of what the lookup kernel emitted: one wave per tile, spread over the whole grid
-        const int n_tiles = (tail_rows + kRowTile - 1) / kRowTile;
-        const int wave = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
-        const int n_waves = int(gridDim.x) * int(gridDim.y) * kWavesPerBlock;
-        for (int tile = wave; tile < n_tiles; tile += n_waves) {
-            const int row = tile * kRowTile + lane_id();
-            const int s0 = wave_sum(row < tail_rows ? w.row_emit[row] : 0);
-            if (lane_id() == 0 && s0) atomicAdd(&w.tile_cnt[tile], s0);
-        }
-    }
+    if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows);
     uint64_t* key = lds_all[wave_in_block()];                                 // path W
     uint32_t* id = reinterpret_cast<uint32_t*>(key + kChunkSyms);             // path W
     uint32_t* fkey = reinterpret_cast<uint32_t*>(key);                        // path F

@@ -90,8 +90,9 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn 
 
 // The words the fused BERT path could not resolve through the memo (encode_kernels.hpp lookup_kernel with the
 // kSplitBertWords scanner): dense batches of 64 deferred words, one lane per word.
+// tail_rows > 0: like merge_kernel, the block that finishes last also scans the per-tile id counts (no count_scan launch).
 static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kernel(RowsIn in, WordpieceDev T, int32_t unk_id,
-                                                                                 EncodeWork w) {
+                                                                                 EncodeWork w, int tail_rows, long long out_cap) {
     __shared__ I2 root_lds[256];
     __shared__ I2 sub_lds[256];
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) {
@@ -100,6 +101,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
     }
     __syncthreads();
     if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
+    if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows);
     const int l = lane_id();
     const int shard = int(blockIdx.y);
     int count = w.status->shard_count[shard * kCounterStride];
@@ -130,8 +132,15 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
         const int prev_row = __shfl_up(my_row, 1), next_row = __shfl_down(my_row, 1);
         const bool head = l == 0 || prev_row != my_row, tail = l == kWave - 1 || next_row != my_row;
         const int seg_base = wave_incl_max(head ? incl - cnt : 0);
-        if (valid && tail && incl - seg_base > 0) atomicAdd(&w.row_cnt[e.row], incl - seg_base);
+        if (valid && tail && incl - seg_base > 0) {
+            atomicAdd(&w.row_cnt[e.row], incl - seg_base);
+            if (w.tile_cnt) atomicAdd(&w.tile_cnt[e.row / kRowTile], incl - seg_base);
+        }
     }
+    if (tail_rows <= 0) return;
+    __syncthreads();
+    if (!last_block_done(&w.status->ticket[0], gridDim.x * gridDim.y, /*release=*/false)) return;  // only atomics to hand over
+    scan_tiles_one_block(tail_rows, w, out_cap);
 }
 
 // =============================================================================================

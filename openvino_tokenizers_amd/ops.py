@@ -792,3 +792,30 @@ class FusedSplitWordpiece:
         L.check(wp._lib, wp._lib.ovtk_wordpiece_encode_run(wp._h, self.whitespace._h, self.delimiters._h, C.byref(rs),
                                                            C.c_int32(unk), C.byref(out), m.mem, m.stream))
         return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+
+    def enqueue(self, ragged_inputs, whitespace_pattern, delimiters_pattern, wordpiece_constant_inputs):
+        """evaluate() in two halves for CUDA tensors (ovtk_wordpiece_encode_enqueue / ovtk_encode_finish): returns a
+        ticket; `ticket()` waits for the kernels and returns evaluate()'s outputs."""
+        self.whitespace._ensure(whitespace_pattern)
+        self.delimiters._ensure(delimiters_pattern)
+        wp = self.wordpiece
+        wp._ensure(list(ragged_inputs[:5]) + list(wordpiece_constant_inputs))
+        unk = int(np.asarray(_host(wordpiece_constant_inputs[3], np.int32)).reshape(-1)[0])
+        m = _Mem(ragged_inputs[4])
+        if not m.torch:
+            raise L.OvtkError(L.E_ARG, "enqueue() needs device-resident (torch CUDA) inputs")
+        rs, (rb, _, _, _, c) = _ragged_in(m, ragged_inputs)
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        cap = len(c)
+        ids, pids = m.alloc(cap, "i32")
+        out = L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
+        lib = wp._lib
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_wordpiece_encode_enqueue(wp._h, self.whitespace._h, self.delimiters._h, C.byref(rs), C.c_int32(unk),
+                                                       C.byref(out), m.stream, C.byref(pending)))
+
+        def ticket(_keep=m):
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(out)))
+            return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+        return ticket

@@ -283,3 +283,26 @@ def test_fuze_and_errors(backend):
     with pytest.raises(L.OvtkError) as ei:
         VocabEncoder(lib=backend.lib).evaluate(list(pack_strings([b"a"])) + list(pack_strings([b"a"])) + [np.zeros(1, np.float32), np.zeros(1, np.float32)])
     assert ei.value.code == L.E_ARG
+
+
+def test_fused_wordpiece_enqueue(gpu_backend):
+    """ovtk_wordpiece_encode_enqueue / ovtk_encode_finish: two batches in flight, each equal to the blocking call."""
+    backend = gpu_backend
+    tok = load_tokenizer("bert_small")
+    ws_pat = np.frombuffer(rb"\s+", np.uint8)
+    from bench import BERT_PUNCT
+    pu_pat = np.frombuffer(BERT_PUNCT.encode(), np.uint8)
+    consts = list(O.pack_strings(tok["vocab"])) + [np.asarray(tok["unk_id"], np.int32)]
+    fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
+                                WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], lib=backend.lib))
+    batches = []
+    for i, n in enumerate((3000, 800)):
+        b, e, c = TextModel(40 + i, "zipf").batch(n, 200)
+        c = np.frombuffer(c.tobytes().lower(), np.uint8).copy()
+        rb_, re_ = ragged_rows(n)
+        batches.append(backend.data([rb_, re_, b, e, c]))
+    want = [fused.evaluate(d, ws_pat, pu_pat, consts) for d in batches]
+    tickets = [fused.enqueue(d, ws_pat, pu_pat, consts) for d in batches]
+    for w_, t in zip(want, tickets):
+        got = t()
+        assert all(np.array_equal(backend.host(x), backend.host(y)) for x, y in zip(w_, got))
