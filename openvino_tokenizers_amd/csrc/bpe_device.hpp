@@ -33,7 +33,7 @@ constexpr int kFastSyms = 16;                            // pieces with more sym
 constexpr int kChunkSyms = 512;                          // path W limit (symbols incl. end_suffix)
 constexpr uint32_t kIdMask = (1u << kIdBits) - 1;
 
-// One lookup of the merge table = both candidate buckets, four independent 16-byte loads.
+// One lookup of the merge table = both candidate slots, two independent 16-byte loads.
 struct MergeFetch { MergeBucket a, b; };
 __device__ __forceinline__ MergeFetch merge_fetch(const BpeDev& T, uint64_t key) {
     return MergeFetch{T.merges[merge_h1(key, T.bucket_shift)], T.merges[merge_h2(key, T.bucket_shift)]};
@@ -45,9 +45,7 @@ __device__ __forceinline__ uint64_t merge_resolve(const MergeFetch& f, uint64_t 
     // an empty slot holds all ones: its upper 42 bits never equal a key (ids < 2^21 - 1)
     uint64_t r = kNoKey;
     if ((f.a.s[0].kr >> kMaxRankBits) == key) r = make_pair_key(f.a.s[0], seq);
-    if ((f.a.s[1].kr >> kMaxRankBits) == key) r = make_pair_key(f.a.s[1], seq);
     if ((f.b.s[0].kr >> kMaxRankBits) == key) r = make_pair_key(f.b.s[0], seq);
-    if ((f.b.s[1].kr >> kMaxRankBits) == key) r = make_pair_key(f.b.s[1], seq);
     return r;
 }
 __device__ __forceinline__ uint64_t pair_key(const BpeDev& T, uint32_t l, uint32_t r, uint32_t seq) {

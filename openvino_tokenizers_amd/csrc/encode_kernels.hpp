@@ -182,13 +182,12 @@ __device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint6
     for (int i = 0; i < plen && i < 8; ++i) r0 |= uint64_t(p[i]) << (8 * i);
     for (int i = 8; i < plen; ++i) r1 |= uint64_t(p[i]) << (8 * (i - 8));
 }
-// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.  Three independent
+// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.  Two independent
 // 32-byte loads (cuckoo table), no probe chain.
 __device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
     const uint32_t mix = piece_mix(k0, k1);
     const PieceEntry e0 = P.slots[piece_h(mix, 0, P.shift)];
     const PieceEntry e1 = P.slots[piece_h(mix, 1, P.shift)];
-    const PieceEntry e2 = P.slots[piece_h(mix, 2, P.shift)];
     int cnt = -1;
     if (e0.k0 == k0 && e0.k1 == k1) {
         cnt = e0.cnt;
@@ -199,11 +198,6 @@ __device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, 
         cnt = e1.cnt;
 #pragma unroll
         for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e1.tok[k];
-    }
-    if (e2.k0 == k0 && e2.k1 == k1) {
-        cnt = e2.cnt;
-#pragma unroll
-        for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e2.tok[k];
     }
     return cnt;
 }

@@ -216,21 +216,21 @@ int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView
     }
     out.suffix = end_suffix;
 
-    // Cuckoo table: 2 hash functions x buckets of 2 slots (load <= 0.75 of the slots; grown on the rare failure).
-    for (uint32_t buckets = std::max<uint32_t>(4, pow2_at_least((uint64_t(rank_of.size()) * 4 + 5) / 6));; buckets *= 2) {
+    // Cuckoo table: 2 hash functions x 1 slot (load < 0.5 of the slots; grown until every pair is placed).
+    for (uint32_t buckets = std::max<uint32_t>(4, pow2_at_least(uint64_t(rank_of.size()) * 2 + 1));; buckets *= 2) {
         out.bucket_shift = 32 - log2u(buckets);
-        std::vector<MergeSlot> flat(size_t(buckets) * 2, MergeSlot{kEmptySlot, 0});
+        std::vector<MergeSlot> flat(size_t(buckets), MergeSlot{kEmptySlot, 0});
         uint64_t rng = 0x2545F4914F6CDD1Dull;
         bool ok = true;
         const uint32_t shift = out.bucket_shift;
         for (const auto& kv : rank_of) {
             const MergeSlot item{(kv.first << kMaxRankBits) | kv.second, uint64_t(uint32_t(out.new_id[kv.second]))};
-            ok = cuckoo_insert<MergeSlot, 4>(
+            ok = cuckoo_insert<MergeSlot, 2>(
                 flat, item,
                 [shift](const MergeSlot& m, uint32_t* idx) {
                     const uint64_t key = m.kr >> kMaxRankBits;
-                    const uint32_t b1 = merge_h1(key, shift), b2 = merge_h2(key, shift);
-                    idx[0] = 2 * b1; idx[1] = 2 * b1 + 1; idx[2] = 2 * b2; idx[3] = 2 * b2 + 1;
+                    idx[0] = merge_h1(key, shift);
+                    idx[1] = merge_h2(key, shift);
                 },
                 [](const MergeSlot& m) { return m.kr == kEmptySlot; }, rng);
             if (!ok) break;
@@ -259,7 +259,7 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
         for (int k = 0; k < cnt; ++k) e.tok[k] = ids[id_begins[i] + k];
         uniq.emplace(std::string(reinterpret_cast<const char*>(kb), 16), e);
     }
-    // Cuckoo table: 3 hash functions x 1 entry, load <= 0.5.
+    // Cuckoo table: 2 hash functions x 1 entry (load < 0.5; the loop doubles the table until every key is placed).
     for (uint32_t cap = std::max<uint32_t>(4, pow2_at_least(uint64_t(uniq.size()) + uniq.size() / 5 + 1));; cap *= 2) {
         out.shift = 32 - log2u(cap);
         out.slots.assign(size_t(cap), PieceEntry{0, 0, {0, 0, 0}, 0});
@@ -267,11 +267,11 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
         bool ok = true;
         const uint32_t shift = out.shift;
         for (const auto& kv : uniq) {
-            ok = cuckoo_insert<PieceEntry, 3>(
+            ok = cuckoo_insert<PieceEntry, 2>(
                 out.slots, kv.second,
                 [shift](const PieceEntry& e, uint32_t* idx) {
                     const uint32_t mix = piece_mix(e.k0, e.k1);
-                    for (int c = 0; c < 3; ++c) idx[c] = piece_h(mix, c, shift);
+                    for (int c = 0; c < 2; ++c) idx[c] = piece_h(mix, c, shift);
                 },
                 [](const PieceEntry& e) { return e.k1 == 0; }, rng);
             if (!ok) break;

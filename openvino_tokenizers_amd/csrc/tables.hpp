@@ -13,10 +13,10 @@
 //             rank:22} + {new_id}: a lookup is FOUR independent global_load_dwordx4 (both buckets),
 //             never a probe chain -- a wave waits for one round trip, not for its unluckiest lane;
 //             new_id[rank] also kept as a dense side array for the exact-heap path
-//   pieces    the piece memo: cuckoo table, 3 hash functions x one 32-byte entry {piece bytes
+//   pieces    the piece memo: cuckoo table, 2 hash functions x one 32-byte entry {piece bytes
 //             (<= 15) + length : 16 B, ids[3], count} holding BPE(piece) for every vocabulary token
 //             used as a whole piece, computed once at create time by the device BPE itself (see
-//             api_encode.cpp); a lookup is three independent 32-byte loads
+//             api_encode.cpp); a lookup is two independent 32-byte loads (a divergent load costs the texture addresser ~64 line lookups whatever its width: fewer, not narrower)
 //   strings   (VocabEncoder) open-addressing table of {hash32, key index}; keys stay in the
 //             decomposed begins/ends/chars form for the final byte compare
 #pragma once
@@ -62,7 +62,7 @@ struct PieceTableDev {
     const PieceEntry* slots;  // nullptr: no memo (every piece takes the merge path)
     uint32_t shift;           // 32 - log2(capacity)
 };
-struct alignas(32) MergeBucket { MergeSlot s[2]; };
+struct alignas(16) MergeBucket { MergeSlot s[1]; };  // one slot per bucket: a lookup is two 16-byte loads (divergent loads cost per instruction)
 
 struct BpeDev {
     TrieDev trie;
