@@ -132,7 +132,10 @@ def test_big_vocab(backend):
     """GPT-2-shaped tokenizer (V = 50 257, 50 000 merges)."""
     b, e, c = TextModel(6, "zipf").batch(16, 256)
     rb, re_ = ragged_rows(16)
-    run_all_paths(backend, BpeTok.load("gpt2"), [rb, re_, b, e, c])
+    tok = BpeTok.load("gpt2")
+    if backend.name == "emu":  # building the memo = the device BPE over all 50 257 tokens: a minute and a half on the emulator;
+        tok.attrs = dict(tok.attrs, cache_capacity=0)  # the memo is covered there by the small vocabularies, here on the GPU
+    run_all_paths(backend, tok, [rb, re_, b, e, c])
 
 
 def test_digits_pattern(backend):
