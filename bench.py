@@ -22,8 +22,12 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
+# The encode streams, the exchange stream and RCCL's own stream must not share a hardware queue (kernels of streams that
+# do run one after another): the HIP runtime folds streams onto 4 queues by default.  Read when the runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
@@ -50,12 +54,14 @@ PMC_FILE = ROOT / "profiles" / "latest_pmc.json"  # HBM traffic of the dominant 
 
 
 class IdOut:
-    """Four sets of ragged-id output buffers used in turn: with N > 1 up to three batches are with the exchange
-    (queued / gathering / unpacking -- a shard that outgrew the agreed pad is packed again) while the next is encoded."""
+    """Six sets of ragged-id output buffers used in turn: up to three batches are being encoded (--depth 2) while,
+    with N > 1, the exchange still holds the two before them (gathering / unpacking -- a shard that outgrew the agreed
+    pad is packed again from its local ids)."""
+    SETS = 6
 
     def __init__(self, rows, cap, dev):
         self.sets = []
-        for _ in range(4):
+        for _ in range(self.SETS):
             b = torch.empty(rows, dtype=torch.int32, device=dev)
             e = torch.empty(rows, dtype=torch.int32, device=dev)
             ids = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -64,7 +70,7 @@ class IdOut:
         self.last = self.sets[0]
 
     def take(self):
-        self.last = self.sets[self.k % 4]
+        self.last = self.sets[self.k % self.SETS]
         self.k += 1
         return self.last
 
@@ -100,11 +106,12 @@ def make_encode_bpe(args, lib, dev, rank):
         L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, stream))
         return o_begins, o_ends, o_ids[: o.n_data]
 
-    def enqueue():
-        """The same step in two halves (ovtk_encode_enqueue / ovtk_encode_finish): -> finish() -> (begins, ends, ids)."""
+    def enqueue(st=stream):
+        """The same step in two halves (ovtk_encode_enqueue / ovtk_encode_finish) on HIP stream `st`: -> finish() ->
+        (begins, ends, ids)."""
         o_begins, o_ends, o_ids, o = out.take()
         pending = C.c_void_p()
-        L.check(lib, lib.ovtk_encode_enqueue(split._h, bpe._h, C.byref(rs), None, C.byref(o), stream, C.byref(pending)))
+        L.check(lib, lib.ovtk_encode_enqueue(split._h, bpe._h, C.byref(rs), None, C.byref(o), st, C.byref(pending)))
 
         def finish():
             L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
@@ -149,10 +156,10 @@ def make_encode_llama3(args, lib, dev, rank):
         L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, stream))
         return o_begins, o_ends, o_ids[: o.n_data]
 
-    def enqueue():
+    def enqueue(st=stream):
         o_begins, o_ends, o_ids, o = out.take()
         pending = C.c_void_p()
-        L.check(lib, lib.ovtk_encode_enqueue(split._h, bpe._h, C.byref(rs), None, C.byref(o), stream, C.byref(pending)))
+        L.check(lib, lib.ovtk_encode_enqueue(split._h, bpe._h, C.byref(rs), None, C.byref(o), st, C.byref(pending)))
 
         def finish():
             L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
@@ -201,10 +208,10 @@ def make_encode_wordpiece(args, lib, dev, rank):
         L.check(lib, lib.ovtk_wordpiece_encode_run(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(o), L.MEM_DEVICE, stream))
         return o_begins, o_ends, o_ids[: o.n_data]
 
-    def enqueue():
+    def enqueue(st=stream):
         o_begins, o_ends, o_ids, o = out.take()
         pending = C.c_void_p()
-        L.check(lib, lib.ovtk_wordpiece_encode_enqueue(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(o), stream, C.byref(pending)))
+        L.check(lib, lib.ovtk_wordpiece_encode_enqueue(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(o), st, C.byref(pending)))
 
         def finish():
             L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
@@ -290,9 +297,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hog", type=int, default=0, help="debug: occupy CU slots with N idle 512-thread blocks on a side stream during "
                                                         "every step (stands in for RCCL's all-gather kernel; tools/cu_hog.hip)")
-    ap.add_argument("--row-tickets", type=int, default=-1, help="ovtk_set_row_tickets(n); default: 0 at N = 1, 2 with an exchange")
+    ap.add_argument("--row-tickets", type=int, default=-1, help="ovtk_set_row_tickets(n); default 0 (static row assignment)")
     ap.add_argument("--hog-lds", type=int, default=0, help="debug: dynamic LDS bytes per hog block")
     ap.add_argument("--lib", default=None, help="debug: load this build of libovtk_amd.so")
+    ap.add_argument("--depth", type=int, default=2, help="batches launched ahead of the one being completed (two-half calls)")
+    ap.add_argument("--exchange-stream", type=int, default=1, help="1: pack/unpack of the exchange on a HIP stream of their own")
+    ap.add_argument("--streams", type=int, default=2, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
     args = ap.parse_args()
@@ -317,15 +327,20 @@ def main():
     # travels over xGMI while batch k + 1 is encoded; flush() completes the last one inside the timed region.
     exchange = None
     if (world > 1 or args.force_exchange) and not args.no_gather and not is_detok:
-        exchange = ShardExchange(wl.get("rows", args.rows) * world, wl["vocab"], dev, lib=lib)
+        xstream = torch.cuda.Stream(dev) if args.exchange_stream else None
+        exchange = ShardExchange(wl.get("rows", args.rows) * world, wl["vocab"], dev, lib=lib, stream=xstream)
 
-    # A step = one batch through the hot path.  Where the op has the two-half form (config 2) the host launches batch k,
-    # then completes batch k-1 (status check, and with N > 1 its exchange) while the GPU works on k: the reference's
-    # evaluate() semantics per batch, without the GPU idling while the host reads a status word.  --sync: one blocking
-    # ovtk_encode_run per step.
-    row_tickets = args.row_tickets if args.row_tickets >= 0 else (2 if exchange is not None else 0)
+    # A step = one batch through the hot path.  Where the op has the two-half form the host launches batch k, then
+    # completes batch k-1 (status check, and with N > 1 its exchange) while the GPU works on k: the reference's
+    # evaluate() semantics per batch, without the GPU idling while the host reads a status word.  Consecutive batches go to
+    # alternating HIP streams: the latency-bound merge kernel of one batch then shares the CUs with the issue-bound
+    # lookup kernel of the next (per-launch durations grow, the step shrinks).  --sync: one blocking call per step.
+    row_tickets = max(args.row_tickets, 0)
     L.check(lib, lib.ovtk_set_row_tickets(row_tickets))
     inflight = []
+    side_streams = [torch.cuda.Stream(dev) for _ in range(max(args.streams - 1, 0))]
+    stream_ptrs = [C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)] + [C.c_void_p(x.cuda_stream) for x in side_streams]
+    launched = [0]
     hog = None
     if args.hog:
         hog_lib = C.CDLL(str(ROOT / "tools" / "build" / "libcuhog.so"))
@@ -340,8 +355,9 @@ def main():
         if hog is not None:
             hog()
         if "enqueue" in wl and not args.sync:
-            inflight.append(wl["enqueue"]())
-            return complete(inflight.pop(0)) if len(inflight) > 1 else None
+            inflight.append(wl["enqueue"](stream_ptrs[launched[0] % len(stream_ptrs)]))
+            launched[0] += 1
+            return complete(inflight.pop(0)) if len(inflight) > args.depth else None
         return complete(wl["step"])
 
     def drain():
@@ -406,6 +422,23 @@ def main():
                     "traffic": traffic, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
                     "launches_per_step": launches_per_step,
                     "all_kernels_ms_per_step": round(sum(per_step.values()), 4)}
+        if "enqueue" in wl and not args.sync and len(stream_ptrs) > 1:
+            # The durations above are of launches that shared the CUs with the neighbouring batch's kernels (that is
+            # the point of the second stream).  For reference: the same kernel with the chip to itself, a short
+            # one-stream leg outside the timed region.
+            lib.ovtk_profile_reset()
+            lib.ovtk_profile_enable(1)
+            for _ in range(20):
+                wl["enqueue"](stream_ptrs[0])()   # launch, then finish: no exchange in this leg
+            torch.cuda.synchronize()
+            lib.ovtk_profile_enable(0)
+            lib.ovtk_profile_dump(buf, 8192)
+            alone = {ln.split()[0]: (float(ln.split()[1]), int(ln.split()[2])) for ln in buf.value.decode().splitlines() if ln.strip()}
+            if dom in alone and alone[dom][1]:
+                a_ms = alone[dom][0] / alone[dom][1]
+                a_gbs = algo_bytes / launches_per_step / (a_ms * 1e-3) / 1e9
+                roofline["alone"] = {"kernel_ms": round(a_ms, 4), "achieved": round(a_gbs, 2), "frac": round(a_gbs / HBM_PEAK_GBS, 5),
+                                     "note": "same kernel without a neighbouring batch on the CUs (20 one-stream launches, untimed leg)"}
 
     if rank != 0:
         if exchange is not None:
@@ -440,8 +473,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
         "config": {"workload": wl["workload"],
                    "row_tickets": row_tickets,
-                   "host_loop": ("launch batch k, then complete batch k-1 (ovtk_encode_enqueue/finish)" if "enqueue" in wl and not args.sync
-                                 else "one blocking call per batch"),
+                   "host_loop": (f"launch batch k, then complete batch k-1 (two-half calls), batches alternate between {len(stream_ptrs)} "
+                                 f"HIP stream(s)" if "enqueue" in wl and not args.sync else "one blocking call per batch"),
                    "rows_per_gpu": wl.get("rows", args.rows), "units_per_gpu": n_units, "outputs_per_gpu": n_out,
                    "exchange": ("none (1 GPU)" if exchange is None and world == 1 else ("none (rank-local consumer)" if exchange is None else
                                                                     f"all-gather of ragged ids over RCCL, {exchange.id_bytes}-byte ids on the wire, "

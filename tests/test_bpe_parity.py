@@ -318,6 +318,33 @@ def test_enqueue_finish_overlapped(gpu_backend):
         fused.enqueue([np.asarray(x.cpu()) for x in batches[0]] + [pat], tok.consts)
 
 
+@pytest.mark.gpu
+def test_enqueue_on_alternating_streams(gpu_backend):
+    """Consecutive batches on two HIP streams (bench.py's host loop): their kernels share the CUs, every batch still
+    equals the oracle."""
+    import torch
+    backend = gpu_backend
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    batches, refs, tickets = [], [], []
+    for i, (n, target, kind) in enumerate([(20000, 300, "zipf"), (4000, 900, "mixed"), (20000, 120, "uniform"), (9000, 500, "zipf")]):
+        b, e, c = TextModel(40 + i, kind).batch(n, target)
+        rb, re_ = ragged_rows(n)
+        refs.append(orc(*rs(rb, re_, b, e, c)[:5]))
+        batches.append(backend.data([rb, re_, b, e, c]))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for rounds in range(2):   # the second round runs on warm memo tables and leased workspaces
+        tickets = []
+        for k, data in enumerate(batches):
+            with torch.cuda.stream(streams[k % 2]):
+                tickets.append(fused.enqueue(data + [pat], tok.consts))
+        for ref, ticket in zip(refs, tickets):
+            assert_same(ref, ticket(), backend.host, "two streams")
+
+
 @pytest.mark.parametrize("rows_per_ticket", [1, 2, 5])
 def test_row_tickets_same_result(backend, rows_per_ticket):
     """ovtk_set_row_tickets: rows handed out dynamically (for a GPU shared with a collective) -- identical output."""

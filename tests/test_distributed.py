@@ -104,17 +104,20 @@ def test_shard_exchange_gloo(emu_lib, world, n_rows, vocab):
 
 
 @pytest.mark.gpu
-def test_shard_exchange_rccl_one_rank(hip_lib):
+@pytest.mark.parametrize("own_stream", [False, True])
+def test_shard_exchange_rccl_one_rank(hip_lib, own_stream):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
         n_rows, vocab = 5000, 50257
         batches = _batches(11, n_rows, vocab, n_batches=5)
-        ex = ShardExchange(n_rows, vocab, dev, lib=hip_lib)
+        ex = ShardExchange(n_rows, vocab, dev, lib=hip_lib, stream=torch.cuda.Stream(dev) if own_stream else None)
         got = []
         for lens, ids in batches:
-            done = ex.submit(*_local_shard(lens, ids, 0, 1, device=dev))
+            local = _local_shard(lens, ids, 0, 1, device=dev)
+            torch.cuda.synchronize()   # a stream of its own: the shard must be complete when it is handed over
+            done = ex.submit(*local)
             if done is not None:
                 got.append([t.cpu().numpy() for t in done])
         got += [[t.cpu().numpy() for t in b] for b in ex.flush()]
