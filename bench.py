@@ -300,9 +300,11 @@ def main():
     ap.add_argument("--row-tickets", type=int, default=-1, help="ovtk_set_row_tickets(n); default 0 (static row assignment)")
     ap.add_argument("--hog-lds", type=int, default=0, help="debug: dynamic LDS bytes per hog block")
     ap.add_argument("--lib", default=None, help="debug: load this build of libovtk_amd.so")
+    ap.add_argument("--no-alone-leg", action="store_true", help="skip the one-stream leg behind roofline.alone (profile runs: "
+                    "rocprofv3's per-kernel average then covers the overlapped launches only)")
     ap.add_argument("--depth", type=int, default=2, help="batches launched ahead of the one being completed (two-half calls)")
     ap.add_argument("--exchange-stream", type=int, default=1, help="1: pack/unpack of the exchange on a HIP stream of their own")
-    ap.add_argument("--streams", type=int, default=2, help="consecutive batches alternate between this many HIP streams (two-half calls)")
+    ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
     args = ap.parse_args()
@@ -422,7 +424,10 @@ def main():
                     "traffic": traffic, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
                     "launches_per_step": launches_per_step,
                     "all_kernels_ms_per_step": round(sum(per_step.values()), 4)}
-        if "enqueue" in wl and not args.sync and len(stream_ptrs) > 1:
+        step_gbs = algo_bytes * (total_units / n_units) / (ms_per_step * 1e-3) / 1e9 / world
+        roofline["step"] = {"achieved": round(step_gbs, 2), "frac": round(step_gbs / HBM_PEAK_GBS, 5),
+                            "note": "algorithmic bytes of one batch / ms_per_step, per GPU: every kernel of the path, overlapped as run"}
+        if "enqueue" in wl and not args.sync and len(stream_ptrs) > 1 and not args.no_alone_leg:
             # The durations above are of launches that shared the CUs with the neighbouring batch's kernels (that is
             # the point of the second stream).  For reference: the same kernel with the chip to itself, a short
             # one-stream leg outside the timed region.
