@@ -57,7 +57,9 @@ struct SplitDev {
 constexpr uint16_t kPieceDropped = 0x8000;  // flag in WaveScratch::pstart: the piece is not emitted
 constexpr uint16_t kPiecePosMask = 0x7FFF;
 
-constexpr int kChunk = 512;               // window bytes (text whose piece starts are decided per pass + halos)
+constexpr int kLaneDwords = 3;            // text dwords a lane classifies in the packed-byte (ASCII) scanner
+constexpr int kChunk = 64 * 4 * kLaneDwords;  // window bytes (text whose piece starts are decided per pass + halos): 768,
+                                          // so that a ~512-byte string with its +-10 % is ONE window (and a "simple" row)
 constexpr int kLeftHalo = 8;
 constexpr int kRightHalo = 12;
 constexpr int kTextPad = 4;               // zero bytes in front of the staged text (the packed-byte path reads 4 bytes back)
@@ -538,31 +540,36 @@ __device__ __forceinline__ uint32_t swar_after(uint32_t lo, uint32_t hi) { retur
 template <int K>
 __device__ __forceinline__ uint32_t swar_before(uint32_t lo, uint32_t hi) { return (hi << (8 * K)) | (lo >> (32 - 8 * K)); }
 
-// Piece-start flags of window bytes [8l, 8l+8) for lane l (bit 8k+7 = byte 8l+k), same rules as gpt2_start_mask.
-// Returns false (wave-uniform) when the window holds a non-ASCII byte: the caller then takes the ballot path.
-// A lane classifies only its own two dwords; what the rules need from the bytes before and after them (the classes
-// of the previous byte, "next byte is not a space", the contraction letters after an apostrophe, contractions that
-// fired up to three bytes back) comes from the neighbouring lanes with one DPP wavefront shift per value.
-// Index convention below: [0] = last dword of lane l-1, [1], [2] = own dwords, [3] = first dword of lane l+1.
-__device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, int skew, int wlen, bool digits,
-                                                       unsigned long long& flags) {
+// Piece-start flags of window bytes [LBy*l, LBy*(l+1)) for lane l, LBy = 4*LB (bit k of `flags` = byte LBy*l + k), same
+// rules as gpt2_start_mask.  Returns false (wave-uniform) when the window holds a non-ASCII byte: the caller then takes
+// the ballot path.  A lane classifies only its own LB dwords; what the rules need from the bytes before and after them
+// (the classes of the previous byte, "next byte is not a space", the contraction letters after an apostrophe,
+// contractions that fired up to three bytes back) comes from the neighbouring lanes with one DPP wavefront shift per
+// value.  Index convention below: [0] = last dword of lane l-1, [1..LB] = own dwords, [LB+1] = first dword of lane l+1.
+template <int LB>
+__device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, int skew, int wlen, bool digits, uint32_t& flags) {
+    constexpr int LBy = 4 * LB;
     const int l = lane_id();
-    const int off = kTextPad + skew + 8 * l;  // byte offset of the lane's first byte in text_w
+    const int off = kTextPad + skew + LBy * l;  // byte offset of the lane's first byte in text_w
     const int a = off >> 2, sh = (off & 3) * 8;
-    const uint32_t r0 = ws.text_w[a], r1 = ws.text_w[a + 1], r2 = ws.text_w[a + 2];
-    int nv = wlen - 8 * l;  // how many of the lane's 8 bytes exist
-    nv = nv < 0 ? 0 : (nv > 8 ? 8 : nv);
-    const uint32_t m1 = nv >= 4 ? ~0u : ((1u << (8 * nv)) - 1u);
-    const uint32_t m2 = nv >= 8 ? ~0u : (nv <= 4 ? 0u : ((1u << (8 * (nv - 4))) - 1u));
-    uint32_t x[4] = {0, 0, 0, 0}, V[4] = {0, 0, 0, 0};
-    x[1] = uint32_t(((static_cast<unsigned long long>(r1) << 32) | r0) >> sh) & m1;
-    x[2] = uint32_t(((static_cast<unsigned long long>(r2) << 32) | r1) >> sh) & m2;
-    V[1] = m1 & kB7;
-    V[2] = m2 & kB7;
-    if (__ballot(((x[1] | x[2]) & kB7) != 0)) return false;
-    uint32_t L[3], N[3], S[3], SP[3], AP[3], O[3];
+    int nv = wlen - LBy * l;  // how many of the lane's bytes exist
+    nv = nv < 0 ? 0 : (nv > LBy ? LBy : nv);
+    uint32_t x[LB + 1], V[LB + 1], r[LB + 1];
 #pragma unroll
-    for (int j = 1; j <= 2; ++j) {
+    for (int j = 0; j <= LB; ++j) r[j] = ws.text_w[a + j];
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 1; j <= LB; ++j) {
+        const int have = nv - 4 * (j - 1);  // bytes of dword j that exist
+        const uint32_t m = have >= 4 ? ~0u : (have <= 0 ? 0u : ((1u << (8 * have)) - 1u));
+        x[j] = uint32_t(((static_cast<unsigned long long>(r[j]) << 32) | r[j - 1]) >> sh) & m;
+        V[j] = m & kB7;
+        any |= x[j];
+    }
+    if (__ballot((any & kB7) != 0)) return false;
+    uint32_t L[LB + 1], N[LB + 1], S[LB + 1], SP[LB + 1], AP[LB + 1], O[LB + 1];
+#pragma unroll
+    for (int j = 1; j <= LB; ++j) {
         L[j] = swar_range(x[j] | 0x20202020u, 'a', 'z');
         N[j] = swar_range(x[j], '0', '9');
         SP[j] = swar_eq(x[j], 0x20) & V[j];  // a non-existing byte is 0x00: never a letter, digit, apostrophe; mask the rest
@@ -570,31 +577,36 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
         AP[j] = swar_eq(x[j], 0x27);
         O[j] = V[j] & ~(L[j] | N[j] | S[j]);
     }
-    L[0] = lane_prev(L[2]);
-    N[0] = lane_prev(N[2]);
-    S[0] = lane_prev(S[2]);
-    O[0] = lane_prev(O[2]);
-    SP[0] = lane_prev(SP[2]);
-    uint32_t NS[4];  // "exists and is not white space"
-    NS[1] = V[1] & ~S[1];
-    NS[2] = V[2] & ~S[2];
-    NS[3] = lane_next(NS[1]);
-    uint32_t f1[3] = {0, 0, 0}, f2[3] = {0, 0, 0};  // contractions ('x / 'xx) firing at an apostrophe
-    if (__ballot((AP[1] | AP[2]) != 0)) {
-        uint32_t X1[4], X2[4], XE[4], XL[4];
+    L[0] = lane_prev(L[LB]);
+    N[0] = lane_prev(N[LB]);
+    S[0] = lane_prev(S[LB]);
+    O[0] = lane_prev(O[LB]);
+    SP[0] = lane_prev(SP[LB]);
+    uint32_t NS[LB + 2];  // "exists and is not white space"
 #pragma unroll
-        for (int j = 1; j <= 2; ++j) {
+    for (int j = 1; j <= LB; ++j) NS[j] = V[j] & ~S[j];
+    NS[LB + 1] = lane_next(NS[1]);
+    uint32_t f1[LB + 1], f2[LB + 1];  // contractions ('x / 'xx) firing at an apostrophe
+#pragma unroll
+    for (int j = 0; j <= LB; ++j) f1[j] = f2[j] = 0;
+    uint32_t any_ap = 0;
+#pragma unroll
+    for (int j = 1; j <= LB; ++j) any_ap |= AP[j];
+    if (__ballot(any_ap != 0)) {
+        uint32_t X1[LB + 2], X2[LB + 2], XE[LB + 2], XL[LB + 2];
+#pragma unroll
+        for (int j = 1; j <= LB; ++j) {
             X1[j] = swar_range(x[j], 's', 't') | swar_eq(x[j], 'm') | swar_eq(x[j], 'd');
             X2[j] = swar_eq(x[j], 'r') | swar_eq(x[j], 'v');
             XE[j] = swar_eq(x[j], 'e');
             XL[j] = swar_eq(x[j], 'l');
         }
-        X1[3] = lane_next(X1[1]);
-        X2[3] = lane_next(X2[1]);
-        XE[3] = lane_next(XE[1]);
-        XL[3] = lane_next(XL[1]);
+        X1[LB + 1] = lane_next(X1[1]);
+        X2[LB + 1] = lane_next(X2[1]);
+        XE[LB + 1] = lane_next(XE[1]);
+        XL[LB + 1] = lane_next(XL[1]);
 #pragma unroll
-        for (int j = 1; j <= 2; ++j) {
+        for (int j = 1; j <= LB; ++j) {
             const uint32_t c1 = AP[j] & swar_after<1>(X1[j], X1[j + 1]);
             const uint32_t c2 = AP[j] & ((swar_after<1>(X2[j], X2[j + 1]) & swar_after<2>(XE[j], XE[j + 1])) |
                                          (swar_after<1>(XL[j], XL[j + 1]) & swar_after<2>(XL[j], XL[j + 1])));
@@ -603,12 +615,12 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
             f1[j] = c1 & ~blocked;
             f2[j] = c2 & ~blocked;
         }
-        f1[0] = lane_prev(f1[2]);
-        f2[0] = lane_prev(f2[2]);
+        f1[0] = lane_prev(f1[LB]);
+        f2[0] = lane_prev(f2[LB]);
     }
-    uint32_t start[2];
+    flags = 0;
 #pragma unroll
-    for (int j = 1; j <= 2; ++j) {
+    for (int j = 1; j <= LB; ++j) {
         const uint32_t pL = swar_before<1>(L[j - 1], L[j]), pN = swar_before<1>(N[j - 1], N[j]);
         const uint32_t pS = swar_before<1>(S[j - 1], S[j]), pO = swar_before<1>(O[j - 1], O[j]);
         const uint32_t pSP = swar_before<1>(SP[j - 1], SP[j]);
@@ -620,9 +632,10 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
         const uint32_t f12_lo = f1[j - 1] | f2[j - 1], f12 = f1[j] | f2[j];
         st |= swar_before<2>(f1[j - 1], f1[j]) | swar_before<3>(f2[j - 1], f2[j]);  // the byte after a contraction
         st &= ~swar_before<1>(f12_lo, f12);                                           // its first letter stays with it
-        start[j - 1] = st & V[j];
+        // bit 7 of the dword's four bytes -> four adjacent bits
+        const uint32_t t = (st & V[j]) >> 7;
+        flags |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * (j - 1));
     }
-    flags = (static_cast<unsigned long long>(start[1]) << 32) | start[0];
     return true;
 }
 
@@ -660,7 +673,7 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
         // rank the starts of [c0, qlim) (window bytes [lo, hi)); c0 itself is a start by construction
         const int lo = c0 - w0, hi = qlim - w0;
         int np = 0;
-        unsigned long long fl = 0;
+        uint32_t fl = 0;
         if constexpr (LLAMA3) {
             int und = 0;
             bool seq = false;
@@ -722,21 +735,20 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                     ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t((w * 64 + l - lo) | (((d >> l) & 1ull) ? kPieceDropped : 0));
                 np += __popcll(m);
             }
-        } else if (gpt2_start_flags_ascii(ws, skew, w1 - w0, digits, fl)) {
-            // lane l holds the flags of window bytes [8l, 8l+8) in bit 7 of each byte
-            int k_lo = lo - 8 * l, k_hi = hi - 8 * l;
-            k_lo = k_lo < 0 ? 0 : (k_lo > 8 ? 8 : k_lo);
-            k_hi = k_hi < 0 ? 0 : (k_hi > 8 ? 8 : k_hi);
-            const unsigned long long below_hi = k_hi == 8 ? ~0ull : ((1ull << (8 * k_hi)) - 1ull);
-            const unsigned long long below_lo = k_lo == 8 ? ~0ull : ((1ull << (8 * k_lo)) - 1ull);
-            fl &= below_hi & ~below_lo;
-            if ((lo >> 3) == l) fl |= 0x80ull << (8 * (lo & 7));
-            const int cnt = __popcll(fl);
+        } else if (gpt2_start_flags_ascii<kLaneDwords>(ws, skew, w1 - w0, digits, fl)) {
+            // lane l holds the flags of window bytes [LBy*l, LBy*(l+1)), one bit per byte
+            constexpr int LBy = 4 * kLaneDwords;
+            int k_lo = lo - LBy * l, k_hi = hi - LBy * l;
+            k_lo = k_lo < 0 ? 0 : (k_lo > LBy ? LBy : k_lo);
+            k_hi = k_hi < 0 ? 0 : (k_hi > LBy ? LBy : k_hi);
+            fl &= ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
+            if (lo / LBy == l) fl |= 1u << (lo % LBy);
+            const int cnt = __popc(fl);
             const int incl = wave_incl_sum(cnt);
             int at = incl - cnt;
+            const int first = LBy * l - lo;
             while (fl) {
-                const int bit = __ffsll(fl) - 1;
-                ws.pstart[at++] = uint16_t(8 * l + (bit >> 3) - lo);
+                ws.pstart[at++] = uint16_t(first + __ffs(fl) - 1);
                 fl &= fl - 1;
             }
             np = wave_readlane(incl, kWave - 1);
