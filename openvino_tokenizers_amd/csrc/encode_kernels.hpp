@@ -248,7 +248,11 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     uint64_t k0 = 0, k1 = 0;
     if (valid && plen >= 1 && plen <= kPieceKeyBytes) {
         piece_key(r0, r1, plen, k0, k1);
+#ifdef OVTK_ABLATE_PROBES
+        cnt = 1; tok[0] = int32_t(k0 & 0xFFFF);
+#else
         if (T.pieces.slots) cnt = memo_lookup(T.pieces, k0, k1, tok);
+#endif
     }
     const bool hit = cnt >= 0;
     const int need = valid ? (hit ? cnt : plen + SL) : 0;
@@ -443,7 +447,7 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
                 const int sb = h.simple ? h.sb : in.begins[col];
                 const int slen = h.simple ? h.slen : in.ends[col] - sb;
                 scan_string<MODE == kFusedLlama3>(
-                    ws, sp, in.chars + sb, slen,
+                    ws, sp, in.chars + sb, slen, in.chars, in.chars + in.n_chars,
                     [&](int np, int c0, int w0, int skew) {
                         for (int jb = 0; jb < np; jb += kWave) {
                             const int j = jb + l;
@@ -809,7 +813,7 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
                 if (out_skips) out_skips[o + count + idx] = 0;
             };
             scan_string<LLAMA3>(
-                ws, sp, in.chars + sb, se - sb,
+                ws, sp, in.chars + sb, se - sb, in.chars, in.chars + in.n_chars,
                 [&](int np, int c0, int, int) {
                     for (int jb = 0; jb < np; jb += kWave) {
                         const int j = jb + l;

@@ -195,9 +195,11 @@ __device__ __forceinline__ int llama3_match_end(const SplitDev& sp, const uint8_
 }
 
 // Stage bytes [w0, w1) of the string at `str` (global) into ws.text_w.  Returns the skew: string
-// byte p lives at text_bytes(ws)[p - w0 + skew].  Whole dwords are fetched where they lie inside
-// the string's own buffer range [0, slen); edge dwords are assembled from byte loads.
-__device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str, int slen, int w0, int w1) {
+// byte p lives at text_bytes(ws)[p - w0 + skew].  Whole aligned dwords are fetched; a dword that straddles an end of
+// the string is masked down to the string's own bytes (the others are staged as zeros) -- it is still one load as long
+// as it lies inside the chars tensor [buf, buf_end); only at the tensor's own unaligned ends are bytes loaded singly.
+__device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str, int slen, int w0, int w1, const uint8_t* buf,
+                                            const uint8_t* buf_end) {
     const uint8_t* g = str + w0;
     const int skew = int(reinterpret_cast<uintptr_t>(g) & 3);
     const uint8_t* ga = g - skew;
@@ -209,6 +211,13 @@ __device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str,
         uint32_t w;
         if (b0 >= lo && b0 + 4 <= hi) {
             w = *reinterpret_cast<const uint32_t*>(ga + b0);
+        } else if (ga + b0 >= buf && ga + b0 + 4 <= buf_end) {
+            int cl = lo - b0, ch = hi - b0;  // keep bytes [cl, ch) of the dword
+            cl = cl < 0 ? 0 : (cl > 4 ? 4 : cl);
+            ch = ch < 0 ? 0 : (ch > 4 ? 4 : ch);
+            const uint32_t below_ch = ch >= 4 ? ~0u : ((1u << (8 * ch)) - 1u);
+            const uint32_t below_cl = cl >= 4 ? ~0u : ((1u << (8 * cl)) - 1u);
+            w = *reinterpret_cast<const uint32_t*>(ga + b0) & below_ch & ~below_cl;
         } else {
             w = 0;
             for (int j = 0; j < 4; ++j)
@@ -639,6 +648,32 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
     return true;
 }
 
+// Packed-byte scan of an ASCII window, LB dwords per lane: ranks the starts of window bytes [lo, hi) (lo itself forced)
+// into ws.pstart, relative to lo.  false (wave-uniform): the window is not ASCII, nothing was written.
+template <int LB>
+__device__ __forceinline__ bool gpt2_packed_starts(WaveScratch& ws, int skew, int wlen, bool digits, int lo, int hi, int& np) {
+    uint32_t fl = 0;
+    if (!gpt2_start_flags_ascii<LB>(ws, skew, wlen, digits, fl)) return false;
+    // lane l holds the flags of window bytes [LBy*l, LBy*(l+1)), one bit per byte
+    constexpr int LBy = 4 * LB;
+    const int l = lane_id();
+    int k_lo = lo - LBy * l, k_hi = hi - LBy * l;
+    k_lo = k_lo < 0 ? 0 : (k_lo > LBy ? LBy : k_lo);
+    k_hi = k_hi < 0 ? 0 : (k_hi > LBy ? LBy : k_hi);
+    fl &= ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
+    if (lo / LBy == l) fl |= 1u << (lo % LBy);
+    const int cnt = __popc(fl);
+    const int incl = wave_incl_sum(cnt);
+    int at = incl - cnt;
+    const int first = LBy * l - lo;
+    while (fl) {
+        ws.pstart[at++] = uint16_t(first + __ffs(fl) - 1);
+        fl &= fl - 1;
+    }
+    np = wave_readlane(incl, kWave - 1);
+    return true;
+}
+
 // Scans string `str` (slen bytes) and hands complete pieces to the caller chunk by chunk.
 //   on_chunk(np, c0, w0, skew): pstart[0..np] (positions relative to c0, pstart[np] = end of the last piece)
 //                               describe np complete pieces; the LDS text covers them (string byte p at
@@ -646,12 +681,13 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
 //                               class patterns: entries carry kPieceDropped when the piece is not to be emitted
 //                               (read positions through kPiecePosMask).
 //   on_long(b, e, dropped):     a piece of more than kChunk bytes, not staged in LDS.
+// [buf, buf_end): the chars tensor the string lies in (what may be read).
 // Wave-uniform; every lane must call it with the same arguments.
 // LLAMA3: the kernel is compiled for the Llama-3 pattern only / for every other pattern (the two families share no
 // scanner code, and either one alone fits the register budget of the lookup kernel).
 template <bool LLAMA3, class OnChunk, class OnLong>
-__device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp, const uint8_t* str, int slen,
-                                            OnChunk&& on_chunk, OnLong&& on_long) {
+__device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp, const uint8_t* str, int slen, const uint8_t* buf,
+                                            const uint8_t* buf_end, OnChunk&& on_chunk, OnLong&& on_long) {
     const bool digits = sp.kind == kSplitGpt2Digits;
     const int l = lane_id();
     int c0 = 0;
@@ -668,12 +704,11 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
         }
         const int w1 = (qlim + kRightHalo < slen) ? qlim + kRightHalo : slen;
         wave_sync();  // previous consumers of the LDS window are done
-        const int skew = stage_window(ws, str, slen, w0, w1);
+        const int skew = stage_window(ws, str, slen, w0, w1, buf, buf_end);
         wave_sync();
         // rank the starts of [c0, qlim) (window bytes [lo, hi)); c0 itself is a start by construction
         const int lo = c0 - w0, hi = qlim - w0;
         int np = 0;
-        uint32_t fl = 0;
         if constexpr (LLAMA3) {
             int und = 0;
             bool seq = false;
@@ -735,23 +770,9 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                     ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t((w * 64 + l - lo) | (((d >> l) & 1ull) ? kPieceDropped : 0));
                 np += __popcll(m);
             }
-        } else if (gpt2_start_flags_ascii<kLaneDwords>(ws, skew, w1 - w0, digits, fl)) {
-            // lane l holds the flags of window bytes [LBy*l, LBy*(l+1)), one bit per byte
-            constexpr int LBy = 4 * kLaneDwords;
-            int k_lo = lo - LBy * l, k_hi = hi - LBy * l;
-            k_lo = k_lo < 0 ? 0 : (k_lo > LBy ? LBy : k_lo);
-            k_hi = k_hi < 0 ? 0 : (k_hi > LBy ? LBy : k_hi);
-            fl &= ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
-            if (lo / LBy == l) fl |= 1u << (lo % LBy);
-            const int cnt = __popc(fl);
-            const int incl = wave_incl_sum(cnt);
-            int at = incl - cnt;
-            const int first = LBy * l - lo;
-            while (fl) {
-                ws.pstart[at++] = uint16_t(first + __ffs(fl) - 1);
-                fl &= fl - 1;
-            }
-            np = wave_readlane(incl, kWave - 1);
+        } else if (w1 - w0 <= 64 * 4 * (kLaneDwords - 1) ? gpt2_packed_starts<kLaneDwords - 1>(ws, skew, w1 - w0, digits, lo, hi, np)
+                                                          : gpt2_packed_starts<kLaneDwords>(ws, skew, w1 - w0, digits, lo, hi, np)) {
+            // ASCII window: the packed-byte scanner filled pstart (with as few dwords per lane as cover the window)
         } else {
             const Mask start = gpt2_start_mask(ws, sp, skew, w1 - w0, digits);
             for (int w = lo >> 6; w * 64 < hi; ++w) {
@@ -782,7 +803,7 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                 const int lq = (e + lspan < slen) ? e + lspan : slen;
                 const int lw1 = (lq + kRightHalo < slen) ? lq + kRightHalo : slen;
                 wave_sync();
-                const int lskew = stage_window(ws, str, slen, lw0, lw1);
+                const int lskew = stage_window(ws, str, slen, lw0, lw1, buf, buf_end);
                 wave_sync();
                 Mask ls, ldrop;
                 if (sp.kind >= kSplitWhitespace) class_start_mask(ws, sp, lskew, lw1 - lw0, ls, ldrop);
