@@ -248,11 +248,7 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     uint64_t k0 = 0, k1 = 0;
     if (valid && plen >= 1 && plen <= kPieceKeyBytes) {
         piece_key(r0, r1, plen, k0, k1);
-#ifdef OVTK_ABLATE_PROBES
-        cnt = 1; tok[0] = int32_t(k0 & 0xFFFF);
-#else
         if (T.pieces.slots) cnt = memo_lookup(T.pieces, k0, k1, tok);
-#endif
     }
     const bool hit = cnt >= 0;
     const int need = valid ? (hit ? cnt : plen + SL) : 0;
