@@ -595,39 +595,43 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
 #pragma unroll
     for (int j = 1; j <= LB; ++j) NS[j] = V[j] & ~S[j];
     NS[LB + 1] = lane_next(NS[1]);
-    uint32_t f1[LB + 1], f2[LB + 1];  // contractions ('x / 'xx) firing at an apostrophe
+    // Contractions ('x / 'xx) firing at an apostrophe.  Apostrophes are few (about one per row of text), so only the
+    // dwords that hold one look at the two bytes behind it -- a divergent branch per dword of the lane whose body most
+    // waves skip -- instead of classifying every byte of the window as a contraction letter.
+    uint32_t f1[LB + 1], f2[LB + 1];
 #pragma unroll
     for (int j = 0; j <= LB; ++j) f1[j] = f2[j] = 0;
     uint32_t any_ap = 0;
 #pragma unroll
     for (int j = 1; j <= LB; ++j) any_ap |= AP[j];
+    bool fired = false;  // wave-uniform: some contraction fired in the window
     if (__ballot(any_ap != 0)) {
-        uint32_t X1[LB + 2], X2[LB + 2], XE[LB + 2], XL[LB + 2];
+        uint32_t xn[LB + 2];
+#pragma unroll
+        for (int j = 1; j <= LB; ++j) xn[j] = x[j];
+        xn[LB + 1] = lane_next(x[1]);
 #pragma unroll
         for (int j = 1; j <= LB; ++j) {
-            X1[j] = swar_range(x[j], 's', 't') | swar_eq(x[j], 'm') | swar_eq(x[j], 'd');
-            X2[j] = swar_eq(x[j], 'r') | swar_eq(x[j], 'v');
-            XE[j] = swar_eq(x[j], 'e');
-            XL[j] = swar_eq(x[j], 'l');
+            if (AP[j]) {
+                const uint32_t n1 = swar_after<1>(xn[j], xn[j + 1]), n2 = swar_after<2>(xn[j], xn[j + 1]);  // the next two bytes
+                const uint32_t c1 = AP[j] & (swar_range(n1, 's', 't') | swar_eq(n1, 'm') | swar_eq(n1, 'd'));
+                const uint32_t c2 = AP[j] & (((swar_eq(n1, 'r') | swar_eq(n1, 'v')) & swar_eq(n2, 'e')) | (swar_eq(n1, 'l') & swar_eq(n2, 'l')));
+                // the apostrophe itself starts a piece unless the previous char is class O or U+0020
+                const uint32_t blocked = swar_before<1>(O[j - 1] | SP[j - 1], O[j] | SP[j]);
+                f1[j] = c1 & ~blocked;
+                f2[j] = c2 & ~blocked;
+            }
         }
-        X1[LB + 1] = lane_next(X1[1]);
-        X2[LB + 1] = lane_next(X2[1]);
-        XE[LB + 1] = lane_next(XE[1]);
-        XL[LB + 1] = lane_next(XL[1]);
+        uint32_t any_f = 0;
 #pragma unroll
-        for (int j = 1; j <= LB; ++j) {
-            const uint32_t c1 = AP[j] & swar_after<1>(X1[j], X1[j + 1]);
-            const uint32_t c2 = AP[j] & ((swar_after<1>(X2[j], X2[j + 1]) & swar_after<2>(XE[j], XE[j + 1])) |
-                                         (swar_after<1>(XL[j], XL[j + 1]) & swar_after<2>(XL[j], XL[j + 1])));
-            // the apostrophe itself starts a piece unless the previous char is class O or U+0020
-            const uint32_t blocked = swar_before<1>(O[j - 1] | SP[j - 1], O[j] | SP[j]);
-            f1[j] = c1 & ~blocked;
-            f2[j] = c2 & ~blocked;
+        for (int j = 1; j <= LB; ++j) any_f |= f1[j] | f2[j];
+        fired = __ballot(any_f != 0) != 0;
+        if (fired) {
+            f1[0] = lane_prev(f1[LB]);
+            f2[0] = lane_prev(f2[LB]);
         }
-        f1[0] = lane_prev(f1[LB]);
-        f2[0] = lane_prev(f2[LB]);
     }
-    flags = 0;
+    uint32_t st[LB + 1];
 #pragma unroll
     for (int j = 1; j <= LB; ++j) {
         const uint32_t pL = swar_before<1>(L[j - 1], L[j]), pN = swar_before<1>(N[j - 1], N[j]);
@@ -635,14 +639,23 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
         const uint32_t pSP = swar_before<1>(SP[j - 1], SP[j]);
         const uint32_t same = (L[j] & pL) | (N[j] & pN) | (S[j] & pS) | (O[j] & pO);
         const uint32_t attaches = ~S[j] & (digits ? ~N[j] : ~0u);
-        uint32_t st = ~same & ~(pSP & attaches);
+        st[j] = ~same & ~(pSP & attaches);
         const uint32_t next_nonspace = swar_after<1>(NS[j], NS[j + 1]);
-        st |= same & ((S[j] & next_nonspace) | (digits ? N[j] : 0u));
-        const uint32_t f12_lo = f1[j - 1] | f2[j - 1], f12 = f1[j] | f2[j];
-        st |= swar_before<2>(f1[j - 1], f1[j]) | swar_before<3>(f2[j - 1], f2[j]);  // the byte after a contraction
-        st &= ~swar_before<1>(f12_lo, f12);                                           // its first letter stays with it
+        st[j] |= same & ((S[j] & next_nonspace) | (digits ? N[j] : 0u));
+    }
+    if (fired) {
+#pragma unroll
+        for (int j = 1; j <= LB; ++j) {
+            const uint32_t f12_lo = f1[j - 1] | f2[j - 1], f12 = f1[j] | f2[j];
+            st[j] |= swar_before<2>(f1[j - 1], f1[j]) | swar_before<3>(f2[j - 1], f2[j]);  // the byte after a contraction
+            st[j] &= ~swar_before<1>(f12_lo, f12);                                           // its first letter stays with it
+        }
+    }
+    flags = 0;
+#pragma unroll
+    for (int j = 1; j <= LB; ++j) {
         // bit 7 of the dword's four bytes -> four adjacent bits
-        const uint32_t t = (st & V[j]) >> 7;
+        const uint32_t t = (st[j] & V[j]) >> 7;
         flags |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * (j - 1));
     }
     return true;
