@@ -687,6 +687,77 @@ __device__ __forceinline__ bool gpt2_packed_starts(WaveScratch& ws, int skew, in
     return true;
 }
 
+// The class patterns (kSplitWhitespace / kSplitBertPunct / kSplitBertWords) on an ASCII window, packed bytes, LB dwords
+// per lane: same result as class_start_mask + the ranking loop of scan_string -- pstart entries of window bytes
+// [lo, hi) relative to lo, kPieceDropped on the pieces that are not emitted.  false (wave-uniform): not ASCII.
+template <int LB>
+__device__ __forceinline__ bool class_packed_starts(WaveScratch& ws, const SplitDev& sp, int skew, int wlen, int lo, int hi, int& np) {
+    constexpr int LBy = 4 * LB;
+    const int l = lane_id();
+    const int off = kTextPad + skew + LBy * l;
+    const int a = off >> 2, sh = (off & 3) * 8;
+    int nv = wlen - LBy * l;
+    nv = nv < 0 ? 0 : (nv > LBy ? LBy : nv);
+    uint32_t x[LB + 1], V[LB + 1], r[LB + 1];
+#pragma unroll
+    for (int j = 0; j <= LB; ++j) r[j] = ws.text_w[a + j];
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 1; j <= LB; ++j) {
+        const int have = nv - 4 * (j - 1);
+        const uint32_t m = have >= 4 ? ~0u : (have <= 0 ? 0u : ((1u << (8 * have)) - 1u));
+        x[j] = uint32_t(((static_cast<unsigned long long>(r[j]) << 32) | r[j - 1]) >> sh) & m;
+        V[j] = m & kB7;
+        any |= x[j];
+    }
+    if (__ballot((any & kB7) != 0)) return false;
+    uint32_t S[LB + 1], P[LB + 1];
+#pragma unroll
+    for (int j = 1; j <= LB; ++j) {
+        S[j] = (swar_eq(x[j], 0x20) | swar_range(x[j], 9, 13)) & V[j];
+        P[j] = (swar_range(x[j], 0x21, 0x2F) | swar_range(x[j], 0x3A, 0x40) | swar_range(x[j], 0x5B, 0x60) |
+                swar_range(x[j], 0x7B, 0x7E)) & V[j];   // bert_delimiter() below 0x80
+    }
+    S[0] = lane_prev(S[LB]);
+    P[0] = lane_prev(P[LB]);
+    uint32_t fl = 0, dr = 0;
+#pragma unroll
+    for (int j = 1; j <= LB; ++j) {
+        const uint32_t pS = swar_before<1>(S[j - 1], S[j]), pP = swar_before<1>(P[j - 1], P[j]);
+        uint32_t st, m;
+        if (sp.kind == kSplitWhitespace) {
+            m = S[j];
+            st = S[j] ^ pS;
+        } else if (sp.kind == kSplitBertPunct) {
+            m = P[j];
+            st = P[j] | pP;
+        } else {
+            m = S[j];
+            st = (S[j] ^ pS) | P[j] | pP;
+        }
+        const uint32_t d = sp.drop == 1 ? m : (sp.drop == 2 ? ~m : 0u);
+        const uint32_t t = (st & V[j]) >> 7, u = (d & V[j]) >> 7;
+        fl |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * (j - 1));
+        dr |= ((u | (u >> 7) | (u >> 14) | (u >> 21)) & 0xFu) << (4 * (j - 1));
+    }
+    int k_lo = lo - LBy * l, k_hi = hi - LBy * l;
+    k_lo = k_lo < 0 ? 0 : (k_lo > LBy ? LBy : k_lo);
+    k_hi = k_hi < 0 ? 0 : (k_hi > LBy ? LBy : k_hi);
+    fl &= ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
+    if (lo / LBy == l) fl |= 1u << (lo % LBy);
+    const int cnt = __popc(fl);
+    const int incl = wave_incl_sum(cnt);
+    int at = incl - cnt;
+    const int first = LBy * l - lo;
+    while (fl) {
+        const int bit = __ffs(fl) - 1;
+        ws.pstart[at++] = uint16_t((first + bit) | (((dr >> bit) & 1u) ? kPieceDropped : 0));
+        fl &= fl - 1;
+    }
+    np = wave_readlane(incl, kWave - 1);
+    return true;
+}
+
 // Scans string `str` (slen bytes) and hands complete pieces to the caller chunk by chunk.
 //   on_chunk(np, c0, w0, skew): pstart[0..np] (positions relative to c0, pstart[np] = end of the last piece)
 //                               describe np complete pieces; the LDS text covers them (string byte p at
@@ -772,6 +843,12 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
             continue;
         }
         if (sp.kind >= kSplitWhitespace) {
+            const int wl = w1 - w0;
+            if (wl <= 256 ? class_packed_starts<1>(ws, sp, skew, wl, lo, hi, np)
+                          : (wl <= 512 ? class_packed_starts<2>(ws, sp, skew, wl, lo, hi, np)
+                                       : class_packed_starts<kLaneDwords>(ws, sp, skew, wl, lo, hi, np))) {
+                // ASCII window: the packed-byte scanner filled pstart
+            } else {
             Mask start, dropped;
             class_start_mask(ws, sp, skew, w1 - w0, start, dropped);
             for (int w = lo >> 6; w * 64 < hi; ++w) {
@@ -782,6 +859,7 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                 if ((m >> l) & 1ull)
                     ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t((w * 64 + l - lo) | (((d >> l) & 1ull) ? kPieceDropped : 0));
                 np += __popcll(m);
+            }
             }
         } else if (w1 - w0 <= 64 * 4 * (kLaneDwords - 1) ? gpt2_packed_starts<kLaneDwords - 1>(ws, skew, w1 - w0, digits, lo, hi, np)
                                                           : gpt2_packed_starts<kLaneDwords>(ws, skew, w1 - w0, digits, lo, hi, np)) {

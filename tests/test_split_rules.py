@@ -104,6 +104,24 @@ def test_bert_patterns(backend, pattern, behaviour, invert):
     check(backend, pattern, strings, behaviour, invert)
 
 
+@pytest.mark.parametrize("pattern,behaviour,invert", [(BERT_WS, "remove", False), (BERT_WS, "isolate", False),
+                                                      (BERT_PUNCT, "isolate", False), (BERT_PUNCT, "remove", True)])
+def test_bert_patterns_ascii_windows(backend, pattern, behaviour, invert):
+    """ASCII-only strings take the packed-byte scanner of the class patterns (class_packed_starts: 4, 8 or 12 bytes per
+    lane by window length): every byte 1..127 in context, and lengths around the 256 / 512 / 768-byte steps."""
+    rng = np.random.default_rng(29)
+    strings = []
+    for c in range(1, 128):
+        ch = chr(c)
+        strings += [ch, "a" + ch + "a", " " + ch + " ", ch + ch, "x " + ch, ch + " x"]
+    ascii_alphabet = ["a", "b", "1", " ", " ", "\t", "\n", "!", "/", ":", "@", "[", "`", "{", "~", "_", "$", "-", "'"]
+    lengths = [3, 60, 250, 255, 256, 257, 300, 500, 511, 512, 513, 600, 760, 767, 768, 769, 800, 1500, 2100]
+    for n in lengths[: 9 if backend.name == "emu" else None] + lengths[-4:]:
+        strings += ["".join(rng.choice(ascii_alphabet, size=n)) for _ in range(2)]
+    strings += ["ab " * 90, "!" * 300, " " * 255 + "x", "a" * 256 + "!", "word, " * 100]
+    check(backend, pattern, strings, behaviour, invert)
+
+
 def test_bert_patterns_max_splits(backend):
     strings = ["one two  three four", "a,b,c,d", "x", "  lead and trail  ", ",,,"]
     for ms in (1, 2, 5):
