@@ -1,0 +1,45 @@
+"""bench.py end to end on the GPU box: one JSON line with the fields the driver reads, for the plain run and for the
+exchange loop (one-rank RCCL group), at a small row count so that both finish in seconds."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(*flags):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "6", "--warmup", "2", "--rows", "4096", *flags],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_json_line():
+    d = _run()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["higher_is_better"] is True and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert r["alone"]["kernel_ms"] > 0 and r["step"]["frac"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert d["parity_prefix_bit_exact"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["2", "3"])
+def test_bench_exchange_loop(config):
+    d = _run("--force-exchange", "--no-cpu-baseline", "--config", config)
+    assert d["value"] > 0 and "all-gather" in d["config"]["exchange"]
+    assert "shard_pack" in d["kernel_ms"] and "shard_unpack" in d["kernel_ms"]
