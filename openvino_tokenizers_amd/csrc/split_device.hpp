@@ -19,11 +19,11 @@
 //   * digits variant (:448-452, `\p{N}` single, no optional space): every N char is its own piece
 //     and a preceding space does not attach to it.
 //
-// Evaluation is bit-parallel.  One wave scans one string: the window (<= 512 bytes incl. halos) is
+// Evaluation is bit-parallel.  One wave scans one string: the window (<= 768 bytes incl. halos) is
 // staged in LDS with coalesced dword loads, then
-//   * ASCII windows (the common case) take the packed-byte path: lane l owns window bytes [8l, 8l+8),
-//     loads the 16 bytes around them and evaluates classes and rules on all of them at once with
-//     SWAR arithmetic (one flag per byte in bit 7) -- ~300 vector instructions per 512-byte window;
+//   * ASCII windows (the common case) take the packed-byte path: lane l owns 8 or 12 window bytes (windows up to
+//     512 / 768 bytes), loads the dwords that hold them and evaluates classes and rules on all of them at once with
+//     SWAR arithmetic (one flag per byte in bit 7) -- ~250 vector instructions per 768-byte window;
 //   * any other window takes the ballot path: for each 64-byte word every lane classifies ONE byte
 //     (non-ASCII code points through the two-level Unicode property table generated from PCRE2
 //     itself), the per-byte predicates become 64-bit masks by wave ballot, lane w owns the masks of
@@ -533,7 +533,7 @@ __device__ __forceinline__ void class_start_mask(const WaveScratch& ws, const Sp
     dropped = (sp.drop == 1 ? m : (sp.drop == 2 ? ~m : 0ull)) & cs;
 }
 
-// ---- packed-byte (SWAR) path: ASCII windows of at most 512 bytes --------------------------------
+// ---- packed-byte (SWAR) path: ASCII windows (at most kChunk bytes) -------------------------------
 // All values are 4 packed bytes with one flag per byte in bit 7.  Inputs must be < 0x80 per byte (no carries).
 constexpr uint32_t kB7 = 0x80808080u;
 __device__ __forceinline__ uint32_t swar_eq(uint32_t x, uint32_t c) {  // x == c, per byte

@@ -3,7 +3,7 @@
 The scanners replace regex matching by a local piece-start predicate (csrc/split_device.hpp); this file is the
 evidence that the predicate is equivalent: every string up to 4 symbols over an alphabet with one representative
 per behaviour class (letters incl. the contraction letters, digit, ASCII space, tab, newline, NBSP, apostrophe,
-punctuation, 2/3/4-byte letters/symbols), plus random long strings that cross the 512-byte LDS chunk boundary.
+punctuation, 2/3/4-byte letters/symbols), plus random long strings that cross the 768-byte LDS chunk boundary.
 """
 import itertools
 
@@ -63,9 +63,10 @@ def test_random_strings(backend, pattern):
 
 
 def test_chunk_boundaries(backend):
-    """Pieces and special sequences placed right at the 512-byte chunk seams, long single-class runs."""
+    """Pieces and special sequences placed right at the chunk seams (the scan window is 768 bytes; 512 is where the
+    packed-byte scanner goes from 8 to 12 bytes per lane), long single-class runs."""
     strings = []
-    for k in range(500, 530):
+    for k in list(range(500, 530, 3)) + list(range(742, 772)):
         strings += ["a" * k + "'s b", "x" * k + "  y", " " * k + "z", "a" * k + " 'll", "é" * (k // 2) + "'t元",
                     "1" * k + "a" * 600, ("ab " * 200)[:k] + "\t\t" + "c" * 20, "a" * k + "\n\n" + "b" * k + " "]
     check(backend, GPT2_PATTERN, strings)
