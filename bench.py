@@ -251,17 +251,47 @@ def make_detokenize(args, lib, dev, rank):
     lens = (vconst[1] - vconst[0]).astype(np.int64)
     n_out = int(lens[ids[ids != pad]].sum())
     cap = n_out + 64
-    o_begins = torch.empty(rows, dtype=torch.int32, device=dev)
-    o_ends = torch.empty(rows, dtype=torch.int32, device=dev)
-    o_chars = torch.empty(cap, dtype=torch.uint8, device=dev)
-    out = L.StringsOut(o_begins.data_ptr(), o_ends.data_ptr(), o_chars.data_ptr(), cap, 0)
+    class CharsOut:
+        """Four output sets used in turn (up to three calls are in flight with --depth 2)."""
+        def __init__(self):
+            self.sets = []
+            for _ in range(4):
+                b = torch.empty(rows, dtype=torch.int32, device=dev)
+                e = torch.empty(rows, dtype=torch.int32, device=dev)
+                c = torch.empty(cap, dtype=torch.uint8, device=dev)
+                self.sets.append((b, e, c, L.StringsOut(b.data_ptr(), e.data_ptr(), c.data_ptr(), cap, 0)))
+            self.k = 0
+            self.last = self.sets[0]
+
+        def take(self):
+            self.last = self.sets[self.k % 4]
+            self.k += 1
+            return self.last
+
+        @property
+        def n_chars(self):
+            return self.last[3].n_chars
+
+    out = CharsOut()
     stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     pids = C.c_void_p(d_ids.data_ptr())
 
     def step():
-        L.check(lib, lib.ovtk_detokenize_run(dec._h, pids, C.c_int64(rows), C.c_int64(S), None, C.c_int64(0), 1, C.byref(out),
+        o_begins, o_ends, o_chars, o = out.take()
+        L.check(lib, lib.ovtk_detokenize_run(dec._h, pids, C.c_int64(rows), C.c_int64(S), None, C.c_int64(0), 1, C.byref(o),
                                              L.MEM_DEVICE, stream))
-        return o_begins, o_ends, o_chars[: out.n_chars]
+        return o_begins, o_ends, o_chars[: o.n_chars]
+
+    def enqueue(st=stream):
+        o_begins, o_ends, o_chars, o = out.take()
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_detokenize_enqueue(dec._h, pids, C.c_int64(rows), C.c_int64(S), None, C.c_int64(0), 1, C.byref(o), st,
+                                                 C.byref(pending)))
+
+        def finish():
+            L.check(lib, lib.ovtk_detokenize_finish(pending, C.byref(o)))
+            return o_begins, o_ends, o_chars[: o.n_chars]
+        return finish
 
     def cpu(n_s):
         from oracle import oracle as O
@@ -277,7 +307,7 @@ def make_detokenize(args, lib, dev, rank):
 
     workload = (f"config 5 chunk: detokenize {rows} x {S} ids (GPT-2-shaped vocabulary, 1 % skipped special ids) per GPU, "
                 f"fused VocabDecoder+ByteFallback+FuzeRagged, inputs and outputs in HBM ({n_out} output bytes < 2^31)")
-    return dict(step=step, cpu=cpu, n_units=rows * S, out=out, keep=(d_ids, dec, o_begins, o_ends, o_chars), workload=workload,
+    return dict(step=step, enqueue=enqueue, cpu=cpu, n_units=rows * S, out=out, keep=(d_ids, dec), workload=workload,
                 metric="token ids/s detokenized (seq 2048)", dtype="int32/u8", unit="Mtok/s", rows=rows,
                 algo=lambda _n: 4 * rows * S + n_out + 8 * rows, sample_rows=min(rows, 1024), is_detok=True, n_out=n_out)
 
@@ -478,7 +508,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
         "config": {"workload": wl["workload"],
                    "row_tickets": row_tickets,
-                   "host_loop": (f"launch batch k, then complete batch k-1 (two-half calls), batches alternate between {len(stream_ptrs)} "
+                   "host_loop": (f"launch batch k, then complete batch k-{args.depth} (two-half calls), batches alternate between {len(stream_ptrs)} "
                                  f"HIP stream(s)" if "enqueue" in wl and not args.sync else "one blocking call per batch"),
                    "rows_per_gpu": wl.get("rows", args.rows), "units_per_gpu": n_units, "outputs_per_gpu": n_out,
                    "exchange": ("none (1 GPU)" if exchange is None and world == 1 else ("none (rank-local consumer)" if exchange is None else

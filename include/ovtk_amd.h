@@ -383,6 +383,12 @@ int ovtk_encode_tail_run(const ovtk_encode_tail_params* p, int32_t* out_ids, uin
 int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len,
                         const int32_t* skip_tokens_input, int64_t n_skip_tokens_input, int byte_fallback,
                         ovtk_strings_out* out, int mem, void* stream);
+/* ovtk_detokenize_run in two halves for device buffers (OVTK_MEM_DEVICE), like ovtk_encode_enqueue / ovtk_encode_finish:
+ * enqueue launches the passes on `stream` and returns; finish waits for that call (its own event), fills out->n_chars or
+ * reports OVTK_E_CAPACITY, and releases `pending` whatever happens.  Calls in flight are independent. */
+int ovtk_detokenize_enqueue(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len, const int32_t* skip_in,
+                            int64_t n_skip_in, int byte_fallback, ovtk_strings_out* out, void* stream, ovtk_pending** pending);
+int ovtk_detokenize_finish(ovtk_pending* pending, ovtk_strings_out* out);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * With profiling on, every kernel launch of the library is bracketed by hipEvents on the stream it is

@@ -98,7 +98,7 @@ EXPORTS = [
     "ovtk_vocab_encoder_create", "ovtk_vocab_encoder_run", "ovtk_vocab_encoder_destroy",
     "ovtk_ragged_to_dense",
     "ovtk_vocab_decoder_create", "ovtk_vocab_decoder_run", "ovtk_vocab_decoder_destroy",
-    "ovtk_byte_fallback", "ovtk_fuze_ragged", "ovtk_detokenize_run",
+    "ovtk_byte_fallback", "ovtk_fuze_ragged", "ovtk_detokenize_run", "ovtk_detokenize_enqueue", "ovtk_detokenize_finish",
     "ovtk_utf8_validate", "ovtk_truncate", "ovtk_combine_segments", "ovtk_encode_tail_run",
     "ovtk_trie_tokenizer_create", "ovtk_trie_tokenizer_run", "ovtk_trie_tokenizer_destroy",
     "ovtk_string_tensor_packed_bytes", "ovtk_string_tensor_unpack", "ovtk_string_tensor_pack",

@@ -160,11 +160,18 @@ struct PendingRun {
     virtual ~PendingRun() = default;
     virtual int finish(ovtk_ragged_i32_out* out) = 0;
 };
+struct PendingStrings {  // a call in flight whose result is a strings tensor (ovtk_detokenize_enqueue)
+    virtual ~PendingStrings() = default;
+    virtual int finish(ovtk_strings_out* out) = 0;
+};
 }  // namespace ovtk
-// A call in flight (ovtk_encode_enqueue / ovtk_wordpiece_encode_enqueue -> ovtk_encode_finish).
+// A call in flight (ovtk_encode_enqueue / ovtk_wordpiece_encode_enqueue -> ovtk_encode_finish;
+// ovtk_detokenize_enqueue -> ovtk_detokenize_finish).
 struct ovtk_pending {
     std::unique_ptr<ovtk::PendingRun> run;  // empty: nothing was launched, `out` was complete at enqueue
     ovtk_ragged_i32_out out{};
+    std::unique_ptr<ovtk::PendingStrings> strings;
+    ovtk_strings_out strings_out{};
 };
 namespace ovtk {
 

@@ -575,6 +575,67 @@ int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch
     return OVTK_OK;
 }
 
+// The same call in two halves for device buffers: enqueue launches the three passes and a copy of the status block,
+// finish waits for that call's own event and reports.  Every call in flight leases its own workspace.
+namespace {
+struct DetokRun final : ovtk::PendingStrings {
+    explicit DetokRun(int device) : ws(device) {}
+    WorkspaceLease ws;
+    int finish(ovtk_strings_out* out) override {
+        OVTK_HIP(hipEventSynchronize(ws->done));
+        Profiler::get().resolve(ws->marks);
+        OVTK_HIP(hipGetLastError());
+        if (ws->host_status->flags & kFlagOutCapacity)
+            return set_error(OVTK_E_CAPACITY, "detokenize: output chars buffer too small or beyond int32 offsets (" +
+                                                  std::to_string(ws->host_status->n_out) + " bytes needed)");
+        out->n_chars = ws->host_status->n_out;
+        return OVTK_OK;
+    }
+};
+}  // namespace
+
+int ovtk_detokenize_enqueue(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len, const int32_t* skip_in,
+                            int64_t n_skip_in, int byte_fallback, ovtk_strings_out* out, void* stream, ovtk_pending** pending) {
+    if (!pending) return set_error(OVTK_E_ARG, "null argument");
+    *pending = nullptr;
+    if (int rc = check_decoder_args(h, ids, batch, seq_len, skip_in, n_skip_in, out)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(h->device));
+    auto p = std::make_unique<ovtk_pending>();
+    p->strings_out = *out;
+    p->strings_out.n_chars = 0;
+    if (batch > 0) {
+        auto run = std::make_unique<DetokRun>(h->device);
+        Workspace& ws = *run->ws.ws;
+        if (!ws.done) OVTK_HIP(hipEventCreateWithFlags(&ws.done, hipEventDisableTiming));
+        RunStatus* st = nullptr;
+        if (int rc = begin_status(ws, s, &st)) return rc;
+        if (seq_len == 0) {
+            OVTK_HIP(hipMemsetAsync(out->begins, 0, size_t(batch) * 4, s));
+            OVTK_HIP(hipMemsetAsync(out->ends, 0, size_t(batch) * 4, s));
+        } else {
+            DecodeDev d;
+            if (int rc = decoder_inputs(h, ws, ids, batch * seq_len, skip_in, n_skip_in, OVTK_MEM_DEVICE, s, byte_fallback != 0, d)) return rc;
+            if (int rc = decode_passes(ws, s, h->device, d, batch, seq_len, nullptr, nullptr, out->begins, out->ends, out->chars,
+                                       (long long)std::min<int64_t>(out->chars_capacity, INT32_MAX - 1), st, "detokenize"))
+                return rc;
+        }
+        OVTK_HIP(hipMemcpyAsync(ws.host_status, ws.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipEventRecord(ws.done, s));
+        p->strings = std::move(run);
+    }
+    *pending = p.release();
+    return OVTK_OK;
+}
+
+int ovtk_detokenize_finish(ovtk_pending* pending, ovtk_strings_out* out) {
+    if (!pending) return set_error(OVTK_E_ARG, "null argument");
+    std::unique_ptr<ovtk_pending> p(pending);  // released whatever happens
+    const int rc = p->strings ? p->strings->finish(&p->strings_out) : OVTK_OK;
+    if (out) *out = p->strings_out;
+    return rc;
+}
+
 // ------------------------------------------------------------------------------- ByteFallback
 int ovtk_byte_fallback(const ovtk_strings* in, ovtk_strings_out* out, int mem, int device, void* stream) {
     if (int rc = check_strings_arg(in, "byte_fallback input")) return rc;

@@ -766,6 +766,26 @@ class FusedDetokenizer:
                                           int(self.byte_fallback), C.byref(out), m.mem, m.stream))
         return [ob[:B], oe[:B], oc[:out.n_chars]]
 
+    def enqueue(self, inputs, chars_capacity=None):
+        """evaluate() in two halves for CUDA tensors (ovtk_detokenize_enqueue / ovtk_detokenize_finish): launches the
+        passes and returns a ticket; `ticket()` waits for them and returns evaluate()'s outputs."""
+        d = self.decoder
+        m, pids, B, S, pskip, nskip, cap = d._prep(inputs, chars_capacity)
+        if not m.torch:
+            raise L.OvtkError(L.E_ARG, "enqueue() needs device-resident (torch CUDA) inputs")
+        ob, pob = m.alloc(B, "i32")
+        oe, poe = m.alloc(B, "i32")
+        oc, poc = m.alloc(cap, "u8")
+        out = L.StringsOut(pob, poe, poc, cap, 0)
+        pending = C.c_void_p()
+        d._chk(d._lib.ovtk_detokenize_enqueue(d._h, pids, C.c_int64(B), C.c_int64(S), pskip, C.c_int64(nskip),
+                                              int(self.byte_fallback), C.byref(out), m.stream, C.byref(pending)))
+
+        def ticket(_keep=(m, inputs)):
+            d._chk(d._lib.ovtk_detokenize_finish(pending, C.byref(out)))
+            return [ob[:B], oe[:B], oc[:out.n_chars]]
+        return ticket
+
 
 class FusedSplitWordpiece:
     """RegexSplit(\\s+, remove) -> RegexSplit(BERT delimiters, isolate) -> WordpieceTokenizer in one pass

@@ -255,6 +255,41 @@ def test_vocab_decoder_chain(backend, B, S):
         assert_same(list(ref_plain) + [ref[4]], fused2, backend.host, "fused detokenizer")
 
 
+def test_detokenize_enqueue_finish(gpu_backend):
+    """ovtk_detokenize_enqueue / ovtk_detokenize_finish: several calls in flight on two streams (per-call skip lists
+    build their own tables in the call's workspace), each equals the oracle chain; a chars buffer that is too small
+    is reported by finish()."""
+    import torch
+    backend = gpu_backend
+    vocab, n_base = detok_vocab()
+    V = len(vocab)
+    vconst = list(pack_strings(vocab))
+    dec = VocabDecoder(skip_tokens=[3, 17], lib=backend.lib)
+    fused = FusedDetokenizer(dec, byte_fallback=True)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    cases, tickets = [], []
+    for k, (B, S, skip_in) in enumerate([(64, 300, None), (5, 0, None), (300, 2050, np.asarray([1, 2, n_base], np.int32)), (1, 1, None),
+                                         (2000, 64, np.zeros(0, np.int32))]):
+        ids = np.random.default_rng(70 + k).integers(-2, V + 2, (B, S)).astype(np.int32)
+        eff = [3, 17] if skip_in is None else skip_in.tolist()
+        r = O.vocab_decoder(ids, vocab, eff)
+        bf = O.byte_fallback(*r[2:5])
+        cases.append(list(O.fuze(r[0], r[1], bf[0], bf[1])) + [bf[2]])
+        inputs = backend.data([ids]) + vconst + ([skip_in] if skip_in is not None else [])
+        torch.cuda.synchronize()
+        with torch.cuda.stream(streams[k % 2]):
+            tickets.append(fused.enqueue(inputs))
+    for ref, ticket in zip(cases, tickets):
+        assert_same(ref, ticket(), backend.host, "detokenize enqueue/finish")
+    ids = np.random.default_rng(5).integers(0, n_base, (8, 100)).astype(np.int32)
+    ticket = fused.enqueue(backend.data([ids]) + vconst, chars_capacity=10)
+    with pytest.raises(L.OvtkError) as ei:
+        ticket()
+    assert ei.value.code == L.E_CAPACITY
+    with pytest.raises(L.OvtkError):   # host arrays have no asynchronous form
+        fused.enqueue([ids] + vconst)
+
+
 def test_byte_fallback_layouts(backend):
     """Strings with gaps / reversed order, every byte value, lower-case hex (-> 0xFF quirk), 6-byte look-alikes."""
     toks = [b"<0x%02X>" % v for v in range(256)] + [b"<0x%02x>" % v for v in (10, 171, 255)] + \
