@@ -51,6 +51,11 @@ def main(prefix):
             d = pd.read_csv(st)
             d = d[d["Name"].str.contains("ovtk")]
             d.to_csv(out_dir / f"{stem}_config{cfg}_kernel_stats.csv", index=False)
+        st1 = newest(str(ROOT / f"gpurun_out/prof1_c{cfg}/*/*kernel_stats.csv"))  # the one-stream pass (bench.py --streams 1)
+        if st1:
+            d = pd.read_csv(st1)
+            d = d[d["Name"].str.contains("ovtk")]
+            d.to_csv(out_dir / f"{stem}_config{cfg}_one_stream_kernel_stats.csv", index=False)
         rows = []
         for ctr in ("fetch", "write"):
             f = newest(str(ROOT / f"gpurun_out/pmc_{ctr}_c{cfg}/*/*counter_collection.csv"))
