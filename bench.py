@@ -363,7 +363,9 @@ def main():
     exchange = None
     if (world > 1 or args.force_exchange) and not args.no_gather and not is_detok:
         xstream = torch.cuda.Stream(dev) if args.exchange_stream else None
-        exchange = ShardExchange(wl.get("rows", args.rows) * world, wl["vocab"], dev, lib=lib, stream=xstream)
+        # equal shards of the same text model: the ranks' id counts differ by well under 0.1 %, so 3 % of padding on the
+        # wire (instead of the class's default 12.5 %) never triggers a re-gather and the gather moves 8 % fewer bytes
+        exchange = ShardExchange(wl.get("rows", args.rows) * world, wl["vocab"], dev, lib=lib, stream=xstream, headroom=1.03)
 
     # A step = one batch through the hot path.  Where the op has the two-half form the host launches batch k, then
     # completes batch k-1 (status check, and with N > 1 its exchange) while the GPU works on k: the reference's
