@@ -29,7 +29,8 @@ namespace ovtk {
 constexpr uint64_t kNoKey = ~0ull;
 constexpr int kSeqBits = 10;
 constexpr int kIdBits = kMaxVocabBits;                   // 21
-constexpr int kFastSyms = 16;                            // pieces with more symbols than this use path W
+constexpr int kFastSyms = 16;                            // pieces with more symbols than this use path L or W
+constexpr int kLongSyms = 32;                            // path L: lane per piece again, 32 pieces of <= 32 symbols at a time
 constexpr int kChunkSyms = 512;                          // path W limit (symbols incl. end_suffix)
 constexpr uint32_t kIdMask = (1u << kIdBits) - 1;
 
@@ -123,13 +124,16 @@ __device__ __forceinline__ void split_pair_key(uint64_t k64, uint32_t& key, uint
 }
 // IdT: uint32_t, or uint16_t when every id of the vocabulary is below 65536 (8 instead of 12 bytes of LDS per symbol:
 // merge_kernel is occupancy-bound by its LDS).
-template <typename IdT>
+// NSYM x LANES: the arrays' geometry -- kFastSyms x 64 for the pieces of a batch, 32 x 32 for its long pieces (17..32
+// symbols, half a wave at a time: the same LDS bytes).  Only lanes < LANES may call it; no wave collectives inside.
+template <typename IdT, int NSYM = kFastSyms, int LANES = kWave>
 __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t* key, IdT* nid, int n) {
+    static_assert(NSYM <= 32, "the live mask is 32 bits");
     const int l = lane_id();
-#define OVTK_AT(k) ((k) * kWave + l)
+#define OVTK_AT(k) ((k) * LANES + l)
     // initial pair keys: the lookups of a group of 4 are issued together
 #pragma unroll
-    for (int k0 = 0; k0 < kFastSyms; k0 += 4) {
+    for (int k0 = 0; k0 < NSYM; k0 += 4) {
         uint64_t mk[4] = {0, 0, 0, 0};
         MergeFetch f[4] = {};
         if (k0 + 1 < n) {
@@ -144,7 +148,7 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = k0 + j;
-            if (k < kFastSyms - 1) {
+            if (k < NSYM - 1) {
                 uint32_t kk = kNoKey32, nn = 0;
                 if (k + 1 < n) split_pair_key(merge_resolve(f[j], mk[j], uint32_t(k)), kk, nn);
                 key[OVTK_AT(k)] = kk;
@@ -156,13 +160,13 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t
     uint32_t seq = n > 0 ? uint32_t(n - 1) : 0;
     bool dup = false;
     while (n >= 2) {
-        uint32_t v[kFastSyms - 1];
+        uint32_t v[NSYM - 1];
 #pragma unroll
-        for (int k = 0; k < kFastSyms - 1; ++k) v[k] = key[OVTK_AT(k)];
+        for (int k = 0; k < NSYM - 1; ++k) v[k] = key[OVTK_AT(k)];
         uint32_t best = kNoKey32;
         int at = 0;
 #pragma unroll
-        for (int k = 0; k < kFastSyms - 1; ++k) {
+        for (int k = 0; k < NSYM - 1; ++k) {
             if (v[k] < best) { best = v[k]; at = k; dup = false; }
             else if (v[k] == best && best != kNoKey32) dup = true;
         }
@@ -192,7 +196,7 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t
         if (nxt >= 0) split_pair_key(merge_resolve(fr, kr, seq), kk, nn);
         key[OVTK_AT(at)] = kk;
         nid[OVTK_AT(at)] = IdT(nn);
-        if (right < kFastSyms - 1) key[OVTK_AT(right)] = kNoKey32;
+        if (right < NSYM - 1) key[OVTK_AT(right)] = kNoKey32;
     }
     if (dup) return -1;
     // compact the surviving symbols to the front (ascending positions: reads never trail writes)

@@ -541,7 +541,9 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
     constexpr int kWaveLdsBytes = kFastSyms * kWave * (4 + 2 * int(sizeof(IdT)));
     static_assert(kWaveLdsBytes >= kChunkSyms * 12, "path W's key u64[] + id u32[] must fit the wave's LDS");
     __shared__ uint64_t lds_all[kWavesPerBlock][kWaveLdsBytes / 8];
+    static_assert(kLongSyms * (kWave / 2) == kFastSyms * kWave, "path L reuses path F's LDS arrays: 32 lanes x 32 symbols");
     __shared__ I2 root_lds[256];
+    __shared__ uint8_t long_src_all[kWavesPerBlock][kWave / 2];  // path L: source lane of the piece lane t works on
     __shared__ int pushed_exact;  // this block stored exact-list entries (plain stores the tail block must see)
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
     if (threadIdx.x == 0) pushed_exact = 0;
@@ -579,8 +581,9 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
         if (valid) e = list[base + l];
         const int need = e.len + SL;
         const bool is_f = valid && e.len >= 1 && e.len <= kPieceKeyBytes && need <= kFastSyms;
-        const bool is_w = valid && !is_f && need <= kChunkSyms;
-        bool is_x = valid && !is_f && !is_w;
+        const bool is_l = valid && !is_f && e.len >= 1 && need <= kLongSyms;
+        const bool is_w = valid && !is_f && !is_l && need <= kChunkSyms;
+        bool is_x = valid && !is_f && !is_l && !is_w;
         int32_t* out = w.stage + e.stage_pos;
         int f_cnt = 0;
         wave_sync();  // the previous batch is done with the LDS arrays
@@ -615,6 +618,45 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
                 atomicAdd(&w.row_cnt[e.row], incl - seg_base);
                 if (w.tile_cnt) atomicAdd(&w.tile_cnt[e.row / kRowTile], incl - seg_base);
             }
+        }
+        // Path L: the batch's pieces of 17..32 symbols, lane per piece again -- 32 of them at a time: 32 lanes x 32
+        // symbols are the bytes of path F's 64 x 16 arrays.  (On path W each of them took the whole wave for about one
+        // global round trip per merge: with mixed scripts a fifth of the deferred pieces, and 70 % of the kernel.)
+        unsigned long long lm = __ballot(is_l);
+        while (lm) {
+            uint8_t* long_src = long_src_all[wave_in_block()];
+            const int rank = __popcll(lm & lanemask_lt());
+            const int cnt = __popcll(lm) < kWave / 2 ? __popcll(lm) : kWave / 2;
+            wave_sync();  // the previous user of the LDS arrays (path F / the previous group) is done
+            if (((lm >> l) & 1ull) && rank < kWave / 2) long_src[rank] = uint8_t(l);
+            wave_sync();
+            const int src = l < cnt ? int(long_src[l]) : 0;
+            const int s_begin = __shfl(e.begin, src), s_len = __shfl(e.len, src), s_pos = __shfl(e.stage_pos, src);
+            const int s_row = __shfl(e.row, src);
+            int res = 0;
+            if (l < cnt) {
+                const uint8_t* text = in.chars + s_begin;
+                const int s_need = s_len + SL;
+                const int n = bpe_symbolize(
+                    T, root_lds, [&](int i) -> uint32_t { return i < s_len ? text[i] : T.suffix[i - s_len]; }, s_need,
+                    [&](int k, int tok) { fid[k * (kWave / 2) + l] = IdT(tok); });
+                res = bpe_merge_lane<IdT, kLongSyms, kWave / 2>(T, fid, fkey, fnid, n);
+                if (res >= 0) {
+                    int32_t* o = w.stage + s_pos;
+                    for (int k = 0; k < res; ++k) o[k] = int32_t(fid[k * (kWave / 2) + l]);
+                    for (int k = res; k < s_need; ++k) o[k] = kEmptyId;
+                    if (res) {
+                        atomicAdd(&w.row_cnt[s_row], res);
+                        if (w.tile_cnt) atomicAdd(&w.tile_cnt[s_row / kRowTile], res);
+                    }
+                }
+            }
+            // a non-unique minimum goes to the exact path: tell the piece's own lane
+            const unsigned long long failed = __ballot(l < cnt && res < 0);
+            if (((lm >> l) & 1ull) && rank < kWave / 2 && ((failed >> rank) & 1ull)) is_x = true;
+            // drop the pieces of this group from the mask
+            const unsigned long long done = __ballot(((lm >> l) & 1ull) && rank < kWave / 2);
+            lm &= ~done;
         }
         unsigned long long wm = __ballot(is_w);
         while (wm) {
