@@ -215,6 +215,26 @@ def pieces_inputs(rows):
     return [(re_ - counts).astype(np.int32), re_, b, e, c]
 
 
+def test_piece_lengths_around_path_limits(backend):
+    """merge_kernel's paths by symbol count: F (<= 16, lane per piece), L (17..32, lane per piece, 32 at a time), W (a wave
+    per piece).  Random letter strings miss the memo; whole batches of one length, and batches that mix them so that a
+    64-piece batch holds more than 32 path-L pieces (two groups) next to F and W pieces."""
+    tok = BpeTok.load("gpt2_small")
+    rng = np.random.default_rng(77)
+    letters = list(b"abcdefghijklmnopqrstuvwxyz")
+    per = 40 if backend.name == "emu" else 300
+    def word(n):
+        return bytes(rng.choice(letters, size=n).tolist())
+    rows = [[word(n) for _ in range(per)] for n in (15, 16, 17, 18, 24, 31, 32, 33, 40)]
+    rows.append([word(int(rng.integers(1, 45))) for _ in range(per * 6)])
+    rows.append([word(int(rng.integers(17, 33))) for _ in range(200)])
+    rows.append([b" " + word(31), b" " + word(32), "é".encode() * 8 + word(15), "元".encode() * 10, "元".encode() * 11])
+    inputs = pieces_inputs(rows)
+    ref = tok.oracle()(*inputs)
+    got = BPETokenizer(**tok.attrs, lib=backend.lib).evaluate(backend.data(inputs) + tok.consts)
+    assert_same(ref, got, backend.host, "path limits")
+
+
 def test_heap_tie_vocabulary(backend):
     """(rank, seq) ties in the merge queue: the two pairs pushed by ONE merge tie when the new
     symbol and both neighbours carry the same id.  Reachable when an added token's id collides with a merge
