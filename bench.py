@@ -179,7 +179,7 @@ def make_encode_llama3(args, lib, dev, rank):
                 f"~{args.bytes}-byte mixed-script strings per GPU, fused RegexSplit (tiktoken-style pattern) + BPETokenizer, "
                 f"inputs and outputs in HBM")
     return dict(step=step, enqueue=enqueue, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe), vocab=len(tok.vocab),
-                dominant="bpe_merge",
+                dominant="lookup_fused",
                 workload=workload, metric="input MB/s encoded (Llama-3 BPE, 512-byte mixed-script strings)", dtype="u8/int32",
                 rows=rows, algo=lambda n_tok: n_chars + 4 * n_tok + 16 * rows, sample_rows=min(rows, 16384))
 
