@@ -103,6 +103,63 @@ def test_shard_exchange_gloo(emu_lib, world, n_rows, vocab):
         assert regathers >= 1 or n_rows == 1   # the growing batches must have forced a larger pad at least once
 
 
+@pytest.mark.parametrize("world, n_rows, vocab", [(2, 1000, 50000), (3, 4099, 130000), (8, 70000, 50000)])
+def test_shard_unpack_of_several_ranks(backend, world, n_rows, vocab):
+    """The kernels of the world > 1 path on ONE device (GPU box: one MI355X; here: the emulator): every rank's shard is
+    packed into its wire, the wires are laid side by side as an all-gather would leave them, one unpack rebuilds the
+    global ragged tensor.  Also a pad that is too small for the largest shard: OVTK_E_CAPACITY and max_shard."""
+    import ctypes as C
+    from openvino_tokenizers_amd import _lib as L
+    lib = backend.lib
+    if backend.name == "emu":
+        n_rows = min(n_rows, 300)
+    if backend.name == "hip-host":
+        pytest.skip("the exchange hands over device (or emulator-host) buffers only")
+    rng = np.random.default_rng(world * 100 + n_rows)
+    lens = rng.integers(0, 40, size=n_rows).astype(np.int64)
+    ids = rng.integers(0, vocab, size=int(lens.sum())).astype(np.int64)
+    id_bytes = 2 if vocab <= 65536 else 4
+    dev = backend.name != "emu"
+    mem = L.MEM_DEVICE if dev else L.MEM_HOST
+    h = C.c_void_p()
+    L.check(lib, lib.ovtk_shard_exchange_create(world, C.c_int64(n_rows), id_bytes, 0, C.byref(h)))
+    try:
+        shards = [_local_shard(lens, ids, r, world, device="cuda" if dev else "cpu") for r in range(world)]
+        biggest = max(int(s[2].numel()) for s in shards)
+
+        def alloc(n, dtype):
+            return torch.empty(max(n, 1), dtype=dtype, device="cuda" if dev else "cpu")
+
+        def ptr(t):
+            return C.c_void_p(t.data_ptr())
+
+        def exchange(pad):
+            wire = int(lib.ovtk_shard_wire_bytes(h, C.c_int64(pad)))
+            recv = alloc(wire * world, torch.uint8)
+            for r, (b, e, d) in enumerate(shards):
+                send = recv[r * wire:(r + 1) * wire]
+                L.check(lib, lib.ovtk_shard_pack(h, ptr(b), ptr(e), ptr(d), C.c_int64(b.numel()), C.c_int64(d.numel()), C.c_int64(pad),
+                                                 ptr(send), mem, None))
+            cap = pad * world
+            ob, oe, oi = alloc(n_rows, torch.int32), alloc(n_rows, torch.int32), alloc(cap, torch.int32)
+            res = alloc(4, torch.int64)
+            rc = lib.ovtk_shard_unpack(h, ptr(recv), C.c_int64(pad), ptr(ob), ptr(oe), ptr(oi), C.c_int64(cap), ptr(res), mem, None)
+            if dev:
+                torch.cuda.synchronize()
+            return rc, res.cpu().numpy(), ob.cpu().numpy(), oe.cpu().numpy(), oi.cpu().numpy()
+
+        rc, res, ob, oe, oi = exchange((biggest + 7) // 8 * 8)
+        assert rc == L.OVTK_OK and res[2] == L.OVTK_OK and res[0] == len(ids) and res[1] == biggest
+        ends = np.cumsum(lens).astype(np.int32)
+        assert np.array_equal(oe[:n_rows], ends) and np.array_equal(ob[:n_rows], ends - lens.astype(np.int32))
+        assert np.array_equal(oi[:len(ids)], ids.astype(np.int32))
+        if biggest > 8:
+            rc, res, *_ = exchange((biggest // 2) // 8 * 8)
+            assert res[2] == L.E_CAPACITY and res[1] == biggest   # every rank learns the pad that is needed
+    finally:
+        lib.ovtk_shard_exchange_destroy(h)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("own_stream", [False, True])
 def test_shard_exchange_rccl_one_rank(hip_lib, own_stream):
