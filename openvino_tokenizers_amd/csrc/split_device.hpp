@@ -345,6 +345,7 @@ __device__ __forceinline__ Mask llama3_start_mask(const WaveScratch& ws, const S
     const uint8_t* t = text_bytes(ws) + skew;
     Mask mL = 0, mN = 0, mW = 0, mNL = 0, mSP = 0, mCONT = 0, mAP = 0, mX1 = 0, mX2 = 0, mXE = 0, mXL = 0;
     bool odd = false;
+    Mask ap_tail = 0;  // wave-uniform: an apostrophe among the last two bytes of the previous word
     const int nwords = (wlen + 63) >> 6;
     for (int w = 0; w < nwords; ++w) {
         const int i = w * 64 + l;
@@ -364,12 +365,19 @@ __device__ __forceinline__ Mask llama3_start_mask(const WaveScratch& ws, const S
         const uint32_t f = b | 0x20u;  // ASCII letters folded to lower case
         const Mask bL = __ballot(cls == kClsL), bN = __ballot(cls == kClsN), bW = __ballot(cls == kClsS);
         const Mask bNL = __ballot(b == '\r' || b == '\n'), bSP = __ballot(b == 0x20u), bCONT = __ballot((b & 0xC0u) == 0x80u);
-        const Mask bAP = __ballot(b == 0x27u), bX1 = __ballot(f == 's' || f == 't' || f == 'm' || f == 'd');
-        const Mask bX2 = __ballot(f == 'r' || f == 'v'), bXE = __ballot(f == 'e'), bXL = __ballot(f == 'l');
+        const Mask bAP = __ballot(b == 0x27u);
         if (l == w) {
             mL = bL; mN = bN; mW = bW; mNL = bNL; mSP = bSP; mCONT = bCONT;
-            mAP = bAP; mX1 = bX1; mX2 = bX2; mXE = bXE; mXL = bXL;
+            mAP = bAP;
         }
+        // contraction letters matter in the two bytes behind an apostrophe only: this word's, or the first two bytes of
+        // the next word when the previous one ended in an apostrophe (most words of a window have neither)
+        if (bAP | ap_tail) {
+            const Mask bX1 = __ballot(f == 's' || f == 't' || f == 'm' || f == 'd');
+            const Mask bX2 = __ballot(f == 'r' || f == 'v'), bXE = __ballot(f == 'e'), bXL = __ballot(f == 'l');
+            if (l == w) { mX1 = bX1; mX2 = bX2; mXE = bXE; mXL = bXL; }
+        }
+        ap_tail = bAP >> 62;
     }
     fallback = __ballot(odd) != 0;
     const int rem = wlen - l * 64;
