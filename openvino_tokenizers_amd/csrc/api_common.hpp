@@ -138,6 +138,15 @@ inline int grid_rows(int device, int n_rows, int blocks_per_cu) {
     return std::max(1, std::min((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, device_cu_count(device) * blocks_per_cu));
 }
 inline int grid_lookup(int device, int n_rows) { return grid_rows(device, n_rows, 6); }
+// Blocks per shard of the kernels that work through the deferred list (merge_kernel, wordpiece_deferred_kernel): the
+// resident number, but no more than the list can give work to -- a piece has at least one byte, a wave takes 64 pieces.
+// Every block draws a "last block done" ticket from one counter (~90 atomics per microsecond on one address), so a
+// 1 000-block grid costs a 32-row batch 11 us of tickets alone.
+inline int grid_deferred_per_shard(long long n_chars, long long n_strings, int resident_per_shard) {
+    const long long most_batches = (n_chars + n_strings + (long long)kShards * kWave - 1) / ((long long)kShards * kWave);
+    const long long blocks = (2 * most_batches + kWavesPerBlock - 1) / kWavesPerBlock;  // x2: shards fill unevenly when few blocks feed them
+    return int(std::max<long long>(1, std::min<long long>(blocks, resident_per_shard)));
+}
 
 // The "ragged strings in -> ragged i32 out" pipeline shared by BPETokenizer, the fused encode and
 // WordpieceTokenizer: prep (validation + per-wave staging arenas) -> middle(ws, d_in, w, grid) (the op's kernels: ids

@@ -387,11 +387,13 @@ int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_
                                const int tail_rows = w.fold_tail ? d_in.n_rows : 0;
                                if (bpe->narrow_ids) {
                                    static const int per_cu = resident_blocks_per_cu(merge_kernel<true>);
-                                   OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<true>, dim3(kShards, std::max(1, device_cu_count(dev) * per_cu / kShards)),
+                                   OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<true>,
+                                               dim3(kShards, grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * per_cu / kShards)),
                                                kBlockThreads, s, d_in, bpe->dev, w, tail_rows, w.out_cap);
                                } else {
                                    static const int per_cu = resident_blocks_per_cu(merge_kernel<false>);
-                                   OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<false>, dim3(kShards, std::max(1, device_cu_count(dev) * per_cu / kShards)),
+                                   OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<false>,
+                                               dim3(kShards, grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * per_cu / kShards)),
                                                kBlockThreads, s, d_in, bpe->dev, w, tail_rows, w.out_cap);
                                }
                                if (!w.fold_tail) OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);

@@ -222,8 +222,8 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                OVTK_LAUNCH(ws.marks, "lookup_words", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp,
                                            memo_only, w);
                                OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel,
-                                           dim3(std::max(1, device_cu_count(dev) * 8 / kShards), kShards), kBlockThreads, s, d_in,
-                                           wdev, unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
+                                           dim3(grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * 8 / kShards), kShards),
+                                           kBlockThreads, s, d_in, wdev, unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
                            },
                            /*self_alloc=*/true, resident_blocks_per_cu(lookup_kernel<kFused>), /*tail_in_middle=*/true);
     if (int rc = r->start()) return rc;
