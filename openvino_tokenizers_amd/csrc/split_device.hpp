@@ -398,14 +398,20 @@ __device__ __forceinline__ Mask llama3_start_mask(const WaveScratch& ws, const S
     if (lo > 0 && l == ((lo - 1) >> 6)) mNd &= ~(1ull << ((lo - 1) & 63));
     const Mask seedN = mNd & ~mask_from_before<1>(mNd);            // N run starts
     const Mask seedA = mNL & ~pNL & pO;                             // line breaks right behind an O char
-    // ---- forward ripples: digit groups G, absorbed line breaks F
+    // ---- forward ripples: digit groups G, absorbed line breaks F (windows without a digit / a line break skip theirs)
+    const bool any_n = __ballot(mN != 0) != 0, any_nl = __ballot(mNL != 0) != 0;
     Mask G = 0, F = 0;
-    {
+    if (any_nl) {
         bool cF = false;
+        for (int w = 0; w < nwords; ++w) {
+            const Mask f = ripple_up(readlane_mask(mNL, w), readlane_mask(seedA, w), cF);
+            if (l == w) F = f;
+        }
+    }
+    if (any_n) {
         int k_prev = 0;  // digits in the last group of the previous word when its run reaches the word's end, else 0
         for (int w = 0; w < nwords; ++w) {
-            const Mask Nw = readlane_mask(mNd, w), Sw = readlane_mask(seedN, w), NLw = readlane_mask(mNL, w);
-            const Mask Aw = readlane_mask(seedA, w);
+            const Mask Nw = readlane_mask(mNd, w), Sw = readlane_mask(seedN, w);
             Mask g = Sw;
             if (k_prev && (Nw & 1ull)) {  // the run continues from the previous word: its next group starts 3 - k_prev digits in
                 const Mask head = Nw & ~(Nw + 1ull);  // the run of ones that starts at bit 0
@@ -423,13 +429,12 @@ __device__ __forceinline__ Mask llama3_start_mask(const WaveScratch& ws, const S
                 const Mask gt = g & top;                                        // never empty: a run has a start every 3 digits
                 k_prev = __clzll(gt) % 3 + 1;
             }
-            const Mask f = ripple_up(NLw, Aw, cF);
-            if (l == w) { G = g; F = f; }
+            if (l == w) G = g;
         }
     }
     // ---- backward ripple: D = "a line break follows (or is here) in this white-space run"
     Mask D = 0;
-    {
+    if (any_nl) {
         bool c = false;
         for (int w = nwords - 1; w >= 0; --w) {
             const Mask Ww = readlane_mask(mW, w), NLw = readlane_mask(mNL, w);
