@@ -228,6 +228,21 @@ __device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str,
     return skew;
 }
 
+// Code point of the char whose lead byte b (>= 0xC0) is window byte i; a char cut off by the window's end is decoded
+// from the bytes that are there.  The four bytes from i come as two aligned LDS dwords and a funnel shift: no loop.
+__device__ __forceinline__ uint32_t decode_lead(const WaveScratch& ws, int skew, int i, uint32_t b, int wlen) {
+    const int off = kTextPad + skew + i;
+    const int a = off >> 2, sh = (off & 3) * 8;
+    const uint32_t x = uint32_t(((static_cast<unsigned long long>(ws.text_w[a + 1]) << 32) | ws.text_w[a]) >> sh);
+    const int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
+    const int have = wlen - i < n ? wlen - i : n;
+    uint32_t cp = b & (0xFFu >> (n + 1));
+    if (have >= 2) cp = (cp << 6) | ((x >> 8) & 0x3Fu);
+    if (have >= 3) cp = (cp << 6) | ((x >> 16) & 0x3Fu);
+    if (have >= 4) cp = (cp << 6) | ((x >> 24) & 0x3Fu);
+    return cp;
+}
+
 // ---- 64-bit masks, lane w = window bytes [64w, 64w + 64) ---------------------------------------
 using Mask = unsigned long long;
 // Bit i of the result = bit (i - k) of the window-wide mask (k in 1..4): "property of the byte k places before".
@@ -253,10 +268,7 @@ __device__ __forceinline__ Mask gpt2_start_mask(const WaveScratch& ws, const Spl
         if (b < 0x80u) {
             cls = valid ? ascii_class(b) : kClsO;
         } else if (b >= 0xC0u) {  // lead byte: decode (truncated at the window edge: the right halo covers real chars)
-            int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
-            uint32_t cp = b & (0xFFu >> (n + 1));
-            if (i + n > wlen) n = wlen - i;
-            for (int j = 1; j < n; ++j) cp = (cp << 6) | (t[i + j] & 0x3Fu);
+            const uint32_t cp = decode_lead(ws, skew, i, b, wlen);
             cls = uc_nibble(sp, cp) & 3u;
         }
         const Mask bL = __ballot(cls == kClsL), bN = __ballot(cls == kClsN), bS = __ballot(cls == kClsS);
@@ -355,10 +367,7 @@ __device__ __forceinline__ Mask llama3_start_mask(const WaveScratch& ws, const S
         if (b < 0x80u) {
             cls = valid ? ascii_class(b) : kClsO;
         } else if (b >= 0xC0u) {
-            int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
-            uint32_t cp = b & (0xFFu >> (n + 1));
-            if (i + n > wlen) n = wlen - i;
-            for (int j = 1; j < n; ++j) cp = (cp << 6) | (t[i + j] & 0x3Fu);
+            const uint32_t cp = decode_lead(ws, skew, i, b, wlen);
             cls = uc_nibble(sp, cp) & 3u;
             if (cls == kClsN || cp == 0x17Fu) odd = true;  // a non-ASCII digit; LATIN SMALL LETTER LONG S folds to 's'
         }
@@ -509,10 +518,7 @@ __device__ __forceinline__ void class_start_mask(const WaveScratch& ws, const Sp
             is_s = valid && ascii_class(b) == kClsS;
             is_p = valid && bert_delimiter(b, 0);
         } else if (b >= 0xC0u) {
-            int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
-            uint32_t cp = b & (0xFFu >> (n + 1));
-            if (i + n > wlen) n = wlen - i;
-            for (int j = 1; j < n; ++j) cp = (cp << 6) | (t[i + j] & 0x3Fu);
+            const uint32_t cp = decode_lead(ws, skew, i, b, wlen);
             const uint32_t nib = uc_nibble(sp, cp);
             is_s = (nib & 3u) == kClsS;
             is_p = bert_delimiter(cp, nib);
