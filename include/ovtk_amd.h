@@ -132,7 +132,10 @@ void ovtk_special_tokens_split_destroy(ovtk_special_tokens_split* h);
  * Constant inputs 5-7 (vocab), 8-10 (merges: "left right" lines, or left halves), 11-13 (right halves; NULL
  * for the 11/15-input text form), last four (added tokens + ids; n_added = 0 if absent) and the attributes
  * unk_token, fuse_unk, suffix_indicator, end_suffix, byte_fallback, cache_capacity (bpe_tokenizer.hpp:220-228).
- * cache_capacity is accepted for interface parity and ignored: the reference cache is pure memoisation. */
+ * cache_capacity: the reference's piece cache is pure memoisation (bpe_tokenizer.cpp:197-205,331-338) and so is its
+ * counterpart here, the piece memo built at create (BPE of every vocabulary token as a whole piece).  0 disables the
+ * memo exactly as it disables the reference's cache (:331 `size() < capacity`); any other value enables it -- the
+ * table is sized by the vocabulary, not by this number.  Results are identical either way. */
 typedef struct ovtk_bpe_params {
     ovtk_strings vocab;
     ovtk_strings merges;       /* text lines or left halves */

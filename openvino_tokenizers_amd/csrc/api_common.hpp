@@ -79,6 +79,7 @@ inline int grid_for_rows(int n_rows) { return std::max(1, (n_rows + kWavesPerBlo
 inline int finish_status(Workspace& ws, hipStream_t s) {
     OVTK_HIP(hipMemcpyAsync(ws.host_status, ws.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s));
     OVTK_HIP(hipStreamSynchronize(s));
+    ws.marks.settled();
     Profiler::get().resolve(ws.marks);
     OVTK_HIP(hipGetLastError());
     return OVTK_OK;
@@ -220,8 +221,10 @@ public:
     }
 
     int finish(ovtk_ragged_i32_out* out) override {
+        OVTK_HIP(hipSetDevice(device_));  // the retry path allocates and launches: on this run's device, whatever is current
         for (int attempt = 0; attempt < 6; ++attempt) {
             OVTK_HIP(hipEventSynchronize(ws_->done));
+            ws_->marks.settled();
             Profiler::get().resolve(ws_->marks);
             OVTK_HIP(hipGetLastError());
             const RunStatus& st = *ws_->host_status;
@@ -261,6 +264,7 @@ public:
 
 private:
     int launch() {
+        OVTK_HIP(hipSetDevice(device_));
         Workspace& ws = *ws_.ws;
         int e = 0;
         e = e ? e : ws.row_stage.ensure(size_t(n_rows_) * 4);

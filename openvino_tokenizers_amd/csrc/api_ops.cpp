@@ -583,6 +583,7 @@ struct DetokRun final : ovtk::PendingStrings {
     WorkspaceLease ws;
     int finish(ovtk_strings_out* out) override {
         OVTK_HIP(hipEventSynchronize(ws->done));
+        ws->marks.settled();
         Profiler::get().resolve(ws->marks);
         OVTK_HIP(hipGetLastError());
         if (ws->host_status->flags & kFlagOutCapacity)
@@ -1033,6 +1034,7 @@ int ovtk_truncate(int n_inputs, const int32_t* begins0, const int32_t* ends0, co
     }
     if (err) return err;
     if (mem == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s));
+    ws->marks.settled();  // host memory: waited above; device memory: the kernel touches the caller's buffers only
     Profiler::get().resolve(ws->marks);  // empty unless profiling (then it waits for the kernel)
     return OVTK_OK;
 }

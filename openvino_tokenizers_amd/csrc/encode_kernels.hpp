@@ -754,7 +754,10 @@ constexpr int kCompactRows = 4;    // rows per work item (8: no better)
 constexpr int kCompactChunks = 3;  // 64-entry chunks of a row held in registers; longer rows finish in a loop
 static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out,
                                                                        int32_t* out_begins, int32_t* out_ends) {
-    if (w.status->flags & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow))
+    // kFlagTailPending: merge_kernel's folded tail left the exact pieces and the tile scan to a second attempt -- tile_off
+    // and parts of the staging buffer hold whatever the previous call left there
+    if (w.status->flags & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
+                           kFlagTailPending))
         return;
     const int l = lane_id();
     const int n_waves = int(gridDim.x) * kWavesPerBlock;

@@ -122,6 +122,10 @@ std::unique_ptr<Workspace> WorkspacePool::acquire() {
 }
 void WorkspacePool::release(std::unique_ptr<Workspace> w) {
     if (!w) return;
+    if (w->marks.in_flight) {  // an error return between launches: the kernels already enqueued still use these buffers
+        (void)hipStreamSynchronize(w->marks.stream);
+        w->marks.settled();
+    }
     std::lock_guard<std::mutex> lk(mu_);
     free_.push_back(std::move(w));
 }

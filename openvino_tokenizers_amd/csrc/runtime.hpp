@@ -65,9 +65,21 @@ private:
     hipEvent_t take();
 };
 
+// The launches of one call: profiler marks, plus "kernels of this workspace may still be running on `stream`" -- set by
+// every launch, cleared where the host has waited for them; a workspace that goes back to the pool while it is set (an
+// error return between launches) is synchronised first, so the next call never shares buffers with running kernels.
+struct LaunchLog : std::vector<Profiler::Mark> {
+    hipStream_t stream = nullptr;
+    bool in_flight = false;
+    void settled() { in_flight = false; }
+};
+inline void note_launch(LaunchLog& log, hipStream_t s) { log.stream = s; log.in_flight = true; }
+inline void note_launch(std::vector<Profiler::Mark>&, hipStream_t) {}
+
 // Launch a kernel, optionally bracketed by profiler events.
 #define OVTK_LAUNCH(marks, name, kernel, grid, block, stream, ...)                   \
     do {                                                                              \
+        ::ovtk::note_launch(marks, stream);                                           \
         ::ovtk::Profiler& pf_ = ::ovtk::Profiler::get();                              \
         if (pf_.enabled()) pf_.begin(name, stream, marks);                            \
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);  \
@@ -83,7 +95,7 @@ struct Workspace {
     DevBuf gen[8];  // op-specific inputs / temporaries (api_ops.cpp)
     RunStatus* host_status = nullptr;  // pinned
     hipEvent_t done = nullptr;         // end of the call in flight (RowsRun)
-    std::vector<Profiler::Mark> marks;
+    LaunchLog marks;
     ~Workspace();
 };
 

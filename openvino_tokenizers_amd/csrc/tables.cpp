@@ -81,41 +81,7 @@ void TrieHost::finalize() {
         }
 }
 
-int TrieHost::find_longest(const uint8_t* s, int n, int& idx) const {
-    const I2 r = root[s[idx]];
-    if (r.y < 0) return -1;
-    int best = r.x, best_end = idx + 1, i = idx + 1;
-    int cur = r.y & ~kLeafBit;
-    bool leaf = (r.y & kLeafBit) != 0;
-    while (!leaf && i < n) {
-        const uint32_t key = (uint32_t(cur) << 8) | s[i];
-        uint32_t p = (hash_u32(key) >> edge_shift) & edge_mask;
-        int child = -1;
-        while (edges[p] != kEmptySlot) {
-            if (uint32_t(edges[p] >> 32) == key) { child = int(uint32_t(edges[p])); break; }
-            p = (p + 1) & edge_mask;
-        }
-        if (child < 0) break;
-        cur = child;
-        ++i;
-        if (node[cur].x != -1) { best = node[cur].x; best_end = i; }
-        leaf = node[cur].y == 0;
-    }
-    if (best == -1) return -1;
-    idx = best_end;
-    return best;
-}
-
 // ------------------------------------------------------------------------------- BPE
-uint32_t BpeHost::find_merge(uint32_t l, uint32_t r) const {
-    if (merges.empty()) return kNoRank;
-    const uint64_t key = merge_key(l, r);
-    for (uint32_t b : {merge_h1(key, bucket_shift), merge_h2(key, bucket_shift)})
-        for (const MergeSlot& s : merges[b].s)
-            if (s.kr != kEmptySlot && (s.kr >> kMaxRankBits) == key) return uint32_t(s.kr) & kNoRank;
-    return kNoRank;
-}
-
 namespace {
 // Cuckoo insertion by random walk (deterministic xorshift): `choices(item, idx)` fills the candidate slot
 // indices of an item, `empty(slot)` tells a free slot.  Returns false when the walk does not terminate.

@@ -129,8 +129,6 @@ struct TrieHost {
     TrieHost();
     void add(const uint8_t* s, size_t n, int32_t value);  // later add of the same string overwrites
     void finalize();                                      // flattens b -> root/node/edges
-    // Host mirror of the device walk (unit tests): longest token starting at s[idx], idx advanced.
-    int find_longest(const uint8_t* s, int n, int& idx) const;
 };
 
 struct BpeHost {
@@ -141,8 +139,6 @@ struct BpeHost {
     std::vector<int32_t> byte_fallback_id;
     int32_t unk_id = -1;
     std::string suffix;
-    // Host mirror of the device probe (unit tests): rank or kNoRank.
-    uint32_t find_merge(uint32_t l, uint32_t r) const;
 };
 
 struct StringsView { const int32_t* begins; const int32_t* ends; const uint8_t* chars; int64_t n; };

@@ -404,3 +404,52 @@ def test_unaligned_chars_tensor(backend, shift):
         data = [rb, re_, b, e, chars]
     fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
     assert_same(ref, fused.evaluate(data + [tok.pattern_u8()], tok.consts), backend.host, "unaligned tensor")
+
+
+@pytest.mark.parametrize("mem", ["device", "host"])
+def test_many_exact_pieces_leave_no_stray_writes(backend, mem):
+    """More exact-path pieces (> 512 bytes) than merge_kernel's folded tail takes (256): that attempt sets
+    kFlagTailPending and the host repeats it with the separate exact / count_scan launches.  compact_kernel of the FIRST
+    attempt must not run on the stale tile offsets an earlier call left in the pooled workspace: a sentinel region behind
+    the ids buffer (and behind begins/ends) stays untouched, and the result equals the oracle."""
+    import ctypes as C
+    if (mem == "device") != (backend.name != "hip-host"):
+        pytest.skip("one memory kind per backend")
+    tok = BpeTok.load("gpt2_small")
+    bpe = BPETokenizer(**tok.attrs, lib=backend.lib)
+    # call A: 3 tiles of long rows -> tile offsets beyond call B's whole ids buffer stay behind in the workspace
+    ba, ea, ca = TextModel(3, "zipf").batch(130, 8000)
+    rba, rea = ragged_rows(130)
+    sp = O.RegexSplit(tok.pattern, "isolate")(rba, rea, ba, ea, ca)
+    bpe.evaluate(backend.data(list(sp[:5])) + tok.consts)
+    # call B: 320 rows, one 600-byte piece each
+    strings = [chr(ord("a") + i % 26) * 600 for i in range(320)]
+    rb, re_, b, e, c = one_string_per_row(strings)
+    ref = tok.oracle()(rb, re_, b, e, c)
+    cap, guard = len(c), 200000
+    SENT = -7777777
+    if backend.name == "hip-device":
+        import torch
+        mk = lambda a: torch.as_tensor(a, device="cuda")  # noqa: E731
+        ptr = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        host = lambda t: t.cpu().numpy()  # noqa: E731
+    else:
+        mk = lambda a: np.ascontiguousarray(a)  # noqa: E731
+        ptr = lambda a: C.c_void_p(a.ctypes.data)  # noqa: E731
+        host = lambda a: a  # noqa: E731
+    d = [mk(x) for x in (rb, re_, b, e, c)]
+    ob = mk(np.full(len(rb) + guard, SENT, np.int32))
+    oe = mk(np.full(len(rb) + guard, SENT, np.int32))
+    ids = mk(np.full(cap + guard, SENT, np.int32))
+    rs = L.RaggedStrings(ptr(d[0]), ptr(d[1]), len(rb), L.Strings(ptr(d[2]), ptr(d[3]), ptr(d[4]), len(b), len(c)))
+    out = L.RaggedI32Out(ptr(ob), ptr(oe), ptr(ids), cap, 0, 0)
+    memk = L.MEM_HOST if backend.name == "hip-host" else L.MEM_DEVICE
+    L.check(backend.lib, backend.lib.ovtk_bpe_run(bpe._h, C.byref(rs), C.byref(out), memk, None))
+    if backend.name == "hip-device":
+        torch.cuda.synchronize()
+    ob, oe, ids = host(ob), host(oe), host(ids)
+    assert out.n_data == len(ref[2])
+    assert np.array_equal(ob[: len(rb)], ref[0]) and np.array_equal(oe[: len(rb)], ref[1])
+    assert np.array_equal(ids[: out.n_data], ref[2])
+    assert (ids[out.n_data:] == SENT).all(), "ids written beyond the result"
+    assert (ob[len(rb):] == SENT).all() and (oe[len(rb):] == SENT).all()

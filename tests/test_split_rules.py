@@ -201,3 +201,24 @@ def test_llama3_rows_with_several_strings_and_skips(backend):
     ref = O.RegexSplit(LLAMA3_PATTERN, "isolate")(rb, re_, b, e, c, skips=skips)
     got = RegexSplit("isolate", lib=backend.lib).evaluate(backend.data([rb, re_, b, e, c, skips]) + [pat])
     assert_same(ref[:4] + [ref[5]], list(got[:4]) + [got[5]], backend.host, "llama3 ragged rows + skips")
+
+
+# ------------------------------------------------------------------ the reference's own RegexSplit known answers on the device
+from tests.golden.reference_kats import REGEX_SPLIT_KATS  # noqa: E402
+
+
+@pytest.mark.parametrize("text, expected, layer", REGEX_SPLIT_KATS)
+def test_reference_regex_split_kats(backend, text, expected, layer):
+    """tests/layer_tests.py:331-389 through ovtk_regex_split_run: the unpacked pieces equal the reference's expected
+    strings (the reference test packs outputs 2..4 with StringTensorPack and compares)."""
+    pattern, behaviour, invert = layer
+    from openvino_tokenizers_amd import _lib as L
+    split = RegexSplit(behaviour, invert, lib=backend.lib)
+    try:
+        out = split.evaluate(backend.data(one_string_per_row([text])) + [np.frombuffer(pattern.encode(), np.uint8)])
+    except L.OvtkError as err:
+        if err.code == L.E_UNSUPPORTED:
+            pytest.skip("pattern / behaviour has no device matcher yet")
+        raise
+    got = tuple(s.decode("utf-8") for s in O.unpack_strings(*[backend.host(x) for x in out[2:5]]))
+    assert got == expected
