@@ -9,16 +9,19 @@
 #include <string>
 
 #include "encode_kernels.hpp"
+#include "regex_device.hpp"
 #include "runtime.hpp"
 #include "tables.hpp"
 
 // Handle of RegexSplit (shared by api_encode.cpp and the fused WordPiece path in api_ops.cpp).
 struct ovtk_regex_split {
     int device = 0;
-    ovtk::SplitDev dev{};
+    ovtk::SplitDev dev{};  // dev.kind: a hand-written scanner, or kSplitGeneral: the compiled DFA below
     int mode = 1;  // 0 removed, 1 isolated, 2 merged-with-previous, 3 merged-with-next
     bool invert = false;
     int max_splits = -1;
+    ovtk::RegexDev regex{};
+    ovtk::DevBuf r_trans, r_ascii, r_index, r_blocks, r_ctx;
 };
 
 namespace ovtk {
@@ -196,14 +199,21 @@ public:
     RowsRun(int device, const char* op, const ovtk_ragged_strings* in, const uint8_t* skips, int mul,
             const ovtk_ragged_i32_out* out, int mem, hipStream_t s, Middle middle, bool self_alloc, int blocks_per_cu,
             bool tail_in_middle)
-        : device_(device), op_(op), in_(*in), skips_(skips), mul_(mul), out_(*out), mem_(mem), s_(s),
+        : device_(device), op_(op), in_(*in), skips_(skips), mul_(mul), out_(*out), mem_(mem), in_mem_(mem), s_(s),
           middle_(std::move(middle)), self_alloc_(self_alloc), blocks_per_cu_(blocks_per_cu), ws_(device),
           fold_tail_(tail_in_middle) {}
+
+    // The input tensors live in device memory whatever `mem` says about the outputs (pieces produced on the device by
+    // a preceding split; `keep` = what owns them, released with this run).
+    void input_on_device(std::shared_ptr<void> keep) {
+        in_mem_ = OVTK_MEM_DEVICE;
+        keep_ = std::move(keep);
+    }
 
     int start() {
         if (!ws_->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
         if (!ws_->done) OVTK_HIP(hipEventCreateWithFlags(&ws_->done, hipEventDisableTiming));
-        if (int rc = stage_input(*ws_.ws, &in_, skips_, mem_, s_, d_in_)) return rc;
+        if (int rc = stage_input(*ws_.ws, &in_, skips_, in_mem_, s_, d_in_)) return rc;
         n_rows_ = d_in_.n_rows;
         stage_cap_ = std::min<int64_t>((in_.strings.n_chars + in_.strings.n) * mul_, INT32_MAX - 1);
         shard_cap_ = std::max<int64_t>({4096, (in_.strings.n_chars / 16 + in_.strings.n / 4) / kShards,
@@ -324,7 +334,8 @@ private:
     const uint8_t* skips_;
     int mul_;
     ovtk_ragged_i32_out out_;
-    int mem_;
+    int mem_, in_mem_;
+    std::shared_ptr<void> keep_;
     hipStream_t s_;
     Middle middle_;
     bool self_alloc_;

@@ -199,27 +199,53 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
         return set_error(OVTK_E_ARG, "RegexSplit max_splits attribute must be greater then `0` or equal to `-1`");
     h->invert = p->invert != 0;
     h->max_splits = p->max_splits;
-    if (pat == kGpt2Pattern) h->dev.kind = kSplitGpt2;
-    else if (pat == kGpt2DigitsPattern) h->dev.kind = kSplitGpt2Digits;
-    else if (pat == kBertWhitespacePattern) h->dev.kind = kSplitWhitespace;
-    else if (pat == kBertDelimitersPattern) h->dev.kind = kSplitBertPunct;
-    else if (pat == kLlama3Pattern) h->dev.kind = kSplitLlama3;
-    else
-        return set_error(OVTK_E_UNSUPPORTED,
-                         "RegexSplit: no gfx950 scanner for this pattern (supported: the byte-level and BERT patterns of "
-                         "tokenizer_pipeline.py:392-457); PCRE2 is not executed on the device");
-    if (h->dev.kind <= kSplitGpt2Digits || h->dev.kind == kSplitLlama3) {
-        if (beh != "isolate")
-            return set_error(OVTK_E_UNSUPPORTED, "RegexSplit: the byte-level patterns are only supported with behaviour=isolate");
-    } else {
+    // regex_split.cpp:33-37: "contiguous" is "isolate" on (pattern)+, unless the pattern already ends in '+'
+    std::string eff = pat;
+    if (beh == "contiguous" && (pat.empty() || pat.back() != '+')) eff = "(" + pat + ")+";
+    // Hand-written scanners for the patterns the converter emits, where the behaviour is one they implement; every
+    // other pattern / behaviour runs the compiled DFA (regex_compile.cpp).
+    h->dev.kind = kSplitGeneral;
+    if (eff == kGpt2Pattern && h->mode == 1) h->dev.kind = kSplitGpt2;
+    else if (eff == kGpt2DigitsPattern && h->mode == 1) h->dev.kind = kSplitGpt2Digits;
+    else if (eff == kLlama3Pattern && h->mode == 1) h->dev.kind = kSplitLlama3;
+    else if (eff == kBertWhitespacePattern && h->mode <= 1) h->dev.kind = kSplitWhitespace;
+    else if (eff == kBertDelimitersPattern && h->mode <= 1) h->dev.kind = kSplitBertPunct;
+    if (h->dev.kind >= kSplitWhitespace && h->dev.kind != kSplitGeneral)
         // regex_split.cpp:244-284: "remove" drops the pieces flagged `invert`: the matches, or the gaps when invert is set
-        if (h->mode == 0) h->dev.drop = h->invert ? 2 : 1;
-        else if (h->mode == 1) h->dev.drop = 0;
-        else return set_error(OVTK_E_UNSUPPORTED, "RegexSplit: merged-with-previous/next is not supported on the device");
+        h->dev.drop = h->mode == 0 ? (h->invert ? 2 : 1) : 0;
+    RegexProgram prog;
+    if (h->dev.kind == kSplitGeneral) {
+        std::string err;
+        if (int rc = compile_regex(eff, prog, err)) return set_error(rc, err);
     }
     if (int rc = use_device(p->device)) return rc;
     h->device = p->device;
     if (int rc = unicode_tables(p->device, &h->dev.uc_index, &h->dev.uc_blocks)) return rc;
+    if (h->dev.kind == kSplitGeneral) {
+        int e = 0;
+        e = e ? e : h->r_trans.upload(prog.trans.data(), prog.trans.size() * sizeof(uint16_t));
+        e = e ? e : h->r_ascii.upload(prog.ascii_class, sizeof prog.ascii_class);
+        e = e ? e : h->r_index.upload(prog.cp_index.data(), prog.cp_index.size() * sizeof(uint16_t));
+        e = e ? e : h->r_blocks.upload(prog.cp_blocks.data(), prog.cp_blocks.size());
+        e = e ? e : h->r_ctx.upload(prog.ctx_of_class.data(), prog.ctx_of_class.size());
+        if (e) return e;
+        OVTK_HIP(hipStreamSynchronize(nullptr));
+        RegexDev& r = h->regex;
+        r.trans = h->r_trans.as<uint16_t>();
+        r.ascii_class = h->r_ascii.as<uint8_t>();
+        r.cp_index = h->r_index.as<uint16_t>();
+        r.cp_blocks = h->r_blocks.as<uint8_t>();
+        r.ctx_of_class = h->r_ctx.as<uint8_t>();
+        r.n_syms = prog.n_syms;
+        r.n_states = prog.n_states;
+        r.sym_eot = prog.sym_eot;
+        r.sym_final_nl = prog.sym_final_nl;
+        r.n_ctx = prog.n_ctx;
+        std::memcpy(r.start, prog.start, sizeof r.start);
+        r.mode = h->mode;
+        r.invert = h->invert ? 1 : 0;
+        r.max_splits = h->max_splits;
+    }
     *out = h.release();
     return OVTK_OK;
 }
@@ -332,10 +358,69 @@ void ovtk_bpe_destroy(ovtk_bpe* h) { delete h; }
 // ------------------------------------------------------------------------------- run pipelines
 namespace {
 
+// RegexSplit on device-resident rows: validation, count pass, offsets, write pass; waits for the piece count.
+// d_* are device buffers (d_b / d_e / d_sk: `capacity` entries; d_sk may be null).
+int split_on_device(const ovtk_regex_split* h, Workspace& ws, const RowsIn& d_in, hipStream_t s, int32_t* d_rb, int32_t* d_re,
+                    int32_t* d_b, int32_t* d_e, uint8_t* d_sk, int64_t capacity, int64_t* n_out) {
+    const int n_rows = d_in.n_rows;
+    const int grid = grid_lookup(h->device, n_rows);
+    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
+    int e = 0;
+    e = e ? e : ws.row_cnt.ensure(size_t(n_rows) * 4);
+    e = e ? e : ws.wave_off.ensure(size_t(grid * kWavesPerBlock + 1) * sizeof(long long));
+    e = e ? e : ws.tiles.ensure(size_t(n_tiles + 1) * sizeof(long long));
+    e = e ? e : ws.status.ensure(sizeof(RunStatus));
+    if (e) return e;
+    EncodeWork w{};
+    w.n_waves = grid * kWavesPerBlock;
+    w.wave_off = ws.wave_off.as<long long>();
+    w.row_cnt = ws.row_cnt.as<int32_t>();
+    w.tile_off = ws.tiles.as<long long>();
+    w.stage_cap = INT32_MAX;
+    w.status = ws.status.as<RunStatus>();
+    OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
+    // range validation of the inputs (the staging arenas it also computes are not needed here)
+    OVTK_LAUNCH(ws.marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);
+    const int lane_grid = (n_rows + kBlockThreads - 1) / kBlockThreads;  // the DFA runs one lane per row
+    int32_t* const nil = nullptr;
+    if (h->dev.kind == kSplitGeneral)
+        OVTK_LAUNCH(ws.marks, "regex_count", regex_split_kernel<0>, lane_grid, kBlockThreads, s, d_in, h->regex, w, nil, nil, nil, nil,
+                    (uint8_t*)nullptr);
+    else if (h->dev.kind == kSplitLlama3)
+        OVTK_LAUNCH(ws.marks, "split_count", (split_kernel<0, true>), grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, nil, nil,
+                    nil, nil, (uint8_t*)nullptr);
+    else
+        OVTK_LAUNCH(ws.marks, "split_count", split_kernel<0>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, nil, nil, nil, nil,
+                    (uint8_t*)nullptr);
+    OVTK_LAUNCH(ws.marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s, n_rows, w,
+                (long long)capacity);
+    if (h->dev.kind == kSplitGeneral)
+        OVTK_LAUNCH(ws.marks, "regex_write", regex_split_kernel<1>, lane_grid, kBlockThreads, s, d_in, h->regex, w, d_rb, d_re, d_b, d_e,
+                    d_sk);
+    else if (h->dev.kind == kSplitLlama3)
+        OVTK_LAUNCH(ws.marks, "split_write", (split_kernel<1, true>), grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb, d_re,
+                    d_b, d_e, d_sk);
+    else
+        OVTK_LAUNCH(ws.marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb, d_re, d_b,
+                    d_e, d_sk);
+    if (int rc = finish_status(ws, s)) return rc;
+    const RunStatus& st = *ws.host_status;
+    if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+    if (st.flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "RegexSplit: output begins/ends too small");
+    *n_out = st.n_out;
+    return OVTK_OK;
+}
+
+// The split runs inside lookup_kernel (scanner -> pieces -> memo probe in one pass over the text).
+bool fusable(const ovtk_regex_split* split) {
+    return split->max_splits == -1 && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3);
+}
+
 // RegexSplit [+] BPETokenizer.  split == nullptr: `in` already holds pieces (the BPETokenizer op).
 // Launches the kernels; `run` stays empty when the result was complete without any (empty batches).
-int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                  ovtk_ragged_i32_out* out, int mem, void* stream, std::unique_ptr<PendingRun>& run) {
+    const ovtk_regex_split* split = split_in;
     if (int rc = check_rows(in)) return rc;
     if (!bpe || !out) return set_error(OVTK_E_ARG, "null argument");
     if (split && split->device != bpe->device) return set_error(OVTK_E_ARG, "split and bpe handles live on different devices");
@@ -362,6 +447,36 @@ int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_
     if (in->n_rows == 0) return OVTK_OK;
 
     const int dev = bpe->device;
+    // A split the lookup kernel has no scanner for (the compiled DFA, the class patterns, max_splits): the pieces are
+    // produced in device memory first -- the chain RegexSplit -> BPETokenizer inside one call; the piece offsets make
+    // one round trip through HBM and the host waits once for their count.
+    std::shared_ptr<WorkspaceLease> pieces_ws;
+    ovtk_ragged_strings pieces{};
+    if (split && !fusable(split)) {
+        pieces_ws = std::make_shared<WorkspaceLease>(dev);
+        Workspace& sw = *pieces_ws->ws;
+        if (!sw.host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
+        RowsIn d_in{};
+        if (int rc = stage_input(sw, in, skips, mem, s, d_in)) return rc;
+        const int64_t cap = in->strings.n_chars + in->strings.n;  // regex_split.cpp:182
+        if (cap >= INT32_MAX) return set_error(OVTK_E_ARG, "tensor sizes must fit int32 offsets");
+        int e = 0;
+        e = e ? e : sw.gen[0].ensure(size_t(d_in.n_rows) * 4);
+        e = e ? e : sw.gen[1].ensure(size_t(d_in.n_rows) * 4);
+        e = e ? e : sw.gen[2].ensure(size_t(cap) * 4);
+        e = e ? e : sw.gen[3].ensure(size_t(cap) * 4);
+        if (e) return e;
+        int64_t n_pieces = 0;
+        if (int rc = split_on_device(split, sw, d_in, s, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(), sw.gen[2].as<int32_t>(),
+                                     sw.gen[3].as<int32_t>(), nullptr, cap, &n_pieces))
+            return rc;
+        pieces = ovtk_ragged_strings{sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(), in->n_rows,
+                                     ovtk_strings{sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>(), d_in.chars, n_pieces,
+                                                  in->strings.n_chars}};
+        in = &pieces;
+        skips = nullptr;  // BPETokenizer has no skips input: skipped strings arrive as whole pieces
+        split = nullptr;
+    }
     auto r = make_rows_run(dev, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
                            [=](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                const bool tickets = w.rows_per_ticket != 0;
@@ -403,6 +518,7 @@ int start_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_
                                   : split->dev.kind == kSplitLlama3 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>)
                                                                     : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
+    if (pieces_ws) r->input_on_device(pieces_ws);
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;
@@ -417,10 +533,6 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
 
 int check_fused(const ovtk_regex_split* split) {
     if (!split) return set_error(OVTK_E_ARG, "null split handle");
-    if (split->max_splits != -1)
-        return set_error(OVTK_E_UNSUPPORTED, "fused encode: max_splits is only supported by the RegexSplit op itself");
-    if (split->dev.kind > kSplitGpt2Digits && split->dev.kind != kSplitLlama3)
-        return set_error(OVTK_E_UNSUPPORTED, "fused encode: this pattern is only supported as RegexSplit followed by BPETokenizer");
     return OVTK_OK;
 }
 
@@ -491,57 +603,24 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     RowsIn d_in{};
     if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
     const int n_rows = d_in.n_rows;
-    const int grid = grid_lookup(h->device, n_rows);
-    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
-    int e = 0;
-    e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
-    e = e ? e : ws->wave_off.ensure(size_t(grid * kWavesPerBlock + 1) * sizeof(long long));
-    e = e ? e : ws->tiles.ensure(size_t(n_tiles + 1) * sizeof(long long));
-    e = e ? e : ws->status.ensure(sizeof(RunStatus));
-    if (e) return e;
     int32_t *d_rb = nullptr, *d_re = nullptr, *d_b = nullptr, *d_e = nullptr;
     uint8_t* d_sk = nullptr;
+    int e = 0;
     e = e ? e : out_target(ws->out_a, out->ragged_begins, size_t(n_rows) * 4, mem, &d_rb);
     e = e ? e : out_target(ws->out_b, out->ragged_ends, size_t(n_rows) * 4, mem, &d_re);
     e = e ? e : out_target(ws->out_c, out->begins, size_t(out->capacity) * 4, mem, &d_b);
     e = e ? e : out_target(ws->out_d, out->ends, size_t(out->capacity) * 4, mem, &d_e);
     if (out->skips) e = e ? e : out_target(ws->out_e, out->skips, size_t(out->capacity), mem, &d_sk);
     if (e) return e;
-    EncodeWork w{};
-    w.n_waves = grid * kWavesPerBlock;
-    w.wave_off = ws->wave_off.as<long long>();
-    w.row_cnt = ws->row_cnt.as<int32_t>();
-    w.tile_off = ws->tiles.as<long long>();
-    w.stage_cap = INT32_MAX;
-    w.status = ws->status.as<RunStatus>();
-    OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-    // range validation of the inputs (the staging arenas it also computes are not needed here)
-    OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);
-    if (h->dev.kind == kSplitLlama3)
-        OVTK_LAUNCH(ws->marks, "split_count", (split_kernel<0, true>), grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
-                    (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
-    else
-        OVTK_LAUNCH(ws->marks, "split_count", split_kernel<0>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w,
-                    (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
-    OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s, n_rows,
-                w, (long long)out->capacity);
-    if (h->dev.kind == kSplitLlama3)
-        OVTK_LAUNCH(ws->marks, "split_write", (split_kernel<1, true>), grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb,
-                    d_re, d_b, d_e, d_sk);
-    else
-        OVTK_LAUNCH(ws->marks, "split_write", split_kernel<1>, grid, kBlockThreads, s, d_in, h->dev, h->max_splits, w, d_rb, d_re,
-                    d_b, d_e, d_sk);
-    if (int rc = finish_status(*ws.ws, s)) return rc;
-    const RunStatus& st = *ws->host_status;
-    if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
-    if (st.flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "RegexSplit: output begins/ends too small");
-    out->n = st.n_out;
+    int64_t n_out = 0;
+    if (int rc = split_on_device(h, *ws.ws, d_in, s, d_rb, d_re, d_b, d_e, d_sk, out->capacity, &n_out)) return rc;
+    out->n = n_out;
     if (mem == OVTK_MEM_HOST) {
         OVTK_HIP(hipMemcpyAsync(out->ragged_begins, d_rb, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
         OVTK_HIP(hipMemcpyAsync(out->ragged_ends, d_re, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));
-        OVTK_HIP(hipMemcpyAsync(out->begins, d_b, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
-        OVTK_HIP(hipMemcpyAsync(out->ends, d_e, size_t(st.n_out) * 4, hipMemcpyDeviceToHost, s));
-        if (out->skips) OVTK_HIP(hipMemcpyAsync(out->skips, d_sk, size_t(st.n_out), hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->begins, d_b, size_t(n_out) * 4, hipMemcpyDeviceToHost, s));
+        OVTK_HIP(hipMemcpyAsync(out->ends, d_e, size_t(n_out) * 4, hipMemcpyDeviceToHost, s));
+        if (out->skips) OVTK_HIP(hipMemcpyAsync(out->skips, d_sk, size_t(n_out), hipMemcpyDeviceToHost, s));
         OVTK_HIP(hipStreamSynchronize(s));
     }
     return OVTK_OK;

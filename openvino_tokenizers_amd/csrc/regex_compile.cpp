@@ -1,0 +1,880 @@
+// regex_compile.cpp -- see regex_compile.hpp.  Plain host C++ (no HIP).
+#include "regex_compile.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <utility>
+
+#include "../../include/ovtk_amd.h"
+#include "unicode_gc.inc"
+
+namespace ovtk {
+namespace {
+
+// ---------------------------------------------------------------------------------------------- character sets
+constexpr uint32_t kMaxCp = 0x10FFFF;
+enum Gc : int {
+    Cn, Lu, Ll, Lt, Lm, Lo, Mn, Mc, Me, Nd, Nl, No, Pc, Pd, Ps, Pe, Pi, Pf, Po, Sm, Sc, Sk, So, Zs, Zl, Zp, Cc, Cf, Cs, Co, kGcCount
+};
+const char* const kGcNames[kGcCount] = {"Cn", "Lu", "Ll", "Lt", "Lm", "Lo", "Mn", "Mc", "Me", "Nd", "Nl", "No", "Pc", "Pd", "Ps",
+                                        "Pe", "Pi", "Pf", "Po", "Sm", "Sc", "Sk", "So", "Zs", "Zl", "Zp", "Cc", "Cf", "Cs", "Co"};
+constexpr uint32_t gc_bit(int g) { return 1u << g; }
+constexpr uint32_t kMaskL = gc_bit(Lu) | gc_bit(Ll) | gc_bit(Lt) | gc_bit(Lm) | gc_bit(Lo);
+constexpr uint32_t kMaskM = gc_bit(Mn) | gc_bit(Mc) | gc_bit(Me);
+constexpr uint32_t kMaskN = gc_bit(Nd) | gc_bit(Nl) | gc_bit(No);
+constexpr uint32_t kMaskP = gc_bit(Pc) | gc_bit(Pd) | gc_bit(Ps) | gc_bit(Pe) | gc_bit(Pi) | gc_bit(Pf) | gc_bit(Po);
+constexpr uint32_t kMaskS = gc_bit(Sm) | gc_bit(Sc) | gc_bit(Sk) | gc_bit(So);
+constexpr uint32_t kMaskZ = gc_bit(Zs) | gc_bit(Zl) | gc_bit(Zp);
+constexpr uint32_t kMaskC = gc_bit(Cn) | gc_bit(Cc) | gc_bit(Cf) | gc_bit(Cs) | gc_bit(Co);
+
+struct CharSet {
+    std::vector<std::pair<uint32_t, uint32_t>> r;  // inclusive ranges; sorted and disjoint after normalize()
+    void add(uint32_t lo, uint32_t hi) { r.emplace_back(lo, hi); }
+    void add(const CharSet& o) { r.insert(r.end(), o.r.begin(), o.r.end()); }
+    void normalize() {
+        std::sort(r.begin(), r.end());
+        std::vector<std::pair<uint32_t, uint32_t>> out;
+        for (const auto& x : r) {
+            if (!out.empty() && x.first <= out.back().second + 1) out.back().second = std::max(out.back().second, x.second);
+            else out.push_back(x);
+        }
+        r.swap(out);
+    }
+    CharSet negated() const {  // of a normalized set
+        CharSet n;
+        uint32_t next = 0;
+        for (const auto& x : r) {
+            if (x.first > next) n.add(next, x.first - 1);
+            next = x.second + 1;
+        }
+        if (next <= kMaxCp) n.add(next, kMaxCp);
+        return n;
+    }
+    bool has(uint32_t cp) const {
+        for (const auto& x : r)
+            if (cp >= x.first && cp <= x.second) return true;
+        return false;
+    }
+};
+
+int gc_of(uint32_t cp) {
+    const unsigned* p = std::upper_bound(kGcStart, kGcStart + kGcRanges + 1, cp);
+    return kGcValue[(p - kGcStart) - 1];
+}
+CharSet gc_set(uint32_t mask) {
+    CharSet s;
+    for (unsigned i = 0; i < kGcRanges; ++i)
+        if (mask >> kGcValue[i] & 1u) s.add(kGcStart[i], kGcStart[i + 1] - 1);
+    s.normalize();
+    return s;
+}
+CharSet hspace_set() {  // PCRE2 \h
+    CharSet s;
+    for (uint32_t c : {0x09u, 0x20u, 0xA0u, 0x1680u, 0x180Eu, 0x202Fu, 0x205Fu, 0x3000u}) s.add(c, c);
+    s.add(0x2000, 0x200A);
+    s.normalize();
+    return s;
+}
+CharSet vspace_set() {  // PCRE2 \v
+    CharSet s;
+    s.add(0x0A, 0x0D);
+    s.add(0x85, 0x85);
+    s.add(0x2028, 0x2029);
+    s.normalize();
+    return s;
+}
+CharSet space_set() {  // \s under UCP: property Z, or \h, or \v
+    CharSet s = gc_set(kMaskZ);
+    s.add(hspace_set());
+    s.add(vspace_set());
+    s.normalize();
+    return s;
+}
+CharSet word_set() {  // \w under UCP in PCRE2 >= 10.43 (the reference pins 10.46): L, N, Mn, Pc
+    return gc_set(kMaskL | kMaskN | gc_bit(Mn) | gc_bit(Pc));
+}
+
+// ---------------------------------------------------------------------------------------------- syntax tree
+enum NodeKind { kEmpty, kSet, kCat, kAlt, kRepeat, kAssert };
+enum AssertKind { kBot, kEot, kEotNl, kWordB, kNotWordB, kAhead, kBehind };
+struct Node {
+    NodeKind kind = kEmpty;
+    CharSet set;            // kSet; kAssert kAhead / kBehind
+    std::vector<int> kids;  // kCat, kAlt; kRepeat: one
+    int min = 0, max = 0;   // kRepeat; max < 0: unbounded
+    int mode = 0;           // kRepeat: 0 greedy, 1 lazy, 2 possessive
+    int akind = 0;
+    bool aneg = false;
+};
+
+struct Unsupported {
+    std::string what;
+};
+
+struct Flags {
+    bool caseless = false, dotall = false;
+};
+
+class Parser {
+public:
+    Parser(const std::string& utf8, std::vector<Node>& nodes) : nodes_(nodes) {
+        // the pattern as code points (the subject is UTF-8, the pattern too: PCRE2_UTF)
+        for (size_t i = 0; i < utf8.size();) {
+            const uint8_t b = uint8_t(utf8[i]);
+            int n = b < 0x80 ? 1 : (b >= 0xF0 ? 4 : (b >= 0xE0 ? 3 : (b >= 0xC0 ? 2 : 0)));
+            if (n == 0 || i + size_t(n) > utf8.size()) throw Unsupported{"pattern is not valid UTF-8"};
+            uint32_t cp = n == 1 ? b : (b & (0xFFu >> (n + 1)));
+            for (int k = 1; k < n; ++k) {
+                const uint8_t c = uint8_t(utf8[i + size_t(k)]);
+                if ((c & 0xC0) != 0x80) throw Unsupported{"pattern is not valid UTF-8"};
+                cp = (cp << 6) | (c & 0x3F);
+            }
+            p_.push_back(cp);
+            i += size_t(n);
+        }
+    }
+    int parse() {
+        Flags f;
+        const int root = parse_alt(f);
+        if (pos_ != p_.size()) throw Unsupported{"unmatched ')'"};
+        return root;
+    }
+
+private:
+    std::vector<Node>& nodes_;
+    std::vector<uint32_t> p_;
+    size_t pos_ = 0;
+
+    bool more() const { return pos_ < p_.size(); }
+    uint32_t peek(size_t k = 0) const { return pos_ + k < p_.size() ? p_[pos_ + k] : 0xFFFFFFFFu; }
+    bool eat(uint32_t c) {
+        if (peek() == c) { ++pos_; return true; }
+        return false;
+    }
+    bool looking_at(const char* s) const {
+        for (size_t k = 0; s[k]; ++k)
+            if (peek(k) != uint32_t(uint8_t(s[k]))) return false;
+        return true;
+    }
+    int add(Node n) {
+        nodes_.push_back(std::move(n));
+        return int(nodes_.size()) - 1;
+    }
+    int set_node(CharSet s) {
+        s.normalize();
+        Node n;
+        n.kind = kSet;
+        n.set = std::move(s);
+        return add(std::move(n));
+    }
+
+    // Caseless closure of explicitly written characters: ASCII letters, plus the two non-ASCII characters that fold to
+    // one (PCRE2 with UTF|UCP: 's' ~ U+017F, 'k' ~ U+212A).  Cased characters beyond ASCII are refused.
+    static void close_caseless(CharSet& s) {
+        s.normalize();
+        CharSet extra;
+        for (const auto& x : s.r) {
+            if (x.second >= 0x80 && x.second - std::max<uint32_t>(x.first, 0x80) > 0x40000) throw Unsupported{"(?i) over a wide range"};
+            for (uint32_t cp = std::max<uint32_t>(x.first, 0x80); cp <= x.second; ++cp) {
+                const int g = gc_of(cp);
+                if (g == Lu || g == Ll || g == Lt || cp == 0x345) throw Unsupported{"(?i) on a cased character outside ASCII"};
+            }
+            const uint32_t lo = x.first, hi = x.second;
+            auto clip = [&](uint32_t a, uint32_t b, int delta) {
+                const uint32_t l = std::max(lo, a), h = std::min(hi, b);
+                if (l <= h) extra.add(uint32_t(int(l) + delta), uint32_t(int(h) + delta));
+            };
+            clip('A', 'Z', 32);
+            clip('a', 'z', -32);
+        }
+        s.add(extra);
+        s.normalize();
+        if (s.has('s')) s.add(0x17F, 0x17F);
+        if (s.has('k')) s.add(0x212A, 0x212A);
+        s.normalize();
+    }
+
+    int parse_alt(Flags& f) {
+        std::vector<int> alts;
+        alts.push_back(parse_cat(f));
+        while (eat('|')) alts.push_back(parse_cat(f));
+        if (alts.size() == 1) return alts[0];
+        Node n;
+        n.kind = kAlt;
+        n.kids = std::move(alts);
+        return add(std::move(n));
+    }
+
+    int parse_cat(Flags& f) {
+        std::vector<int> items;
+        while (more() && peek() != '|' && peek() != ')') {
+            int atom = parse_atom(f);
+            if (atom < 0) continue;  // a flag setting (?i)
+            atom = parse_quantifier(atom);
+            items.push_back(atom);
+        }
+        if (items.empty()) return add(Node{});
+        if (items.size() == 1) return items[0];
+        Node n;
+        n.kind = kCat;
+        n.kids = std::move(items);
+        return add(std::move(n));
+    }
+
+    bool parse_braces(int& mn, int& mx) {  // at '{': {m} {m,} {m,n}; anything else is a literal brace
+        size_t q = pos_ + 1;
+        auto number = [&](int& v) {
+            if (!(q < p_.size() && p_[q] >= '0' && p_[q] <= '9')) return false;
+            long long x = 0;
+            while (q < p_.size() && p_[q] >= '0' && p_[q] <= '9') {
+                x = x * 10 + (p_[q] - '0');
+                if (x > 65535) throw Unsupported{"repeat count too large"};
+                ++q;
+            }
+            v = int(x);
+            return true;
+        };
+        if (!number(mn)) {
+            // "{,n}": a literal in PCRE2 up to 10.42, {0,n} from 10.43 on -- refused rather than guessed
+            size_t t = q;
+            if (t < p_.size() && p_[t] == ',') {
+                ++t;
+                const size_t d0 = t;
+                while (t < p_.size() && p_[t] >= '0' && p_[t] <= '9') ++t;
+                if (t > d0 && t < p_.size() && p_[t] == '}') throw Unsupported{"{,n} quantifier"};
+            }
+            return false;
+        }
+        mx = mn;
+        if (q < p_.size() && p_[q] == ',') {
+            ++q;
+            if (!number(mx)) mx = -1;
+        }
+        if (!(q < p_.size() && p_[q] == '}')) return false;
+        if (mx >= 0 && mx < mn) throw Unsupported{"{m,n} with n < m"};
+        pos_ = q + 1;
+        return true;
+    }
+
+    int parse_quantifier(int atom) {
+        for (int count = 0;; ++count) {
+            int mn, mx;
+            if (eat('*')) { mn = 0; mx = -1; }
+            else if (eat('+')) { mn = 1; mx = -1; }
+            else if (eat('?')) { mn = 0; mx = 1; }
+            else if (peek() == '{' && parse_braces(mn, mx)) {}
+            else return atom;
+            if (count) throw Unsupported{"quantifier on a quantifier"};
+            if (nodes_[size_t(atom)].kind == kAssert) throw Unsupported{"quantifier on an assertion"};
+            Node n;
+            n.kind = kRepeat;
+            n.kids = {atom};
+            n.min = mn;
+            n.max = mx;
+            if (eat('?')) n.mode = 1;
+            else if (eat('+')) n.mode = 2;
+            if (n.mode == 2 && nodes_[size_t(atom)].kind != kSet)
+                throw Unsupported{"possessive quantifier on something longer than one character"};
+            if (n.max > 1000 || n.min > 1000) throw Unsupported{"repeat count too large"};
+            atom = add(std::move(n));
+        }
+    }
+
+    static int hex(uint32_t c) {
+        if (c >= '0' && c <= '9') return int(c - '0');
+        if (c >= 'a' && c <= 'f') return int(c - 'a' + 10);
+        if (c >= 'A' && c <= 'F') return int(c - 'A' + 10);
+        return -1;
+    }
+
+    // \p / \P at pos_ (behind the letter): the set, by General_Category.
+    CharSet parse_property(bool negate, bool caseless = false) {
+        std::string name;
+        if (eat('{')) {
+            if (eat('^')) negate = !negate;
+            while (more() && peek() != '}') name.push_back(char(p_[pos_++]));
+            if (!eat('}')) throw Unsupported{"unterminated \\p{"};
+        } else if (more()) {
+            name.push_back(char(p_[pos_++]));
+        }
+        std::string key;
+        for (char c : name)
+            if (c != ' ' && c != '_' && c != '-') key.push_back(c);
+        uint32_t mask = 0;
+        CharSet s;
+        bool direct = false;
+        if (key == "L") mask = kMaskL;
+        else if (key == "M") mask = kMaskM;
+        else if (key == "N") mask = kMaskN;
+        else if (key == "P") mask = kMaskP;
+        else if (key == "S") mask = kMaskS;
+        else if (key == "Z") mask = kMaskZ;
+        else if (key == "C") mask = kMaskC;
+        else if (key == "L&" || key == "Lc" || key == "LC") mask = gc_bit(Lu) | gc_bit(Ll) | gc_bit(Lt);
+        else if (key == "Any" || key == "any") { s.add(0, kMaxCp); direct = true; }
+        else if (key == "Xan") mask = kMaskL | kMaskN;
+        else if (key == "Xsp" || key == "Xps") { s = space_set(); direct = true; }
+        else if (key == "Xwd") { s = word_set(); direct = true; }
+        else {
+            for (int g = 0; g < kGcCount; ++g)
+                if (key == kGcNames[g]) mask = gc_bit(g);
+            if (!mask) throw Unsupported{"\\p{" + name + "}: only General_Category properties are supported"};
+        }
+        // \p{Lu} \p{Ll} \p{Lt} match any cased letter under PCRE2's caseless rules: not reproduced
+        const uint32_t cased = gc_bit(Lu) | gc_bit(Ll) | gc_bit(Lt);
+        if (caseless && !direct && (mask & cased) && (mask & cased) != cased) throw Unsupported{"(?i) with \\p{Lu} / \\p{Ll} / \\p{Lt}"};
+        if (!direct) s = gc_set(mask);
+        s.normalize();
+        return negate ? s.negated() : s;
+    }
+
+    // An escape (pos_ behind the backslash).  Returns true and fills `set` for a character-type escape; returns false
+    // and fills `cp` for a single character.  in_class: inside [...].
+    bool parse_escape(bool in_class, CharSet& set, uint32_t& cp, bool caseless = false) {
+        if (!more()) throw Unsupported{"pattern ends with a backslash"};
+        const uint32_t c = p_[pos_++];
+        switch (c) {
+            case 'd': set = gc_set(gc_bit(Nd)); return true;
+            case 'D': set = gc_set(gc_bit(Nd)).negated(); return true;
+            case 's': set = space_set(); return true;
+            case 'S': set = space_set().negated(); return true;
+            case 'w': set = word_set(); return true;
+            case 'W': set = word_set().negated(); return true;
+            case 'h': set = hspace_set(); return true;
+            case 'H': set = hspace_set().negated(); return true;
+            case 'v': set = vspace_set(); return true;
+            case 'V': set = vspace_set().negated(); return true;
+            case 'p': set = parse_property(false, caseless); return true;
+            case 'P': set = parse_property(true, caseless); return true;
+            case 'N':
+                if (in_class || peek() == '{') throw Unsupported{"\\N{...}"};
+                set = CharSet{};
+                set.add('\n', '\n');
+                set = set.negated();
+                return true;
+            case 't': cp = '\t'; return false;
+            case 'n': cp = '\n'; return false;
+            case 'r': cp = '\r'; return false;
+            case 'f': cp = '\f'; return false;
+            case 'e': cp = 0x1B; return false;
+            case 'a': cp = 0x07; return false;
+            case '0': {
+                uint32_t v = 0;
+                for (int k = 0; k < 2 && peek() >= '0' && peek() <= '7'; ++k) v = v * 8 + (p_[pos_++] - '0');
+                cp = v;
+                return false;
+            }
+            case 'x': {
+                uint32_t v = 0;
+                if (eat('{')) {
+                    int digits = 0;
+                    while (more() && hex(peek()) >= 0) {
+                        v = v * 16 + uint32_t(hex(p_[pos_++]));
+                        if (++digits > 6) throw Unsupported{"\\x{...} too long"};
+                    }
+                    if (!eat('}') || digits == 0) throw Unsupported{"malformed \\x{...}"};
+                } else {
+                    for (int k = 0; k < 2 && more() && hex(peek()) >= 0; ++k) v = v * 16 + uint32_t(hex(p_[pos_++]));
+                }
+                if (v > kMaxCp) throw Unsupported{"\\x beyond U+10FFFF"};
+                cp = v;
+                return false;
+            }
+            case 'b':
+                if (in_class) { cp = 0x08; return false; }
+                break;
+            default: break;
+        }
+        if (c < 0x80 && ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')))
+            throw Unsupported{std::string("escape \\") + char(c)};
+        cp = c;  // an escaped punctuation / non-ASCII character stands for itself
+        return false;
+    }
+
+    int parse_class(const Flags& f) {  // pos_ behind '['
+        const bool negate = eat('^');
+        CharSet explicit_chars, props;
+        bool first = true, after_class_item = false;
+        for (;;) {
+            if (!more()) throw Unsupported{"unterminated character class"};
+            uint32_t c = p_[pos_];
+            if (c == ']' && !first) { ++pos_; break; }
+            first = false;
+            // "[\d-x]": PCRE2 rejects a range that starts at a class escape / POSIX class (only "-]" is a literal hyphen there)
+            if (c == '-' && after_class_item && peek(1) != ']') throw Unsupported{"hyphen behind a class escape"};
+            after_class_item = false;
+            if (c == '[' && peek(1) == ':') {  // POSIX class; under UCP: Unicode properties
+                size_t q = pos_ + 2;
+                bool neg = false;
+                if (q < p_.size() && p_[q] == '^') { neg = true; ++q; }
+                std::string name;
+                while (q < p_.size() && p_[q] != ':') name.push_back(char(p_[q++]));
+                if (!(q + 1 < p_.size() && p_[q + 1] == ']')) throw Unsupported{"malformed POSIX class"};
+                pos_ = q + 2;
+                CharSet s;
+                if (name == "alpha") s = gc_set(kMaskL);
+                else if (name == "lower") s = gc_set(gc_bit(Ll));
+                else if (name == "upper") s = gc_set(gc_bit(Lu));
+                else if (name == "alnum") s = gc_set(kMaskL | kMaskN);
+                else if (name == "digit") s = gc_set(gc_bit(Nd));
+                else if (name == "space") s = space_set();
+                else if (name == "word") s = word_set();
+                else throw Unsupported{"POSIX class [:" + name + ":]"};
+                if ((name == "lower" || name == "upper") && f.caseless) throw Unsupported{"(?i) with [:lower:] / [:upper:]"};
+                props.add(neg ? s.negated() : s);
+                after_class_item = true;
+                continue;
+            }
+            if (c == '[' && (peek(1) == '.' || peek(1) == '=')) throw Unsupported{"POSIX collating element"};
+            uint32_t lo;
+            ++pos_;
+            if (c == '\\') {
+                if (looking_at("Q")) throw Unsupported{"\\Q inside a class"};
+                CharSet s;
+                if (parse_escape(true, s, lo, f.caseless)) {
+                    props.add(s);
+                    after_class_item = true;
+                    continue;
+                }
+            } else {
+                lo = c;
+            }
+            uint32_t hi = lo;
+            if (peek() == '-' && peek(1) != ']' && pos_ + 1 < p_.size()) {
+                ++pos_;
+                uint32_t c2 = p_[pos_++];
+                if (c2 == '\\') {
+                    CharSet s;
+                    if (parse_escape(true, s, hi, f.caseless)) throw Unsupported{"class range that ends at a class escape"};
+                } else if (c2 == '[' && peek() == ':') {
+                    throw Unsupported{"class range that ends at a POSIX class"};
+                } else {
+                    hi = c2;
+                }
+                if (hi < lo) throw Unsupported{"class range out of order"};
+            }
+            explicit_chars.add(lo, hi);
+        }
+        if (f.caseless) close_caseless(explicit_chars);
+        explicit_chars.add(props);
+        explicit_chars.normalize();
+        return set_node(negate ? explicit_chars.negated() : explicit_chars);
+    }
+
+    int assert_node(int kind, bool neg = false, CharSet set = CharSet{}) {
+        Node n;
+        n.kind = kAssert;
+        n.akind = kind;
+        n.aneg = neg;
+        set.normalize();
+        n.set = std::move(set);
+        return add(std::move(n));
+    }
+
+    // The body of a look-around group as ONE character set (a class, a literal, an alternation of those).
+    bool single_char_set(int node, CharSet& out) const {
+        const Node& n = nodes_[size_t(node)];
+        if (n.kind == kSet) { out.add(n.set); return true; }
+        if (n.kind == kAlt) {
+            for (int k : n.kids)
+                if (!single_char_set(k, out)) return false;
+            return true;
+        }
+        return false;
+    }
+
+    int parse_group(Flags& outer) {  // pos_ behind '('
+        Flags f = outer;
+        if (eat('?')) {
+            if (eat(':')) {
+            } else if (peek() == '=' || peek() == '!') {
+                const bool neg = p_[pos_++] == '!';
+                const int body = parse_alt(f);
+                if (!eat(')')) throw Unsupported{"unterminated group"};
+                CharSet s;
+                if (!single_char_set(body, s)) throw Unsupported{"look-ahead on more than one character"};
+                return assert_node(kAhead, neg, s);
+            } else if (peek() == '<' && (peek(1) == '=' || peek(1) == '!')) {
+                const bool neg = peek(1) == '!';
+                pos_ += 2;
+                const int body = parse_alt(f);
+                if (!eat(')')) throw Unsupported{"unterminated group"};
+                CharSet s;
+                if (!single_char_set(body, s)) throw Unsupported{"look-behind on more than one character"};
+                return assert_node(kBehind, neg, s);
+            } else if (peek() == '<' || looking_at("P<") || peek() == '\'') {  // named capture: a plain group here
+                const uint32_t close = peek() == '\'' ? '\'' : '>';
+                while (more() && peek() != close) ++pos_;
+                if (!eat(close)) throw Unsupported{"malformed group name"};
+            } else {
+                // flag settings: (?i) (?s) (?is) (?-i) ... and the scoped form (?i: ... )
+                bool on = true, any = false;
+                Flags g = f;
+                while (more() && peek() != ')' && peek() != ':') {
+                    const uint32_t c = p_[pos_++];
+                    if (c == '-') on = false;
+                    else if (c == 'i') g.caseless = on;
+                    else if (c == 's') g.dotall = on;
+                    else throw Unsupported{std::string("group option (?") + char(c < 0x80 ? c : '?') + ")"};
+                    any = true;
+                }
+                if (!any) throw Unsupported{"unsupported group type"};
+                if (eat(')')) {  // applies to the rest of the enclosing group, later alternatives included
+                    outer = g;
+                    return -1;
+                }
+                if (!eat(':')) throw Unsupported{"malformed group options"};
+                f = g;
+            }
+        } else if (peek() == '*') {
+            throw Unsupported{"(*VERB)"};
+        }
+        const int body = parse_alt(f);
+        if (!eat(')')) throw Unsupported{"unterminated group"};
+        return body;
+    }
+
+    int literal(uint32_t cp, const Flags& f) {
+        CharSet s;
+        s.add(cp, cp);
+        if (f.caseless) close_caseless(s);
+        return set_node(s);
+    }
+
+    int parse_atom(Flags& f) {
+        const uint32_t c = p_[pos_++];
+        switch (c) {
+            case '(': return parse_group(f);
+            case '[': return parse_class(f);
+            case '.': {
+                CharSet s;
+                if (f.dotall) s.add(0, kMaxCp);
+                else { s.add('\n', '\n'); s = s.negated(); }
+                return set_node(s);
+            }
+            case '^': return assert_node(kBot);
+            case '$': return assert_node(kEotNl);
+            case '*': case '+': case '?': throw Unsupported{"quantifier without an operand"};
+            case '\\': {
+                if (eat('Q')) {  // \Q ... \E: literal text
+                    std::vector<int> items;
+                    while (more() && !looking_at("\\E")) items.push_back(literal(p_[pos_++], f));
+                    if (more()) pos_ += 2;
+                    if (items.empty()) return -1;
+                    if (items.size() == 1) return items[0];
+                    // quantifiers apply to the last character only: return a concatenation whose last element the
+                    // caller cannot separate -- refuse the rare quantified form
+                    if (peek() == '*' || peek() == '+' || peek() == '?' || peek() == '{') throw Unsupported{"quantifier behind \\E"};
+                    Node n;
+                    n.kind = kCat;
+                    n.kids = std::move(items);
+                    return add(std::move(n));
+                }
+                if (eat('E')) return -1;
+                switch (peek()) {
+                    case 'A': ++pos_; return assert_node(kBot);
+                    case 'z': ++pos_; return assert_node(kEot);
+                    case 'Z': ++pos_; return assert_node(kEotNl);
+                    case 'b': ++pos_; return assert_node(kWordB);
+                    case 'B': ++pos_; return assert_node(kNotWordB);
+                    case 'G': case 'K': case 'R': case 'X': case 'C': case 'g': case 'k':
+                        throw Unsupported{std::string("escape \\") + char(peek())};
+                    default: break;
+                }
+                if (peek() >= '1' && peek() <= '9') throw Unsupported{"back-reference"};
+                CharSet s;
+                uint32_t cp = 0;
+                if (parse_escape(false, s, cp, f.caseless)) return set_node(s);
+                return literal(cp, f);
+            }
+            default: return literal(c, f);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------- backtracking automaton
+enum Op : uint8_t { kChar, kSplit, kJmp, kAssertOp, kMatch };
+struct Inst {
+    Op op;
+    int x = 0, y = 0;  // kChar: x = set id, y = next; kSplit: x preferred, y other; kJmp: x; kAssertOp: x = assert id, y = next
+};
+struct AssertInfo {
+    int kind;
+    bool neg;
+    int set;  // index into sets, or -1
+};
+
+struct Builder {
+    const std::vector<Node>& nodes;
+    std::vector<Inst> prog;
+    std::vector<CharSet> sets;
+    std::vector<AssertInfo> asserts;
+
+    int set_id(const CharSet& s) {
+        for (size_t i = 0; i < sets.size(); ++i)
+            if (sets[i].r == s.r) return int(i);
+        sets.push_back(s);
+        return int(sets.size()) - 1;
+    }
+    int emit(Inst i) {
+        if (prog.size() > 20000) throw Unsupported{"pattern too large"};
+        prog.push_back(i);
+        return int(prog.size()) - 1;
+    }
+    int emit_assert(int kind, bool neg, const CharSet* s, int next) {
+        asserts.push_back(AssertInfo{kind, neg, s ? set_id(*s) : -1});
+        return emit(Inst{kAssertOp, int(asserts.size()) - 1, next});
+    }
+    // Code that matches node `n` and continues at `next`; returns its entry.
+    int gen(int n, int next) {
+        const Node& nd = nodes[size_t(n)];
+        switch (nd.kind) {
+            case kEmpty: return next;
+            case kSet: return emit(Inst{kChar, set_id(nd.set), next});
+            case kCat: {
+                int e = next;
+                for (size_t k = nd.kids.size(); k-- > 0;) e = gen(nd.kids[k], e);
+                return e;
+            }
+            case kAlt: {
+                std::vector<int> entries;
+                for (int k : nd.kids) entries.push_back(gen(k, next));
+                int e = entries.back();
+                for (size_t k = entries.size() - 1; k-- > 0;) e = emit(Inst{kSplit, entries[k], e});
+                return e;
+            }
+            case kAssert: return emit_assert(nd.akind, nd.aneg, (nd.akind == kAhead || nd.akind == kBehind) ? &nd.set : nullptr, next);
+            case kRepeat: {
+                const int child = nd.kids[0];
+                // where the "no further repetition" edge goes: straight on, or (possessive X: never give a character
+                // back) through "the next character is not an X"
+                auto skip_target = [&](int to) {
+                    if (nd.mode != 2) return to;
+                    return emit_assert(kAhead, true, &nodes[size_t(child)].set, to);
+                };
+                auto split = [&](int body, int skip) {
+                    return nd.mode == 1 ? emit(Inst{kSplit, skip, body}) : emit(Inst{kSplit, body, skip});
+                };
+                int e = next;
+                if (nd.max < 0) {
+                    const int loop = emit(Inst{kSplit, 0, 0});
+                    const int body = gen(child, loop);
+                    const int skip = skip_target(next);
+                    prog[size_t(loop)] = nd.mode == 1 ? Inst{kSplit, skip, body} : Inst{kSplit, body, skip};
+                    e = loop;
+                } else {
+                    for (int k = nd.min; k < nd.max; ++k) {
+                        const int body = gen(child, e);
+                        e = split(body, skip_target(next));
+                    }
+                }
+                for (int k = 0; k < nd.min; ++k) e = gen(child, e);
+                return e;
+            }
+        }
+        return next;
+    }
+};
+
+}  // namespace
+
+int compile_regex(const std::string& pattern, RegexProgram& out, std::string& err) {
+    try {
+        std::vector<Node> nodes;
+        Parser parser(pattern, nodes);
+        const int root = parser.parse();
+        Builder b{nodes, {}, {}, {}};
+        const int match_pc = b.emit(Inst{kMatch});
+        const int entry = b.gen(root, match_pc);
+
+        // ---- which contexts the assertions look at
+        bool uses_bot = false, uses_word = false, uses_final_nl = false;
+        std::vector<int> behind_sets;
+        for (const AssertInfo& a : b.asserts) {
+            if (a.kind == kBot) uses_bot = true;
+            if (a.kind == kWordB || a.kind == kNotWordB) uses_word = true;
+            if (a.kind == kEotNl) uses_final_nl = true;
+            if (a.kind == kBehind) behind_sets.push_back(a.set);
+        }
+        int word_set_id = -1;
+        if (uses_word) word_set_id = b.set_id(word_set());
+
+        // ---- partition of the code points: signature = membership in every set
+        const size_t n_sets = b.sets.size();
+        std::vector<uint32_t> cuts{0, 0x80, kMaxCp + 1};  // (ASCII / non-ASCII is not a class border by itself; harmless)
+        for (const CharSet& s : b.sets)
+            for (const auto& r : s.r) {
+                cuts.push_back(r.first);
+                cuts.push_back(r.second + 1);
+            }
+        std::sort(cuts.begin(), cuts.end());
+        cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+        std::map<std::vector<bool>, int> class_of_sig;
+        std::vector<std::vector<bool>> sig_of_class;
+        std::vector<uint8_t> cls(size_t(kMaxCp) + 1, 0);
+        for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+            const uint32_t lo = cuts[i], hi = cuts[i + 1] - 1;
+            std::vector<bool> sig(n_sets);
+            for (size_t s = 0; s < n_sets; ++s) sig[s] = b.sets[s].has(lo);
+            auto it = class_of_sig.find(sig);
+            if (it == class_of_sig.end()) {
+                if (sig_of_class.size() >= size_t(kRegexMaxClasses)) throw Unsupported{"too many character classes"};
+                it = class_of_sig.emplace(sig, int(sig_of_class.size())).first;
+                sig_of_class.push_back(sig);
+            }
+            std::fill(cls.begin() + lo, cls.begin() + hi + 1, uint8_t(it->second));
+        }
+        const int n_classes = int(sig_of_class.size());
+        const int sym_eot = n_classes, sym_final_nl = uses_final_nl ? n_classes + 1 : -1;
+        const int n_syms = n_classes + 1 + (uses_final_nl ? 1 : 0);
+        const int nl_class = cls['\n'];
+        auto sym_class = [&](int sym) { return sym == sym_final_nl ? nl_class : (sym < n_classes ? sym : -1); };
+
+        // ---- "previous character" contexts: 0 = start of subject, else 1 + signature over the sets looked at behind
+        std::vector<int> ctx_sets = behind_sets;
+        if (uses_word) ctx_sets.push_back(word_set_id);
+        std::sort(ctx_sets.begin(), ctx_sets.end());
+        ctx_sets.erase(std::unique(ctx_sets.begin(), ctx_sets.end()), ctx_sets.end());
+        const bool track_ctx = uses_bot || !ctx_sets.empty();
+        std::vector<uint8_t> ctx_of_class(size_t(n_classes), 0);
+        std::vector<std::vector<bool>> ctx_sig{std::vector<bool>(ctx_sets.size(), false)};  // ctx 0: nothing behind
+        int n_ctx = 1;
+        if (track_ctx) {
+            std::map<std::vector<bool>, int> ids;
+            for (int c = 0; c < n_classes; ++c) {
+                std::vector<bool> sig(ctx_sets.size());
+                for (size_t k = 0; k < ctx_sets.size(); ++k) sig[k] = sig_of_class[size_t(c)][size_t(ctx_sets[k])];
+                auto it = ids.find(sig);
+                if (it == ids.end()) {
+                    if (n_ctx >= kRegexMaxCtx) throw Unsupported{"too many look-behind contexts"};
+                    it = ids.emplace(sig, n_ctx++).first;
+                    ctx_sig.push_back(sig);
+                }
+                ctx_of_class[size_t(c)] = uint8_t(it->second);
+            }
+        }
+        auto ctx_has = [&](int ctx, int set) {
+            if (ctx == 0) return false;
+            for (size_t k = 0; k < ctx_sets.size(); ++k)
+                if (ctx_sets[k] == set) return bool(ctx_sig[size_t(ctx)][k]);
+            return false;
+        };
+
+        // ---- subset construction over ordered position lists
+        using Key = std::pair<int, std::vector<int>>;  // (context, positions in priority order)
+        std::map<Key, int> ids;
+        std::vector<Key> states;
+        states.push_back(Key{0, {}});  // state 0: dead
+        ids.emplace(states[0], 0);
+        auto intern = [&](Key k) {
+            if (k.second.empty()) return 0;
+            if (!track_ctx) k.first = 0;
+            auto it = ids.find(k);
+            if (it != ids.end()) return it->second;
+            if (states.size() >= size_t(kRegexMaxStates)) throw Unsupported{"pattern needs more than 4096 DFA states"};
+            const int id = int(states.size());
+            ids.emplace(k, id);
+            states.push_back(std::move(k));
+            return id;
+        };
+        for (int c = 0; c < n_ctx; ++c) out.start[c] = uint16_t(intern(Key{c, {entry}}));
+        std::vector<uint16_t> trans;
+        std::vector<uint8_t> seen(b.prog.size());
+        std::vector<int> pending;
+        for (size_t s = 0; s < states.size(); ++s) {
+            trans.resize((s + 1) * size_t(n_syms), 0);
+            if (s == 0) continue;
+            const Key st = states[s];  // copy: `states` grows below
+            for (int sym = 0; sym < n_syms; ++sym) {
+                const int c = sym_class(sym);
+                std::fill(seen.begin(), seen.end(), 0);
+                pending.clear();
+                bool matched = false;
+                // the closure at this position: previous character = st.first, next symbol = sym
+                std::vector<int> stack;
+                for (size_t k = st.second.size(); k-- > 0;) stack.push_back(st.second[k]);
+                while (!stack.empty() && !matched) {
+                    const int pc = stack.back();
+                    stack.pop_back();
+                    if (seen[size_t(pc)]) continue;
+                    seen[size_t(pc)] = 1;
+                    const Inst& in = b.prog[size_t(pc)];
+                    switch (in.op) {
+                        case kJmp: stack.push_back(in.x); break;
+                        case kSplit:
+                            stack.push_back(in.y);
+                            stack.push_back(in.x);
+                            break;
+                        case kChar: pending.push_back(pc); break;
+                        case kMatch: matched = true; break;  // everything of lower priority is cut
+                        case kAssertOp: {
+                            const AssertInfo& a = b.asserts[size_t(in.x)];
+                            bool ok = false;
+                            switch (a.kind) {
+                                case kBot: ok = st.first == 0; break;
+                                case kEot: ok = sym == sym_eot; break;
+                                case kEotNl: ok = sym == sym_eot || sym == sym_final_nl; break;
+                                case kAhead: ok = (c >= 0 && sig_of_class[size_t(c)][size_t(a.set)]) != a.neg; break;
+                                case kBehind: ok = ctx_has(st.first, a.set) != a.neg; break;
+                                case kWordB:
+                                case kNotWordB: {
+                                    const bool wp = ctx_has(st.first, word_set_id);
+                                    const bool wn = c >= 0 && sig_of_class[size_t(c)][size_t(word_set_id)];
+                                    ok = (wp != wn) == (a.kind == kWordB);
+                                    break;
+                                }
+                            }
+                            if (ok) stack.push_back(in.y);
+                            break;
+                        }
+                    }
+                }
+                Key next{0, {}};
+                if (c >= 0) {
+                    next.first = ctx_of_class[size_t(c)];
+                    for (int pc : pending) {
+                        const Inst& in = b.prog[size_t(pc)];
+                        if (sig_of_class[size_t(c)][size_t(in.x)] &&
+                            std::find(next.second.begin(), next.second.end(), in.y) == next.second.end())
+                            next.second.push_back(in.y);
+                    }
+                }
+                trans[s * size_t(n_syms) + size_t(sym)] = uint16_t(intern(std::move(next))) | (matched ? kRegexMatchBit : 0);
+            }
+        }
+        out.trans = std::move(trans);
+        out.n_states = int(states.size());
+        out.n_syms = n_syms;
+        out.n_classes = n_classes;
+        out.sym_eot = sym_eot;
+        out.sym_final_nl = sym_final_nl;
+        out.n_ctx = n_ctx;
+        out.ctx_of_class = std::move(ctx_of_class);
+        out.can_match_empty = false;
+        for (int c = 0; c < n_ctx; ++c)
+            for (int sym = 0; sym < n_syms; ++sym)
+                if (out.trans[size_t(out.start[c]) * size_t(n_syms) + size_t(sym)] & kRegexMatchBit) out.can_match_empty = true;
+        std::memcpy(out.ascii_class, cls.data(), 128);
+        // two-level table over blocks of 128 code points
+        const size_t n_blocks_all = (size_t(kMaxCp) + 1) >> 7;
+        out.cp_index.assign(n_blocks_all, 0);
+        out.cp_blocks.clear();
+        std::map<std::vector<uint8_t>, int> block_ids;
+        for (size_t blk = 0; blk < n_blocks_all; ++blk) {
+            std::vector<uint8_t> v(cls.begin() + long(blk * 128), cls.begin() + long(blk * 128 + 128));
+            auto it = block_ids.find(v);
+            if (it == block_ids.end()) {
+                it = block_ids.emplace(v, int(block_ids.size())).first;
+                out.cp_blocks.insert(out.cp_blocks.end(), v.begin(), v.end());
+            }
+            out.cp_index[blk] = uint16_t(it->second);
+        }
+        return OVTK_OK;
+    } catch (const Unsupported& u) {
+        err = "RegexSplit: pattern outside the subset compiled for the GPU (" + u.what + "); PCRE2 is not executed on the device";
+        return OVTK_E_UNSUPPORTED;
+    }
+}
+
+}  // namespace ovtk

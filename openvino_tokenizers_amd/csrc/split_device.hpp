@@ -46,6 +46,7 @@ enum SplitKind : int32_t {
     kSplitBertPunct = 3,   // bert_keep_delimeters_splitter(): one char of [!-/] [:-@] [\[-`] [{-~] \p{P} or the CJK blocks
     kSplitBertWords = 4,   // both of the above chained (\s+ removed, then delimiters isolated): the fused WordPiece path
     kSplitLlama3 = 5,      // tiktoken-style pattern of Llama-3 (llama3_start_mask; its kernels are separate instantiations)
+    kSplitGeneral = 6,     // any other pattern: the DFA of regex_compile.cpp, one lane per row (regex_device.hpp)
 };
 
 struct SplitDev {
