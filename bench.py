@@ -4,13 +4,21 @@ per GPU (config 2), inputs resident in HBM, fused RegexSplit+BPETokenizer throug
 
     python bench.py [--gpus N] [--steps K] [--warmup W]           (N > 1: launched by torch.distributed.run)
     python bench.py --config 3      BERT-shaped WordPiece, 65 536 x ~256-byte strings (fused BERT split + WordPiece)
-    python bench.py --config 4      one 8-GPU shard of the Llama-3-shaped config (RegexSplit -> BPETokenizer chain, mixed scripts)
+    python bench.py --config 4      one 8-GPU shard of the Llama-3-shaped config (fused Llama-3 split + BPE, mixed scripts)
     python bench.py --config 5      detokenizer (VocabDecoder + ByteFallback + FuzeRagged fused), rows x 2048 ids
+    python bench.py --config 1      small-batch latency: 32 x ~128-byte strings, one blocking call per step
+    python bench.py --config r2d    RaggedToDense on config 2's ids ([65 536, T] ids + mask)
+    python bench.py --config vocab_encoder   VocabEncoder on ~3 M words
 
-One "step" = one pass of the hot path over one batch.  With N > 1 every rank encodes its own shard of the same size
-(weak scaling) and the step includes the all-gather of the ragged token ids over RCCL/xGMI
-(openvino_tokenizers_amd/distributed.py); `value` = bytes of all ranks / max-over-ranks time.
-Prints ONE JSON line on rank 0.  The oracle is used only for the cpu_baseline leg and a parity spot-check.
+One "step" = one pass of the hot path over one batch.  The timed loop ROTATES `--batches` (default 8) distinct input
+batches -- more than 256 MB of text in all, so a step reads its text from HBM, not from the 256 MB Infinity Cache a single
+re-fed batch would sit in.  With N > 1 every rank encodes its own shards of the same size (weak scaling) and the step
+includes the all-gather of the ragged token ids over RCCL/xGMI (openvino_tokenizers_amd/distributed.py);
+`value` = units of all ranks / max-over-ranks time.
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries, measured after the timed region: the per-kernel
+one-stream leg behind `roofline`, `stress` (uniform-random text; piece memo off), `end_to_end` (pinned host buffers in
+and out over PCIe) and the CPU baselines (1 core, and all host cores sharing one tokenizer).  The oracle is used only for
+the cpu_baseline legs and a parity spot-check.
 """
 from __future__ import annotations
 
@@ -19,6 +27,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -33,24 +42,44 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from openvino_tokenizers_amd import _lib as L  # noqa: E402
-from openvino_tokenizers_amd.ops import (BPETokenizer, RegexSplit, VocabDecoder, WordpieceTokenizer)  # noqa: E402
+from openvino_tokenizers_amd.ops import (BPETokenizer, RegexSplit, VocabDecoder, VocabEncoder, WordpieceTokenizer)  # noqa: E402
 from tools.harness import BpeTok, pack_strings  # noqa: E402
 from tools.make_tokenizers import load_tokenizer  # noqa: E402
 from tools.workloads import TextModel, ragged_rows  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 KERNEL_NAMES = {"lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>", "shard_pack": "shard_pack_kernel",
-                "shard_unpack": "shard_unpack_kernel",
+                "shard_unpack": "shard_unpack_kernel", "scan_rows": "scan_kernel", "lookup_flat": "piece_lookup_kernel",
                 "lookup_words": "lookup_kernel<kFused> (BERT words)", "wordpiece_deferred": "wordpiece_deferred_kernel",
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",
                 "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel", "split_count": "split_kernel<0>",
-                "split_write": "split_kernel<1>",
+                "split_write": "split_kernel<1>", "ragged_to_dense": "ragged_to_dense_kernel", "vocab_encoder": "vocab_encoder_kernel",
                 "detokenize": "decode_write_kernel", "decode_count": "decode_count_kernel", "decode_scan": "tile_{reduce,scan,apply}_kernel<UnitLen>"}
 BERT_WS = r"\s+"
 BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\x{4E00}-\x{9FFF}]", r"[\x{3400}-\x{4DBF}]",
                        r"[\x{20000}-\x{2A6DF}]", r"[\x{2A700}-\x{2B73F}]", r"[\x{2B740}-\x{2B81F}]",
                        r"[\x{2B820}-\x{2CEAF}]", r"[\x{F900}-\x{FAFF}]", r"[\x{2F800}-\x{2FA1F}]"])
 PMC_FILE = ROOT / "profiles" / "latest_pmc.json"  # HBM traffic of the dominant kernels from a separate rocprofv3 --pmc run
+
+
+class TextBatches:
+    """`n` distinct text batches (one string per row) resident in HBM; batch k of the rotation is k % n."""
+
+    def __init__(self, model, rows, nbytes, seeds, dev, lower=False):
+        self.rows, self.dev, self.host, self.d, self.rs, self.n_chars = rows, dev, [], [], [], []
+        rb, re_ = ragged_rows(rows)
+        for seed in seeds:
+            begins, ends, chars = model.batch(rows, nbytes, seed=seed)
+            if lower:
+                chars = np.frombuffer(chars.tobytes().lower(), np.uint8).copy()
+            d = [torch.as_tensor(x, device=dev) for x in (rb, re_, begins, ends, chars)]
+            self.host.append((rb, re_, begins, ends, chars) if not self.host else None)  # batch 0 stays on the host: CPU legs
+            self.d.append(d)
+            self.n_chars.append(int(len(chars)))
+            self.rs.append(L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), rows,
+                                           L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), rows, len(chars))))
+        self.n = len(self.rs)
+        self.cap = max(self.n_chars)
 
 
 class IdOut:
@@ -67,237 +96,232 @@ class IdOut:
             ids = torch.empty(cap, dtype=torch.int32, device=dev)
             self.sets.append((b, e, ids, L.RaggedI32Out(b.data_ptr(), e.data_ptr(), ids.data_ptr(), cap, 0, 0)))
         self.k = 0
-        self.last = self.sets[0]
 
     def take(self):
-        self.last = self.sets[self.k % self.SETS]
+        s = self.sets[self.k % self.SETS]
         self.k += 1
-        return self.last
-
-    @property
-    def n_data(self):
-        return self.last[3].n_data
+        return s
 
 
-class Workload:
-    """One BASELINE.json configuration: how to build the inputs, run a step, count units, and check/baseline it."""
-    metric = "input MB/s encoded (GPT-2 BPE, 512-byte strings)"
+class EncodeWorkload:
+    """A ragged-strings -> ragged-ids workload over rotating batches; `launch(rs, skips, out, stream, pending)` /
+    `run(rs, out, stream)` are the library calls of the concrete op chain."""
     unit = "MB/s"
+    dtype = "u8/int32"
 
+    def __init__(self, lib, dev, batches):
+        self.lib, self.dev, self.batches = lib, dev, batches
+        self.out = IdOut(batches.rows, batches.cap, dev)
+        self.n_out = {}  # batch index -> ids produced
+        self.stream0 = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
-def make_encode_bpe(args, lib, dev, rank):
-    tok = BpeTok.load(args.tokenizer)
-    begins, ends, chars = TextModel(1234, args.text).batch(args.rows, args.bytes, seed=1000 + rank)
-    rb, re_ = ragged_rows(args.rows)
-    n_chars = int(len(chars))
-    d = [torch.as_tensor(x, device=dev) for x in (rb, re_, begins, ends, chars)]
-    split = RegexSplit("isolate", device=dev.index, lib=lib)
-    bpe = BPETokenizer(**dict(tok.attrs, cache_capacity=0 if args.no_memo else tok.attrs.get("cache_capacity", 20000)),
-                       device=dev.index, lib=lib)
-    split._ensure(tok.pattern_u8())
-    bpe._ensure(d + tok.consts)
-    rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), args.rows,
-                         L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), args.rows, n_chars))
-    out = IdOut(args.rows, n_chars, dev)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    def units(self, i):
+        return self.batches.n_chars[i % self.batches.n]
 
-    def step():
-        o_begins, o_ends, o_ids, o = out.take()
-        L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, stream))
+    def step(self, i):
+        k = i % self.batches.n
+        o_begins, o_ends, o_ids, o = self.out.take()
+        L.check(self.lib, self.run(self.batches.rs[k], o, self.stream0))
+        self.n_out[k] = int(o.n_data)
         return o_begins, o_ends, o_ids[: o.n_data]
 
-    def enqueue(st=stream):
-        """The same step in two halves (ovtk_encode_enqueue / ovtk_encode_finish) on HIP stream `st`: -> finish() ->
-        (begins, ends, ids)."""
-        o_begins, o_ends, o_ids, o = out.take()
+    def enqueue(self, i, st=None):
+        k = i % self.batches.n
+        o_begins, o_ends, o_ids, o = self.out.take()
         pending = C.c_void_p()
-        L.check(lib, lib.ovtk_encode_enqueue(split._h, bpe._h, C.byref(rs), None, C.byref(o), st, C.byref(pending)))
+        L.check(self.lib, self.launch(self.batches.rs[k], o, st or self.stream0, pending))
 
         def finish():
-            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
+            L.check(self.lib, self.lib.ovtk_encode_finish(pending, C.byref(o)))
+            self.n_out[k] = int(o.n_data)
             return o_begins, o_ends, o_ids[: o.n_data]
         return finish
 
-    def cpu(n_s):
+    def algo(self):
+        """algorithmic bytes of one pass, A_enc = N_c + 4 N_t + 16 B, averaged over the rotation."""
+        ks = sorted(self.n_out)
+        return float(np.mean([self.batches.n_chars[k] + 4 * self.n_out[k] + 16 * self.batches.rows for k in ks]))
+
+    def mean_out(self):
+        return float(np.mean(list(self.n_out.values())))
+
+
+class BpeEncode(EncodeWorkload):
+    def __init__(self, args, lib, dev, rank, tokenizer, kind, rows, nbytes, seed0, no_memo=False, n_batches=None):
+        self.tok = BpeTok.load(tokenizer)
+        model = TextModel(1234, kind)
+        nb = n_batches or args.batches
+        super().__init__(lib, dev, TextBatches(model, rows, nbytes, [seed0 + 100 * rank + 7 * j for j in range(nb)], dev))
+        self.split = RegexSplit("isolate", device=dev.index, lib=lib)
+        attrs = dict(self.tok.attrs)
+        if no_memo:
+            attrs["cache_capacity"] = 0
+        self.bpe = BPETokenizer(**attrs, device=dev.index, lib=lib)
+        self.split._ensure(self.tok.pattern_u8())
+        self.bpe._ensure(self.batches.d[0] + self.tok.consts)
+        self.vocab = len(self.tok.vocab)
+
+    def run(self, rs, o, st):
+        return self.lib.ovtk_encode_run(self.split._h, self.bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, st)
+
+    def launch(self, rs, o, st, pending):
+        return self.lib.ovtk_encode_enqueue(self.split._h, self.bpe._h, C.byref(rs), None, C.byref(o), st, C.byref(pending))
+
+    def cpu_chain(self):
         from oracle import oracle as O
-        orc, ors = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
-        ref = orc(*ors(rb[:1024], re_[:1024], begins[:1024], ends[:1024], chars)[:5])  # parity prefix + warms the piece cache
-        t1 = time.perf_counter()
-        orc(*ors(rb[:n_s], re_[:n_s], begins[:n_s], ends[:n_s], chars)[:5])
-        return ref, time.perf_counter() - t1, int(ends[n_s - 1] - begins[0]), "RegexSplit(PCRE2 JIT)+BPETokenizer restatement with warm piece cache"
-
-    workload = (f"config 2: GPT-2-shaped byte-level BPE (V=50257, 50000 merges, trained in-process), {args.rows} x "
-                f"~{args.bytes}-byte {args.text} strings per GPU, fused RegexSplit+BPETokenizer, inputs and outputs in HBM"
-                + (", piece memo disabled (cache_capacity=0)" if args.no_memo else ""))
-    return dict(step=step, enqueue=enqueue, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe), workload=workload, vocab=len(tok.vocab),
-                dominant="lookup_fused",
-                metric="input MB/s encoded (GPT-2 BPE, 512-byte strings)", dtype="u8/int32",
-                algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=args.rows)
+        orc, ors = self.tok.oracle(), O.RegexSplit(self.tok.pattern, "isolate")
+        return (lambda rb, re_, b, e, c: orc(*ors(rb, re_, b, e, c)[:5])), "RegexSplit(PCRE2 JIT)+BPETokenizer restatement, piece cache warm"
 
 
-def make_encode_llama3(args, lib, dev, rank):
-    """Config 4 shard: Llama-3-shaped byte-level BPE (tiktoken-style split pattern, 128k merges) on mixed-script text,
-    fused RegexSplit + BPETokenizer (bit-parallel Llama-3 scanner)."""
-    tok = BpeTok.load("llama3")
-    rows = args.rows if args.rows != 65536 else 131072  # 1 M rows / 8 GPUs
-    begins, ends, chars = TextModel(1234, "mixed").batch(rows, args.bytes, seed=4000 + rank)
-    rb, re_ = ragged_rows(rows)
-    n_chars = int(len(chars))
-    d = [torch.as_tensor(x, device=dev) for x in (rb, re_, begins, ends, chars)]
-    split = RegexSplit("isolate", device=dev.index, lib=lib)
-    bpe = BPETokenizer(**tok.attrs, device=dev.index, lib=lib)
-    split._ensure(tok.pattern_u8())
-    bpe._ensure(d + tok.consts)
-    rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), rows, L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), rows, n_chars))
-    out = IdOut(rows, n_chars, dev)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+class WordpieceEncode(EncodeWorkload):
+    def __init__(self, args, lib, dev, rank):
+        self.tok = load_tokenizer("bert")
+        nbytes = args.bytes if args.bytes != 512 else 256
+        self.nbytes = nbytes
+        model = TextModel(1234, "zipf")
+        super().__init__(lib, dev, TextBatches(model, args.rows, nbytes, [2000 + 100 * rank + 7 * j for j in range(args.batches)], dev,
+                                               lower=True))  # BERT-uncased normalisation is upstream of this path
+        self.ws = RegexSplit("remove", device=dev.index, lib=lib)
+        self.pu = RegexSplit("isolate", device=dev.index, lib=lib)
+        self.wp = WordpieceTokenizer(self.tok["suffix_indicator"], self.tok["max_bytes_per_word"], device=dev.index, lib=lib)
+        self.ws._ensure(BERT_WS)
+        self.pu._ensure(BERT_PUNCT)
+        consts = list(pack_strings(self.tok["vocab"])) + [np.asarray(self.tok["unk_id"], np.int32)]
+        self.wp._ensure(self.batches.d[0] + consts)
+        self.unk = C.c_int32(int(self.tok["unk_id"]))
+        self.vocab = len(self.tok["vocab"])
 
-    def step():
-        o_begins, o_ends, o_ids, o = out.take()
-        L.check(lib, lib.ovtk_encode_run(split._h, bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, stream))
-        return o_begins, o_ends, o_ids[: o.n_data]
+    def run(self, rs, o, st):
+        return self.lib.ovtk_wordpiece_encode_run(self.wp._h, self.ws._h, self.pu._h, C.byref(rs), self.unk, C.byref(o), L.MEM_DEVICE, st)
 
-    def enqueue(st=stream):
-        o_begins, o_ends, o_ids, o = out.take()
-        pending = C.c_void_p()
-        L.check(lib, lib.ovtk_encode_enqueue(split._h, bpe._h, C.byref(rs), None, C.byref(o), st, C.byref(pending)))
+    def launch(self, rs, o, st, pending):
+        return self.lib.ovtk_wordpiece_encode_enqueue(self.wp._h, self.ws._h, self.pu._h, C.byref(rs), self.unk, C.byref(o), st,
+                                                      C.byref(pending))
 
-        def finish():
-            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
-            return o_begins, o_ends, o_ids[: o.n_data]
-        return finish
-
-    def cpu(n_s):
+    def cpu_chain(self):
         from oracle import oracle as O
-        orc, ors = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
-        ref = orc(*ors(rb[:1024], re_[:1024], begins[:1024], ends[:1024], chars)[:5])
-        t1 = time.perf_counter()
-        orc(*ors(rb[:n_s], re_[:n_s], begins[:n_s], ends[:n_s], chars)[:5])
-        return ref, time.perf_counter() - t1, int(ends[n_s - 1] - begins[0]), "RegexSplit(PCRE2 JIT)+BPETokenizer restatement with warm piece cache"
-
-    workload = (f"config 4 shard: Llama-3-shaped byte-level BPE (V=128256, 127999 merges, trained in-process), {rows} x "
-                f"~{args.bytes}-byte mixed-script strings per GPU, fused RegexSplit (tiktoken-style pattern) + BPETokenizer, "
-                f"inputs and outputs in HBM")
-    return dict(step=step, enqueue=enqueue, cpu=cpu, n_units=n_chars, out=out, keep=(d, split, bpe), vocab=len(tok.vocab),
-                dominant="lookup_fused",
-                workload=workload, metric="input MB/s encoded (Llama-3 BPE, 512-byte mixed-script strings)", dtype="u8/int32",
-                rows=rows, algo=lambda n_tok: n_chars + 4 * n_tok + 16 * rows, sample_rows=min(rows, 16384))
-
-
-def make_encode_wordpiece(args, lib, dev, rank):
-    tok = load_tokenizer("bert")
-    nbytes = args.bytes if args.bytes != 512 else 256
-    begins, ends, chars = TextModel(1234, "zipf").batch(args.rows, nbytes, seed=2000 + rank)
-    chars = np.frombuffer(chars.tobytes().lower(), np.uint8).copy()  # BERT-uncased normalisation is upstream of this path
-    rb, re_ = ragged_rows(args.rows)
-    n_chars = int(len(chars))
-    d = [torch.as_tensor(x, device=dev) for x in (rb, re_, begins, ends, chars)]
-    ws = RegexSplit("remove", device=dev.index, lib=lib)
-    pu = RegexSplit("isolate", device=dev.index, lib=lib)
-    wp = WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], device=dev.index, lib=lib)
-    ws._ensure(BERT_WS)
-    pu._ensure(BERT_PUNCT)
-    consts = list(pack_strings(tok["vocab"])) + [np.asarray(tok["unk_id"], np.int32)]
-    wp._ensure(d + consts)
-    rs = L.RaggedStrings(d[0].data_ptr(), d[1].data_ptr(), args.rows,
-                         L.Strings(d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), args.rows, n_chars))
-    out = IdOut(args.rows, n_chars, dev)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    unk = C.c_int32(int(tok["unk_id"]))
-
-    def step():
-        o_begins, o_ends, o_ids, o = out.take()
-        L.check(lib, lib.ovtk_wordpiece_encode_run(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(o), L.MEM_DEVICE, stream))
-        return o_begins, o_ends, o_ids[: o.n_data]
-
-    def enqueue(st=stream):
-        o_begins, o_ends, o_ids, o = out.take()
-        pending = C.c_void_p()
-        L.check(lib, lib.ovtk_wordpiece_encode_enqueue(wp._h, ws._h, pu._h, C.byref(rs), unk, C.byref(o), st, C.byref(pending)))
-
-        def finish():
-            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(o)))
-            return o_begins, o_ends, o_ids[: o.n_data]
-        return finish
-
-    def cpu(n_s):
-        from oracle import oracle as O
+        tok = self.tok
         s1, s2 = O.RegexSplit(BERT_WS, "remove"), O.RegexSplit(BERT_PUNCT, "isolate")
         owp = O.WordpieceTokenizer(tok["vocab"], tok["suffix_indicator"], tok["max_bytes_per_word"])
-        chain = lambda n: owp(*s2(*s1(rb[:n], re_[:n], begins[:n], ends[:n], chars)[:5])[:5], tok["unk_id"])
-        ref = chain(1024)
-        t1 = time.perf_counter()
-        chain(n_s)
-        return ref, time.perf_counter() - t1, int(ends[n_s - 1] - begins[0]), "2 x RegexSplit(PCRE2 JIT) + WordpieceTokenizer restatement"
-
-    workload = (f"config 3: BERT-shaped WordPiece (V=30522, trained in-process), {args.rows} x ~{nbytes}-byte lower-cased zipf "
-                f"strings per GPU, fused RegexSplit(\\s+)+RegexSplit(delimiters)+WordpieceTokenizer, inputs and outputs in HBM")
-    return dict(step=step, cpu=cpu, n_units=n_chars, out=out, enqueue=enqueue, keep=(d, ws, pu, wp), workload=workload, vocab=len(tok["vocab"]),
-                dominant="lookup_words",
-                metric="input MB/s encoded (BERT WordPiece, 256-byte strings)", dtype="u8/int32",
-                algo=lambda n_tok: n_chars + 4 * n_tok + 16 * args.rows, sample_rows=args.rows)
+        return (lambda rb, re_, b, e, c: owp(*s2(*s1(rb, re_, b, e, c)[:5])[:5], tok["unk_id"])), \
+            "2 x RegexSplit(PCRE2 JIT) + WordpieceTokenizer restatement"
 
 
-def make_detokenize(args, lib, dev, rank):
-    tok = BpeTok.load(args.tokenizer)
-    rows = args.rows if args.rows != 65536 else 16384
-    S = 2048
-    V = len(tok.vocab)
-    rng = np.random.default_rng(3000 + rank)
-    ids = rng.integers(0, V - 1, size=(rows, S), dtype=np.int32)
-    pad = V - 1                                   # the special token: 1 % of the positions, skipped by the decoder
-    ids[rng.random((rows, S)) < 0.01] = pad
-    d_ids = torch.as_tensor(ids, device=dev)
-    dec = VocabDecoder(skip_tokens=[pad], device=dev.index, lib=lib)
-    vconst = list(pack_strings(tok.vocab))
-    dec._ensure([d_ids] + vconst)
-    lens = (vconst[1] - vconst[0]).astype(np.int64)
-    n_out = int(lens[ids[ids != pad]].sum())
-    cap = n_out + 64
-    class CharsOut:
-        """Four output sets used in turn (up to three calls are in flight with --depth 2)."""
-        def __init__(self):
-            self.sets = []
-            for _ in range(4):
-                b = torch.empty(rows, dtype=torch.int32, device=dev)
-                e = torch.empty(rows, dtype=torch.int32, device=dev)
-                c = torch.empty(cap, dtype=torch.uint8, device=dev)
-                self.sets.append((b, e, c, L.StringsOut(b.data_ptr(), e.data_ptr(), c.data_ptr(), cap, 0)))
-            self.k = 0
-            self.last = self.sets[0]
+def make_workload(args, lib, dev, rank):
+    """-> (workload object or dict, description pieces)."""
+    cfg = args.config
+    if cfg == "2":
+        w = BpeEncode(args, lib, dev, rank, args.tokenizer, args.text, args.rows, args.bytes, 1000, no_memo=args.no_memo)
+        w.metric = "input MB/s encoded (GPT-2 BPE, 512-byte strings)"
+        w.dominant_hint = "lookup_fused"
+        w.workload = (f"config 2: GPT-2-shaped byte-level BPE (V=50257, 50000 merges, trained in-process), {args.rows} x "
+                      f"~{args.bytes}-byte {args.text} strings per GPU and batch, {w.batches.n} distinct batches in rotation "
+                      f"({sum(w.batches.n_chars) / 1e6:.0f} MB of text), fused RegexSplit+BPETokenizer, inputs and outputs in HBM"
+                      + (", piece memo disabled (cache_capacity=0)" if args.no_memo else ""))
+        w.sample_rows = args.rows
+        return w
+    if cfg == "4":
+        rows = args.rows if args.rows != 65536 else 131072  # 1 M rows / 8 GPUs
+        w = BpeEncode(args, lib, dev, rank, "llama3", "mixed", rows, args.bytes, 4000)
+        w.metric = "input MB/s encoded (Llama-3 BPE, 512-byte mixed-script strings)"
+        w.dominant_hint = "lookup_fused"
+        w.workload = (f"config 4 shard: Llama-3-shaped byte-level BPE (V=128256, 127999 merges, trained in-process), {rows} x "
+                      f"~{args.bytes}-byte mixed-script strings per GPU and batch, {w.batches.n} distinct batches in rotation "
+                      f"({sum(w.batches.n_chars) / 1e6:.0f} MB of text), fused RegexSplit (tiktoken-style pattern) + BPETokenizer, "
+                      f"inputs and outputs in HBM")
+        w.sample_rows = min(rows, 16384)
+        return w
+    if cfg == "3":
+        w = WordpieceEncode(args, lib, dev, rank)
+        w.metric = "input MB/s encoded (BERT WordPiece, 256-byte strings)"
+        w.dominant_hint = "lookup_words"
+        w.workload = (f"config 3: BERT-shaped WordPiece (V=30522, trained in-process), {args.rows} x ~{w.nbytes}-byte lower-cased zipf "
+                      f"strings per GPU and batch, {w.batches.n} distinct batches in rotation, fused RegexSplit(\\s+)+RegexSplit(delimiters)+"
+                      f"WordpieceTokenizer, inputs and outputs in HBM")
+        w.sample_rows = args.rows
+        return w
+    raise SystemExit(f"unknown config {cfg}")
 
-        def take(self):
-            self.last = self.sets[self.k % 4]
-            self.k += 1
-            return self.last
 
-        @property
-        def n_chars(self):
-            return self.last[3].n_chars
+# ---------------------------------------------------------------------------------------------- other ops
+class Detokenize:
+    """Config 5 chunk: VocabDecoder + ByteFallback + FuzeRagged fused, rows x 2048 ids, rotating id batches."""
+    unit, dtype, metric, dominant_hint = "Mtok/s", "int32/u8", "token ids/s detokenized (seq 2048)", "detokenize"
 
-    out = CharsOut()
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    pids = C.c_void_p(d_ids.data_ptr())
+    def __init__(self, args, lib, dev, rank):
+        self.lib, self.dev = lib, dev
+        tok = BpeTok.load(args.tokenizer)
+        self.tok = tok
+        self.rows = rows = args.rows if args.rows != 65536 else 16384
+        self.S = S = 2048
+        V = len(tok.vocab)
+        self.pad = pad = V - 1                       # the special token: 1 % of the positions, skipped by the decoder
+        nb = max(2, min(args.batches, 4))            # 4 x 134 MB of ids + 4 x ~0.55 GB of output: beyond the Infinity Cache
+        self.ids_host, self.d_ids, self.n_out = [], [], []
+        vconst = list(pack_strings(tok.vocab))
+        lens = (vconst[1] - vconst[0]).astype(np.int64)
+        for j in range(nb):
+            rng = np.random.default_rng(3000 + 100 * rank + j)
+            ids = rng.integers(0, V - 1, size=(rows, S), dtype=np.int32)
+            ids[rng.random((rows, S)) < 0.01] = pad
+            self.d_ids.append(torch.as_tensor(ids, device=dev))
+            self.n_out.append(int(lens[ids[ids != pad]].sum()))
+            if j == 0:
+                self.ids_host = ids
+        self.dec = VocabDecoder(skip_tokens=[pad], device=dev.index, lib=lib)
+        self.dec._ensure([self.d_ids[0]] + vconst)
+        cap = max(self.n_out) + 64
+        self.sets = []
+        for _ in range(4):  # four output sets used in turn (up to three calls are in flight with --depth 2)
+            b = torch.empty(rows, dtype=torch.int32, device=dev)
+            e = torch.empty(rows, dtype=torch.int32, device=dev)
+            c = torch.empty(cap, dtype=torch.uint8, device=dev)
+            self.sets.append((b, e, c, L.StringsOut(b.data_ptr(), e.data_ptr(), c.data_ptr(), cap, 0)))
+        self.k = 0
+        self.stream0 = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self.nb = nb
+        self.workload = (f"config 5 chunk: detokenize {rows} x {S} ids (GPT-2-shaped vocabulary, 1 % skipped special ids) per GPU and "
+                         f"batch, {nb} distinct batches in rotation, fused VocabDecoder+ByteFallback+FuzeRagged, inputs and outputs in HBM "
+                         f"({self.n_out[0]} output bytes < 2^31)")
+        self.sample_rows = min(rows, 1024)
+        self.vocab = V
 
-    def step():
-        o_begins, o_ends, o_chars, o = out.take()
-        L.check(lib, lib.ovtk_detokenize_run(dec._h, pids, C.c_int64(rows), C.c_int64(S), None, C.c_int64(0), 1, C.byref(o),
-                                             L.MEM_DEVICE, stream))
+    def units(self, i):
+        return self.rows * self.S
+
+    def _take(self):
+        s = self.sets[self.k % 4]
+        self.k += 1
+        return s
+
+    def step(self, i):
+        o_begins, o_ends, o_chars, o = self._take()
+        L.check(self.lib, self.lib.ovtk_detokenize_run(self.dec._h, C.c_void_p(self.d_ids[i % self.nb].data_ptr()), C.c_int64(self.rows),
+                                                       C.c_int64(self.S), None, C.c_int64(0), 1, C.byref(o), L.MEM_DEVICE, self.stream0))
         return o_begins, o_ends, o_chars[: o.n_chars]
 
-    def enqueue(st=stream):
-        o_begins, o_ends, o_chars, o = out.take()
+    def enqueue(self, i, st=None):
+        o_begins, o_ends, o_chars, o = self._take()
         pending = C.c_void_p()
-        L.check(lib, lib.ovtk_detokenize_enqueue(dec._h, pids, C.c_int64(rows), C.c_int64(S), None, C.c_int64(0), 1, C.byref(o), st,
-                                                 C.byref(pending)))
+        L.check(self.lib, self.lib.ovtk_detokenize_enqueue(self.dec._h, C.c_void_p(self.d_ids[i % self.nb].data_ptr()), C.c_int64(self.rows),
+                                                           C.c_int64(self.S), None, C.c_int64(0), 1, C.byref(o), st or self.stream0,
+                                                           C.byref(pending)))
 
         def finish():
-            L.check(lib, lib.ovtk_detokenize_finish(pending, C.byref(o)))
+            L.check(self.lib, self.lib.ovtk_detokenize_finish(pending, C.byref(o)))
             return o_begins, o_ends, o_chars[: o.n_chars]
         return finish
 
-    def cpu(n_s):
+    def algo(self):
+        return float(np.mean([4 * self.rows * self.S + n + 8 * self.rows for n in self.n_out]))
+
+    def mean_out(self):
+        return float(np.mean(self.n_out))
+
+    def cpu_sample(self, n_s):
         from oracle import oracle as O
+        ids, tok, pad = self.ids_host, self.tok, self.pad
+
         def chain(n):
             r = O.vocab_decoder(ids[:n], tok.vocab, [pad])
             bf = O.byte_fallback(*r[2:5])
@@ -306,13 +330,317 @@ def make_detokenize(args, lib, dev, rank):
         ref = chain(16)
         t1 = time.perf_counter()
         chain(n_s)
-        return ref, time.perf_counter() - t1, n_s * S, "VocabDecoder + ByteFallback + FuzeRagged restatement"
+        return ref, time.perf_counter() - t1, n_s * self.S, "VocabDecoder + ByteFallback + FuzeRagged restatement"
 
-    workload = (f"config 5 chunk: detokenize {rows} x {S} ids (GPT-2-shaped vocabulary, 1 % skipped special ids) per GPU, "
-                f"fused VocabDecoder+ByteFallback+FuzeRagged, inputs and outputs in HBM ({n_out} output bytes < 2^31)")
-    return dict(step=step, enqueue=enqueue, cpu=cpu, n_units=rows * S, out=out, keep=(d_ids, dec), workload=workload,
-                metric="token ids/s detokenized (seq 2048)", dtype="int32/u8", unit="Mtok/s", rows=rows, dominant="detokenize",
-                algo=lambda _n: 4 * rows * S + n_out + 8 * rows, sample_rows=min(rows, 1024), is_detok=True, n_out=n_out)
+
+class RaggedToDenseBench:
+    """a7 at config-2 size: the ragged ids of a config-2 batch -> input_ids [rows, T] + attention mask, T = longest row."""
+    unit, dtype, metric, dominant_hint = "GB/s", "int32/u8", "algorithmic GB/s (RaggedToDense, config-2 ids)", "ragged_to_dense"
+
+    def __init__(self, args, lib, dev, rank):
+        self.lib, self.dev = lib, dev
+        enc = BpeEncode(args, lib, dev, rank, args.tokenizer, "zipf", args.rows, args.bytes, 1000)
+        self.rows = rows = args.rows
+        self.inputs, self.T = [], 0
+        for k in range(enc.batches.n):
+            b, e, ids = enc.step(k)
+            torch.cuda.synchronize()
+            self.inputs.append((b.clone(), e.clone(), ids.clone()))
+            self.T = max(self.T, int((e - b).max()))
+        del enc
+        self.nb = len(self.inputs)
+        self.outs = [(torch.empty((rows, self.T), dtype=torch.int32, device=dev), torch.empty((rows, self.T), dtype=torch.uint8, device=dev))
+                     for _ in range(self.nb)]
+        self.copied = [int(torch.clamp(e - b, max=self.T).sum()) for b, e, _ in self.inputs]
+        self.pad = np.asarray([50256], np.int32)
+        self.stream0 = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self.workload = (f"RaggedToDense (a7): {rows} rows of config-2 token ids -> [rows, {self.T}] i32 + mask u8, right padding, "
+                         f"{self.nb} distinct input / output sets in rotation, inputs and outputs in HBM")
+        self.vocab = 0
+        self.sample_rows = 4096
+
+    def units(self, i):  # algorithmic bytes: 8 B + 4 sum(min(len, T)) + 5 B T  (SURVEY 8d)
+        k = i % self.nb
+        return 8 * self.rows + 4 * self.copied[k] + 5 * self.rows * self.T
+
+    def step(self, i):
+        k = i % self.nb
+        b, e, ids = self.inputs[k]
+        dense, mask = self.outs[k]
+        L.check(self.lib, self.lib.ovtk_ragged_to_dense(C.c_void_p(b.data_ptr()), C.c_void_p(e.data_ptr()), C.c_int64(self.rows),
+                                                        C.c_void_p(ids.data_ptr()), C.c_int64(ids.numel()), 4, C.c_int64(1), C.c_int32(self.T),
+                                                        C.c_void_p(self.pad.ctypes.data), 1, 0, C.c_void_p(dense.data_ptr()),
+                                                        C.c_void_p(mask.data_ptr()), L.MEM_DEVICE, self.dev.index, self.stream0))
+        return dense, mask
+
+    def algo(self):
+        return float(np.mean([self.units(k) for k in range(self.nb)]))
+
+    def mean_out(self):
+        return self.rows * self.T
+
+    def cpu_sample(self, n_s):
+        from oracle import oracle as O
+        b, e, ids = (x.cpu().numpy() for x in self.inputs[0])
+        ref = O.ragged_to_dense(b[:n_s], e[:n_s], ids, self.T, 50256)
+        t1 = time.perf_counter()
+        O.ragged_to_dense(b[:n_s], e[:n_s], ids, self.T, 50256)
+        return ref, time.perf_counter() - t1, 8 * n_s + 4 * int(np.minimum(e[:n_s] - b[:n_s], self.T).sum()) + 5 * n_s * self.T, \
+            "ragged_to_dense restatement"
+
+
+class VocabEncoderBench:
+    """a6: VocabEncoder on the words of config-3 text (~3 M words per batch), keys = the BERT-shaped vocabulary."""
+    unit, dtype, metric, dominant_hint = "Mwords/s", "u8/int32", "words/s looked up (VocabEncoder, BERT-shaped vocabulary)", "vocab_encoder"
+
+    def __init__(self, args, lib, dev, rank):
+        self.lib, self.dev = lib, dev
+        tok = load_tokenizer("bert")
+        self.tok = tok
+        model = TextModel(1234, "zipf")
+        tb = TextBatches(model, args.rows, 256, [2000 + 7 * j for j in range(min(args.batches, 4))], dev, lower=True)
+        ws = RegexSplit("remove", device=dev.index, lib=lib)
+        self.words = []
+        for k in range(tb.n):
+            out = ws.evaluate(tb.d[k] + [np.frombuffer(BERT_WS.encode(), np.uint8)])
+            torch.cuda.synchronize()
+            self.words.append((out[2].clone(), out[3].clone(), tb.d[k][4]))
+        self.host0 = tb.host[0]
+        self.nb = len(self.words)
+        keys = list(pack_strings(tok["vocab"]))
+        self.values = np.arange(len(tok["vocab"]), dtype=np.int32)
+        self.enc = VocabEncoder(device=dev.index, lib=lib)
+        self.enc._ensure(list(self.words[0]) + keys + [self.values, np.int32(-1)])
+        self.keys = keys
+        self.outs = [torch.empty(w[0].numel(), dtype=torch.int32, device=dev) for w in self.words]
+        self.dflt = np.asarray([-1], np.int32)
+        self.stream0 = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self.workload = (f"VocabEncoder (a6): {self.words[0][0].numel()} words per batch (config-3 text split at white space), "
+                         f"V={len(tok['vocab'])} keys, i32 values, {self.nb} distinct batches in rotation, inputs and outputs in HBM")
+        self.vocab = len(tok["vocab"])
+        self.sample_rows = 4096
+
+    def units(self, i):
+        return self.words[i % self.nb][0].numel()
+
+    def step(self, i):
+        k = i % self.nb
+        b, e, c = self.words[k]
+        s = L.Strings(b.data_ptr(), e.data_ptr(), c.data_ptr(), b.numel(), c.numel())
+        L.check(self.lib, self.lib.ovtk_vocab_encoder_run(self.enc._h, C.byref(s), C.c_void_p(self.dflt.ctypes.data),
+                                                          C.c_void_p(self.outs[k].data_ptr()), L.MEM_DEVICE, self.stream0))
+        return (self.outs[k],)
+
+    def algo(self):  # N_c(words) + 8 N_e + 4 N_e  (SURVEY 8d)
+        return float(np.mean([int((e - b).sum()) + 12 * b.numel() for b, e, _ in self.words]))
+
+    def mean_out(self):
+        return float(np.mean([w[0].numel() for w in self.words]))
+
+    def cpu_sample(self, n_s):
+        from oracle import oracle as O
+        b, e, c = (x.cpu().numpy() for x in self.words[0])
+        n = min(len(b), n_s * 50)
+        enc = O.VocabEncoder(self.tok["vocab"], self.values)
+        ref = enc(b[:n], e[:n], c, -1)
+        t1 = time.perf_counter()
+        enc(b[:n], e[:n], c, -1)
+        return (ref,), time.perf_counter() - t1, n, "VocabEncoder restatement (std::unordered_map<string,T>)"
+
+
+class SmallBatchLatency:
+    """Config 1: 32 x ~128-byte ASCII strings, one BLOCKING ovtk_encode_run per step -- the latency a single evaluate()
+    of the converted GPT-2 tokenizer sees (device-resident buffers)."""
+    unit, dtype, metric, dominant_hint = "us/call", "u8/int32", "latency per blocking encode call (32 x 128-byte strings)", "lookup_fused"
+    higher_is_better = False
+
+    def __init__(self, args, lib, dev, rank):
+        args2 = argparse.Namespace(**vars(args))
+        args2.batches = 8
+        self.enc = BpeEncode(args2, lib, dev, rank, args.tokenizer, "zipf", 32, 128, 1234, n_batches=8)
+        self.workload = ("config 1: GPT-2-shaped byte-level BPE, 32 x ~128-byte zipf strings, one blocking ovtk_encode_run per step "
+                         "(device-resident buffers), 8 distinct batches in rotation")
+        self.vocab = self.enc.vocab
+        self.sample_rows = 32
+        self.batches = self.enc.batches
+        self.cpu_chain = self.enc.cpu_chain
+
+    def units(self, i):
+        return 1
+
+    def step(self, i):
+        return self.enc.step(i)
+
+    def algo(self):
+        return self.enc.algo()
+
+    def mean_out(self):
+        return self.enc.mean_out()
+
+
+# ---------------------------------------------------------------------------------------------- measurement helpers
+def bind_to_gpu_numa_node(dev):
+    """Runs this process on the CPUs of the NUMA node the GPU hangs off (2-socket hosts: pinned buffers allocated from
+    the other socket cross the inter-socket link on every PCIe transfer, and launches pay for it too).  Returns
+    (original affinity, description)."""
+    try:
+        before = os.sched_getaffinity(0)
+        p = torch.cuda.get_device_properties(dev)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        cpus = Path(f"/sys/bus/pci/devices/{bdf}/local_cpulist").read_text().strip()
+        want = set()
+        for part in cpus.split(","):
+            lo, _, hi = part.partition("-")
+            want.update(range(int(lo), int(hi or lo) + 1))
+        want &= before
+        if want:
+            os.sched_setaffinity(0, want)
+            return before, f"bound to the GPU's NUMA node (PCI {bdf}, CPUs {cpus})"
+        return before, "GPU NUMA node unknown: not bound"
+    except Exception as err:  # noqa: BLE001 -- best effort: containers may hide sysfs
+        return None, f"not bound ({type(err).__name__})"
+
+
+def profile_table(lib):
+    buf = C.create_string_buffer(16384)
+    lib.ovtk_profile_dump(buf, 16384)
+    return {ln.split()[0]: (float(ln.split()[1]), int(ln.split()[2])) for ln in buf.value.decode().splitlines() if ln.strip()}
+
+
+def run_pipelined(wl, steps, stream_ptrs, depth, first=0, complete=lambda f: f()):
+    """The host loop: launch batch k (streams in turn), then complete batch k - depth."""
+    inflight = []
+    for i in range(first, first + steps):
+        inflight.append(wl.enqueue(i, stream_ptrs[i % len(stream_ptrs)]))
+        if len(inflight) > depth:
+            complete(inflight.pop(0))
+    while inflight:
+        complete(inflight.pop(0))
+
+
+def timed(fn):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def cpu_one_core(wl, n_s):
+    """~10 s of the oracle ("port" of the reference's algorithm) on one core over the first rows of batch 0."""
+    if hasattr(wl, "cpu_sample"):
+        ref, cdt, units, what = wl.cpu_sample(n_s)
+        passes = 1
+        while cdt < 8.0 and passes < 64:
+            _, more, u, _ = wl.cpu_sample(n_s)
+            cdt, units, passes = cdt + more, units + u, passes + 1
+        return ref, cdt, units, what, passes
+    chain, what = wl.cpu_chain()
+    rb, re_, b, e, c = wl.batches.host[0]
+    ref = chain(rb[:1024], re_[:1024], b[:1024], e[:1024], c)  # parity prefix + warms the piece cache
+    cdt, units, passes = 0.0, 0, 0
+    while cdt < 8.0 and passes < 32:
+        t1 = time.perf_counter()
+        chain(rb[:n_s], re_[:n_s], b[:n_s], e[:n_s], c)
+        cdt += time.perf_counter() - t1
+        units += int(e[n_s - 1] - b[0])
+        passes += 1
+    return ref, cdt, units, what, passes
+
+
+def cpu_all_cores(wl, seconds=8.0):
+    """Every host core on a contiguous row shard of batch 0, ONE tokenizer object shared by all threads (its piece cache
+    behind a shared_mutex as in the reference): what OpenVINO's THROUGHPUT streams do with one compiled tokenizer
+    (benchmark/benchmark.py:301-302).  The oracle calls release the GIL (ctypes)."""
+    if not hasattr(wl, "cpu_chain"):
+        return None
+    chain, what = wl.cpu_chain()
+    rb, re_, b, e, c = wl.batches.host[0]
+    threads = max(1, os.cpu_count() or 1)
+    rows = len(rb)
+    per = max(1, rows // threads)
+    threads = min(threads, rows // per)
+    chain(rb[:1024], re_[:1024], b[:1024], e[:1024], c)  # warm cache
+    done = [0] * threads
+    stop = time.perf_counter() + seconds
+
+    def work(t):
+        # the thread's shard as a tensor of its own (rebased offsets, its slice of the chars): the op sizes its outputs by
+        # the chars tensor it is given (regex_split.cpp:182, bpe_tokenizer.cpp:135)
+        lo, hi = t * per, (t + 1) * per
+        c0, c1 = int(b[lo]), int(e[hi - 1])
+        rbt = (rb[lo:hi] - rb[lo]).astype(np.int32)
+        ret = (re_[lo:hi] - rb[lo]).astype(np.int32)
+        bt, et, ct = (b[lo:hi] - c0).astype(np.int32), (e[lo:hi] - c0).astype(np.int32), c[c0:c1].copy()
+        nbytes = c1 - c0
+        while time.perf_counter() < stop:
+            chain(rbt, ret, bt, et, ct)
+            done[t] += nbytes
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    t0 = time.perf_counter()
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {"value": round(sum(done) / dt / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} threads x {per} rows of batch 0 each, ONE shared tokenizer as under OpenVINO's THROUGHPUT streams (the piece "
+                      f"cache sits behind a std::shared_mutex taken per piece, bpe_tokenizer.cpp:197-205: the reader lock's cache line is "
+                      f"what the threads contend for), repeated for {dt:.1f} s ({sum(done)} bytes in all), {what}",
+            "host_cpus": os.cpu_count()}
+
+
+def end_to_end_leg(wl, lib, dev, ptrs, steps=32, depth=3):
+    """Host buffers in, host buffers out (what a CPU-plugin evaluate() holds): pinned numpy views, ovtk_encode_enqueue_host
+    on alternating streams, so the H2D copy and kernels of batch k+1 run under the D2H copy of batch k."""
+    if not isinstance(wl, BpeEncode):
+        return None
+    tb = wl.batches
+    nb = min(tb.n, 4)
+
+    def pin(t):
+        p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        p.copy_(t)
+        return p
+    hin = [[pin(x) for x in tb.d[k]] for k in range(nb)]
+    rs = [L.RaggedStrings(h[0].data_ptr(), h[1].data_ptr(), tb.rows, L.Strings(h[2].data_ptr(), h[3].data_ptr(), h[4].data_ptr(), tb.rows,
+                                                                                 h[4].numel())) for h in hin]
+    outs = []
+    for _ in range(depth + 2):
+        b = torch.empty(tb.rows, dtype=torch.int32, pin_memory=True)
+        e = torch.empty(tb.rows, dtype=torch.int32, pin_memory=True)
+        ids = torch.empty(tb.cap, dtype=torch.int32, pin_memory=True)
+        outs.append((b, e, ids, L.RaggedI32Out(b.data_ptr(), e.data_ptr(), ids.data_ptr(), tb.cap, 0, 0)))
+    n_streams = len(ptrs)
+    moved = [0]
+
+    def loop(n):
+        inflight = []
+        for i in range(n):
+            o = outs[i % len(outs)]
+            pending = C.c_void_p()
+            L.check(lib, lib.ovtk_encode_enqueue_host(wl.split._h, wl.bpe._h, C.byref(rs[i % nb]), None, C.byref(o[3]), ptrs[i % n_streams],
+                                                      C.byref(pending)))
+            inflight.append((pending, o, i % nb))
+            if len(inflight) > depth:
+                p, oo, k = inflight.pop(0)
+                L.check(lib, lib.ovtk_encode_finish(p, C.byref(oo[3])))
+                moved[0] += tb.n_chars[k] + 16 * tb.rows + 4 * int(oo[3].n_data)
+        for p, oo, k in inflight:
+            L.check(lib, lib.ovtk_encode_finish(p, C.byref(oo[3])))
+            moved[0] += tb.n_chars[k] + 16 * tb.rows + 4 * int(oo[3].n_data)
+    loop(8)
+    moved[0] = 0
+    dt = timed(lambda: loop(steps))
+    units = sum(tb.n_chars[i % nb] for i in range(steps))
+    # the result is the same as the device-resident path's
+    o = outs[(steps - 1) % len(outs)]
+    return {"value": round(units / dt / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dt / steps * 1e3, 4),
+            "pcie_GBps_both_directions": round(moved[0] / dt / 1e9, 2),
+            "note": f"pinned host buffers in and out (ovtk_encode_enqueue_host / ovtk_encode_finish), {n_streams} streams, {depth} batches "
+                    f"ahead: H2D of batch k+1 under the D2H of batch k; {steps} steps over {nb} batches; never reported as `value`",
+            "ids_last_batch": int(o[3].n_data)}
 
 
 def main():
@@ -320,21 +648,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5])
+    ap.add_argument("--config", default="2", choices=["1", "2", "3", "4", "5", "r2d", "vocab_encoder"])
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--bytes", type=int, default=512)
+    ap.add_argument("--batches", type=int, default=8, help="distinct input batches rotated through the timed loop")
     ap.add_argument("--text", default="zipf", choices=["zipf", "uniform", "mixed"])
     ap.add_argument("--tokenizer", default="gpt2")
     ap.add_argument("--no-memo", action="store_true", help="config 2: BPETokenizer with cache_capacity=0 (no piece memo)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the all-gather (rank-local consumer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stress / end_to_end / all-cores legs behind the timed region")
     ap.add_argument("--hog", type=int, default=0, help="debug: occupy CU slots with N idle 512-thread blocks on a side stream during "
                                                         "every step (stands in for RCCL's all-gather kernel; tools/cu_hog.hip)")
     ap.add_argument("--row-tickets", type=int, default=-1, help="ovtk_set_row_tickets(n); default 0 (static row assignment)")
     ap.add_argument("--hog-lds", type=int, default=0, help="debug: dynamic LDS bytes per hog block")
     ap.add_argument("--lib", default=None, help="debug: load this build of libovtk_amd.so")
-    ap.add_argument("--no-alone-leg", action="store_true", help="skip the one-stream leg behind roofline.alone (profile runs: "
-                    "rocprofv3's per-kernel average then covers the overlapped launches only)")
+    ap.add_argument("--no-alone-leg", action="store_true", help="skip the one-stream leg behind `roofline` (profile runs of the "
+                    "overlapped loop: rocprofv3's per-kernel average then covers the overlapped launches only)")
     ap.add_argument("--depth", type=int, default=2, help="batches launched ahead of the one being completed (two-half calls)")
     ap.add_argument("--exchange-stream", type=int, default=1, help="1: pack/unpack of the exchange on a HIP stream of their own")
     ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
@@ -355,29 +685,30 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from openvino_tokenizers_amd.distributed import ShardExchange
 
+    affinity0, numa_note = bind_to_gpu_numa_node(dev)
     lib = L.load(args.lib)
-    wl = {2: make_encode_bpe, 3: make_encode_wordpiece, 4: make_encode_llama3, 5: make_detokenize}[args.config](args, lib, dev, rank)
-    is_detok = wl.get("is_detok", False)
+    special = {"5": Detokenize, "r2d": RaggedToDenseBench, "vocab_encoder": VocabEncoderBench, "1": SmallBatchLatency}
+    wl = special[args.config](args, lib, dev, rank) if args.config in special else make_workload(args, lib, dev, rank)
+    is_encode = isinstance(wl, EncodeWorkload)
+    two_half = hasattr(wl, "enqueue") and not args.sync
     # N > 1: every rank's ragged ids are all-gathered (RCCL), one batch behind the encode so that the gather of batch k
     # travels over xGMI while batch k + 1 is encoded; flush() completes the last one inside the timed region.
     exchange = None
-    if (world > 1 or args.force_exchange) and not args.no_gather and not is_detok:
+    if dist_on and not args.no_gather and is_encode:
         xstream = torch.cuda.Stream(dev) if args.exchange_stream else None
         # equal shards of the same text model: the ranks' id counts differ by well under 0.1 %, so 3 % of padding on the
         # wire (instead of the class's default 12.5 %) never triggers a re-gather and the gather moves 8 % fewer bytes
-        exchange = ShardExchange(wl.get("rows", args.rows) * world, wl["vocab"], dev, lib=lib, stream=xstream, headroom=1.03)
+        exchange = ShardExchange(wl.batches.rows * world, wl.vocab, dev, lib=lib, stream=xstream, headroom=1.03)
 
     # A step = one batch through the hot path.  Where the op has the two-half form the host launches batch k, then
-    # completes batch k-1 (status check, and with N > 1 its exchange) while the GPU works on k: the reference's
+    # completes batch k-depth (status check, and with N > 1 its exchange) while the GPU works on k: the reference's
     # evaluate() semantics per batch, without the GPU idling while the host reads a status word.  Consecutive batches go to
     # alternating HIP streams: the latency-bound merge kernel of one batch then shares the CUs with the issue-bound
     # lookup kernel of the next (per-launch durations grow, the step shrinks).  --sync: one blocking call per step.
     row_tickets = max(args.row_tickets, 0)
     L.check(lib, lib.ovtk_set_row_tickets(row_tickets))
-    inflight = []
     side_streams = [torch.cuda.Stream(dev) for _ in range(max(args.streams - 1, 0))]
     stream_ptrs = [C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)] + [C.c_void_p(x.cuda_stream) for x in side_streams]
-    launched = [0]
     hog = None
     if args.hog:
         hog_lib = C.CDLL(str(ROOT / "tools" / "build" / "libcuhog.so"))
@@ -388,18 +719,20 @@ def main():
         res = finish()
         return exchange.submit(*res) if exchange is not None else res
 
-    def step():
-        if hog is not None:
-            hog()
-        if "enqueue" in wl and not args.sync:
-            inflight.append(wl["enqueue"](stream_ptrs[launched[0] % len(stream_ptrs)]))
-            launched[0] += 1
-            return complete(inflight.pop(0)) if len(inflight) > args.depth else None
-        return complete(wl["step"])
-
-    def drain():
-        while inflight:
-            complete(inflight.pop(0))
+    def run_steps(first, n):
+        if two_half:
+            inflight = []
+            for i in range(first, first + n):
+                if hog is not None:
+                    hog()
+                inflight.append(wl.enqueue(i, stream_ptrs[i % len(stream_ptrs)]))
+                if len(inflight) > args.depth:
+                    complete(inflight.pop(0))
+            while inflight:
+                complete(inflight.pop(0))
+        else:
+            for i in range(first, first + n):
+                complete(lambda i=i: wl.step(i))
         if exchange is not None:
             exchange.flush()
 
@@ -409,67 +742,61 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    drain()
+    run_steps(0, args.warmup)
     lib.ovtk_profile_reset()
     lib.ovtk_profile_enable(1)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    drain()   # every one of the K batches is complete (and, N > 1, gathered on every rank) before the clock stops
+    run_steps(args.warmup, args.steps)   # every one of the K batches is complete (and, N > 1, gathered on every rank) when it returns
     barrier()
     dt = time.perf_counter() - t0
     lib.ovtk_profile_enable(0)
-    n_units = wl["n_units"]
+    my_units = sum(wl.units(i) for i in range(args.warmup, args.warmup + args.steps))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        nb = torch.tensor([n_units], dtype=torch.int64, device=dev)
+        nb = torch.tensor([my_units], dtype=torch.int64, device=dev)
         dist.all_reduce(nb)
         total_units = int(nb.item())
     else:
-        total_units = n_units
+        total_units = my_units
 
-    n_out = int(wl["out"].n_chars) if is_detok else int(wl["out"].n_data)
     ms_per_step = dt / args.steps * 1e3
-    value = total_units * args.steps / dt / 1e6  # MB/s (or Mtok/s), whole job
+    latency = isinstance(wl, SmallBatchLatency)
+    value = ms_per_step * 1e3 if latency else total_units / dt / (1e9 if wl.unit == "GB/s" else 1e6)
 
-    # ---- roofline of the dominant kernel (HIP events recorded by the library on the launch stream)
-    buf = C.create_string_buffer(8192)
-    lib.ovtk_profile_dump(buf, 8192)
-    prof = {ln.split()[0]: (float(ln.split()[1]), int(ln.split()[2])) for ln in buf.value.decode().splitlines() if ln.strip()}
+    # ---- roofline of the dominant kernel: HIP events recorded by the library on the launch stream.
+    # `roofline.achieved / frac` come from a ONE-STREAM leg run right here (each kernel with the chip to itself: the duration
+    # rocprofv3 --kernel-trace --stats reproduces for `bench.py --streams 1`, profiles/); the timed loop's own events are of
+    # launches that share the CUs with the neighbouring batches' kernels (the point of the streams) and are reported as
+    # `overlapped` for information only.
+    prof = profile_table(lib)
     kernels = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
-    per_step = {k: v[0] / args.steps for k, v in prof.items()}  # ms of each kernel family per step
+    per_step = {k: v[0] / args.steps for k, v in prof.items()}
     roofline = None
     if per_step:
-        # The same kernels with the chip to themselves: with several streams the durations above are of launches that
-        # shared the CUs with the neighbouring batches' kernels (that is the point of the streams), and which of two
-        # kernels of similar length looks longer then changes from run to run.  A short one-stream leg outside the timed
-        # region gives each kernel's own duration; the dominant kernel is the longest one THERE.
         alone = {}
-        if "enqueue" in wl and not args.sync and len(stream_ptrs) > 1 and not args.no_alone_leg:
+        if not args.no_alone_leg:
             lib.ovtk_profile_reset()
             lib.ovtk_profile_enable(1)
-            for _ in range(20):
-                wl["enqueue"](stream_ptrs[0])()   # launch, then finish: no exchange in this leg
+            n_leg = 24
+            for i in range(n_leg):
+                (wl.enqueue(i, stream_ptrs[0])() if two_half else wl.step(i))
             torch.cuda.synchronize()
             lib.ovtk_profile_enable(0)
-            lib.ovtk_profile_dump(buf, 8192)
-            alone = {ln.split()[0]: (float(ln.split()[1]), int(ln.split()[2])) for ln in buf.value.decode().splitlines() if ln.strip()}
-            alone = {k: v for k, v in alone.items() if k in per_step and v[1]}
-        hint = wl.get("dominant")
-        if alone:
-            dom = max(alone, key=lambda k: alone[k][0])
-        elif hint in per_step and per_step[hint] >= 0.8 * max(per_step.values()):
-            dom = hint   # profile runs (--no-alone-leg): the workload's usual dominant kernel unless another is clearly longer
-        else:
-            dom = max(per_step, key=per_step.get)
-        launches_per_step = max(1, round(prof[dom][1] / args.steps))
-        k_ms = prof[dom][0] / max(prof[dom][1], 1)
-        algo_bytes = wl["algo"](n_out)  # algorithmic bytes of one pass
+            alone = {k: v for k, v in profile_table(lib).items() if v[1]}
+        src = alone or prof
+        n_src = 24 if alone else args.steps
+        hint = getattr(wl, "dominant_hint", None)
+        per_launch = {k: v[0] / v[1] for k, v in src.items()}
+        per_step_src = {k: v[0] / n_src for k, v in src.items()}
+        dom = max(per_step_src, key=per_step_src.get)
+        if not alone and hint in per_step_src and per_step_src[hint] >= 0.8 * per_step_src[dom]:
+            dom = hint
+        launches_per_step = max(1, round(src[dom][1] / n_src))
+        k_ms = per_launch[dom]
+        algo_bytes = wl.algo()   # algorithmic bytes of one pass
         achieved = algo_bytes / launches_per_step / (k_ms * 1e-3) / 1e9
         traffic = None
         if PMC_FILE.exists():  # per-launch FETCH_SIZE (doubled: gfx950 correction) + WRITE_SIZE of this kernel, see profiles/README.md
@@ -477,17 +804,19 @@ def main():
             traffic = pmc.get(f"config{args.config}", {}).get(dom)
         roofline = {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom), "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": traffic, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
+                    "traffic": traffic, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": round(algo_bytes),
                     "launches_per_step": launches_per_step,
-                    "all_kernels_ms_per_step": round(sum(per_step.values()), 4)}
-        step_gbs = algo_bytes * (total_units / n_units) / (ms_per_step * 1e-3) / 1e9 / world
+                    "measured": ("one-stream leg of 24 batches behind the timed region (every kernel alone on the chip)" if alone
+                                 else "the timed loop's own launches"),
+                    "one_stream_kernel_ms": {k: round(v, 4) for k, v in sorted(per_launch.items())},
+                    "one_stream_kernel_sum_ms_per_step": round(sum(per_step_src.values()), 4)}
+        step_gbs = algo_bytes / (ms_per_step * 1e-3) / 1e9 * (total_units / max(my_units, 1)) / world
         roofline["step"] = {"achieved": round(step_gbs, 2), "frac": round(step_gbs / HBM_PEAK_GBS, 5),
                             "note": "algorithmic bytes of one batch / ms_per_step, per GPU: every kernel of the path, overlapped as run"}
         if alone:
-            a_ms = alone[dom][0] / alone[dom][1]
-            a_gbs = algo_bytes / launches_per_step / (a_ms * 1e-3) / 1e9
-            roofline["alone"] = {"kernel_ms": round(a_ms, 4), "achieved": round(a_gbs, 2), "frac": round(a_gbs / HBM_PEAK_GBS, 5),
-                                 "note": "same kernel without a neighbouring batch on the CUs (20 one-stream launches, untimed leg)"}
+            roofline["alone"] = {"kernel_ms": round(k_ms, 4), "achieved": round(achieved, 2), "frac": round(achieved / HBM_PEAK_GBS, 5)}
+            roofline["overlapped"] = {"kernel_ms": kernels.get(dom), "note": f"wall time of the same kernel's launches in the timed loop "
+                                      f"({len(stream_ptrs)} streams: neighbouring batches share the CUs); not used for frac"}
 
     if rank != 0:
         if exchange is not None:
@@ -496,39 +825,63 @@ def main():
             dist.destroy_process_group()
         return
 
-    # ---- parity spot-check + CPU baseline (oracle = "port" of the reference's algorithm), rank 0 only
-    cpu_baseline, parity = None, None
-    if not args.no_cpu_baseline and world == 1:  # N > 1: the ranks are done once the line is printed
-        n_s = wl["sample_rows"]
-        ref, cdt, sample_units, what = wl["cpu"](n_s)
-        passes = 1
-        while cdt < 10.0 and passes < 16:  # about 10 s of CPU work in all: repeat the sample (same rows, cache stays warm)
-            _, more, units, _ = wl["cpu"](n_s)
-            cdt, sample_units, passes = cdt + more, sample_units + units, passes + 1
-        b, e, payload = wl["step"]()
-        n_chk = len(ref[1])
-        got_ends = e[:n_chk].cpu().numpy()
-        got = payload[: int(got_ends[-1])].cpu().numpy()
-        parity = bool(np.array_equal(ref[1], got_ends) and np.array_equal(ref[2], got))
-        if world == 1:
-            cpu_baseline = {"value": round(sample_units / cdt / 1e6, 2), "unit": wl.get("unit", "MB/s"), "cores": 1, "kind": "port",
-                            "sample": f"{passes} pass(es) over the first {n_s} rows of the same batch ({sample_units} "
-                                      f"{'ids' if is_detok else 'bytes'} in all), {what}, {cdt:.2f} s",
-                            "host_cpus": os.cpu_count()}
+    # ---- parity spot-check + CPU baselines (oracle = "port" of the reference's algorithm) + extra legs, rank 0, N = 1
+    cpu_baseline, cpu_all, parity, stress, e2e = None, None, None, None, None
+    if world == 1 and not args.no_cpu_baseline:
+        n_s = wl.sample_rows
+        ref, cdt, sample_units, what, passes = cpu_one_core(wl, n_s)
+        res = wl.step(0)
+        torch.cuda.synchronize()
+        if isinstance(wl, (RaggedToDenseBench,)):
+            parity = bool(np.array_equal(ref[0], res[0][: len(ref[0])].cpu().numpy()))
+        elif isinstance(wl, VocabEncoderBench):
+            parity = bool(np.array_equal(ref[0], res[0][: len(ref[0])].cpu().numpy()))
+        else:
+            b, e, payload = res
+            n_chk = len(ref[1])
+            got_ends = e[:n_chk].cpu().numpy()
+            parity = bool(np.array_equal(ref[1], got_ends) and np.array_equal(ref[2][: int(ref[1][-1])], payload[: int(got_ends[-1])].cpu().numpy()))
+        cpu_baseline = {"value": round(sample_units / cdt / (1e9 if wl.unit == "GB/s" else 1e6), 3),
+                        "unit": wl.unit if not latency else "MB/s", "cores": 1, "kind": "port",
+                        "sample": f"{passes} pass(es) over the first {n_s} rows of batch 0 ({sample_units} units in all), {what}, {cdt:.2f} s",
+                        "host_cpus": os.cpu_count()}
+        if not args.no_extras:
+            if affinity0:
+                os.sched_setaffinity(0, affinity0)   # this leg uses every host core
+            cpu_all = cpu_all_cores(wl)
+    if world == 1 and not args.no_extras and args.config == "2" and args.text == "zipf" and not args.no_memo:
+        stress = {}
+        for name, kw in (("uniform_text", dict(kind="uniform")), ("no_memo", dict(kind="zipf", no_memo=True))):
+            s_args = argparse.Namespace(**vars(args))
+            w2 = BpeEncode(s_args, lib, dev, rank, args.tokenizer, kw["kind"], args.rows, args.bytes, 5000, no_memo=kw.get("no_memo", False),
+                           n_batches=4)
+            run_pipelined(w2, 4, stream_ptrs, args.depth)
+            n2 = 16
+            d2 = timed(lambda: run_pipelined(w2, n2, stream_ptrs, args.depth, first=4))
+            u2 = sum(w2.units(i) for i in range(4, 4 + n2))
+            stress[name] = {"value": round(u2 / d2 / 1e6, 1), "unit": "MB/s", "ms_per_step": round(d2 / n2 * 1e3, 4),
+                            "ids_per_batch": round(w2.mean_out()),
+                            "note": ("uniform-random printable bytes (SURVEY 8d stress text: cache-hostile, 3x the pieces)" if name == "uniform_text"
+                                     else "zipf text with cache_capacity=0: every piece takes the merge path")}
+            del w2
+        extra_streams = [torch.cuda.Stream(dev) for _ in range(max(0, 4 - len(stream_ptrs)))]
+        e2e = end_to_end_leg(wl, lib, dev, stream_ptrs + [C.c_void_p(x.cuda_stream) for x in extra_streams])
 
     line = {
-        "metric": wl["metric"], "value": round(value, 1), "unit": wl.get("unit", "MB/s"),
+        "metric": wl.metric, "value": round(value, 1 if not latency else 2), "unit": wl.unit,
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
-        "config": {"workload": wl["workload"],
-                   "row_tickets": row_tickets,
+        "higher_is_better": getattr(wl, "higher_is_better", True), "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
+        "data": "synthetic",
+        "config": {"workload": wl.workload,
+                   "row_tickets": row_tickets, "host_cpu_affinity": numa_note,
                    "host_loop": (f"launch batch k, then complete batch k-{args.depth} (two-half calls), batches alternate between {len(stream_ptrs)} "
-                                 f"HIP stream(s)" if "enqueue" in wl and not args.sync else "one blocking call per batch"),
-                   "rows_per_gpu": wl.get("rows", args.rows), "units_per_gpu": n_units, "outputs_per_gpu": n_out,
+                                 f"HIP stream(s)" if two_half else "one blocking call per batch"),
+                   "units_per_gpu_and_step": round(my_units / args.steps), "outputs_per_gpu_and_step": round(wl.mean_out()),
                    "exchange": ("none (1 GPU)" if exchange is None and world == 1 else ("none (rank-local consumer)" if exchange is None else
                                                                     f"all-gather of ragged ids over RCCL, {exchange.id_bytes}-byte ids on the wire, "
                                                                     f"gather overlapped with the next encode, unpack one batch later ({exchange.regathers} re-gathers)"))},
-        "roofline": roofline, "cpu_baseline": cpu_baseline, "parity_prefix_bit_exact": parity,
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all, "stress": stress, "end_to_end": e2e,
+        "parity_prefix_bit_exact": parity,
         "kernel_ms": kernels,
     }
     print(json.dumps(line))

@@ -183,6 +183,15 @@ typedef struct ovtk_pending ovtk_pending;
 int ovtk_encode_enqueue(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                         const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending);
 int ovtk_encode_finish(ovtk_pending* pending, ovtk_ragged_i32_out* out);
+/* The two halves for HOST buffers -- what a CPU-plugin evaluate() holds (every input of BPETokenizer::evaluate is a host
+ * tensor, src/bpe_tokenizer.cpp:122-140).  enqueue puts the copies of the inputs to the device and the kernels on
+ * `stream` and returns; finish (ovtk_encode_finish) waits for them, copies begins / ends and exactly n_data ids back and
+ * returns when they have arrived.  With PINNED buffers (hipHostMalloc / hipHostRegister) the copies are asynchronous:
+ * a host that enqueues batch k+1 (on another stream) before finishing batch k overlaps k+1's host-to-device copy and
+ * kernels with k's device-to-host copy -- PCIe is full duplex, the step is bound by the larger copy.  Pageable buffers
+ * work too (the runtime then stages the copies synchronously).  Buffers must stay valid until finish. */
+int ovtk_encode_enqueue_host(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+                             const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending);
 
 /* ---------------------------------------------------------------- WordpieceTokenizer
  * Replaces WordpieceTokenizer::evaluate, src/wordpiece_tokenizer.cpp:49-133.  Inputs 5-7 + attributes at

@@ -567,6 +567,17 @@ int ovtk_encode_enqueue(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragge
     return OVTK_OK;
 }
 
+int ovtk_encode_enqueue_host(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+                             const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending) {
+    if (!pending || !out) return set_error(OVTK_E_ARG, "null argument");
+    if (int rc = check_fused(split)) return rc;
+    auto p = std::make_unique<ovtk_pending>();
+    p->out = *out;
+    if (int rc = start_encode(split, bpe, in, skips, &p->out, OVTK_MEM_HOST, stream, p->run)) return rc;
+    *pending = p.release();
+    return OVTK_OK;
+}
+
 int ovtk_encode_finish(ovtk_pending* pending, ovtk_ragged_i32_out* out) {
     if (!pending) return set_error(OVTK_E_ARG, "null argument");
     std::unique_ptr<ovtk_pending> p(pending);  // released whatever happens

@@ -19,7 +19,10 @@ const char* last_error() { return g_err.c_str(); }
 int DevBuf::ensure(size_t bytes) {
     if (bytes <= cap_ && p_) return OVTK_OK;
     release();
+    // Headroom of 1/8 (large buffers): consecutive batches of a serving loop differ by a fraction of a percent in size,
+    // and every regrowth is a hipFree + hipMalloc -- two device-wide synchronisations in the middle of the pipeline.
     size_t want = bytes < 256 ? 256 : bytes;
+    if (want >= (size_t(1) << 16)) want += want / 8;
     OVTK_HIP(hipMalloc(&p_, want));
     cap_ = want;
     return OVTK_OK;

@@ -294,6 +294,30 @@ class FusedSplitBPE:
             return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
         return ticket
 
+    def enqueue_host(self, split_inputs, bpe_constant_inputs, outputs=None, stream=None):
+        """The two halves for HOST arrays (ovtk_encode_enqueue_host): numpy inputs -- pinned ones (e.g. views of
+        torch.empty(..., pin_memory=True)) make the copies asynchronous --, `outputs` = (begins, ends, ids) numpy arrays to
+        fill (allocated here when None), `stream` a HIP stream handle (int) or None.  `ticket()` -> [begins, ends, ids]."""
+        has_skips = len(split_inputs) == 7
+        self.split._ensure(split_inputs[5 + has_skips])
+        self.bpe._ensure(list(split_inputs[:5]) + list(bpe_constant_inputs))
+        m = _Mem(np.empty(0, np.uint8))
+        rs, (rb, _, _, _, c) = _ragged_in(m, split_inputs)
+        _, pskips = (m.inp(split_inputs[5], "bool") if has_skips else (None, None))
+        if outputs is None:
+            outputs = (np.empty(max(len(rb), 1), np.int32), np.empty(max(len(rb), 1), np.int32), np.empty(max(len(c), 1), np.int32))
+        ob, oe, ids = outputs
+        out = L.RaggedI32Out(ob.ctypes.data, oe.ctypes.data, ids.ctypes.data, len(ids), 0, 0)
+        lib = self.bpe._lib
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_encode_enqueue_host(self.split._h, self.bpe._h, C.byref(rs), pskips, C.byref(out),
+                                                  C.c_void_p(stream or 0), C.byref(pending)))
+
+        def ticket(_keep=(m, outputs)):
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(out)))
+            return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+        return ticket
+
 
 class WordpieceTokenizer(_Op):
     """Reference: src/wordpiece_tokenizer.cpp (evaluate :49-133).  Inputs: ragged strings (5), vocab (3),

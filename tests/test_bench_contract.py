@@ -32,9 +32,20 @@ def test_bench_json_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["alone"]["kernel_ms"] > 0 and r["step"]["frac"] > 0
+    assert r["kernel_ms"] == r["alone"]["kernel_ms"], "frac must come from the one-stream leg, not from overlapped launches"
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert d["cpu_baseline_all_cores"]["cores"] >= 1 and d["cpu_baseline_all_cores"]["value"] > 0
+    assert d["stress"]["uniform_text"]["value"] > 0 and d["stress"]["no_memo"]["ms_per_step"] > 0
+    assert d["end_to_end"]["value"] > 0 and "8 distinct batches" in d["config"]["workload"]
     assert d["parity_prefix_bit_exact"] is True
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("config", ["1", "5", "r2d", "vocab_encoder"])
+def test_bench_other_configs(config):
+    d = _run("--config", config, "--no-extras")
+    assert d["value"] > 0 and d["parity_prefix_bit_exact"] is True and 0 < d["roofline"]["frac"] < 1
 
 
 @pytest.mark.gpu

@@ -453,3 +453,40 @@ def test_many_exact_pieces_leave_no_stray_writes(backend, mem):
     assert np.array_equal(ids[: out.n_data], ref[2])
     assert (ids[out.n_data:] == SENT).all(), "ids written beyond the result"
     assert (ob[len(rb):] == SENT).all() and (oe[len(rb):] == SENT).all()
+
+
+def test_enqueue_host_buffers(backend):
+    """ovtk_encode_enqueue_host / ovtk_encode_finish: host buffers in, host buffers out, several batches in flight (on
+    the GPU box: pinned buffers on two HIP streams, so that copies and kernels of neighbouring batches overlap)."""
+    if backend.name == "hip-host":
+        pytest.skip("covered by the other two backends")
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    gpu = backend.name != "emu"
+    streams = [None, None]
+    if gpu:
+        import torch
+        side = torch.cuda.Stream()
+        streams = [torch.cuda.current_stream().cuda_stream, side.cuda_stream]
+
+    def pinned(a):
+        if not gpu:
+            return a
+        t = torch.empty(a.shape, dtype=getattr(torch, str(a.dtype)), pin_memory=True)
+        v = t.numpy()
+        v[...] = a
+        return v
+
+    refs, tickets = [], []
+    for i, (n, target, kind) in enumerate([(40, 300, "zipf"), (12, 900, "mixed"), (60, 120, "uniform"), (3, 20, "zipf")]):
+        if gpu:
+            n *= 50
+        b, e, c = TextModel(n + i, kind).batch(n, target)
+        rb, re_ = ragged_rows(n)
+        refs.append(orc(*rs(rb, re_, b, e, c)[:5]))
+        outs = tuple(pinned(np.zeros(k, np.int32)) for k in (n, n, len(c)))
+        tickets.append(fused.enqueue_host([pinned(x) for x in (rb, re_, b, e, c)] + [pat], tok.consts, outs, streams[i % 2]))
+    for ref, ticket in zip(refs, tickets):
+        assert_same(ref, ticket(), lambda x: x, "enqueue_host/finish")
