@@ -490,7 +490,18 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                else if (split && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFused, true>), grid, kBlockThreads, s, d_in,
                                                split->dev, bpe->dev, w);
-                               else if (split)
+                               else if (split && split->dev.kind <= kSplitGpt2Digits) {
+                                   // rows that are one ASCII scan window: the specialised kernel; whatever it leaves
+                                   // (marked in row_used) goes through the generic one
+                                   if (split->dev.kind == kSplitGpt2Digits)
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<true>, grid, kBlockThreads, s, d_in, bpe->dev, w);
+                                   else
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<false>, grid, kBlockThreads, s, d_in, bpe->dev, w);
+                                   EncodeWork w2 = w;
+                                   w2.only_pending = 1;
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
+                                               bpe->dev, w2);
+                               } else if (split)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in,
                                                split->dev, bpe->dev, w);
                                else if (tickets)
@@ -516,7 +527,9 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            /*self_alloc=*/true,
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
                                   : split->dev.kind == kSplitLlama3 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>)
-                                                                    : resident_blocks_per_cu(lookup_kernel<kFused>),
+                                  : split->dev.kind <= kSplitGpt2Digits && !row_tickets().load(std::memory_order_relaxed)
+                                      ? resident_blocks_per_cu(lookup_ascii_kernel<false>, 6)
+                                      : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (pieces_ws) r->input_on_device(pieces_ws);
     if (int rc = r->start()) return rc;

@@ -49,13 +49,16 @@ struct alignas(32) DeferredPiece {
 };
 struct ExactPiece { int32_t begin, len, stage_pos, row; };
 
-constexpr int kMissBuf = 128;  // per-wave LDS buffer of deferred pieces (flushed when >= 64 are pending)
+constexpr int kMissBuf = 96;   // per-wave LDS buffer of deferred pieces: flushed 64 at a time, or early when a batch would not fit
+                               // (3 KB per wave instead of 4: with the 2.3 KB scan window a seventh block fits a CU's LDS)
 
 constexpr int kRowTile = 64;  // rows per tile of the final offset scan
+constexpr int32_t kRowPending = -1;  // row_used: lookup_ascii_kernel left the row to lookup_kernel<kFused>
 
 struct EncodeWork {
     int32_t fold_tail;      // merge_kernel's last block also runs exact pieces + the row scan (no exact / count_scan launches)
     long long out_cap;      // caller's ids capacity (the folded tail's capacity check)
+    int32_t only_pending;   // lookup_kernel<kFused>: take only the rows lookup_ascii_kernel marked kRowPending in row_used
     int32_t rows_per_ticket;  // lookup_kernel, allocator mode: 0 = static rows per wave, else rows handed out per ticket
     int32_t n_waves;        // persistent waves of the prep / lookup launches (wave w owns rows w, w + n_waves, ...)
     long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities), or
@@ -262,6 +265,7 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     const bool miss = valid && !hit;
     const unsigned long long mm = __ballot(miss);
     if (mm) {
+        if (n_miss + __popcll(mm) > kMissBuf) flush_misses(mb, n_miss, n_miss, w);  // (rare: a batch with > 32 misses)
         if (miss) mb.e[n_miss + __popcll(mm & lanemask_lt())] = DeferredPiece{k0, k1, pos, st.row, abs_begin, plen};
         n_miss += __popcll(mm);
         wave_sync();
@@ -351,6 +355,7 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
     __shared__ WaveScratch ws_all[kWavesPerBlock];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
     if (w.status->flags & kFatalFlags) return;
+    if (w.only_pending && w.status->n_pending == 0) return;  // lookup_ascii_kernel took every row
     WaveScratch& ws = ws_all[wave_in_block()];
     WaveMiss& mb = miss_all[wave_in_block()];
     const int l = lane_id();
@@ -407,6 +412,10 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
         chunk_end = row + rpt;
     }
     while (row >= 0 && row < in.n_rows) {
+        if (!TICKETS && w.only_pending && uniform_load(w.row_used + row) != kRowPending) {  // done by lookup_ascii_kernel
+            row += n_waves;
+            continue;
+        }
         if (rpt && row + rpt == chunk_end) tk_issue();  // first row of a ticket
         RowHdr h{0, 0, 0, 0, false};
         if (MODE != kPieces) h = load_row_string(in, load_row_range(in, row));
@@ -479,6 +488,88 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
         }
     }
     if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
+}
+
+
+// ---- the GPT-2 family's common case as a kernel of its own: rows of ONE string that is ONE ASCII scan window.
+// The same work as lookup_kernel<kFused> does for such a row (stage the text in LDS, packed-byte scanner, 64-piece
+// batches through the memo) without the generic kernel's other paths -- several strings per row, skips, chunked strings,
+// the ballot scanner, the class patterns, row tickets --, whose live state costs the generic kernel 68 spilled SGPRs and
+// a fifth of its instructions.  Any other row is marked kRowPending in row_used and left to lookup_kernel<kFused>
+// (launched right behind with only_pending set; it returns at once when nothing was left).
+template <bool DIGITS>
+static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_ascii_kernel(RowsIn in, BpeDev T, EncodeWork w) {
+    __shared__ WaveScratch ws_all[kWavesPerBlock];
+    __shared__ WaveMiss miss_all[kWavesPerBlock];
+    if (w.status->flags & kFatalFlags) return;
+    WaveScratch& ws = ws_all[wave_in_block()];
+    WaveMiss& mb = miss_all[wave_in_block()];
+    const int l = lane_id();
+    const int n_waves = w.n_waves;
+    const int wave = wave_uniform(int(blockIdx.x) * kWavesPerBlock + wave_in_block());
+    const int mul = T.suffix_len + 1;
+    int n_miss = 0, n_pending = 0;
+    int cursor = 0, limit = 0;
+    bool dead = false;  // staging exhausted: the host grows the buffer and reruns
+    for (int row = wave; row < in.n_rows; row += n_waves) {
+        const RowHdr h = load_row_string(in, load_row_range(in, row));
+        bool fast = h.simple && !dead;
+        int np = 0, skew = 0;
+        if (fast) {
+            wave_sync();  // the previous row's batches are done with the LDS window
+            skew = stage_window(ws, in.chars + h.sb, h.slen, 0, h.slen, in.chars, in.chars + in.n_chars);
+            wave_sync();
+            fast = h.slen <= 64 * 4 * (kLaneDwords - 1) ? gpt2_packed_starts<kLaneDwords - 1>(ws, skew, h.slen, DIGITS, 0, h.slen, np)
+                                                        : gpt2_packed_starts<kLaneDwords>(ws, skew, h.slen, DIGITS, 0, h.slen, np);
+        }
+        if (fast) {
+            const int cap = h.slen * mul;  // (h.simple: the offsets lie inside the chars tensor)
+            if (cursor + cap > limit) {
+                const int size = cap > kStageChunk ? cap : kStageChunk;
+                const int shard = wave % kShards;
+                int base = 0;
+                if (l == 0) base = atomicAdd(&w.status->stage_top[shard * kCounterStride], size);
+                base = wave_readlane(base, 0);
+                if (base < 0 || base > w.stage_region - size) {
+                    if (l == 0) atomicOr(&w.status->flags, kFlagStageOverflow);
+                    dead = true;
+                    fast = false;
+                } else {
+                    cursor = shard * w.stage_region + base;
+                    limit = cursor + size;
+                }
+            }
+        }
+        if (!fast) {
+            if (l == 0) w.row_used[row] = kRowPending;
+            ++n_pending;
+            continue;
+        }
+        if (l == 0) ws.pstart[np] = uint16_t(h.slen);
+        wave_sync();
+        RowState st{cursor, 0, 0, row};
+        for (int jb = 0; jb < np; jb += kWave) {
+            const int j = jb + l;
+            const bool valid = j < np;
+            int ps = 0, plen = 0;
+            uint64_t r0 = 0, r1 = 0;
+            if (valid) {
+                ps = int(ws.pstart[j]);
+                plen = int(ws.pstart[j + 1]) - ps;
+                if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps + skew, r0, r1);
+            }
+            lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, h.sb + ps);
+        }
+        if (l == 0) {
+            w.row_stage[row] = cursor;
+            w.row_cnt[row] = st.emitted;
+            if (w.row_emit) w.row_emit[row] = st.emitted;
+            w.row_used[row] = st.used;
+        }
+        cursor += st.used;
+    }
+    if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
+    if (n_pending && l == 0) atomicAdd(&w.status->n_pending, n_pending);
 }
 
 // ---- path X, one lane per piece.
