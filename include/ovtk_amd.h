@@ -296,7 +296,8 @@ int ovtk_string_tensor_pack(const ovtk_strings* in, uint8_t* packed, int64_t cap
 
 /* ---------------------------------------------------------------- row-shard exchange
  * No reference counterpart (the reference is single-process).  Rows shard contiguously over the ranks of one node
- * (rank r owns rows first(r) .. first(r+1), balanced like numpy.array_split); the one exchange step is an all-gather
+ * (any contiguous partition in rank order: balanced by row count, or by bytes -- every wire says how many rows it holds;
+ * max_shard_rows = the largest shard's row count, <= 0: ceil(n_rows / world)); the one exchange step is an all-gather
  * of fixed-size "wires": a 16-byte header (n_ids, n_rows), i32 ends[max_rows] (the shard's own end offsets), then
  * pad_ids ids of id_bytes (2 when every id < 65536, else 4) bytes.
  *   ovtk_shard_pack    builds this rank's wire from the ragged ids an encode call returned (ascending, gap-free
@@ -306,7 +307,8 @@ int ovtk_string_tensor_pack(const ovtk_strings* in, uint8_t* packed, int64_t cap
  *                      sum of the n_ids before it, its rows' offsets are that base plus the local ones): begins/ends
  *                      [n_rows], ids widened to i32.  Device memory: only enqueues work on `stream`; `result` lives
  *                      in device memory.  Host memory: synchronous, `result` in host memory.
- * result->status: OVTK_OK; OVTK_E_CAPACITY with max_shard_ids > pad_ids when some shard held more ids than the wire
+ * result->status: OVTK_OK; OVTK_E_ARG when the wires' row counts are not a partition of n_rows (or exceed max_shard_rows);
+ * OVTK_E_CAPACITY with max_shard_ids > pad_ids when some shard held more ids than the wire
  * has room for (identical on every rank: repeat the exchange with a larger pad); OVTK_E_RANGE when out_capacity is
  * too small; OVTK_E_UNSUPPORTED beyond 2^31 ids. */
 typedef struct {
@@ -316,7 +318,8 @@ typedef struct {
     int64_t reserved;
 } ovtk_shard_result;
 typedef struct ovtk_shard_exchange ovtk_shard_exchange;
-int ovtk_shard_exchange_create(int world, int64_t n_rows, int id_bytes, int device, ovtk_shard_exchange** out);
+int ovtk_shard_exchange_create(int world, int64_t n_rows, int id_bytes, int64_t max_shard_rows, int device,
+                               ovtk_shard_exchange** out);
 int64_t ovtk_shard_max_rows(const ovtk_shard_exchange* h);                    /* lens slots per wire */
 int64_t ovtk_shard_wire_bytes(const ovtk_shard_exchange* h, int64_t pad_ids); /* pad_ids: multiple of 8 */
 int ovtk_shard_pack(ovtk_shard_exchange* h, const int32_t* begins, const int32_t* ends, const int32_t* ids,

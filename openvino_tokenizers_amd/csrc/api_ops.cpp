@@ -856,16 +856,17 @@ struct ovtk_shard_exchange {
     std::vector<Profiler::Mark> marks;
 };
 
-int ovtk_shard_exchange_create(int world, int64_t n_rows, int id_bytes, int device, ovtk_shard_exchange** out) {
-    if (!out || world < 1 || n_rows < 0 || n_rows >= INT32_MAX || (id_bytes != 2 && id_bytes != 4))
+int ovtk_shard_exchange_create(int world, int64_t n_rows, int id_bytes, int64_t max_shard_rows, int device,
+                               ovtk_shard_exchange** out) {
+    if (!out || world < 1 || n_rows < 0 || n_rows >= INT32_MAX || (id_bytes != 2 && id_bytes != 4) || max_shard_rows > n_rows)
         return set_error(OVTK_E_ARG, "shard exchange: bad geometry");
     if (int rc = use_device(device)) return rc;
     auto h = std::make_unique<ovtk_shard_exchange>();
     h->device = device;
     ShardGeom& g = h->g;
     g.n_rows = n_rows; g.world = world; g.id_bytes = id_bytes;
-    g.base = n_rows / world; g.rem = n_rows % world;
-    g.max_rows = (g.base + (g.rem ? 1 : 0) + 3) / 4 * 4;  // ids start 16-byte aligned in the wire
+    if (max_shard_rows <= 0) max_shard_rows = (n_rows + world - 1) / world;  // rows balanced by count
+    g.max_rows = (max_shard_rows + 3) / 4 * 4;  // ids start 16-byte aligned in the wire
     *out = h.release();
     return OVTK_OK;
 }

@@ -969,8 +969,9 @@ static __global__ __launch_bounds__(kWave) void pack_header_kernel(int32_t* head
 // Wire format of one rank's ragged ids for the RCCL all-gather (no reference counterpart).  Every rank sends the same
 // number of bytes because RCCL has no all-gather-v:
 //     i32 n_ids, i32 n_rows, 2 x i32 0 | i32 ends[max_rows] (the shard's own end offsets) | pad_ids ids of 2 or 4 bytes
-// The receiver needs no scan and no counts exchange: rank r's ids go to the sum of the n_ids of the ranks before it,
-// and a row's global offsets are that base plus its local ones.  One kernel packs, one kernel unpacks.
+// The receiver needs no scan and no counts exchange: rank r's ids go to the sum of the n_ids of the ranks before it, its
+// rows to the sum of their n_rows (any contiguous partition of the rows: balanced by count or by bytes), and a row's
+// global offsets are the id base plus its local ones.  One kernel packs, one kernel unpacks.
 constexpr int kShardHeaderBytes = 16;
 struct ShardGeom {
     long long n_rows;    // global rows
@@ -978,9 +979,6 @@ struct ShardGeom {
     long long pad_ids;   // id slots per wire
     long long stride;    // bytes per wire
     int world, id_bytes;
-    long long base, rem;  // shard_rows(): ranks < rem own base + 1 rows
-
-    __host__ __device__ long long first_row(long long r) const { return r * base + (r < rem ? r : rem); }
 };
 
 static __global__ __launch_bounds__(kBlockThreads) void shard_pack_kernel(const int32_t* begins, const int32_t* ends,
@@ -1013,25 +1011,30 @@ static __global__ __launch_bounds__(kBlockThreads) void shard_unpack_kernel(cons
                                                                             int32_t* out_ends, int32_t* out_ids, long long out_cap,
                                                                             ovtk_shard_result* res) {
     const long long r = blockIdx.y;
-    long long off = 0, total = 0, biggest = 0;
+    long long off = 0, total = 0, biggest = 0, row0 = 0, rows_total = 0;
+    bool bad_rows = false;
     for (int q = 0; q < g.world; ++q) {  // the world's headers: a few scalar loads per block
-        const long long c = reinterpret_cast<const int32_t*>(wires + q * g.stride)[0];
-        if (q < r) off += c;
+        const int32_t* h = reinterpret_cast<const int32_t*>(wires + q * g.stride);
+        const long long c = h[0], nr = h[1];
+        if (q < r) { off += c; row0 += nr; }
         total += c;
+        rows_total += nr;
         biggest = c > biggest ? c : biggest;
+        bad_rows = bad_rows || nr < 0 || nr > g.max_rows;
     }
+    bad_rows = bad_rows || rows_total != g.n_rows;  // the shards are not a partition of the batch's rows
     const bool cut = biggest > g.pad_ids, too_big = total > INT32_MAX - 1, no_room = total > out_cap;
     if (blockIdx.x == 0 && r == 0 && threadIdx.x == 0) {
         res->n_ids = total;
         res->max_shard_ids = biggest;
         res->reserved = 0;
-        res->status = too_big ? OVTK_E_UNSUPPORTED : cut ? OVTK_E_CAPACITY : no_room ? OVTK_E_RANGE : OVTK_OK;
+        res->status = bad_rows ? OVTK_E_ARG : too_big ? OVTK_E_UNSUPPORTED : cut ? OVTK_E_CAPACITY : no_room ? OVTK_E_RANGE : OVTK_OK;
     }
-    if (cut || too_big || no_room) return;
+    if (bad_rows || cut || too_big || no_room) return;
     const uint8_t* wire = wires + r * g.stride;
     const int32_t* hdr = reinterpret_cast<const int32_t*>(wire);
     const int32_t* w_ends = hdr + kShardHeaderBytes / 4;
-    const long long cnt = hdr[0], rows = g.first_row(r + 1) - g.first_row(r), row0 = g.first_row(r);
+    const long long cnt = hdr[0], rows = hdr[1];
     const long long stride = (long long)gridDim.x * kBlockThreads, t0 = (long long)blockIdx.x * kBlockThreads + threadIdx.x;
     for (long long i = t0; i < rows; i += stride) {
         const long long e = w_ends[i], b = i ? w_ends[i - 1] : 0;

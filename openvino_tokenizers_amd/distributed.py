@@ -32,6 +32,32 @@ def shard_rows(n_rows: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_rows_by_bytes(begins, ends, world: int, ragged_begins=None, ragged_ends=None):
+    """Contiguous row ranges balanced by BYTES (prefix sum over ends - begins, cut at row boundaries): the
+    cost of a row is its text, and real batches are not of equal-length rows.  begins / ends: the strings' offsets
+    (numpy or torch, host); ragged_begins / ragged_ends: the rows' string ranges (default: one string per row).
+    Returns [(lo, hi)] * world, identical on every rank; every row lands in the shard that holds the midpoint of its
+    bytes in the cumulative text, so no shard exceeds its fair share by more than one row."""
+    import numpy as np
+    b = np.asarray(begins, dtype=np.int64)
+    e = np.asarray(ends, dtype=np.int64)
+    str_len = e - b
+    if ragged_begins is None:
+        row_len = str_len
+    else:
+        csum = np.concatenate([[0], np.cumsum(str_len)])
+        row_len = csum[np.asarray(ragged_ends, dtype=np.int64)] - csum[np.asarray(ragged_begins, dtype=np.int64)]
+    n = len(row_len)
+    cum = np.cumsum(row_len)
+    total = int(cum[-1]) if n else 0
+    if total == 0:
+        return [shard_rows(n, r, world) for r in range(world)]
+    mid = cum - row_len / 2.0
+    cuts = [int(np.searchsorted(mid, total * r / world, side="left")) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, n
+    return [(cuts[r], max(cuts[r], cuts[r + 1])) for r in range(world)]
+
+
 def _round_up(x, m):
     return (int(x) + m - 1) // m * m
 
@@ -60,7 +86,7 @@ class ShardExchange:
     """
 
     def __init__(self, n_rows: int, vocab_size: int, device, group=None, lib=None, pad_ids: int = 0, headroom: float = 1.125,
-                 stream=None):
+                 stream=None, max_shard_rows: int = 0):
         self.lib = lib if lib is not None else L.load()
         self.group = group
         self.world = dist.get_world_size(group)
@@ -73,7 +99,9 @@ class ShardExchange:
         self.headroom = float(headroom)
         self.pad_ids = _round_up(pad_ids, 8)
         self._h = C.c_void_p()
-        L.check(self.lib, self.lib.ovtk_shard_exchange_create(self.world, C.c_int64(self.n_rows), self.id_bytes,
+        # max_shard_rows: row slots per wire; 0 = shards balanced by row count, else the largest shard of the partition in
+        # use (shard_rows_by_bytes: pass n_rows when the partition changes from batch to batch)
+        L.check(self.lib, self.lib.ovtk_shard_exchange_create(self.world, C.c_int64(self.n_rows), self.id_bytes, C.c_int64(max_shard_rows),
                                                               (self.device.index or 0) if self.cuda else 0, C.byref(self._h)))
         self.max_rows = int(self.lib.ovtk_shard_max_rows(self._h))
         self._wires = {}          # slot -> (send, recv); two slots: a wire is free again once its batch is unpacked
@@ -217,10 +245,11 @@ class _NullCtx:
 
 
 def all_gather_ragged(begins: torch.Tensor, ends: torch.Tensor, ids: torch.Tensor, n_rows: int, vocab_size: int = 1 << 31,
-                      group=None, lib=None):
+                      group=None, lib=None, max_shard_rows: int = 0):
     """Unpipelined form: local ragged ids of every rank -> the global ragged tensor (begins, ends, ids) in rank
-    order, identical on all ranks.  n_rows: global row count (shard_rows() decides who owns what)."""
-    ex = ShardExchange(n_rows, vocab_size, ids.device, group=group, lib=lib)
+    order, identical on all ranks.  n_rows: global row count; the shards are any contiguous partition of the rows in
+    rank order (shard_rows() / shard_rows_by_bytes(); max_shard_rows as for ShardExchange)."""
+    ex = ShardExchange(n_rows, vocab_size, ids.device, group=group, lib=lib, max_shard_rows=max_shard_rows)
     ex.submit(begins, ends, ids)
     out = ex.flush()[-1]
     ex.close()

@@ -13,7 +13,7 @@ for cfg in 2 3 4; do
              "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
     rm -rf "$OUT/pmc_inst"
     timeout 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/pmc_inst" -- \
-        python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-alone-leg --streams 1 > "$OUT/pmc_inst.log" 2>&1
+        python bench.py --config $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-alone-leg --streams 1 > "$OUT/pmc_inst.log" 2>&1
     python - "$cfg" "$OUT" <<'PY'
 import csv, glob, collections, sys
 cfg, out = sys.argv[1], sys.argv[2]
