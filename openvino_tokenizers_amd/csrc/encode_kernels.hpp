@@ -185,24 +185,40 @@ __device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint6
     for (int i = 0; i < plen && i < 8; ++i) r0 |= uint64_t(p[i]) << (8 * i);
     for (int i = 8; i < plen; ++i) r1 |= uint64_t(p[i]) << (8 * (i - 8));
 }
-// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.  Two independent
-// 32-byte loads (cuckoo table), no probe chain.
-__device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
+// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.  Both candidate entries
+// (cuckoo table, no probe chain) are fetched with four independent 16-byte loads issued together and chosen by selects:
+// written with `if (key matches) take the payload`, the compiler sinks the payload load behind the key compare and a
+// lookup costs two dependent round trips instead of one.
+struct MemoFetch {
+    uint4 k[2], p[2];  // key halves {k0, k1} and payload {tok[3], cnt} of the two candidates
+};
+__device__ __forceinline__ MemoFetch memo_fetch(const PieceTableDev& P, uint64_t k0, uint64_t k1) {
     const uint32_t mix = piece_mix(k0, k1);
-    const PieceEntry e0 = P.slots[piece_h(mix, 0, P.shift)];
-    const PieceEntry e1 = P.slots[piece_h(mix, 1, P.shift)];
-    int cnt = -1;
-    if (e0.k0 == k0 && e0.k1 == k1) {
-        cnt = e0.cnt;
-#pragma unroll
-        for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e0.tok[k];
-    }
-    if (e1.k0 == k0 && e1.k1 == k1) {
-        cnt = e1.cnt;
-#pragma unroll
-        for (int k = 0; k < kPieceMaxIds; ++k) tok[k] = e1.tok[k];
-    }
-    return cnt;
+    const uint4* e0 = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, 0, P.shift));
+    const uint4* e1 = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, 1, P.shift));
+    MemoFetch f;
+    f.k[0] = e0[0];
+    f.p[0] = e0[1];
+    f.k[1] = e1[0];
+    f.p[1] = e1[1];
+#ifndef OVTK_SIMT_EMULATOR
+    // all four loads are in flight before anything looks at a result
+    asm volatile("" : "+v"(f.p[0].x), "+v"(f.p[0].y), "+v"(f.p[0].z), "+v"(f.p[0].w), "+v"(f.p[1].x), "+v"(f.p[1].y), "+v"(f.p[1].z),
+                 "+v"(f.p[1].w));
+#endif
+    return f;
+}
+__device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
+    const uint32_t a = uint32_t(k0), b = uint32_t(k0 >> 32), c = uint32_t(k1), d = uint32_t(k1 >> 32);
+    const bool m0 = f.k[0].x == a && f.k[0].y == b && f.k[0].z == c && f.k[0].w == d;
+    const bool m1 = f.k[1].x == a && f.k[1].y == b && f.k[1].z == c && f.k[1].w == d;
+    tok[0] = int32_t(m1 ? f.p[1].x : f.p[0].x);
+    tok[1] = int32_t(m1 ? f.p[1].y : f.p[0].y);
+    tok[2] = int32_t(m1 ? f.p[1].z : f.p[0].z);
+    return m1 ? int(f.p[1].w) : (m0 ? int(f.p[0].w) : -1);
+}
+__device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
+    return memo_resolve(memo_fetch(P, k0, k1), k0, k1, tok);
 }
 
 // ---- lookup kernel ------------------------------------------------------------------------------
