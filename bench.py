@@ -48,7 +48,7 @@ from tools.make_tokenizers import load_tokenizer  # noqa: E402
 from tools.workloads import TextModel, ragged_rows  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-KERNEL_NAMES = {"lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>", "shard_pack": "shard_pack_kernel",
+KERNEL_NAMES = {"lookup_ascii": "lookup_ascii_kernel", "lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>", "shard_pack": "shard_pack_kernel",
                 "shard_unpack": "shard_unpack_kernel", "scan_rows": "scan_kernel", "lookup_flat": "piece_lookup_kernel",
                 "lookup_words": "lookup_kernel<kFused> (BERT words)", "wordpiece_deferred": "wordpiece_deferred_kernel",
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",
@@ -213,7 +213,7 @@ def make_workload(args, lib, dev, rank):
     if cfg == "2":
         w = BpeEncode(args, lib, dev, rank, args.tokenizer, args.text, args.rows, args.bytes, 1000, no_memo=args.no_memo)
         w.metric = "input MB/s encoded (GPT-2 BPE, 512-byte strings)"
-        w.dominant_hint = "lookup_fused"
+        w.dominant_hint = "lookup_ascii"
         w.workload = (f"config 2: GPT-2-shaped byte-level BPE (V=50257, 50000 merges, trained in-process), {args.rows} x "
                       f"~{args.bytes}-byte {args.text} strings per GPU and batch, {w.batches.n} distinct batches in rotation "
                       f"({sum(w.batches.n_chars) / 1e6:.0f} MB of text), fused RegexSplit+BPETokenizer, inputs and outputs in HBM"
@@ -666,6 +666,8 @@ def main():
     ap.add_argument("--no-alone-leg", action="store_true", help="skip the one-stream leg behind `roofline` (profile runs of the "
                     "overlapped loop: rocprofv3's per-kernel average then covers the overlapped launches only)")
     ap.add_argument("--depth", type=int, default=2, help="batches launched ahead of the one being completed (two-half calls)")
+    ap.add_argument("--exchange", default="allgather", choices=["allgather", "p2p"],
+                    help="N > 1: one RCCL all-gather of the wires, or grouped direct sends / receives (one xGMI link per pair)")
     ap.add_argument("--exchange-stream", type=int, default=1, help="1: pack/unpack of the exchange on a HIP stream of their own")
     ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
@@ -698,7 +700,7 @@ def main():
         xstream = torch.cuda.Stream(dev) if args.exchange_stream else None
         # equal shards of the same text model: the ranks' id counts differ by well under 0.1 %, so 3 % of padding on the
         # wire (instead of the class's default 12.5 %) never triggers a re-gather and the gather moves 8 % fewer bytes
-        exchange = ShardExchange(wl.batches.rows * world, wl.vocab, dev, lib=lib, stream=xstream, headroom=1.03)
+        exchange = ShardExchange(wl.batches.rows * world, wl.vocab, dev, lib=lib, stream=xstream, headroom=1.03, transport=args.exchange)
 
     # A step = one batch through the hot path.  Where the op has the two-half form the host launches batch k, then
     # completes batch k-depth (status check, and with N > 1 its exchange) while the GPU works on k: the reference's
@@ -878,7 +880,7 @@ def main():
                                  f"HIP stream(s)" if two_half else "one blocking call per batch"),
                    "units_per_gpu_and_step": round(my_units / args.steps), "outputs_per_gpu_and_step": round(wl.mean_out()),
                    "exchange": ("none (1 GPU)" if exchange is None and world == 1 else ("none (rank-local consumer)" if exchange is None else
-                                                                    f"all-gather of ragged ids over RCCL, {exchange.id_bytes}-byte ids on the wire, "
+                                                                    f"{'all-gather' if exchange.transport == 'allgather' else 'grouped direct send/recv'} of ragged ids over RCCL, {exchange.id_bytes}-byte ids on the wire, "
                                                                     f"gather overlapped with the next encode, unpack one batch later ({exchange.regathers} re-gathers)"))},
         "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all, "stress": stress, "end_to_end": e2e,
         "parity_prefix_bit_exact": parity,

@@ -103,6 +103,7 @@ struct ovtk_vocab_encoder {
     int device = 0;
     int value_size = 4;
     StringMapDev dev{};
+    long long n_key_chars = 0;
     DevBuf slots, kb, ke, kc, values;
 };
 
@@ -281,6 +282,7 @@ int ovtk_vocab_encoder_create(const ovtk_vocab_encoder_params* p, ovtk_vocab_enc
     h->dev.key_begins = h->kb.as<int32_t>();
     h->dev.key_ends = h->ke.as<int32_t>();
     h->dev.key_chars = h->kc.as<uint8_t>();
+    h->n_key_chars = (long long)host.key_chars.size();
     h->dev.values = h->values.as<void>();
     h->dev.value_size = p->value_size;
     *out = h.release();
@@ -311,12 +313,12 @@ int ovtk_vocab_encoder_run(ovtk_vocab_encoder* h, const ovtk_strings* in, const 
         int32_t d;
         std::memcpy(&d, default_value, 4);
         OVTK_LAUNCH(ws->marks, "vocab_encoder", vocab_encoder_kernel<int32_t>, grid_for_elems(n), kBlockThreads, s, b, e, c,
-                    (long long)in->n_chars, n, h->dev, d, reinterpret_cast<int32_t*>(d_out), st);
+                    (long long)in->n_chars, n, h->dev, h->n_key_chars, d, reinterpret_cast<int32_t*>(d_out), st);
     } else {
         long long d;
         std::memcpy(&d, default_value, 8);
         OVTK_LAUNCH(ws->marks, "vocab_encoder", vocab_encoder_kernel<long long>, grid_for_elems(n), kBlockThreads, s, b, e, c,
-                    (long long)in->n_chars, n, h->dev, d, reinterpret_cast<long long*>(d_out), st);
+                    (long long)in->n_chars, n, h->dev, h->n_key_chars, d, reinterpret_cast<long long*>(d_out), st);
     }
     if (int rc = finish_status(*ws.ws, s)) return rc;
     if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside the chars tensor");
@@ -366,7 +368,15 @@ int ovtk_ragged_to_dense(const int32_t* begins, const int32_t* ends, int64_t n_r
     a.mask = nullptr;
     if (out_mask)
         if (int rc = out_target(ws->out_b, out_mask, mask_bytes, mem, &a.mask)) return rc;
-    OVTK_LAUNCH(ws->marks, "ragged_to_dense", ragged_to_dense_kernel, grid_for_rows(a.n_rows), kBlockThreads, s, a);
+    const unsigned long long total = (unsigned long long)n_rows * (unsigned long long)target_dim;
+    const bool flat = a.cell == 4 && total < (1ull << 31) && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+                      (!a.mask || (reinterpret_cast<uintptr_t>(a.mask) & 3) == 0) && (reinterpret_cast<uintptr_t>(a.data) & 3) == 0;
+    if (flat)
+        OVTK_LAUNCH(ws->marks, "ragged_to_dense", ragged_to_dense_flat4_kernel,
+                    int(std::min<unsigned long long>((total / 4 + kBlockThreads) / kBlockThreads, 1ull << 22)),  // one group of four per thread
+                    kBlockThreads, s, a);
+    else
+        OVTK_LAUNCH(ws->marks, "ragged_to_dense", ragged_to_dense_kernel, grid_for_rows(a.n_rows), kBlockThreads, s, a);
     if (int rc = finish_status(*ws.ws, s)) return rc;
     if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "ragged_to_dense: a row reads past the data tensor");
     if (int rc = copy_back(out_dense, a.out, dense_bytes, mem, s)) return rc;

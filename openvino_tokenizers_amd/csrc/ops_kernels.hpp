@@ -144,12 +144,35 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
 }
 
 // =============================================================================================
-// VocabEncoder (src/vocab_encoder.cpp:88-91): one lane per element, FNV-1a hash, open addressing.
+// VocabEncoder (src/vocab_encoder.cpp:88-91): one lane per element, open addressing.  A string of up to 16 bytes (nearly
+// every word) is fetched as the aligned dwords that hold it -- five loads instead of one per byte -- and hashed / compared
+// from registers; the key it is compared with is fetched the same way.  Longer strings take the byte loops.
 // =============================================================================================
+// Bytes [p, p + len) (len <= 16) as four little-endian words, zero-padded; false when an aligned dword that holds them
+// would reach outside [buf, buf_end) (the caller then reads bytes).
+__device__ __forceinline__ bool load_words16(const uint8_t* p, int len, const uint8_t* buf, const uint8_t* buf_end, uint32_t (&w)[4]) {
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    const uint8_t* a = p - (addr & 3);
+    const int sh = int(addr & 3) * 8;
+    const int nw = (int(addr & 3) + len + 3) >> 2;  // 1..5 dwords
+    if (a < buf || a + 4 * nw > buf_end) return false;
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(a);
+    uint32_t r[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) r[j] = j < nw ? q[j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t x = uint32_t(((static_cast<unsigned long long>(r[j + 1]) << 32) | r[j]) >> sh);
+        const int have = len - 4 * j;
+        w[j] = have >= 4 ? x : (have <= 0 ? 0u : (x & ((1u << (8 * have)) - 1u)));
+    }
+    return true;
+}
 template <typename T>
 static __global__ __launch_bounds__(kBlockThreads) void vocab_encoder_kernel(const int32_t* begins, const int32_t* ends,
                                                                       const uint8_t* chars, long long n_chars, int n,
-                                                                      StringMapDev M, T dflt, T* out, RunStatus* status) {
+                                                                      StringMapDev M, long long n_key_chars, T dflt, T* out,
+                                                                      RunStatus* status) {
     const int stride = int(gridDim.x) * kBlockThreads;
     const T* values = static_cast<const T*>(M.values);
     for (int i = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); i < n; i += stride) {
@@ -160,7 +183,18 @@ static __global__ __launch_bounds__(kBlockThreads) void vocab_encoder_kernel(con
         }
         const uint8_t* s = chars + b;
         const int len = int(e - b);
-        const uint32_t h = hash_bytes(s, len);
+        uint32_t w[4] = {0, 0, 0, 0};
+        const bool packed = len <= 16 && load_words16(s, len, chars, chars + n_chars, w);
+        uint32_t h;
+        if (packed) {
+            h = 2166136261u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * j < len) h = hash_word_step(h, w[j]);
+            h = hash_finish(h, len);
+        } else {
+            h = hash_bytes(s, len);
+        }
         uint32_t p = h & M.mask;
         T val = dflt;
         for (;;) {
@@ -171,7 +205,11 @@ static __global__ __launch_bounds__(kBlockThreads) void vocab_encoder_kernel(con
                 const int kb = M.key_begins[k];
                 if (M.key_ends[k] - kb == len) {
                     bool same = true;
-                    for (int j = 0; j < len && same; ++j) same = M.key_chars[kb + j] == s[j];
+                    uint32_t kw[4];
+                    if (packed && load_words16(M.key_chars + kb, len, M.key_chars, M.key_chars + n_key_chars, kw))
+                        same = kw[0] == w[0] && kw[1] == w[1] && kw[2] == w[2] && kw[3] == w[3];
+                    else
+                        for (int j = 0; j < len && same; ++j) same = M.key_chars[kb + j] == s[j];
                     if (same) { val = values[k]; break; }
                 }
             }
@@ -240,6 +278,62 @@ static __global__ __launch_bounds__(kBlockThreads) void ragged_to_dense_kernel(D
                     const long long k = m / a.inner;
                     mrow[m] = (k >= first && k < first + take) ? 1 : 0;
                 }
+        }
+    }
+}
+
+// The common case -- 4-byte elements (token ids), the whole output below 2^31 elements and 16-byte aligned -- as a flat
+// streaming kernel: a thread produces FOUR consecutive output elements (one 16-byte store of ids, one 4-byte store of mask
+// bytes) wherever they fall in the [rows, target] grid; a group of four may straddle two rows.  Every store instruction of
+// a wave is a full 1 KB (ids) / 256 B (mask) of consecutive bytes; the wave-per-row form above stores 4 bytes and ONE
+// mask byte per lane and leaves a third of its lanes idle on the last 64 columns of a 150-wide row (42 -> 2x us at
+// config-2 size).
+static __global__ __launch_bounds__(kBlockThreads) void ragged_to_dense_flat4_kernel(DenseArgs a) {
+    const unsigned total = unsigned(a.n_rows) * unsigned(a.target);
+    const unsigned T = unsigned(a.target);
+    const uint32_t dflt = uint32_t(a.dflt[0]) | uint32_t(a.dflt[1]) << 8 | uint32_t(a.dflt[2]) << 16 | uint32_t(a.dflt[3]) << 24;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(a.data);
+    const unsigned stride = gridDim.x * kBlockThreads * 4u;
+    for (unsigned idx = (blockIdx.x * kBlockThreads + threadIdx.x) * 4u; idx < total; idx += stride) {
+        unsigned row = idx / T, k = idx - row * T;
+        uint32_t v[4];
+        uint32_t m = 0;
+        long long b = 0, take = 0, first = 0;
+        bool have = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (idx + unsigned(j) < total) {
+                if (!have) {  // the row's range (again after the group crossed into the next row)
+                    b = a.begins[row];
+                    const long long len = (long long)a.ends[row] - b;
+                    take = (a.pad_max_length || len < 0 || len > a.target) ? a.target : len;
+                    first = a.pad_right ? 0 : a.target - take;
+                    if (b < 0 || b + take > a.n_data) {
+                        atomicOr(&a.status->flags, kFlagRange);
+                        take = 0;
+                    }
+                    have = true;
+                }
+                const bool data = (long long)k >= first && (long long)k < first + take;
+                v[j] = data ? src[b + k - first] : dflt;
+                m |= (data ? 1u : 0u) << (8 * j);
+                if (++k == T) {
+                    k = 0;
+                    ++row;
+                    have = false;
+                }
+            } else {
+                v[j] = 0;
+            }
+        }
+        if (idx + 4u <= total) {
+            *reinterpret_cast<uint4*>(a.out + (size_t)idx * 4) = make_uint4(v[0], v[1], v[2], v[3]);
+            if (a.mask) *reinterpret_cast<uint32_t*>(a.mask + idx) = m;
+        } else {
+            for (unsigned j = 0; idx + j < total; ++j) {
+                reinterpret_cast<uint32_t*>(a.out)[idx + j] = v[j];
+                if (a.mask) a.mask[idx + j] = uint8_t(m >> (8 * j));
+            }
         }
     }
 }

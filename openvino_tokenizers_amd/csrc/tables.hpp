@@ -110,11 +110,23 @@ __host__ __device__ inline uint32_t piece_h(uint32_t mix, int which, uint32_t sh
     const uint32_t c = which == 0 ? 0x9E3779B1u : (which == 1 ? 0xD6E8FEB9u : 0xA0761D65u);
     return (mix * c) >> shift;
 }
-// FNV-1a over the bytes; the same function on host (table build) and device (probe).
+// Hash of a byte string, four bytes per step (little-endian words, the last one zero-padded), the same function on host
+// (table build) and device (probe).  The device feeds it words it already holds in registers: hash_words().
+__host__ __device__ inline uint32_t hash_word_step(uint32_t h, uint32_t w) { return (h ^ w) * 0x9E3779B1u; }
+__host__ __device__ inline uint32_t hash_finish(uint32_t h, int n) {
+    h ^= uint32_t(n) * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    return h ^ (h >> 13);
+}
 __host__ __device__ inline uint32_t hash_bytes(const uint8_t* p, int n) {
     uint32_t h = 2166136261u;
-    for (int i = 0; i < n; ++i) h = (h ^ p[i]) * 16777619u;
-    return h;
+    for (int i = 0; i < n; i += 4) {
+        uint32_t w = 0;
+        for (int j = 0; j < 4 && i + j < n; ++j) w |= uint32_t(p[i + j]) << (8 * j);
+        h = hash_word_step(h, w);
+    }
+    return hash_finish(h, n);
 }
 
 // ---- host builders ----------------------------------------------------------------------

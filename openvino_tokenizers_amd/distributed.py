@@ -86,7 +86,7 @@ class ShardExchange:
     """
 
     def __init__(self, n_rows: int, vocab_size: int, device, group=None, lib=None, pad_ids: int = 0, headroom: float = 1.125,
-                 stream=None, max_shard_rows: int = 0):
+                 stream=None, max_shard_rows: int = 0, transport: str = "allgather"):
         self.lib = lib if lib is not None else L.load()
         self.group = group
         self.world = dist.get_world_size(group)
@@ -95,6 +95,14 @@ class ShardExchange:
         self.device = torch.device(device)
         self.cuda = self.device.type == "cuda"
         self.stream = stream      # torch.cuda.Stream for pack / unpack (None: the stream current at each call)
+        # How the wires travel.  "allgather": one all_gather_into_tensor (RCCL picks the algorithm -- on a ring every byte
+        # crosses N-1 links one after the other).  "p2p": every rank sends its wire straight to each peer and receives
+        # theirs, as ONE group of isend / irecv pairs (RCCL: grouped ncclSend / ncclRecv) -- on the MI355X node's fully
+        # connected xGMI each pair has a link of its own, so a wire crosses exactly one link and the 7 transfers of a
+        # rank run side by side ("direct 7-link exchange").  Same wires, same unpack, same result.
+        if transport not in ("allgather", "p2p"):
+            raise ValueError("transport must be 'allgather' or 'p2p'")
+        self.transport = transport
         self.id_bytes = 2 if int(vocab_size) <= 65536 else 4
         self.headroom = float(headroom)
         self.pad_ids = _round_up(pad_ids, 8)
@@ -163,8 +171,21 @@ class ShardExchange:
         L.check(self.lib, self.lib.ovtk_shard_pack(self._h, self._ptr(begins), self._ptr(ends), self._ptr(ids), C.c_int64(begins.numel()),
                                                    C.c_int64(ids.numel()), C.c_int64(self.pad_ids), self._ptr(send), self._mem,
                                                    self._stream_ptr()))
-        work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)  # RCCL's stream waits for the pack
+        if self.transport == "allgather" or self.world == 1:
+            work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)  # RCCL's stream waits for the pack
+        else:
+            n = send.numel()
+            recv[self.rank * n:(self.rank + 1) * n].copy_(send, non_blocking=True)
+            ops = []
+            for step in range(1, self.world):   # rank r's k-th pair: send to r+k, receive from r-k -- every link busy at once
+                to, frm = (self.rank + step) % self.world, (self.rank - step) % self.world
+                ops.append(dist.P2POp(dist.isend, send, self._global_rank(to), group=self.group))
+                ops.append(dist.P2POp(dist.irecv, recv[frm * n:(frm + 1) * n], self._global_rank(frm), group=self.group))
+            work = _Works(dist.batch_isend_irecv(ops))
         return dict(local=local, slot=slot, work=work, recv=recv, pad=self.pad_ids)
+
+    def _global_rank(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
 
     def _start_unpack(self, b):
         """Gathered wires -> global ragged tensor; only enqueues (CUDA)."""
@@ -234,6 +255,17 @@ class ShardExchange:
             out.append(self._collect(self._start_unpack(self._gathering)))
         self._unpacking = self._gathering = None
         return out
+
+
+class _Works:
+    """Several async work handles waited for as one."""
+
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
 
 
 class _NullCtx:

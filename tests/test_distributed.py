@@ -53,14 +53,14 @@ def _spans(lens, world, by_bytes):
     return shard_rows_by_bytes(ends - lens, ends, world)
 
 
-def _worker(rank, world, port, n_rows, vocab, q, by_bytes=False):
+def _worker(rank, world, port, n_rows, vocab, q, by_bytes=False, transport="allgather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from openvino_tokenizers_amd import _lib as L
         lib = L.load(EMU)
         batches = _batches(7, n_rows, vocab)
-        ex = ShardExchange(n_rows, vocab, "cpu", lib=lib, max_shard_rows=n_rows if by_bytes else 0)
+        ex = ShardExchange(n_rows, vocab, "cpu", lib=lib, max_shard_rows=n_rows if by_bytes else 0, transport=transport)
         got = []
         for lens, ids in batches:
             done = ex.submit(*_local_shard(lens, ids, rank, world, span=_spans(lens, world, by_bytes)[rank]))
@@ -116,13 +116,14 @@ def test_shard_rows_by_bytes():
     assert shard_rows_by_bytes(b, e, 2, rb, re_) == [(0, 2), (2, 3)]
 
 
-@pytest.mark.parametrize("world, n_rows, vocab, by_bytes", [(2, 37, 50000, False), (3, 10, 130000, False), (2, 1, 100, False),
-                                                            (2, 41, 50000, True), (3, 64, 130000, True)])
-def test_shard_exchange_gloo(emu_lib, world, n_rows, vocab, by_bytes):
+@pytest.mark.parametrize("world, n_rows, vocab, by_bytes, transport", [
+    (2, 37, 50000, False, "allgather"), (3, 10, 130000, False, "allgather"), (2, 1, 100, False, "allgather"),
+    (2, 41, 50000, True, "allgather"), (3, 64, 130000, True, "allgather"), (2, 37, 50000, False, "p2p"), (3, 64, 130000, True, "p2p")])
+def test_shard_exchange_gloo(emu_lib, world, n_rows, vocab, by_bytes, transport):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, vocab, q, by_bytes)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, vocab, q, by_bytes, transport)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=180) for _ in procs]

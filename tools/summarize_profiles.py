@@ -14,7 +14,9 @@ from pathlib import Path
 import pandas as pd
 
 ROOT = Path(__file__).resolve().parent.parent
-TAG = {"lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "lookup_kernel<2>": "lookup_fused",
+TAG = {"lookup_ascii_kernel": "lookup_ascii", "regex_split_kernel<0>": "regex_count", "regex_split_kernel<1>": "regex_write",
+       "ragged_to_dense_kernel": "ragged_to_dense", "vocab_encoder_kernel": "vocab_encoder",
+       "lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "lookup_kernel<2>": "lookup_fused",
        "merge_kernel": "bpe_merge",
        "split_seq_kernel<0>": "split_count", "split_seq_kernel<1>": "split_write",
        "exact_kernel": "bpe_exact", "compact_kernel": "compact", "prep_rows_kernel": "prep_rows",
@@ -36,7 +38,7 @@ def tag_of(kernel):
     """bench.py's name of a kernel: template arguments matter only for the first one of lookup / split kernels."""
     base, _, args = kernel.partition("<")
     first = args.split(",")[0].rstrip(">").strip() if args else ""
-    keyed = f"{base}<{first}>" if base in ("lookup_kernel", "split_seq_kernel", "split_kernel") and first else base
+    keyed = f"{base}<{first}>" if base in ("lookup_kernel", "split_seq_kernel", "split_kernel", "regex_split_kernel") and first else base
     return TAG.get(keyed, TAG.get(base, kernel))
 
 
@@ -45,7 +47,7 @@ def main(prefix):
     out_dir.mkdir(parents=True, exist_ok=True)
     stem = Path(prefix).name
     pmc_json = {}
-    for cfg in (2, 3, 4, 5):
+    for cfg in (2, 3, 4, 5, "r2d", "vocab_encoder"):
         st = newest(str(ROOT / f"gpurun_out/prof_c{cfg}/*/*kernel_stats.csv"))
         if st:
             d = pd.read_csv(st)
