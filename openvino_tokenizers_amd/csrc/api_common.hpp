@@ -191,6 +191,9 @@ namespace ovtk {
 // Up to this many rows the last block of merge_kernel sums the row counts itself (one block reads 4 bytes per row);
 // larger batches keep the parallel count_scan_kernel.
 constexpr int kFoldTailRows = 1 << 18;
+// A batch this small is one launch of one block (encode_small_kernel): BASELINE config 1 is 32 rows / 4 KB.
+constexpr int kSmallRows = 256;
+constexpr int64_t kSmallChars = 64 << 10;
 
 
 template <class Middle>
@@ -209,6 +212,8 @@ public:
         in_mem_ = OVTK_MEM_DEVICE;
         keep_ = std::move(keep);
     }
+    // The middle knows the one-launch form of a small batch (EncodeWork::small, encode_small_kernel).
+    void enable_small() { small_ok_ = true; }
 
     int start() {
         if (!ws_->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
@@ -227,6 +232,7 @@ public:
         n_tiles_ = (n_rows_ + kRowTile - 1) / kRowTile;
         if (self_alloc_)  // every wave may leave one chunk partly unused
             stage_cap_ = std::min<int64_t>(stage_cap_ + int64_t(grid_ * kWavesPerBlock + kShards) * kStageChunk, INT32_MAX - 1);
+        small_ = small_ok_ && self_alloc_ && fold_tail_ && n_rows_ <= kSmallRows && in_.strings.n_chars <= kSmallChars;
         return launch();
     }
 
@@ -256,6 +262,7 @@ public:
                     return set_error(OVTK_E_UNSUPPORTED, "exact-path scratch would exceed 3 GiB; split the call");
             } else if (st.flags & kFlagTailPending) {
                 fold_tail_ = false;  // more exact pieces than the folded tail takes: once more with their own launches
+                small_ = false;
             } else {
                 if (st.flags & kFlagOutCapacity)
                     return set_error(OVTK_E_CAPACITY, op_ + ": output ids buffer too small (" + std::to_string(st.n_out) +
@@ -267,6 +274,7 @@ public:
                 if (mem_ == OVTK_MEM_HOST) OVTK_HIP(hipStreamSynchronize(s_));
                 return OVTK_OK;
             }
+            small_ = false;                    // (whatever it was: the repeat takes the ordinary launches)
             if (int rc = launch()) return rc;  // a workspace was too small: once more with the size the kernels asked for
         }
         return set_error(OVTK_E_HIP, "workspace sizing did not converge");
@@ -314,6 +322,28 @@ private:
         w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap_, 0xFFFFFFF0ll));
         w.status = ws.status.as<RunStatus>();
 
+        if (small_ && fold) {  // one launch: blocks look their rows up, the last one merges, compacts and reports
+            w.small = 1;
+            const int blocks = std::max(1, std::min((n_rows_ + kWavesPerBlock - 1) / kWavesPerBlock, kSmallRows / kWavesPerBlock));
+            w.n_waves = blocks * kWavesPerBlock;
+            w.out_ids = d_ids_;
+            w.out_begins = d_begins_;
+            w.out_ends = d_ends_;
+            w.host_status = ws.host_status;
+            w.status_words = int32_t(status_bytes / 4);
+            // the kernel leaves the device-side status zeroed behind itself: the memset is for a workspace it has not seen
+            if (ws.clean_status != w.status || ws.clean_bytes < status_bytes || ws.clean_after_lease + 1 != ws.lease_count)
+                OVTK_HIP(hipMemsetAsync(w.status, 0, status_bytes, s_));
+            ws.clean_status = w.status;
+            ws.clean_bytes = status_bytes;
+            ws.clean_after_lease = ws.lease_count;
+            std::memset(ws.host_status, 0, sizeof(RunStatus));  // the kernel fills the scalar fields and shard_count[0] only
+            ws.host_status->flags = kFlagStageOverflow;          // overwritten by the kernel; one that did not run leaves an error
+            middle_(ws, d_in_, w, blocks);
+            OVTK_HIP(hipEventRecord(ws.done, s_));
+            return OVTK_OK;
+        }
+        ws.clean_status = nullptr;  // (the ordinary launches below leave their counters in the status block)
         OVTK_HIP(hipMemsetAsync(w.status, 0, status_bytes, s_));
         if (!self_alloc_)
             OVTK_LAUNCH(ws.marks, "prep_rows", prep_rows_kernel, std::min(grid_, kTicketBlocks), kBlockThreads, s_, d_in_, mul_, w);
@@ -342,6 +372,7 @@ private:
     int blocks_per_cu_;
     WorkspaceLease ws_;
     bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
+    bool small_ok_ = false, small_ = false;
     RowsIn d_in_{};
     int n_rows_ = 0, grid_ = 0, n_tiles_ = 0;
     int64_t stage_cap_ = 0, shard_cap_ = 0, exact_cap_ = 0, scratch_cap_ = 0;

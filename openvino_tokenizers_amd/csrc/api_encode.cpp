@@ -481,6 +481,20 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            [=](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                const bool tickets = w.rows_per_ticket != 0;
                                const bool llama3 = split && split->dev.kind == kSplitLlama3;
+                               if (w.small) {  // the whole call in one launch of one block
+                                   const SplitDev sd = split ? split->dev : SplitDev{};
+                                   const bool nar = bpe->narrow_ids;
+#define OVTK_SMALL(MODE)                                                                                                          \
+    do {                                                                                                                          \
+        if (nar) OVTK_LAUNCH(ws.marks, "encode_small", (encode_small_kernel<MODE, true>), grid, kBlockThreads, s, d_in, sd, bpe->dev, w); \
+        else OVTK_LAUNCH(ws.marks, "encode_small", (encode_small_kernel<MODE, false>), grid, kBlockThreads, s, d_in, sd, bpe->dev, w);    \
+    } while (0)
+                                   if (llama3) OVTK_SMALL(kFusedLlama3);
+                                   else if (split) OVTK_SMALL(kFused);
+                                   else OVTK_SMALL(kPieces);
+#undef OVTK_SMALL
+                                   return;
+                               }
                                if (llama3 && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFusedLlama3, true>), grid, kBlockThreads, s, d_in,
                                                split->dev, bpe->dev, w);
@@ -532,6 +546,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (pieces_ws) r->input_on_device(pieces_ws);
+    if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;

@@ -19,6 +19,7 @@
 //                               compaction)
 #pragma once
 
+#include <cstddef>
 #include <type_traits>
 
 #include "bpe_device.hpp"
@@ -59,6 +60,12 @@ struct EncodeWork {
     int32_t fold_tail;      // merge_kernel's last block also runs exact pieces + the row scan (no exact / count_scan launches)
     long long out_cap;      // caller's ids capacity (the folded tail's capacity check)
     int32_t only_pending;   // lookup_kernel<kFused>: take only the rows lookup_ascii_kernel marked kRowPending in row_used
+    int32_t small;          // the whole call is ONE launch of encode_small_kernel (one block): the fields below are set
+    int32_t* out_ids;       //   caller's ids / begins / ends (device pointers) ...
+    int32_t* out_begins;
+    int32_t* out_ends;
+    RunStatus* host_status; //   ... and the pinned status block the kernel itself fills (no memset / copy dispatches)
+    int32_t status_words;   //   dwords of `status` to zero at the kernel's start (RunStatus + the tile counts behind it)
     int32_t rows_per_ticket;  // lookup_kernel, allocator mode: 0 = static rows per wave, else rows handed out per ticket
     int32_t n_waves;        // persistent waves of the prep / lookup launches (wave w owns rows w, w + n_waves, ...)
     long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities), or
@@ -236,7 +243,7 @@ struct WaveMiss {
 // Writes the first `n` (<= 64) buffered pieces to this block's shard of the deferred list, moves the rest up.
 __device__ __forceinline__ void flush_misses(WaveMiss& mb, int& n_miss, int n, const EncodeWork& w) {
     const int l = lane_id();
-    const int shard = int(blockIdx.x) % kShards;
+    const int shard = w.small ? 0 : int(blockIdx.x) % kShards;  // (a small batch: one dense list for the one block that merges)
     int idx = 0;
     if (l == 0) idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
     idx = wave_readlane(idx, 0);
@@ -367,7 +374,7 @@ __device__ __forceinline__ int row_capacity_checked(const RowsIn& in, const RowH
 }
 
 template <int MODE, bool TICKETS = false>
-static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+__device__ __forceinline__ void lookup_body(const RowsIn& in, const SplitDev& sp, const BpeDev& T, const EncodeWork& w) {
     __shared__ WaveScratch ws_all[kWavesPerBlock];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
     if (w.status->flags & kFatalFlags) return;
@@ -505,6 +512,10 @@ static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn 
     }
     if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
 }
+template <int MODE, bool TICKETS = false>
+static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+    lookup_body<MODE, TICKETS>(in, sp, T, w);
+}
 
 
 // ---- the GPT-2 family's common case as a kernel of its own: rows of ONE string that is ONE ASCII scan window.
@@ -624,10 +635,10 @@ __device__ __forceinline__ void scan_tiles_one_block(int n_rows, const EncodeWor
 
 // Start of a kernel that folds the row scan into its end (merge_kernel, wordpiece_deferred_kernel): tile sums of what the
 // lookup kernel emitted, one wave per tile, spread over the whole grid (2-D grids: x fastest).
-__device__ __forceinline__ void fold_emitted_tile_sums(const EncodeWork& w, int tail_rows) {
+__device__ __forceinline__ void fold_emitted_tile_sums(const EncodeWork& w, int tail_rows, bool solo = false) {
     const int n_tiles = (tail_rows + kRowTile - 1) / kRowTile;
-    const int wave = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
-    const int n_waves = int(gridDim.x) * int(gridDim.y) * kWavesPerBlock;
+    const int wave = solo ? wave_in_block() : (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
+    const int n_waves = solo ? kWavesPerBlock : int(gridDim.x) * int(gridDim.y) * kWavesPerBlock;
     for (int tile = wave; tile < n_tiles; tile += n_waves) {
         const int row = tile * kRowTile + lane_id();
         const int s0 = wave_sum(row < tail_rows ? w.row_emit[row] : 0);
@@ -641,9 +652,10 @@ __device__ __forceinline__ void fold_emitted_tile_sums(const EncodeWork& w, int 
 // NARROW: every id < 65536 -- path F keeps ids and merged ids as u16 (8 KB of LDS per wave instead of 12: 4 resident
 // blocks per CU instead of 3, and the kernel's time follows its occupancy).
 // A wave's LDS: path F  key u32[16*64] | id IdT[16*64] | nid IdT[16*64];  path W  key u64[512] | id u32[512].
+// solo: this block is the only one at work (the last block of encode_small_kernel): every shard is its, no ticket.
 template <bool NARROW>
-static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w, int tail_rows,
-                                                                     long long out_cap) {
+__device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, const EncodeWork& w, int tail_rows, long long out_cap,
+                                           bool solo = false) {
     using IdT = typename std::conditional<NARROW, uint16_t, uint32_t>::type;
     constexpr int kWaveLdsBytes = kFastSyms * kWave * (4 + 2 * int(sizeof(IdT)));
     static_assert(kWaveLdsBytes >= kChunkSyms * 12, "path W's key u64[] + id u32[] must fit the wave's LDS");
@@ -656,7 +668,7 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
     if (threadIdx.x == 0) pushed_exact = 0;
     __syncthreads();
     if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
-    if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows);
+    if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows, solo);
     uint64_t* key = lds_all[wave_in_block()];                                 // path W
     uint32_t* id = reinterpret_cast<uint32_t*>(key + kChunkSyms);             // path W
     uint32_t* fkey = reinterpret_cast<uint32_t*>(key);                        // path F
@@ -664,15 +676,17 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
     IdT* fnid = fid + kFastSyms * kWave;                                      // path F
     const int l = lane_id();
     const int SL = T.suffix_len;
-    const int shard = int(blockIdx.x);  // fastest-varying: blocks that become resident late are spread over all shards
+    {  // (x is the fastest-varying block index: blocks that become resident late are spread over all shards; solo: the
+       // small batch's blocks filed everything under shard 0)
+    const int shard = solo ? 0 : int(blockIdx.x);
     int count = w.status->shard_count[shard * kCounterStride];
     if (count > w.shard_cap) count = w.shard_cap;
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
     // 64-piece batches of the shard: strided over its waves, or (w.rows_per_ticket != 0, see lookup_kernel: late blocks
     // take fewer) handed out by a per-shard ticket, the next one requested before this batch's entries are loaded.
     const bool dyn = w.rows_per_ticket != 0;
-    const int stride = int(gridDim.y) * kBlockThreads;
-    int bt_pend = 0, base = (int(blockIdx.y) * kWavesPerBlock + wave_in_block()) * kWave;
+    const int stride = (solo ? 1 : int(gridDim.y)) * kBlockThreads;
+    int bt_pend = 0, base = ((solo ? 0 : int(blockIdx.y)) * kWavesPerBlock + wave_in_block()) * kWave;
     auto bt_issue = [&]() {
         if (l == 0) bt_pend = atomicAdd(&w.status->batch_ticket[shard * kCounterStride], 1);
     };
@@ -805,10 +819,17 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
             if (l == 0) pushed_exact = 1;
         }
     }
+    }
     if (tail_rows <= 0) return;
     // ---- folded tail: every block takes a ticket when its batches are done; the last one is alone on the data
     __syncthreads();
-    if (!last_block_done(&w.status->ticket[0], gridDim.x * gridDim.y, pushed_exact != 0)) return;
+    if (solo) {
+        if (threadIdx.x == 0) publish_release();
+        __syncthreads();
+        publish_acquire();
+    } else if (!last_block_done(&w.status->ticket[0], gridDim.x * gridDim.y, pushed_exact != 0)) {
+        return;
+    }
     const int n_exact = w.status->n_exact;
     if (n_exact > kBlockThreads || (w.status->flags & kFlagExactOverflow)) {  // too many for one block: separate launches
         if (threadIdx.x == 0) atomicOr(&w.status->flags, kFlagTailPending);
@@ -822,6 +843,11 @@ static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, 
         if (w.status->flags & kFlagScratchOverflow) return;
     }
     scan_tiles_one_block(tail_rows, w, out_cap);
+}
+template <bool NARROW>
+static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w, int tail_rows,
+                                                                     long long out_cap) {
+    merge_body<NARROW>(in, T, w, tail_rows, out_cap);
 }
 
 // ---- path X as its own launch.
@@ -859,18 +885,18 @@ static __global__ __launch_bounds__(kBlockThreads) void count_scan_kernel(int n_
 // Unused staging entries (rows that had deferred pieces) are squeezed out by ballot compaction.
 constexpr int kCompactRows = 4;    // rows per work item (8: no better)
 constexpr int kCompactChunks = 3;  // 64-entry chunks of a row held in registers; longer rows finish in a loop
-static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out,
-                                                                       int32_t* out_begins, int32_t* out_ends) {
+__device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, int32_t* out, int32_t* out_begins, int32_t* out_ends,
+                                             bool solo = false) {
     // kFlagTailPending: merge_kernel's folded tail left the exact pieces and the tile scan to a second attempt -- tile_off
     // and parts of the staging buffer hold whatever the previous call left there
     if (w.status->flags & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
                            kFlagTailPending))
         return;
     const int l = lane_id();
-    const int n_waves = int(gridDim.x) * kWavesPerBlock;
+    const int n_waves = (solo ? 1 : int(gridDim.x)) * kWavesPerBlock;
     constexpr int kSubs = kRowTile / kCompactRows;
     const int n_items = ((n_rows + kRowTile - 1) / kRowTile) * kSubs;
-    for (int item = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); item < n_items; item += n_waves) {
+    for (int item = (solo ? 0 : int(blockIdx.x)) * kWavesPerBlock + wave_in_block(); item < n_items; item += n_waves) {
         const int tile = item / kSubs, sub = item % kSubs;
         const int rj = tile * kRowTile + l;
         const bool have = rj < n_rows;
@@ -918,6 +944,39 @@ static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_row
                 run += __popcll(m);
             }
         }
+    }
+}
+
+static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out,
+                                                                       int32_t* out_begins, int32_t* out_ends) {
+    compact_body(n_rows, w, out, out_begins, out_ends);
+}
+
+// ---- a small batch in ONE launch (BASELINE config 1: 32 x 128-byte strings; any batch of a few hundred short rows).
+// A call of the pipeline above is six dispatches (status memset, two lookup kernels, merge, compact, status copy), each
+// waiting for the one before: tens of microseconds of launch latency for microseconds of work.  Here every block runs
+// the lookup body on its rows (a wave per row, as ever); the block that finishes LAST ("last block done": agent-scope
+// release, ticket, acquire) goes on alone with the merge body (every shard, the exact pieces, the tile scan), the compact
+// body, writes the status block straight into the caller's pinned host block and leaves the device-side status zeroed for
+// the next call -- no memset, no copy.  Same bodies, same results.
+template <int MODE, bool NARROW>
+static __global__ __launch_bounds__(kBlockThreads) void encode_small_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+    lookup_body<MODE, false>(in, sp, T, w);
+    if (!last_block_done(&w.status->ticket[1], gridDim.x)) return;
+    merge_body<NARROW>(in, T, w, in.n_rows, w.out_cap, /*solo=*/true);
+    __syncthreads();
+    if (threadIdx.x == 0) publish_release();
+    __syncthreads();
+    publish_acquire();
+    compact_body(in.n_rows, w, w.out_ids, w.out_begins, w.out_ends, /*solo=*/true);
+    __syncthreads();
+    uint32_t* src = reinterpret_cast<uint32_t*>(w.status);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(w.host_status);
+    constexpr int kHead = int(offsetof(RunStatus, shard_count) / 4);  // the scalar fields; of the counter arrays the host reads
+    for (int i = int(threadIdx.x); i < w.status_words; i += kBlockThreads) {  // shard_count[0] only (the one shard in use)
+        const uint32_t v = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i <= kHead) __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // each one a write over PCIe
+        src[i] = 0;  // clean for the next call of this workspace
     }
 }
 

@@ -115,6 +115,7 @@ std::unique_ptr<Workspace> WorkspacePool::acquire() {
         if (!free_.empty()) {
             auto w = std::move(free_.back());
             free_.pop_back();
+            ++w->lease_count;
             return w;
         }
     }

@@ -94,6 +94,11 @@ struct Workspace {
     DevBuf out_a, out_b, out_c, out_d, out_e;
     DevBuf gen[8];  // op-specific inputs / temporaries (api_ops.cpp)
     RunStatus* host_status = nullptr;  // pinned
+    // encode_small_kernel leaves the device status block zeroed: true for the call of lease number `clean_after_lease` + 1
+    // of this workspace if nothing else has used it (any other op leases it, counts, and does its own memset)
+    const void* clean_status = nullptr;
+    size_t clean_bytes = 0;
+    uint64_t lease_count = 0, clean_after_lease = ~0ull;
     hipEvent_t done = nullptr;         // end of the call in flight (RowsRun)
     LaunchLog marks;
     ~Workspace();

@@ -277,7 +277,9 @@ template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + 
 template <typename T> static inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> static inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <typename T> static inline T __hip_atomic_load(T* p, int, int) { return *p; }
+template <typename T> static inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
 template <typename T> static inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> static inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> static inline T atomicCAS(T* p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
