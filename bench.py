@@ -167,6 +167,21 @@ class BpeEncode(EncodeWorkload):
     def launch(self, rs, o, st, pending):
         return self.lib.ovtk_encode_enqueue(self.split._h, self.bpe._h, C.byref(rs), None, C.byref(o), st, C.byref(pending))
 
+    def enqueue_wire(self, i, st, wire, ex):
+        """The encode of batch i straight into a send wire of the exchange (ovtk_encode_enqueue_wire)."""
+        k = i % self.batches.n
+        pending = C.c_void_p()
+        L.check(self.lib, self.lib.ovtk_encode_enqueue_wire(self.split._h, self.bpe._h, C.byref(self.batches.rs[k]), None,
+                                                            C.c_void_p(wire.t.data_ptr()), C.c_int64(ex.max_rows), C.c_int64(wire.pad),
+                                                            ex.id_bytes, st or self.stream0, C.byref(pending)))
+        o = L.RaggedI32Out(None, None, None, 0, 0, 0)
+
+        def finish():
+            L.check(self.lib, self.lib.ovtk_encode_finish(pending, C.byref(o)))
+            self.n_out[k] = int(o.n_data)
+            return wire, (lambda w: self.enqueue_wire(i, st, w, ex)())
+        return finish
+
     def cpu_chain(self):
         from oracle import oracle as O
         orc, ors = self.tok.oracle(), O.RegexSplit(self.tok.pattern, "isolate")
@@ -668,6 +683,9 @@ def main():
     ap.add_argument("--depth", type=int, default=2, help="batches launched ahead of the one being completed (two-half calls)")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "p2p"],
                     help="N > 1: one RCCL all-gather of the wires, or grouped direct sends / receives (one xGMI link per pair)")
+    ap.add_argument("--wire", type=int, default=1,
+                    help="N > 1, fused BPE: 1 = the encode writes the exchange's send wire itself (compact_kernel narrows the ids; no "
+                         "ragged int32 ids, no pack kernel), 0 = encode to ragged ids, then ovtk_shard_pack")
     ap.add_argument("--exchange-stream", type=int, default=1, help="1: pack/unpack of the exchange on a HIP stream of their own")
     ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
@@ -717,9 +735,18 @@ def main():
         hog_stream = torch.cuda.Stream(dev)
         hog = lambda: hog_lib.cu_hog(args.hog, 512, args.hog_lds, C.c_double(300.0), C.c_void_p(hog_stream.cuda_stream))  # noqa: E731
 
+    to_wire = exchange is not None and args.wire and hasattr(wl, "enqueue_wire") and two_half
+    if to_wire:
+        # the pad the wires are sized with: the largest shard of the rotation (one untimed pass), agreed over the ranks
+        for k in range(wl.batches.n):
+            wl.step(k)
+        exchange.agree_pad(max(wl.n_out.values()))
+
     def complete(finish):
         res = finish()
-        return exchange.submit(*res) if exchange is not None else res
+        if exchange is None:
+            return res
+        return exchange.submit_wire(*res) if to_wire else exchange.submit(*res)
 
     def run_steps(first, n):
         if two_half:
@@ -727,7 +754,8 @@ def main():
             for i in range(first, first + n):
                 if hog is not None:
                     hog()
-                inflight.append(wl.enqueue(i, stream_ptrs[i % len(stream_ptrs)]))
+                st = stream_ptrs[i % len(stream_ptrs)]
+                inflight.append(wl.enqueue_wire(i, st, exchange.lease_wire(), exchange) if to_wire else wl.enqueue(i, st))
                 if len(inflight) > args.depth:
                     complete(inflight.pop(0))
             while inflight:
@@ -881,6 +909,7 @@ def main():
                    "units_per_gpu_and_step": round(my_units / args.steps), "outputs_per_gpu_and_step": round(wl.mean_out()),
                    "exchange": ("none (1 GPU)" if exchange is None and world == 1 else ("none (rank-local consumer)" if exchange is None else
                                                                     f"{'all-gather' if exchange.transport == 'allgather' else 'grouped direct send/recv'} of ragged ids over RCCL, {exchange.id_bytes}-byte ids on the wire, "
+                                                                    f"{'written by the encode itself (compact_kernel), ' if to_wire else 'packed by shard_pack_kernel, '}"
                                                                     f"gather overlapped with the next encode, unpack one batch later ({exchange.regathers} re-gathers)"))},
         "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all, "stress": stress, "end_to_end": e2e,
         "parity_prefix_bit_exact": parity,

@@ -328,6 +328,13 @@ int ovtk_shard_unpack(ovtk_shard_exchange* h, const void* wires, int64_t pad_ids
                       int32_t* out_ends, int32_t* out_ids, int64_t out_capacity, ovtk_shard_result* result,
                       int mem, void* stream);
 void ovtk_shard_exchange_destroy(ovtk_shard_exchange* h);
+/* The fused encode of ovtk_encode_enqueue with its result written straight in wire form (device memory): the ids leave the
+ * last kernel narrowed to id_bytes and in place for the all-gather -- no i32 ids buffer, no ovtk_shard_pack.  `wire`:
+ * ovtk_shard_wire_bytes(h, pad_ids) bytes; max_rows = ovtk_shard_max_rows(h); id_bytes as given to the exchange.  Finish
+ * with ovtk_encode_finish: out->n_data = the shard's id count -- above pad_ids the wire is cut exactly as ovtk_shard_pack
+ * cuts it (every receiver sees OVTK_E_CAPACITY in its unpack verdict; encode again into a larger wire). */
+int ovtk_encode_enqueue_wire(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
+                             void* wire, int64_t max_rows, int64_t pad_ids, int id_bytes, void* stream, ovtk_pending** pending);
 
 /* ---------------------------------------------------------------- TrieTokenizer (RWKV)
  * Replaces TrieTokenizer::evaluate, src/trie_tokenizer.cpp:23-81: greedy longest match over a trie of vocab[i] ->

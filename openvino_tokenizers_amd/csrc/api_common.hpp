@@ -214,6 +214,11 @@ public:
     }
     // The middle knows the one-launch form of a small batch (EncodeWork::small, encode_small_kernel).
     void enable_small() { small_ok_ = true; }
+    // The result leaves in the row-shard exchange's wire form (device memory) instead of begins / ends / ids.
+    void output_to_wire(const WireSink& wire) {
+        wire_ = wire;
+        small_ok_ = false;
+    }
 
     int start() {
         if (!ws_->host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
@@ -225,9 +230,11 @@ public:
                                         int64_t(ws_->deferred.size() / sizeof(DeferredPiece) / kShards)});
         exact_cap_ = std::max<int64_t>(4096, int64_t(ws_->exact.size() / sizeof(ExactPiece)));
         scratch_cap_ = std::max<int64_t>(ws_->scratch.size(), int64_t(16) << 20);
-        if (int rc = out_target(ws_->out_a, out_.begins, size_t(n_rows_) * 4, mem_, &d_begins_)) return rc;
-        if (int rc = out_target(ws_->out_b, out_.ends, size_t(n_rows_) * 4, mem_, &d_ends_)) return rc;
-        if (int rc = out_target(ws_->out_c, out_.data, size_t(out_.data_capacity) * 4, mem_, &d_ids_)) return rc;
+        if (!wire_.hdr) {
+            if (int rc = out_target(ws_->out_a, out_.begins, size_t(n_rows_) * 4, mem_, &d_begins_)) return rc;
+            if (int rc = out_target(ws_->out_b, out_.ends, size_t(n_rows_) * 4, mem_, &d_ends_)) return rc;
+            if (int rc = out_target(ws_->out_c, out_.data, size_t(out_.data_capacity) * 4, mem_, &d_ids_)) return rc;
+        }
         grid_ = grid_rows(device_, n_rows_, blocks_per_cu_);
         n_tiles_ = (n_rows_ + kRowTile - 1) / kRowTile;
         if (self_alloc_)  // every wave may leave one chunk partly unused
@@ -268,6 +275,7 @@ public:
                     return set_error(OVTK_E_CAPACITY, op_ + ": output ids buffer too small (" + std::to_string(st.n_out) +
                                                           " ids, capacity " + std::to_string(out_.data_capacity) + ")");
                 out->n_data = st.n_out;
+                if (wire_.hdr) return OVTK_OK;  // (device memory: the wire is complete)
                 if (int rc = copy_back(out_.begins, d_begins_, size_t(n_rows_) * 4, mem_, s_)) return rc;
                 if (int rc = copy_back(out_.ends, d_ends_, size_t(n_rows_) * 4, mem_, s_)) return rc;
                 if (int rc = copy_back(out_.data, d_ids_, size_t(st.n_out) * 4, mem_, s_)) return rc;
@@ -351,8 +359,11 @@ private:
         if (!w.fold_tail)
             OVTK_LAUNCH(ws.marks, "count_scan", count_scan_kernel, std::min((n_tiles_ + 3) / 4, kTicketBlocks), kBlockThreads, s_,
                         n_rows_, w, (long long)out_.data_capacity);
-        OVTK_LAUNCH(ws.marks, "compact", compact_kernel, grid_lookup(device_, n_rows_), kBlockThreads, s_, n_rows_, w, d_ids_,
-                    d_begins_, d_ends_);
+        if (wire_.hdr)
+            OVTK_LAUNCH(ws.marks, "compact", compact_kernel<WireSink>, grid_lookup(device_, n_rows_), kBlockThreads, s_, n_rows_, w, wire_);
+        else
+            OVTK_LAUNCH(ws.marks, "compact", compact_kernel<RaggedSink>, grid_lookup(device_, n_rows_), kBlockThreads, s_, n_rows_, w,
+                        RaggedSink{d_ids_, d_begins_, d_ends_});
         OVTK_HIP(hipMemcpyAsync(ws.host_status, ws.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s_));
         OVTK_HIP(hipEventRecord(ws.done, s_));
         return OVTK_OK;
@@ -373,6 +384,7 @@ private:
     WorkspaceLease ws_;
     bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
     bool small_ok_ = false, small_ = false;
+    WireSink wire_{};
     RowsIn d_in_{};
     int n_rows_ = 0, grid_ = 0, n_tiles_ = 0;
     int64_t stage_cap_ = 0, shard_cap_ = 0, exact_cap_ = 0, scratch_cap_ = 0;

@@ -419,7 +419,7 @@ bool fusable(const ovtk_regex_split* split) {
 // RegexSplit [+] BPETokenizer.  split == nullptr: `in` already holds pieces (the BPETokenizer op).
 // Launches the kernels; `run` stays empty when the result was complete without any (empty batches).
 int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
-                 ovtk_ragged_i32_out* out, int mem, void* stream, std::unique_ptr<PendingRun>& run) {
+                 ovtk_ragged_i32_out* out, int mem, void* stream, std::unique_ptr<PendingRun>& run, const WireSink* wire = nullptr) {
     const ovtk_regex_split* split = split_in;
     if (int rc = check_rows(in)) return rc;
     if (!bpe || !out) return set_error(OVTK_E_ARG, "null argument");
@@ -547,6 +547,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            /*tail_in_middle=*/true);
     if (pieces_ws) r->input_on_device(pieces_ws);
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
+    if (wire) r->output_to_wire(*wire);
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;
@@ -602,6 +603,24 @@ int ovtk_encode_enqueue_host(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_
     auto p = std::make_unique<ovtk_pending>();
     p->out = *out;
     if (int rc = start_encode(split, bpe, in, skips, &p->out, OVTK_MEM_HOST, stream, p->run)) return rc;
+    *pending = p.release();
+    return OVTK_OK;
+}
+
+int ovtk_encode_enqueue_wire(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips, void* wire,
+                             int64_t max_rows, int64_t pad_ids, int id_bytes, void* stream, ovtk_pending** pending) {
+    if (!pending || !wire || !in) return set_error(OVTK_E_ARG, "null argument");
+    if (int rc = check_fused(split)) return rc;
+    if ((id_bytes != 2 && id_bytes != 4) || pad_ids < 0 || pad_ids % 8 || pad_ids >= INT32_MAX || max_rows % 4 || in->n_rows > max_rows)
+        return set_error(OVTK_E_ARG, "encode to wire: bad wire geometry (ovtk_shard_max_rows / pad_ids / id_bytes of the exchange)");
+    if (in->strings.n_chars == 0 || in->n_rows == 0)
+        return set_error(OVTK_E_UNSUPPORTED, "encode to wire: empty batches take ovtk_encode_enqueue + ovtk_shard_pack");
+    auto p = std::make_unique<ovtk_pending>();
+    p->out = ovtk_ragged_i32_out{nullptr, nullptr, nullptr, INT32_MAX - 2, 0, 0};  // the wire cuts at pad_ids, nothing overflows
+    uint8_t* base = static_cast<uint8_t*>(wire);
+    const WireSink sink{reinterpret_cast<int32_t*>(base), reinterpret_cast<int32_t*>(base + kShardHeaderBytes),
+                        base + kShardHeaderBytes + max_rows * 4, int32_t(pad_ids), int32_t(max_rows), id_bytes};
+    if (int rc = start_encode(split, bpe, in, skips, &p->out, OVTK_MEM_DEVICE, stream, p->run, &sink)) return rc;
     *pending = p.release();
     return OVTK_OK;
 }

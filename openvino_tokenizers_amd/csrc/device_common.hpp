@@ -19,6 +19,7 @@ constexpr int32_t kEmptyId = INT32_MIN;
 // Status block of one run, written by the kernels, read by the host after the final sync.  The
 // deferred-piece list is sharded (one region + one counter per shard, each counter on its own 128-byte
 // line: a single device-scope counter saturates at ~90 atomics/us on gfx950).
+constexpr int kShardHeaderBytes = 16;  // row-shard exchange wire: i32 n_ids, i32 n_rows, 2 x i32 0 (ops_kernels.hpp)
 constexpr int kShards = 16;
 constexpr int kCounterStride = 32;  // int32 slots between shard counters
 struct RunStatus {

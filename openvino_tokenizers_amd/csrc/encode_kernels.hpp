@@ -885,8 +885,43 @@ static __global__ __launch_bounds__(kBlockThreads) void count_scan_kernel(int n_
 // Unused staging entries (rows that had deferred pieces) are squeezed out by ballot compaction.
 constexpr int kCompactRows = 4;    // rows per work item (8: no better)
 constexpr int kCompactChunks = 3;  // 64-entry chunks of a row held in registers; longer rows finish in a loop
-__device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, int32_t* out, int32_t* out_begins, int32_t* out_ends,
-                                             bool solo = false) {
+// Where compact_body puts the result.  RaggedSink: the caller's begins / ends / ids (the ops' contract).  WireSink: the
+// row-shard exchange's wire (ops_kernels.hpp "row-shard exchange": header | i32 ends[max_rows] | pad_ids ids of 2 or 4
+// bytes) -- the ids leave the encode already narrowed and in place for the all-gather, no i32 copy, no pack kernel; ids
+// beyond the wire's pad are dropped (the header's n_ids says so: the receivers ask for a larger pad).
+struct RaggedSink {
+    int32_t *ids, *begins, *ends;
+    __device__ __forceinline__ void row(int r, int b, int e) const {
+        begins[r] = b;
+        ends[r] = e;
+    }
+    __device__ __forceinline__ void id(int pos, int32_t v) const { ids[pos] = v; }
+    __device__ __forceinline__ void finish(int, const RunStatus*) const {}
+};
+struct WireSink {
+    int32_t* hdr;      // i32 n_ids, i32 n_rows, 0, 0
+    int32_t* ends;     // [max_rows]
+    void* ids;         // [pad_ids] u16 or i32
+    int32_t pad_ids, max_rows, id_bytes;
+    __device__ __forceinline__ void row(int r, int, int e) const { ends[r] = e; }
+    __device__ __forceinline__ void id(int pos, int32_t v) const {
+        if (pos >= pad_ids) return;
+        if (id_bytes == 2) static_cast<uint16_t*>(ids)[pos] = uint16_t(v);
+        else static_cast<int32_t*>(ids)[pos] = v;
+    }
+    __device__ __forceinline__ void finish(int n_rows, const RunStatus* st) const {  // the first block: header, unused row slots
+        if (blockIdx.x != 0) return;
+        if (threadIdx.x == 0) {
+            hdr[0] = st->n_out;
+            hdr[1] = n_rows;
+            hdr[2] = hdr[3] = 0;
+        }
+        for (int r = n_rows + int(threadIdx.x); r < max_rows; r += kBlockThreads) ends[r] = 0;
+    }
+};
+
+template <class Sink>
+__device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, const Sink& sink, bool solo = false) {
     // kFlagTailPending: merge_kernel's folded tail left the exact pieces and the tile scan to a second attempt -- tile_off
     // and parts of the staging buffer hold whatever the previous call left there
     if (w.status->flags & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
@@ -924,32 +959,30 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, in
         for (int q = 0; q < kCompactRows; ++q) {
             const int row = tile * kRowTile + sub * kCompactRows + q;
             if (row >= n_rows) break;
-            if (l == 0) {
-                out_begins[row] = o[q];
-                out_ends[row] = o[q] + cnt[q];
-            }
+            if (l == 0) sink.row(row, o[q], o[q] + cnt[q]);
             int run = 0;
 #pragma unroll
             for (int k = 0; k < kCompactChunks; ++k) {
                 if (k * kWave < used[q]) {
                     const unsigned long long m = __ballot(v[q][k] != kEmptyId);
-                    if (v[q][k] != kEmptyId) out[o[q] + run + __popcll(m & lanemask_lt())] = v[q][k];
+                    if (v[q][k] != kEmptyId) sink.id(o[q] + run + __popcll(m & lanemask_lt()), v[q][k]);
                     run += __popcll(m);
                 }
             }
             for (int b = kCompactChunks * kWave; b < used[q]; b += kWave) {
                 const int x = (b + l < used[q]) ? w.stage[base[q] + b + l] : kEmptyId;
                 const unsigned long long m = __ballot(x != kEmptyId);
-                if (x != kEmptyId) out[o[q] + run + __popcll(m & lanemask_lt())] = x;
+                if (x != kEmptyId) sink.id(o[q] + run + __popcll(m & lanemask_lt()), x);
                 run += __popcll(m);
             }
         }
     }
+    sink.finish(n_rows, w.status);
 }
 
-static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, int32_t* out,
-                                                                       int32_t* out_begins, int32_t* out_ends) {
-    compact_body(n_rows, w, out, out_begins, out_ends);
+template <class Sink>
+static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, Sink sink) {
+    compact_body(n_rows, w, sink);
 }
 
 // ---- a small batch in ONE launch (BASELINE config 1: 32 x 128-byte strings; any batch of a few hundred short rows).
@@ -968,7 +1001,7 @@ static __global__ __launch_bounds__(kBlockThreads) void encode_small_kernel(Rows
     if (threadIdx.x == 0) publish_release();
     __syncthreads();
     publish_acquire();
-    compact_body(in.n_rows, w, w.out_ids, w.out_begins, w.out_ends, /*solo=*/true);
+    compact_body(in.n_rows, w, RaggedSink{w.out_ids, w.out_begins, w.out_ends}, /*solo=*/true);
     __syncthreads();
     uint32_t* src = reinterpret_cast<uint32_t*>(w.status);
     uint32_t* dst = reinterpret_cast<uint32_t*>(w.host_status);

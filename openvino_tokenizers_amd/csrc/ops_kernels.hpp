@@ -1066,7 +1066,6 @@ static __global__ __launch_bounds__(kWave) void pack_header_kernel(int32_t* head
 // The receiver needs no scan and no counts exchange: rank r's ids go to the sum of the n_ids of the ranks before it, its
 // rows to the sum of their n_rows (any contiguous partition of the rows: balanced by count or by bytes), and a row's
 // global offsets are the id base plus its local ones.  One kernel packs, one kernel unpacks.
-constexpr int kShardHeaderBytes = 16;
 struct ShardGeom {
     long long n_rows;    // global rows
     long long max_rows;  // ends slots per wire

@@ -113,6 +113,7 @@ class ShardExchange:
                                                               (self.device.index or 0) if self.cuda else 0, C.byref(self._h)))
         self.max_rows = int(self.lib.ovtk_shard_max_rows(self._h))
         self._wires = {}          # slot -> (send, recv); two slots: a wire is free again once its batch is unpacked
+        self._free_wires = []     # send wires handed out by lease_wire() and back from their batches (encode-to-wire mode)
         self._verdicts = [self._verdict_slot() for _ in range(2)]
         self._k = 0
         self._gathering = None    # batch whose all-gather is in flight
@@ -165,12 +166,45 @@ class ShardExchange:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         self.pad_ids = max(self.pad_ids, _round_up(int(t.item()) * self.headroom + 8, 8))
 
+    def agree_pad(self, n_local: int):
+        """Fix the pad from an id count the caller already knows (a collective: every rank calls it).  The encode-to-wire
+        mode needs the pad before its first encode, where submit() learns it from its first shard."""
+        self._agree_pad(int(n_local))
+        return self.pad_ids
+
+    def lease_wire(self):
+        """A send wire for FusedSplitBPE.enqueue_wire(..., wire.t, ex.max_rows, wire.pad, ex.id_bytes) to fill -- the
+        encode's compact_kernel then writes header, row ends and narrowed ids itself, and submit_wire() sends the wire as
+        it is: no ragged int32 ids in between, no pack kernel.  The wire comes back to the pool with its batch."""
+        if self.pad_ids == 0:
+            raise RuntimeError("the encode-to-wire mode needs a pad first: ShardExchange(pad_ids=...) or agree_pad()")
+        while self._free_wires:
+            w = self._free_wires.pop()
+            if w.pad == self.pad_ids:
+                return w
+        nbytes = int(self.lib.ovtk_shard_wire_bytes(self._h, C.c_int64(self.pad_ids)))
+        return _Wire(torch.empty(nbytes, dtype=torch.uint8, device=self.device), self.pad_ids)
+
+    def submit_wire(self, wire, refill):
+        """submit() for a wire the fused encode filled (the encode's ticket() has returned: the wire is complete).
+        refill(wire) -> None encodes the same shard again, synchronously, into another leased wire: called when the pad grew
+        after this wire was leased, or when this shard is the one that outgrew it (every rank learns that from the
+        headers, together)."""
+        with self._on_stream():
+            return self._submit(_FromWire(wire, refill))
+
     def _start_gather(self, local, slot):
-        begins, ends, ids = local
-        send, recv = self._buffers(slot)
-        L.check(self.lib, self.lib.ovtk_shard_pack(self._h, self._ptr(begins), self._ptr(ends), self._ptr(ids), C.c_int64(begins.numel()),
-                                                   C.c_int64(ids.numel()), C.c_int64(self.pad_ids), self._ptr(send), self._mem,
-                                                   self._stream_ptr()))
+        if isinstance(local, _FromWire):
+            if local.wire.pad != self.pad_ids:
+                local.wire = self.lease_wire()
+                local.refill(local.wire)
+            send, recv = local.wire.t, self._buffers(slot)[1]
+        else:
+            begins, ends, ids = local
+            send, recv = self._buffers(slot)
+            L.check(self.lib, self.lib.ovtk_shard_pack(self._h, self._ptr(begins), self._ptr(ends), self._ptr(ids), C.c_int64(begins.numel()),
+                                                       C.c_int64(ids.numel()), C.c_int64(self.pad_ids), self._ptr(send), self._mem,
+                                                       self._stream_ptr()))
         if self.transport == "allgather" or self.world == 1:
             work = dist.all_gather_into_tensor(recv, send, group=self.group, async_op=True)  # RCCL's stream waits for the pack
         else:
@@ -219,21 +253,23 @@ class ShardExchange:
                 continue
             if status != L.OVTK_OK:
                 raise L.OvtkError(status, "shard exchange failed (see ovtk_shard_result in include/ovtk_amd.h)")
+            if isinstance(b["local"], _FromWire):
+                self._free_wires.append(b["local"].wire)
             begins, ends, ids = b["out"]
             return begins[: self.n_rows], ends[: self.n_rows], ids[:n_ids]
 
     # -- API
     def submit(self, begins: torch.Tensor, ends: torch.Tensor, ids: torch.Tensor):
         with self._on_stream():
-            return self._submit(begins, ends, ids)
+            local = (begins.contiguous(), ends.contiguous(), ids.contiguous())
+            if self.pad_ids == 0:
+                self._agree_pad(ids.numel())
+            return self._submit(local)
 
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.cuda and self.stream is not None else _NullCtx()
 
-    def _submit(self, begins, ends, ids):
-        local = (begins.contiguous(), ends.contiguous(), ids.contiguous())
-        if self.pad_ids == 0:
-            self._agree_pad(ids.numel())
+    def _submit(self, local):
         done = self._collect(self._unpacking) if self._unpacking is not None else None   # frees the slot reused below
         self._unpacking = None
         started = self._start_gather(local, self._k & 1)
@@ -255,6 +291,18 @@ class ShardExchange:
             out.append(self._collect(self._start_unpack(self._gathering)))
         self._unpacking = self._gathering = None
         return out
+
+
+class _Wire:
+    """A send wire of the encode-to-wire mode: the tensor and the pad (id slots) it was sized for."""
+
+    def __init__(self, t, pad):
+        self.t, self.pad = t, pad
+
+
+class _FromWire:
+    def __init__(self, wire, refill):
+        self.wire, self.refill = wire, refill
 
 
 class _Works:

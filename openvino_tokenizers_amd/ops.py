@@ -318,6 +318,32 @@ class FusedSplitBPE:
             return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
         return ticket
 
+    def enqueue_wire(self, split_inputs, bpe_constant_inputs, wire, max_rows, pad_ids, id_bytes, stream=None):
+        """The encode straight into a ShardExchange send wire (ovtk_encode_enqueue_wire): CUDA inputs, `wire` a uint8 CUDA
+        tensor of ovtk_shard_wire_bytes(pad_ids) bytes with `max_rows` row slots.  compact_kernel writes the header, the
+        row ends and the ids narrowed to `id_bytes`, so no ragged int32 tensor and no pack kernel are in between.
+        `ticket()` waits and returns the shard's id count (more than pad_ids: the wire was cut, encode again into a
+        larger one)."""
+        has_skips = len(split_inputs) == 7
+        self.split._ensure(split_inputs[5 + has_skips])
+        self.bpe._ensure(list(split_inputs[:5]) + list(bpe_constant_inputs))
+        m = _Mem(split_inputs[4])
+        lib = self.bpe._lib
+        if not m.torch and not hasattr(lib, "ovtk_emulator_build"):   # the emulator build's device memory IS host memory (tests)
+            raise L.OvtkError(L.E_ARG, "enqueue_wire() needs device-resident (torch CUDA) inputs")
+        rs, _ = _ragged_in(m, split_inputs)
+        _, pskips = (m.inp(split_inputs[5], "bool") if has_skips else (None, None))
+        pending = C.c_void_p()
+        st = C.c_void_p(stream) if isinstance(stream, int) else (stream if stream is not None else m.stream)
+        L.check(lib, lib.ovtk_encode_enqueue_wire(self.split._h, self.bpe._h, C.byref(rs), pskips, C.c_void_p(wire.data_ptr()),
+                                                  C.c_int64(max_rows), C.c_int64(pad_ids), int(id_bytes), st, C.byref(pending)))
+        out = L.RaggedI32Out(None, None, None, 0, 0, 0)
+
+        def ticket(_keep=(m, wire)):
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(out)))
+            return int(out.n_data)
+        return ticket
+
 
 class WordpieceTokenizer(_Op):
     """Reference: src/wordpiece_tokenizer.cpp (evaluate :49-133).  Inputs: ragged strings (5), vocab (3),

@@ -63,6 +63,10 @@ struct hipDeviceProp_t {
 };
 #define hipHostMallocDefault 0
 
+// Marks the emulator build for the Python side: "device" pointers are host pointers here, so CPU tensors may be handed
+// to the device-only entry points (the HIP build does not export this symbol).
+extern "C" __attribute__((weak, visibility("default"))) int ovtk_emulator_build() { return 1; }
+
 namespace emu {
 
 constexpr int WAVE = 64;

@@ -230,3 +230,150 @@ def test_shard_exchange_rccl_one_rank(hip_lib, own_stream):
             assert np.array_equal(gi, ids.astype(np.int32))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("vocab_name, pad_frac", [("gpt2_small", 1.2), ("gpt2_small", 0.5), ("llama3_small", 1.1)])
+def test_encode_straight_to_wire(backend, vocab_name, pad_frac):
+    """ovtk_encode_enqueue_wire: the fused encode writes the exchange's wire itself (ids narrowed in compact_kernel) --
+    byte for byte what ovtk_shard_pack builds from the ragged ids of ovtk_encode_run, a too small pad included (the wire
+    is cut, the header still says how many ids the shard has)."""
+    import ctypes as C
+    from openvino_tokenizers_amd import _lib as L
+    from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
+    from tests.util import BpeTok
+    from tools.workloads import TextModel, ragged_rows
+    if backend.name == "hip-host":
+        pytest.skip("the exchange hands over device (or emulator-host) buffers only")
+    lib = backend.lib
+    dev = backend.name != "emu"
+    tok = BpeTok.load(vocab_name)
+    n = 300 if dev else 70   # more than a small batch: the three-kernel pipeline with compact_kernel<WireSink>
+    b, e, c = TextModel(17, "mixed" if "llama" in vocab_name else "zipf").batch(n, 300 if dev else 1100)
+    rb, re_ = ragged_rows(n)
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**tok.attrs, lib=lib))
+    data = backend.data([rb, re_, b, e, c])
+    ob, oe, ids = fused.evaluate(data + [tok.pattern_u8()], tok.consts)
+    n_ids = int(len(ids))
+    id_bytes = 2 if len(tok.vocab) <= 65536 else 4
+    pad = max(8, int(n_ids * pad_frac) // 8 * 8)
+    h = C.c_void_p()
+    L.check(lib, lib.ovtk_shard_exchange_create(1, C.c_int64(n), id_bytes, C.c_int64(0), 0, C.byref(h)))
+    try:
+        max_rows = int(lib.ovtk_shard_max_rows(h))
+        nbytes = int(lib.ovtk_shard_wire_bytes(h, C.c_int64(pad)))
+
+        def alloc():
+            return torch.zeros(nbytes, dtype=torch.uint8, device="cuda" if dev else "cpu")
+
+        def ptr(t):
+            return C.c_void_p(t.data_ptr())
+
+        t_ob, t_oe, t_ids = (torch.as_tensor(backend.host(x)).to("cuda" if dev else "cpu") for x in (ob, oe, ids))
+        want, got = alloc(), alloc()
+        mem = L.MEM_DEVICE if dev else L.MEM_HOST
+        L.check(lib, lib.ovtk_shard_pack(h, ptr(t_ob), ptr(t_oe), ptr(t_ids), C.c_int64(n), C.c_int64(n_ids), C.c_int64(pad), ptr(want), mem, None))
+        d = [torch.as_tensor(backend.host(x)).to("cuda" if dev else "cpu") for x in data]
+        rs = L.RaggedStrings(ptr(d[0]), ptr(d[1]), n, L.Strings(ptr(d[2]), ptr(d[3]), ptr(d[4]), n, len(c)))
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_encode_enqueue_wire(fused.split._h, fused.bpe._h, C.byref(rs), None, ptr(got), C.c_int64(max_rows),
+                                                  C.c_int64(pad), id_bytes, None, C.byref(pending)))
+        out = L.RaggedI32Out(None, None, None, 0, 0, 0)
+        L.check(lib, lib.ovtk_encode_finish(pending, C.byref(out)))
+        if dev:
+            torch.cuda.synchronize()
+        assert out.n_data == n_ids
+        used = 16 + 4 * max_rows + id_bytes * min(n_ids, pad)
+        assert torch.equal(want[:used].cpu(), got[:used].cpu())
+    finally:
+        lib.ovtk_shard_exchange_destroy(h)
+
+
+def _wire_mode_run(lib, device, rank, world, n_rows, nbytes, n_batches=3):
+    """Every rank encodes its row shard of each batch straight into a leased wire and submits it; returns (exchanged
+    global tensors, single-process encodes of the whole batches, regathers).  Later batches are longer, so a wire leased
+    with the first pad is outgrown and the shard is encoded again (refill)."""
+    from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
+    from tests.util import BpeTok
+    from tools.workloads import TextModel, ragged_rows
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**tok.attrs, lib=lib))
+    pat = tok.pattern_u8()
+
+    def on_dev(x):
+        return torch.as_tensor(np.ascontiguousarray(x), device=device)
+    ex = ShardExchange(n_rows, len(tok.vocab), device, lib=lib, headroom=1.0)
+    got, want = [], []
+    for k in range(n_batches):
+        b, e, c = TextModel(40 + k, "zipf").batch(n_rows, nbytes * (1 + k))
+        whole = fused.evaluate([on_dev(x) for x in (*ragged_rows(n_rows), b, e, c)] + [pat], tok.consts)
+        want.append([np.asarray(t.cpu() if hasattr(t, "cpu") else t).copy() for t in whole])
+        lo, hi = shard_rows(n_rows, rank, world)
+        rb, re_ = ragged_rows(hi - lo)
+        mine = [on_dev(x) for x in (rb, re_, b[lo:hi], e[lo:hi], c)] + [pat]
+
+        def encode(wire, wait=True, mine=mine):   # bound now: a refill comes batches later
+            t = fused.enqueue_wire(mine, tok.consts, wire.t, ex.max_rows, wire.pad, ex.id_bytes)
+            return t() if wait else t
+        if k == 0:   # the pad comes from a count the caller knows: one throw-away encode into a minimal wire tells it
+            ex.pad_ids = 8
+            n0 = encode(ex.lease_wire())
+            ex.pad_ids = 0
+            ex.agree_pad(n0)
+        wire = ex.lease_wire()
+        encode(wire)
+        done = ex.submit_wire(wire, encode)
+        if done is not None:
+            got.append([t.cpu().numpy().copy() for t in done])
+    got += [[t.cpu().numpy().copy() for t in b] for b in ex.flush()]
+    regathers = ex.regathers
+    ex.close()
+    return got, want, regathers
+
+
+def _wire_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from openvino_tokenizers_amd import _lib as L
+        q.put((rank,) + _wire_mode_run(L.load(EMU), "cpu", rank, world, n_rows=22, nbytes=900))
+    except BaseException as exc:
+        q.put((rank, repr(exc), None, 0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_encode_to_wire_exchange_gloo(emu_lib):
+    """World 2: the fused encode of each rank writes its send wire itself (compact_kernel<WireSink>); what the exchange
+    hands back equals the one-process encode of the whole batch, through a pad that had to grow."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wire_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(isinstance(r[1], list) for r in results), [r[1] for r in results]
+    for _, got, want, regathers in results:
+        assert len(got) == len(want) == 3 and regathers >= 1
+        for g, w in zip(got, want):
+            for a, b in zip(g, w):
+                assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_encode_to_wire_exchange_rccl_one_rank(hip_lib):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        got, want, regathers = _wire_mode_run(hip_lib, dev, 0, 1, n_rows=3000, nbytes=400000, n_batches=4)
+        assert len(got) == len(want) == 4 and regathers >= 1
+        for g, w in zip(got, want):
+            for a, b in zip(g, w):
+                assert np.array_equal(a, b)
+    finally:
+        dist.destroy_process_group()
