@@ -133,9 +133,11 @@ void ovtk_special_tokens_split_destroy(ovtk_special_tokens_split* h);
  * for the 11/15-input text form), last four (added tokens + ids; n_added = 0 if absent) and the attributes
  * unk_token, fuse_unk, suffix_indicator, end_suffix, byte_fallback, cache_capacity (bpe_tokenizer.hpp:220-228).
  * cache_capacity: the reference's piece cache is pure memoisation (bpe_tokenizer.cpp:197-205,331-338) and so is its
- * counterpart here, the piece memo built at create (BPE of every vocabulary token as a whole piece).  0 disables the
- * memo exactly as it disables the reference's cache (:331 `size() < capacity`); any other value enables it -- the
- * table is sized by the vocabulary, not by this number.  Results are identical either way. */
+ * counterpart here, the piece memo: BPE of every vocabulary token as a whole piece, built at create, plus up to
+ * cache_capacity pieces that take several tokens (at most 15 bytes and 3 ids each), kept by the device the first time
+ * it merges them and while there is room -- the reference's rule (:335 `size() < capacity`, nothing is evicted).  0
+ * disables the memo altogether, exactly as it disables the reference's cache.  Results are identical for every value
+ * and every history of calls; a handle may be used from several streams at once. */
 typedef struct ovtk_bpe_params {
     ovtk_strings vocab;
     ovtk_strings merges;       /* text lines or left halves */
@@ -160,6 +162,10 @@ int ovtk_bpe_create(const ovtk_bpe_params* params, ovtk_bpe** out);
 /* The op itself: pre-split pieces in, ragged ids out (out->data_capacity: reference uses n_chars). */
 int ovtk_bpe_run(ovtk_bpe* h, const ovtk_ragged_strings* in, ovtk_ragged_i32_out* out, int mem, void* stream);
 void ovtk_bpe_destroy(ovtk_bpe* h);
+/* Entries of the piece memo: built at create from the vocabulary (*fixed) and kept since by the device (*learned, at most
+ * cache_capacity -- the size() of the reference's m_cache, bpe_tokenizer.hpp:150, which the reference does not expose).
+ * Waits for the device. */
+int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned);
 
 /* Fused RegexSplit -> BPETokenizer (the sub-graph tokenizer_pipeline.py:1613-1631 builds for byte-level BPE
  * models): same result as ovtk_regex_split_run followed by ovtk_bpe_run on its outputs, without the piece

@@ -57,8 +57,9 @@ int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks) {
 struct ovtk_bpe {
     int device = 0;
     BpeDev dev{};
-    DevBuf root, node, edges, merges, new_id, bf, pieces;
+    DevBuf root, edges, merges, new_id, bf, pieces, memo_room;
     size_t memo_entries = 0;
+    int32_t memo_capacity = 0;  // entries the device may add (cache_capacity)
     bool narrow_ids = false;  // every token id < 65536: merge_kernel keeps ids as u16 in LDS
 };
 
@@ -67,10 +68,11 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
                ovtk_ragged_i32_out* out, int mem, void* stream);
 
 // The piece memo (tables.hpp PieceEntry): BPE(t) for every vocabulary token t used as a whole piece, computed by the
-// device BPE itself -- the handle (still without memo) encodes its own vocabulary, one token per row.  This is the
-// parallel-machine form of the reference's piece cache (bpe_tokenizer.cpp:197-205,331-338): same pure function
-// piece -> ids, filled from the model constants instead of from previous inputs, so results never depend on history.
-int build_memo(ovtk_bpe* h, const ovtk_strings& vocab) {
+// device BPE itself -- the handle (still without memo) encodes its own vocabulary, one token per row -- plus, filled
+// while encoding, up to cache_capacity pieces that take several tokens.  It is the parallel-machine form of the
+// reference's piece cache (bpe_tokenizer.cpp:197-205,331-338): the same pure function piece -> ids, so results never
+// depend on what was encoded before; only the time does.
+int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     const int64_t V = vocab.n;
     if (V == 0) return OVTK_OK;
     const size_t nv = size_t(V);
@@ -88,8 +90,13 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab) {
     PieceTableHost host;
     build_piece_table(view_of(vocab), ob.data(), oe.data(), ids.data(), host);
     if (int rc = h->pieces.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
+    // The dynamic part (memo_insert in encode_kernels.hpp): up to cache_capacity further pieces, the ones the vocabulary
+    // needs more than one token for, kept the first time merge_kernel computes them -- the reference's rule, its numbers.
+    const int32_t room = int32_t(std::min<int64_t>(std::max<int64_t>(cache_capacity, 0), INT32_MAX / 2));
+    if (int rc = h->memo_room.upload(&room, sizeof room)) return rc;
+    h->memo_capacity = room;
     OVTK_HIP(hipStreamSynchronize(nullptr));
-    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift};
+    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>()};
     h->memo_entries = host.stored;
     return OVTK_OK;
 }
@@ -321,8 +328,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
         if (p->added_ids[i] < 0 || p->added_ids[i] > 65535) h->narrow_ids = false;
     int e = 0;
     e = e ? e : h->root.upload(host.trie.root.data(), host.trie.root.size() * sizeof(I2));
-    e = e ? e : h->node.upload(host.trie.node.data(), host.trie.node.size() * sizeof(I2));
-    e = e ? e : h->edges.upload(host.trie.edges.data(), host.trie.edges.size() * sizeof(uint64_t));
+    e = e ? e : h->edges.upload(host.trie.edges.data(), host.trie.edges.size() * sizeof(TrieEdge));
     e = e ? e : h->merges.upload(host.merges.data(), host.merges.size() * sizeof(MergeBucket));
     e = e ? e : h->new_id.upload(host.new_id.data(), host.new_id.size() * sizeof(int32_t));
     e = e ? e : h->bf.upload(host.byte_fallback_id.data(), host.byte_fallback_id.size() * sizeof(int32_t));
@@ -330,8 +336,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     OVTK_HIP(hipStreamSynchronize(nullptr));
     BpeDev& d = h->dev;
     d.trie.root = h->root.as<I2>();
-    d.trie.node = h->node.as<I2>();
-    d.trie.edges = h->edges.as<uint64_t>();
+    d.trie.edges = h->edges.as<TrieEdge>();
     d.trie.edge_mask = host.trie.edge_mask;
     d.trie.edge_shift = host.trie.edge_shift;
     d.merges = h->merges.as<MergeBucket>();
@@ -346,12 +351,25 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     // cache_capacity == 0 disables the reference's piece cache (bpe_tokenizer.cpp:331: size() < capacity); here it
     // disables the memo the same way.  Results are identical either way.
     if (p->cache_capacity != 0)
-        if (int rc = build_memo(h.get(), p->vocab)) return rc;
+        if (int rc = build_memo(h.get(), p->vocab, p->cache_capacity)) return rc;
     *out = h.release();
     return OVTK_OK;
 }
 
 void ovtk_bpe_destroy(ovtk_bpe* h) { delete h; }
+
+int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned) {
+    if (!h || !fixed || !learned) return set_error(OVTK_E_ARG, "null argument");
+    *fixed = int64_t(h->memo_entries);
+    *learned = 0;
+    if (!h->dev.pieces.room) return OVTK_OK;
+    if (int rc = use_device(h->device)) return rc;
+    int32_t room = 0;
+    OVTK_HIP(hipDeviceSynchronize());
+    OVTK_HIP(hipMemcpy(&room, h->dev.pieces.room, sizeof room, hipMemcpyDeviceToHost));
+    *learned = h->memo_capacity - std::max<int32_t>(room, 0);
+    return OVTK_OK;
+}
 
 }  // extern "C"
 
@@ -747,3 +765,14 @@ int ovtk_special_tokens_split_run(ovtk_special_tokens_split* h, const ovtk_ragge
 }
 
 }  // extern "C"
+
+#ifdef OVTK_PROBE
+extern "C" __attribute__((visibility("default"))) int ovtk_debug_probe(unsigned long long* out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 16);
+    if (reset) {
+        unsigned long long init[16] = {~0ull, 0, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_probe), init, sizeof(init));
+    }
+    return 0;
+}
+#endif

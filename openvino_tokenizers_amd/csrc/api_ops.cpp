@@ -19,16 +19,14 @@ using namespace ovtk;
 namespace {
 
 struct TrieBufs {
-    DevBuf root, node, edges;
+    DevBuf root, edges;
     int upload(const TrieHost& t, TrieDev& d) {
         int e = 0;
         e = e ? e : root.upload(t.root.data(), t.root.size() * sizeof(I2));
-        e = e ? e : node.upload(t.node.data(), t.node.size() * sizeof(I2));
-        e = e ? e : edges.upload(t.edges.data(), t.edges.size() * sizeof(uint64_t));
+        e = e ? e : edges.upload(t.edges.data(), t.edges.size() * sizeof(TrieEdge));
         if (e) return e;
         d.root = root.as<I2>();
-        d.node = node.as<I2>();
-        d.edges = edges.as<uint64_t>();
+        d.edges = edges.as<TrieEdge>();
         d.edge_mask = t.edge_mask;
         d.edge_shift = t.edge_shift;
         return OVTK_OK;

@@ -59,13 +59,14 @@ __device__ __forceinline__ uint32_t merge_rank(const BpeDev& T, uint32_t l, uint
     return k == kNoKey ? kNoRank : uint32_t(k >> (kSeqBits + kIdBits));
 }
 
-__device__ __forceinline__ int trie_child(const TrieDev& t, int node, uint32_t byte) {
+// The edge (node, byte) -> e; false when the node has no such child.
+__device__ __forceinline__ bool trie_step(const TrieDev& t, int node, uint32_t byte, TrieEdge& e) {
     const uint32_t key = (uint32_t(node) << 8) | byte;
     uint32_t p = (hash_u32(key) >> t.edge_shift) & t.edge_mask;
     for (;;) {
-        const uint64_t e = t.edges[p];
-        if (e == kEmptySlot) return -1;
-        if (uint32_t(e >> 32) == key) return int(uint32_t(e));
+        e = t.edges[p];
+        if (e.key == key) return true;
+        if (e.key == kNoEdge) return false;
         p = (p + 1) & t.edge_mask;
     }
 }
@@ -79,13 +80,12 @@ __device__ __forceinline__ int trie_longest(const TrieDev& t, const I2* root, Ge
     int cur = r.y & ~kLeafBit;
     bool leaf = (r.y & kLeafBit) != 0;
     while (!leaf && i < n) {
-        const int child = trie_child(t, cur, getb(i));
-        if (child < 0) break;
-        cur = child;
+        TrieEdge e;
+        if (!trie_step(t, cur, getb(i), e)) break;
+        cur = e.child;
         ++i;
-        const I2 nd = t.node[cur];
-        if (nd.x != -1) { best = nd.x; best_end = i; }
-        leaf = nd.y == 0;
+        if (e.value != -1) { best = e.value; best_end = i; }
+        leaf = e.has_kids == 0;
     }
     if (best == -1) return -1;
     idx = best_end;

@@ -197,13 +197,15 @@ __device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint6
 // written with `if (key matches) take the payload`, the compiler sinks the payload load behind the key compare and a
 // lookup costs two dependent round trips instead of one.
 struct MemoFetch {
-    uint4 k[2], p[2];  // key halves {k0, k1} and payload {tok[3], cnt} of the two candidates
+    uint4 k[2], p[2];  // key halves {k0, k1} and payload {tok[3], tag} of the two candidates
+    uint32_t mix;
 };
 __device__ __forceinline__ MemoFetch memo_fetch(const PieceTableDev& P, uint64_t k0, uint64_t k1) {
     const uint32_t mix = piece_mix(k0, k1);
     const uint4* e0 = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, 0, P.shift));
     const uint4* e1 = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, 1, P.shift));
     MemoFetch f;
+    f.mix = mix;
     f.k[0] = e0[0];
     f.p[0] = e0[1];
     f.k[1] = e1[0];
@@ -217,12 +219,44 @@ __device__ __forceinline__ MemoFetch memo_fetch(const PieceTableDev& P, uint64_t
 }
 __device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
     const uint32_t a = uint32_t(k0), b = uint32_t(k0 >> 32), c = uint32_t(k1), d = uint32_t(k1 >> 32);
-    const bool m0 = f.k[0].x == a && f.k[0].y == b && f.k[0].z == c && f.k[0].w == d;
-    const bool m1 = f.k[1].x == a && f.k[1].y == b && f.k[1].z == c && f.k[1].w == d;
+    // the payload's tag with the expected one folded out: the id count (0..3) when the payload is this key's
+    const uint32_t expect = piece_tag(f.mix, 0);
+    const uint32_t c0 = f.p[0].w ^ expect, c1 = f.p[1].w ^ expect;
+    const bool m0 = f.k[0].x == a && f.k[0].y == b && f.k[0].z == c && f.k[0].w == d && c0 <= uint32_t(kPieceMaxIds);
+    const bool m1 = f.k[1].x == a && f.k[1].y == b && f.k[1].z == c && f.k[1].w == d && c1 <= uint32_t(kPieceMaxIds);
     tok[0] = int32_t(m1 ? f.p[1].x : f.p[0].x);
     tok[1] = int32_t(m1 ? f.p[1].y : f.p[0].y);
     tok[2] = int32_t(m1 ? f.p[1].z : f.p[0].z);
-    return m1 ? int(f.p[1].w) : (m0 ? int(f.p[0].w) : -1);
+    return m1 ? int(c1) : (m0 ? int(c0) : -1);
+}
+// merge_kernel's side of the memo -- the reference's piece cache (bpe_tokenizer.cpp:197-205, 331-338: a piece's ids are
+// kept the first time it is seen, while the cache holds fewer than cache_capacity entries; nothing is ever evicted).
+// This lane's piece (1..15 bytes, `cnt` <= kPieceMaxIds ids) goes into one of its two candidate slots if that slot is
+// free: no entry ever moves or changes, so a concurrent reader sees a slot either free, or claimed (kPieceBusy never
+// equals a key), or complete (payload checked by its tag).  A piece whose slots are both taken stays a miss.
+// `granted`: this lane may take one entry of the remaining room.  Returns false when nothing was added.
+__device__ __forceinline__ bool memo_insert(const PieceTableDev& P, uint64_t k0, uint64_t k1, const int32_t (&tok)[kPieceMaxIds], int cnt) {
+    const uint32_t mix = piece_mix(k0, k1);
+    const uint32_t d3 = uint32_t(k1 >> 32);
+    PieceEntry* cand[2] = {const_cast<PieceEntry*>(P.slots) + piece_h(mix, 0, P.shift), const_cast<PieceEntry*>(P.slots) + piece_h(mix, 1, P.shift)};
+    uint32_t seen[2][4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            seen[c][j] = __hip_atomic_load(reinterpret_cast<uint32_t*>(cand[c]) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (seen[c][3] == kPieceBusy) return false;  // somebody is writing there, possibly this very piece: not now
+        if (seen[c][0] == uint32_t(k0) && seen[c][1] == uint32_t(k0 >> 32) && seen[c][2] == uint32_t(k1) && seen[c][3] == d3) return false;
+    }
+    const int c = seen[0][3] == 0 ? 0 : (seen[1][3] == 0 ? 1 : -1);
+    if (c < 0) return false;
+    uint32_t* slot = reinterpret_cast<uint32_t*>(cand[c]);
+    if (atomicCAS(slot + 3, 0u, kPieceBusy) != 0u) return false;  // lost the slot (no second try: the winner may hold this piece)
+    *reinterpret_cast<uint4*>(slot + 4) = uint4{uint32_t(tok[0]), uint32_t(tok[1]), uint32_t(tok[2]), piece_tag(mix, cnt)};
+    *reinterpret_cast<uint4*>(slot) = uint4{uint32_t(k0), uint32_t(k0 >> 32), uint32_t(k1), d3};
+    return true;
 }
 __device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
     return memo_resolve(memo_fetch(P, k0, k1), k0, k1, tok);
@@ -646,6 +680,14 @@ __device__ __forceinline__ void fold_emitted_tile_sums(const EncodeWork& w, int 
     }
 }
 
+#ifdef OVTK_PROBE
+static __device__ unsigned long long g_probe[16];
+#define PROBE_MIN(i) do { if (threadIdx.x == 0) atomicMin(&g_probe[i], (unsigned long long)wall_clock64()); } while (0)
+#define PROBE_MAX(i) do { if (threadIdx.x == 0) atomicMax(&g_probe[i], (unsigned long long)wall_clock64()); } while (0)
+#else
+#define PROBE_MIN(i)
+#define PROBE_MAX(i)
+#endif
 // ---- merge kernel: dense batches of deferred pieces ----------------------------------------------
 // tail_rows > 0: the block that finishes last also runs the exact pieces (when few) and the scan of the row counts, so
 // that exact_kernel and count_scan_kernel need no launches of their own (tail_rows = n_rows, out_cap as for count_scan).
@@ -667,8 +709,10 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
     if (threadIdx.x == 0) pushed_exact = 0;
     __syncthreads();
+    PROBE_MIN(0);
     if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
     if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows, solo);
+    PROBE_MAX(1);
     uint64_t* key = lds_all[wave_in_block()];                                 // path W
     uint32_t* id = reinterpret_cast<uint32_t*>(key + kChunkSyms);             // path W
     uint32_t* fkey = reinterpret_cast<uint32_t*>(key);                        // path F
@@ -707,6 +751,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         bool is_x = valid && !is_f && !is_l && !is_w;
         int32_t* out = w.stage + e.stage_pos;
         int f_cnt = 0;
+        bool keep = false;  // path F result short enough for a memo entry
         wave_sync();  // the previous batch is done with the LDS arrays
         if (is_f) {
             const uint64_t k0 = e.k0, k1 = e.k1;
@@ -725,6 +770,28 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 for (int k = 0; k < res; ++k) out[k] = int32_t(fid[k * kWave + l]);
                 for (int k = res; k < need; ++k) out[k] = kEmptyId;
                 f_cnt = res;
+                keep = res <= kPieceMaxIds;
+            }
+        }
+        // the memo learns the batch's short results while it has room (one atomic per wave takes the room)
+        if (T.pieces.room) {
+            const unsigned long long km = __ballot(keep);
+            int room_now = 0;
+            if (l == 0 && km) room_now = __hip_atomic_load(T.pieces.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave_readlane(room_now, 0) > 0) {
+                int left = 0;
+                if (l == 0) left = atomicAdd(T.pieces.room, -int(__popcll(km)));
+                left = wave_readlane(left, 0);
+                const int rank = __popcll(km & lanemask_lt());
+                bool added = false;
+                if (keep && rank < left) {
+                    int32_t t3[kPieceMaxIds];
+#pragma unroll
+                    for (int k = 0; k < kPieceMaxIds; ++k) t3[k] = k < f_cnt ? int32_t(fid[k * kWave + l]) : 0;
+                    added = memo_insert(T.pieces, e.k0, e.k1, t3, f_cnt);
+                }
+                const int unused = __popcll(km) - __popcll(__ballot(added));  // room taken but not filled goes back
+                if (l == 0 && unused) atomicAdd(T.pieces.room, unused);
             }
         }
         // ids of the lane-per-piece results go to row_cnt: the 64 entries of a batch were flushed by ONE wave in
@@ -823,6 +890,8 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     if (tail_rows <= 0) return;
     // ---- folded tail: every block takes a ticket when its batches are done; the last one is alone on the data
     __syncthreads();
+    PROBE_MIN(2);
+    PROBE_MAX(3);
     if (solo) {
         if (threadIdx.x == 0) publish_release();
         __syncthreads();
@@ -830,6 +899,10 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     } else if (!last_block_done(&w.status->ticket[0], gridDim.x * gridDim.y, pushed_exact != 0)) {
         return;
     }
+    PROBE_MAX(4);
+#ifdef OVTK_PROBE
+    if (threadIdx.x == 0) g_probe[7] = (unsigned long long)w.status->n_exact;
+#endif
     const int n_exact = w.status->n_exact;
     if (n_exact > kBlockThreads || (w.status->flags & kFlagExactOverflow)) {  // too many for one block: separate launches
         if (threadIdx.x == 0) atomicOr(&w.status->flags, kFlagTailPending);
@@ -842,7 +915,9 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         publish_acquire();
         if (w.status->flags & kFlagScratchOverflow) return;
     }
+    PROBE_MAX(5);
     scan_tiles_one_block(tail_rows, w, out_cap);
+    PROBE_MAX(6);
 }
 template <bool NARROW>
 static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w, int tail_rows,

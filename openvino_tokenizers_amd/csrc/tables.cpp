@@ -57,12 +57,8 @@ void TrieHost::add(const uint8_t* s, size_t n, int32_t value) {
 
 void TrieHost::finalize() {
     const size_t n = b.kids.size();
-    node.assign(n, I2{-1, 0});
     size_t n_edges = 0;
-    for (size_t i = 0; i < n; ++i) {
-        node[i] = I2{b.value[i], b.kids[i].empty() ? 0 : 1};
-        if (i != 0) n_edges += b.kids[i].size();
-    }
+    for (size_t i = 1; i < n; ++i) n_edges += b.kids[i].size();
     root.assign(256, I2{-1, -1});
     for (const auto& k : b.kids[0]) {
         const int child = k.second;
@@ -71,13 +67,14 @@ void TrieHost::finalize() {
     const uint32_t cap = std::max<uint32_t>(8, pow2_at_least(uint64_t(n_edges) * 2 + 1));
     edge_mask = cap - 1;
     edge_shift = 32 - log2u(cap);
-    edges.assign(cap, kEmptySlot);
+    edges.assign(cap, TrieEdge{kNoEdge, -1, -1, 0});
     for (size_t i = 1; i < n; ++i)
         for (const auto& k : b.kids[i]) {
             const uint32_t key = (uint32_t(i) << 8) | k.first;
             uint32_t idx = (hash_u32(key) >> edge_shift) & edge_mask;
-            while (edges[idx] != kEmptySlot) idx = (idx + 1) & edge_mask;
-            edges[idx] = (uint64_t(key) << 32) | uint32_t(k.second);
+            while (edges[idx].key != kNoEdge) idx = (idx + 1) & edge_mask;
+            const int child = k.second;
+            edges[idx] = TrieEdge{key, child, b.value[child], b.kids[child].empty() ? 0 : 1};
         }
 }
 
@@ -219,9 +216,10 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
         uint8_t kb[16] = {0};
         std::memcpy(kb, pieces.chars + pieces.begins[i], size_t(len));
         kb[15] = uint8_t(len);
-        PieceEntry e{0, 0, {0, 0, 0}, cnt};
+        PieceEntry e{0, 0, {0, 0, 0}, 0};
         std::memcpy(&e.k0, kb, 8);
         std::memcpy(&e.k1, kb + 8, 8);
+        e.tag = piece_tag(piece_mix(e.k0, e.k1), cnt);
         for (int k = 0; k < cnt; ++k) e.tok[k] = ids[id_begins[i] + k];
         uniq.emplace(std::string(reinterpret_cast<const char*>(kb), 16), e);
     }

@@ -38,10 +38,19 @@ constexpr int kMaxSuffix = 6;                // end_suffix bytes supported on th
 constexpr int32_t kLeafBit = 1 << 30;        // root[b].y / node child field: node has no children
 
 // ---- device views -----------------------------------------------------------------------
+// One edge of the flattened trie WITH what the walk wants to know about the node it leads to: a step of the longest-match
+// walk is one 16-byte load (edge and node apart were two dependent loads per byte, and the walk is the longest chain
+// of dependent loads in merge_kernel).
+struct alignas(16) TrieEdge {
+    uint32_t key;       // parent node << 8 | byte; kNoEdge = free slot
+    int32_t child;      // node index
+    int32_t value;      // token id ending at the child, or -1
+    int32_t has_kids;   // 0: the child is a leaf
+};
+constexpr uint32_t kNoEdge = 0xFFFFFFFFu;
 struct TrieDev {
     const I2* root;          // [256] x = token id ending at this byte or -1; y = node | kLeafBit, or -1 (no child)
-    const I2* node;          // [n_nodes] x = value (-1 none), y = 1 if the node has children
-    const uint64_t* edges;   // [edge_mask+1]
+    const TrieEdge* edges;   // [edge_mask+1], open addressing (linear probing, load <= 0.5)
     uint32_t edge_mask;
     uint32_t edge_shift;     // 32 - log2(capacity)
 };
@@ -56,11 +65,16 @@ constexpr int kPieceMaxIds = 3;     // longest id sequence it stores
 struct alignas(32) PieceEntry {
     uint64_t k0, k1;  // piece bytes 0..7 / 8..14 (little endian, zero padded) | length << 56; k1 == 0: free (length >= 1)
     int32_t tok[kPieceMaxIds];
-    int32_t cnt;
+    uint32_t tag;     // piece_tag(piece_mix(k0, k1), id count): the payload half says which key it belongs to
 };
+// merge_kernel adds entries while lookups of another stream read the table (the dynamic part of the memo, below).  The
+// two 16-byte halves of an entry are written by two stores, so a reader may see a key whose payload has not arrived:
+// the tag makes that a miss (24 bits of the key's hash + a bit that a zeroed payload lacks) instead of a wrong answer.
+constexpr uint32_t kPieceBusy = 0xFF000000u;  // dword 3 of a key (length byte 255) while a writer fills the slot it claimed
 struct PieceTableDev {
     const PieceEntry* slots;  // nullptr: no memo (every piece takes the merge path)
     uint32_t shift;           // 32 - log2(capacity)
+    int32_t* room;            // entries merge_kernel may still add (cache_capacity at create); nullptr: a fixed table
 };
 struct alignas(16) MergeBucket { MergeSlot s[1]; };  // one slot per bucket: a lookup is two 16-byte loads (divergent loads cost per instruction)
 
@@ -106,6 +120,7 @@ __host__ __device__ inline uint32_t piece_mix(uint64_t k0, uint64_t k1) {
     h *= 0x2C1B3C6Du;
     return h ^ (h >> 13);
 }
+__host__ __device__ inline uint32_t piece_tag(uint32_t mix, int cnt) { return (mix & 0xFFFFFF00u) | 0x80u | uint32_t(cnt); }
 __host__ __device__ inline uint32_t piece_h(uint32_t mix, int which, uint32_t shift) {  // shift = 32 - log2(capacity)
     const uint32_t c = which == 0 ? 0x9E3779B1u : (which == 1 ? 0xD6E8FEB9u : 0xA0761D65u);
     return (mix * c) >> shift;
@@ -132,8 +147,7 @@ __host__ __device__ inline uint32_t hash_bytes(const uint8_t* p, int n) {
 // ---- host builders ----------------------------------------------------------------------
 struct TrieHost {
     std::vector<I2> root;
-    std::vector<I2> node;
-    std::vector<uint64_t> edges;
+    std::vector<TrieEdge> edges;
     uint32_t edge_mask = 0, edge_shift = 32;
 
     // Incremental form used while inserting.

@@ -490,3 +490,37 @@ def test_enqueue_host_buffers(backend):
         tickets.append(fused.enqueue_host([pinned(x) for x in (rb, re_, b, e, c)] + [pat], tok.consts, outs, streams[i % 2]))
     for ref, ticket in zip(refs, tickets):
         assert_same(ref, ticket(), lambda x: x, "enqueue_host/finish")
+
+
+@pytest.mark.parametrize("capacity", [20000, 7, 0])
+def test_memo_learns_and_results_stay(backend, capacity):
+    """The dynamic part of the piece memo (the reference's m_cache, bpe_tokenizer.cpp:197-205 / :331-338): pieces of
+    several tokens are kept the first time merge_kernel computes them, up to cache_capacity; the results of every call --
+    before, while and after learning, and with the table's room exhausted -- equal the oracle's."""
+    import ctypes as C
+    tok = BpeTok.load("gpt2_small")
+    attrs = dict(tok.attrs, cache_capacity=capacity)
+    bpe = BPETokenizer(**attrs, lib=backend.lib)
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), bpe)
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    lib = backend.lib
+    learned = []
+    n = 48 if backend.name == "emu" else 600
+    for k in range(4):
+        b, e, c = TextModel(70 + (k & 1), "zipf").batch(n, 300)   # batches 2, 3 repeat 0, 1: their pieces are known by then
+        rb, re_ = ragged_rows(n)
+        ref = orc(*rs(rb, re_, b, e, c)[:5])
+        assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [pat], tok.consts), backend.host)
+        fixed, got = C.c_int64(), C.c_int64()
+        L.check(lib, lib.ovtk_bpe_memo_entries(bpe._h, C.byref(fixed), C.byref(got)))
+        learned.append(int(got.value))
+        assert (fixed.value > 0) == (capacity != 0)
+    assert all(0 <= x <= capacity for x in learned)
+    if capacity == 0:
+        assert learned == [0, 0, 0, 0]
+    elif capacity == 7:
+        assert learned[0] >= 5 and learned[-1] <= 7   # (a piece whose two slots are taken is not kept: 7 need not be reached)
+    else:
+        # the repeats add next to nothing (only pieces that lost a race for a slot the first time round, on the GPU)
+        assert learned[0] > 20 and learned[1] > learned[0] and learned[1] <= learned[3] <= learned[1] * 1.15
