@@ -147,7 +147,7 @@ class EncodeWorkload:
 
 
 class BpeEncode(EncodeWorkload):
-    def __init__(self, args, lib, dev, rank, tokenizer, kind, rows, nbytes, seed0, no_memo=False, n_batches=None):
+    def __init__(self, args, lib, dev, rank, tokenizer, kind, rows, nbytes, seed0, no_memo=False, n_batches=None, cache_capacity=None):
         self.tok = BpeTok.load(tokenizer)
         model = TextModel(1234, kind)
         nb = n_batches or args.batches
@@ -156,10 +156,19 @@ class BpeEncode(EncodeWorkload):
         attrs = dict(self.tok.attrs)
         if no_memo:
             attrs["cache_capacity"] = 0
+        elif cache_capacity is not None:
+            attrs["cache_capacity"] = cache_capacity
+        self.cache_capacity = attrs.get("cache_capacity", 20000)
         self.bpe = BPETokenizer(**attrs, device=dev.index, lib=lib)
         self.split._ensure(self.tok.pattern_u8())
         self.bpe._ensure(self.batches.d[0] + self.tok.consts)
         self.vocab = len(self.tok.vocab)
+
+    def memo(self):
+        """Entries of the piece memo: from the vocabulary at create / learned from the text since (<= cache_capacity)."""
+        fixed, learned = C.c_int64(), C.c_int64()
+        L.check(self.lib, self.lib.ovtk_bpe_memo_entries(self.bpe._h, C.byref(fixed), C.byref(learned)))
+        return {"fixed": int(fixed.value), "learned": int(learned.value), "cache_capacity": int(self.cache_capacity)}
 
     def run(self, rs, o, st):
         return self.lib.ovtk_encode_run(self.split._h, self.bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, st)
@@ -881,18 +890,21 @@ def main():
             cpu_all = cpu_all_cores(wl)
     if world == 1 and not args.no_extras and args.config == "2" and args.text == "zipf" and not args.no_memo:
         stress = {}
-        for name, kw in (("uniform_text", dict(kind="uniform")), ("no_memo", dict(kind="zipf", no_memo=True))):
+        for name, kw in (("uniform_text", dict(kind="uniform")), ("no_memo", dict(kind="zipf", no_memo=True)),
+                         ("fixed_memo_only", dict(kind="zipf", cache_capacity=1))):
             s_args = argparse.Namespace(**vars(args))
             w2 = BpeEncode(s_args, lib, dev, rank, args.tokenizer, kw["kind"], args.rows, args.bytes, 5000, no_memo=kw.get("no_memo", False),
-                           n_batches=4)
+                           n_batches=4, cache_capacity=kw.get("cache_capacity"))
             run_pipelined(w2, 4, stream_ptrs, args.depth)
             n2 = 16
             d2 = timed(lambda: run_pipelined(w2, n2, stream_ptrs, args.depth, first=4))
             u2 = sum(w2.units(i) for i in range(4, 4 + n2))
             stress[name] = {"value": round(u2 / d2 / 1e6, 1), "unit": "MB/s", "ms_per_step": round(d2 / n2 * 1e3, 4),
                             "ids_per_batch": round(w2.mean_out()),
-                            "note": ("uniform-random printable bytes (SURVEY 8d stress text: cache-hostile, 3x the pieces)" if name == "uniform_text"
-                                     else "zipf text with cache_capacity=0: every piece takes the merge path")}
+                            "note": {"uniform_text": "uniform-random printable bytes (SURVEY 8d stress text: cache-hostile, 3x the pieces)",
+                                     "no_memo": "zipf text with cache_capacity=0: every piece takes the merge path",
+                                     "fixed_memo_only": "zipf text with cache_capacity=1: the memo holds the vocabulary's own tokens and learns "
+                                                        "nothing from the text (every multi-token word is merged every time)"}[name]}
             del w2
         extra_streams = [torch.cuda.Stream(dev) for _ in range(max(0, 4 - len(stream_ptrs)))]
         e2e = end_to_end_leg(wl, lib, dev, stream_ptrs + [C.c_void_p(x.cuda_stream) for x in extra_streams])
@@ -915,6 +927,10 @@ def main():
         "parity_prefix_bit_exact": parity,
         "kernel_ms": kernels,
     }
+    if hasattr(wl, "memo"):
+        # the reference's piece cache (m_cache, cache_capacity = 20000) fills during ITS first calls too; here it is full
+        # before the warm-up steps are over, so the timed steps run with the learned entries in place
+        line["config"]["piece_memo"] = wl.memo()
     print(json.dumps(line))
     if exchange is not None:
         exchange.close()

@@ -768,10 +768,11 @@ int ovtk_special_tokens_split_run(ovtk_special_tokens_split* h, const ovtk_ragge
 
 #ifdef OVTK_PROBE
 extern "C" __attribute__((visibility("default"))) int ovtk_debug_probe(unsigned long long* out, int reset) {
-    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 16);
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * 8192 * 8);
     if (reset) {
-        unsigned long long init[16] = {~0ull, 0, ~0ull, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        hipMemcpyToSymbol(HIP_SYMBOL(g_probe), init, sizeof(init));
+        void* p = nullptr;
+        (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_ts));
+        (void)hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 8);
     }
     return 0;
 }

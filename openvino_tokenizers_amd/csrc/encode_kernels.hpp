@@ -681,12 +681,16 @@ __device__ __forceinline__ void fold_emitted_tile_sums(const EncodeWork& w, int 
 }
 
 #ifdef OVTK_PROBE
-static __device__ unsigned long long g_probe[16];
-#define PROBE_MIN(i) do { if (threadIdx.x == 0) atomicMin(&g_probe[i], (unsigned long long)wall_clock64()); } while (0)
-#define PROBE_MAX(i) do { if (threadIdx.x == 0) atomicMax(&g_probe[i], (unsigned long long)wall_clock64()); } while (0)
+// Diagnostic build (tools/probe_merge.py): wall_clock64() stamps per wave of merge_kernel, plain stores (atomics on one
+// address would serialise the waves they are meant to time).
+static __device__ unsigned long long g_ts[8192][8];
+#define PROBE(i)                                                                                                          \
+    do {                                                                                                                  \
+        const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();         \
+        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][i] = (unsigned long long)wall_clock64();                             \
+    } while (0)
 #else
-#define PROBE_MIN(i)
-#define PROBE_MAX(i)
+#define PROBE(i)
 #endif
 // ---- merge kernel: dense batches of deferred pieces ----------------------------------------------
 // tail_rows > 0: the block that finishes last also runs the exact pieces (when few) and the scan of the row counts, so
@@ -709,10 +713,10 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
     if (threadIdx.x == 0) pushed_exact = 0;
     __syncthreads();
-    PROBE_MIN(0);
+    PROBE(0);
     if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
     if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows, solo);
-    PROBE_MAX(1);
+    PROBE(1);
     uint64_t* key = lds_all[wave_in_block()];                                 // path W
     uint32_t* id = reinterpret_cast<uint32_t*>(key + kChunkSyms);             // path W
     uint32_t* fkey = reinterpret_cast<uint32_t*>(key);                        // path F
@@ -763,7 +767,9 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                     return uint32_t((i < 8 ? k0 >> (8 * i) : k1 >> (8 * (i - 8))) & 0xFF);
                 },
                 need, [&](int k, int tok) { fid[k * kWave + l] = IdT(tok); });
+            PROBE(2);
             const int res = bpe_merge_lane<IdT>(T, fid, fkey, fnid, n);
+            PROBE(3);
             if (res < 0) {
                 is_x = true;
             } else {
@@ -890,8 +896,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     if (tail_rows <= 0) return;
     // ---- folded tail: every block takes a ticket when its batches are done; the last one is alone on the data
     __syncthreads();
-    PROBE_MIN(2);
-    PROBE_MAX(3);
+    PROBE(4);
     if (solo) {
         if (threadIdx.x == 0) publish_release();
         __syncthreads();
@@ -899,10 +904,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     } else if (!last_block_done(&w.status->ticket[0], gridDim.x * gridDim.y, pushed_exact != 0)) {
         return;
     }
-    PROBE_MAX(4);
-#ifdef OVTK_PROBE
-    if (threadIdx.x == 0) g_probe[7] = (unsigned long long)w.status->n_exact;
-#endif
+    PROBE(5);
     const int n_exact = w.status->n_exact;
     if (n_exact > kBlockThreads || (w.status->flags & kFlagExactOverflow)) {  // too many for one block: separate launches
         if (threadIdx.x == 0) atomicOr(&w.status->flags, kFlagTailPending);
@@ -915,9 +917,8 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         publish_acquire();
         if (w.status->flags & kFlagScratchOverflow) return;
     }
-    PROBE_MAX(5);
     scan_tiles_one_block(tail_rows, w, out_cap);
-    PROBE_MAX(6);
+    PROBE(6);
 }
 template <bool NARROW>
 static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w, int tail_rows,

@@ -37,6 +37,9 @@ def test_bench_json_line():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert d["cpu_baseline_all_cores"]["cores"] >= 1 and d["cpu_baseline_all_cores"]["value"] > 0
     assert d["stress"]["uniform_text"]["value"] > 0 and d["stress"]["no_memo"]["ms_per_step"] > 0
+    assert d["stress"]["fixed_memo_only"]["ms_per_step"] > 0
+    memo = d["config"]["piece_memo"]
+    assert memo["fixed"] > 1000 and 0 < memo["learned"] <= memo["cache_capacity"] == 20000
     assert d["end_to_end"]["value"] > 0 and "8 distinct batches" in d["config"]["workload"]
     assert d["parity_prefix_bit_exact"] is True
 
@@ -52,5 +55,14 @@ def test_bench_other_configs(config):
 @pytest.mark.parametrize("config", ["2", "3"])
 def test_bench_exchange_loop(config):
     d = _run("--force-exchange", "--no-cpu-baseline", "--config", config)
-    assert d["value"] > 0 and "all-gather" in d["config"]["exchange"]
-    assert "shard_pack" in d["kernel_ms"] and "shard_unpack" in d["kernel_ms"]
+    assert d["value"] > 0 and "all-gather" in d["config"]["exchange"] and "shard_unpack" in d["kernel_ms"]
+    if config == "2":   # the fused BPE encode writes the send wire itself
+        assert "shard_pack" not in d["kernel_ms"] and "written by the encode itself" in d["config"]["exchange"]
+    else:
+        assert "shard_pack" in d["kernel_ms"]
+
+
+@pytest.mark.gpu
+def test_bench_exchange_loop_packed():
+    d = _run("--force-exchange", "--no-cpu-baseline", "--wire", "0", "--exchange", "p2p")
+    assert d["value"] > 0 and "shard_pack" in d["kernel_ms"] and "grouped direct" in d["config"]["exchange"]

@@ -1,4 +1,8 @@
-"""Temporary: where merge_kernel's time goes (wall_clock64 probes; needs the -DOVTK_PROBE build in tools/build)."""
+"""Diagnostic: where merge_kernel's time goes.  Needs the -DOVTK_PROBE build of the library:
+  cd openvino_tokenizers_amd/csrc && hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -x hip -w -DOVTK_PROBE -shared \\
+      -o ../../tools/build/libovtk_probe.so api_encode.cpp api_ops.cpp tables.cpp runtime.cpp regex_compile.cpp
+Per wave: 0 start, 1 tile sums folded, 2 symbols of its (last) batch in LDS, 3 merges of that batch done, 4 out of the batch
+loop, 5/6 (last block only) tail start / scan done.  wall_clock64 ticks are 10 ns."""
 import ctypes as C, sys, argparse
 from pathlib import Path
 from types import SimpleNamespace
@@ -14,16 +18,21 @@ args = SimpleNamespace(config=a.config, tokenizer="gpt2", text="zipf", rows=6553
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 wl = bench.make_workload(args, lib, dev, 0)
-for i in range(6):
+for i in range(8):
     wl.step(i)
 torch.cuda.synchronize()
-out = (C.c_ulonglong * 16)()
-for i in range(6):
+out = np.zeros((8192, 8), np.uint64)
+for i in range(4):
     lib.ovtk_debug_probe(None, 1)
     wl.step(i)
     torch.cuda.synchronize()
-    lib.ovtk_debug_probe(out, 0)
-    t0 = out[0]
-    us = lambda k: (out[k] - t0) / 100.0
-    print(f"batch {i}: fold done(max) {us(1):.1f}  first block out of batches {us(2):.1f}  last block out {us(3):.1f}  tail start {us(4):.1f} "
-          f"exact done {us(5):.1f}  scan done {us(6):.1f}  n_exact {out[7]}")
+    lib.ovtk_debug_probe(out.ctypes.data_as(C.POINTER(C.c_ulonglong)), 0)
+    ts = out.astype(np.int64)
+    live = ts[:, 0] > 0
+    t0 = ts[live, 0].min()
+    def stat(k, rel=None):
+        m = live & (ts[:, k] > 0)
+        v = (ts[m, k] - (t0 if rel is None else ts[m, rel])) / 100.0
+        return f"n={m.sum()} min {v.min():.1f} p50 {np.median(v):.1f} p90 {np.percentile(v, 90):.1f} max {v.max():.1f}" if m.any() else "-"
+    print(f"batch {i}: waves {live.sum()}\n  start        {stat(0)}\n  folded       {stat(1)}\n  symbolize    {stat(2)}   (took: {stat(2, 1)})\n"
+          f"  merges       {stat(3)}   (took: {stat(3, 2)})\n  out of loop  {stat(4)}\n  tail start   {stat(5)}\n  scan done    {stat(6)}")
