@@ -159,7 +159,20 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t
     uint32_t live = n >= 32 ? ~0u : ((1u << n) - 1u);
     uint32_t seq = n > 0 ? uint32_t(n - 1) : 0;
     bool dup = false;
+#ifdef OVTK_PROBE
+    if (NSYM == kFastSyms) {
+        PROBE(7);
+        int mx = n;
+        for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+        const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
+        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][5] = (unsigned long long)mx;
+    }
+    int iters_ = 0;
+#endif
     while (n >= 2) {
+#ifdef OVTK_PROBE
+        ++iters_;
+#endif
         uint32_t v[NSYM - 1];
 #pragma unroll
         for (int k = 0; k < NSYM - 1; ++k) v[k] = key[OVTK_AT(k)];
@@ -198,6 +211,14 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t
         nid[OVTK_AT(at)] = IdT(nn);
         if (right < NSYM - 1) key[OVTK_AT(right)] = kNoKey32;
     }
+#ifdef OVTK_PROBE
+    if (NSYM == kFastSyms) {
+        int mx = iters_;
+        for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+        const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
+        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][6] = (unsigned long long)mx;
+    }
+#endif
     if (dup) return -1;
     // compact the surviving symbols to the front (ascending positions: reads never trail writes)
     int m = 0;

@@ -50,6 +50,19 @@ constexpr uint32_t kFlagTailPending = 128u;     // merge_kernel's folded tail le
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x) & (kWave - 1); }
 __device__ __forceinline__ int wave_in_block() { return int(threadIdx.x) >> 6; }
 
+#ifdef OVTK_PROBE
+// Diagnostic build (tools/probe_merge.py): wall_clock64() stamps per wave of merge_kernel (slots 5 / 6: the wave's largest symbol count / merge steps), plain stores (atomics on one
+// address would serialise the waves they are meant to time).
+static __device__ unsigned long long g_ts[8192][8];
+#define PROBE(i)                                                                                                          \
+    do {                                                                                                                  \
+        const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();         \
+        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][i] = (unsigned long long)wall_clock64();                             \
+    } while (0)
+#else
+#define PROBE(i)
+#endif
+
 // Orders the LDS accesses of the lanes of one wave -- the wave-level counterpart of __syncthreads() for data handed
 // from lane to lane through LDS.  Deliberately NOT a fence: a wavefront-scope fence makes the compiler drain every
 // outstanding global load and store (s_waitcnt vmcnt(0)) at each hand-off.  LDS operations of one wave execute in

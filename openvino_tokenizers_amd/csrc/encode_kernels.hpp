@@ -680,18 +680,6 @@ __device__ __forceinline__ void fold_emitted_tile_sums(const EncodeWork& w, int 
     }
 }
 
-#ifdef OVTK_PROBE
-// Diagnostic build (tools/probe_merge.py): wall_clock64() stamps per wave of merge_kernel, plain stores (atomics on one
-// address would serialise the waves they are meant to time).
-static __device__ unsigned long long g_ts[8192][8];
-#define PROBE(i)                                                                                                          \
-    do {                                                                                                                  \
-        const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();         \
-        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][i] = (unsigned long long)wall_clock64();                             \
-    } while (0)
-#else
-#define PROBE(i)
-#endif
 // ---- merge kernel: dense batches of deferred pieces ----------------------------------------------
 // tail_rows > 0: the block that finishes last also runs the exact pieces (when few) and the scan of the row counts, so
 // that exact_kernel and count_scan_kernel need no launches of their own (tail_rows = n_rows, out_cap as for count_scan).
@@ -749,6 +737,9 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         DeferredPiece e{};
         if (valid) e = list[base + l];
         const int need = e.len + SL;
+#ifdef OVTK_PROBE
+        if (valid) atomicAdd(&g_ts[8000 + (e.len < 20 ? e.len : 20)][0], 1ull);
+#endif
         const bool is_f = valid && e.len >= 1 && e.len <= kPieceKeyBytes && need <= kFastSyms;
         const bool is_l = valid && !is_f && e.len >= 1 && need <= kLongSyms;
         const bool is_w = valid && !is_f && !is_l && need <= kChunkSyms;
@@ -904,7 +895,6 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     } else if (!last_block_done(&w.status->ticket[0], gridDim.x * gridDim.y, pushed_exact != 0)) {
         return;
     }
-    PROBE(5);
     const int n_exact = w.status->n_exact;
     if (n_exact > kBlockThreads || (w.status->flags & kFlagExactOverflow)) {  // too many for one block: separate launches
         if (threadIdx.x == 0) atomicOr(&w.status->flags, kFlagTailPending);
@@ -918,7 +908,6 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         if (w.status->flags & kFlagScratchOverflow) return;
     }
     scan_tiles_one_block(tail_rows, w, out_cap);
-    PROBE(6);
 }
 template <bool NARROW>
 static __global__ __launch_bounds__(kBlockThreads) void merge_kernel(RowsIn in, BpeDev T, EncodeWork w, int tail_rows,

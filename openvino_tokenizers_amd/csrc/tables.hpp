@@ -7,8 +7,8 @@
 //   VocabEncoder string -> value map         src/vocab_encoder.cpp:62-79
 //
 // Device layouts (all flat arrays, sized for L2 residency, probed with one or two 8/16-byte loads):
-//   trie      root[256] {value, child|leaf bit}; node[n] {value, has_children};
-//             edges: open-addressing table of u64 {key = node<<8|byte : 32, child : 32}
+//   trie      root[256] {value, child|leaf bit}; edges: open-addressing table of 16-byte {key = node<<8|byte, child,
+//             value at the child, child has children} -- one load per byte of the longest-match walk
 //   merges    cuckoo table, 2 hash functions x buckets of two 16-byte slots {left:21 | right:21 |
 //             rank:22} + {new_id}: a lookup is FOUR independent global_load_dwordx4 (both buckets),
 //             never a probe chain -- a wave waits for one round trip, not for its unluckiest lane;

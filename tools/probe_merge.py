@@ -28,11 +28,17 @@ for i in range(4):
     torch.cuda.synchronize()
     lib.ovtk_debug_probe(out.ctypes.data_as(C.POINTER(C.c_ulonglong)), 0)
     ts = out.astype(np.int64)
+    print("  piece bytes histogram:", ts[8000:8021, 0].tolist())
+    print("  symbols histogram:    ", ts[8100:8121, 0].tolist())
+    ts[8000:8200] = 0
     live = ts[:, 0] > 0
     t0 = ts[live, 0].min()
     def stat(k, rel=None):
         m = live & (ts[:, k] > 0)
         v = (ts[m, k] - (t0 if rel is None else ts[m, rel])) / 100.0
         return f"n={m.sum()} min {v.min():.1f} p50 {np.median(v):.1f} p90 {np.percentile(v, 90):.1f} max {v.max():.1f}" if m.any() else "-"
+    m = live & (ts[:, 7] > 0)
+    print(f"  initial pairs took: {stat(7, 2)}; merge loop took: {stat(3, 7)}; max symbols per wave p50 {np.median(ts[m, 5])} max {ts[m, 5].max()}; "
+          f"loop iterations per wave p50 {np.median(ts[m, 6])} p90 {np.percentile(ts[m, 6], 90)} max {ts[m, 6].max()}")
     print(f"batch {i}: waves {live.sum()}\n  start        {stat(0)}\n  folded       {stat(1)}\n  symbolize    {stat(2)}   (took: {stat(2, 1)})\n"
-          f"  merges       {stat(3)}   (took: {stat(3, 2)})\n  out of loop  {stat(4)}\n  tail start   {stat(5)}\n  scan done    {stat(6)}")
+          f"  merges       {stat(3)}   (took: {stat(3, 2)})\n  out of loop  {stat(4)}")
