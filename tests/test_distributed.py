@@ -370,7 +370,7 @@ def test_encode_to_wire_exchange_rccl_one_rank(hip_lib):
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        got, want, regathers = _wire_mode_run(hip_lib, dev, 0, 1, n_rows=3000, nbytes=400000, n_batches=4)
+        got, want, regathers = _wire_mode_run(hip_lib, dev, 0, 1, n_rows=3000, nbytes=200, n_batches=4)
         assert len(got) == len(want) == 4 and regathers >= 1
         for g, w in zip(got, want):
             for a, b in zip(g, w):
