@@ -191,11 +191,13 @@ int ovtk_encode_enqueue(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragge
 int ovtk_encode_finish(ovtk_pending* pending, ovtk_ragged_i32_out* out);
 /* The two halves for HOST buffers -- what a CPU-plugin evaluate() holds (every input of BPETokenizer::evaluate is a host
  * tensor, src/bpe_tokenizer.cpp:122-140).  enqueue puts the copies of the inputs to the device and the kernels on
- * `stream` and returns; finish (ovtk_encode_finish) waits for them, copies begins / ends and exactly n_data ids back and
- * returns when they have arrived.  With PINNED buffers (hipHostMalloc / hipHostRegister) the copies are asynchronous:
- * a host that enqueues batch k+1 (on another stream) before finishing batch k overlaps k+1's host-to-device copy and
- * kernels with k's device-to-host copy -- PCIe is full duplex, the step is bound by the larger copy.  Pageable buffers
- * work too (the runtime then stages the copies synchronously).  Buffers must stay valid until finish. */
+ * `stream` and returns; finish (ovtk_encode_finish) returns when begins / ends and exactly n_data ids are in the caller's
+ * buffers.  With PINNED buffers (hipHostMalloc / hipHostRegister) nothing blocks in between: the input copies are
+ * asynchronous, and the output buffers are written by the last kernel itself through their device-side addresses (no
+ * device-to-host copy; finish only waits for the call's event) -- a host that keeps a few batches in flight on different
+ * streams runs the host-to-device copies of the next batches under the kernels and PCIe stores of this one.  Pageable
+ * buffers work too (staged on the device, copied synchronously).  Buffers must stay valid and untouched until finish;
+ * pinned output buffers may hold partial data while the call is in flight and after a failed call. */
 int ovtk_encode_enqueue_host(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                              const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending);
 

@@ -100,6 +100,24 @@ inline int out_target(DevBuf& stage, T* user, size_t bytes, int mem, T** dev) {
     *dev = stage.as<T>();
     return OVTK_OK;
 }
+// The device-side address of a caller's PINNED host buffer (hipHostMalloc / hipHostRegister: mapped into the device's
+// address space), or nullptr for pageable memory.  The last kernel of an encode writes its outputs straight through it.
+// On this runtime (ROCm 7) a D2H hipMemcpyAsync is a copy KERNEL (rocprofv3 --memory-copy-trace shows H2D only), which the
+// host can issue only after it has read the id count -- one finish() at a time, each blocked for the length of its copy:
+// the pinned-buffer pipeline settles at H2D + D2H per batch (1.22 ms for config 2; only its first ~30 batches run at the
+// 0.8 ms that two-way PCIe allows).  compact_kernel's stores over PCIe need neither the copy nor the host: 0.78-0.80 ms per
+// batch in the steady state (tools/e2e_age_probe.py).  Tried on the way and dropped: copy streams of the library's own, one
+// per direction (no better with the copy kernel, and two more streams move every stream of the process to other hardware
+// queues: the device-resident pipeline went from 0.165 to 0.22 ms per step).
+inline void* mapped_host_pointer(const void* user) {
+    if (!user) return nullptr;
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, user) != hipSuccess) {
+        (void)hipGetLastError();  // pageable memory is reported as an error by some runtimes
+        return nullptr;
+    }
+    return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
+}
 inline int copy_back(void* user, const void* dev, size_t bytes, int mem, hipStream_t s) {
     if (mem == OVTK_MEM_DEVICE || bytes == 0) return OVTK_OK;
     OVTK_HIP(hipMemcpyAsync(user, dev, bytes, hipMemcpyDeviceToHost, s));
@@ -231,9 +249,22 @@ public:
         exact_cap_ = std::max<int64_t>(4096, int64_t(ws_->exact.size() / sizeof(ExactPiece)));
         scratch_cap_ = std::max<int64_t>(ws_->scratch.size(), int64_t(16) << 20);
         if (!wire_.hdr) {
-            if (int rc = out_target(ws_->out_a, out_.begins, size_t(n_rows_) * 4, mem_, &d_begins_)) return rc;
-            if (int rc = out_target(ws_->out_b, out_.ends, size_t(n_rows_) * 4, mem_, &d_ends_)) return rc;
-            if (int rc = out_target(ws_->out_c, out_.data, size_t(out_.data_capacity) * 4, mem_, &d_ids_)) return rc;
+            if (mem_ == OVTK_MEM_HOST) {  // pinned output buffers are written by the kernels themselves
+                void* pb = mapped_host_pointer(out_.begins);
+                void* pe = mapped_host_pointer(out_.ends);
+                void* pd = mapped_host_pointer(out_.data);
+                if (pb && pe && pd) {
+                    d_begins_ = static_cast<int32_t*>(pb);
+                    d_ends_ = static_cast<int32_t*>(pe);
+                    d_ids_ = static_cast<int32_t*>(pd);
+                    direct_out_ = true;
+                }
+            }
+            if (!direct_out_) {
+                if (int rc = out_target(ws_->out_a, out_.begins, size_t(n_rows_) * 4, mem_, &d_begins_)) return rc;
+                if (int rc = out_target(ws_->out_b, out_.ends, size_t(n_rows_) * 4, mem_, &d_ends_)) return rc;
+                if (int rc = out_target(ws_->out_c, out_.data, size_t(out_.data_capacity) * 4, mem_, &d_ids_)) return rc;
+            }
         }
         grid_ = grid_rows(device_, n_rows_, blocks_per_cu_);
         n_tiles_ = (n_rows_ + kRowTile - 1) / kRowTile;
@@ -276,6 +307,7 @@ public:
                                                           " ids, capacity " + std::to_string(out_.data_capacity) + ")");
                 out->n_data = st.n_out;
                 if (wire_.hdr) return OVTK_OK;  // (device memory: the wire is complete)
+                if (direct_out_) return OVTK_OK;  // the kernels wrote the caller's pinned buffers
                 if (int rc = copy_back(out_.begins, d_begins_, size_t(n_rows_) * 4, mem_, s_)) return rc;
                 if (int rc = copy_back(out_.ends, d_ends_, size_t(n_rows_) * 4, mem_, s_)) return rc;
                 if (int rc = copy_back(out_.data, d_ids_, size_t(st.n_out) * 4, mem_, s_)) return rc;
@@ -376,6 +408,7 @@ private:
     int mul_;
     ovtk_ragged_i32_out out_;
     int mem_, in_mem_;
+    bool direct_out_ = false;      // host-memory call whose output buffers are pinned: the kernels write them (no D2H copy)
     std::shared_ptr<void> keep_;
     hipStream_t s_;
     Middle middle_;

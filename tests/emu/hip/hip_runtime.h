@@ -311,6 +311,13 @@ static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMem
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) std::memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum { hipStreamNonBlocking = 1 };
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {  // nothing is pinned here: always staged
+    a->type = hipMemoryTypeUnregistered; a->device = 0; a->devicePointer = nullptr; a->hostPointer = const_cast<void*>(p);
+    return hipSuccess;
+}
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }

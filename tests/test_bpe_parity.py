@@ -524,3 +524,37 @@ def test_memo_learns_and_results_stay(backend, capacity):
     else:
         # the repeats add next to nothing (only pieces that lost a race for a slot the first time round, on the GPU)
         assert learned[0] > 20 and learned[1] > learned[0] and learned[1] <= learned[3] <= learned[1] * 1.15
+
+
+@pytest.mark.gpu
+def test_pinned_outputs_written_by_the_kernels(hip_lib):
+    """Host-memory calls with PINNED output buffers take no D2H copy: compact_kernel (or encode_small_kernel) stores through
+    the buffers' device-side addresses.  Same results as with pageable buffers (staged + copied), mixed cases too; a too
+    small pinned ids buffer is OVTK_E_CAPACITY with nothing written past its end; a workspace that has to grow (the call is
+    repeated inside finish) ends in the same place."""
+    import torch
+    tok = BpeTok.load("gpt2_small")
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+
+    def pinned(a):
+        t = torch.empty(a.shape, dtype=getattr(torch, str(a.dtype)), pin_memory=True)
+        v = t.numpy()
+        v[...] = a
+        return v
+    for n, target, kind in [(3000, 300, "zipf"), (20, 100, "zipf"), (2500, 200, "uniform")]:   # (20 rows: the one-launch path)
+        fused = FusedSplitBPE(RegexSplit("isolate", lib=hip_lib), BPETokenizer(**tok.attrs, lib=hip_lib))   # fresh workspace sizes
+        b, e, c = TextModel(n, kind).batch(n, target)
+        rb, re_ = ragged_rows(n)
+        ref = orc(*rs(rb, re_, b, e, c)[:5])
+        ins = [rb, re_, b, e, c]
+        for pin_out in ((True, True, True), (False, False, False), (True, False, True)):
+            outs = tuple((pinned if p else (lambda a: a))(np.full(k, -7, np.int32)) for p, k in zip(pin_out, (n, n, len(c) + 64)))
+            got = fused.enqueue_host([pinned(x) for x in ins] + [pat], tok.consts, outs)()
+            assert_same(ref, got, lambda x: x, f"pinned outputs {pin_out}")
+            assert np.all(outs[2][len(ref[2]):] == -7)   # nothing behind the ids
+        short = tuple(pinned(np.full(k, -7, np.int32)) for k in (n, n, len(ref[2]) // 2 + 64))
+        guard = short[2][len(ref[2]) // 2:]
+        with pytest.raises(L.OvtkError) as ei:
+            fused.enqueue_host([pinned(x) for x in ins] + [pat], tok.consts, (short[0], short[1], short[2][: len(ref[2]) // 2]))()
+        assert ei.value.code == L.E_CAPACITY and np.all(guard == -7)
