@@ -558,3 +558,44 @@ def test_pinned_outputs_written_by_the_kernels(hip_lib):
         with pytest.raises(L.OvtkError) as ei:
             fused.enqueue_host([pinned(x) for x in ins] + [pat], tok.consts, (short[0], short[1], short[2][: len(ref[2]) // 2]))()
         assert ei.value.code == L.E_CAPACITY and np.all(guard == -7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("vocab", ["gpt2_small", "llama3_small"])
+def test_memo_learns_under_concurrent_lookups(gpu_backend, vocab):
+    """One handle on three HIP streams, twelve different batches in flight three at a time: merge_kernel of one batch
+    inserts memo entries while the lookup kernels of its neighbours probe the same table (tables.hpp, kPieceBusy / the
+    payload tag).  Every batch equals the oracle, the first time and again with the memo as the race left it."""
+    import ctypes as C
+    import torch
+    backend = gpu_backend
+    tok = BpeTok.load(vocab)
+    bpe = BPETokenizer(**dict(tok.attrs, cache_capacity=200000), lib=backend.lib)   # room for everything: inserts all the way
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), bpe)
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    batches, refs = [], []
+    for i in range(12):
+        kind = ("zipf", "mixed", "uniform")[i % 3]
+        n = 3000 + 500 * (i % 4)
+        b, e, c = TextModel(900 + i, kind).batch(n, 200 + 40 * (i % 5))
+        rb, re_ = ragged_rows(n)
+        refs.append(orc(*rs(rb, re_, b, e, c)[:5]))
+        batches.append(backend.data([rb, re_, b, e, c]))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    learned = []
+    for rounds in range(3):
+        inflight = []
+        for k, data in enumerate(batches):
+            with torch.cuda.stream(streams[k % 3]):
+                inflight.append((k, fused.enqueue(data + [pat], tok.consts)))
+            if len(inflight) > 2:
+                j, t = inflight.pop(0)
+                assert_same(refs[j], t(), backend.host, f"round {rounds} batch {j}")
+        for j, t in inflight:
+            assert_same(refs[j], t(), backend.host, f"round {rounds} batch {j}")
+        fixed, got = C.c_int64(), C.c_int64()
+        L.check(backend.lib, backend.lib.ovtk_bpe_memo_entries(bpe._h, C.byref(fixed), C.byref(got)))
+        learned.append(int(got.value))
+    assert learned[0] > 1000 and learned[0] <= learned[1] <= learned[2] <= 200000
