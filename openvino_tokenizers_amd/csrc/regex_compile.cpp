@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <set>
 #include <utility>
 
 #include "../../include/ovtk_amd.h"
@@ -598,6 +599,10 @@ enum Op : uint8_t { kChar, kSplit, kJmp, kAssertOp, kMatch };
 struct Inst {
     Op op;
     int x = 0, y = 0;  // kChar: x = set id, y = next; kSplit: x preferred, y other; kJmp: x; kAssertOp: x = assert id, y = next
+    // kSplit at the head of a greedy / possessive unbounded repeat (x = one more round of the body, y = the way out).  When
+    // the body gets back here without having consumed a character, PCRE2 ends the repeat THERE -- what follows the repeat is
+    // tried before the body's remaining alternatives ((a??)+ on "a" matches the empty string, not "a").
+    bool loop = false;
 };
 struct AssertInfo {
     int kind;
@@ -661,7 +666,7 @@ struct Builder {
                     const int loop = emit(Inst{kSplit, 0, 0});
                     const int body = gen(child, loop);
                     const int skip = skip_target(next);
-                    prog[size_t(loop)] = nd.mode == 1 ? Inst{kSplit, skip, body} : Inst{kSplit, body, skip};
+                    prog[size_t(loop)] = nd.mode == 1 ? Inst{kSplit, skip, body} : Inst{kSplit, body, skip, true};
                     e = loop;
                 } else {
                     for (int k = nd.min; k < nd.max; ++k) {
@@ -780,7 +785,10 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
         };
         for (int c = 0; c < n_ctx; ++c) out.start[c] = uint16_t(intern(Key{c, {entry}}));
         std::vector<uint16_t> trans;
-        std::vector<uint8_t> seen(b.prog.size());
+        std::vector<uint8_t> open(b.prog.size());
+        std::set<std::pair<int, uint64_t>> visited;
+        long long closure_steps = 0;
+        constexpr long long kMaxClosureSteps = 50'000'000;
         std::vector<int> pending;
         for (size_t s = 0; s < states.size(); ++s) {
             trans.resize((s + 1) * size_t(n_syms), 0);
@@ -788,25 +796,46 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
             const Key st = states[s];  // copy: `states` grows below
             for (int sym = 0; sym < n_syms; ++sym) {
                 const int c = sym_class(sym);
-                std::fill(seen.begin(), seen.end(), 0);
                 pending.clear();
                 bool matched = false;
                 // the closure at this position: previous character = st.first, next symbol = sym
                 std::vector<int> stack;
                 for (size_t k = st.second.size(); k-- > 0;) stack.push_back(st.second[k]);
+                std::fill(open.begin(), open.end(), 0);
+                visited.clear();
+                uint64_t open_sig = 0;  // which repeats are open on the way to the node at hand (order-independent sum)
+                auto sig_of = [](int loop_pc) { return (uint64_t(loop_pc) + 1) * 0x9E3779B97F4A7C15ull; };
                 while (!stack.empty() && !matched) {
                     const int pc = stack.back();
                     stack.pop_back();
-                    if (seen[size_t(pc)]) continue;
-                    seen[size_t(pc)] = 1;
+                    if (pc < 0) {  // the body of repeat -pc - 1 has been walked
+                        open[size_t(-pc - 1)] = 0;
+                        open_sig -= sig_of(-pc - 1);
+                        continue;
+                    }
+                    if (open[size_t(pc)]) {  // an empty round of an open repeat: PCRE2 leaves the repeat here
+                        stack.push_back(b.prog[size_t(pc)].y);
+                        continue;
+                    }
+                    // A node reached again is the same thread only if the same repeats are open: what follows an empty round
+                    // depends on them.  (Character threads are told apart by `pending` below: the first one wins.)
+                    if (!visited.insert({pc, open_sig}).second) continue;
+                    if (++closure_steps > kMaxClosureSteps) throw Unsupported{"pattern too intricate for the table builder"};
                     const Inst& in = b.prog[size_t(pc)];
                     switch (in.op) {
                         case kJmp: stack.push_back(in.x); break;
                         case kSplit:
                             stack.push_back(in.y);
+                            if (in.loop) {
+                                stack.push_back(-pc - 1);
+                                open[size_t(pc)] = 1;
+                                open_sig += sig_of(pc);
+                            }
                             stack.push_back(in.x);
                             break;
-                        case kChar: pending.push_back(pc); break;
+                        case kChar:
+                            if (std::find(pending.begin(), pending.end(), pc) == pending.end()) pending.push_back(pc);
+                            break;
                         case kMatch: matched = true; break;  // everything of lower priority is cut
                         case kAssertOp: {
                             const AssertInfo& a = b.asserts[size_t(in.x)];

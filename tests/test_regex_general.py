@@ -91,6 +91,41 @@ def test_pcre2_semantics(backend, pattern):
         assert err.code == L.E_UNSUPPORTED and pattern in (r"a{,3}", r"[\p{L}--a]"), pattern
 
 
+# Repeats whose body can match the empty string: PCRE2 ends a repeat at the first round that consumed nothing, and what
+# follows the repeat is tried BEFORE the remaining alternatives of that round (found by tools/fuzz_regex.py).
+EMPTY_ROUNDS = [r"(é??)+", r"(?:a??)+b?", r"(?:\d?[ab]?|\n)+", r"(?:\d?+[ab]?+|\n*+)+", r"(?:\Aa?a|(?!\P{L}))*?", r"(?:a?|b)+", r"(?:a*?|b)*c?",
+                r"(?:(?:a??)+|b)+"]
+
+
+@pytest.mark.parametrize("pattern", EMPTY_ROUNDS)
+@pytest.mark.parametrize("behaviour", ["isolate", "contiguous"])
+def test_repeats_with_empty_rounds(backend, pattern, behaviour):
+    strs = strings_for(backend, ["a", "b", "1", "\n", "é", " "], 5, n_emu=300, n_gpu=4000) + ["a1\n", "éa", "ab", "aab\n"]
+    check(backend, pattern, strs, behaviour)
+
+
+def test_fuzzed_patterns(backend):
+    """A fixed sample of tools/fuzz_regex.py's random patterns (all five behaviours) against PCRE2."""
+    from tools import fuzz_regex as F
+    rng = np.random.default_rng(2026)
+    strings = ["".join(t) for k in range(1, 4) for t in itertools.product(F.ALPHA, repeat=k)]
+    strings += ["".join(rng.choice(F.ALPHA, size=int(k))) for k in rng.integers(4, 12, size=200)] + [""]
+    behaviours = ["isolate", "remove", "mergedwithprevious", "mergedwithnext", "contiguous"]
+    compared = 0
+    for i in range(40 if backend.name == "emu" else 160):
+        pat = F.gen(rng)
+        try:
+            check(backend, pat, strings, behaviours[i % 5])
+            compared += 1
+        except L.OvtkError as err:
+            assert err.code == L.E_UNSUPPORTED, pat
+        except AssertionError:
+            raise
+        except Exception:   # the oracle's PCRE2 refused the pattern
+            pass
+    assert compared >= 20
+
+
 @pytest.mark.parametrize("pattern", [r"(a)\1", r"(?>a+)b", r"\p{Han}+", r"\p{Greek}", r"a(?=bc)", r"(?<=ab)c", r"(?m)^a", r"(?x) a b", r"\R",
                                      r"\X", r"a\Kb", r"(?|a|b)", r"(?R)", r"(?(1)a|b)", r"(?i)é", r"(?i)[à-ý]", r"(a|b)++c", r"a**",
                                      r"(?i)\p{Lu}x", r"[[:punct:]]", r"(*UTF)a", r"(", r"a)", r"[a", r"\p{Foo}", "\\"])

@@ -1,0 +1,76 @@
+"""Differential fuzzer for the compiled-pattern RegexSplit: random patterns from a small grammar, every string over a small
+alphabet up to length 4 plus random longer ones, the emulator build of the device matcher against PCRE2 (the oracle).
+Patterns either side refuses are skipped; a mismatch prints the pattern and the first offending string.
+    python tools/fuzz_regex.py [seed] [n_patterns]"""
+import itertools
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from openvino_tokenizers_amd import _lib as L  # noqa: E402
+from tests.conftest import Backend  # noqa: E402
+from tests.test_split_rules import check  # noqa: E402
+
+ATOMS = ["a", "b", "c", " ", r"\n", ".", r"\s", r"\S", r"\d", r"\w", r"\W", "[ab]", "[^a]", "[a-c]", r"[^\s]", r"\p{L}", r"\P{L}", r"\p{N}",
+         "1", "é", "[é1]", r"[\s\d]", r"\b", r"\B", "^", "$", r"\z", r"\A"]
+QUANT = ["", "", "", "*", "+", "?", "{1,2}", "{2}", "{0,2}", "*?", "+?", "??", "*+", "++", "?+", "{1,2}?", "{1,2}+"]
+ALPHA = ["a", "b", "c", " ", "\n", "1", "é", "A"]
+
+
+def gen(rng, depth=0):
+    r = rng.random()
+    if depth >= 3 or r < 0.45:
+        a = ATOMS[rng.integers(len(ATOMS))]
+        if a in (r"\b", r"\B", "^", "$", r"\z", r"\A"):
+            return a
+        return a + QUANT[rng.integers(len(QUANT))]
+    if r < 0.65:
+        return gen(rng, depth + 1) + gen(rng, depth + 1)
+    if r < 0.80:
+        return "(?:" + gen(rng, depth + 1) + "|" + gen(rng, depth + 1) + ")" + QUANT[rng.integers(len(QUANT))]
+    if r < 0.88:
+        return "(" + gen(rng, depth + 1) + ")" + QUANT[rng.integers(len(QUANT))]
+    if r < 0.94:
+        kind = ["(?=", "(?!", "(?<=", "(?<!"][rng.integers(4)]
+        inner = ATOMS[rng.integers(18)]  # single-character atoms only (fixed-width look-behind)
+        return kind + inner + ")"
+    return "(?i:" + gen(rng, depth + 1) + ")"
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    n_pat = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+    rng = np.random.default_rng(seed)
+    lib = L.load(ROOT / "tests" / "emu" / "build" / "libovtk_emu.so")
+    backend = Backend("emu", lib)
+    strings = ["".join(t) for k in range(1, 4) for t in itertools.product(ALPHA, repeat=k)]
+    strings += ["".join(rng.choice(ALPHA, size=int(k))) for k in rng.integers(4, 12, size=400)] + [""]
+    done = refused = bad = 0
+    behaviours = ["isolate", "remove", "mergedwithprevious", "mergedwithnext", "contiguous"]
+    for i in range(n_pat):
+        pat = gen(rng)
+        beh = behaviours[rng.integers(len(behaviours))]
+        inv = bool(rng.integers(2)) and beh in ("isolate", "remove")
+        try:
+            check(backend, pat, strings, beh, inv)
+            done += 1
+        except L.OvtkError as e:
+            if e.code != L.E_UNSUPPORTED:
+                print("ERROR", repr(pat), e)
+                bad += 1
+            refused += 1
+        except AssertionError as e:
+            print("MISMATCH", repr(pat), beh, inv, str(e)[:300])
+            bad += 1
+        except Exception as e:  # the oracle's PCRE2 refused the pattern
+            refused += 1
+            if "compil" not in str(e).lower() and "pcre" not in str(e).lower():
+                print("??", repr(pat), type(e).__name__, str(e)[:200])
+    print(f"seed {seed}: {done} patterns compared, {refused} refused by one side, {bad} BAD")
+
+
+if __name__ == "__main__":
+    main()
