@@ -599,3 +599,20 @@ def test_memo_learns_under_concurrent_lookups(gpu_backend, vocab):
         L.check(backend.lib, backend.lib.ovtk_bpe_memo_entries(bpe._h, C.byref(fixed), C.byref(got)))
         learned.append(int(got.value))
     assert learned[0] > 1000 and learned[0] <= learned[1] <= learned[2] <= 200000
+
+
+def test_fuzzed_tables(backend):
+    """A fixed sample of tools/fuzz_bpe.py: random (untrained) vocabularies and merge tables -- duplicate strings, added
+    tokens whose ids collide, missing bytes with and without unk / byte_fallback, end_suffix, text-form merges -- and pieces
+    of every length class, twice per handle (the second call on what the memo learned)."""
+    from tools import fuzz_bpe as F
+    rng = np.random.default_rng(77)
+    for k in range(25 if backend.name == "emu" else 120):
+        tok, rows = F.case(rng)
+        inputs = F.pieces_inputs(rows)
+        cap = int(sum(len(p) + 8 for r in rows for p in r) * 2 + 64)
+        ref = tok.oracle()(*inputs, cap=cap)
+        op = BPETokenizer(**tok.attrs, lib=backend.lib)
+        for rep in range(2):
+            got = op.evaluate(backend.data(inputs) + tok.consts, ids_capacity=cap)
+            assert_same(ref, got, backend.host, f"case {k} rep {rep} attrs {tok.attrs}")

@@ -16,8 +16,11 @@ from tests.test_split_rules import check  # noqa: E402
 
 ATOMS = ["a", "b", "c", " ", r"\n", ".", r"\s", r"\S", r"\d", r"\w", r"\W", "[ab]", "[^a]", "[a-c]", r"[^\s]", r"\p{L}", r"\P{L}", r"\p{N}",
          "1", "é", "[é1]", r"[\s\d]", r"\b", r"\B", "^", "$", r"\z", r"\A"]
+if "wide" in sys.argv[3:]:
+    ATOMS = ATOMS[:18] + ["A", r"\h", r"\v", r"\N", "[[:alpha:]]", r"\p{Lu}", r"\p{Ll}", "元", r"(?s:.)", "_", r"[^\r\n]", r"\r", r"\t", r"[\p{L}\p{N}]",
+                         r"[^\s\p{L}\p{N}]", "'", r"\b", r"\B", "^", "$", r"\z", r"\Z", r"\A"]
 QUANT = ["", "", "", "*", "+", "?", "{1,2}", "{2}", "{0,2}", "*?", "+?", "??", "*+", "++", "?+", "{1,2}?", "{1,2}+"]
-ALPHA = ["a", "b", "c", " ", "\n", "1", "é", "A"]
+ALPHA = ["a", "b", "c", " ", "\n", "1", "é", "A"] + (["元", "\r", "\t", "_", "'"] if "wide" in sys.argv[3:] else [])
 
 
 def gen(rng, depth=0):
@@ -46,7 +49,8 @@ def main():
     rng = np.random.default_rng(seed)
     lib = L.load(ROOT / "tests" / "emu" / "build" / "libovtk_emu.so")
     backend = Backend("emu", lib)
-    strings = ["".join(t) for k in range(1, 4) for t in itertools.product(ALPHA, repeat=k)]
+    strings = ["".join(t) for k in range(1, 4 if len(ALPHA) <= 8 else 3) for t in itertools.product(ALPHA, repeat=k)]
+    strings += ["".join(rng.choice(ALPHA, size=3)) for _ in range(600)] if len(ALPHA) > 8 else []
     strings += ["".join(rng.choice(ALPHA, size=int(k))) for k in rng.integers(4, 12, size=400)] + [""]
     done = refused = bad = 0
     behaviours = ["isolate", "remove", "mergedwithprevious", "mergedwithnext", "contiguous"]
