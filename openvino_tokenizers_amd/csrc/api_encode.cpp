@@ -768,11 +768,11 @@ int ovtk_special_tokens_split_run(ovtk_special_tokens_split* h, const ovtk_ragge
 
 #ifdef OVTK_PROBE
 extern "C" __attribute__((visibility("default"))) int ovtk_debug_probe(unsigned long long* out, int reset) {
-    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * 8192 * 8);
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * 8192 * 12);
     if (reset) {
         void* p = nullptr;
         (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_ts));
-        (void)hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 8);
+        (void)hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 12);
     }
     return 0;
 }

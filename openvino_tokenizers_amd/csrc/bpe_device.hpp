@@ -161,11 +161,10 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t
     bool dup = false;
 #ifdef OVTK_PROBE
     if (NSYM == kFastSyms) {
-        PROBE(7);
         int mx = n;
         for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
         const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
-        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][5] = (unsigned long long)mx;
+        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][8] = (unsigned long long)mx;
     }
     int iters_ = 0;
 #endif
@@ -216,7 +215,7 @@ __device__ __forceinline__ int bpe_merge_lane(const BpeDev& T, IdT* id, uint32_t
         int mx = iters_;
         for (int d = 32; d > 0; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
         const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();
-        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][6] = (unsigned long long)mx;
+        if (lane_id() == 0 && pw_ < 8192) g_ts[pw_][9] = (unsigned long long)mx;
     }
 #endif
     if (dup) return -1;

@@ -53,7 +53,7 @@ __device__ __forceinline__ int wave_in_block() { return int(threadIdx.x) >> 6; }
 #ifdef OVTK_PROBE
 // Diagnostic build (tools/probe_merge.py): wall_clock64() stamps per wave of merge_kernel (slots 5 / 6: the wave's largest symbol count / merge steps), plain stores (atomics on one
 // address would serialise the waves they are meant to time).
-static __device__ unsigned long long g_ts[8192][8];
+static __device__ unsigned long long g_ts[8192][12];
 #define PROBE(i)                                                                                                          \
     do {                                                                                                                  \
         const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block();         \

@@ -738,7 +738,16 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         if (valid) e = list[base + l];
         const int need = e.len + SL;
 #ifdef OVTK_PROBE
-        if (valid) atomicAdd(&g_ts[8000 + (e.len < 20 ? e.len : 20)][0], 1ull);
+        unsigned long long pt_ = wall_clock64();   // phase clock of this batch
+#define PHASE(slot)                                                                                     \
+    do {                                                                                                \
+        const unsigned long long now_ = wall_clock64();                                                 \
+        const int pw_ = (int(blockIdx.y) * int(gridDim.x) + int(blockIdx.x)) * kWavesPerBlock + wave_in_block(); \
+        if (lane_id() == 0 && pw_ < 8000) g_ts[pw_][slot] += now_ - pt_;                                \
+        pt_ = now_;                                                                                     \
+    } while (0)
+#else
+#define PHASE(slot)
 #endif
         const bool is_f = valid && e.len >= 1 && e.len <= kPieceKeyBytes && need <= kFastSyms;
         const bool is_l = valid && !is_f && e.len >= 1 && need <= kLongSyms;
@@ -758,9 +767,9 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                     return uint32_t((i < 8 ? k0 >> (8 * i) : k1 >> (8 * (i - 8))) & 0xFF);
                 },
                 need, [&](int k, int tok) { fid[k * kWave + l] = IdT(tok); });
-            PROBE(2);
+            PHASE(2);
             const int res = bpe_merge_lane<IdT>(T, fid, fkey, fnid, n);
-            PROBE(3);
+            PHASE(3);
             if (res < 0) {
                 is_x = true;
             } else {
@@ -843,6 +852,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
             const unsigned long long done = __ballot(((lm >> l) & 1ull) && rank < kWave / 2);
             lm &= ~done;
         }
+        PHASE(10);
         unsigned long long wm = __ballot(is_w);
         while (wm) {
             const int src = __ffsll(wm) - 1;
@@ -871,6 +881,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 }
             }
         }
+        PHASE(11);
         const unsigned long long xm = __ballot(is_x);
         if (xm) {
             int idx = 0;

@@ -14,31 +14,31 @@ import bench
 lib = L.load(ROOT / "tools" / "build" / "libovtk_probe.so")
 ap = argparse.ArgumentParser(); ap.add_argument("--config", default="2"); ap.add_argument("--no-memo", action="store_true")
 a = ap.parse_args()
-args = SimpleNamespace(config=a.config, tokenizer="gpt2", text="zipf", rows=65536, bytes=512, batches=4, no_memo=a.no_memo)
+args = SimpleNamespace(config=a.config, tokenizer="gpt2", text="zipf", rows=65536 if a.config != "4" else 131072, bytes=512, batches=4, no_memo=a.no_memo)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 wl = bench.make_workload(args, lib, dev, 0)
 for i in range(8):
     wl.step(i)
 torch.cuda.synchronize()
-out = np.zeros((8192, 8), np.uint64)
+out = np.zeros((8192, 12), np.uint64)
 for i in range(4):
     lib.ovtk_debug_probe(None, 1)
     wl.step(i)
     torch.cuda.synchronize()
     lib.ovtk_debug_probe(out.ctypes.data_as(C.POINTER(C.c_ulonglong)), 0)
     ts = out.astype(np.int64)
-    print("  piece bytes histogram:", ts[8000:8021, 0].tolist())
-    print("  symbols histogram:    ", ts[8100:8121, 0].tolist())
-    ts[8000:8200] = 0
     live = ts[:, 0] > 0
     t0 = ts[live, 0].min()
-    def stat(k, rel=None):
+    def stat(k):
         m = live & (ts[:, k] > 0)
-        v = (ts[m, k] - (t0 if rel is None else ts[m, rel])) / 100.0
+        v = (ts[m, k] - t0) / 100.0
         return f"n={m.sum()} min {v.min():.1f} p50 {np.median(v):.1f} p90 {np.percentile(v, 90):.1f} max {v.max():.1f}" if m.any() else "-"
-    m = live & (ts[:, 7] > 0)
-    print(f"  initial pairs took: {stat(7, 2)}; merge loop took: {stat(3, 7)}; max symbols per wave p50 {np.median(ts[m, 5])} max {ts[m, 5].max()}; "
-          f"loop iterations per wave p50 {np.median(ts[m, 6])} p90 {np.percentile(ts[m, 6], 90)} max {ts[m, 6].max()}")
-    print(f"batch {i}: waves {live.sum()}\n  start        {stat(0)}\n  folded       {stat(1)}\n  symbolize    {stat(2)}   (took: {stat(2, 1)})\n"
-          f"  merges       {stat(3)}   (took: {stat(3, 2)})\n  out of loop  {stat(4)}")
+
+    def phase(k):   # accumulated over the wave's batches
+        v = ts[live, k] / 100.0
+        return f"p50 {np.median(v):.1f} p90 {np.percentile(v, 90):.1f} max {v.max():.1f} us"
+    m = live & (ts[:, 8] > 0)
+    print(f"batch {i}: waves {live.sum()}; start {stat(0)}; folded {stat(1)}; out of the batch loop {stat(4)}\n"
+          f"  per wave, summed over its batches: entries + symbols (F) {phase(2)}; merges (F) {phase(3)}; path L {phase(10)}; path W {phase(11)}\n"
+          f"  largest symbol count per wave p50 {np.median(ts[m, 8])}; merge steps per wave (last batch) p50 {np.median(ts[m, 9])} max {ts[m, 9].max()}")
