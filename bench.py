@@ -851,6 +851,9 @@ def main():
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": round(algo_bytes),
                     "launches_per_step": launches_per_step,
+                    "bytes_note": ("algorithmic bytes of the whole pass (SURVEY 8d) over the dominant kernel's own time.  For the encode "
+                                   "configurations that kernel reads all the text and stages all ids but those of the deferred pieces, "
+                                   "so its own algorithmic bytes are the same figure within ~5 %; `step` prices every kernel of the path"),
                     "measured": ("one-stream leg of 24 batches behind the timed region (every kernel alone on the chip)" if alone
                                  else "the timed loop's own launches"),
                     "one_stream_kernel_ms": {k: round(v, 4) for k, v in sorted(per_launch.items())},
