@@ -547,7 +547,7 @@ __device__ __forceinline__ void lookup_body(const RowsIn& in, const SplitDev& sp
     if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
 }
 template <int MODE, bool TICKETS = false>
-static __global__ __launch_bounds__(kBlockThreads, 5) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads, MODE == kFusedLlama3 ? 4 : 5) void lookup_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     lookup_body<MODE, TICKETS>(in, sp, T, w);
 }
 

@@ -707,6 +707,252 @@ __device__ __forceinline__ bool gpt2_packed_starts(WaveScratch& ws, int skew, in
     return true;
 }
 
+// ---- the Llama-3 pattern, packed bytes ------------------------------------------------------------------------------
+// llama3_start_mask's rules with every lane deciding its own 12 bytes (three dwords, one flag per byte in bit 7) instead of
+// nine lanes holding a 64-byte word each: the rule algebra is the same, but all 64 lanes do useful work and nothing is
+// gathered by ballots.  What a rule needs from the bytes around the lane's own comes from the two neighbouring lanes' dwords
+// (DPP moves): index 0..1 = the two dwords before, 2..4 = own, 5..6 = the two after.  Non-ASCII characters are classified by
+// a per-lane loop over the lane's lead bytes (table look-up per character, as in the ballot form).  The three ripples
+// become bounded look-arounds, and the window goes to the ballot form (return false, wave-uniform) when a bound is hit: a
+// digit run of nine or more, five line breaks in a row, a line break followed by four or more further white-space bytes;
+// and, as there, a non-ASCII digit or U+017F sends it to the literal matcher (fallback).
+template <int K>
+__device__ __forceinline__ uint32_t l3_bk(const uint32_t (&f)[7], int a) {  // flag of the byte K places before (K in 1..8)
+    constexpr int q = K / 4, r = K % 4;
+    if constexpr (r == 0) return f[a - q];
+    else return (f[a - q] << (8 * r)) | (f[a - q - 1] >> (32 - 8 * r));
+}
+template <int K>
+__device__ __forceinline__ uint32_t l3_ak(const uint32_t (&f)[7], int a) {  // flag of the byte K places after (K in 1..8)
+    constexpr int q = K / 4, r = K % 4;
+    if constexpr (r == 0) return f[a + q];
+    else return (f[a + q] >> (8 * r)) | (f[a + q + 1] << (32 - 8 * r));
+}
+__device__ __forceinline__ void l3_halo(uint32_t (&f)[7]) {  // own dwords [2..4] are set: fetch the neighbours'
+    f[0] = lane_prev(f[3]);
+    f[1] = lane_prev(f[4]);
+    f[5] = lane_next(f[2]);
+    f[6] = lane_next(f[3]);
+}
+// Ranks the piece starts of window bytes [lo, hi2) into ws.pstart (relative to lo; lo itself forced), hi2 = min(hi, und).
+// false: the window is for llama3_start_mask (nothing written); `fallback`: for the literal matcher.
+__device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const SplitDev& sp, int skew, int wlen, int lo, int hi, bool at_end,
+                                                     int& np, int& undecided, bool& fallback) {
+    constexpr int LB = 3, LBy = 12;
+    const int l = lane_id();
+    const int off = kTextPad + skew + LBy * l;
+    const int a0 = off >> 2, sh = (off & 3) * 8;
+    int nv = wlen - LBy * l;
+    nv = nv < 0 ? 0 : (nv > LBy ? LBy : nv);
+    uint32_t r[LB + 1], x[7], V[7], L[7], N[7], W[7], NL[7], SP[7], CT[7], AP[7];
+    x[0] = x[1] = x[5] = x[6] = 0;
+    AP[0] = AP[1] = AP[5] = AP[6] = 0;
+#pragma unroll
+    for (int j = 0; j <= LB; ++j) r[j] = ws.text_w[a0 + j];
+    uint32_t leads = 0;  // bit k: own byte k is a lead byte (>= 0xC0)
+    bool odd = false;
+#pragma unroll
+    for (int j = 0; j < LB; ++j) {
+        const int have = nv - 4 * j;
+        const uint32_t m = have >= 4 ? ~0u : (have <= 0 ? 0u : ((1u << (8 * have)) - 1u));
+        const uint32_t xx = uint32_t(((static_cast<unsigned long long>(r[j + 1]) << 32) | r[j]) >> sh) & m;
+        const int a = j + 2;
+        x[a] = xx;
+        V[a] = m & kB7;
+        const uint32_t hi7 = xx & kB7, lo7 = xx & 0x7F7F7F7Fu;  // the packed compares want bytes below 0x80
+        const uint32_t asc = ~hi7 & V[a];
+        L[a] = swar_range(lo7 | 0x20202020u, 'a', 'z') & asc;
+        N[a] = swar_range(lo7, '0', '9') & asc;
+        SP[a] = swar_eq(lo7, 0x20) & asc;
+        NL[a] = (swar_eq(lo7, '\n') | swar_eq(lo7, '\r')) & asc;
+        W[a] = (SP[a] | swar_range(lo7, 9, 13)) & asc;
+        AP[a] = swar_eq(lo7, 0x27) & asc;
+        CT[a] = hi7 & ~((xx << 1) & kB7);                     // 10xxxxxx
+        const uint32_t ld = hi7 & ((xx << 1) & kB7);           // 11xxxxxx
+        const uint32_t t = ld >> 7;
+        leads |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * j);
+    }
+    // non-ASCII characters: class of each lead byte of the lane
+    for (uint32_t rest = leads; rest; rest &= rest - 1) {
+        const int k = __ffs(rest) - 1;
+        const int i = LBy * l + k;
+        const uint32_t b = (x[2 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu;
+        const uint32_t cp = decode_lead(ws, skew, i, b, wlen);
+        const uint32_t cls = uc_nibble(sp, cp) & 3u;
+        if (cls == kClsN || cp == 0x17Fu) odd = true;
+        const uint32_t bit = 0x80u << (8 * (k & 3));
+        if (cls == kClsL) L[2 + (k >> 2)] |= bit;
+        if (cls == kClsS) W[2 + (k >> 2)] |= bit;
+    }
+    fallback = __ballot(odd) != 0;
+    if (fallback) return true;  // (the caller looks at fallback first)
+    const bool any_ct = __ballot((CT[2] | CT[3] | CT[4]) != 0) != 0;
+    // digit groups count from the chunk start: the digit in front of it is not part of the run
+    uint32_t Nd[7];
+#pragma unroll
+    for (int a = 2; a <= 4; ++a) Nd[a] = N[a];
+    if (lo > 0 && (lo - 1) / LBy == l) Nd[2 + ((lo - 1) % LBy >> 2)] &= ~(0x80u << (8 * ((lo - 1) & 3)));
+    l3_halo(V); l3_halo(L); l3_halo(N); l3_halo(Nd); l3_halo(W); l3_halo(NL); l3_halo(SP); l3_halo(CT);
+    if (any_ct) {  // continuation bytes take the class of their lead byte (up to three of them behind it)
+        uint32_t l2[7], w2[7];
+#pragma unroll
+        for (int a = 0; a < 7; ++a) { l2[a] = L[a]; w2[a] = W[a]; }
+#pragma unroll
+        for (int a = 2; a <= 4; ++a) {
+            const uint32_t c1 = CT[a], c2 = c1 & l3_bk<1>(CT, a), c3 = c2 & l3_bk<2>(CT, a);
+            l2[a] |= (c1 & l3_bk<1>(L, a)) | (c2 & l3_bk<2>(L, a)) | (c3 & l3_bk<3>(L, a));
+            w2[a] |= (c1 & l3_bk<1>(W, a)) | (c2 & l3_bk<2>(W, a)) | (c3 & l3_bk<3>(W, a));
+        }
+#pragma unroll
+        for (int a = 2; a <= 4; ++a) { L[a] = l2[a]; W[a] = w2[a]; }
+        l3_halo(L);
+        l3_halo(W);
+    }
+    uint32_t O[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) O[a] = V[a] & ~(L[a] | N[a] | W[a]);
+    // ---- bounded forms of the ripples
+    uint32_t G[7] = {0, 0, 0, 0, 0, 0, 0};        // digit group starts
+    uint32_t FE[7] = {0, 0, 0, 0, 0, 0, 0};       // last byte of a line-break run that began right behind an O char
+    uint32_t LN[7] = {0, 0, 0, 0, 0, 0, 0};       // the last line break of its white-space run
+    bool far = false;
+    const bool any_n = __ballot((Nd[2] | Nd[3] | Nd[4]) != 0) != 0, any_nl = __ballot((NL[2] | NL[3] | NL[4]) != 0) != 0;
+    if (any_n) {
+#pragma unroll
+        for (int a = 2; a <= 4; ++a) {
+            const uint32_t n1 = l3_bk<1>(Nd, a), n2 = l3_bk<2>(Nd, a), n3 = l3_bk<3>(Nd, a), n4 = l3_bk<4>(Nd, a), n5 = l3_bk<5>(Nd, a),
+                           n6 = l3_bk<6>(Nd, a), n7 = l3_bk<7>(Nd, a), n8 = l3_bk<8>(Nd, a);
+            const uint32_t r2 = Nd[a] & n1 & n2, r5 = r2 & n3 & n4 & n5;  // a digit here and at the 2 / 5 bytes before
+            const uint32_t s0 = Nd[a] & ~n1;                              // run start here
+            const uint32_t s3 = r2 & n3 & ~n4, s6 = r5 & n6 & ~n7;        // run start 3 / 6 bytes back
+            G[a] = s0 | s3 | s6;
+            if (r5 & n6 & n7 & n8) far = true;                            // nine digits in a row
+        }
+    }
+    if (any_nl) {
+#pragma unroll
+        for (int a = 2; a <= 4; ++a) {
+            const uint32_t e = NL[a] & ~l3_ak<1>(NL, a);                  // last byte of a line-break run
+            const uint32_t b1 = l3_bk<1>(NL, a), b2 = l3_bk<2>(NL, a), b3 = l3_bk<3>(NL, a), b4 = l3_bk<4>(NL, a);
+            const uint32_t o1 = l3_bk<1>(O, a), o2 = l3_bk<2>(O, a), o3 = l3_bk<3>(O, a), o4 = l3_bk<4>(O, a);
+            FE[a] = e & ((~b1 & o1) | (b1 & ~b2 & o2) | (b1 & b2 & ~b3 & o3) | (b1 & b2 & b3 & ~b4 & o4));
+            if (e & b1 & b2 & b3 & b4) far = true;                        // five line breaks in a row
+            // a later line break in the same white-space run, within four bytes
+            const uint32_t w1 = l3_ak<1>(W, a), w2 = w1 & l3_ak<2>(W, a), w3 = w2 & l3_ak<3>(W, a), w4 = w3 & l3_ak<4>(W, a);
+            const uint32_t later = (w1 & l3_ak<1>(NL, a)) | (w2 & l3_ak<2>(NL, a)) | (w3 & l3_ak<3>(NL, a)) | (w4 & l3_ak<4>(NL, a));
+            LN[a] = NL[a] & ~later;
+            if (NL[a] & w4 & ~later) far = true;                          // the run goes on: cannot tell from here
+        }
+    }
+    if (__ballot(far)) return false;
+    l3_halo(FE);
+    l3_halo(LN);
+    // ---- local rules (llama3_start_mask's)
+    uint32_t sO[7], f1[7], f2[7], TK[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) sO[a] = f1[a] = f2[a] = TK[a] = 0;
+    const bool any_ap = __ballot((AP[2] | AP[3] | AP[4]) != 0) != 0;
+    x[5] = any_ap ? lane_next(x[2]) : 0u;
+#pragma unroll
+    for (int a = 2; a <= 4; ++a) {
+        const uint32_t pO = l3_bk<1>(O, a), pSP = l3_bk<1>(SP, a);
+        sO[a] = O[a] & ~pO;
+        if (any_ap && AP[a]) {
+            // the two bytes behind the apostrophe (raw bytes of this dword and the next one; a non-ASCII byte matches no letter)
+            const uint32_t nxt = x[a + 1];
+            const uint32_t n1 = ((x[a] >> 8) | (nxt << 24)), n2 = ((x[a] >> 16) | (nxt << 16));
+            const uint32_t m1 = ~n1 & kB7, m2 = ~n2 & kB7;  // ASCII bytes only
+            const uint32_t l1 = (n1 & 0x7F7F7F7Fu) | 0x20202020u, l2 = (n2 & 0x7F7F7F7Fu) | 0x20202020u;
+            const uint32_t c1 = AP[a] & m1 & (swar_range(l1, 's', 't') | swar_eq(l1, 'm') | swar_eq(l1, 'd'));
+            const uint32_t c2 = AP[a] & m1 & m2 & (((swar_eq(l1, 'r') | swar_eq(l1, 'v')) & swar_eq(l2, 'e')) | (swar_eq(l1, 'l') & swar_eq(l2, 'l')));
+            f1[a] = c1 & sO[a] & ~pSP;
+            f2[a] = c2 & sO[a] & ~pSP & ~f1[a];
+        }
+    }
+    if (any_ap) {
+        l3_halo(f1);
+        l3_halo(f2);
+    }
+    // O runs of one char that go in front of the letters behind them
+#pragma unroll
+    for (int a = 2; a <= 4; ++a) {
+        const uint32_t endO = O[a] & ~l3_ak<1>(O, a);
+        const uint32_t eo1 = l3_ak<1>(O, a) & ~l3_ak<2>(O, a), eo2 = l3_ak<2>(O, a) & ~l3_ak<3>(O, a), eo3 = l3_ak<3>(O, a) & ~l3_ak<4>(O, a);
+        const uint32_t c1 = l3_ak<1>(CT, a), c2 = c1 & l3_ak<2>(CT, a), c3 = c2 & l3_ak<3>(CT, a);
+        const uint32_t lead_of_last = ~CT[a] & (endO | (c1 & eo1) | (c2 & eo2) | (c3 & eo3));   // to_lead(endO)
+        const uint32_t single_o = sO[a] & lead_of_last;
+        TK[a] = single_o & ~l3_bk<1>(SP, a) & ~(f1[a] | f2[a]);
+    }
+    l3_halo(TK);
+    if (any_ct) {  // spread over the char's continuation bytes
+        uint32_t t2[7];
+#pragma unroll
+        for (int a = 2; a <= 4; ++a) {
+            const uint32_t c1 = CT[a], c2 = c1 & l3_bk<1>(CT, a), c3 = c2 & l3_bk<2>(CT, a);
+            t2[a] = TK[a] | (c1 & l3_bk<1>(TK, a)) | (c2 & l3_bk<2>(TK, a)) | (c3 & l3_bk<3>(TK, a));
+        }
+#pragma unroll
+        for (int a = 2; a <= 4; ++a) TK[a] = t2[a];
+        TK[1] = lane_prev(TK[4]);
+    }
+    uint32_t flags = 0;
+    uint32_t nonw = 0;
+#pragma unroll
+    for (int a = 2; a <= 4; ++a) {
+        const uint32_t pL = l3_bk<1>(L, a), pW = l3_bk<1>(W, a), pO = l3_bk<1>(O, a), pSP = l3_bk<1>(SP, a), pNL = l3_bk<1>(NL, a);
+        const uint32_t sL = L[a] & ~pL, sW = W[a] & ~pW;
+        const uint32_t f12[2] = {f1[a - 1] | f2[a - 1], f1[a] | f2[a]};
+        const uint32_t supL = sL & ((pW & ~pNL) | ((TK[a] << 8) | (TK[a - 1] >> 24)) | ((f12[1] << 8) | (f12[0] >> 24)));
+        const uint32_t supO = sO[a] & pSP;
+        const uint32_t supW = sW & pO & NL[a];
+        const uint32_t b_abs = l3_bk<1>(FE, a) & W[a];
+        const uint32_t b_ln = l3_bk<1>(LN, a) & W[a];
+        // last char of a white-space run that is followed by a char
+        const uint32_t aV1 = l3_ak<1>(V, a), aV2 = l3_ak<2>(V, a), aV3 = l3_ak<3>(V, a), aV4 = l3_ak<4>(V, a);
+        const uint32_t ew0 = W[a] & ~l3_ak<1>(W, a) & aV1, ew1 = l3_ak<1>(W, a) & ~l3_ak<2>(W, a) & aV2,
+                       ew2 = l3_ak<2>(W, a) & ~l3_ak<3>(W, a) & aV3, ew3 = l3_ak<3>(W, a) & ~l3_ak<4>(W, a) & aV4;
+        const uint32_t c1 = l3_ak<1>(CT, a), c2 = c1 & l3_ak<2>(CT, a), c3 = c2 & l3_ak<3>(CT, a);
+        const uint32_t last_w = ~CT[a] & (ew0 | (c1 & ew1) | (c2 & ew2) | (c3 & ew3));
+        const uint32_t b_last = last_w & W[a] & ~NL[a] & pW & ~pNL;
+        const uint32_t b_con = ((f1[a] << 16) | (f1[a - 1] >> 16)) | ((f2[a] << 24) | (f2[a - 1] >> 8));
+        const uint32_t st = ((sL & ~supL) | G[a] | (sO[a] & ~supO) | (sW & ~supW) | b_abs | b_ln | b_last | b_con) & V[a] & ~CT[a];
+        const uint32_t t = st >> 7;
+        flags |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * (a - 2));
+        const uint32_t u = (V[a] & ~W[a]) >> 7;
+        nonw |= ((u | (u >> 7) | (u >> 14) | (u >> 21)) & 0xFu) << (4 * (a - 2));
+    }
+    // ---- how far the window decides (llama3_start_mask's rule)
+    undecided = 0x7FFFFFFF;
+    if (!at_end) {
+        undecided = wlen > 8 ? wlen - 8 : 0;
+        const unsigned long long nwl = __ballot(nonw != 0);
+        int nonw_end = 0;  // window position behind the last byte that is not white space
+        if (nwl) {
+            const int hl = 63 - __clzll(nwl);
+            nonw_end = hl * LBy + (32 - __clz(wave_readlane(int(nonw), hl)));
+        }
+        if (nonw_end < wlen && nonw_end + 1 < undecided) undecided = nonw_end + 1;
+    }
+    const int hi2 = hi < undecided ? hi : undecided;
+    np = 0;
+    if (hi2 <= lo) return true;
+    int k_lo = lo - LBy * l, k_hi = hi2 - LBy * l;
+    k_lo = k_lo < 0 ? 0 : (k_lo > LBy ? LBy : k_lo);
+    k_hi = k_hi < 0 ? 0 : (k_hi > LBy ? LBy : k_hi);
+    uint32_t fl = flags & ((1u << k_hi) - 1u) & ~((1u << k_lo) - 1u);
+    if (lo / LBy == l) fl |= 1u << (lo % LBy);
+    const int cnt = __popc(fl);
+    const int incl = wave_incl_sum(cnt);
+    int at = incl - cnt;
+    const int first = LBy * l - lo;
+    while (fl) {
+        ws.pstart[at++] = uint16_t(first + __ffs(fl) - 1);
+        fl &= fl - 1;
+    }
+    np = wave_readlane(incl, kWave - 1);
+    return true;
+}
+
 // The class patterns (kSplitWhitespace / kSplitBertPunct / kSplitBertWords) on an ASCII window, packed bytes, LB dwords
 // per lane: same result as class_start_mask + the ranking loop of scan_string -- pstart entries of window bytes
 // [lo, hi) relative to lo, kPieceDropped on the pieces that are not emitted.  false (wave-uniform): not ASCII.
@@ -816,17 +1062,50 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
         if constexpr (LLAMA3) {
             int und = 0;
             bool seq = false;
-            const Mask start = llama3_start_mask(ws, sp, skew, w1 - w0, lo, w1 == slen, und, seq);
+            // every lane its own 12 bytes (packed bytes); the windows that form does not cover: lane w = 64-byte word w (ballots)
+            const bool packed = llama3_packed_starts(ws, sp, skew, w1 - w0, lo, hi, w1 == slen, np, und, seq);
+#ifdef OVTK_SIMT_EMULATOR
+            if (l == 0 && getenv("OVTK_L3_STATS")) fprintf(stderr, "L3 %s\n", !packed ? "ballot" : (seq ? "literal" : "packed"));
+            if (packed && !seq) {  // the emulator build checks the packed form against the ballot form on every window
+                int und0 = 0;
+                bool seq0 = false;
+                const Mask start0 = llama3_start_mask(ws, sp, skew, w1 - w0, lo, w1 == slen, und0, seq0);
+                const int h0 = hi < und0 ? hi : und0;
+                int np0 = 0;
+                bool same = !seq0 && und0 == und;
+                if (same && h0 > lo) {
+                    for (int w = lo >> 6; w * 64 < h0; ++w) {
+                        Mask m = wave_readlane(start0, w);
+                        if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
+                        if (h0 - w * 64 < 64) m &= (1ull << (h0 - w * 64)) - 1ull;
+                        if (((m >> l) & 1ull) && ws.pstart[np0 + __popcll(m & lanemask_lt())] != uint16_t(w * 64 + l - lo)) same = false;
+                        np0 += __popcll(m);
+                    }
+                    if (np0 != np) same = false;
+                }
+                if (__ballot(!same)) {
+                    if (l == 0) printf("llama3 packed starts differ: wlen %d lo %d hi %d und %d/%d np %d/%d seq0 %d\n", w1 - w0, lo, hi, und, und0, np, np0, int(seq0));
+                    __builtin_trap();
+                }
+            }
+#endif
+            if (!packed) {
+                np = 0;
+                const Mask start = llama3_start_mask(ws, sp, skew, w1 - w0, lo, w1 == slen, und, seq);
+                const int h2 = hi < und ? hi : und;
+                if (!seq && h2 > lo) {
+                    for (int w = lo >> 6; w * 64 < h2; ++w) {
+                        Mask m = wave_readlane(start, w);
+                        if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
+                        if (h2 - w * 64 < 64) m &= (1ull << (h2 - w * 64)) - 1ull;
+                        if ((m >> l) & 1ull) ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t(w * 64 + l - lo);
+                        np += __popcll(m);
+                    }
+                }
+            }
             const int hi2 = hi < und ? hi : und;
             const bool whole = qlim == slen && hi2 == hi;  // every piece that starts in the window also ends in it
             if (!seq && hi2 > lo) {
-                for (int w = lo >> 6; w * 64 < hi2; ++w) {
-                    Mask m = wave_readlane(start, w);
-                    if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
-                    if (hi2 - w * 64 < 64) m &= (1ull << (hi2 - w * 64)) - 1ull;
-                    if ((m >> l) & 1ull) ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t(w * 64 + l - lo);
-                    np += __popcll(m);
-                }
                 wave_sync();
                 if (whole) {
                     if (l == 0) ws.pstart[np] = uint16_t(slen - c0);
