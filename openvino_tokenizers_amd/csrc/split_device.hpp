@@ -716,37 +716,39 @@ __device__ __forceinline__ bool gpt2_packed_starts(WaveScratch& ws, int skew, in
 // become bounded look-arounds, and the window goes to the ballot form (return false, wave-uniform) when a bound is hit: a
 // digit run of nine or more, five line breaks in a row, a line break followed by four or more further white-space bytes;
 // and, as there, a non-ASCII digit or U+017F sends it to the literal matcher (fallback).
-template <int K>
-__device__ __forceinline__ uint32_t l3_bk(const uint32_t (&f)[7], int a) {  // flag of the byte K places before (K in 1..8)
+template <int K, int M>
+__device__ __forceinline__ uint32_t l3_bk(const uint32_t (&f)[M], int a) {  // flag of the byte K places before (K in 1..8)
     constexpr int q = K / 4, r = K % 4;
     if constexpr (r == 0) return f[a - q];
     else return (f[a - q] << (8 * r)) | (f[a - q - 1] >> (32 - 8 * r));
 }
-template <int K>
-__device__ __forceinline__ uint32_t l3_ak(const uint32_t (&f)[7], int a) {  // flag of the byte K places after (K in 1..8)
+template <int K, int M>
+__device__ __forceinline__ uint32_t l3_ak(const uint32_t (&f)[M], int a) {  // flag of the byte K places after (K in 1..8)
     constexpr int q = K / 4, r = K % 4;
     if constexpr (r == 0) return f[a + q];
     else return (f[a + q] >> (8 * r)) | (f[a + q + 1] << (32 - 8 * r));
 }
-__device__ __forceinline__ void l3_halo(uint32_t (&f)[7]) {  // own dwords [2..4] are set: fetch the neighbours'
-    f[0] = lane_prev(f[3]);
-    f[1] = lane_prev(f[4]);
-    f[5] = lane_next(f[2]);
-    f[6] = lane_next(f[3]);
+template <int M>
+__device__ __forceinline__ void l3_halo(uint32_t (&f)[M]) {  // own dwords [2 .. M-3] are set: fetch the neighbours'
+    f[0] = lane_prev(f[M - 4]);
+    f[1] = lane_prev(f[M - 3]);
+    f[M - 2] = lane_next(f[2]);
+    f[M - 1] = lane_next(f[3]);
 }
 // Ranks the piece starts of window bytes [lo, hi2) into ws.pstart (relative to lo; lo itself forced), hi2 = min(hi, und).
 // false: the window is for llama3_start_mask (nothing written); `fallback`: for the literal matcher.
+template <int LB>
 __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const SplitDev& sp, int skew, int wlen, int lo, int hi, bool at_end,
                                                      int& np, int& undecided, bool& fallback) {
-    constexpr int LB = 3, LBy = 12;
+    constexpr int LBy = 4 * LB, M = LB + 4, AL = LB + 1;  // own dwords at [2 .. AL]
     const int l = lane_id();
     const int off = kTextPad + skew + LBy * l;
     const int a0 = off >> 2, sh = (off & 3) * 8;
     int nv = wlen - LBy * l;
     nv = nv < 0 ? 0 : (nv > LBy ? LBy : nv);
-    uint32_t r[LB + 1], x[7], V[7], L[7], N[7], W[7], NL[7], SP[7], CT[7], AP[7];
-    x[0] = x[1] = x[5] = x[6] = 0;
-    AP[0] = AP[1] = AP[5] = AP[6] = 0;
+    uint32_t r[LB + 1], x[M], V[M], L[M], N[M], W[M], NL[M], SP[M], CT[M], AP[M];
+    x[0] = x[1] = x[M - 2] = x[M - 1] = 0;
+    AP[0] = AP[1] = AP[M - 2] = AP[M - 1] = 0;
 #pragma unroll
     for (int j = 0; j <= LB; ++j) r[j] = ws.text_w[a0 + j];
     uint32_t leads = 0;  // bit k: own byte k is a lead byte (>= 0xC0)
@@ -772,6 +774,9 @@ __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const Spli
         const uint32_t t = ld >> 7;
         leads |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * j);
     }
+    uint32_t ct_any = 0, nl_any = 0, ap_any = 0;
+#pragma unroll
+    for (int a = 2; a <= AL; ++a) { ct_any |= CT[a]; nl_any |= NL[a]; ap_any |= AP[a]; }
     // non-ASCII characters: class of each lead byte of the lane
     for (uint32_t rest = leads; rest; rest &= rest - 1) {
         const int k = __ffs(rest) - 1;
@@ -786,40 +791,44 @@ __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const Spli
     }
     fallback = __ballot(odd) != 0;
     if (fallback) return true;  // (the caller looks at fallback first)
-    const bool any_ct = __ballot((CT[2] | CT[3] | CT[4]) != 0) != 0;
+    const bool any_ct = __ballot(ct_any != 0) != 0;
     // digit groups count from the chunk start: the digit in front of it is not part of the run
-    uint32_t Nd[7];
+    uint32_t Nd[M];
 #pragma unroll
-    for (int a = 2; a <= 4; ++a) Nd[a] = N[a];
+    for (int a = 2; a <= AL; ++a) Nd[a] = N[a];
     if (lo > 0 && (lo - 1) / LBy == l) Nd[2 + ((lo - 1) % LBy >> 2)] &= ~(0x80u << (8 * ((lo - 1) & 3)));
+    uint32_t nd_any = 0;
+#pragma unroll
+    for (int a = 2; a <= AL; ++a) nd_any |= Nd[a];
     l3_halo(V); l3_halo(L); l3_halo(N); l3_halo(Nd); l3_halo(W); l3_halo(NL); l3_halo(SP); l3_halo(CT);
     if (any_ct) {  // continuation bytes take the class of their lead byte (up to three of them behind it)
-        uint32_t l2[7], w2[7];
+        uint32_t l2[M], w2[M];
 #pragma unroll
-        for (int a = 0; a < 7; ++a) { l2[a] = L[a]; w2[a] = W[a]; }
+        for (int a = 0; a < M; ++a) { l2[a] = L[a]; w2[a] = W[a]; }
 #pragma unroll
-        for (int a = 2; a <= 4; ++a) {
+        for (int a = 2; a <= AL; ++a) {
             const uint32_t c1 = CT[a], c2 = c1 & l3_bk<1>(CT, a), c3 = c2 & l3_bk<2>(CT, a);
             l2[a] |= (c1 & l3_bk<1>(L, a)) | (c2 & l3_bk<2>(L, a)) | (c3 & l3_bk<3>(L, a));
             w2[a] |= (c1 & l3_bk<1>(W, a)) | (c2 & l3_bk<2>(W, a)) | (c3 & l3_bk<3>(W, a));
         }
 #pragma unroll
-        for (int a = 2; a <= 4; ++a) { L[a] = l2[a]; W[a] = w2[a]; }
+        for (int a = 2; a <= AL; ++a) { L[a] = l2[a]; W[a] = w2[a]; }
         l3_halo(L);
         l3_halo(W);
     }
-    uint32_t O[7];
+    uint32_t O[M];
 #pragma unroll
-    for (int a = 0; a < 7; ++a) O[a] = V[a] & ~(L[a] | N[a] | W[a]);
+    for (int a = 0; a < M; ++a) O[a] = V[a] & ~(L[a] | N[a] | W[a]);
     // ---- bounded forms of the ripples
-    uint32_t G[7] = {0, 0, 0, 0, 0, 0, 0};        // digit group starts
-    uint32_t FE[7] = {0, 0, 0, 0, 0, 0, 0};       // last byte of a line-break run that began right behind an O char
-    uint32_t LN[7] = {0, 0, 0, 0, 0, 0, 0};       // the last line break of its white-space run
+    uint32_t G[M], FE[M], LN[M];  // digit group starts; last byte of a line-break run that began right behind an O char;
+                                  // the last line break of its white-space run
+#pragma unroll
+    for (int a = 0; a < M; ++a) G[a] = FE[a] = LN[a] = 0;
     bool far = false;
-    const bool any_n = __ballot((Nd[2] | Nd[3] | Nd[4]) != 0) != 0, any_nl = __ballot((NL[2] | NL[3] | NL[4]) != 0) != 0;
+    const bool any_n = __ballot(nd_any != 0) != 0, any_nl = __ballot(nl_any != 0) != 0;
     if (any_n) {
 #pragma unroll
-        for (int a = 2; a <= 4; ++a) {
+        for (int a = 2; a <= AL; ++a) {
             const uint32_t n1 = l3_bk<1>(Nd, a), n2 = l3_bk<2>(Nd, a), n3 = l3_bk<3>(Nd, a), n4 = l3_bk<4>(Nd, a), n5 = l3_bk<5>(Nd, a),
                            n6 = l3_bk<6>(Nd, a), n7 = l3_bk<7>(Nd, a), n8 = l3_bk<8>(Nd, a);
             const uint32_t r2 = Nd[a] & n1 & n2, r5 = r2 & n3 & n4 & n5;  // a digit here and at the 2 / 5 bytes before
@@ -831,7 +840,7 @@ __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const Spli
     }
     if (any_nl) {
 #pragma unroll
-        for (int a = 2; a <= 4; ++a) {
+        for (int a = 2; a <= AL; ++a) {
             const uint32_t e = NL[a] & ~l3_ak<1>(NL, a);                  // last byte of a line-break run
             const uint32_t b1 = l3_bk<1>(NL, a), b2 = l3_bk<2>(NL, a), b3 = l3_bk<3>(NL, a), b4 = l3_bk<4>(NL, a);
             const uint32_t o1 = l3_bk<1>(O, a), o2 = l3_bk<2>(O, a), o3 = l3_bk<3>(O, a), o4 = l3_bk<4>(O, a);
@@ -848,13 +857,13 @@ __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const Spli
     l3_halo(FE);
     l3_halo(LN);
     // ---- local rules (llama3_start_mask's)
-    uint32_t sO[7], f1[7], f2[7], TK[7];
+    uint32_t sO[M], f1[M], f2[M], TK[M];
 #pragma unroll
-    for (int a = 0; a < 7; ++a) sO[a] = f1[a] = f2[a] = TK[a] = 0;
-    const bool any_ap = __ballot((AP[2] | AP[3] | AP[4]) != 0) != 0;
-    x[5] = any_ap ? lane_next(x[2]) : 0u;
+    for (int a = 0; a < M; ++a) sO[a] = f1[a] = f2[a] = TK[a] = 0;
+    const bool any_ap = __ballot(ap_any != 0) != 0;
+    x[M - 2] = any_ap ? lane_next(x[2]) : 0u;
 #pragma unroll
-    for (int a = 2; a <= 4; ++a) {
+    for (int a = 2; a <= AL; ++a) {
         const uint32_t pO = l3_bk<1>(O, a), pSP = l3_bk<1>(SP, a);
         sO[a] = O[a] & ~pO;
         if (any_ap && AP[a]) {
@@ -875,7 +884,7 @@ __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const Spli
     }
     // O runs of one char that go in front of the letters behind them
 #pragma unroll
-    for (int a = 2; a <= 4; ++a) {
+    for (int a = 2; a <= AL; ++a) {
         const uint32_t endO = O[a] & ~l3_ak<1>(O, a);
         const uint32_t eo1 = l3_ak<1>(O, a) & ~l3_ak<2>(O, a), eo2 = l3_ak<2>(O, a) & ~l3_ak<3>(O, a), eo3 = l3_ak<3>(O, a) & ~l3_ak<4>(O, a);
         const uint32_t c1 = l3_ak<1>(CT, a), c2 = c1 & l3_ak<2>(CT, a), c3 = c2 & l3_ak<3>(CT, a);
@@ -885,20 +894,20 @@ __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const Spli
     }
     l3_halo(TK);
     if (any_ct) {  // spread over the char's continuation bytes
-        uint32_t t2[7];
+        uint32_t t2[M];
 #pragma unroll
-        for (int a = 2; a <= 4; ++a) {
+        for (int a = 2; a <= AL; ++a) {
             const uint32_t c1 = CT[a], c2 = c1 & l3_bk<1>(CT, a), c3 = c2 & l3_bk<2>(CT, a);
             t2[a] = TK[a] | (c1 & l3_bk<1>(TK, a)) | (c2 & l3_bk<2>(TK, a)) | (c3 & l3_bk<3>(TK, a));
         }
 #pragma unroll
-        for (int a = 2; a <= 4; ++a) TK[a] = t2[a];
-        TK[1] = lane_prev(TK[4]);
+        for (int a = 2; a <= AL; ++a) TK[a] = t2[a];
+        TK[1] = lane_prev(TK[AL]);
     }
     uint32_t flags = 0;
     uint32_t nonw = 0;
 #pragma unroll
-    for (int a = 2; a <= 4; ++a) {
+    for (int a = 2; a <= AL; ++a) {
         const uint32_t pL = l3_bk<1>(L, a), pW = l3_bk<1>(W, a), pO = l3_bk<1>(O, a), pSP = l3_bk<1>(SP, a), pNL = l3_bk<1>(NL, a);
         const uint32_t sL = L[a] & ~pL, sW = W[a] & ~pW;
         const uint32_t f12[2] = {f1[a - 1] | f2[a - 1], f1[a] | f2[a]};
@@ -1063,9 +1072,9 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
             int und = 0;
             bool seq = false;
             // every lane its own 12 bytes (packed bytes); the windows that form does not cover: lane w = 64-byte word w (ballots)
-            const bool packed = llama3_packed_starts(ws, sp, skew, w1 - w0, lo, hi, w1 == slen, np, und, seq);
+            const bool packed = w1 - w0 <= 512 ? llama3_packed_starts<2>(ws, sp, skew, w1 - w0, lo, hi, w1 == slen, np, und, seq)
+                                               : llama3_packed_starts<3>(ws, sp, skew, w1 - w0, lo, hi, w1 == slen, np, und, seq);
 #ifdef OVTK_SIMT_EMULATOR
-            if (l == 0 && getenv("OVTK_L3_STATS")) fprintf(stderr, "L3 %s\n", !packed ? "ballot" : (seq ? "literal" : "packed"));
             if (packed && !seq) {  // the emulator build checks the packed form against the ballot form on every window
                 int und0 = 0;
                 bool seq0 = false;

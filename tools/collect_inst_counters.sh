@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 echo "config,kernel,counter,mean_per_launch,launches" > "$OUT/inst_counters.csv"
-for cfg in 2 3 4; do
+for cfg in ${CONFIGS:-2 3 4}; do
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
              "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU"; do
     rm -rf "$OUT/pmc_inst"
