@@ -777,17 +777,35 @@ __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const Spli
     uint32_t ct_any = 0, nl_any = 0, ap_any = 0;
 #pragma unroll
     for (int a = 2; a <= AL; ++a) { ct_any |= CT[a]; nl_any |= NL[a]; ap_any |= AP[a]; }
-    // non-ASCII characters: class of each lead byte of the lane
-    for (uint32_t rest = leads; rest; rest &= rest - 1) {
-        const int k = __ffs(rest) - 1;
-        const int i = LBy * l + k;
-        const uint32_t b = (x[2 + (k >> 2)] >> (8 * (k & 3))) & 0xFFu;
-        const uint32_t cp = decode_lead(ws, skew, i, b, wlen);
-        const uint32_t cls = uc_nibble(sp, cp) & 3u;
-        if (cls == kClsN || cp == 0x17Fu) odd = true;
-        const uint32_t bit = 0x80u << (8 * (k & 3));
-        if (cls == kClsL) L[2 + (k >> 2)] |= bit;
-        if (cls == kClsS) W[2 + (k >> 2)] |= bit;
+    // non-ASCII characters: class of each lead byte of the lane.  Up to six at a time (twelve bytes of two-byte characters)
+    // with the table loads of all of them in flight together: one lead after the other, every character was two dependent
+    // round trips, and a window of Greek or Cyrillic text waited for twelve of them.
+    for (uint32_t rest = leads; __ballot(rest != 0);) {
+        int kk[6];
+        uint32_t cps[6], i1[6], nb[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            kk[j] = rest ? __ffs(rest) - 1 : -1;
+            rest &= rest - 1;   // (0 stays 0)
+            cps[j] = 0x110000u;
+            if (kk[j] >= 0) {
+                const uint32_t b = (x[2 + (kk[j] >> 2)] >> (8 * (kk[j] & 3))) & 0xFFu;
+                cps[j] = decode_lead(ws, skew, LBy * l + kk[j], b, wlen);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) i1[j] = cps[j] < 0x110000u ? uint32_t(sp.uc_index[cps[j] >> 7]) : 0u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) nb[j] = cps[j] < 0x110000u ? uint32_t(sp.uc_blocks[i1[j] * 64 + ((cps[j] & 127) >> 1)]) : 0u;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (kk[j] < 0) continue;
+            const uint32_t cls = ((cps[j] & 1) ? (nb[j] >> 4) : (nb[j] & 15u)) & 3u;
+            if (cls == kClsN || cps[j] == 0x17Fu) odd = true;
+            const uint32_t bit = 0x80u << (8 * (kk[j] & 3));
+            if (cls == kClsL) L[2 + (kk[j] >> 2)] |= bit;
+            if (cls == kClsS) W[2 + (kk[j] >> 2)] |= bit;
+        }
     }
     fallback = __ballot(odd) != 0;
     if (fallback) return true;  // (the caller looks at fallback first)
