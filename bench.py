@@ -900,7 +900,7 @@ def main():
     if world == 1 and not args.no_extras and args.config == "2" and args.text == "zipf" and not args.no_memo:
         stress = {}
         for name, kw in (("uniform_text", dict(kind="uniform")), ("no_memo", dict(kind="zipf", no_memo=True)),
-                         ("fixed_memo_only", dict(kind="zipf", cache_capacity=1))):
+                         ("fixed_memo_only", dict(kind="zipf", cache_capacity=1)), ("mixed_script_text", dict(kind="mixed"))):
             s_args = argparse.Namespace(**vars(args))
             w2 = BpeEncode(s_args, lib, dev, rank, args.tokenizer, kw["kind"], args.rows, args.bytes, 5000, no_memo=kw.get("no_memo", False),
                            n_batches=4, cache_capacity=kw.get("cache_capacity"))
@@ -913,7 +913,11 @@ def main():
                             "note": {"uniform_text": "uniform-random printable bytes (SURVEY 8d stress text: cache-hostile, 3x the pieces)",
                                      "no_memo": "zipf text with cache_capacity=0: every piece takes the merge path",
                                      "fixed_memo_only": "zipf text with cache_capacity=1: the memo holds the vocabulary's own tokens and learns "
-                                                        "nothing from the text (every multi-token word is merged every time)"}[name]}
+                                                        "nothing from the text (every multi-token word is merged every time)",
+                                     "mixed_script_text": "config 4's text (30 % of the words Greek / Cyrillic / CJK / kana / emoji, rows of 700-1000 "
+                                                          "bytes) through THIS tokenizer: rows with a non-ASCII byte leave lookup_ascii_kernel for "
+                                                          "the generic lookup_kernel<kFused> (ballot scanner), and random non-Latin words never hit "
+                                                          "the memo"}[name]}
             del w2
         # the loop's own streams and one more: every further stream a process creates shares a hardware queue with an older
         # one sooner (GPU_MAX_HW_QUEUES), and streams on one queue take turns

@@ -37,7 +37,7 @@ def test_bench_json_line():
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert d["cpu_baseline_all_cores"]["cores"] >= 1 and d["cpu_baseline_all_cores"]["value"] > 0
     assert d["stress"]["uniform_text"]["value"] > 0 and d["stress"]["no_memo"]["ms_per_step"] > 0
-    assert d["stress"]["fixed_memo_only"]["ms_per_step"] > 0
+    assert d["stress"]["fixed_memo_only"]["ms_per_step"] > 0 and d["stress"]["mixed_script_text"]["value"] > 0
     memo = d["config"]["piece_memo"]
     assert memo["fixed"] > 1000 and 0 < memo["learned"] <= memo["cache_capacity"] == 20000
     assert d["end_to_end"]["value"] > 0 and "8 distinct batches" in d["config"]["workload"]
