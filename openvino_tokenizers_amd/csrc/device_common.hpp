@@ -98,6 +98,12 @@ __device__ __forceinline__ void publish_release() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
+// Waits until this wave's outstanding global loads, stores and atomics have completed.
+__device__ __forceinline__ void drain_vmem() {
+#ifndef OVTK_SIMT_EMULATOR
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 __device__ __forceinline__ void publish_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }

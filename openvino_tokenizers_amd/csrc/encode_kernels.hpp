@@ -117,6 +117,11 @@ __device__ __forceinline__ long long row_capacity(const RowsIn& in, int mul, lon
 // writes the XCD's dirty L2 lines back -- hundreds of blocks doing that at the end of a kernel cost tens of us).
 __device__ __forceinline__ bool last_block_done(uint32_t* ticket, unsigned n_blocks, bool release = true) {
     __shared__ int is_last_s;
+    // Every wave's own atomics (the per-tile and per-row counts are returnless adds) must have been performed before the
+    // block's ticket is drawn: __syncthreads() is a workgroup-scope fence and does not wait for them, and a ticket that
+    // overtakes them lets the last block scan counts that are a batch short (tools/soak.py: one encode in ~15 000 lost
+    // the ids of one 64-piece batch in one tile).
+    drain_vmem();
     __syncthreads();
     if (threadIdx.x == 0) {
         if (release) publish_release();

@@ -1,0 +1,84 @@
+"""Soak: many batches through every calling mode of the fused encode on one handle (device-resident on three streams,
+pinned host buffers on four, straight to an exchange wire), each result compared with the first (blocking, device) result
+of the same batch.  python tools/soak.py [rounds]"""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from openvino_tokenizers_amd import _lib as L  # noqa: E402
+from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit  # noqa: E402
+from tools.harness import BpeTok  # noqa: E402
+from tools.workloads import TextModel, ragged_rows  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
+CAP = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
+
+
+def report(name, r, j, ref, got, mode):
+    msg = [f"MISMATCH {name} round {r} batch {j} mode {mode}:"]
+    for q, (a, b) in enumerate(zip(ref, got)):
+        if a.shape != b.shape:
+            msg.append(f"out{q} shape {a.shape} vs {b.shape}")
+        else:
+            d = np.flatnonzero(a != b)
+            if len(d):
+                msg.append(f"out{q} {len(d)} diffs, first at {d[0]}: {a[d[0]:d[0]+6].tolist()} vs {b[d[0]:d[0]+6].tolist()}")
+    print(" ".join(msg), flush=True)
+lib = L.load()
+dev = torch.device("cuda", 0)
+for name, kinds in (("gpt2", ("zipf", "uniform", "mixed")), ("llama3", ("mixed", "zipf"))):
+    if ONLY and name != ONLY:
+        continue
+    tok = BpeTok.load(name)
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**dict(tok.attrs, cache_capacity=CAP), lib=lib))
+    pat = tok.pattern_u8()
+    batches, refs = [], []
+    for i in range(9):
+        n = 6000 + 1500 * (i % 3)
+        b, e, c = TextModel(300 + i, kinds[i % len(kinds)]).batch(n, 300 + 60 * (i % 4))
+        rb, re_ = ragged_rows(n)
+        host = [rb, re_, b, e, c]
+        data = [torch.as_tensor(x, device=dev) for x in host]
+        ref = [t.cpu().numpy().copy() for t in fused.evaluate(data + [pat], tok.consts)]
+        batches.append((host, data))
+        refs.append(ref)
+    streams = [torch.cuda.Stream(dev) for _ in range(4)]
+
+    def pinned(a):
+        t = torch.empty(a.shape, dtype=getattr(torch, str(a.dtype)), pin_memory=True)
+        v = t.numpy()
+        v[...] = a
+        return v
+    pin_in = [[pinned(x) for x in host] for host, _ in batches]
+    bad = 0
+    for r in range(rounds):
+        inflight = []
+        for k, (host, data) in enumerate(batches):
+            mode = (k + r) % 2
+            if mode == 0:
+                with torch.cuda.stream(streams[k % 3]):
+                    t = fused.enqueue(data + [pat], tok.consts)
+                get = (lambda t=t: [x.cpu().numpy() for x in t()])
+            else:
+                outs = tuple(pinned(np.full(m, -1, np.int32)) for m in (len(host[0]), len(host[0]), len(host[4])))
+                t = fused.enqueue_host(pin_in[k] + [pat], tok.consts, outs, streams[k % 4].cuda_stream)
+                get = (lambda t=t: [np.asarray(x) for x in t()])
+            inflight.append((k, get, mode))
+            if len(inflight) > 3:
+                j, g, md = inflight.pop(0)
+                got = g()
+                if not all(np.array_equal(a, b) for a, b in zip(refs[j], got)):
+                    bad += 1
+                    report(name, r, j, refs[j], got, md)
+        for j, g, md in inflight:
+            got = g()
+            if not all(np.array_equal(a, b) for a, b in zip(refs[j], got)):
+                bad += 1
+                report(name, r, j, refs[j], got, md)
+    print(name, "rounds", rounds, "batches", rounds * len(batches), "bad", bad)
