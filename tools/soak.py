@@ -82,3 +82,76 @@ for name, kinds in (("gpt2", ("zipf", "uniform", "mixed")), ("llama3", ("mixed",
                 bad += 1
                 report(name, r, j, refs[j], got, md)
     print(name, "rounds", rounds, "batches", rounds * len(batches), "bad", bad)
+
+# ---- the fused BERT chain (WordPiece) and the fused detokenizer, two-half calls on three streams
+if not ONLY or ONLY in ("bert", "detok"):
+    import bench
+    from openvino_tokenizers_amd.ops import FusedDetokenizer, FusedSplitWordpiece, VocabDecoder, WordpieceTokenizer
+    from tools.harness import pack_strings
+    from tools.make_tokenizers import load_tokenizer
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    if not ONLY or ONLY == "bert":
+        tokw = load_tokenizer("bert")
+        ws_pat, pu_pat = np.frombuffer(bench.BERT_WS.encode(), np.uint8), np.frombuffer(bench.BERT_PUNCT.encode(), np.uint8)
+        consts = list(pack_strings(tokw["vocab"])) + [np.asarray(tokw["unk_id"], np.int32)]
+        fw = FusedSplitWordpiece(RegexSplit("remove", lib=lib), RegexSplit("isolate", lib=lib),
+                                 WordpieceTokenizer(tokw["suffix_indicator"], tokw["max_bytes_per_word"], lib=lib))
+        batches, refs = [], []
+        for i in range(9):
+            n = 6000 + 1500 * (i % 3)
+            b, e, c = TextModel(500 + i, ("zipf", "mixed")[i % 2]).batch(n, 200 + 50 * (i % 4))
+            if i % 2 == 0:
+                c = np.frombuffer(c.tobytes().lower(), np.uint8)
+            rb, re_ = ragged_rows(n)
+            data = [torch.as_tensor(x, device=dev) for x in (rb, re_, b, e, c)]
+            refs.append([t.cpu().numpy().copy() for t in fw.evaluate(data, ws_pat, pu_pat, consts)])
+            batches.append(data)
+        bad = 0
+        for r in range(rounds):
+            inflight = []
+            for k, data in enumerate(batches):
+                with torch.cuda.stream(streams[(k + r) % 3]):
+                    inflight.append((k, fw.enqueue(data, ws_pat, pu_pat, consts)))
+                if len(inflight) > 2:
+                    j, t = inflight.pop(0)
+                    got = [x.cpu().numpy() for x in t()]
+                    if not all(np.array_equal(a, g) for a, g in zip(refs[j], got)):
+                        bad += 1
+                        report("bert", r, j, refs[j], got, "enqueue")
+            for j, t in inflight:
+                got = [x.cpu().numpy() for x in t()]
+                if not all(np.array_equal(a, g) for a, g in zip(refs[j], got)):
+                    bad += 1
+                    report("bert", r, j, refs[j], got, "enqueue")
+        print("bert rounds", rounds, "batches", rounds * len(batches), "bad", bad)
+    if not ONLY or ONLY == "detok":
+        tok = BpeTok.load("gpt2")
+        V = len(tok.vocab)
+        vconst = list(pack_strings(tok.vocab))
+        dec = VocabDecoder(skip_tokens=[V - 1], lib=lib)
+        fd = FusedDetokenizer(dec, byte_fallback=True)
+        batches, refs = [], []
+        for i in range(6):
+            rng = np.random.default_rng(700 + i)
+            ids = rng.integers(0, V, size=(1500 + 500 * (i % 3), 256 + 128 * (i % 2)), dtype=np.int32)
+            data = [torch.as_tensor(ids, device=dev)] + vconst
+            refs.append([t.cpu().numpy().copy() for t in fd.evaluate(data)])
+            batches.append(data)
+        bad = 0
+        for r in range(rounds):
+            inflight = []
+            for k, data in enumerate(batches):
+                with torch.cuda.stream(streams[(k + r) % 3]):
+                    inflight.append((k, fd.enqueue(data)))
+                if len(inflight) > 2:
+                    j, t = inflight.pop(0)
+                    got = [x.cpu().numpy() for x in t()]
+                    if not all(np.array_equal(a, g) for a, g in zip(refs[j], got)):
+                        bad += 1
+                        report("detok", r, j, refs[j], got, "enqueue")
+            for j, t in inflight:
+                got = [x.cpu().numpy() for x in t()]
+                if not all(np.array_equal(a, g) for a, g in zip(refs[j], got)):
+                    bad += 1
+                    report("detok", r, j, refs[j], got, "enqueue")
+        print("detok rounds", rounds, "batches", rounds * len(batches), "bad", bad)
