@@ -155,3 +155,37 @@ if not ONLY or ONLY in ("bert", "detok"):
                     bad += 1
                     report("detok", r, j, refs[j], got, "enqueue")
         print("detok rounds", rounds, "batches", rounds * len(batches), "bad", bad)
+
+# ---- small batches (the one-launch path: encode_small_kernel, whose last block merges and compacts what the others staged)
+if not ONLY or ONLY == "small":
+    for name in ("gpt2", "llama3"):
+        tok = BpeTok.load(name)
+        fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**tok.attrs, lib=lib))
+        pat = tok.pattern_u8()
+        batches, refs = [], []
+        for i in range(12):
+            n = [1, 7, 32, 60, 130, 256][i % 6]
+            b, e, c = TextModel(800 + i, ("zipf", "mixed", "uniform")[i % 3]).batch(n, 60 + 40 * (i % 4))
+            rb, re_ = ragged_rows(n)
+            data = [torch.as_tensor(np.array(x), device=dev) for x in (rb, re_, b, e, c)]
+            refs.append([t.cpu().numpy().copy() for t in fused.evaluate(data + [pat], tok.consts)])
+            batches.append(data)
+        streams = [torch.cuda.Stream(dev) for _ in range(3)]
+        bad = 0
+        for r in range(rounds):
+            inflight = []
+            for k, data in enumerate(batches):
+                with torch.cuda.stream(streams[(k + r) % 3]):
+                    inflight.append((k, fused.enqueue(data + [pat], tok.consts)))
+                if len(inflight) > 2:
+                    j, t = inflight.pop(0)
+                    got = [x.cpu().numpy() for x in t()]
+                    if not all(np.array_equal(a, g) for a, g in zip(refs[j], got)):
+                        bad += 1
+                        report("small-" + name, r, j, refs[j], got, "enqueue")
+            for j, t in inflight:
+                got = [x.cpu().numpy() for x in t()]
+                if not all(np.array_equal(a, g) for a, g in zip(refs[j], got)):
+                    bad += 1
+                    report("small-" + name, r, j, refs[j], got, "enqueue")
+        print("small", name, "rounds", rounds, "batches", rounds * len(batches), "bad", bad)
