@@ -189,3 +189,53 @@ if not ONLY or ONLY == "small":
                     bad += 1
                     report("small-" + name, r, j, refs[j], got, "enqueue")
         print("small", name, "rounds", rounds, "batches", rounds * len(batches), "bad", bad)
+
+# ---- the encode straight into an exchange wire (compact_kernel<WireSink>), three streams
+if not ONLY or ONLY == "wire":
+    tok = BpeTok.load("gpt2")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**tok.attrs, lib=lib))
+    pat = tok.pattern_u8()
+    streams = [torch.cuda.Stream(dev) for _ in range(3)]
+    batches, refs, geo = [], [], []
+    for i in range(9):
+        n = 6000 + 1500 * (i % 3)
+        b, e, c = TextModel(900 + i, ("zipf", "uniform")[i % 2]).batch(n, 250 + 50 * (i % 3))
+        rb, re_ = ragged_rows(n)
+        data = [torch.as_tensor(np.array(x), device=dev) for x in (rb, re_, b, e, c)]
+        ob, oe, ids = fused.evaluate(data + [pat], tok.consts)
+        h = C.c_void_p()
+        L.check(lib, lib.ovtk_shard_exchange_create(1, C.c_int64(n), 2, C.c_int64(0), 0, C.byref(h)))
+        max_rows = int(lib.ovtk_shard_max_rows(h))
+        pad = (int(len(ids)) + 64) // 8 * 8
+        nbytes = int(lib.ovtk_shard_wire_bytes(h, C.c_int64(pad)))
+        want = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        L.check(lib, lib.ovtk_shard_pack(h, C.c_void_p(ob.data_ptr()), C.c_void_p(oe.data_ptr()), C.c_void_p(ids.data_ptr()), C.c_int64(n),
+                                         C.c_int64(len(ids)), C.c_int64(pad), C.c_void_p(want.data_ptr()), L.MEM_DEVICE, None))
+        torch.cuda.synchronize()
+        used = 16 + 4 * max_rows + 2 * int(len(ids))
+        refs.append(want[:used].cpu())
+        geo.append((max_rows, pad, nbytes, used))
+        batches.append(data)
+        lib.ovtk_shard_exchange_destroy(h)
+    bad = 0
+    for r in range(rounds):
+        inflight = []
+        for k, data in enumerate(batches):
+            max_rows, pad, nbytes, used = geo[k]
+            wire = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            with torch.cuda.stream(streams[(k + r) % 3]):
+                wire.zero_()
+                t = fused.enqueue_wire(data + [pat], tok.consts, wire, max_rows, pad, 2)
+            inflight.append((k, t, wire))
+            if len(inflight) > 2:
+                j, tt, wv = inflight.pop(0)
+                tt()
+                if not torch.equal(refs[j], wv[:geo[j][3]].cpu()):
+                    bad += 1
+                    print("MISMATCH wire round", r, "batch", j, flush=True)
+        for j, tt, wv in inflight:
+            tt()
+            if not torch.equal(refs[j], wv[:geo[j][3]].cpu()):
+                bad += 1
+                print("MISMATCH wire round", r, "batch", j, flush=True)
+    print("wire rounds", rounds, "batches", rounds * len(batches), "bad", bad)
