@@ -630,4 +630,4 @@ def test_soak_of_calling_modes(hip_lib):
     p = subprocess.run([sys.executable, str(root / "tools" / "soak.py"), "120"], capture_output=True, text=True, timeout=900, cwd=str(root))
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if " rounds " in ln]
-    assert len(lines) == 7 and all(ln.endswith("bad 0") for ln in lines), p.stdout[-2000:]   # gpt2, llama3, bert, detok, small x 2, wire
+    assert len(lines) == 8 and all(ln.endswith("bad 0") for ln in lines), p.stdout[-2000:]   # gpt2, llama3, bert, detok, small x 2, wire, ops

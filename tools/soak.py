@@ -239,3 +239,36 @@ if not ONLY or ONLY == "wire":
                 bad += 1
                 print("MISMATCH wire round", r, "batch", j, flush=True)
     print("wire rounds", rounds, "batches", rounds * len(batches), "bad", bad)
+
+# ---- a mix of blocking ops taking turns on the pooled workspaces (each op's result against its own first one)
+if not ONLY or ONLY == "ops":
+    from openvino_tokenizers_amd.ops import RaggedToDense, VocabEncoder
+    from tools.harness import one_string_per_row
+    tok = BpeTok.load("gpt2_small")
+    QWEN2 = (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+")
+    b, e, c = TextModel(950, "mixed").batch(3000, 200)
+    rb, re_ = ragged_rows(3000)
+    text = [torch.as_tensor(np.array(x), device=dev) for x in (rb, re_, b, e, c)]
+    calls = {}
+    calls["split-gpt2"] = lambda: RegexSplit("isolate", lib=lib).evaluate(text + [tok.pattern_u8()])
+    calls["split-qwen2-dfa"] = lambda: RegexSplit("isolate", lib=lib).evaluate(text + [np.frombuffer(QWEN2.encode(), np.uint8)])
+    calls["split-removed"] = lambda: RegexSplit("remove", lib=lib).evaluate(text + [np.frombuffer(rb"\s+", np.uint8)])
+    bpe = BPETokenizer(**tok.attrs, lib=lib)
+    pieces = RegexSplit("isolate", lib=lib).evaluate(text + [tok.pattern_u8()])
+    calls["bpe-on-pieces"] = lambda: bpe.evaluate(list(pieces[:5]) + tok.consts)
+    enc = bpe.evaluate(list(pieces[:5]) + tok.consts)
+    target = int((enc[1] - enc[0]).max().item())
+    calls["ragged-to-dense"] = lambda: RaggedToDense(lib=lib).evaluate(list(enc) + [np.asarray(target, np.int32), np.asarray(0, np.int32)])
+    small = [torch.as_tensor(np.array(x), device=dev) for x in one_string_per_row(["hello world", "", "a b c"])]
+    calls["small-encode"] = lambda: FusedSplitBPE(RegexSplit("isolate", lib=lib), bpe).evaluate(small + [tok.pattern_u8()], tok.consts)
+    first = {k: [np.asarray(t.cpu() if hasattr(t, "cpu") else t).copy() for t in f()] for k, f in calls.items()}
+    bad = 0
+    order = list(calls)
+    rng = np.random.default_rng(1)
+    for r in range(rounds):
+        for k in rng.permutation(order):
+            got = [np.asarray(t.cpu() if hasattr(t, "cpu") else t) for t in calls[k]()]
+            if not all(np.array_equal(a, g) for a, g in zip(first[k], got)):
+                bad += 1
+                report("ops-" + k, r, 0, first[k], got, "blocking")
+    print("ops rounds", rounds, "calls", rounds * len(order), "bad", bad)
