@@ -43,7 +43,7 @@ sys.path.insert(0, str(ROOT))
 
 from openvino_tokenizers_amd import _lib as L  # noqa: E402
 from openvino_tokenizers_amd.ops import (BPETokenizer, RegexSplit, VocabDecoder, VocabEncoder, WordpieceTokenizer)  # noqa: E402
-from tools.harness import BpeTok, pack_strings  # noqa: E402
+from tools.harness import BERT_PUNCT, BERT_WS, BpeTok, pack_strings  # noqa: E402
 from tools.make_tokenizers import load_tokenizer  # noqa: E402
 from tools.workloads import TextModel, ragged_rows  # noqa: E402
 
@@ -55,10 +55,6 @@ KERNEL_NAMES = {"lookup_ascii": "lookup_ascii_kernel", "lookup_fused": "lookup_k
                 "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel", "split_count": "split_kernel<0>",
                 "split_write": "split_kernel<1>", "ragged_to_dense": "ragged_to_dense_kernel", "vocab_encoder": "vocab_encoder_kernel",
                 "detokenize": "decode_write_kernel", "decode_count": "decode_count_kernel", "decode_scan": "tile_{reduce,scan,apply}_kernel<UnitLen>"}
-BERT_WS = r"\s+"
-BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\x{4E00}-\x{9FFF}]", r"[\x{3400}-\x{4DBF}]",
-                       r"[\x{20000}-\x{2A6DF}]", r"[\x{2A700}-\x{2B73F}]", r"[\x{2B740}-\x{2B81F}]",
-                       r"[\x{2B820}-\x{2CEAF}]", r"[\x{F900}-\x{FAFF}]", r"[\x{2F800}-\x{2FA1F}]"])
 PMC_FILE = ROOT / "profiles" / "latest_pmc.json"  # HBM traffic of the dominant kernels from a separate rocprofv3 --pmc run
 
 
@@ -141,6 +137,14 @@ class EncodeWorkload:
         """algorithmic bytes of one pass, A_enc = N_c + 4 N_t + 16 B, averaged over the rotation."""
         ks = sorted(self.n_out)
         return float(np.mean([self.batches.n_chars[k] + 4 * self.n_out[k] + 16 * self.batches.rows for k in ks]))
+
+    def kernel_algo(self, dom):
+        """The algorithmic bytes of the dominant kernel ALONE, where it is one of the lookup kernels: it reads the text and
+        the strings' begins / ends and writes (stages) the ids; the rows' begins / ends are written by compact_kernel."""
+        if not dom.startswith("lookup"):
+            return None
+        ks = sorted(self.n_out)
+        return float(np.mean([self.batches.n_chars[k] + 4 * self.n_out[k] + 8 * self.batches.rows for k in ks]))
 
     def mean_out(self):
         return float(np.mean(list(self.n_out.values())))
@@ -673,6 +677,14 @@ def end_to_end_leg(wl, lib, dev, ptrs, steps=64, depth=3):
             "ids_last_batch": int(o[3].n_data)}
 
 
+def relaunch_argv(n_gpus, argv, port=None):
+    """The command `bench.py --gpus N` replaces itself with when nobody launched it as N ranks (WORLD_SIZE unset): one
+    process per GPU under torch.distributed.run, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    port = port or int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -705,10 +717,18 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
+    ap.add_argument("--spawn", action="store_true", help="take the `--gpus N` relaunch under torch.distributed.run even for N = 1 (test)")
     args = ap.parse_args()
 
+    if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:   # `python bench.py --gpus N`: become N ranks
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.exit(f"bench.py --gpus {args.gpus}: this node shows {have} GPU(s)")
+        os.execv(sys.executable, relaunch_argv(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus} was launched as {world} rank(s) (WORLD_SIZE): the two must agree")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -788,13 +808,18 @@ def main():
             torch.cuda.synchronize()
 
     run_steps(0, args.warmup)
-    lib.ovtk_profile_reset()
-    lib.ovtk_profile_enable(1)
+    lib.ovtk_profile_enable(0)   # the timed region runs without the library's per-kernel event brackets
     barrier()
     t0 = time.perf_counter()
     run_steps(args.warmup, args.steps)   # every one of the K batches is complete (and, N > 1, gathered on every rank) when it returns
     barrier()
     dt = time.perf_counter() - t0
+    # per-kernel wall times of the same loop (overlapped launches), collected in a leg of its own behind the timed region
+    n_prof = min(args.steps, 48)
+    lib.ovtk_profile_reset()
+    lib.ovtk_profile_enable(1)
+    run_steps(args.warmup + args.steps, n_prof)
+    barrier()
     lib.ovtk_profile_enable(0)
     my_units = sum(wl.units(i) for i in range(args.warmup, args.warmup + args.steps))
     if world > 1:
@@ -818,7 +843,7 @@ def main():
     # `overlapped` for information only.
     prof = profile_table(lib)
     kernels = {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}
-    per_step = {k: v[0] / args.steps for k, v in prof.items()}
+    per_step = {k: v[0] / n_prof for k, v in prof.items()}
     roofline = None
     if per_step:
         alone = {}
@@ -832,7 +857,7 @@ def main():
             lib.ovtk_profile_enable(0)
             alone = {k: v for k, v in profile_table(lib).items() if v[1]}
         src = alone or prof
-        n_src = 24 if alone else args.steps
+        n_src = 24 if alone else n_prof
         hint = getattr(wl, "dominant_hint", None)
         per_launch = {k: v[0] / v[1] for k, v in src.items()}
         per_step_src = {k: v[0] / n_src for k, v in src.items()}
@@ -843,10 +868,10 @@ def main():
         k_ms = per_launch[dom]
         algo_bytes = wl.algo()   # algorithmic bytes of one pass
         achieved = algo_bytes / launches_per_step / (k_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, pmc_cfg = None, None
         if PMC_FILE.exists():  # per-launch FETCH_SIZE (doubled: gfx950 correction) + WRITE_SIZE of this kernel, see profiles/README.md
-            pmc = json.loads(PMC_FILE.read_text())
-            traffic = pmc.get(f"config{args.config}", {}).get(dom)
+            pmc_cfg = json.loads(PMC_FILE.read_text()).get(f"config{args.config}", {})
+            traffic = pmc_cfg.get(dom)
         roofline = {"bound": "hbm", "kernel": KERNEL_NAMES.get(dom, dom), "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": traffic, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": round(algo_bytes),
@@ -859,6 +884,13 @@ def main():
                     "one_stream_kernel_ms": {k: round(v, 4) for k, v in sorted(per_launch.items())},
                     "one_stream_kernel_sum_ms_per_step": round(sum(per_step_src.values()), 4)}
         step_gbs = algo_bytes / (ms_per_step * 1e-3) / 1e9 * (total_units / max(my_units, 1)) / world
+        # counted HBM bytes of EVERY kernel of the step (profiles/latest_pmc.json, a separate --pmc run) over the algorithmic bytes
+        step_traffic = sum(v for k, v in (pmc_cfg or {}).items() if k in per_step_src and src[k][1]) if pmc_cfg else None
+        roofline["step_traffic"] = step_traffic
+        roofline["traffic_ratio"] = round(step_traffic / algo_bytes, 3) if step_traffic else None
+        kb = getattr(wl, "kernel_algo", lambda _dom: None)(dom)
+        roofline["kernel_bytes"] = round(kb) if kb else None
+        roofline["kernel_frac"] = round(kb / launches_per_step / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if kb else None
         roofline["step"] = {"achieved": round(step_gbs, 2), "frac": round(step_gbs / HBM_PEAK_GBS, 5),
                             "note": "algorithmic bytes of one batch / ms_per_step, per GPU: every kernel of the path, overlapped as run"}
         if alone:
@@ -930,6 +962,8 @@ def main():
         "higher_is_better": getattr(wl, "higher_is_better", True), "scaling": "weak", "vs_baseline": None, "dtype": wl.dtype,
         "data": "synthetic",
         "config": {"workload": wl.workload,
+                   "world": {"ranks": (dist.get_world_size() if dist_on else 1),
+                             "launched_by": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "python"},
                    "row_tickets": row_tickets, "host_cpu_affinity": numa_note,
                    "host_loop": (f"launch batch k, then complete batch k-{args.depth} (two-half calls), batches alternate between {len(stream_ptrs)} "
                                  f"HIP stream(s)" if two_half else "one blocking call per batch"),

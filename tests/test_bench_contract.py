@@ -66,3 +66,31 @@ def test_bench_exchange_loop(config):
 def test_bench_exchange_loop_packed():
     d = _run("--force-exchange", "--no-cpu-baseline", "--wire", "0", "--exchange", "p2p")
     assert d["value"] > 0 and "shard_pack" in d["kernel_ms"] and "grouped direct" in d["config"]["exchange"]
+
+
+def test_relaunch_argv():
+    """`python bench.py --gpus N` without WORLD_SIZE replaces itself with N ranks under torch.distributed.run (CPU: the
+    command only)."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    argv = bench.relaunch_argv(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], port=29611)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=8" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29611"
+    k = argv.index(str(ROOT / "bench.py"))
+    assert argv[k + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+
+
+def test_gpus_must_match_world_size():
+    """Launched as 2 ranks but told --gpus 1 (or the reverse): refuse before touching a GPU."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and "must agree" in p.stderr
+
+
+@pytest.mark.gpu
+def test_bench_through_the_relaunch():
+    """--spawn: the path `--gpus N` takes (re-exec under torch.distributed.run), with one rank and its RCCL group."""
+    d = _run("--spawn", "--force-exchange", "--no-cpu-baseline", "--no-extras")
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "all-gather" in d["config"]["exchange"]
+    assert d["config"]["world"] == {"ranks": 1, "launched_by": "torch.distributed.run"}

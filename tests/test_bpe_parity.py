@@ -616,18 +616,3 @@ def test_fuzzed_tables(backend):
         for rep in range(2):
             got = op.evaluate(backend.data(inputs) + tok.consts, ids_capacity=cap)
             assert_same(ref, got, backend.host, f"case {k} rep {rep} attrs {tok.attrs}")
-
-
-@pytest.mark.gpu
-def test_soak_of_calling_modes(hip_lib):
-    """tools/soak.py in small (fused BPE with two tokenizers, the BERT chain, the detokenizer): the same batches through the device-resident two-half calls on three streams and the
-    pinned-host calls on four, interleaved, round after round, every result equal to the first blocking one.  (The full
-    soak -- tens of thousands of batches -- is what found the ticket that overtook its block's count atomics.)"""
-    import subprocess
-    import sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parent.parent
-    p = subprocess.run([sys.executable, str(root / "tools" / "soak.py"), "120"], capture_output=True, text=True, timeout=900, cwd=str(root))
-    assert p.returncode == 0, p.stderr[-2000:]
-    lines = [ln for ln in p.stdout.splitlines() if " rounds " in ln]
-    assert len(lines) == 8 and all(ln.endswith("bad 0") for ln in lines), p.stdout[-2000:]   # gpt2, llama3, bert, detok, small x 2, wire, ops

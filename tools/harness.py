@@ -6,6 +6,12 @@ import numpy as np
 from tools.make_tokenizers import load_tokenizer
 from tools.workloads import ragged_rows
 
+# The two RegexSplit patterns of a converted BERT pipeline (python/openvino_tokenizers/tokenizer_pipeline.py:392-435):
+# whitespace is removed, punctuation / CJK characters are isolated.
+BERT_WS = r"\s+"
+BERT_PUNCT = "|".join([r"[!-/]", r"[:-@]", r"[\[-`]", r"[{-~]", r"[\p{P}]", r"[\x{4E00}-\x{9FFF}]", r"[\x{3400}-\x{4DBF}]",
+                       r"[\x{20000}-\x{2A6DF}]", r"[\x{2A700}-\x{2B73F}]", r"[\x{2B740}-\x{2B81F}]",
+                       r"[\x{2B820}-\x{2CEAF}]", r"[\x{F900}-\x{FAFF}]", r"[\x{2F800}-\x{2FA1F}]"])
 
 def pack_strings(strings):
     """list of bytes/str -> (begins, ends, chars): python/openvino_tokenizers/utils.py:436-458."""
