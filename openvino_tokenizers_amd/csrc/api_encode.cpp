@@ -631,11 +631,25 @@ int ovtk_encode_enqueue_wire(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_
     if (int rc = check_fused(split)) return rc;
     if ((id_bytes != 2 && id_bytes != 4) || pad_ids < 0 || pad_ids % 8 || pad_ids >= INT32_MAX || max_rows % 4 || in->n_rows > max_rows)
         return set_error(OVTK_E_ARG, "encode to wire: bad wire geometry (ovtk_shard_max_rows / pad_ids / id_bytes of the exchange)");
-    if (in->strings.n_chars == 0 || in->n_rows == 0)
-        return set_error(OVTK_E_UNSUPPORTED, "encode to wire: empty batches take ovtk_encode_enqueue + ovtk_shard_pack");
+    if (int rc = check_rows(in)) return rc;
     auto p = std::make_unique<ovtk_pending>();
     p->out = ovtk_ragged_i32_out{nullptr, nullptr, nullptr, INT32_MAX - 2, 0, 0};  // the wire cuts at pad_ids, nothing overflows
     uint8_t* base = static_cast<uint8_t*>(wire);
+    if (in->strings.n_chars == 0 || in->n_rows == 0) {
+        // A shard without text (shard_rows_by_bytes next to one very long row, or rows of empty strings): its wire is the
+        // header {0 ids, n_rows} and row ends of zero -- written here, no kernel has anything to do.  (The one-row quirk
+        // of an all-empty RegexSplit batch, regex_split.cpp:129-143, is a property of a whole batch; a shard keeps its rows.)
+        if (!bpe) return set_error(OVTK_E_ARG, "null argument");
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        OVTK_HIP(hipSetDevice(bpe->device));
+        OVTK_HIP(hipMemsetAsync(base, 0, size_t(kShardHeaderBytes) + size_t(max_rows) * 4, s));
+        const int32_t rows32 = int32_t(in->n_rows);
+        OVTK_HIP(hipMemcpyAsync(base + 4, &rows32, 4, hipMemcpyHostToDevice, s));
+        OVTK_HIP(hipStreamSynchronize(s));   // (rows32 is read by then) ovtk_encode_finish() of this call has nothing to wait for
+        p->out.n_rows = in->n_rows;
+        *pending = p.release();
+        return OVTK_OK;
+    }
     const WireSink sink{reinterpret_cast<int32_t*>(base), reinterpret_cast<int32_t*>(base + kShardHeaderBytes),
                         base + kShardHeaderBytes + max_rows * 4, int32_t(pad_ids), int32_t(max_rows), id_bytes};
     if (int rc = start_encode(split, bpe, in, skips, &p->out, OVTK_MEM_DEVICE, stream, p->run, &sink)) return rc;

@@ -367,7 +367,9 @@ int ovtk_ragged_to_dense(const int32_t* begins, const int32_t* ends, int64_t n_r
     if (out_mask)
         if (int rc = out_target(ws->out_b, out_mask, mask_bytes, mem, &a.mask)) return rc;
     const unsigned long long total = (unsigned long long)n_rows * (unsigned long long)target_dim;
-    const bool flat = a.cell == 4 && total < (1ull << 31) && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
+    // (dword cells only when ONE 4-byte element is the cell: 2 x 2-byte or 4 x 1-byte cells have a mask byte per inner element
+    // and a default that repeats per element -- the generic path)
+    const bool flat = a.elem_size == 4 && a.inner == 1 && total < (1ull << 31) && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 &&
                       (!a.mask || (reinterpret_cast<uintptr_t>(a.mask) & 3) == 0) && (reinterpret_cast<uintptr_t>(a.data) & 3) == 0;
     if (flat)
         OVTK_LAUNCH(ws->marks, "ragged_to_dense", ragged_to_dense_flat4_kernel,

@@ -258,7 +258,7 @@ static __global__ __launch_bounds__(kBlockThreads) void ragged_to_dense_kernel(D
         uint8_t* orow = a.out + (long long)row * a.target * a.cell;
         uint8_t* mrow = a.mask ? a.mask + (long long)row * a.target * a.inner : nullptr;
         const uint8_t* src = a.data + b * a.cell;
-        if (a.cell == 4) {  // the common case (i32 ids): one dword per lane
+        if (a.elem_size == 4 && a.inner == 1) {  // the common case (i32 ids): one dword per lane
             uint32_t d;
             d = uint32_t(a.dflt[0]) | uint32_t(a.dflt[1]) << 8 | uint32_t(a.dflt[2]) << 16 | uint32_t(a.dflt[3]) << 24;
             for (long long k = l; k < a.target; k += kWave) {

@@ -288,6 +288,49 @@ def test_encode_straight_to_wire(backend, vocab_name, pad_frac):
         lib.ovtk_shard_exchange_destroy(h)
 
 
+@pytest.mark.parametrize("n_rows", [0, 5])
+def test_encode_to_wire_of_a_shard_without_text(backend, n_rows):
+    """A shard of empty strings (or of no rows at all: shard_rows_by_bytes next to one very long row) still yields a wire --
+    header {0 ids, n_rows}, row ends of zero -- byte for byte what ovtk_shard_pack makes of n_rows empty rows; the other
+    ranks are already in the collective, an error here would leave them there."""
+    import ctypes as C
+    from openvino_tokenizers_amd import _lib as L
+    from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
+    from tests.util import BpeTok
+    from tools.workloads import ragged_rows
+    if backend.name == "hip-host":
+        pytest.skip("the exchange hands over device (or emulator-host) buffers only")
+    lib = backend.lib
+    dev = backend.name != "emu"
+    where = "cuda" if dev else "cpu"
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**tok.attrs, lib=lib))
+    rb, re_ = ragged_rows(n_rows)
+    zeros = np.zeros(n_rows, np.int32)
+    data = [torch.as_tensor(np.ascontiguousarray(x)).to(where) for x in (rb, re_, zeros, zeros, np.zeros(1, np.uint8))]
+    h = C.c_void_p()
+    L.check(lib, lib.ovtk_shard_exchange_create(2, C.c_int64(16), 2, C.c_int64(0), 0, C.byref(h)))
+    try:
+        max_rows, pad = int(lib.ovtk_shard_max_rows(h)), 64
+        nbytes = int(lib.ovtk_shard_wire_bytes(h, C.c_int64(pad)))
+        want = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=where)
+        got = torch.full((nbytes,), 0x5A, dtype=torch.uint8, device=where)
+
+        def ptr(t):
+            return C.c_void_p(t.data_ptr())
+        mem = L.MEM_DEVICE if dev else L.MEM_HOST
+        L.check(lib, lib.ovtk_shard_pack(h, ptr(data[2]), ptr(data[3]), ptr(data[2]), C.c_int64(n_rows), C.c_int64(0), C.c_int64(pad), ptr(want), mem, None))
+        n_ids = fused.enqueue_wire(data[:4] + [data[4][:0]] + [tok.pattern_u8()], tok.consts, got, max_rows, pad, 2)()
+        if dev:
+            torch.cuda.synchronize()
+        used = 16 + 4 * max_rows
+        assert n_ids == 0
+        assert torch.equal(want[:used].cpu(), got[:used].cpu())
+        assert got[:8].cpu().numpy().view(np.int32).tolist() == [0, n_rows]
+    finally:
+        lib.ovtk_shard_exchange_destroy(h)
+
+
 def _wire_mode_run(lib, device, rank, world, n_rows, nbytes, n_batches=3):
     """Every rank encodes its row shard of each batch straight into a leased wire and submits it; returns (exchanged
     global tensors, single-process encodes of the whole batches, regathers).  Later batches are longer, so a wire leased

@@ -110,7 +110,7 @@ def test_wordpiece_full_size(hip_lib):
     b, e, c = TextModel(1234, "zipf").batch(rows, 256, seed=78)
     c = np.frombuffer(c.tobytes().lower(), np.uint8).copy()
     rb, re_ = ragged_rows(rows)
-    from bench import BERT_PUNCT, BERT_WS
+    from tools.harness import BERT_PUNCT, BERT_WS
     ws = RegexSplit("remove", lib=hip_lib)
     pu = RegexSplit("isolate", lib=hip_lib)
     wp = WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], lib=hip_lib)

@@ -179,7 +179,8 @@ def test_ragged_to_dense_reference_kats(backend, inp, attr_pad_right, input_pad_
     assert np.array_equal(backend.host(mask), ref_mask)
 
 
-@pytest.mark.parametrize("dtype,inner", [(np.int32, ()), (np.int64, ()), (np.uint8, ()), (np.int32, (3,)), (np.int16, (2, 2))])
+@pytest.mark.parametrize("dtype,inner", [(np.int32, ()), (np.int64, ()), (np.uint8, ()), (np.int32, (3,)), (np.int16, (2, 2)),
+                                         (np.int16, (2,)), (np.uint8, (4,)), (np.uint8, (2, 2))])   # 4-byte cells of several elements
 @pytest.mark.parametrize("pad_right", [True, False])
 def test_ragged_to_dense_shapes(backend, dtype, inner, pad_right):
     rng = np.random.default_rng(5)
@@ -325,7 +326,7 @@ def test_fused_wordpiece_enqueue(gpu_backend):
     backend = gpu_backend
     tok = load_tokenizer("bert_small")
     ws_pat = np.frombuffer(rb"\s+", np.uint8)
-    from bench import BERT_PUNCT
+    from tools.harness import BERT_PUNCT
     pu_pat = np.frombuffer(BERT_PUNCT.encode(), np.uint8)
     consts = list(O.pack_strings(tok["vocab"])) + [np.asarray(tok["unk_id"], np.int32)]
     fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),

@@ -47,8 +47,8 @@ def main():
     rng = np.random.default_rng(seed)
     lib = L.load(ROOT / "tests" / "emu" / "build" / "libovtk_emu.so")
     ws_pat = np.frombuffer(BERT_WS.encode(), np.uint8)
-    import bench
-    pu_pat = np.frombuffer(bench.BERT_PUNCT.encode(), np.uint8)
+    from tools.harness import BERT_PUNCT
+    pu_pat = np.frombuffer(BERT_PUNCT.encode(), np.uint8)
     bad = 0
     for k in range(n):
         vocab, si, words, max_bytes = case(rng)

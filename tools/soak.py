@@ -16,7 +16,11 @@ from tools.harness import BpeTok  # noqa: E402
 from tools.workloads import TextModel, ragged_rows  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
+SEL = set(sys.argv[2].split(",")) if len(sys.argv) > 2 and sys.argv[2] else set()   # modes to run; none named: all but wire-racy
+
+
+def on(*names):
+    return (not SEL and "wire-racy" not in names) or bool(SEL & set(names))
 CAP = int(sys.argv[3]) if len(sys.argv) > 3 else 20000
 
 
@@ -33,7 +37,7 @@ def report(name, r, j, ref, got, mode):
 lib = L.load()
 dev = torch.device("cuda", 0)
 for name, kinds in (("gpt2", ("zipf", "uniform", "mixed")), ("llama3", ("mixed", "zipf"))):
-    if ONLY and name != ONLY:
+    if not on(name):
         continue
     tok = BpeTok.load(name)
     fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**dict(tok.attrs, cache_capacity=CAP), lib=lib))
@@ -84,12 +88,12 @@ for name, kinds in (("gpt2", ("zipf", "uniform", "mixed")), ("llama3", ("mixed",
     print(name, "rounds", rounds, "batches", rounds * len(batches), "bad", bad)
 
 # ---- the fused BERT chain (WordPiece) and the fused detokenizer, two-half calls on three streams
-if not ONLY or ONLY in ("bert", "detok"):
+if on("bert", "detok"):
     from openvino_tokenizers_amd.ops import FusedDetokenizer, FusedSplitWordpiece, VocabDecoder, WordpieceTokenizer
     from tools.harness import BERT_PUNCT, BERT_WS, pack_strings
     from tools.make_tokenizers import load_tokenizer
     streams = [torch.cuda.Stream(dev) for _ in range(3)]
-    if not ONLY or ONLY == "bert":
+    if on("bert"):
         tokw = load_tokenizer("bert")
         ws_pat, pu_pat = np.frombuffer(BERT_WS.encode(), np.uint8), np.frombuffer(BERT_PUNCT.encode(), np.uint8)
         consts = list(pack_strings(tokw["vocab"])) + [np.asarray(tokw["unk_id"], np.int32)]
@@ -123,7 +127,7 @@ if not ONLY or ONLY in ("bert", "detok"):
                     bad += 1
                     report("bert", r, j, refs[j], got, "enqueue")
         print("bert rounds", rounds, "batches", rounds * len(batches), "bad", bad)
-    if not ONLY or ONLY == "detok":
+    if on("detok"):
         tok = BpeTok.load("gpt2")
         V = len(tok.vocab)
         vconst = list(pack_strings(tok.vocab))
@@ -156,7 +160,7 @@ if not ONLY or ONLY in ("bert", "detok"):
         print("detok rounds", rounds, "batches", rounds * len(batches), "bad", bad)
 
 # ---- small batches (the one-launch path: encode_small_kernel, whose last block merges and compacts what the others staged)
-if not ONLY or ONLY == "small":
+if on("small"):
     for name in ("gpt2", "llama3"):
         tok = BpeTok.load(name)
         fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**tok.attrs, lib=lib))
@@ -195,8 +199,7 @@ if not ONLY or ONLY == "small":
 # default-stream fill kernel against them, and with every CU held by the persistent lookup waves of three streams that
 # fill could land after compact_kernel<WireSink> and wipe part of a finished wire (GPUTEST_r02: 1 bad wire in 1 080).
 # "wire-racy" keeps that harness order on purpose, to show the difference; it is not part of the default run.
-if not ONLY or ONLY in ("wire", "wire-racy"):
-    racy = ONLY == "wire-racy"
+for racy in [r for r, m in ((False, "wire"), (True, "wire-racy")) if on(m)]:
     tok = BpeTok.load("gpt2")
     fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**tok.attrs, lib=lib))
     pat = tok.pattern_u8()
@@ -258,7 +261,7 @@ if not ONLY or ONLY in ("wire", "wire-racy"):
     print("wire-racy" if racy else "wire", "rounds", rounds, "batches", rounds * len(batches), "bad", bad)
 
 # ---- a mix of blocking ops taking turns on the pooled workspaces (each op's result against its own first one)
-if not ONLY or ONLY == "ops":
+if on("ops"):
     from openvino_tokenizers_amd.ops import RaggedToDense, VocabEncoder
     from tools.harness import one_string_per_row
     tok = BpeTok.load("gpt2_small")
