@@ -27,6 +27,7 @@ OPENVINO_CREATE_EXTENSIONS(
         std::make_shared<ov::OpExtension<FuzeRagged>>(),
         std::make_shared<ov::OpExtension<SpecialTokensSplit>>(),
         std::make_shared<ov::OpExtension<StringTensorUnpack>>(),
+        std::make_shared<ov::OpExtension<StringTensorPack>>(),
         std::make_shared<ov::OpExtension<Truncate>>(),
         std::make_shared<ov::OpExtension<CombineSegments>>(),
         std::make_shared<ov::OpExtension<UTF8Validate>>(),
@@ -49,6 +50,7 @@ namespace tokenizers {
 OPENVINO_API_C(ov::OutputVector)
 create_tokenizer_node(const std::string& op_type, const ov::OutputVector& inputs, const ov::AnyMap& attributes) {
     if (op_type == "StringTensorUnpack") return std::make_shared<StringTensorUnpack>(inputs)->outputs();
+    if (op_type == "StringTensorPack") return std::make_shared<StringTensorPack>(inputs)->outputs();
     if (op_type == "SpecialTokensSplit") return std::make_shared<SpecialTokensSplit>(inputs)->outputs();
     if (op_type == "RegexSplit")
         return std::make_shared<RegexSplit>(inputs, attr<std::string>(attributes, "behaviour", "remove"), attr<bool>(attributes, "invert", false),

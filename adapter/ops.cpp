@@ -95,9 +95,10 @@ RegexSplit::RegexSplit(const ov::OutputVector& arguments, const std::string& beh
 }
 void RegexSplit::validate_and_infer_types() {
     const size_t n = get_input_size();
-    OPENVINO_ASSERT(n == 6 || n == 7, "RegexSplit: 6 or 7 inputs are supported by this library (the legacy 9-input form with "
-                                      "skip-token strings is not), got ", n);
+    OPENVINO_ASSERT(n == 6 || n == 7 || n == 9, "Incorrect number of inputs passed to RegexSplit: ", n,
+                    "; try to reconvert tokenizer with newer version of OpenVINO Tokenizers");
     expect_ragged_strings(this, "RegexSplit");
+    if (n == 9) expect_strings(this, 6, "RegexSplit skip tokens");
     OPENVINO_ASSERT(m_max_splits == -1 || m_max_splits > 0, "RegexSplit max_splits attribute must be greater then `0` or equal to `-1`, got ",
                     m_max_splits);
     ragged_string_outputs(this, get_input_partial_shape(0));
@@ -106,6 +107,7 @@ void RegexSplit::validate_and_infer_types() {
 std::shared_ptr<ov::Node> RegexSplit::clone_with_new_inputs(const ov::OutputVector& inputs) const {
     auto c = std::make_shared<RegexSplit>(inputs, m_behaviour, m_invert, m_max_splits);
     c->m_state = m_state;  // the compiled pattern is shared (regex_split.hpp:37-40)
+    c->m_skip_set = m_skip_set;
     return c;
 }
 bool RegexSplit::visit_attributes(ov::AttributeVisitor& visitor) {
@@ -116,6 +118,22 @@ bool RegexSplit::visit_attributes(ov::AttributeVisitor& visitor) {
 }
 bool RegexSplit::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
     const bool has_skips = inputs.size() == 7;
+    // The 9-input form of old IRs (regex_split.cpp:102,164-179,235-238): a string that equals one of the "skip tokens"
+    // (inputs 6-8) passes through unsplit.  Membership in that set is the VocabEncoder kernel with the tokens as keys (value
+    // 1, default 0); the flags then play the part of the skips input, and do not become an output.
+    std::vector<uint8_t> legacy_skips;
+    if (inputs.size() == 9 && inputs[6].get_size() > 0 && inputs[4].get_size() > 0) {
+        const std::vector<int32_t> ones(inputs[6].get_size(), 1);
+        ovtk_vocab_encoder* set = ensure(*m_skip_set, ovtk_vocab_encoder_destroy, [&](ovtk_vocab_encoder** out) {
+            const ovtk_vocab_encoder_params p{strings_at(inputs, 6), ones.data(), 4, device()};
+            check(ovtk_vocab_encoder_create(&p, out), "RegexSplit (skip-token set)");
+        });
+        const ovtk_strings strings = strings_at(inputs, 2);
+        std::vector<int32_t> flags(size_t(strings.n), 0);
+        const int32_t none = 0;
+        check(ovtk_vocab_encoder_run(set, &strings, &none, flags.data(), OVTK_MEM_HOST, nullptr), "RegexSplit (skip tokens)");
+        legacy_skips.assign(flags.begin(), flags.end());
+    }
     const ov::Tensor& pattern = inputs[5 + has_skips];
     ovtk_regex_split* h = ensure(*m_state, ovtk_regex_split_destroy, [&](ovtk_regex_split** out) {
         const std::string pat = text_of(pattern);
@@ -130,9 +148,11 @@ bool RegexSplit::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inp
     outputs[2].set_shape(one_dim(cap));
     outputs[3].set_shape(one_dim(cap));
     if (has_skips) outputs[5].set_shape(one_dim(cap));
+    std::vector<uint8_t> dropped_skips(legacy_skips.empty() ? 0 : cap);  // (the library writes a skips tensor whenever it reads one)
     ovtk_ragged_strings_out out{i32(outputs[0]), i32(outputs[1]), 0, i32(outputs[2]), i32(outputs[3]),
-                                has_skips ? u8(outputs[5]) : nullptr, int64_t(cap), 0};
-    check(ovtk_regex_split_run(h, &in, has_skips ? u8(inputs[5]) : nullptr, &out, OVTK_MEM_HOST, nullptr), "RegexSplit");
+                                has_skips ? u8(outputs[5]) : (legacy_skips.empty() ? nullptr : dropped_skips.data()), int64_t(cap), 0};
+    const uint8_t* skips_in = has_skips ? u8(inputs[5]) : (legacy_skips.empty() ? nullptr : legacy_skips.data());
+    check(ovtk_regex_split_run(h, &in, skips_in, &out, OVTK_MEM_HOST, nullptr), "RegexSplit");
     outputs[0].set_shape(one_dim(size_t(out.n_rows)));
     outputs[1].set_shape(one_dim(size_t(out.n_rows)));
     if (out.n < 0) {  // the all-empty batch: the string tensors pass through (regex_split.cpp:129-143)
@@ -619,6 +639,23 @@ bool StringTensorUnpack::evaluate(ov::TensorVector& outputs, const ov::TensorVec
         std::memcpy(outputs[1].data(), offsets + 1, 4 * size_t(n));  // ends
     }
     if (n_chars) std::memcpy(outputs[2].data(), p + 8 + 4 * size_t(n), n_chars);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ StringTensorPack
+StringTensorPack::StringTensorPack(const ov::OutputVector& arguments, const std::string& mode)
+    : ov::op::v15::StringTensorPack(arguments.at(0), arguments.at(1), arguments.at(2)), m_mode(mode) {
+    constructor_validate_and_infer_types();
+}
+void StringTensorPack::validate_and_infer_types() {
+    OPENVINO_ASSERT(m_mode == "begins_ends", "StringTensorPack supports only 'begins_ends' mode, but get ", m_mode);
+    ov::op::v15::StringTensorPack::validate_and_infer_types();
+}
+std::shared_ptr<ov::Node> StringTensorPack::clone_with_new_inputs(const ov::OutputVector& inputs) const {
+    return std::make_shared<StringTensorPack>(inputs, m_mode);
+}
+bool StringTensorPack::visit_attributes(ov::AttributeVisitor& visitor) {
+    visitor.on_attribute("mode", m_mode);
     return true;
 }
 

@@ -10,7 +10,7 @@
 //   ByteFallback          src/byte_fallback.hpp / .cpp         FuzeRagged        src/fuze.hpp / .cpp
 //   SpecialTokensSplit    src/special_tokens_split.hpp / .cpp  Truncate          src/truncate.hpp / .cpp
 //   CombineSegments       src/combine_segments.hpp / .cpp      UTF8Validate      src/utf8_validate.hpp / .cpp
-//   TrieTokenizer         src/trie_tokenizer.hpp / .cpp        StringTensorUnpack / StringTensorPack (u8 wire form)
+//   TrieTokenizer         src/trie_tokenizer.hpp / .cpp        StringTensorUnpack (u8 wire form) / StringTensorPack
 // Device tables are built on the first evaluate() under a mutex and shared by clones, like the reference's lazily built
 // state (bpe_tokenizer.hpp:215-218, regex_split.hpp:37-40).  evaluate() is const and re-entrant: the handles are
 // immutable, every call leases its own workspace inside the library.
@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <openvino/op/op.hpp>
+#include <openvino/op/string_tensor_pack.hpp>
 
 #include "ovtk_amd.h"
 
@@ -63,6 +64,8 @@ private:
     bool m_invert = false;
     int m_max_splits = -1;
     mutable std::shared_ptr<Lazy<ovtk_regex_split>> m_state = std::make_shared<Lazy<ovtk_regex_split>>();
+    // the 9-input form of old IRs: the set of "skip tokens" (inputs 6-8) as a string -> flag map on the device
+    mutable std::shared_ptr<Lazy<ovtk_vocab_encoder>> m_skip_set = std::make_shared<Lazy<ovtk_vocab_encoder>>();
 };
 
 class SpecialTokensSplit : public Base {
@@ -230,6 +233,25 @@ public:
     std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
     bool visit_attributes(ov::AttributeVisitor& visitor) override;
     bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+
+private:
+    std::string m_mode = "begins_ends";
+};
+
+// StringTensorPack of the "extension" opset (src/string_tensor_pack.hpp:13-43; extension list src/ov_extension.cpp:74,
+// factory src/tokenizers_factory.cpp:41-42): in the reference it is nothing but the official opset-15 op under the old
+// type name, kept for IRs written before opset 15 -- its output is an element::string tensor, i.e. std::string objects on
+// the host, and its evaluate() is OpenVINO's own.  Same here: the class exists so that such IRs and GenAI's
+// create_tokenizer_node("StringTensorPack") resolve against this library alone; there is nothing for the GPU in it.  (The
+// packed-u8 wire form, the one that crosses PCIe, is ovtk_string_tensor_pack in the C ABI.)
+class StringTensorPack : public ov::op::v15::StringTensorPack {
+public:
+    OPENVINO_OP("StringTensorPack", "extension", ov::op::v15::StringTensorPack);
+    StringTensorPack() = default;
+    StringTensorPack(const ov::OutputVector& arguments, const std::string& mode = "begins_ends");
+    void validate_and_infer_types() override;
+    std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
+    bool visit_attributes(ov::AttributeVisitor& visitor) override;
 
 private:
     std::string m_mode = "begins_ends";

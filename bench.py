@@ -361,6 +361,97 @@ class Detokenize:
         return ref, time.perf_counter() - t1, n_s * self.S, "VocabDecoder + ByteFallback + FuzeRagged restatement"
 
 
+class DetokenizeFull:
+    """Config 5 as BASELINE states it: ONE batch of `rows` x 2048 ids (1 048 576 rows = 2.1 G ids = 8.6 GB, 9-10 GB of text out),
+    which the reference's int32 char offsets cannot hold in one call (src/vocab_decoder.cpp:62-80).  A step = the whole batch
+    through FusedDetokenizer.evaluate_chunked: row chunks below 2^31 output bytes each, pipelined over three HIP streams."""
+    unit, dtype, metric, dominant_hint = "Mtok/s", "int32/u8", "token ids/s detokenized (seq 2048)", "detokenize"
+
+    def __init__(self, args, lib, dev, rank):
+        from openvino_tokenizers_amd.ops import FusedDetokenizer
+        self.lib, self.dev = lib, dev
+        tok = BpeTok.load(args.tokenizer)
+        self.tok = tok
+        self.rows, self.S = args.rows, 2048
+        V = len(tok.vocab)
+        self.pad = pad = V - 1
+        g = torch.Generator(device=dev)
+        g.manual_seed(3000 + 100 * rank)
+        self.ids = torch.empty((self.rows, self.S), dtype=torch.int32, device=dev)
+        slab = 32768
+        for a in range(0, self.rows, slab):   # in slabs: the int64 draw and the mask of a slab are 0.8 GB of temporaries
+            b = min(a + slab, self.rows)
+            part = torch.randint(0, V - 1, (b - a, self.S), generator=g, device=dev).to(torch.int32)
+            part[torch.rand((b - a, self.S), generator=g, device=dev) < 0.01] = pad
+            self.ids[a:b] = part
+            del part
+        self.vconst = list(pack_strings(tok.vocab))
+        self.dec = VocabDecoder(skip_tokens=[pad], device=dev.index, lib=lib)
+        self.fused = FusedDetokenizer(self.dec, byte_fallback=True)
+        self.n_out, self.chunks = [], []
+        self.n_streams = 3
+        self.sample_rows = 1024
+        self.vocab = V
+        self.first = None
+        self.step(0)   # (sizes the estimate; the caching allocator keeps the chunk buffers for the timed passes)
+        torch.cuda.synchronize()
+        self.workload = (f"config 5: detokenize ONE batch of {self.rows} x {self.S} ids (GPT-2-shaped vocabulary, 1 % skipped special ids) "
+                         f"per GPU and step = {self.rows * self.S} ids in, {self.n_out[0]} bytes of text out, in {self.chunks[0]} row "
+                         f"chunks below 2^31 output bytes each (FusedDetokenizer.evaluate_chunked: ovtk_detokenize_enqueue / _finish, "
+                         f"three HIP streams, two chunks ahead), fused VocabDecoder+ByteFallback+FuzeRagged, inputs and outputs in HBM")
+
+    def units(self, i):
+        return self.rows * self.S
+
+    def step(self, i):
+        total, first = [0], []
+
+        def sink(a, b, cb, ce, cc):
+            total[0] += int(cc.numel())
+            if a == 0:
+                first.append((cb, ce, cc))
+        n = self.fused.evaluate_chunked([self.ids] + self.vconst, sink=sink, streams=self.n_streams, depth=2 if self.n_streams > 1 else 0)
+        self.n_out.append(total[0])
+        self.chunks.append(n)
+        self.first = first[0]
+        return self.first
+
+    def algo(self):
+        return float(np.mean([4 * self.rows * self.S + n + 8 * self.rows for n in self.n_out]))
+
+    def mean_out(self):
+        return float(np.mean(self.n_out))
+
+    def _chain(self, ids):
+        from oracle import oracle as O
+        r = O.vocab_decoder(ids, self.tok.vocab, [self.pad])
+        bf = O.byte_fallback(*r[2:5])
+        fz = O.fuze(r[0], r[1], bf[0], bf[1])
+        return fz[0], fz[1], bf[2]
+
+    def cpu_sample(self, n_s):
+        ids = self.ids[:n_s].cpu().numpy()
+        ref = self._chain(ids[:16])
+        t1 = time.perf_counter()
+        self._chain(ids)
+        return ref, time.perf_counter() - t1, n_s * self.S, "VocabDecoder + ByteFallback + FuzeRagged restatement"
+
+    def parity_per_chunk(self, n_rows=8):
+        """The first rows of EVERY chunk against the oracle chain (one more, untimed pass)."""
+        ok, seen = [], []
+
+        def sink(a, b, cb, ce, cc):
+            n = min(n_rows, b - a)
+            rb, re_, rc = self._chain(self.ids[a:a + n].cpu().numpy())
+            e = ce[:n].cpu().numpy()
+            ok.append(bool(np.array_equal(cb[:n].cpu().numpy(), rb) and np.array_equal(e, re_) and
+                           np.array_equal(cc[: int(e[-1])].cpu().numpy(), rc[: int(re_[-1])])))
+            seen.append((a, b, int(cc.numel())))
+        self.fused.evaluate_chunked([self.ids] + self.vconst, sink=sink)
+        return {"chunks": len(ok), "all_bit_exact": bool(all(ok)), "rows_checked_per_chunk": n_rows,
+                "chunk_rows_and_bytes": seen, "max_chunk_bytes": max(x[2] for x in seen), "limit": (1 << 31) - 2}
+
+
 class RaggedToDenseBench:
     """a7 at config-2 size: the ragged ids of a config-2 batch -> input_ids [rows, T] + attention mask, T = longest row."""
     unit, dtype, metric, dominant_hint = "GB/s", "int32/u8", "algorithmic GB/s (RaggedToDense, config-2 ids)", "ragged_to_dense"
@@ -743,6 +834,8 @@ def main():
     affinity0, numa_note = bind_to_gpu_numa_node(dev)
     lib = L.load(args.lib)
     special = {"5": Detokenize, "r2d": RaggedToDenseBench, "vocab_encoder": VocabEncoderBench, "1": SmallBatchLatency}
+    if args.config == "5" and args.rows > 131072:   # more than one int32-offset call can hold: the chunk loop
+        special["5"] = DetokenizeFull
     wl = special[args.config](args, lib, dev, rank) if args.config in special else make_workload(args, lib, dev, rank)
     is_encode = isinstance(wl, EncodeWorkload)
     two_half = hasattr(wl, "enqueue") and not args.sync
@@ -850,14 +943,18 @@ def main():
         if not args.no_alone_leg:
             lib.ovtk_profile_reset()
             lib.ovtk_profile_enable(1)
-            n_leg = 24
+            n_leg = 24 if not isinstance(wl, DetokenizeFull) else 3
+            if hasattr(wl, "n_streams"):
+                wl.n_streams = 1   # (a workload that pipelines inside a step: its chunks one after the other)
             for i in range(n_leg):
                 (wl.enqueue(i, stream_ptrs[0])() if two_half else wl.step(i))
             torch.cuda.synchronize()
+            if hasattr(wl, "n_streams"):
+                wl.n_streams = 3
             lib.ovtk_profile_enable(0)
             alone = {k: v for k, v in profile_table(lib).items() if v[1]}
         src = alone or prof
-        n_src = 24 if alone else n_prof
+        n_src = n_leg if alone else n_prof
         hint = getattr(wl, "dominant_hint", None)
         per_launch = {k: v[0] / v[1] for k, v in src.items()}
         per_step_src = {k: v[0] / n_src for k, v in src.items()}
@@ -879,7 +976,7 @@ def main():
                     "bytes_note": ("algorithmic bytes of the whole pass (SURVEY 8d) over the dominant kernel's own time.  For the encode "
                                    "configurations that kernel reads all the text and stages all ids but those of the deferred pieces, "
                                    "so its own algorithmic bytes are the same figure within ~5 %; `step` prices every kernel of the path"),
-                    "measured": ("one-stream leg of 24 batches behind the timed region (every kernel alone on the chip)" if alone
+                    "measured": (f"one-stream leg of {n_leg} batches behind the timed region (every kernel alone on the chip)" if alone
                                  else "the timed loop's own launches"),
                     "one_stream_kernel_ms": {k: round(v, 4) for k, v in sorted(per_launch.items())},
                     "one_stream_kernel_sum_ms_per_step": round(sum(per_step_src.values()), 4)}
@@ -974,6 +1071,7 @@ def main():
                                                                     f"gather overlapped with the next encode, unpack one batch later ({exchange.regathers} re-gathers)"))},
         "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all, "stress": stress, "end_to_end": e2e,
         "parity_prefix_bit_exact": parity,
+        "parity_per_chunk": (wl.parity_per_chunk() if hasattr(wl, "parity_per_chunk") and world == 1 and not args.no_cpu_baseline else None),
         "kernel_ms": kernels,
     }
     if hasattr(wl, "memo"):

@@ -84,7 +84,13 @@ typedef struct ovtk_ragged_i32_out {
  * Replaces RegexSplit::evaluate, src/regex_split.cpp:124-324 (+ PCRE2Wrapper::match, src/utils.cpp:396-420).
  * The pattern is not interpreted by PCRE2 on the device: create() recognises the pattern families the
  * reference's converter emits (python/openvino_tokenizers/tokenizer_pipeline.py:392-457) and selects a
- * hand-written gfx950 scanner with identical results; any other pattern is OVTK_E_UNSUPPORTED.
+ * hand-written gfx950 scanner with identical results; any other pattern is compiled into a leftmost-first DFA
+ * (csrc/regex_compile.cpp: the PCRE2 subset listed in regex_compile.hpp -- classes, \p{..} by General_Category,
+ * groups, alternation, greedy / lazy / possessive repeats, anchors, one-character look-around) and run one lane
+ * per row; only constructs outside that subset (back-references, atomic groups, recursion, script properties ...)
+ * are OVTK_E_UNSUPPORTED -- never an approximation, never a CPU fallback.  A split that the fused encode has no
+ * scanner for (compiled DFA, class patterns, max_splits) runs as its own pass inside ovtk_encode_* and the host
+ * waits once for the piece count: ovtk_encode_enqueue / _host / _wire block for that pass with such patterns.
  * Inputs 0-4 (+5 skips) of the op = `in` (+ `skips`); input "pattern" and attributes = params. */
 typedef struct ovtk_regex_split_params {
     const char* pattern;
@@ -192,7 +198,8 @@ int ovtk_encode_finish(ovtk_pending* pending, ovtk_ragged_i32_out* out);
 /* The two halves for HOST buffers -- what a CPU-plugin evaluate() holds (every input of BPETokenizer::evaluate is a host
  * tensor, src/bpe_tokenizer.cpp:122-140).  enqueue puts the copies of the inputs to the device and the kernels on
  * `stream` and returns; finish (ovtk_encode_finish) returns when begins / ends and exactly n_data ids are in the caller's
- * buffers.  With PINNED buffers (hipHostMalloc / hipHostRegister) nothing blocks in between: the input copies are
+ * buffers.  With PINNED buffers (hipHostMalloc / hipHostRegister) and a split pattern the fused scanners cover (the
+ * GPT-2 / Llama-3 families; see RegexSplit above for the others) nothing blocks in between: the input copies are
  * asynchronous, and the output buffers are written by the last kernel itself through their device-side addresses (no
  * device-to-host copy; finish only waits for the call's event) -- a host that keeps a few batches in flight on different
  * streams runs the host-to-device copies of the next batches under the kernels and PCIe stores of this one.  Pageable
@@ -409,13 +416,18 @@ typedef struct {
 int ovtk_encode_tail_run(const ovtk_encode_tail_params* p, int32_t* out_ids, uint8_t* out_mask, int32_t* out_type_ids,
                          int64_t out_capacity, int32_t* out_target_dim, int mem, int device, void* stream);
 
-/* Fused VocabDecoder -> [ByteFallback] -> FuzeRagged (tokenizer_pipeline.py:1321-1371): one string per row. */
+/* Fused VocabDecoder -> [ByteFallback] -> FuzeRagged (tokenizer_pipeline.py:1321-1371): one string per row.
+ * Offsets are int32 as in the reference (src/vocab_decoder.cpp:62-63,69,80 count chars in int32): a call whose output would
+ * not fit out->chars_capacity (at most 2^31 - 2 bytes) returns OVTK_E_CAPACITY with out->n_chars = the bytes it needs
+ * (INT32_MAX: beyond int32).  Batches of that size -- BASELINE config 5, 1 M x 2 048 ids = 8-9 GB of text -- are cut into
+ * row chunks by the caller; the Python mirror's FusedDetokenizer.evaluate_chunked() is that loop (chunks pipelined over
+ * HIP streams with the two-half form below, an overflowing chunk is cut again). */
 int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len,
                         const int32_t* skip_tokens_input, int64_t n_skip_tokens_input, int byte_fallback,
                         ovtk_strings_out* out, int mem, void* stream);
 /* ovtk_detokenize_run in two halves for device buffers (OVTK_MEM_DEVICE), like ovtk_encode_enqueue / ovtk_encode_finish:
- * enqueue launches the passes on `stream` and returns; finish waits for that call (its own event), fills out->n_chars or
- * reports OVTK_E_CAPACITY, and releases `pending` whatever happens.  Calls in flight are independent. */
+ * enqueue launches the passes on `stream` and returns; finish waits for that call (its own event), fills out->n_chars (on
+ * OVTK_E_CAPACITY: the bytes the call needs), and releases `pending` whatever happens.  Calls in flight are independent. */
 int ovtk_detokenize_enqueue(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch, int64_t seq_len, const int32_t* skip_in,
                             int64_t n_skip_in, int byte_fallback, ovtk_strings_out* out, void* stream, ovtk_pending** pending);
 int ovtk_detokenize_finish(ovtk_pending* pending, ovtk_strings_out* out);

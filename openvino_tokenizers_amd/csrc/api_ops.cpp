@@ -572,10 +572,10 @@ int ovtk_detokenize_run(ovtk_vocab_decoder* h, const int32_t* ids, int64_t batch
             return rc;
     }
     if (int rc = finish_status(*ws.ws, s)) return rc;
+    out->n_chars = ws->host_status->n_out;  // (on E_CAPACITY: what the call needs, INT32_MAX = more than int32 offsets reach)
     if (ws->host_status->flags & kFlagOutCapacity)
         return set_error(OVTK_E_CAPACITY, "detokenize: output chars buffer too small or beyond int32 offsets (" +
                                               std::to_string(ws->host_status->n_out) + " bytes needed)");
-    out->n_chars = ws->host_status->n_out;
     int e = 0;
     e = e ? e : copy_back(out->begins, d_b, size_t(batch) * 4, mem, s);
     e = e ? e : copy_back(out->ends, d_e, size_t(batch) * 4, mem, s);
@@ -596,10 +596,10 @@ struct DetokRun final : ovtk::PendingStrings {
         ws->marks.settled();
         Profiler::get().resolve(ws->marks);
         OVTK_HIP(hipGetLastError());
+        out->n_chars = ws->host_status->n_out;  // (on E_CAPACITY: what the call needs, INT32_MAX = more than int32 offsets reach)
         if (ws->host_status->flags & kFlagOutCapacity)
             return set_error(OVTK_E_CAPACITY, "detokenize: output chars buffer too small or beyond int32 offsets (" +
                                                   std::to_string(ws->host_status->n_out) + " bytes needed)");
-        out->n_chars = ws->host_status->n_out;
         return OVTK_OK;
     }
 };

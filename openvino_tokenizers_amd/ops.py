@@ -129,9 +129,29 @@ class RegexSplit(_Op):
         p = L.RegexSplitParams(pat, len(pat), self.behaviour.encode(), int(self.invert), self.max_splits, self.device)
         self._chk(self._lib.ovtk_regex_split_create(C.byref(p), C.byref(self._h)))
 
+    def _legacy_skips(self, inputs):
+        """The 9-input form of old IRs (regex_split.cpp:102, 164-179, 235-238): inputs 6-8 are a string tensor of "skip
+        tokens"; a string that EQUALS one of them passes through unsplit.  That is a set-membership flag per string -- the
+        VocabEncoder kernel with the skip tokens as keys (value 1, default 0) --, and from there on the op is the 7-input
+        form; the flags do not become an output (the legacy form has five)."""
+        if not hasattr(self, "_skip_set"):
+            n_keys = len(_host(inputs[6], np.int32))
+            self._skip_set = VocabEncoder(self.device, self._lib) if n_keys else None
+            self._skip_consts = list(inputs[6:9]) + [np.ones(n_keys, np.int32), np.zeros((), np.int32)]
+        if self._skip_set is None:
+            return None
+        (flags,) = self._skip_set.evaluate(list(inputs[2:5]) + self._skip_consts)
+        return flags != 0
+
     def evaluate(self, inputs):
+        if len(inputs) == 9:
+            skips = self._legacy_skips(inputs)
+            if skips is None:
+                return self.evaluate(list(inputs[:6]))
+            return self.evaluate(list(inputs[:5]) + [skips, inputs[5]])[:5]
         if len(inputs) not in (6, 7):
-            raise L.OvtkError(L.E_ARG, f"Incorrect number of inputs passed to RegexSplit: {len(inputs)}")
+            raise L.OvtkError(L.E_ARG, f"Incorrect number of inputs passed to RegexSplit: {len(inputs)}; try to reconvert tokenizer "
+                                       "with newer version of OpenVINO Tokenizers")
         has_skips = len(inputs) == 7
         self._ensure(inputs[5 + has_skips])
         m = _Mem(inputs[4])
@@ -486,6 +506,7 @@ class VocabDecoder(_Op):
         vocab = _strings_struct(*inputs[1:4], keep)
         lens = keep[1] - keep[0]
         self.max_token_len = int(lens.max()) if len(lens) else 0
+        self.mean_token_len = float(lens.mean()) if len(lens) else 0.0
         skip = np.asarray(self.skip_tokens, np.int32)
         p = L.VocabDecoderParams(vocab, skip.ctypes.data if len(skip) else None, len(skip), self.device)
         self._chk(self._lib.ovtk_vocab_decoder_create(C.byref(p), C.byref(self._h)))
@@ -835,6 +856,129 @@ class FusedDetokenizer:
             d._chk(d._lib.ovtk_detokenize_finish(pending, C.byref(out)))
             return [ob[:B], oe[:B], oc[:out.n_chars]]
         return ticket
+
+
+    def evaluate_chunked(self, inputs, chunk_chars=(1 << 31) - 2, bytes_per_id=None, streams=3, depth=2, sink=None):
+        """ids [B, S] of ANY size -> one string per row, in row chunks (BASELINE config 5: 1 M x 2 048 ids are 8-9 GB of text).
+        The reference counts chars in int32 (src/vocab_decoder.cpp:62-63,69,80), so one VocabDecoder call cannot hold more
+        than 2^31 bytes: the batch is cut into chunks of consecutive rows whose output stays below `chunk_chars`, each
+        chunk is one ovtk_detokenize_enqueue on one of `streams` HIP streams, `depth` chunks ahead of the one being
+        completed (host arrays: one blocking ovtk_detokenize_run per chunk).  Rows per chunk come from an estimate of
+        the output bytes per id (`bytes_per_id`, default: the vocabulary's mean token length; refined with every
+        completed chunk); a chunk that overflows its buffer all the same is reported by the library with the size it
+        needs (OVTK_E_CAPACITY) and is cut again.  Returns the chunks in row order as (row_begin, row_end, begins, ends,
+        chars) -- begins / ends int32 offsets into that chunk's own chars -- or, with `sink`, hands each one to
+        sink(row_begin, row_end, begins, ends, chars) as it completes and returns the number of chunks (the tensors may be
+        dropped or reused by the caller; nothing else keeps them)."""
+        d = self.decoder
+        d._ensure(inputs)
+        ids = inputs[0]
+        B, S = int(ids.shape[0]), int(ids.shape[1])
+        tail = list(inputs[1:])
+        chunk_chars = int(min(chunk_chars, (1 << 31) - 2))
+        est = float(bytes_per_id) if bytes_per_id else max(d.mean_token_len, 0.25)
+        row_cap = max(1, ((1 << 31) - 2) // max(S, 1))   # batch * seq_len must fit int32 as well (vocab_decoder.cpp:45-46)
+        m0 = _Mem(ids)
+        side = [m0.t.cuda.Stream(m0.device) for _ in range(max(int(streams), 1))] if m0.torch else []
+        done, inflight, n_launched = [], [], 0
+        self.chunk_log = []   # (row_begin, row_end, capacity, bytes or None when it overflowed): how the batch was cut
+        lo, pending_rows = 0, []   # pending_rows: re-cut chunks (row ranges) that go before the rest of the batch
+
+        def next_range():
+            nonlocal lo
+            if pending_rows:
+                return pending_rows.pop(0)
+            if lo >= B:
+                return None
+            rows = int(chunk_chars / (max(S, 1) * est * 1.08)) if S else B
+            rows = max(1, min(rows, row_cap, B - lo))
+            r = (lo, lo + rows)
+            lo += rows
+            return r
+
+        def launch(r):
+            nonlocal n_launched
+            a, b = r
+            cap = int(min(chunk_chars, (b - a) * S * est * 1.12 + 4096))
+            part = [ids[a:b]] + tail
+            if m0.torch:
+                st = side[n_launched % len(side)]
+                st.wait_stream(m0.t.cuda.current_stream(m0.device))   # the ids were produced on the caller's stream
+                with m0.t.cuda.stream(st):
+                    m, pids, nb, _, pskip, nskip, _ = d._prep(part, cap)
+                    ob, pob = m.alloc(nb, "i32")
+                    oe, poe = m.alloc(nb, "i32")
+                    oc, poc = m.alloc(cap, "u8")
+                    out = L.StringsOut(pob, poe, poc, cap, 0)
+                    pend = C.c_void_p()
+                    d._chk(d._lib.ovtk_detokenize_enqueue(d._h, pids, C.c_int64(nb), C.c_int64(S), pskip, C.c_int64(nskip),
+                                                          int(self.byte_fallback), C.byref(out), m.stream, C.byref(pend)))
+                n_launched += 1
+                return (r, cap, m, ob, oe, oc, out, pend, st)
+            m, pids, nb, _, pskip, nskip, _ = d._prep(part, cap)
+            ob, pob = m.alloc(nb, "i32")
+            oe, poe = m.alloc(nb, "i32")
+            oc, poc = m.alloc(cap, "u8")
+            out = L.StringsOut(pob, poe, poc, cap, 0)
+            rc = d._lib.ovtk_detokenize_run(d._h, pids, C.c_int64(nb), C.c_int64(S), pskip, C.c_int64(nskip),
+                                            int(self.byte_fallback), C.byref(out), m.mem, m.stream)
+            n_launched += 1
+            return (r, cap, m, ob, oe, oc, out, rc, None)
+
+        def complete(item):
+            nonlocal est
+            (a, b), cap, m, ob, oe, oc, out, pend, st = item
+            rc = d._lib.ovtk_detokenize_finish(pend, C.byref(out)) if st is not None else pend
+            if rc == L.E_CAPACITY:
+                need = int(out.n_chars)
+                self.chunk_log.append((a, b, cap, None))
+                if b - a == 1 and cap >= chunk_chars:
+                    d._chk(rc)   # one row alone is beyond the chunk size: nothing to cut
+                # cut again: as many pieces as the reported need asks for (at least two); the estimate learns from it
+                if 0 < need < (1 << 31) - 1:
+                    est = max(est, need / max((b - a) * S, 1))
+                parts = max(2, -(-need // max(int(chunk_chars / 1.08), 1))) if need < (1 << 31) - 1 else 2
+                parts = min(parts, b - a) if b - a > 1 else 1
+                step = -(-(b - a) // parts)
+                pending_rows[:0] = [(x, min(x + step, b)) for x in range(a, b, step)]
+                return
+            d._chk(rc)
+            n = int(out.n_chars)
+            self.chunk_log.append((a, b, cap, n))
+            if (b - a) * S:
+                est = 0.5 * est + 0.5 * max(n / ((b - a) * S), 0.25)
+            res = (a, b, ob[:b - a], oe[:b - a], oc[:n])
+            if st is not None:
+                m0.t.cuda.current_stream(m0.device).wait_stream(st)   # (finish() waited on the host; this orders later device work)
+            if sink is not None:
+                sink(*res)
+                done.append(None)
+            else:
+                done.append(res)
+
+        # Chunks complete in launch order, so `done` is in row order as long as a re-cut chunk is relaunched before anything
+        # behind it completes: on an overflow everything in flight behind it is completed first only AFTER its pieces --
+        # simplest: drain the pipeline, relaunch the pieces, go on.
+        while True:
+            r = next_range()
+            if r is None and not inflight:
+                break
+            if r is not None:
+                inflight.append(launch(r))
+            while inflight and (len(inflight) > depth or r is None or not m0.torch):
+                item = inflight.pop(0)
+                before = len(pending_rows)
+                complete(item)
+                if len(pending_rows) > before and inflight:   # overflow: what was launched behind it is redone after its pieces
+                    redo = [it[0] for it in inflight]
+                    for it in inflight:
+                        if it[8] is not None:
+                            d._lib.ovtk_detokenize_finish(it[7], C.byref(it[6]))   # (result dropped)
+                    inflight.clear()
+                    pending_rows.extend(redo)
+                    pending_rows.sort()
+                    break
+        return len(done) if sink is not None else done
 
 
 class FusedSplitWordpiece:

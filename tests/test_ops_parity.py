@@ -256,6 +256,49 @@ def test_vocab_decoder_chain(backend, B, S):
         assert_same(list(ref_plain) + [ref[4]], fused2, backend.host, "fused detokenizer")
 
 
+@pytest.mark.parametrize("bytes_per_id", [None, 0.4])
+def test_detokenize_chunked(backend, bytes_per_id):
+    """FusedDetokenizer.evaluate_chunked: the caller's loop over row chunks that BASELINE config 5 needs (the reference
+    counts chars in int32, src/vocab_decoder.cpp:62-80) -- at a chunk size small enough to see it work: at least three
+    chunks, every chunk below the limit, a deliberately low estimate so that a chunk overflows its buffer and is cut
+    again; the chunks back to back are the oracle chain's strings."""
+    vocab, n_base = detok_vocab()
+    V = len(vocab)
+    B, S = (90, 48) if backend.name == "emu" else (3000, 96)
+    limit = 6000 if backend.name == "emu" else 300_000
+    ids = np.random.default_rng(31).integers(-1, V + 1, (B, S)).astype(np.int32)
+    ids[B // 3] = 5                      # a row of short tokens next to ...
+    ids[B // 3 + 1] = n_base - 1         # ... a row of one long token: the estimate is wrong for both
+    inputs = backend.data([ids]) + list(pack_strings(vocab))
+    fused = FusedDetokenizer(VocabDecoder(skip_tokens=[3, 17], lib=backend.lib), byte_fallback=True)
+    chunks = fused.evaluate_chunked(inputs, chunk_chars=limit, bytes_per_id=bytes_per_id)
+    r = O.vocab_decoder(ids, vocab, [3, 17])
+    bf = O.byte_fallback(*r[2:5])
+    fb, fe = O.fuze(r[0], r[1], bf[0], bf[1])
+    want = O.unpack_strings(fb, fe, bf[2])
+    got, at = [], 0
+    for a, b, cb, ce, cc in chunks:
+        assert a == at and b > a
+        at = b
+        cb, ce, cc = backend.host(cb), backend.host(ce), backend.host(cc)
+        assert len(cc) <= limit and cb[0] == 0 and ce[-1] == len(cc) and np.all(cb[1:] == ce[:-1])
+        got += O.unpack_strings(cb, ce, cc)
+    assert at == B and got == want
+    assert len(chunks) >= 3
+    overflowed = [c for c in fused.chunk_log if c[3] is None]
+    if bytes_per_id:
+        assert overflowed, "the low estimate must have produced a chunk that was cut again"
+    # with a sink nothing is kept: the chunks arrive in row order
+    seen = []
+    n = fused.evaluate_chunked(inputs, chunk_chars=limit, bytes_per_id=bytes_per_id,
+                               sink=lambda a, b, cb, ce, cc: seen.append((a, b, len(backend.host(cc)))))
+    assert n == len(seen) and [x[:2] for x in seen] == [c[:2] for c in chunks] and sum(x[2] for x in seen) == len(bf[2])
+    # one row that alone exceeds the chunk size cannot be cut
+    with pytest.raises(L.OvtkError) as ei:
+        fused.evaluate_chunked(inputs, chunk_chars=40)
+    assert ei.value.code == L.E_CAPACITY
+
+
 def test_detokenize_enqueue_finish(gpu_backend):
     """ovtk_detokenize_enqueue / ovtk_detokenize_finish: several calls in flight on two streams (per-call skip lists
     build their own tables in the call's workspace), each equals the oracle chain; a chars buffer that is too small

@@ -223,3 +223,27 @@ def test_reference_regex_split_kats(backend, text, expected, layer):
         raise
     got = tuple(s.decode("utf-8") for s in O.unpack_strings(*[backend.host(x) for x in out[2:5]]))
     assert got == expected
+
+
+@pytest.mark.parametrize("pattern,behaviour", [(GPT2_PATTERN, "isolate"), (r"\s+", "remove")])
+def test_legacy_nine_input_form(backend, pattern, behaviour):
+    """RegexSplit of old IRs (regex_split.cpp:102,164-179,235-238): inputs 6-8 hold "skip tokens"; a string that EQUALS one
+    passes through unsplit, everything else is split; five outputs.  Expected value: the oracle given the membership flags as
+    its skips input (the same pass-through branch, :231-238)."""
+    from tests.util import pack_strings
+    rows = [["<s>", "hello world", "</s>"], ["<s> x", "", "<mask>"], ["</s>", "</s> ", "don't <s>"], []]
+    skip_tokens = ["<s>", "</s>", "<mask>", "<s>"]
+    flat = [s for r in rows for s in r]
+    b, e, c = pack_strings(flat)
+    rends = np.cumsum([len(r) for r in rows]).astype(np.int32)
+    rbeg = (rends - np.asarray([len(r) for r in rows], np.int32)).astype(np.int32)
+    pat = np.frombuffer(pattern.encode(), np.uint8)
+    flags = np.asarray([s in set(skip_tokens) for s in flat])
+    ref = O.RegexSplit(pattern, behaviour)(rbeg, rends, b, e, c, skips=flags)
+    got = RegexSplit(behaviour, lib=backend.lib).evaluate(backend.data([rbeg, rends, b, e, c]) + [pat] + list(pack_strings(skip_tokens)))
+    assert len(got) == 5
+    assert_same(list(ref[:4]), got[:4], backend.host, "RegexSplit, 9 inputs")
+    # no skip tokens: plain six-input behaviour
+    ref0 = O.RegexSplit(pattern, behaviour)(rbeg, rends, b, e, c)
+    got0 = RegexSplit(behaviour, lib=backend.lib).evaluate(backend.data([rbeg, rends, b, e, c]) + [pat] + list(pack_strings([])))
+    assert_same(list(ref0[:4]), got0[:4], backend.host, "RegexSplit, 9 inputs, empty skip set")
