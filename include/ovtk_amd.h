@@ -172,6 +172,16 @@ void ovtk_bpe_destroy(ovtk_bpe* h);
  * cache_capacity -- the size() of the reference's m_cache, bpe_tokenizer.hpp:150, which the reference does not expose).
  * Waits for the device. */
 int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned);
+/* The memo's second level, the piece store: what a handle had to MERGE once (a piece of up to 31 bytes that came to at most 15
+ * ids -- 7 when an id needs more than 16 bits) is filed in a table of the handle's own and found there by every later call
+ * before any merging starts: one table probe instead of the chain of dependent merge-table lookups.  Like the reference's
+ * cache it is pure memoisation -- results are identical with any capacity, any history, and without it -- but it is sized by
+ * this library, not by cache_capacity: that attribute bounds the host memory of the reference's std::string cache, an entry
+ * here is 64 bytes of HBM.  cache_capacity == 0 still means "no memo at all".  `entries`: capacity of the store of handles
+ * created afterwards (default 131072; 0 = no store: the memo is then exactly the reference's cache_capacity entries).
+ * Process-wide; ovtk_bpe_store_entries reports a handle's count (waits for the device). */
+int ovtk_set_memo_store(int64_t entries);
+int ovtk_bpe_store_entries(ovtk_bpe* h, int64_t* stored, int64_t* capacity);
 
 /* Fused RegexSplit -> BPETokenizer (the sub-graph tokenizer_pipeline.py:1613-1631 builds for byte-level BPE
  * models): same result as ovtk_regex_split_run followed by ovtk_bpe_run on its outputs, without the piece

@@ -57,13 +57,20 @@ int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks) {
 struct ovtk_bpe {
     int device = 0;
     BpeDev dev{};
-    DevBuf root, edges, merges, new_id, bf, pieces, memo_room;
+    DevBuf root, edges, merges, new_id, bf, pieces, memo_room, store, store_room;
+    int32_t store_capacity = 0;  // entries the piece store may take
     size_t memo_entries = 0;
     int32_t memo_capacity = 0;  // entries the device may add (cache_capacity)
     bool narrow_ids = false;  // every token id < 65536: merge_kernel keeps ids as u16 in LDS
 };
 
 namespace {
+// Entries the piece store (tables.hpp) of handles created from now on may take; 0: no store.  Process-wide, like
+// ovtk_set_row_tickets: the reference's attribute list has no room for it (cache_capacity keeps its meaning: 0 = no memo at all).
+std::atomic<int64_t>& memo_store_entries() {
+    static std::atomic<int64_t> v{131072};
+    return v;
+}
 int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                ovtk_ragged_i32_out* out, int mem, void* stream);
 
@@ -98,6 +105,21 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     OVTK_HIP(hipStreamSynchronize(nullptr));
     h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>()};
     h->memo_entries = host.stored;
+    // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.  Two candidate slots per piece
+    // and no relocation on the device, so the table is kept below a third full.
+    // (no more than a few entries per vocabulary token: a 3 000-token test vocabulary does not need 32 MiB of table)
+    const int64_t want = std::min<int64_t>({memo_store_entries().load(std::memory_order_relaxed), int64_t(1) << 22,
+                                            std::max<int64_t>(8192, 4 * V)});
+    if (want > 0) {
+        const uint32_t slots = std::max<uint32_t>(1024, pow2_at_least(uint64_t(want) * 3));
+        if (int rc = h->store.ensure(size_t(slots) * sizeof(StoreEntry))) return rc;
+        OVTK_HIP(hipMemset(h->store.as<void>(), 0, size_t(slots) * sizeof(StoreEntry)));
+        const int32_t sroom = int32_t(want);
+        if (int rc = h->store_room.upload(&sroom, sizeof sroom)) return rc;
+        OVTK_HIP(hipStreamSynchronize(nullptr));
+        h->store_capacity = sroom;
+        h->dev.store = PieceStoreDev{h->store.as<StoreEntry>(), 32u - log2u(slots), h->store_room.as<int32_t>(), h->narrow_ids ? 1 : 0};
+    }
     return OVTK_OK;
 }
 }  // namespace
@@ -342,6 +364,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     d.merges = h->merges.as<MergeBucket>();
     d.bucket_shift = host.bucket_shift;
     d.pieces = PieceTableDev{nullptr, 30};
+    d.store = PieceStoreDev{nullptr, 30, nullptr, 0};
     d.new_id = h->new_id.as<int32_t>();
     d.byte_fallback_id = h->bf.as<int32_t>();
     d.unk_id = host.unk_id;
@@ -368,6 +391,25 @@ int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned) {
     OVTK_HIP(hipDeviceSynchronize());
     OVTK_HIP(hipMemcpy(&room, h->dev.pieces.room, sizeof room, hipMemcpyDeviceToHost));
     *learned = h->memo_capacity - std::max<int32_t>(room, 0);
+    return OVTK_OK;
+}
+
+int ovtk_set_memo_store(int64_t entries) {
+    if (entries < 0 || entries > (int64_t(1) << 22)) return set_error(OVTK_E_ARG, "memo store: 0 (off) .. 4194304 entries");
+    memo_store_entries().store(entries, std::memory_order_relaxed);
+    return OVTK_OK;
+}
+
+int ovtk_bpe_store_entries(ovtk_bpe* h, int64_t* stored, int64_t* capacity) {
+    if (!h || !stored || !capacity) return set_error(OVTK_E_ARG, "null argument");
+    *stored = 0;
+    *capacity = h->store_capacity;
+    if (!h->dev.store.room) return OVTK_OK;
+    if (int rc = use_device(h->device)) return rc;
+    int32_t room = 0;
+    OVTK_HIP(hipDeviceSynchronize());
+    OVTK_HIP(hipMemcpy(&room, h->dev.store.room, sizeof room, hipMemcpyDeviceToHost));
+    *stored = h->store_capacity - std::max<int32_t>(room, 0);
     return OVTK_OK;
 }
 

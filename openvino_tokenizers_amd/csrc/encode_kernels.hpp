@@ -267,6 +267,90 @@ __device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, 
     return memo_resolve(memo_fetch(P, k0, k1), k0, k1, tok);
 }
 
+// ---- the piece store (tables.hpp): the memo's second level, merge_kernel's own ------------------------------------
+// Key of a piece of 1..15 bytes from its first-level key halves (k1 carries the length in its top byte).
+__device__ __forceinline__ void store_key_short(uint64_t k0, uint64_t k1, int len, uint32_t (&key)[8]) {
+    key[0] = uint32_t(k0);
+    key[1] = uint32_t(k0 >> 32);
+    key[2] = uint32_t(k1);
+    key[3] = uint32_t(k1 >> 32) & 0x00FFFFFFu;
+    key[4] = key[5] = key[6] = 0;
+    key[7] = uint32_t(len) << 24;
+}
+// Key of a piece of 16..31 bytes: its bytes come from the text (a deferred entry carries 15).
+__device__ __forceinline__ void store_key_long(const uint8_t* p, int len, uint32_t (&key)[8]) {
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = 4 * w + b;
+            if (i < kStoreKeyBytes && i < len) v |= uint32_t(p[i]) << (8 * b);
+        }
+        key[w] = v;
+    }
+    key[7] |= uint32_t(len) << 24;
+}
+__device__ __forceinline__ bool store_key_eq(const uint4& a, const uint4& b, const uint32_t (&key)[8]) {
+    return a.x == key[0] && a.y == key[1] && a.z == key[2] && a.w == key[3] && b.x == key[4] && b.y == key[5] && b.z == key[6] &&
+           b.w == key[7];
+}
+// -> id count and the payload, or -1.  Both candidates are fetched together (eight independent 16-byte loads).
+template <bool NARROW>
+__device__ __forceinline__ int store_lookup(const PieceStoreDev& S, const uint32_t (&key)[8], uint32_t (&pay)[8]) {
+    const uint32_t mix = store_mix(key);
+    const uint4* e0 = reinterpret_cast<const uint4*>(S.slots + store_h(mix, 0, S.shift));
+    const uint4* e1 = reinterpret_cast<const uint4*>(S.slots + store_h(mix, 1, S.shift));
+    const uint4 a0 = e0[0], a1 = e0[1], a2 = e0[2], a3 = e0[3];
+    const uint4 b0 = e1[0], b1 = e1[1], b2 = e1[2], b3 = e1[3];
+    const bool m0 = store_key_eq(a0, a1, key), m1 = store_key_eq(b0, b1, key);
+    const uint4 p0 = m1 ? b2 : a2, p1 = m1 ? b3 : a3;
+    pay[0] = p0.x; pay[1] = p0.y; pay[2] = p0.z; pay[3] = p0.w;
+    pay[4] = p1.x; pay[5] = p1.y; pay[6] = p1.z; pay[7] = p1.w;
+    if (!(m0 || m1)) return -1;
+    if (NARROW) {
+        const uint32_t t = pay[7] >> 16;
+        const int cnt = int((t >> 11) & 15u);
+        return t == store_tag16(pay, cnt) ? cnt : -1;
+    }
+    const int cnt = int((pay[7] >> 24) & 0x7Fu);
+    return (pay[7] == store_tag32(pay, cnt) && cnt <= kStoreIds32) ? cnt : -1;
+}
+template <bool NARROW>
+__device__ __forceinline__ int32_t store_id(const uint32_t (&pay)[8], int k) {  // k: compile-time after unrolling
+    return NARROW ? int32_t((pay[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) : int32_t(pay[k]);
+}
+// Files a piece under its key if one of its two slots is free; `pay` carries the ids, the tag is added here.
+template <bool NARROW>
+__device__ __forceinline__ bool store_insert(const PieceStoreDev& S, const uint32_t (&key)[8], uint32_t (&pay)[8], int cnt) {
+    if (NARROW) pay[7] = (pay[7] & 0xFFFFu) | (store_tag16(pay, cnt) << 16);
+    else pay[7] = store_tag32(pay, cnt);
+    const uint32_t mix = store_mix(key);
+    uint32_t* cand[2] = {reinterpret_cast<uint32_t*>(S.slots + store_h(mix, 0, S.shift)),
+                         reinterpret_cast<uint32_t*>(S.slots + store_h(mix, 1, S.shift))};
+    uint32_t last[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        last[c] = __hip_atomic_load(cand[c] + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last[c] == kPieceBusy) return false;  // somebody is writing there, possibly this very piece
+        if (last[c] == key[7]) {                  // same length: is it this piece already?
+            bool same = true;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) same = same && __hip_atomic_load(cand[c] + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[j];
+            if (same) return false;
+        }
+    }
+    const int c = last[0] == 0 ? 0 : (last[1] == 0 ? 1 : -1);
+    if (c < 0) return false;
+    uint32_t* slot = cand[c];
+    if (atomicCAS(slot + 7, 0u, kPieceBusy) != 0u) return false;
+    *reinterpret_cast<uint4*>(slot + 8) = uint4{pay[0], pay[1], pay[2], pay[3]};
+    *reinterpret_cast<uint4*>(slot + 12) = uint4{pay[4], pay[5], pay[6], pay[7]};
+    *reinterpret_cast<uint4*>(slot) = uint4{key[0], key[1], key[2], key[3]};
+    *reinterpret_cast<uint4*>(slot + 4) = uint4{key[4], key[5], key[6], key[7]};  // (replaces kPieceBusy: the entry is complete)
+    return true;
+}
+
 // ---- lookup kernel ------------------------------------------------------------------------------
 struct RowState {
     int base;      // staging offset of the row
@@ -754,12 +838,46 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
 #else
 #define PHASE(slot)
 #endif
-        const bool is_f = valid && e.len >= 1 && e.len <= kPieceKeyBytes && need <= kFastSyms;
-        const bool is_l = valid && !is_f && e.len >= 1 && need <= kLongSyms;
-        const bool is_w = valid && !is_f && !is_l && need <= kChunkSyms;
-        bool is_x = valid && !is_f && !is_l && !is_w;
         int32_t* out = w.stage + e.stage_pos;
         int f_cnt = 0;
+        // The piece store first (tables.hpp): a piece it holds is one round trip, not a merge chain.
+        constexpr int kStoreIds = NARROW ? kStoreIds16 : kStoreIds32;
+        const bool keyed = T.store.slots && valid && e.len >= 1 && e.len <= kStoreKeyBytes;
+        bool stored = false;
+        uint32_t skey[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (keyed) {
+            if (e.len <= kPieceKeyBytes) store_key_short(e.k0, e.k1, e.len, skey);
+            else store_key_long(in.chars + e.begin, e.len, skey);
+            uint32_t pay[8];
+            const int c = store_lookup<NARROW>(T.store, skey, pay);
+            if (c >= 0) {
+                stored = true;
+                f_cnt = c;
+#pragma unroll
+                for (int k = 0; k < kStoreIds; ++k)
+                    if (k < c) out[k] = store_id<NARROW>(pay, k);
+                for (int k = c; k < need; ++k) out[k] = kEmptyId;
+            }
+        }
+        // What the batch had to merge is offered to the store, while it has room (one atomic per wave takes the room).
+        auto store_offer = [&](bool want, const uint32_t (&key)[8], uint32_t (&pay)[8], int cnt) {
+            const unsigned long long wm = __ballot(want);
+            if (!wm) return;
+            int room_now = 0;
+            if (l == 0) room_now = __hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave_readlane(room_now, 0) <= 0) return;
+            int left = 0;
+            if (l == 0) left = atomicAdd(T.store.room, -int(__popcll(wm)));
+            left = wave_readlane(left, 0);
+            bool added = false;
+            if (want && int(__popcll(wm & lanemask_lt())) < left) added = store_insert<NARROW>(T.store, key, pay, cnt);
+            const int unused = __popcll(wm) - __popcll(__ballot(added));  // room taken but not filled goes back
+            if (l == 0 && unused) atomicAdd(T.store.room, unused);
+        };
+        const bool is_f = valid && !stored && e.len >= 1 && e.len <= kPieceKeyBytes && need <= kFastSyms;
+        const bool is_l = valid && !stored && !is_f && e.len >= 1 && need <= kLongSyms;
+        const bool is_w = valid && !stored && !is_f && !is_l && need <= kChunkSyms;
+        bool is_x = valid && !stored && !is_f && !is_l && !is_w;
         bool keep = false;  // path F result short enough for a memo entry
         wave_sync();  // the previous batch is done with the LDS arrays
         if (is_f) {
@@ -783,6 +901,19 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 f_cnt = res;
                 keep = res <= kPieceMaxIds;
             }
+        }
+        if (T.store.slots) {
+            const bool want = is_f && !is_x && keyed && f_cnt <= kStoreIds;
+            uint32_t pay[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (want) {
+#pragma unroll
+                for (int k = 0; k < kStoreIds; ++k) {
+                    const uint32_t v = k < f_cnt ? uint32_t(fid[k * kWave + l]) : 0u;
+                    if (NARROW) pay[k >> 1] |= v << (16 * (k & 1));
+                    else pay[k] = v;
+                }
+            }
+            store_offer(want, skey, pay, f_cnt);
         }
         // the memo learns the batch's short results while it has room (one atomic per wave takes the room)
         if (T.pieces.room) {
@@ -849,6 +980,20 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                         if (w.tile_cnt) atomicAdd(&w.tile_cnt[s_row / kRowTile], res);
                     }
                 }
+            }
+            if (T.store.slots) {  // the long pieces' results: the store keys up to 31 bytes
+                const bool want = l < cnt && res >= 0 && res <= kStoreIds && s_len <= kStoreKeyBytes;
+                uint32_t lkey[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pay[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (want) {
+                    store_key_long(in.chars + s_begin, s_len, lkey);
+#pragma unroll
+                    for (int k = 0; k < kStoreIds; ++k) {
+                        const uint32_t v = k < res ? uint32_t(fid[k * (kWave / 2) + l]) : 0u;
+                        if (NARROW) pay[k >> 1] |= v << (16 * (k & 1));
+                        else pay[k] = v;
+                    }
+                }
+                store_offer(want, lkey, pay, res);
             }
             // a non-unique minimum goes to the exact path: tell the piece's own lane
             const unsigned long long failed = __ballot(l < cnt && res < 0);

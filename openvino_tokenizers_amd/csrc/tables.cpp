@@ -18,6 +18,7 @@ std::string view_str(const StringsView& v, int64_t i) {
     return std::string(reinterpret_cast<const char*>(v.chars) + v.begins[i],
                        reinterpret_cast<const char*>(v.chars) + v.ends[i]);
 }
+}  // namespace
 uint32_t pow2_at_least(uint64_t n) {
     uint32_t c = 1;
     while (c < n) c <<= 1;
@@ -28,7 +29,6 @@ int log2u(uint32_t c) {
     while ((1u << b) < c) ++b;
     return b;
 }
-}  // namespace
 
 // ------------------------------------------------------------------------------- trie
 TrieHost::TrieHost() {

@@ -76,6 +76,54 @@ struct PieceTableDev {
     uint32_t shift;           // 32 - log2(capacity)
     int32_t* room;            // entries merge_kernel may still add (cache_capacity at create); nullptr: a fixed table
 };
+// ---- the piece store: the memo's second level, probed by merge_kernel only (never by the lookup kernels).
+// The first level above is sized for an XCD's L2 and for ONE round trip in the hot loop: 15-byte keys, 3 ids, the
+// vocabulary's own tokens plus cache_capacity learned pieces.  What it does not hold reaches merge_kernel as a deferred
+// piece; before merging it, merge_kernel asks the store -- 64-byte entries, pieces up to 31 bytes, up to 15 ids (u16, every
+// id < 65536) or 7 ids (i32) -- and files there what it had to merge.  A hit costs the piece one round trip instead of a chain
+// of ~12 dependent ones.  Same pure function piece -> ids, same insert-only protocol as the first level (a slot is claimed
+// with a CAS on the key's last dword, payload and key are written once and never change; a reader takes an entry whose 32 key
+// bytes match and whose payload carries the valid bit and the checksum of its own ids).
+constexpr int kStoreKeyBytes = 31;
+constexpr int kStoreIds16 = 15, kStoreIds32 = 7;
+struct alignas(64) StoreEntry {
+    uint32_t key[8];  // piece bytes 0..30 (little endian, zero padded), byte 31 = length; key[7] == 0: free (length >= 1)
+    uint32_t pay[8];  // narrow: u16 ids[15], u16 tag   wide: i32 ids[7], u32 tag
+};
+struct PieceStoreDev {
+    StoreEntry* slots;  // nullptr: no store
+    uint32_t shift;     // 32 - log2(capacity)
+    int32_t* room;      // entries that may still be added
+    int32_t narrow;     // every id < 65536
+};
+__host__ __device__ inline uint32_t store_mix(const uint32_t (&key)[8]) {
+    uint32_t h = 0x811C9DC5u;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 8; ++i) {
+        h = (h ^ key[i]) * 0x9E3779B1u;
+        h ^= h >> 15;
+    }
+    return h;
+}
+__host__ __device__ inline uint32_t store_h(uint32_t mix, int which, uint32_t shift) {
+    return (which == 0 ? mix * 0x2C1B3C6Du : (mix ^ (mix >> 13)) * 0x85EBCA77u) >> shift;
+}
+// tag of a payload: valid bit | id count | checksum of the ids (a payload that is not completely there does not pass)
+__host__ __device__ inline uint32_t store_fold(const uint32_t (&pay)[8], bool narrow) {
+    uint32_t x = pay[0] ^ pay[1] * 3u ^ pay[2] * 5u ^ pay[3] * 7u ^ pay[4] * 11u ^ pay[5] * 13u ^ pay[6] * 17u ^
+                 (narrow ? (pay[7] & 0xFFFFu) * 19u : 0u);
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t store_tag16(const uint32_t (&pay)[8], int cnt) {   // the upper half of pay[7]
+    return 0x8000u | (uint32_t(cnt) << 11) | (store_fold(pay, true) & 0x7FFu);
+}
+__host__ __device__ inline uint32_t store_tag32(const uint32_t (&pay)[8], int cnt) {   // pay[7]
+    return 0x80000000u | (uint32_t(cnt) << 24) | (store_fold(pay, false) & 0xFFFFFFu);
+}
+
 struct alignas(16) MergeBucket { MergeSlot s[1]; };  // one slot per bucket: a lookup is two 16-byte loads (divergent loads cost per instruction)
 
 struct BpeDev {
@@ -84,6 +132,7 @@ struct BpeDev {
     uint32_t bucket_shift;      // 32 - log2(buckets)
     const int32_t* new_id;      // [n_merges]
     PieceTableDev pieces;
+    PieceStoreDev store;
     const int32_t* byte_fallback_id;  // [256], -1 = none (all -1 when byte_fallback is off)
     int32_t unk_id;
     int32_t suffix_len;
@@ -149,6 +198,9 @@ __host__ __device__ inline uint32_t hash_bytes(const uint8_t* p, int n) {
     }
     return hash_finish(h, n);
 }
+
+uint32_t pow2_at_least(uint64_t n);
+int log2u(uint32_t c);
 
 // ---- host builders ----------------------------------------------------------------------
 struct TrieHost {

@@ -526,6 +526,48 @@ def test_memo_learns_and_results_stay(backend, capacity):
         assert learned[0] > 20 and learned[1] > learned[0] and learned[1] <= learned[3] <= learned[1] * 1.15
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_piece_store_holds_what_was_merged(backend, wide):
+    """The memo's second level (tables.hpp "piece store"): what merge_kernel had to merge -- pieces up to 31 bytes, up to 15 ids
+    (7 when ids need more than 16 bits: `wide`, a vocabulary with an added token beyond 65535) -- is found there by the next
+    call.  cache_capacity = 7 keeps the first level from learning, so the repeats live off the store; every call equals the
+    oracle; with the store switched off (ovtk_set_memo_store(0)) a new handle works as before."""
+    import ctypes as C
+    from tools.make_tokenizers import load_tokenizer
+    lib = backend.lib
+    t = load_tokenizer("gpt2_small")
+    added = dict(t["added"])
+    if wide:
+        added[b"<|far|>"] = 70000   # (an added token's id is just a number: bpe_tokenizer.cpp:110-114 -- the vocabulary stays small)
+    tok = BpeTok(t["vocab"], t["merges"], added, t["pattern"], **dict(t["attrs"], cache_capacity=7))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    n = 24 if backend.name == "emu" else 800
+    batches = []
+    for k, kind in enumerate(("zipf", "mixed")):   # "mixed": non-Latin words of 16..31 bytes (the long-piece path)
+        b, e, c = TextModel(80 + k, kind).batch(n, 260)
+        rb, re_ = ragged_rows(n)
+        batches.append(([rb, re_, b, e, c], orc(*rs(rb, re_, b, e, c)[:5])))
+    for entries in (4096, 0):
+        L.check(lib, lib.ovtk_set_memo_store(C.c_int64(entries)))
+        try:
+            bpe = BPETokenizer(**tok.attrs, lib=lib)
+            fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), bpe)
+            counts = []
+            for rep in range(3):
+                for data, ref in batches:
+                    assert_same(ref, fused.evaluate(backend.data(data) + [pat], tok.consts), backend.host, f"store {entries} rep {rep}")
+                stored, cap = C.c_int64(), C.c_int64()
+                L.check(lib, lib.ovtk_bpe_store_entries(bpe._h, C.byref(stored), C.byref(cap)))
+                counts.append(int(stored.value))
+            if entries:
+                assert cap.value > 0 and counts[0] > 20 and counts[0] <= counts[1] <= counts[2] <= counts[0] * 1.2 + 2
+            else:
+                assert cap.value == 0 and counts == [0, 0, 0]
+        finally:
+            L.check(lib, lib.ovtk_set_memo_store(C.c_int64(131072)))
+
+
 @pytest.mark.gpu
 def test_pinned_outputs_written_by_the_kernels(hip_lib):
     """Host-memory calls with PINNED output buffers take no D2H copy: compact_kernel (or encode_small_kernel) stores through
