@@ -172,7 +172,11 @@ class BpeEncode(EncodeWorkload):
         """Entries of the piece memo: from the vocabulary at create / learned from the text since (<= cache_capacity)."""
         fixed, learned = C.c_int64(), C.c_int64()
         L.check(self.lib, self.lib.ovtk_bpe_memo_entries(self.bpe._h, C.byref(fixed), C.byref(learned)))
-        return {"fixed": int(fixed.value), "learned": int(learned.value), "cache_capacity": int(self.cache_capacity)}
+        stored, cap = C.c_int64(), C.c_int64()
+        L.check(self.lib, self.lib.ovtk_bpe_store_entries(self.bpe._h, C.byref(stored), C.byref(cap)))
+        return {"fixed": int(fixed.value), "learned": int(learned.value), "cache_capacity": int(self.cache_capacity),
+                "store": {"entries": int(stored.value), "capacity": int(cap.value),
+                          "note": "second level, probed by merge_kernel only: pieces it had to merge once (include/ovtk_amd.h ovtk_set_memo_store)"}}
 
     def run(self, rs, o, st):
         return self.lib.ovtk_encode_run(self.split._h, self.bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, st)
@@ -710,49 +714,57 @@ def cpu_all_cores(wl, seconds=8.0):
             "host_cpus": os.cpu_count()}
 
 
-def end_to_end_leg(wl, lib, dev, ptrs, steps=64, depth=3):
-    """Host buffers in, host buffers out (what a CPU-plugin evaluate() holds): pinned numpy views, ovtk_encode_enqueue_host
-    on alternating streams, so the H2D copy and kernels of batch k+1 run under the D2H copy of batch k."""
+def end_to_end_leg(wl, lib, dev, n_streams=4, steps=64, depth=3):
+    """Host buffers in, host buffers out -- what a CPU-plugin evaluate() holds.  In: the batch as ONE packed u8 string tensor
+    ([i32 n][i32 begin_0][i32 end_i x n][bytes], src/utils.cpp:18-29) in pinned memory, handed to ovtk_encode_enqueue_packed
+    (StringTensorUnpack -> RegexSplit -> BPETokenizer; one H2D copy per batch, the decomposed tensors are views of the device
+    copy).  Out: pinned begins / ends / ids written by the kernels themselves.  Batches alternate between `n_streams` HIP
+    streams, `depth` ahead, so the copy of batch k+1 runs under the kernels and PCIe stores of batch k."""
     if not isinstance(wl, BpeEncode):
         return None
     tb = wl.batches
     nb = min(tb.n, 4)
-
-    def pin(t):
-        p = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        p.copy_(t)
-        return p
-    hin = [[pin(x) for x in tb.d[k]] for k in range(nb)]
-    rs = [L.RaggedStrings(h[0].data_ptr(), h[1].data_ptr(), tb.rows, L.Strings(h[2].data_ptr(), h[3].data_ptr(), h[4].data_ptr(), tb.rows,
-                                                                                 h[4].numel())) for h in hin]
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)]
+    ptrs = [C.c_void_p(x.cuda_stream) for x in streams]
+    packed = []
+    for k in range(nb):
+        b, e, c = (x.cpu().numpy() for x in tb.d[k][2:5])
+        head = np.concatenate([[tb.rows, int(b[0])], e]).astype(np.int32).view(np.uint8)
+        buf = torch.empty(len(head) + len(c), dtype=torch.uint8, pin_memory=True)
+        v = buf.numpy()
+        v[: len(head)] = head
+        v[len(head):] = c      # (the generator's strings are back to back from 0: the packed form's layout)
+        packed.append(buf)
     outs = []
     for _ in range(depth + 2):
         b = torch.empty(tb.rows, dtype=torch.int32, pin_memory=True)
         e = torch.empty(tb.rows, dtype=torch.int32, pin_memory=True)
         ids = torch.empty(tb.cap, dtype=torch.int32, pin_memory=True)
         outs.append((b, e, ids, L.RaggedI32Out(b.data_ptr(), e.data_ptr(), ids.data_ptr(), tb.cap, 0, 0)))
-    n_streams = len(ptrs)
-    moved = [0]
+    moved_in, moved_out = [0], [0]
     stamps = []
 
     def loop(n):
         inflight = []
         for i in range(n):
             o = outs[i % len(outs)]
+            pk = packed[i % nb]
             pending = C.c_void_p()
-            L.check(lib, lib.ovtk_encode_enqueue_host(wl.split._h, wl.bpe._h, C.byref(rs[i % nb]), None, C.byref(o[3]), ptrs[i % n_streams],
-                                                      C.byref(pending)))
+            L.check(lib, lib.ovtk_encode_enqueue_packed(wl.split._h, wl.bpe._h, C.c_void_p(pk.data_ptr()), C.c_int64(pk.numel()), C.byref(o[3]),
+                                                        L.MEM_HOST, ptrs[i % n_streams], C.byref(pending)))
             inflight.append((pending, o, i % nb))
             if len(inflight) > depth:
                 p, oo, k = inflight.pop(0)
                 L.check(lib, lib.ovtk_encode_finish(p, C.byref(oo[3])))
                 stamps.append(time.perf_counter())
-                moved[0] += tb.n_chars[k] + 16 * tb.rows + 4 * int(oo[3].n_data)
+                moved_in[0] += packed[k].numel()
+                moved_out[0] += 8 * tb.rows + 4 * int(oo[3].n_data)
         for p, oo, k in inflight:
             L.check(lib, lib.ovtk_encode_finish(p, C.byref(oo[3])))
-            moved[0] += tb.n_chars[k] + 16 * tb.rows + 4 * int(oo[3].n_data)
+            moved_in[0] += packed[k].numel()
+            moved_out[0] += 8 * tb.rows + 4 * int(oo[3].n_data)
     loop(48)   # the first ~30 batches on fresh streams run ahead of the steady state (tools/e2e_age_probe.py): not timed
-    moved[0] = 0
+    moved_in[0] = moved_out[0] = 0
     stamps.clear()
     dt_all = timed(lambda: loop(steps + 8))
     # the pipeline's rate: from the return of one finish() to the return of the next, without the 8 calls it takes to fill
@@ -760,12 +772,32 @@ def end_to_end_leg(wl, lib, dev, ptrs, steps=64, depth=3):
     units = sum(tb.n_chars[i % nb] for i in range(8, 8 + (len(stamps) - 8)))
     steps = len(stamps) - 8
     # the result is the same as the device-resident path's
-    o = outs[(steps - 1) % len(outs)]
+    o = outs[(steps + 8 - 1) % len(outs)]
+    k_last = (steps + 8 - 1) % nb
+    same = None
+    if k_last in wl.n_out:
+        same = bool(int(o[3].n_data) == wl.n_out[k_last])
     return {"value": round(units / dt / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dt / steps * 1e3, 4),
-            "pcie_GBps_both_directions": round(moved[0] / dt_all / 1e9, 2),
-            "note": f"pinned host buffers in and out (ovtk_encode_enqueue_host / ovtk_encode_finish), {n_streams} streams, {depth} batches "
-                    f"ahead: the kernels write the pinned output buffers themselves (no D2H copy), H2D of the next batches runs under them; {steps} steps over {nb} batches after 48 untimed ones; never reported as `value`",
-            "ids_last_batch": int(o[3].n_data)}
+            "h2d_GBps": round(moved_in[0] / dt_all / 1e9, 2), "d2h_GBps": round(moved_out[0] / dt_all / 1e9, 2),
+            "pcie_GBps_both_directions": round((moved_in[0] + moved_out[0]) / dt_all / 1e9, 2),
+            "note": f"ONE pinned packed u8 string tensor in per batch (ovtk_encode_enqueue_packed: the f2 wire form, one H2D copy), pinned "
+                    f"begins / ends / ids out written by the kernels themselves (no D2H copy), {n_streams} streams, {depth} batches ahead; "
+                    f"{steps} steps over {nb} batches after 48 untimed ones, in a process of its own (fresh HIP streams); never reported as `value`",
+            "ids_last_batch": int(o[3].n_data), "same_id_count_as_device_path": same}
+
+
+def end_to_end_in_child(args):
+    """The end_to_end leg in a process of its own: every stream a process has ever created keeps its hardware queue, and the
+    streams of the legs before this one would share queues with the leg's own (0.78 ms per batch alone, 0.92 ms
+    behind a dozen older streams)."""
+    import subprocess
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--e2e-child", "--rows", str(args.rows), "--bytes", str(args.bytes), "--tokenizer",
+           args.tokenizer, "--text", args.text, "--batches", "4"] + (["--lib", args.lib] if args.lib else [])
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": (p.stderr or p.stdout)[-500:]}
+    return json.loads(lines[-1])
 
 
 def relaunch_argv(n_gpus, argv, port=None):
@@ -808,6 +840,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
+    ap.add_argument("--memo-store", type=int, default=-1, help="ovtk_set_memo_store(n) before the tokenizer is built (debug; default: the library's)")
+    ap.add_argument("--e2e-child", action="store_true", help="internal: run only the end_to_end leg and print its JSON object")
     ap.add_argument("--spawn", action="store_true", help="take the `--gpus N` relaunch under torch.distributed.run even for N = 1 (test)")
     args = ap.parse_args()
 
@@ -833,6 +867,15 @@ def main():
 
     affinity0, numa_note = bind_to_gpu_numa_node(dev)
     lib = L.load(args.lib)
+    if args.memo_store >= 0:
+        L.check(lib, lib.ovtk_set_memo_store(C.c_int64(args.memo_store)))
+    if args.e2e_child:
+        wl = make_workload(args, lib, dev, rank)
+        for k in range(wl.batches.n):   # the id counts of the device-resident path (and the memo learns what it will know)
+            wl.step(k)
+        torch.cuda.synchronize()
+        print(json.dumps(end_to_end_leg(wl, lib, dev)))
+        return
     special = {"5": Detokenize, "r2d": RaggedToDenseBench, "vocab_encoder": VocabEncoderBench, "1": SmallBatchLatency}
     if args.config == "5" and args.rows > 131072:   # more than one int32-offset call can hold: the chunk loop
         special["5"] = DetokenizeFull
@@ -1048,10 +1091,7 @@ def main():
                                                           "the generic lookup_kernel<kFused> (ballot scanner), and random non-Latin words never hit "
                                                           "the memo"}[name]}
             del w2
-        # the loop's own streams and one more: every further stream a process creates shares a hardware queue with an older
-        # one sooner (GPU_MAX_HW_QUEUES), and streams on one queue take turns
-        e2e_streams = [torch.cuda.Stream(dev) for _ in range(max(0, 4 - len(stream_ptrs)))]
-        e2e = end_to_end_leg(wl, lib, dev, stream_ptrs + [C.c_void_p(x.cuda_stream) for x in e2e_streams])
+        e2e = end_to_end_in_child(args)
 
     line = {
         "metric": wl.metric, "value": round(value, 1 if not latency else 2), "unit": wl.unit,

@@ -178,7 +178,7 @@ int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned);
  * cache it is pure memoisation -- results are identical with any capacity, any history, and without it -- but it is sized by
  * this library, not by cache_capacity: that attribute bounds the host memory of the reference's std::string cache, an entry
  * here is 64 bytes of HBM.  cache_capacity == 0 still means "no memo at all".  `entries`: capacity of the store of handles
- * created afterwards (default 131072; 0 = no store: the memo is then exactly the reference's cache_capacity entries).
+ * created afterwards (default 262144; 0 = no store: the memo is then exactly the reference's cache_capacity entries).
  * Process-wide; ovtk_bpe_store_entries reports a handle's count (waits for the device). */
 int ovtk_set_memo_store(int64_t entries);
 int ovtk_bpe_store_entries(ovtk_bpe* h, int64_t* stored, int64_t* capacity);
@@ -217,6 +217,15 @@ int ovtk_encode_finish(ovtk_pending* pending, ovtk_ragged_i32_out* out);
  * pinned output buffers may hold partial data while the call is in flight and after a failed call. */
 int ovtk_encode_enqueue_host(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                              const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending);
+
+/* The same, from the PACKED form of the string tensor -- [i32 n][i32 begin_0][i32 end_i x n][bytes], parse_packed_strings
+ * src/utils.cpp:18-29, what a host holds before StringTensorUnpack (src/string_tensor_unpack.cpp:53-71): `packed` is HOST
+ * memory (pinned: the copy is asynchronous), ONE buffer crosses PCIe, begins / ends / chars are views of its device copy and
+ * never exist as separate tensors; every string is a row (the ragged dimension converted pipelines build with Range,
+ * tokenizer_pipeline.py:1668-1676).  = StringTensorUnpack -> RegexSplit -> BPETokenizer.  `out` lives in out_mem; pinned
+ * host outputs are written by the kernels as above.  The packed buffer must stay valid until finish. */
+int ovtk_encode_enqueue_packed(ovtk_regex_split* split, ovtk_bpe* bpe, const uint8_t* packed, int64_t n_bytes,
+                               const ovtk_ragged_i32_out* out, int out_mem, void* stream, ovtk_pending** pending);
 
 /* ---------------------------------------------------------------- WordpieceTokenizer
  * Replaces WordpieceTokenizer::evaluate, src/wordpiece_tokenizer.cpp:49-133.  Inputs 5-7 + attributes at

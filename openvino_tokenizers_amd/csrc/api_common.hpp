@@ -109,14 +109,31 @@ inline int out_target(DevBuf& stage, T* user, size_t bytes, int mem, T** dev) {
 // batch in the steady state (tools/e2e_age_probe.py).  Tried on the way and dropped: copy streams of the library's own, one
 // per direction (no better with the copy kernel, and two more streams move every stream of the process to other hardware
 // queues: the device-resident pipeline went from 0.165 to 0.22 ms per step).
-inline void* mapped_host_pointer(const void* user) {
+// `bytes`: the kernels will store that many bytes from `user` on -- the LAST byte must belong to the same pinned mapping (a
+// buffer pinned only in part would otherwise be a GPU page fault instead of the staged copy).  The mapping of a buffer
+// registered without hipHostRegisterPortable is valid on the device it was registered on: the check below queries the
+// attributes with the run's device current (the callers have set it), and takes the device-side pointer that query returns.
+inline void* mapped_host_pointer(const void* user, size_t bytes = 1) {
     if (!user) return nullptr;
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, user) != hipSuccess) {
         (void)hipGetLastError();  // pageable memory is reported as an error by some runtimes
         return nullptr;
     }
-    return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return nullptr;
+    if (bytes > 1) {
+        hipPointerAttribute_t z{};
+        const char* last = static_cast<const char*>(user) + (bytes - 1);
+        if (hipPointerGetAttributes(&z, last) != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        // the same registration maps both ends: host and device addresses advance together
+        if (z.type != hipMemoryTypeHost || !z.devicePointer ||
+            static_cast<const char*>(z.devicePointer) - static_cast<const char*>(a.devicePointer) != std::ptrdiff_t(bytes - 1))
+            return nullptr;
+    }
+    return a.devicePointer;
 }
 inline int copy_back(void* user, const void* dev, size_t bytes, int mem, hipStream_t s) {
     if (mem == OVTK_MEM_DEVICE || bytes == 0) return OVTK_OK;
@@ -250,9 +267,9 @@ public:
         scratch_cap_ = std::max<int64_t>(ws_->scratch.size(), int64_t(16) << 20);
         if (!wire_.hdr) {
             if (mem_ == OVTK_MEM_HOST) {  // pinned output buffers are written by the kernels themselves
-                void* pb = mapped_host_pointer(out_.begins);
-                void* pe = mapped_host_pointer(out_.ends);
-                void* pd = mapped_host_pointer(out_.data);
+                void* pb = mapped_host_pointer(out_.begins, size_t(n_rows_) * 4);
+                void* pe = mapped_host_pointer(out_.ends, size_t(n_rows_) * 4);
+                void* pd = mapped_host_pointer(out_.data, size_t(std::max<int64_t>(out_.data_capacity, 1)) * 4);
                 if (pb && pe && pd) {
                     d_begins_ = static_cast<int32_t*>(pb);
                     d_ends_ = static_cast<int32_t*>(pe);

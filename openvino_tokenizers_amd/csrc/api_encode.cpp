@@ -68,7 +68,7 @@ namespace {
 // Entries the piece store (tables.hpp) of handles created from now on may take; 0: no store.  Process-wide, like
 // ovtk_set_row_tickets: the reference's attribute list has no room for it (cache_capacity keeps its meaning: 0 = no memo at all).
 std::atomic<int64_t>& memo_store_entries() {
-    static std::atomic<int64_t> v{131072};
+    static std::atomic<int64_t> v{262144};
     return v;
 }
 int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
@@ -105,8 +105,9 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     OVTK_HIP(hipStreamSynchronize(nullptr));
     h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>()};
     h->memo_entries = host.stored;
-    // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.  Two candidate slots per piece
-    // and no relocation on the device, so the table is kept below a third full.
+    // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.  kStoreWays candidate slots per
+    // piece and no relocation on the device: the table is kept below a third full (an insert then finds both taken one time in ten
+    // at the very end, far less on the way).
     // (no more than a few entries per vocabulary token: a 3 000-token test vocabulary does not need 32 MiB of table)
     const int64_t want = std::min<int64_t>({memo_store_entries().load(std::memory_order_relaxed), int64_t(1) << 22,
                                             std::max<int64_t>(8192, 4 * V)});
@@ -409,7 +410,7 @@ int ovtk_bpe_store_entries(ovtk_bpe* h, int64_t* stored, int64_t* capacity) {
     int32_t room = 0;
     OVTK_HIP(hipDeviceSynchronize());
     OVTK_HIP(hipMemcpy(&room, h->dev.store.room, sizeof room, hipMemcpyDeviceToHost));
-    *stored = h->store_capacity - std::max<int32_t>(room, 0);
+    *stored = int64_t(h->store_capacity) - room;  // (room may end a few below zero: every wave reads it once per launch)
     return OVTK_OK;
 }
 
@@ -479,7 +480,11 @@ bool fusable(const ovtk_regex_split* split) {
 // RegexSplit [+] BPETokenizer.  split == nullptr: `in` already holds pieces (the BPETokenizer op).
 // Launches the kernels; `run` stays empty when the result was complete without any (empty batches).
 int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
-                 ovtk_ragged_i32_out* out, int mem, void* stream, std::unique_ptr<PendingRun>& run, const WireSink* wire = nullptr) {
+                 ovtk_ragged_i32_out* out, int mem, void* stream, std::unique_ptr<PendingRun>& run, const WireSink* wire = nullptr,
+                 std::shared_ptr<void> device_inputs = nullptr) {
+    // device_inputs: `in` names device memory whatever `mem` says about the outputs (ovtk_encode_enqueue_packed: the packed
+    // batch was copied to the device by the caller of this function); the object owns that memory until the run is over.
+    const int in_mem = device_inputs ? OVTK_MEM_DEVICE : mem;
     const ovtk_regex_split* split = split_in;
     if (int rc = check_rows(in)) return rc;
     if (!bpe || !out) return set_error(OVTK_E_ARG, "null argument");
@@ -517,7 +522,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
         Workspace& sw = *pieces_ws->ws;
         if (!sw.host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
         RowsIn d_in{};
-        if (int rc = stage_input(sw, in, skips, mem, s, d_in)) return rc;
+        if (int rc = stage_input(sw, in, skips, in_mem, s, d_in)) return rc;
         const int64_t cap = in->strings.n_chars + in->strings.n;  // regex_split.cpp:182
         if (cap >= INT32_MAX) return set_error(OVTK_E_ARG, "tensor sizes must fit int32 offsets");
         int e = 0;
@@ -605,7 +610,11 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                       ? resident_blocks_per_cu(lookup_ascii_kernel<false>, 6)
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
-    if (pieces_ws) r->input_on_device(pieces_ws);
+    if (pieces_ws) {
+        r->input_on_device(std::make_shared<std::pair<std::shared_ptr<void>, std::shared_ptr<void>>>(pieces_ws, device_inputs));
+    } else if (device_inputs) {
+        r->input_on_device(device_inputs);
+    }
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
     if (wire) r->output_to_wire(*wire);
     if (int rc = r->start()) return rc;
@@ -695,6 +704,43 @@ int ovtk_encode_enqueue_wire(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_
     const WireSink sink{reinterpret_cast<int32_t*>(base), reinterpret_cast<int32_t*>(base + kShardHeaderBytes),
                         base + kShardHeaderBytes + max_rows * 4, int32_t(pad_ids), int32_t(max_rows), id_bytes};
     if (int rc = start_encode(split, bpe, in, skips, &p->out, OVTK_MEM_DEVICE, stream, p->run, &sink)) return rc;
+    *pending = p.release();
+    return OVTK_OK;
+}
+
+int ovtk_encode_enqueue_packed(ovtk_regex_split* split, ovtk_bpe* bpe, const uint8_t* packed, int64_t n_bytes,
+                               const ovtk_ragged_i32_out* out, int out_mem, void* stream, ovtk_pending** pending) {
+    if (!pending || !out || !packed || !bpe) return set_error(OVTK_E_ARG, "null argument");
+    if (int rc = check_fused(split)) return rc;
+    if (out_mem != OVTK_MEM_HOST && out_mem != OVTK_MEM_DEVICE) return set_error(OVTK_E_ARG, "out_mem must be OVTK_MEM_HOST or OVTK_MEM_DEVICE");
+    // the reference's format checks (src/utils.cpp:21-25), on the host copy
+    if (n_bytes < 4) return set_error(OVTK_E_ARG, "Incorrect packed string tensor format: no batch size in the packed string tensor");
+    int32_t batch = 0, total = 0;
+    std::memcpy(&batch, packed, 4);
+    if (batch < 0 || n_bytes < 8 + 4 * int64_t(batch))
+        return set_error(OVTK_E_ARG, "Incorrect packed string tensor format: the packed string tensor must contain first string offset and end indices");
+    if (batch > 0) std::memcpy(&total, packed + 4 + 4 * size_t(batch), 4);  // end_ids[batch - 1] (string_tensor_unpack.cpp:59)
+    if (total < 0 || 8 + 4 * int64_t(batch) + total > n_bytes) return set_error(OVTK_E_RANGE, "packed string tensor: end offsets exceed the buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    OVTK_HIP(hipSetDevice(bpe->device));
+    auto p = std::make_unique<ovtk_pending>();
+    p->out = *out;
+    // ONE copy over PCIe; the decomposed tensors are views of the device copy (begin_ids = words 1.., end_ids = words 2..,
+    // utils.cpp:26-27), the rows are the strings (ragged_begins = 0, 1, ..; ragged_ends = 1, 2, ..: one table, read at +0 and +1)
+    auto ws = std::make_shared<WorkspaceLease>(bpe->device);
+    Workspace& w = *ws->ws;
+    const size_t used = 8 + 4 * size_t(batch) + size_t(total);
+    if (int rc = w.in_chars.upload(packed, used, s)) return rc;
+    if (int rc = w.in_rb.ensure((size_t(batch) + 1) * 4)) return rc;
+    if (batch > 0)
+        hipLaunchKernelGGL(iota_kernel, dim3(std::min<int>((batch + kBlockThreads) / kBlockThreads, 1024)), dim3(kBlockThreads), 0, s,
+                           batch + 1, w.in_rb.as<int32_t>());  // (this lease is held until the run is over: finish() has waited by then)
+    const uint8_t* d = w.in_chars.as<uint8_t>();
+    const int32_t* iota = w.in_rb.as<int32_t>();
+    const ovtk_ragged_strings in{iota, iota + 1, batch,
+                                 ovtk_strings{reinterpret_cast<const int32_t*>(d + 4), reinterpret_cast<const int32_t*>(d + 8),
+                                              d + 8 + 4 * size_t(batch), batch, total}};
+    if (int rc = start_encode(split, bpe, &in, nullptr, &p->out, out_mem, stream, p->run, nullptr, ws)) return rc;
     *pending = p.release();
     return OVTK_OK;
 }

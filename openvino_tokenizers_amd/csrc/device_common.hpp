@@ -89,6 +89,27 @@ __device__ __forceinline__ T uniform_load(const T* p) {
 #endif
 }
 
+// Streaming accesses -- the text a row is read from once, the staged ids a later kernel reads once -- carry the non-temporal
+// hint (global_load / global_store ... nt): they do not age the lines the XCD's 4 MiB L2 should keep, the memo and merge
+// tables every wave probes.  (Counted in round 3, tools/fetch_calib.hip for the units: lookup_ascii_kernel fetched 118 MB to
+// read 34.6 MB of text -- the rest were memo probes whose lines the streams had pushed out.)
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if defined(OVTK_SIMT_EMULATOR) || defined(OVTK_NO_NT)
+    return *p;
+#else
+    return __builtin_nontemporal_load(p);
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void stream_store(T* p, T v) {
+#if defined(OVTK_SIMT_EMULATOR) || defined(OVTK_NO_NT)
+    *p = v;
+#else
+    __builtin_nontemporal_store(v, p);
+#endif
+}
+
 // Publishing data to other workgroups of the same launch (MI355X_MICROARCH.md "inter-workgroup visibility"): the
 // producer's plain stores -> __syncthreads() -> ONE lane: agent-scope release + vmcnt drain -> device-scope atomic
 // ticket; the block that draws the last ticket does an agent-scope acquire -> __syncthreads() -> plain loads.

@@ -92,6 +92,12 @@ struct EncodeWork {
 
 constexpr uint32_t kFatalFlags = kFlagRange | kFlagStageOverflow;
 
+// out[i] = i: the ragged dimension of a batch of plain strings (one string per row).
+static __global__ __launch_bounds__(kBlockThreads) void iota_kernel(int n, int32_t* out) {
+    const int stride = int(gridDim.x) * kBlockThreads;
+    for (int i = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); i < n; i += stride) out[i] = i;
+}
+
 // ---- row capacity: mul * sum over the row's strings of max(len, 1), with range validation.
 __device__ __forceinline__ long long row_capacity(const RowsIn& in, int mul, long long row, RunStatus* status) {
     long long cap = 0;
@@ -295,19 +301,33 @@ __device__ __forceinline__ bool store_key_eq(const uint4& a, const uint4& b, con
     return a.x == key[0] && a.y == key[1] && a.z == key[2] && a.w == key[3] && b.x == key[4] && b.y == key[5] && b.z == key[6] &&
            b.w == key[7];
 }
-// -> id count and the payload, or -1.  Both candidates are fetched together (eight independent 16-byte loads).
+// -> id count and the payload, or -1.  All kStoreWays candidates are fetched together (independent 16-byte loads).
 template <bool NARROW>
 __device__ __forceinline__ int store_lookup(const PieceStoreDev& S, const uint32_t (&key)[8], uint32_t (&pay)[8]) {
     const uint32_t mix = store_mix(key);
-    const uint4* e0 = reinterpret_cast<const uint4*>(S.slots + store_h(mix, 0, S.shift));
-    const uint4* e1 = reinterpret_cast<const uint4*>(S.slots + store_h(mix, 1, S.shift));
-    const uint4 a0 = e0[0], a1 = e0[1], a2 = e0[2], a3 = e0[3];
-    const uint4 b0 = e1[0], b1 = e1[1], b2 = e1[2], b3 = e1[3];
-    const bool m0 = store_key_eq(a0, a1, key), m1 = store_key_eq(b0, b1, key);
-    const uint4 p0 = m1 ? b2 : a2, p1 = m1 ? b3 : a3;
-    pay[0] = p0.x; pay[1] = p0.y; pay[2] = p0.z; pay[3] = p0.w;
-    pay[4] = p1.x; pay[5] = p1.y; pay[6] = p1.z; pay[7] = p1.w;
-    if (!(m0 || m1)) return -1;
+    uint4 k0[kStoreWays], k1[kStoreWays], p0[kStoreWays], p1[kStoreWays];
+#pragma unroll
+    for (int c = 0; c < kStoreWays; ++c) {
+        const uint4* e = reinterpret_cast<const uint4*>(S.slots + store_h(mix, c, S.shift));
+        k0[c] = e[0];
+        k1[c] = e[1];
+        p0[c] = e[2];
+        p1[c] = e[3];
+    }
+    bool any = false;
+    uint4 q0 = p0[0], q1 = p1[0];
+#pragma unroll
+    for (int c = 0; c < kStoreWays; ++c) {
+        const bool m = store_key_eq(k0[c], k1[c], key);
+        if (m) {
+            q0 = p0[c];
+            q1 = p1[c];
+        }
+        any = any || m;
+    }
+    pay[0] = q0.x; pay[1] = q0.y; pay[2] = q0.z; pay[3] = q0.w;
+    pay[4] = q1.x; pay[5] = q1.y; pay[6] = q1.z; pay[7] = q1.w;
+    if (!any) return -1;
     if (NARROW) {
         const uint32_t t = pay[7] >> 16;
         const int cnt = int((t >> 11) & 15u);
@@ -320,30 +340,28 @@ template <bool NARROW>
 __device__ __forceinline__ int32_t store_id(const uint32_t (&pay)[8], int k) {  // k: compile-time after unrolling
     return NARROW ? int32_t((pay[k >> 1] >> (16 * (k & 1))) & 0xFFFFu) : int32_t(pay[k]);
 }
-// Files a piece under its key if one of its two slots is free; `pay` carries the ids, the tag is added here.
+// Files a piece under its key in the first of its kStoreWays slots that is free; `pay` carries the ids, the tag is added
+// here.  The caller has just looked the piece up and missed, so nothing is read first: one CAS per way tried.  (The first
+// version read every candidate with agent-scope loads before claiming one and kept an exact count of the room with a
+// returning atomic: five dependent round trips behind every merge chain -- with a store that still had room merge_kernel
+// took 78 us instead of 57.)  A slot that holds another piece of the same length and tail, or is being written, ends the
+// attempt: it may be this very piece, filed by another wave a moment ago; a duplicate in the second way would be harmless
+// (equal payloads) but wastes a slot.
 template <bool NARROW>
 __device__ __forceinline__ bool store_insert(const PieceStoreDev& S, const uint32_t (&key)[8], uint32_t (&pay)[8], int cnt) {
     if (NARROW) pay[7] = (pay[7] & 0xFFFFu) | (store_tag16(pay, cnt) << 16);
     else pay[7] = store_tag32(pay, cnt);
     const uint32_t mix = store_mix(key);
-    uint32_t* cand[2] = {reinterpret_cast<uint32_t*>(S.slots + store_h(mix, 0, S.shift)),
-                         reinterpret_cast<uint32_t*>(S.slots + store_h(mix, 1, S.shift))};
-    uint32_t last[2];
+    uint32_t* slot = nullptr;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        last[c] = __hip_atomic_load(cand[c] + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (last[c] == kPieceBusy) return false;  // somebody is writing there, possibly this very piece
-        if (last[c] == key[7]) {                  // same length: is it this piece already?
-            bool same = true;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) same = same && __hip_atomic_load(cand[c] + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[j];
-            if (same) return false;
-        }
+    for (int c = 0; c < kStoreWays; ++c) {
+        if (slot) break;
+        uint32_t* cand = reinterpret_cast<uint32_t*>(S.slots + store_h(mix, c, S.shift));
+        const uint32_t old = atomicCAS(cand + 7, 0u, kPieceBusy);
+        if (old == 0u) slot = cand;
+        else if (old == kPieceBusy || old == key[7]) return false;
     }
-    const int c = last[0] == 0 ? 0 : (last[1] == 0 ? 1 : -1);
-    if (c < 0) return false;
-    uint32_t* slot = cand[c];
-    if (atomicCAS(slot + 7, 0u, kPieceBusy) != 0u) return false;
+    if (!slot) return false;
     *reinterpret_cast<uint4*>(slot + 8) = uint4{pay[0], pay[1], pay[2], pay[3]};
     *reinterpret_cast<uint4*>(slot + 12) = uint4{pay[4], pay[5], pay[6], pay[7]};
     *reinterpret_cast<uint4*>(slot) = uint4{key[0], key[1], key[2], key[3]};
@@ -406,7 +424,7 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     if (hit) {
 #pragma unroll
         for (int k = 0; k < kPieceMaxIds; ++k)
-            if (k < cnt) w.stage[pos + k] = tok[k];
+            if (k < cnt) w.stage[pos + k] = tok[k];   // (not a streaming store: compact_kernel reads it back within microseconds -- measured: 21.7 -> 26.5 us for compact with the hint)
     }
     const bool miss = valid && !hit;
     const unsigned long long mm = __ballot(miss);
@@ -801,6 +819,8 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     IdT* fnid = fid + kFastSyms * kWave;                                      // path F
     const int l = lane_id();
     const int SL = T.suffix_len;
+    // the piece store takes entries while its room counter is positive (a few more may slip in: every wave reads it once)
+    const bool store_open = T.store.slots && wave_uniform(__hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > 0;
     {  // (x is the fastest-varying block index: blocks that become resident late are spread over all shards; solo: the
        // small batch's blocks filed everything under shard 0)
     const int shard = solo ? 0 : int(blockIdx.x);
@@ -859,20 +879,13 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 for (int k = c; k < need; ++k) out[k] = kEmptyId;
             }
         }
-        // What the batch had to merge is offered to the store, while it has room (one atomic per wave takes the room).
+        // What the batch had to merge is offered to the store while it has room (`store_open`, read once per wave at the
+        // kernel's start: the count is kept with returnless adds, nothing here waits for an atomic's answer).
         auto store_offer = [&](bool want, const uint32_t (&key)[8], uint32_t (&pay)[8], int cnt) {
-            const unsigned long long wm = __ballot(want);
-            if (!wm) return;
-            int room_now = 0;
-            if (l == 0) room_now = __hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (wave_readlane(room_now, 0) <= 0) return;
-            int left = 0;
-            if (l == 0) left = atomicAdd(T.store.room, -int(__popcll(wm)));
-            left = wave_readlane(left, 0);
-            bool added = false;
-            if (want && int(__popcll(wm & lanemask_lt())) < left) added = store_insert<NARROW>(T.store, key, pay, cnt);
-            const int unused = __popcll(wm) - __popcll(__ballot(added));  // room taken but not filled goes back
-            if (l == 0 && unused) atomicAdd(T.store.room, unused);
+            if (!store_open || !__ballot(want)) return;
+            const bool added = want && store_insert<NARROW>(T.store, key, pay, cnt);
+            const int n_added = __popcll(__ballot(added));
+            if (l == 0 && n_added) atomicAdd(T.store.room, -n_added);
         };
         const bool is_f = valid && !stored && e.len >= 1 && e.len <= kPieceKeyBytes && need <= kFastSyms;
         const bool is_l = valid && !stored && !is_f && e.len >= 1 && need <= kLongSyms;

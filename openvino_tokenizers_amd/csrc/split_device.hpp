@@ -211,7 +211,7 @@ __device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str,
         const int b0 = k * 4;
         uint32_t w;
         if (b0 >= lo && b0 + 4 <= hi) {
-            w = *reinterpret_cast<const uint32_t*>(ga + b0);
+            w = stream_load(reinterpret_cast<const uint32_t*>(ga + b0));
         } else if (ga + b0 >= buf && ga + b0 + 4 <= buf_end) {
             int cl = lo - b0, ch = hi - b0;  // keep bytes [cl, ch) of the dword
             cl = cl < 0 ? 0 : (cl > 4 ? 4 : cl);

@@ -70,6 +70,13 @@ struct alignas(32) PieceEntry {
 // merge_kernel adds entries while lookups of another stream read the table (the dynamic part of the memo, below).  The
 // two 16-byte halves of an entry are written by two stores, so a reader may see a key whose payload has not arrived:
 // the tag makes that a miss (24 bits of the key's hash + a bit that a zeroed payload lacks) instead of a wrong answer.
+// What the protocol relies on, stated once: (i) a slot is written ONCE -- claimed by CAS, payload stored, key stored -- and never
+// changes afterwards, so the only incomplete state a reader can meet is "key there, payload still zero", which the tag's valid
+// bit rejects; (ii) each half is ONE aligned 16-byte store (global_store_dwordx4) and is read by ONE aligned 16-byte load: both
+// lie inside one 32-byte sector of one cache line, and the memory system moves sectors, not dwords -- a reader sees the half
+// before or after the store, not a mixture (the HIP memory model does not promise this; gfx9 hardware behaves so, and the
+// multi-stream learning soak, tests/test_bpe_parity.py::test_memo_learns_under_concurrent_lookups, is the regression test).
+// The piece store below, whose lookups are off the hot path, additionally carries a checksum of its ids in the tag.
 constexpr uint32_t kPieceBusy = 0xFF000000u;  // dword 3 of a key (length byte 255) while a writer fills the slot it claimed
 struct PieceTableDev {
     const PieceEntry* slots;  // nullptr: no memo (every piece takes the merge path)
@@ -107,8 +114,12 @@ __host__ __device__ inline uint32_t store_mix(const uint32_t (&key)[8]) {
     }
     return h;
 }
+constexpr int kStoreWays = 2;  // candidate slots of a piece: a lookup fetches both, an insert takes the first free one
+                               // (4 ways, measured: 1 % instead of 6 % failed inserts, merge_kernel 58 -> 69 us alone, step 0.142 -> 0.146 ms)
 __host__ __device__ inline uint32_t store_h(uint32_t mix, int which, uint32_t shift) {
-    return (which == 0 ? mix * 0x2C1B3C6Du : (mix ^ (mix >> 13)) * 0x85EBCA77u) >> shift;
+    const uint32_t m = which == 0 ? mix * 0x2C1B3C6Du : which == 1 ? (mix ^ (mix >> 13)) * 0x85EBCA77u
+                     : which == 2 ? (mix ^ (mix >> 9)) * 0xC2B2AE3Du : (mix ^ (mix >> 17)) * 0x27D4EB2Fu;
+    return m >> shift;
 }
 // tag of a payload: valid bit | id count | checksum of the ids (a payload that is not completely there does not pass)
 __host__ __device__ inline uint32_t store_fold(const uint32_t (&pay)[8], bool narrow) {

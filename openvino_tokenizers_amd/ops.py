@@ -338,6 +338,36 @@ class FusedSplitBPE:
             return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
         return ticket
 
+    def enqueue_packed(self, packed, pattern, bpe_constant_inputs, outputs=None, stream=None):
+        """StringTensorUnpack -> RegexSplit -> BPETokenizer from the PACKED u8 form of a batch of strings, [i32 n][i32 begin_0]
+        [i32 end_i x n][bytes] (src/utils.cpp:18-29), in host memory (ovtk_encode_enqueue_packed): one buffer crosses PCIe,
+        every string is a row.  `outputs` = (begins, ends, ids) numpy arrays to fill -- pinned ones are written by the kernels
+        themselves --, allocated here when None.  `ticket()` -> [begins, ends, ids]."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        if len(packed) < 4:
+            raise L.OvtkError(L.E_ARG, "Incorrect packed string tensor format: no batch size in the packed string tensor")
+        n = int(packed[:4].view(np.int32)[0])
+        if n < 0 or len(packed) < 8 + 4 * n:
+            raise L.OvtkError(L.E_ARG, "Incorrect packed string tensor format: the packed string tensor must contain first string "
+                                       "offset and end indices")
+        self.split._ensure(pattern)
+        z = np.zeros(1, np.int32)
+        self.bpe._ensure([z, z, z, z, np.zeros(0, np.uint8)] + list(bpe_constant_inputs))
+        if outputs is None:
+            n_chars = max(len(packed) - 8 - 4 * n, 1)
+            outputs = (np.empty(max(n, 1), np.int32), np.empty(max(n, 1), np.int32), np.empty(n_chars, np.int32))
+        ob, oe, ids = outputs
+        out = L.RaggedI32Out(ob.ctypes.data, oe.ctypes.data, ids.ctypes.data, len(ids), 0, 0)
+        lib = self.bpe._lib
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_encode_enqueue_packed(self.split._h, self.bpe._h, C.c_void_p(packed.ctypes.data), C.c_int64(len(packed)),
+                                                    C.byref(out), L.MEM_HOST, C.c_void_p(stream or 0), C.byref(pending)))
+
+        def ticket(_keep=(packed, outputs)):
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(out)))
+            return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+        return ticket
+
     def enqueue_wire(self, split_inputs, bpe_constant_inputs, wire, max_rows, pad_ids, id_bytes, stream=None):
         """The encode straight into a ShardExchange send wire (ovtk_encode_enqueue_wire): CUDA inputs, `wire` a uint8 CUDA
         tensor of ovtk_shard_wire_bytes(pad_ids) bytes with `max_rows` row slots.  compact_kernel writes the header, the

@@ -63,3 +63,59 @@ def test_pack_roundtrip_with_gaps_and_order(backend):
     with pytest.raises(L.OvtkError) as ei:
         StringTensorPack(lib=backend.lib).evaluate([np.array([0], np.int32), np.array([99999999], np.int32), chars[:4]])
     assert ei.value.code == L.E_RANGE
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_encode_from_the_packed_tensor(backend, pinned):
+    """ovtk_encode_enqueue_packed = StringTensorUnpack -> RegexSplit -> BPETokenizer with ONE buffer over PCIe: the packed u8
+    tensor of a batch against the oracle chain on the unpacked strings; empty strings, an empty batch, the all-empty batch
+    quirk (regex_split.cpp:129-143), format errors."""
+    from openvino_tokenizers_amd import _lib as L
+    from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
+    from oracle import oracle as O
+    from tests.util import BpeTok, assert_same, one_string_per_row
+    from tools.workloads import TextModel
+    if backend.name == "hip-device":
+        pytest.skip("the packed tensor is host memory by definition")
+    if pinned and backend.name == "emu":
+        pytest.skip("pinned memory needs the HIP runtime")
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    b, e, c = TextModel(61, "mixed").batch(40 if backend.name == "emu" else 700, 180)
+    raw = c.tobytes()
+    strings = [raw[x:y] for x, y in zip(b.tolist(), e.tolist())]
+    strings[3] = b""
+    strings[-1] = b""
+
+    def host(a):
+        if not pinned:
+            return a
+        import torch
+        t = torch.empty(a.shape, dtype=getattr(torch, str(a.dtype)), pin_memory=True).numpy()
+        t[...] = a
+        return t
+    for batch in (strings, strings[:1], [b"", b""], []):
+        packed = host(wire(batch))
+        n = len(batch)
+        n_chars = sum(len(s) for s in batch)
+        outs = tuple(host(np.full(m, -1, np.int32)) for m in (max(n, 1), max(n, 1), max(n_chars, 1)))
+        got = fused.enqueue_packed(packed, tok.pattern_u8(), tok.consts, outs)()
+        ref = orc(*rs(*one_string_per_row(batch))[:5]) if n_chars else None
+        if ref is not None:
+            assert_same(list(ref), got, backend.host, f"packed batch of {n}")
+        else:   # no chars at all: RegexSplit's shape-{1} quirk (regex_split.cpp:129-143), one empty row whatever the batch held
+            assert len(got[2]) == 0 and got[0].tolist() == [0] and got[1].tolist() == [0]
+    with pytest.raises(L.OvtkError) as ei:
+        fused.enqueue_packed(np.zeros(2, np.uint8), tok.pattern_u8(), tok.consts)
+    assert ei.value.code == L.E_ARG
+    bad = wire(strings[:4]).copy()
+    bad[:4].view(np.int32)[0] = 1000   # more strings than the buffer has offsets for
+    with pytest.raises(L.OvtkError) as ei:
+        fused.enqueue_packed(bad, tok.pattern_u8(), tok.consts)
+    assert ei.value.code == L.E_ARG
+    bad = wire(strings[:4]).copy()
+    bad[4 + 4 * 4: 8 + 4 * 4].view(np.int32)[0] = 10 ** 6   # the last end offset leaves the buffer
+    with pytest.raises(L.OvtkError) as ei:
+        fused.enqueue_packed(bad, tok.pattern_u8(), tok.consts)
+    assert ei.value.code == L.E_RANGE
