@@ -178,7 +178,7 @@ int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned);
  * cache it is pure memoisation -- results are identical with any capacity, any history, and without it -- but it is sized by
  * this library, not by cache_capacity: that attribute bounds the host memory of the reference's std::string cache, an entry
  * here is 64 bytes of HBM.  cache_capacity == 0 still means "no memo at all".  `entries`: capacity of the store of handles
- * created afterwards (default 262144; 0 = no store: the memo is then exactly the reference's cache_capacity entries).
+ * created afterwards (default 1048576, and never more than four entries per vocabulary token; 0 = no store: the memo is then exactly the reference's cache_capacity entries).
  * Process-wide; ovtk_bpe_store_entries reports a handle's count (waits for the device). */
 int ovtk_set_memo_store(int64_t entries);
 int ovtk_bpe_store_entries(ovtk_bpe* h, int64_t* stored, int64_t* capacity);

@@ -68,7 +68,7 @@ namespace {
 // Entries the piece store (tables.hpp) of handles created from now on may take; 0: no store.  Process-wide, like
 // ovtk_set_row_tickets: the reference's attribute list has no room for it (cache_capacity keeps its meaning: 0 = no memo at all).
 std::atomic<int64_t>& memo_store_entries() {
-    static std::atomic<int64_t> v{262144};
+    static std::atomic<int64_t> v{1048576};
     return v;
 }
 int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,

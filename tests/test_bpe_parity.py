@@ -565,7 +565,7 @@ def test_piece_store_holds_what_was_merged(backend, wide):
             else:
                 assert cap.value == 0 and counts == [0, 0, 0]
         finally:
-            L.check(lib, lib.ovtk_set_memo_store(C.c_int64(262144)))
+            L.check(lib, lib.ovtk_set_memo_store(C.c_int64(1048576)))
 
 
 @pytest.mark.gpu
