@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
+
 #include "api_common.hpp"
 #include "encode_kernels.hpp"
 #include "runtime.hpp"
@@ -572,7 +574,17 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                else if (split && split->dev.kind <= kSplitGpt2Digits) {
                                    // rows that are one ASCII scan window: the specialised kernel; whatever it leaves
                                    // (marked in row_used) goes through the generic one
-                                   if (split->dev.kind == kSplitGpt2Digits)
+                                   // (consecutive rows per wave, headers by one vector load, the next row's text requested
+                                   // ahead into LDS: lookup_rows_kernel; OVTK_LOOKUP_STRIDED=1 keeps the round-2 kernel, for A/B runs)
+                                   static const bool strided = std::getenv("OVTK_LOOKUP_STRIDED") != nullptr;
+                                   EncodeWork w1 = w;
+                                   w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
+                                   const bool ahead = !strided && w1.rows_per_wave <= kWave;
+                                   if (ahead && split->dev.kind == kSplitGpt2Digits)
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<true>, grid, kBlockThreads, s, d_in, bpe->dev, w1);
+                                   else if (ahead)
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<false>, grid, kBlockThreads, s, d_in, bpe->dev, w1);
+                                   else if (split->dev.kind == kSplitGpt2Digits)
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<true>, grid, kBlockThreads, s, d_in, bpe->dev, w);
                                    else
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<false>, grid, kBlockThreads, s, d_in, bpe->dev, w);

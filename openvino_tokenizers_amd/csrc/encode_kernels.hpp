@@ -67,6 +67,7 @@ struct EncodeWork {
     RunStatus* host_status; //   ... and the pinned status block the kernel itself fills (no memset / copy dispatches)
     int32_t status_words;   //   dwords of `status` to zero at the kernel's start (RunStatus + the tile counts behind it)
     int32_t rows_per_ticket;  // lookup_kernel, allocator mode: 0 = static rows per wave, else rows handed out per ticket
+    int32_t rows_per_wave;    // lookup_rows_kernel: wave w owns the rows [w * rows_per_wave, (w + 1) * rows_per_wave)
     int32_t n_waves;        // persistent waves of the prep / lookup launches (wave w owns rows w, w + n_waves, ...)
     long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities), or
                             // nullptr: the lookup kernel takes staging chunks from kShards bump allocators itself
@@ -727,6 +728,147 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_ascii_kernel(R
                 if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps + skew, r0, r1);
             }
             lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, h.sb + ps);
+        }
+        if (l == 0) {
+            w.row_stage[row] = cursor;
+            w.row_cnt[row] = st.emitted;
+            if (w.row_emit) w.row_emit[row] = st.emitted;
+            w.row_used[row] = st.used;
+        }
+        cursor += st.used;
+    }
+    if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
+    if (n_pending && l == 0) atomicAdd(&w.status->n_pending, n_pending);
+}
+
+// ---- lookup_ascii_kernel with the memory latency of a row taken out of its critical path (round 3).
+// lookup_ascii_kernel pays four dependent round trips per row -- the row's header (scalar loads), its text, and two batches of
+// memo probes -- and a wave's rows are n_waves apart, so every header load is a scalar-cache miss.  Here a wave owns
+// rows_per_wave CONSECUTIVE rows:
+//  * their headers arrive with ONE vector load (lane i = row i of the range), two dependent round trips per wave instead of
+//    two per row;
+//  * the text of row i + 1 is requested while row i is scanned, straight into LDS (global_load_lds: no registers in between),
+//    into the second of two windows -- by the time row i's batches are through it has landed.
+// Everything else is lookup_ascii_kernel: the packed-byte scanner, 64-piece batches through the memo, staging chunks from the
+// bump allocators, rows that are not one ASCII window marked kRowPending for lookup_kernel<kFused>.
+__device__ __forceinline__ void lds_fetch_words(const uint8_t* ga, int nwords, uint32_t* dst) {
+    const int l = lane_id();
+#if defined(OVTK_SIMT_EMULATOR)
+    for (int k = l; k < nwords; k += kWave) dst[k] = *reinterpret_cast<const uint32_t*>(ga + 4 * k);
+#else
+    // one instruction per 64 dwords: lane l's dword goes to dst[64 c + l] (the LDS address is the wave-uniform base + 4 l)
+    for (int c = 0; c * kWave < nwords; ++c)
+        if (c * kWave + l < nwords)
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint32_t*>(ga) + c * kWave + l,
+                                             (__attribute__((address_space(3))) uint32_t*)(dst + c * kWave), 4, 0, /*aux: nt*/ 2);
+#endif
+}
+template <bool DIGITS>
+static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(RowsIn in, BpeDev T, EncodeWork w) {
+    __shared__ uint32_t text_all[kWavesPerBlock][2][kWinBytes / 4];
+    __shared__ uint16_t pstart_all[kWavesPerBlock][kChunk + 2];
+    __shared__ WaveMiss miss_all[kWavesPerBlock];
+    if (w.status->flags & kFatalFlags) return;
+    WaveMiss& mb = miss_all[wave_in_block()];
+    const int l = lane_id();
+    const int wave = wave_uniform(int(blockIdx.x) * kWavesPerBlock + wave_in_block());
+    const int R = w.rows_per_wave;  // <= kWave
+    const int row0 = wave * R;
+    if (row0 >= in.n_rows) return;
+    const int nr = in.n_rows - row0 < R ? in.n_rows - row0 : R;
+    const int mul = T.suffix_len + 1;
+    // ---- the headers of all my rows: lane i = row row0 + i
+    int h_sb = 0, h_len = 0;
+    bool h_simple = false;
+    if (l < nr) {
+        const int cb = in.ragged_begins[row0 + l], ce = in.ragged_ends[row0 + l];
+        if (ce == cb + 1 && cb >= 0 && cb < in.n_strings && !(in.skips && in.skips[cb])) {
+            h_sb = in.begins[cb];
+            h_len = in.ends[cb] - h_sb;
+            h_simple = h_len > 0 && h_len <= kChunk && h_sb >= 0 && (long long)h_sb + h_len <= in.n_chars;
+        }
+    }
+    const unsigned skew0 = unsigned(reinterpret_cast<uintptr_t>(in.chars) & 3u);
+    // a window may be requested ahead when its aligned dwords lie inside the chars tensor (all but the tensor's last row or so)
+    const int h_skew = int((skew0 + unsigned(h_sb)) & 3u);
+    const int h_nwords = (h_skew + h_len + 3) >> 2;
+    const bool h_ahead = h_simple && (long long)h_sb - h_skew + 4ll * h_nwords <= in.n_chars;
+    const unsigned long long simple_m = __ballot(h_simple), ahead_m = __ballot(h_ahead);
+    auto request = [&](int i) {  // row i's text -> window i & 1
+        const int sb = wave_readlane(h_sb, i), skew = wave_readlane(h_skew, i), nwords = wave_readlane(h_nwords, i);
+        lds_fetch_words(in.chars + sb - skew, nwords, text_all[wave_in_block()][i & 1] + kTextPad / 4);
+    };
+    int n_miss = 0, n_pending = 0;
+    int cursor = 0, limit = 0;
+    bool dead = false;  // staging exhausted: the host grows the buffer and reruns
+    if (ahead_m & 1ull) request(0);
+    for (int i = 0; i < nr; ++i) {
+        const int row = row0 + i;
+        const int sb = wave_readlane(h_sb, i), slen = wave_readlane(h_len, i), skew = wave_readlane(h_skew, i);
+        WsView ws{text_all[wave_in_block()][i & 1], pstart_all[wave_in_block()]};
+        bool fast = ((simple_m >> i) & 1ull) != 0 && !dead;
+        int np = 0;
+        if (fast) {
+            // what was requested one row ago has had that row's batches to arrive; nothing else of this wave is in flight
+            drain_vmem();
+            wave_sync();
+            if ((ahead_m >> i) & 1ull) {
+                // the string's own bytes only: those in front of it and behind it in its first / last dword are staged as zeros
+                if (l == 0) {
+                    const int nwords = (skew + slen + 3) >> 2;
+                    uint32_t* t = ws.text_w + kTextPad / 4;
+                    ws.text_w[0] = 0;  // kTextPad
+                    t[0] &= ~((1u << (8 * skew)) - 1u);
+                    const int keep = skew + slen - 4 * (nwords - 1);  // bytes of the last dword that belong to the string: 1..4
+                    if (keep < 4) t[nwords - 1] &= (1u << (8 * keep)) - 1u;
+                }
+            } else {
+                stage_window(ws, in.chars + sb, slen, 0, slen, in.chars, in.chars + in.n_chars);
+            }
+            wave_sync();
+        }
+        // the next row's text, under this row's scan and batches (its window is free: row i - 1 is done with it)
+        if (i + 1 < nr && ((ahead_m >> (i + 1)) & 1ull) && !dead) request(i + 1);
+        if (fast)
+            fast = slen <= 64 * 4 * (kLaneDwords - 1) ? gpt2_packed_starts<kLaneDwords - 1>(ws, skew, slen, DIGITS, 0, slen, np)
+                                                      : gpt2_packed_starts<kLaneDwords>(ws, skew, slen, DIGITS, 0, slen, np);
+        if (fast) {
+            const int cap = slen * mul;
+            if (cursor + cap > limit) {
+                const int size = cap > kStageChunk ? cap : kStageChunk;
+                const int shard = wave % kShards;
+                int base = 0;
+                if (l == 0) base = atomicAdd(&w.status->stage_top[shard * kCounterStride], size);
+                base = wave_readlane(base, 0);
+                if (base < 0 || base > w.stage_region - size) {
+                    if (l == 0) atomicOr(&w.status->flags, kFlagStageOverflow);
+                    dead = true;
+                    fast = false;
+                } else {
+                    cursor = shard * w.stage_region + base;
+                    limit = cursor + size;
+                }
+            }
+        }
+        if (!fast) {
+            if (l == 0) w.row_used[row] = kRowPending;
+            ++n_pending;
+            continue;
+        }
+        if (l == 0) ws.pstart[np] = uint16_t(slen);
+        wave_sync();
+        RowState st{cursor, 0, 0, row};
+        for (int jb = 0; jb < np; jb += kWave) {
+            const int j = jb + l;
+            const bool valid = j < np;
+            int ps = 0, plen = 0;
+            uint64_t r0 = 0, r1 = 0;
+            if (valid) {
+                ps = int(ws.pstart[j]);
+                plen = int(ws.pstart[j + 1]) - ps;
+                if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps + skew, r0, r1);
+            }
+            lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, sb + ps);
         }
         if (l == 0) {
             w.row_stage[row] = cursor;

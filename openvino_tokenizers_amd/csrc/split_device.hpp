@@ -77,6 +77,13 @@ struct WaveScratch {
 __device__ __forceinline__ const uint8_t* text_bytes(const WaveScratch& ws) {
     return reinterpret_cast<const uint8_t*>(ws.text_w) + kTextPad;
 }
+// The same two arrays by pointer: lookup_rows_kernel keeps TWO text windows per wave (the next row's text lands in one while
+// the other is scanned) and one piece list.  The window-level functions it shares with the other kernels are templates over
+// the scratch type.
+struct WsView {
+    uint32_t* text_w;
+    uint16_t* pstart;
+};
 
 __device__ __forceinline__ uint32_t uc_nibble(const SplitDev& sp, uint32_t cp) {
     if (cp >= 0x110000u) return 0;
@@ -199,7 +206,8 @@ __device__ __forceinline__ int llama3_match_end(const SplitDev& sp, const uint8_
 // byte p lives at text_bytes(ws)[p - w0 + skew].  Whole aligned dwords are fetched; a dword that straddles an end of
 // the string is masked down to the string's own bytes (the others are staged as zeros) -- it is still one load as long
 // as it lies inside the chars tensor [buf, buf_end); only at the tensor's own unaligned ends are bytes loaded singly.
-__device__ __forceinline__ int stage_window(WaveScratch& ws, const uint8_t* str, int slen, int w0, int w1, const uint8_t* buf,
+template <class WS>
+__device__ __forceinline__ int stage_window(WS& ws, const uint8_t* str, int slen, int w0, int w1, const uint8_t* buf,
                                             const uint8_t* buf_end) {
     const uint8_t* g = str + w0;
     const int skew = int(reinterpret_cast<uintptr_t>(g) & 3);
@@ -575,8 +583,8 @@ __device__ __forceinline__ uint32_t swar_before(uint32_t lo, uint32_t hi) { retu
 // (the classes of the previous byte, "next byte is not a space", the contraction letters after an apostrophe,
 // contractions that fired up to three bytes back) comes from the neighbouring lanes with one DPP wavefront shift per
 // value.  Index convention below: [0] = last dword of lane l-1, [1..LB] = own dwords, [LB+1] = first dword of lane l+1.
-template <int LB>
-__device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, int skew, int wlen, bool digits, uint32_t& flags) {
+template <int LB, class WS>
+__device__ __forceinline__ bool gpt2_start_flags_ascii(const WS& ws, int skew, int wlen, bool digits, uint32_t& flags) {
     constexpr int LBy = 4 * LB;
     const int l = lane_id();
     const int off = kTextPad + skew + LBy * l;  // byte offset of the lane's first byte in text_w
@@ -683,8 +691,8 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WaveScratch& ws, in
 
 // Packed-byte scan of an ASCII window, LB dwords per lane: ranks the starts of window bytes [lo, hi) (lo itself forced)
 // into ws.pstart, relative to lo.  false (wave-uniform): the window is not ASCII, nothing was written.
-template <int LB>
-__device__ __forceinline__ bool gpt2_packed_starts(WaveScratch& ws, int skew, int wlen, bool digits, int lo, int hi, int& np) {
+template <int LB, class WS>
+__device__ __forceinline__ bool gpt2_packed_starts(WS& ws, int skew, int wlen, bool digits, int lo, int hi, int& np) {
     uint32_t fl = 0;
     if (!gpt2_start_flags_ascii<LB>(ws, skew, wlen, digits, fl)) return false;
     // lane l holds the flags of window bytes [LBy*l, LBy*(l+1)), one bit per byte
