@@ -107,9 +107,9 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     OVTK_HIP(hipStreamSynchronize(nullptr));
     h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>()};
     h->memo_entries = host.stored;
-    // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.  kStoreWays candidate slots per
-    // piece and no relocation on the device: the table is kept below a third full (an insert then finds both taken one time in ten
-    // at the very end, far less on the way).
+    // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.  A piece's two candidate slots are
+    // the halves of one 128-byte line and nothing is relocated on the device: the table is kept below a third full (an insert
+    // finds its line taken a few times in a hundred then).
     // (no more than a few entries per vocabulary token: a 3 000-token test vocabulary does not need 32 MiB of table)
     const int64_t want = std::min<int64_t>({memo_store_entries().load(std::memory_order_relaxed), int64_t(1) << 22,
                                             std::max<int64_t>(8192, 4 * V)});
@@ -121,7 +121,7 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
         if (int rc = h->store_room.upload(&sroom, sizeof sroom)) return rc;
         OVTK_HIP(hipStreamSynchronize(nullptr));
         h->store_capacity = sroom;
-        h->dev.store = PieceStoreDev{h->store.as<StoreEntry>(), 32u - log2u(slots), h->store_room.as<int32_t>(), h->narrow_ids ? 1 : 0};
+        h->dev.store = PieceStoreDev{h->store.as<StoreEntry>(), 32u - log2u(slots / 2), h->store_room.as<int32_t>(), h->narrow_ids ? 1 : 0};  // (shift of the LINE index)
     }
     return OVTK_OK;
 }

@@ -1099,9 +1099,16 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
             const int prev_row = __shfl_up(my_row, 1), next_row = __shfl_down(my_row, 1);
             const bool head = l == 0 || prev_row != my_row, tail = l == kWave - 1 || next_row != my_row;
             const int seg_base = wave_incl_max(head ? incl - f_cnt : 0);  // prefix before this lane's run (monotone)
-            if (valid && tail && incl - seg_base > 0) {
-                atomicAdd(&w.row_cnt[e.row], incl - seg_base);
-                if (w.tile_cnt) atomicAdd(&w.tile_cnt[e.row / kRowTile], incl - seg_base);
+            if (valid && tail && incl - seg_base > 0) atomicAdd(&w.row_cnt[e.row], incl - seg_base);
+            if (w.tile_cnt) {
+                // the same once more per run of equal TILES: with consecutive rows per lookup wave (lookup_rows_kernel) a batch's
+                // rows share a tile, and a dozen adds to ONE address in one instruction are served one after the other
+                // (merge_kernel 58 -> 69 us alone with the per-row adds)
+                const int my_tile = valid ? e.row / kRowTile : -1;
+                const int prev_tile = __shfl_up(my_tile, 1), next_tile = __shfl_down(my_tile, 1);
+                const bool t_head = l == 0 || prev_tile != my_tile, t_tail = l == kWave - 1 || next_tile != my_tile;
+                const int t_base = wave_incl_max(t_head ? incl - f_cnt : 0);
+                if (valid && t_tail && incl - t_base > 0) atomicAdd(&w.tile_cnt[my_tile], incl - t_base);
             }
         }
         // Path L: the batch's pieces of 17..32 symbols, lane per piece again -- 32 of them at a time: 32 lanes x 32

@@ -114,12 +114,12 @@ __host__ __device__ inline uint32_t store_mix(const uint32_t (&key)[8]) {
     }
     return h;
 }
-constexpr int kStoreWays = 2;  // candidate slots of a piece: a lookup fetches both, an insert takes the first free one
-                               // (4 ways, measured: 1 % instead of 6 % failed inserts, merge_kernel 58 -> 69 us alone, step 0.142 -> 0.146 ms)
-__host__ __device__ inline uint32_t store_h(uint32_t mix, int which, uint32_t shift) {
-    const uint32_t m = which == 0 ? mix * 0x2C1B3C6Du : which == 1 ? (mix ^ (mix >> 13)) * 0x85EBCA77u
-                     : which == 2 ? (mix ^ (mix >> 9)) * 0xC2B2AE3Du : (mix ^ (mix >> 17)) * 0x27D4EB2Fu;
-    return m >> shift;
+constexpr int kStoreWays = 2;  // candidate slots of a piece: the two halves of ONE 128-byte line (a lookup fetches both, an insert
+                               // takes the first free one).  Measured on the way: two independent lines per piece doubled the
+                               // kernel's counted HBM traffic for the same hit rate (merge_kernel 47 -> 81 MB per config-2 batch);
+                               // four ways: 1 % instead of 6 % failed inserts, merge_kernel 58 -> 69 us alone, step 0.142 -> 0.146 ms
+__host__ __device__ inline uint32_t store_h(uint32_t mix, int which, uint32_t shift) {  // shift = 32 - log2(lines)
+    return (((mix * 0x2C1B3C6Du) >> shift) << 1) | uint32_t(which);
 }
 // tag of a payload: valid bit | id count | checksum of the ids (a payload that is not completely there does not pass)
 __host__ __device__ inline uint32_t store_fold(const uint32_t (&pay)[8], bool narrow) {
