@@ -48,7 +48,7 @@ from tools.make_tokenizers import load_tokenizer  # noqa: E402
 from tools.workloads import TextModel, ragged_rows  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-KERNEL_NAMES = {"lookup_ascii": "lookup_ascii_kernel", "lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>", "shard_pack": "shard_pack_kernel",
+KERNEL_NAMES = {"lookup_ascii": "lookup_rows_kernel (lookup_ascii_kernel with OVTK_LOOKUP_STRIDED)", "lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>", "shard_pack": "shard_pack_kernel",
                 "shard_unpack": "shard_unpack_kernel", "scan_rows": "scan_kernel", "lookup_flat": "piece_lookup_kernel",
                 "lookup_words": "lookup_kernel<kFused> (BERT words)", "wordpiece_deferred": "wordpiece_deferred_kernel",
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",

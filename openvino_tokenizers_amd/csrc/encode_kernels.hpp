@@ -768,6 +768,10 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
     __shared__ uint32_t text_all[kWavesPerBlock][2][kWinBytes / 4];
     __shared__ uint16_t pstart_all[kWavesPerBlock][kChunk + 2];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
+#ifdef OVTK_LOOKUP_PAD_LDS
+    __shared__ uint32_t lds_pad[OVTK_LOOKUP_PAD_LDS / 4];   // ablation build, see merge_body
+    if (T.unk_id == -12345) lds_pad[threadIdx.x] = 1;
+#endif
     if (w.status->flags & kFatalFlags) return;
     WaveMiss& mb = miss_all[wave_in_block()];
     const int l = lane_id();
@@ -947,6 +951,11 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     __shared__ I2 root_lds[256];
     __shared__ uint8_t long_src_all[kWavesPerBlock][kWave / 2];  // path L: source lane of the piece lane t works on
     __shared__ int pushed_exact;  // this block stored exact-list entries (plain stores the tail block must see)
+#ifdef OVTK_MERGE_PAD_LDS
+    // ablation build ("tables in LDS"): what the kernel would pay in occupancy for an LDS-resident table of this size
+    __shared__ uint32_t lds_pad[OVTK_MERGE_PAD_LDS / 4];
+    if (T.unk_id == -12345) lds_pad[threadIdx.x] = 1;
+#endif
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
     if (threadIdx.x == 0) pushed_exact = 0;
     __syncthreads();

@@ -13,7 +13,7 @@ for ctr, sub in (("FETCH_SIZE", "calib_fetch"), ("WRITE_SIZE", "calib_write")):
     if not f:
         continue
     d = pd.read_csv(f[0])
-    d = d[d.Counter_Name == ctr].sort_values("Dispatch_Id")
+    d = d[(d.Counter_Name == ctr) & d.Kernel_Name.str.contains("calib_")].sort_values("Dispatch_Id")
     print(f"# {ctr} (KB as reported) per launch, in launch order")
     for (_, r), k in zip(d.iterrows(), known):
         name = re.sub(r"\(.*", "", r.Kernel_Name)

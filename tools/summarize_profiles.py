@@ -14,7 +14,7 @@ from pathlib import Path
 import pandas as pd
 
 ROOT = Path(__file__).resolve().parent.parent
-TAG = {"lookup_ascii_kernel": "lookup_ascii", "regex_split_kernel<0>": "regex_count", "regex_split_kernel<1>": "regex_write",
+TAG = {"lookup_ascii_kernel": "lookup_ascii", "lookup_rows_kernel": "lookup_ascii", "regex_split_kernel<0>": "regex_count", "regex_split_kernel<1>": "regex_write",
        "ragged_to_dense_kernel": "ragged_to_dense", "vocab_encoder_kernel": "vocab_encoder",
        "lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "lookup_kernel<2>": "lookup_fused",
        "merge_kernel": "bpe_merge",
