@@ -85,6 +85,7 @@ class IdOut:
     SETS = 6
 
     def __init__(self, rows, cap, dev):
+        self.SETS = max(6, int(os.environ.get("OVTK_BENCH_DEPTH", "2")) + 4)   # (set by main() from --depth)
         self.sets = []
         for _ in range(self.SETS):
             b = torch.empty(rows, dtype=torch.int32, device=dev)
@@ -844,6 +845,7 @@ def main():
     ap.add_argument("--e2e-child", action="store_true", help="internal: run only the end_to_end leg and print its JSON object")
     ap.add_argument("--spawn", action="store_true", help="take the `--gpus N` relaunch under torch.distributed.run even for N = 1 (test)")
     args = ap.parse_args()
+    os.environ["OVTK_BENCH_DEPTH"] = str(args.depth)   # the output rings are sized for the batches in flight
 
     if (args.gpus > 1 or args.spawn) and "WORLD_SIZE" not in os.environ:   # `python bench.py --gpus N`: become N ranks
         have = torch.cuda.device_count()

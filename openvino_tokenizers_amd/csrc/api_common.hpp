@@ -37,6 +37,33 @@ inline int use_device(int device) {
 
 inline StringsView view_of(const ovtk_strings& s) { return StringsView{s.begins, s.ends, s.chars, s.n}; }
 
+// Entries the piece store (tables.hpp) of handles created from now on may take; 0: no store.  Process-wide, like
+// ovtk_set_row_tickets: the reference's attribute list has no room for it (cache_capacity keeps its meaning: 0 = no memo at all).
+inline std::atomic<int64_t>& memo_store_entries() {
+    static std::atomic<int64_t> v{1048576};
+    return v;
+}
+// A handle's piece store: the table (zeroed), its room counter, the device view.  A piece's two candidate slots are the
+// halves of one 128-byte line and nothing is relocated on the device: the table is kept below a third full (an insert finds
+// its line taken a few times in a hundred then).  No more than a few entries per vocabulary token: a 3 000-token test vocabulary
+// does not need 32 MiB of table.
+inline int alloc_piece_store(DevBuf& table, DevBuf& room, int64_t vocab_n, bool narrow, PieceStoreDev& dev, int32_t& capacity) {
+    dev = PieceStoreDev{nullptr, 30, nullptr, 0};
+    capacity = 0;
+    const int64_t want = std::min<int64_t>({memo_store_entries().load(std::memory_order_relaxed), int64_t(1) << 22,
+                                            std::max<int64_t>(8192, 4 * vocab_n)});
+    if (want <= 0) return OVTK_OK;
+    const uint32_t slots = std::max<uint32_t>(1024, pow2_at_least(uint64_t(want) * 3));
+    if (int rc = table.ensure(size_t(slots) * sizeof(StoreEntry))) return rc;
+    OVTK_HIP(hipMemset(table.as<void>(), 0, size_t(slots) * sizeof(StoreEntry)));
+    const int32_t sroom = int32_t(want);
+    if (int rc = room.upload(&sroom, sizeof sroom)) return rc;
+    OVTK_HIP(hipStreamSynchronize(nullptr));
+    capacity = sroom;
+    dev = PieceStoreDev{table.as<StoreEntry>(), 32u - uint32_t(log2u(slots / 2)), room.as<int32_t>(), narrow ? 1 : 0};  // (shift of the LINE index)
+    return OVTK_OK;
+}
+
 inline int check_rows(const ovtk_ragged_strings* in) {
     if (!in) return set_error(OVTK_E_ARG, "null input");
     if (in->n_rows < 0 || in->strings.n < 0 || in->strings.n_chars < 0) return set_error(OVTK_E_ARG, "negative size");

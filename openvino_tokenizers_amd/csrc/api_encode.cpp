@@ -67,12 +67,6 @@ struct ovtk_bpe {
 };
 
 namespace {
-// Entries the piece store (tables.hpp) of handles created from now on may take; 0: no store.  Process-wide, like
-// ovtk_set_row_tickets: the reference's attribute list has no room for it (cache_capacity keeps its meaning: 0 = no memo at all).
-std::atomic<int64_t>& memo_store_entries() {
-    static std::atomic<int64_t> v{1048576};
-    return v;
-}
 int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                ovtk_ragged_i32_out* out, int mem, void* stream);
 
@@ -107,22 +101,8 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     OVTK_HIP(hipStreamSynchronize(nullptr));
     h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>()};
     h->memo_entries = host.stored;
-    // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.  A piece's two candidate slots are
-    // the halves of one 128-byte line and nothing is relocated on the device: the table is kept below a third full (an insert
-    // finds its line taken a few times in a hundred then).
-    // (no more than a few entries per vocabulary token: a 3 000-token test vocabulary does not need 32 MiB of table)
-    const int64_t want = std::min<int64_t>({memo_store_entries().load(std::memory_order_relaxed), int64_t(1) << 22,
-                                            std::max<int64_t>(8192, 4 * V)});
-    if (want > 0) {
-        const uint32_t slots = std::max<uint32_t>(1024, pow2_at_least(uint64_t(want) * 3));
-        if (int rc = h->store.ensure(size_t(slots) * sizeof(StoreEntry))) return rc;
-        OVTK_HIP(hipMemset(h->store.as<void>(), 0, size_t(slots) * sizeof(StoreEntry)));
-        const int32_t sroom = int32_t(want);
-        if (int rc = h->store_room.upload(&sroom, sizeof sroom)) return rc;
-        OVTK_HIP(hipStreamSynchronize(nullptr));
-        h->store_capacity = sroom;
-        h->dev.store = PieceStoreDev{h->store.as<StoreEntry>(), 32u - log2u(slots / 2), h->store_room.as<int32_t>(), h->narrow_ids ? 1 : 0};  // (shift of the LINE index)
-    }
+    // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.
+    if (int rc = alloc_piece_store(h->store, h->store_room, V, h->narrow_ids, h->dev.store, h->store_capacity)) return rc;
     return OVTK_OK;
 }
 }  // namespace

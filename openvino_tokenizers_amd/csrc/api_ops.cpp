@@ -93,7 +93,8 @@ struct ovtk_wordpiece {
     int device = 0;
     WordpieceDev dev{};
     TrieBufs root, sub;
-    DevBuf memo_buf;
+    DevBuf memo_buf, store, store_room;
+    int32_t store_capacity = 0;
     PieceTableDev memo{nullptr, 30};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
 };
 
@@ -153,6 +154,8 @@ int ovtk_wordpiece_create(const ovtk_wordpiece_params* p, ovtk_wordpiece** out) 
         if (int rc = h->memo_buf.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
         OVTK_HIP(hipStreamSynchronize(nullptr));
         h->memo = PieceTableDev{h->memo_buf.as<PieceEntry>(), host.shift};
+        // the words the fused path has to walk the tries for are filed in a store of the handle's own (tables.hpp "piece store")
+        if (int rc = alloc_piece_store(h->store, h->store_room, p->vocab.n, p->vocab.n <= 65535, h->dev.store, h->store_capacity)) return rc;
     }
     *out = h.release();
     return OVTK_OK;

@@ -805,6 +805,9 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
     int n_miss = 0, n_pending = 0;
     int cursor = 0, limit = 0;
     bool dead = false;  // staging exhausted: the host grows the buffer and reruns
+    // the rows' records (staging offset, ids, entries used) collect in lane i for row i and leave with ONE store per array at the
+    // end: four 4-byte stores per row from lane 0 were four partly written 32-byte sectors per row
+    int rec_stage = 0, rec_cnt = 0, rec_used = 0;
     if (ahead_m & 1ull) request(0);
     for (int i = 0; i < nr; ++i) {
         const int row = row0 + i;
@@ -855,7 +858,7 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
             }
         }
         if (!fast) {
-            if (l == 0) w.row_used[row] = kRowPending;
+            if (l == i) rec_used = kRowPending;
             ++n_pending;
             continue;
         }
@@ -874,13 +877,20 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
             }
             lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, sb + ps);
         }
-        if (l == 0) {
-            w.row_stage[row] = cursor;
-            w.row_cnt[row] = st.emitted;
-            if (w.row_emit) w.row_emit[row] = st.emitted;
-            w.row_used[row] = st.used;
+        if (l == i) {
+            rec_stage = cursor;
+            rec_cnt = st.emitted;
+            rec_used = st.used;
         }
         cursor += st.used;
+    }
+    if (l < nr) {
+        w.row_used[row0 + l] = rec_used;
+        if (rec_used != kRowPending) {
+            w.row_stage[row0 + l] = rec_stage;
+            w.row_cnt[row0 + l] = rec_cnt;
+            if (w.row_emit) w.row_emit[row0 + l] = rec_cnt;
+        }
     }
     if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
     if (n_pending && l == 0) atomicAdd(&w.status->n_pending, n_pending);

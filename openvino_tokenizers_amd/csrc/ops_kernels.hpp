@@ -17,6 +17,7 @@ namespace ovtk {
 struct WordpieceDev {
     TrieDev root, sub;
     int32_t max_bytes;
+    PieceStoreDev store;  // word -> ids of the words wordpiece_deferred_kernel had to walk the tries for (tables.hpp "piece store")
 };
 
 // WordPiece of one word (wordpiece_tokenizer.cpp:100-126) into slot[0..): returns the id count (>= 1).
@@ -108,13 +109,40 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
     if (count > w.shard_cap) count = w.shard_cap;
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
     const int stride = int(gridDim.x) * kBlockThreads;
+    const bool store_open = T.store.slots && wave_uniform(__hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > 0;
     for (int base = (int(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kWave; base < count; base += stride) {
         const bool valid = base + l < count;
         DeferredPiece e{};
         if (valid) e = list[base + l];
         int cnt = 0;
-        if (valid) {
-            int32_t* out = w.stage + e.stage_pos;
+        // The word store first (the piece store of tables.hpp, keyed by the word): a word it holds is one probe instead of a
+        // trie walk of one dependent load per byte.  What is filed there never depends on unk_token_id -- a word that came out
+        // as unk is not stored --, so the table stays valid whatever input 8 says on the next call.
+        int32_t* out = w.stage + e.stage_pos;
+        uint32_t skey[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool keyed = T.store.slots && valid && e.len >= 1 && e.len <= kStoreKeyBytes;
+        bool stored = false;
+        if (keyed) {
+            if (e.len <= kPieceKeyBytes) store_key_short(e.k0, e.k1, e.len, skey);
+            else store_key_long(in.chars + e.begin, e.len, skey);
+            uint32_t pay[8];
+            const int c = T.store.narrow ? store_lookup<true>(T.store, skey, pay) : store_lookup<false>(T.store, skey, pay);
+            if (c >= 1) {
+                stored = true;
+                cnt = c;
+                if (T.store.narrow) {
+#pragma unroll
+                    for (int k = 0; k < kStoreIds16; ++k)
+                        if (k < c) out[k] = store_id<true>(pay, k);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < kStoreIds32; ++k)
+                        if (k < c) out[k] = store_id<false>(pay, k);
+                }
+                for (int k = c; k < e.len; ++k) out[k] = kEmptyId;
+            }
+        }
+        if (valid && !stored) {
             if (e.len >= 1 && e.len <= kPieceKeyBytes) {
                 const uint64_t k0 = e.k0, k1 = e.k1;
                 cnt = wordpiece_word(
@@ -126,6 +154,25 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                 cnt = wordpiece_word(T, root_lds, sub_lds, [&](int i) -> uint32_t { return s[i]; }, e.len, unk_id, out);
             }
             for (int k = cnt; k < e.len; ++k) out[k] = kEmptyId;
+        }
+        if (store_open) {  // file what was walked: its ids come back from the lane's own staging entries
+            const int max_ids = T.store.narrow ? kStoreIds16 : kStoreIds32;
+            const bool want = keyed && !stored && cnt <= max_ids && !(cnt == 1 && out[0] == unk_id);
+            if (__ballot(want)) {
+                bool added = false;
+                if (want) {
+                    uint32_t pay[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < kStoreIds16; ++k) {
+                        const uint32_t v = k < cnt ? uint32_t(out[k]) : 0u;
+                        if (T.store.narrow) pay[k >> 1] |= v << (16 * (k & 1));
+                        else if (k < kStoreIds32) pay[k] = v;
+                    }
+                    added = T.store.narrow ? store_insert<true>(T.store, skey, pay, cnt) : store_insert<false>(T.store, skey, pay, cnt);
+                }
+                const int n_added = __popcll(__ballot(added));
+                if (l == 0 && n_added) atomicAdd(T.store.room, -n_added);
+            }
         }
         const int incl = wave_incl_sum(cnt);
         const int my_row = valid ? e.row : -1;

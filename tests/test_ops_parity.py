@@ -95,8 +95,16 @@ def test_fused_split_wordpiece(backend, name, kind, n, target):
     assert_same(words[:4], s2[:4], backend.host, "BERT split chain")
     got = wp.evaluate(list(s2[:5]) + wp_consts(tok))
     assert_same(ref, got, backend.host, "WordpieceTokenizer on device-split words")
-    fused = FusedSplitWordpiece(ws, pu, wp).evaluate(data, ws_pat, pu_pat, wp_consts(tok)[0:3] + [np.asarray(tok["unk_id"], np.int32)])
+    chain = FusedSplitWordpiece(ws, pu, wp)
+    fused = chain.evaluate(data, ws_pat, pu_pat, wp_consts(tok)[0:3] + [np.asarray(tok["unk_id"], np.int32)])
     assert_same(ref, fused, backend.host, "fused split + WordPiece")
+    # once more on what the word store learned, and with another unk_token_id (input 8 is read every call,
+    # wordpiece_tokenizer.cpp:74: nothing that was filed may depend on it)
+    fused = chain.evaluate(data, ws_pat, pu_pat, wp_consts(tok)[0:3] + [np.asarray(tok["unk_id"], np.int32)])
+    assert_same(ref, fused, backend.host, "fused split + WordPiece, second call")
+    ref7 = O.WordpieceTokenizer(tok["vocab"], tok["suffix_indicator"], tok["max_bytes_per_word"])(*words, 7)
+    fused = chain.evaluate(data, ws_pat, pu_pat, wp_consts(tok)[0:3] + [np.asarray(7, np.int32)])
+    assert_same(ref7, fused, backend.host, "fused split + WordPiece, unk_token_id = 7")
 
 
 def test_fused_split_wordpiece_edge_cases(backend):
@@ -113,6 +121,7 @@ def test_fused_split_wordpiece_edge_cases(backend):
         fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
                                     WordpieceTokenizer("##", max_bytes, lib=backend.lib))
         assert_same(ref, fused.evaluate(backend.data(inputs), ws_pat, pu_pat, consts), backend.host, f"max_bytes={max_bytes}")
+        assert_same(ref, fused.evaluate(backend.data(inputs), ws_pat, pu_pat, consts), backend.host, f"max_bytes={max_bytes}, word store warm")
     empty = one_string_per_row(["", ""])
     ref = O.WordpieceTokenizer(vocab, "##", 100)(*bert_words(empty), 0)
     fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
