@@ -2,6 +2,7 @@
 #pragma once
 
 #include <atomic>
+#include <functional>
 
 #include <hip/hip_runtime.h>
 
@@ -276,6 +277,8 @@ public:
     }
     // The middle knows the one-launch form of a small batch (EncodeWork::small, encode_small_kernel).
     void enable_small() { small_ok_ = true; }
+    // Called with the status block of the attempt that completed the run (finish(), the caller's thread).
+    void on_status(std::function<void(const RunStatus&)> f) { on_status_ = std::move(f); }
     // The result leaves in the row-shard exchange's wire form (device memory) instead of begins / ends / ids.
     void output_to_wire(const WireSink& wire) {
         wire_ = wire;
@@ -350,6 +353,7 @@ public:
                     return set_error(OVTK_E_CAPACITY, op_ + ": output ids buffer too small (" + std::to_string(st.n_out) +
                                                           " ids, capacity " + std::to_string(out_.data_capacity) + ")");
                 out->n_data = st.n_out;
+                if (on_status_) on_status_(st);
                 if (wire_.hdr) return OVTK_OK;  // (device memory: the wire is complete)
                 if (direct_out_) return OVTK_OK;  // the kernels wrote the caller's pinned buffers
                 if (int rc = copy_back(out_.begins, d_begins_, size_t(n_rows_) * 4, mem_, s_)) return rc;
@@ -462,6 +466,7 @@ private:
     bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
     bool small_ok_ = false, small_ = false;
     WireSink wire_{};
+    std::function<void(const RunStatus&)> on_status_;
     RowsIn d_in_{};
     int n_rows_ = 0, grid_ = 0, n_tiles_ = 0;
     int64_t stage_cap_ = 0, shard_cap_ = 0, exact_cap_ = 0, scratch_cap_ = 0;

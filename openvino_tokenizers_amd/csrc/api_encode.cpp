@@ -64,6 +64,8 @@ struct ovtk_bpe {
     size_t memo_entries = 0;
     int32_t memo_capacity = 0;  // entries the device may add (cache_capacity)
     bool narrow_ids = false;  // every token id < 65536: merge_kernel keeps ids as u16 in LDS
+    // rows the specialised lookup kernel left to the generic one in the handle's most recent call (-1: none finished yet)
+    mutable std::atomic<int> last_pending{-1};
 };
 
 namespace {
@@ -561,16 +563,24 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
                                    const bool ahead = !strided && w1.rows_per_wave <= kWave;
                                    if (ahead && split->dev.kind == kSplitGpt2Digits)
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<true>, grid, kBlockThreads, s, d_in, bpe->dev, w1);
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsGpt2Digits>, grid, kBlockThreads, s, d_in,
+                                                   split->dev, bpe->dev, w1);
                                    else if (ahead)
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<false>, grid, kBlockThreads, s, d_in, bpe->dev, w1);
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsGpt2>, grid, kBlockThreads, s, d_in, split->dev,
+                                                   bpe->dev, w1);
                                    else if (split->dev.kind == kSplitGpt2Digits)
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<true>, grid, kBlockThreads, s, d_in, bpe->dev, w);
                                    else
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<false>, grid, kBlockThreads, s, d_in, bpe->dev, w);
+                                   // what it left: the generic kernel, rows strided over ITS waves.  A full grid of blocks that
+                                   // find nothing to do costs 4-6 us per batch; when the handle's last call left no row (text that is
+                                   // ASCII throughout keeps being so) a few blocks stand by instead -- they take whatever does turn
+                                   // up, just more slowly, and the next call sees the count and launches the full grid again
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
+                                   const int g2 = bpe->last_pending.load(std::memory_order_relaxed) == 0 ? std::min(grid, 64) : grid;
+                                   w2.n_waves = g2 * kWavesPerBlock;
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, g2, kBlockThreads, s, d_in, split->dev,
                                                bpe->dev, w2);
                                } else if (split)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in,
@@ -607,6 +617,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     } else if (device_inputs) {
         r->input_on_device(device_inputs);
     }
+    r->on_status([bpe](const RunStatus& st) { bpe->last_pending.store(st.n_pending, std::memory_order_relaxed); });
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
     if (wire) r->output_to_wire(*wire);
     if (int rc = r->start()) return rc;

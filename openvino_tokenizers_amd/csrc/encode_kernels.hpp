@@ -763,8 +763,11 @@ __device__ __forceinline__ void lds_fetch_words(const uint8_t* ga, int nwords, u
                                              (__attribute__((address_space(3))) uint32_t*)(dst + c * kWave), 4, 0, /*aux: nt*/ 2);
 #endif
 }
-template <bool DIGITS>
-static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(RowsIn in, BpeDev T, EncodeWork w) {
+// SCAN: which packed-byte scanner reads the window -- the GPT-2 rules, the same with every digit on its own, or the BERT words
+// (white space dropped, every delimiter character a word: the fused WordPiece path; `T` then holds nothing but the word memo).
+enum RowsScan : int { kRowsGpt2 = 0, kRowsGpt2Digits = 1, kRowsBertWords = 2 };
+template <int SCAN>
+static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ uint32_t text_all[kWavesPerBlock][2][kWinBytes / 4];
     __shared__ uint16_t pstart_all[kWavesPerBlock][kChunk + 2];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
@@ -836,9 +839,16 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
         }
         // the next row's text, under this row's scan and batches (its window is free: row i - 1 is done with it)
         if (i + 1 < nr && ((ahead_m >> (i + 1)) & 1ull) && !dead) request(i + 1);
-        if (fast)
-            fast = slen <= 64 * 4 * (kLaneDwords - 1) ? gpt2_packed_starts<kLaneDwords - 1>(ws, skew, slen, DIGITS, 0, slen, np)
-                                                      : gpt2_packed_starts<kLaneDwords>(ws, skew, slen, DIGITS, 0, slen, np);
+        if (fast) {
+            if (SCAN == kRowsBertWords)
+                fast = slen <= 256 ? class_packed_starts<1>(ws, sp, skew, slen, 0, slen, np)
+                                   : (slen <= 512 ? class_packed_starts<2>(ws, sp, skew, slen, 0, slen, np)
+                                                  : class_packed_starts<kLaneDwords>(ws, sp, skew, slen, 0, slen, np));
+            else
+                fast = slen <= 64 * 4 * (kLaneDwords - 1)
+                           ? gpt2_packed_starts<kLaneDwords - 1>(ws, skew, slen, SCAN == kRowsGpt2Digits, 0, slen, np)
+                           : gpt2_packed_starts<kLaneDwords>(ws, skew, slen, SCAN == kRowsGpt2Digits, 0, slen, np);
+        }
         if (fast) {
             const int cap = slen * mul;
             if (cursor + cap > limit) {
@@ -867,13 +877,20 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
         RowState st{cursor, 0, 0, row};
         for (int jb = 0; jb < np; jb += kWave) {
             const int j = jb + l;
-            const bool valid = j < np;
+            bool valid = j < np;
             int ps = 0, plen = 0;
             uint64_t r0 = 0, r1 = 0;
             if (valid) {
-                ps = int(ws.pstart[j]);
-                plen = int(ws.pstart[j + 1]) - ps;
-                if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps + skew, r0, r1);
+                if (SCAN == kRowsBertWords) {   // (the class scanners flag the pieces RegexSplit drops: white space)
+                    const uint32_t p0 = ws.pstart[j];
+                    ps = int(p0 & kPiecePosMask);
+                    plen = int(ws.pstart[j + 1] & kPiecePosMask) - ps;
+                    valid = !(p0 & kPieceDropped);
+                } else {
+                    ps = int(ws.pstart[j]);
+                    plen = int(ws.pstart[j + 1]) - ps;
+                }
+                if (valid && plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps + skew, r0, r1);
             }
             lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, sb + ps);
         }

@@ -991,8 +991,8 @@ __device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const Spli
 // The class patterns (kSplitWhitespace / kSplitBertPunct / kSplitBertWords) on an ASCII window, packed bytes, LB dwords
 // per lane: same result as class_start_mask + the ranking loop of scan_string -- pstart entries of window bytes
 // [lo, hi) relative to lo, kPieceDropped on the pieces that are not emitted.  false (wave-uniform): not ASCII.
-template <int LB>
-__device__ __forceinline__ bool class_packed_starts(WaveScratch& ws, const SplitDev& sp, int skew, int wlen, int lo, int hi, int& np) {
+template <int LB, class WS>
+__device__ __forceinline__ bool class_packed_starts(WS& ws, const SplitDev& sp, int skew, int wlen, int lo, int hi, int& np) {
     constexpr int LBy = 4 * LB;
     const int l = lane_id();
     const int off = kTextPad + skew + LBy * l;

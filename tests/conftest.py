@@ -21,8 +21,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def emu_lib():
     """The kernel sources compiled against tests/emu (CPU fibers).  Test infrastructure only."""
+    import fcntl
     from openvino_tokenizers_amd import _lib as L
-    subprocess.run(["make", "-C", str(ROOT / "openvino_tokenizers_amd" / "csrc"), "-s", "emu"], check=True)
+    (ROOT / "tests" / "emu" / "build").mkdir(parents=True, exist_ok=True)
+    with open(ROOT / "tests" / "emu" / "build" / ".lock", "w") as lock:   # pytest -n: one worker builds, the others wait
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.run(["make", "-C", str(ROOT / "openvino_tokenizers_amd" / "csrc"), "-s", "emu"], check=True)
     return L.load(ROOT / "tests" / "emu" / "build" / "libovtk_emu.so")
 
 

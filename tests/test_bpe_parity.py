@@ -658,3 +658,22 @@ def test_fuzzed_tables(backend):
         for rep in range(2):
             got = op.evaluate(backend.data(inputs) + tok.consts, ids_capacity=cap)
             assert_same(ref, got, backend.host, f"case {k} rep {rep} attrs {tok.attrs}")
+
+
+def test_pending_rows_after_a_call_without_any(backend):
+    """The generic lookup kernel that takes what the ASCII kernel leaves stands by with a few blocks when the handle's last call
+    left nothing (api_encode.cpp, last_pending): an all-ASCII batch, then batches full of non-ASCII rows, multi-string rows
+    and over-long rows on the SAME handle, then ASCII again -- every call equals the oracle."""
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    n = 40 if backend.name == "emu" else 2000
+    for k, kind in enumerate(("zipf", "mixed", "mixed", "zipf", "mixed")):
+        b, e, c = TextModel(90 + k, kind).batch(n, 200)
+        rb, re_ = ragged_rows(n)
+        if k == 2:   # rows of two strings, and one string longer than a scan window
+            rb = np.arange(0, n, 2, dtype=np.int32)
+            re_ = np.minimum(rb + 2, n).astype(np.int32)
+        ref = orc(*rs(rb, re_, b, e, c)[:5])
+        assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [pat], tok.consts), backend.host, f"call {k} ({kind})")
