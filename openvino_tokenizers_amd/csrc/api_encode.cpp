@@ -547,9 +547,24 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                if (llama3 && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFusedLlama3, true>), grid, kBlockThreads, s, d_in,
                                                split->dev, bpe->dev, w);
-                               else if (llama3)
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in,
-                                               split->dev, bpe->dev, w);
+                               else if (llama3) {
+                                   static const bool strided = std::getenv("OVTK_LOOKUP_STRIDED") != nullptr;
+                                   EncodeWork w1 = w;
+                                   w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
+                                   if (!strided && w1.rows_per_wave <= kWave) {   // as for the GPT-2 family below
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsLlama3>, grid, kBlockThreads, s, d_in, split->dev,
+                                                   bpe->dev, w1);
+                                       EncodeWork w2 = w;
+                                       w2.only_pending = 1;
+                                       const int g2 = bpe->last_pending.load(std::memory_order_relaxed) == 0 ? std::min(grid, 64) : grid;
+                                       w2.n_waves = g2 * kWavesPerBlock;
+                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, g2, kBlockThreads, s, d_in, split->dev,
+                                                   bpe->dev, w2);
+                                   } else {
+                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in,
+                                                   split->dev, bpe->dev, w);
+                                   }
+                               }
                                else if (split && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFused, true>), grid, kBlockThreads, s, d_in,
                                                split->dev, bpe->dev, w);

@@ -765,9 +765,9 @@ __device__ __forceinline__ void lds_fetch_words(const uint8_t* ga, int nwords, u
 }
 // SCAN: which packed-byte scanner reads the window -- the GPT-2 rules, the same with every digit on its own, or the BERT words
 // (white space dropped, every delimiter character a word: the fused WordPiece path; `T` then holds nothing but the word memo).
-enum RowsScan : int { kRowsGpt2 = 0, kRowsGpt2Digits = 1, kRowsBertWords = 2 };
+enum RowsScan : int { kRowsGpt2 = 0, kRowsGpt2Digits = 1, kRowsBertWords = 2, kRowsLlama3 = 3 };
 template <int SCAN>
-static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? 4 : 6) void lookup_rows_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ uint32_t text_all[kWavesPerBlock][2][kWinBytes / 4];
     __shared__ uint16_t pstart_all[kWavesPerBlock][kChunk + 2];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
@@ -797,12 +797,17 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
     }
     const unsigned skew0 = unsigned(reinterpret_cast<uintptr_t>(in.chars) & 3u);
     // a window may be requested ahead when its aligned dwords lie inside the chars tensor (all but the tensor's last row or so)
-    const int h_skew = int((skew0 + unsigned(h_sb)) & 3u);
-    const int h_nwords = (h_skew + h_len + 3) >> 2;
-    const bool h_ahead = h_simple && (long long)h_sb - h_skew + 4ll * h_nwords <= in.n_chars;
-    const unsigned long long simple_m = __ballot(h_simple), ahead_m = __ballot(h_ahead);
+    unsigned long long simple_m, ahead_m;
+    {
+        const int h_skew = int((skew0 + unsigned(h_sb)) & 3u);
+        const int h_nwords = (h_skew + h_len + 3) >> 2;
+        const bool h_ahead = h_simple && (long long)h_sb - h_skew + 4ll * h_nwords <= in.n_chars;
+        simple_m = __ballot(h_simple);
+        ahead_m = __ballot(h_ahead);
+    }
     auto request = [&](int i) {  // row i's text -> window i & 1
-        const int sb = wave_readlane(h_sb, i), skew = wave_readlane(h_skew, i), nwords = wave_readlane(h_nwords, i);
+        const int sb = wave_readlane(h_sb, i), slen = wave_readlane(h_len, i);
+        const int skew = int((skew0 + unsigned(sb)) & 3u), nwords = (skew + slen + 3) >> 2;
         lds_fetch_words(in.chars + sb - skew, nwords, text_all[wave_in_block()][i & 1] + kTextPad / 4);
     };
     int n_miss = 0, n_pending = 0;
@@ -814,7 +819,8 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
     if (ahead_m & 1ull) request(0);
     for (int i = 0; i < nr; ++i) {
         const int row = row0 + i;
-        const int sb = wave_readlane(h_sb, i), slen = wave_readlane(h_len, i), skew = wave_readlane(h_skew, i);
+        const int sb = wave_readlane(h_sb, i), slen = wave_readlane(h_len, i);
+        const int skew = int((skew0 + unsigned(sb)) & 3u);
         WsView ws{text_all[wave_in_block()][i & 1], pstart_all[wave_in_block()]};
         bool fast = ((simple_m >> i) & 1ull) != 0 && !dead;
         int np = 0;
@@ -840,7 +846,15 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
         // the next row's text, under this row's scan and batches (its window is free: row i - 1 is done with it)
         if (i + 1 < nr && ((ahead_m >> (i + 1)) & 1ull) && !dead) request(i + 1);
         if (fast) {
-            if (SCAN == kRowsBertWords)
+            if (SCAN == kRowsLlama3) {
+                // the packed form of the Llama-3 rules decides the whole string, or says that it cannot (a window that needs the
+                // ballot form or the literal matcher: a non-ASCII digit, nine digits in a row ...): the generic kernel's business
+                int und = 0;
+                bool seq = false;
+                fast = slen <= 512 ? llama3_packed_starts<2>(ws, sp, skew, slen, 0, slen, true, np, und, seq)
+                                   : llama3_packed_starts<3>(ws, sp, skew, slen, 0, slen, true, np, und, seq);
+                if (seq || und < slen) fast = false;
+            } else if (SCAN == kRowsBertWords)
                 fast = slen <= 256 ? class_packed_starts<1>(ws, sp, skew, slen, 0, slen, np)
                                    : (slen <= 512 ? class_packed_starts<2>(ws, sp, skew, slen, 0, slen, np)
                                                   : class_packed_starts<kLaneDwords>(ws, sp, skew, slen, 0, slen, np));
@@ -881,7 +895,7 @@ static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_rows_kernel(Ro
             int ps = 0, plen = 0;
             uint64_t r0 = 0, r1 = 0;
             if (valid) {
-                if (SCAN == kRowsBertWords) {   // (the class scanners flag the pieces RegexSplit drops: white space)
+                if (SCAN == kRowsBertWords || SCAN == kRowsLlama3) {   // (the class scanners flag the pieces RegexSplit drops: white space)
                     const uint32_t p0 = ws.pstart[j];
                     ps = int(p0 & kPiecePosMask);
                     plen = int(ws.pstart[j + 1] & kPiecePosMask) - ps;

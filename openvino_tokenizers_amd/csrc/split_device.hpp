@@ -239,7 +239,8 @@ __device__ __forceinline__ int stage_window(WS& ws, const uint8_t* str, int slen
 
 // Code point of the char whose lead byte b (>= 0xC0) is window byte i; a char cut off by the window's end is decoded
 // from the bytes that are there.  The four bytes from i come as two aligned LDS dwords and a funnel shift: no loop.
-__device__ __forceinline__ uint32_t decode_lead(const WaveScratch& ws, int skew, int i, uint32_t b, int wlen) {
+template <class WS>
+__device__ __forceinline__ uint32_t decode_lead(const WS& ws, int skew, int i, uint32_t b, int wlen) {
     const int off = kTextPad + skew + i;
     const int a = off >> 2, sh = (off & 3) * 8;
     const uint32_t x = uint32_t(((static_cast<unsigned long long>(ws.text_w[a + 1]) << 32) | ws.text_w[a]) >> sh);
@@ -745,8 +746,8 @@ __device__ __forceinline__ void l3_halo(uint32_t (&f)[M]) {  // own dwords [2 ..
 }
 // Ranks the piece starts of window bytes [lo, hi2) into ws.pstart (relative to lo; lo itself forced), hi2 = min(hi, und).
 // false: the window is for llama3_start_mask (nothing written); `fallback`: for the literal matcher.
-template <int LB>
-__device__ __forceinline__ bool llama3_packed_starts(WaveScratch& ws, const SplitDev& sp, int skew, int wlen, int lo, int hi, bool at_end,
+template <int LB, class WS>
+__device__ __forceinline__ bool llama3_packed_starts(WS& ws, const SplitDev& sp, int skew, int wlen, int lo, int hi, bool at_end,
                                                      int& np, int& undecided, bool& fallback) {
     constexpr int LBy = 4 * LB, M = LB + 4, AL = LB + 1;  // own dwords at [2 .. AL]
     const int l = lane_id();
