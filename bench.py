@@ -50,7 +50,7 @@ from tools.workloads import TextModel, ragged_rows  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 KERNEL_NAMES = {"lookup_ascii": "lookup_rows_kernel (lookup_ascii_kernel with OVTK_LOOKUP_STRIDED)", "lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>", "shard_pack": "shard_pack_kernel",
                 "shard_unpack": "shard_unpack_kernel", "scan_rows": "scan_kernel", "lookup_flat": "piece_lookup_kernel",
-                "lookup_words": "lookup_kernel<kFused> (BERT words)", "wordpiece_deferred": "wordpiece_deferred_kernel",
+                "lookup_words": "lookup_rows_kernel<BERT words> (lookup_kernel<kFused> with OVTK_LOOKUP_STRIDED)", "wordpiece_deferred": "wordpiece_deferred_kernel",
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",
                 "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel", "split_count": "split_kernel<0>",
                 "split_write": "split_kernel<1>", "ragged_to_dense": "ragged_to_dense_kernel", "vocab_encoder": "vocab_encoder_kernel",

@@ -64,8 +64,6 @@ struct ovtk_bpe {
     size_t memo_entries = 0;
     int32_t memo_capacity = 0;  // entries the device may add (cache_capacity)
     bool narrow_ids = false;  // every token id < 65536: merge_kernel keeps ids as u16 in LDS
-    // rows the specialised lookup kernel left to the generic one in the handle's most recent call (-1: none finished yet)
-    mutable std::atomic<int> last_pending{-1};
 };
 
 namespace {
@@ -556,9 +554,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                                    bpe->dev, w1);
                                        EncodeWork w2 = w;
                                        w2.only_pending = 1;
-                                       const int g2 = bpe->last_pending.load(std::memory_order_relaxed) == 0 ? std::min(grid, 64) : grid;
-                                       w2.n_waves = g2 * kWavesPerBlock;
-                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, g2, kBlockThreads, s, d_in, split->dev,
+                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
                                                    bpe->dev, w2);
                                    } else {
                                        OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in,
@@ -587,15 +583,12 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<true>, grid, kBlockThreads, s, d_in, bpe->dev, w);
                                    else
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<false>, grid, kBlockThreads, s, d_in, bpe->dev, w);
-                                   // what it left: the generic kernel, rows strided over ITS waves.  A full grid of blocks that
-                                   // find nothing to do costs 4-6 us per batch; when the handle's last call left no row (text that is
-                                   // ASCII throughout keeps being so) a few blocks stand by instead -- they take whatever does turn
-                                   // up, just more slowly, and the next call sees the count and launches the full grid again
+                                   // what it left: the generic kernel (it returns at once when nothing was left).  A smaller stand-by
+                                   // grid for handles whose last call left no row was measured: nothing gained on all-ASCII text
+                                   // (6.0 vs 6.2 us), and the rows that do turn up then wait for 64 blocks to walk every row's flag
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
-                                   const int g2 = bpe->last_pending.load(std::memory_order_relaxed) == 0 ? std::min(grid, 64) : grid;
-                                   w2.n_waves = g2 * kWavesPerBlock;
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, g2, kBlockThreads, s, d_in, split->dev,
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
                                                bpe->dev, w2);
                                } else if (split)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in,
@@ -632,7 +625,6 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     } else if (device_inputs) {
         r->input_on_device(device_inputs);
     }
-    r->on_status([bpe](const RunStatus& st) { bpe->last_pending.store(st.n_pending, std::memory_order_relaxed); });
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
     if (wire) r->output_to_wire(*wire);
     if (int rc = r->start()) return rc;

@@ -96,7 +96,6 @@ struct ovtk_wordpiece {
     TrieBufs root, sub;
     DevBuf memo_buf, store, store_room;
     int32_t store_capacity = 0;
-    mutable std::atomic<int> last_pending{-1};  // rows lookup_rows_kernel left to the generic kernel in the most recent fused call
     PieceTableDev memo{nullptr, 30};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
 };
 
@@ -225,7 +224,7 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                            [=](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                // rows that are one ASCII window: lookup_rows_kernel (consecutive rows per wave, the next row's text
                                    // requested ahead: encode_kernels.hpp); what it leaves -- marked in row_used -- goes through the
-                                   // generic kernel, which stands by with a few blocks when the handle's last call left nothing
+                                   // generic kernel
                                static const bool strided = std::getenv("OVTK_LOOKUP_STRIDED") != nullptr;
                                EncodeWork w1 = w;
                                w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
@@ -234,9 +233,7 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                                memo_only, w1);
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
-                                   const int g2 = h->last_pending.load(std::memory_order_relaxed) == 0 ? std::min(grid, 64) : grid;
-                                   w2.n_waves = g2 * kWavesPerBlock;
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, g2, kBlockThreads, s, d_in, sp, memo_only, w2);
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp, memo_only, w2);
                                } else {
                                    OVTK_LAUNCH(ws.marks, "lookup_words", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp, memo_only, w);
                                }
@@ -245,7 +242,6 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                            kBlockThreads, s, d_in, wdev, unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
                            },
                            /*self_alloc=*/true, resident_blocks_per_cu(lookup_kernel<kFused>), /*tail_in_middle=*/true);
-    r->on_status([h](const RunStatus& st) { h->last_pending.store(st.n_pending, std::memory_order_relaxed); });
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;

@@ -661,9 +661,8 @@ def test_fuzzed_tables(backend):
 
 
 def test_pending_rows_after_a_call_without_any(backend):
-    """The generic lookup kernel that takes what the ASCII kernel leaves stands by with a few blocks when the handle's last call
-    left nothing (api_encode.cpp, last_pending): an all-ASCII batch, then batches full of non-ASCII rows, multi-string rows
-    and over-long rows on the SAME handle, then ASCII again -- every call equals the oracle."""
+    """lookup_rows_kernel leaves the rows that are not one ASCII window to the generic kernel: an all-ASCII batch, then batches
+    full of non-ASCII rows and multi-string rows on the SAME handle, then ASCII again -- every call equals the oracle."""
     tok = BpeTok.load("gpt2_small")
     fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
     orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")

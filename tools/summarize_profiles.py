@@ -81,8 +81,8 @@ def main(prefix):
                 fetch = float(g[g.Counter_Name == "FETCH_SIZE"].mean_KB.sum())
                 write = float(g[g.Counter_Name == "WRITE_SIZE"].mean_KB.sum())
                 per[tag_of(k)] = int((2 * fetch + write) * 1024)
-            if cfg == 3 and "lookup_fused" in per:
-                per["lookup_words"] = per["lookup_fused"]  # bench.py's name for the same kernel run with the BERT scanner
+            if cfg == 3:   # bench.py's name for the lookup kernel run with the BERT words scanner (lookup_rows_kernel since r03)
+                per["lookup_words"] = per.pop("lookup_ascii") if "lookup_ascii" in per else per.get("lookup_fused", 0)
             pmc_json[f"config{cfg}"] = per
     (ROOT / "profiles" / "latest_pmc.json").write_text(json.dumps(pmc_json, indent=1, sort_keys=True) + "\n")
     print(json.dumps(pmc_json, indent=1))
