@@ -416,7 +416,18 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     uint64_t k0 = 0, k1 = 0;
     if (valid && plen >= 1 && plen <= kPieceKeyBytes) {
         piece_key(r0, r1, plen, k0, k1);
+#if defined(OVTK_ABLATE) && OVTK_ABLATE == 2   // counter build: no hash, no probe -- every piece "hits" with one id
+        cnt = 1;
+        tok[0] = int32_t(k0 & 0xFF);
+#elif defined(OVTK_ABLATE) && OVTK_ABLATE == 3   // counter build: hash and loads, no compare / select
+        {
+            const MemoFetch f = memo_fetch(T.pieces, k0, k1);
+            cnt = 1;
+            tok[0] = int32_t(f.p[0].x ^ f.p[1].x ^ f.k[0].x ^ f.k[1].x);
+        }
+#else
         if (T.pieces.slots) cnt = memo_lookup(T.pieces, k0, k1, tok);
+#endif
     }
     const bool hit = cnt >= 0;
     const int need = valid ? (hit ? cnt : plen + SL) : 0;
@@ -889,6 +900,10 @@ static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? 4 : 6) 
         if (l == 0) ws.pstart[np] = uint16_t(slen);
         wave_sync();
         RowState st{cursor, 0, 0, row};
+#if defined(OVTK_ABLATE) && OVTK_ABLATE == 1   // counter build: the scan alone (no batches)
+        st.used = np;
+        np = 0;
+#endif
         for (int jb = 0; jb < np; jb += kWave) {
             const int j = jb + l;
             bool valid = j < np;
