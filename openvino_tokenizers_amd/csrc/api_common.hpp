@@ -386,12 +386,14 @@ private:
         const size_t status_bytes = sizeof(RunStatus) + (fold ? size_t(n_tiles_) * 4 : 0);  // + tile_cnt, zeroed with the status
         e = e ? e : ws.status.ensure(status_bytes);
         if (fold) e = e ? e : ws.gen[4].ensure(size_t(n_rows_) * 4);
+        if (self_alloc_) e = e ? e : ws.gen[5].ensure(size_t(n_rows_) * 4);
         if (e) return e;
         EncodeWork w{};
         w.n_waves = grid_ * kWavesPerBlock;
         w.fold_tail = fold;
         w.tile_cnt = fold ? reinterpret_cast<int32_t*>(ws.status.as<uint8_t>() + sizeof(RunStatus)) : nullptr;
         w.row_emit = fold ? ws.gen[4].as<int32_t>() : nullptr;
+        w.pending_rows = self_alloc_ ? ws.gen[5].as<int32_t>() : nullptr;
         w.out_cap = out_.data_capacity;
         w.rows_per_ticket = self_alloc_ ? row_tickets().load(std::memory_order_relaxed) : 0;
         w.wave_off = self_alloc_ ? nullptr : ws.wave_off.as<long long>();

@@ -588,6 +588,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // (6.0 vs 6.2 us), and the rows that do turn up then wait for 64 blocks to walk every row's flag
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
+                                   if (!ahead) w2.pending_rows = nullptr;   // (lookup_ascii_kernel marks its rows in row_used only)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
                                                bpe->dev, w2);
                                } else if (split)

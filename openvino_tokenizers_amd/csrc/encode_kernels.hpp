@@ -68,6 +68,8 @@ struct EncodeWork {
     int32_t status_words;   //   dwords of `status` to zero at the kernel's start (RunStatus + the tile counts behind it)
     int32_t rows_per_ticket;  // lookup_kernel, allocator mode: 0 = static rows per wave, else rows handed out per ticket
     int32_t rows_per_wave;    // lookup_rows_kernel: wave w owns the rows [w * rows_per_wave, (w + 1) * rows_per_wave)
+    int32_t* pending_rows;    // [n_rows] or nullptr: the rows lookup_rows_kernel left to the generic kernel, status->n_pending of
+                              //          them in no particular order (nullptr: the generic kernel looks for kRowPending in row_used)
     int32_t n_waves;        // persistent waves of the prep / lookup launches (wave w owns rows w, w + n_waves, ...)
     long long* wave_off;    // [n_waves + 1] staging arena of each wave (exclusive scan of its rows' capacities), or
                             // nullptr: the lookup kernel takes staging chunks from kShards bump allocators itself
@@ -587,8 +589,14 @@ __device__ __forceinline__ void lookup_body(const RowsIn& in, const SplitDev& sp
         row = tk_resolve();
         chunk_end = row + rpt;
     }
+    // only_pending with a list: wave k takes entries k, k + n_waves, ... of it (a few thousand rows of a batch of 131 072: walking
+    // every row's flag cost the Llama-3 configuration 27 us)
+    const bool listed = !TICKETS && w.only_pending && w.pending_rows;
+    const int n_listed = listed ? w.status->n_pending : 0;
+    int list_at = wave;
+    if (listed) row = list_at < n_listed ? uniform_load(w.pending_rows + list_at) : -1;
     while (row >= 0 && row < in.n_rows) {
-        if (!TICKETS && w.only_pending && uniform_load(w.row_used + row) != kRowPending) {  // done by lookup_ascii_kernel
+        if (!TICKETS && !listed && w.only_pending && uniform_load(w.row_used + row) != kRowPending) {  // done by lookup_ascii_kernel
             row += n_waves;
             continue;
         }
@@ -656,7 +664,10 @@ __device__ __forceinline__ void lookup_body(const RowsIn& in, const SplitDev& sp
             w.row_used[row] = st.used;
         }
         cursor += st.used;
-        if (!rpt) {
+        if (listed) {
+            list_at += n_waves;
+            row = list_at < n_listed ? uniform_load(w.pending_rows + list_at) : -1;
+        } else if (!rpt) {
             row += n_waves;
         } else if (++row == chunk_end) {
             row = tk_resolve();
@@ -939,7 +950,13 @@ static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? 4 : 6) 
         }
     }
     if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
-    if (n_pending && l == 0) atomicAdd(&w.status->n_pending, n_pending);
+    if (n_pending) {   // (wave-uniform) the rows left to the generic kernel: counted, and listed for it
+        int base = 0;
+        if (l == 0) base = atomicAdd(&w.status->n_pending, n_pending);
+        base = wave_readlane(base, 0);
+        const unsigned long long pm = __ballot(l < nr && rec_used == kRowPending);
+        if (w.pending_rows && ((pm >> l) & 1ull)) w.pending_rows[base + __popcll(pm & lanemask_lt())] = row0 + l;
+    }
 }
 
 // ---- path X, one lane per piece.
