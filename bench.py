@@ -244,7 +244,8 @@ def make_workload(args, lib, dev, rank):
     """-> (workload object or dict, description pieces)."""
     cfg = args.config
     if cfg == "2":
-        w = BpeEncode(args, lib, dev, rank, args.tokenizer, args.text, args.rows, args.bytes, 1000, no_memo=args.no_memo)
+        w = BpeEncode(args, lib, dev, rank, args.tokenizer, args.text, args.rows, args.bytes, 1000, no_memo=args.no_memo,
+                      cache_capacity=getattr(args, "cache_capacity", None))
         w.metric = "input MB/s encoded (GPT-2 BPE, 512-byte strings)"
         w.dominant_hint = "lookup_ascii"
         w.workload = (f"config 2: GPT-2-shaped byte-level BPE (V=50257, 50000 merges, trained in-process), {args.rows} x "
@@ -841,6 +842,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
+    ap.add_argument("--cache-capacity", type=int, default=None, help="config 2: the BPETokenizer attribute (debug; default: the converter's 20000)")
     ap.add_argument("--memo-store", type=int, default=-1, help="ovtk_set_memo_store(n) before the tokenizer is built (debug; default: the library's)")
     ap.add_argument("--e2e-child", action="store_true", help="internal: run only the end_to_end leg and print its JSON object")
     ap.add_argument("--spawn", action="store_true", help="take the `--gpus N` relaunch under torch.distributed.run even for N = 1 (test)")
