@@ -64,6 +64,9 @@ struct ovtk_bpe {
     size_t memo_entries = 0;
     int32_t memo_capacity = 0;  // entries the device may add (cache_capacity)
     bool narrow_ids = false;  // every token id < 65536: merge_kernel keeps ids as u16 in LDS
+    // calls that still leave the piece store out: set to 32 after four calls in a row in which fewer than one probe in eight
+    // hit (then the store is asked again, and so on -- text changes)
+    mutable std::atomic<int> store_pause{0}, store_low{0};  // store_low: calls in a row with that little use of it
 };
 
 namespace {
@@ -524,7 +527,14 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
         skips = nullptr;  // BPETokenizer has no skips input: skipped strings arrive as whole pieces
         split = nullptr;
     }
-    auto r = make_rows_run(dev, "BPETokenizer", in, skips, 1 + bpe->dev.suffix_len, out, mem, s,
+    // This call's view of the tables: the piece store is left out while it is paused (a text whose pieces never repeat -- uniform
+    // random bytes -- only pays for it: probes that miss, inserts nobody reads; 0.56 -> 0.62 ms per step before the pause existed)
+    BpeDev T = bpe->dev;
+    if (T.store.slots && bpe->store_pause.load(std::memory_order_relaxed) > 0) {
+        bpe->store_pause.fetch_sub(1, std::memory_order_relaxed);
+        T.store = PieceStoreDev{nullptr, 30, nullptr, 0};
+    }
+    auto r = make_rows_run(dev, "BPETokenizer", in, skips, 1 + T.suffix_len, out, mem, s,
                            [=](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                const bool tickets = w.rows_per_ticket != 0;
                                const bool llama3 = split && split->dev.kind == kSplitLlama3;
@@ -533,8 +543,8 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    const bool nar = bpe->narrow_ids;
 #define OVTK_SMALL(MODE)                                                                                                          \
     do {                                                                                                                          \
-        if (nar) OVTK_LAUNCH(ws.marks, "encode_small", (encode_small_kernel<MODE, true>), grid, kBlockThreads, s, d_in, sd, bpe->dev, w); \
-        else OVTK_LAUNCH(ws.marks, "encode_small", (encode_small_kernel<MODE, false>), grid, kBlockThreads, s, d_in, sd, bpe->dev, w);    \
+        if (nar) OVTK_LAUNCH(ws.marks, "encode_small", (encode_small_kernel<MODE, true>), grid, kBlockThreads, s, d_in, sd, T, w); \
+        else OVTK_LAUNCH(ws.marks, "encode_small", (encode_small_kernel<MODE, false>), grid, kBlockThreads, s, d_in, sd, T, w);    \
     } while (0)
                                    if (llama3) OVTK_SMALL(kFusedLlama3);
                                    else if (split) OVTK_SMALL(kFused);
@@ -544,26 +554,26 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                }
                                if (llama3 && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFusedLlama3, true>), grid, kBlockThreads, s, d_in,
-                                               split->dev, bpe->dev, w);
+                                               split->dev, T, w);
                                else if (llama3) {
                                    static const bool strided = std::getenv("OVTK_LOOKUP_STRIDED") != nullptr;
                                    EncodeWork w1 = w;
                                    w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
                                    if (!strided && w1.rows_per_wave <= kWave) {   // as for the GPT-2 family below
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsLlama3>, grid, kBlockThreads, s, d_in, split->dev,
-                                                   bpe->dev, w1);
+                                                   T, w1);
                                        EncodeWork w2 = w;
                                        w2.only_pending = 1;
                                        OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
-                                                   bpe->dev, w2);
+                                                   T, w2);
                                    } else {
                                        OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in,
-                                                   split->dev, bpe->dev, w);
+                                                   split->dev, T, w);
                                    }
                                }
                                else if (split && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFused, true>), grid, kBlockThreads, s, d_in,
-                                               split->dev, bpe->dev, w);
+                                               split->dev, T, w);
                                else if (split && split->dev.kind <= kSplitGpt2Digits) {
                                    // rows that are one ASCII scan window: the specialised kernel; whatever it leaves
                                    // (marked in row_used) goes through the generic one
@@ -575,14 +585,14 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    const bool ahead = !strided && w1.rows_per_wave <= kWave;
                                    if (ahead && split->dev.kind == kSplitGpt2Digits)
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsGpt2Digits>, grid, kBlockThreads, s, d_in,
-                                                   split->dev, bpe->dev, w1);
+                                                   split->dev, T, w1);
                                    else if (ahead)
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsGpt2>, grid, kBlockThreads, s, d_in, split->dev,
-                                                   bpe->dev, w1);
+                                                   T, w1);
                                    else if (split->dev.kind == kSplitGpt2Digits)
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<true>, grid, kBlockThreads, s, d_in, bpe->dev, w);
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<true>, grid, kBlockThreads, s, d_in, T, w);
                                    else
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<false>, grid, kBlockThreads, s, d_in, bpe->dev, w);
+                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<false>, grid, kBlockThreads, s, d_in, T, w);
                                    // what it left: the generic kernel (it returns at once when nothing was left).  A smaller stand-by
                                    // grid for handles whose last call left no row was measured: nothing gained on all-ASCII text
                                    // (6.0 vs 6.2 us), and the rows that do turn up then wait for 64 blocks to walk every row's flag
@@ -590,29 +600,29 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    w2.only_pending = 1;
                                    if (!ahead) w2.pending_rows = nullptr;   // (lookup_ascii_kernel marks its rows in row_used only)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
-                                               bpe->dev, w2);
+                                               T, w2);
                                } else if (split)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in,
-                                               split->dev, bpe->dev, w);
+                                               split->dev, T, w);
                                else if (tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_pieces", (lookup_kernel<kPieces, true>), grid, kBlockThreads, s, d_in,
-                                               SplitDev{}, bpe->dev, w);
+                                               SplitDev{}, T, w);
                                else
                                    OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid, kBlockThreads, s, d_in,
-                                               SplitDev{}, bpe->dev, w);
+                                               SplitDev{}, T, w);
                                const int tail_rows = w.fold_tail ? d_in.n_rows : 0;
                                if (bpe->narrow_ids) {
                                    static const int per_cu = resident_blocks_per_cu(merge_kernel<true>);
                                    OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<true>,
                                                dim3(kShards, grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * per_cu / kShards)),
-                                               kBlockThreads, s, d_in, bpe->dev, w, tail_rows, w.out_cap);
+                                               kBlockThreads, s, d_in, T, w, tail_rows, w.out_cap);
                                } else {
                                    static const int per_cu = resident_blocks_per_cu(merge_kernel<false>);
                                    OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<false>,
                                                dim3(kShards, grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * per_cu / kShards)),
-                                               kBlockThreads, s, d_in, bpe->dev, w, tail_rows, w.out_cap);
+                                               kBlockThreads, s, d_in, T, w, tail_rows, w.out_cap);
                                }
-                               if (!w.fold_tail) OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, bpe->dev, w);
+                               if (!w.fold_tail) OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, T, w);
                            },
                            /*self_alloc=*/true,
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
@@ -626,6 +636,16 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     } else if (device_inputs) {
         r->input_on_device(device_inputs);
     }
+    if (T.store.slots)   // what the store did for this call decides whether the next ones ask it at all
+        r->on_status([bpe](const RunStatus& st) {
+            if (st.n_store_probe < 4096) return;
+            // (a cold store misses everything too: only a run of such calls says that the text is the reason)
+            if (st.n_store_hit * 8 >= st.n_store_probe) bpe->store_low.store(0, std::memory_order_relaxed);
+            else if (bpe->store_low.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {
+                bpe->store_low.store(0, std::memory_order_relaxed);
+                bpe->store_pause.store(32, std::memory_order_relaxed);
+            }
+        });
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
     if (wire) r->output_to_wire(*wire);
     if (int rc = r->start()) return rc;

@@ -32,7 +32,9 @@ struct RunStatus {
     uint32_t ticket[2];    // "last block done" tickets of prep_rows_kernel / count_scan_kernel
     uint32_t rows_done;    // bit s: row-ticket shard s is exhausted (lookup_kernel)
     int32_t n_pending;     // rows lookup_ascii_kernel left to lookup_kernel<kFused> (not a single ASCII window)
-    int32_t pad[22];
+    int32_t n_store_probe; // deferred pieces merge_kernel looked up in the piece store ...
+    int32_t n_store_hit;   // ... and found there
+    int32_t pad[20];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
     int32_t stage_top[kShards * kCounterStride];    // [s * kCounterStride] = staging entries handed out in region s
     int32_t row_ticket[kShards * kCounterStride];   // [s * kCounterStride] = rows of range s handed to waves (lookup_kernel)

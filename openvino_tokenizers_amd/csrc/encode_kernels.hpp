@@ -1103,6 +1103,13 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 for (int k = c; k < need; ++k) out[k] = kEmptyId;
             }
         }
+        if (T.store.slots) {   // (returnless: what the store does for this call decides whether the next ones ask it)
+            const unsigned long long pm = __ballot(keyed), hm = __ballot(stored);
+            if (l == 0 && pm) {
+                atomicAdd(&w.status->n_store_probe, int(__popcll(pm)));
+                if (hm) atomicAdd(&w.status->n_store_hit, int(__popcll(hm)));
+            }
+        }
         // What the batch had to merge is offered to the store while it has room (`store_open`, read once per wave at the
         // kernel's start: the count is kept with returnless adds, nothing here waits for an atomic's answer).
         auto store_offer = [&](bool want, const uint32_t (&key)[8], uint32_t (&pay)[8], int cnt) {

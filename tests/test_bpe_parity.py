@@ -676,3 +676,20 @@ def test_pending_rows_after_a_call_without_any(backend):
             re_ = np.minimum(rb + 2, n).astype(np.int32)
         ref = orc(*rs(rb, re_, b, e, c)[:5])
         assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [pat], tok.consts), backend.host, f"call {k} ({kind})")
+
+
+def test_store_pauses_on_text_it_cannot_help(gpu_backend):
+    """Uniform-random text: every piece is new, the piece store is probed and filled for nothing.  After four such calls in a
+    row the handle leaves the store out for a while (api_encode.cpp store_pause); results never depend on that -- every call,
+    before, during and after the pause, equals the oracle."""
+    backend = gpu_backend
+    tok = BpeTok.load("gpt2_small")
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    n = 2500
+    for k, kind in enumerate(["uniform"] * 7 + ["zipf", "uniform", "zipf"]):
+        b, e, c = TextModel(300 + k, kind).batch(n, 220)
+        rb, re_ = ragged_rows(n)
+        ref = orc(*rs(rb, re_, b, e, c)[:5])
+        assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [pat], tok.consts), backend.host, f"call {k} ({kind})")
