@@ -638,7 +638,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     }
     if (T.store.slots)   // what the store did for this call decides whether the next ones ask it at all
         r->on_status([bpe](const RunStatus& st) {
-            if (st.n_store_probe < 4096) return;
+            if (st.n_store_probe < 256) return;   // (counted by one wave in 64)
             // (a cold store misses everything too: only a run of such calls says that the text is the reason)
             if (st.n_store_hit * 8 >= st.n_store_probe) bpe->store_low.store(0, std::memory_order_relaxed);
             else if (bpe->store_low.fetch_add(1, std::memory_order_relaxed) + 1 >= 4) {

@@ -32,7 +32,7 @@ struct RunStatus {
     uint32_t ticket[2];    // "last block done" tickets of prep_rows_kernel / count_scan_kernel
     uint32_t rows_done;    // bit s: row-ticket shard s is exhausted (lookup_kernel)
     int32_t n_pending;     // rows lookup_ascii_kernel left to lookup_kernel<kFused> (not a single ASCII window)
-    int32_t n_store_probe; // deferred pieces merge_kernel looked up in the piece store ...
+    int32_t n_store_probe; // deferred pieces merge_kernel looked up in the piece store (a sample: one wave in 64 counts) ...
     int32_t n_store_hit;   // ... and found there
     int32_t pad[20];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
