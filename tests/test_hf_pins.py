@@ -170,7 +170,8 @@ def test_oracle_wordpiece_full_vocabulary_matches_hf():
     assert np.array_equal(b, z["id_begins"]) and np.array_equal(e, z["id_ends"]) and np.array_equal(ids, z["ids"])
 
 
-def test_device_wordpiece_full_vocabulary_matches_hf(backend):
+def test_device_wordpiece_full_vocabulary_matches_hf(gpu_backend):
+    backend = gpu_backend   # (building the V = 30 522 handle on the emulator takes half a minute; the small vocabulary runs there)
     z, rows = _bert_inputs()
     t = load_tokenizer("bert")
     consts = list(pack_strings(t["vocab"])) + [np.asarray(t["unk_id"], np.int32)]
