@@ -173,12 +173,13 @@ def test_detokenize_full_size(hip_lib):
     assert np.array_equal(ofz[1], fused[1][:k].cpu().numpy()) and np.array_equal(obf[2][: int(ofz[1][-1])], fused[2][: int(ofz[1][-1])].cpu().numpy())
 
 
-def test_many_short_rows(hip_lib):
-    """300 000 rows (more than the folded tail of merge_kernel takes: the separate exact / count_scan launches run)
-    of ~24 bytes: halves back to back = the whole batch, offsets gap-free, the oracle on a prefix."""
+@pytest.mark.parametrize("rows", [300000, 420000])
+def test_many_short_rows(hip_lib, rows):
+    """300 000 rows (more than the folded tail of merge_kernel takes: the separate exact / count_scan launches run; 49
+    consecutive rows per wave of lookup_rows_kernel) and 420 000 (more than 64 rows per wave: the strided lookup_ascii_kernel
+    takes over) of ~24 bytes: halves back to back = the whole batch, offsets gap-free, the oracle on a prefix."""
     import torch
     tok = BpeTok.load("gpt2")
-    rows = 300000
     b, e, c = TextModel(99, "zipf").batch(rows, 24, seed=5)
     rb, re_ = ragged_rows(rows)
     pat = tok.pattern_u8()
