@@ -99,10 +99,14 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     // The dynamic part (memo_insert in encode_kernels.hpp): up to cache_capacity further pieces, the ones the vocabulary
     // needs more than one token for, kept the first time merge_kernel computes them -- the reference's rule, its numbers.
     const int32_t room = int32_t(std::min<int64_t>(std::max<int64_t>(cache_capacity, 0), INT32_MAX / 2));
-    if (int rc = h->memo_room.upload(&room, sizeof room)) return rc;
+    const uint32_t room_mask = room >= 4096 ? uint32_t(kRoomShards - 1) : 0u;   // (a handful of entries: one counter)
+    std::vector<int32_t> rooms(size_t(kRoomShards) * kRoomStride, 0);
+    for (uint32_t k = 0; k <= room_mask; ++k)
+        rooms[size_t(k) * kRoomStride] = room / int32_t(room_mask + 1) + (int32_t(k) < room % int32_t(room_mask + 1) ? 1 : 0);
+    if (int rc = h->memo_room.upload(rooms.data(), rooms.size() * sizeof(int32_t))) return rc;
     h->memo_capacity = room;
     OVTK_HIP(hipStreamSynchronize(nullptr));
-    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>()};
+    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), room_mask};
     h->memo_entries = host.stored;
     // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.
     if (int rc = alloc_piece_store(h->store, h->store_room, V, h->narrow_ids, h->dev.store, h->store_capacity)) return rc;
@@ -349,7 +353,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     d.trie.edge_shift = host.trie.edge_shift;
     d.merges = h->merges.as<MergeBucket>();
     d.bucket_shift = host.bucket_shift;
-    d.pieces = PieceTableDev{nullptr, 30};
+    d.pieces = PieceTableDev{nullptr, 30, nullptr, 0};
     d.store = PieceStoreDev{nullptr, 30, nullptr, 0};
     d.new_id = h->new_id.as<int32_t>();
     d.byte_fallback_id = h->bf.as<int32_t>();
@@ -373,10 +377,12 @@ int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned) {
     *learned = 0;
     if (!h->dev.pieces.room) return OVTK_OK;
     if (int rc = use_device(h->device)) return rc;
-    int32_t room = 0;
+    std::vector<int32_t> rooms(size_t(kRoomShards) * kRoomStride, 0);
     OVTK_HIP(hipDeviceSynchronize());
-    OVTK_HIP(hipMemcpy(&room, h->dev.pieces.room, sizeof room, hipMemcpyDeviceToHost));
-    *learned = h->memo_capacity - std::max<int32_t>(room, 0);
+    OVTK_HIP(hipMemcpy(rooms.data(), h->dev.pieces.room, rooms.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int64_t left = 0;
+    for (uint32_t k = 0; k <= h->dev.pieces.room_mask; ++k) left += std::max<int32_t>(rooms[size_t(k) * kRoomStride], 0);
+    *learned = h->memo_capacity - left;
     return OVTK_OK;
 }
 

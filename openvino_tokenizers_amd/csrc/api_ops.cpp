@@ -96,7 +96,7 @@ struct ovtk_wordpiece {
     TrieBufs root, sub;
     DevBuf memo_buf, store, store_room;
     int32_t store_capacity = 0;
-    PieceTableDev memo{nullptr, 30};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
+    PieceTableDev memo{nullptr, 30, nullptr, 0};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
 };
 
 struct ovtk_vocab_encoder {
@@ -154,7 +154,7 @@ int ovtk_wordpiece_create(const ovtk_wordpiece_params* p, ovtk_wordpiece** out) 
         build_piece_table(view_of(p->vocab), ob.data(), oe.data(), ids.data(), host);
         if (int rc = h->memo_buf.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
         OVTK_HIP(hipStreamSynchronize(nullptr));
-        h->memo = PieceTableDev{h->memo_buf.as<PieceEntry>(), host.shift};
+        h->memo = PieceTableDev{h->memo_buf.as<PieceEntry>(), host.shift, nullptr, 0};
         // the words the fused path has to walk the tries for are filed in a store of the handle's own (tables.hpp "piece store")
         if (int rc = alloc_piece_store(h->store, h->store_room, p->vocab.n, p->vocab.n <= 65535, h->dev.store, h->store_capacity)) return rc;
     }

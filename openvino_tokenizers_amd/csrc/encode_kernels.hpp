@@ -250,24 +250,28 @@ __device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uin
 // equals a key), or complete (payload checked by its tag).  A piece whose slots are both taken stays a miss.
 // `granted`: this lane may take one entry of the remaining room.  Returns false when nothing was added.
 __device__ __forceinline__ bool memo_insert(const PieceTableDev& P, uint64_t k0, uint64_t k1, const int32_t (&tok)[kPieceMaxIds], int cnt) {
+    // (the lookup kernel has just missed this piece; nothing is read first -- one CAS per candidate tried.  A candidate that is
+    // being written, or holds this very piece -- filed by another wave a moment ago -- ends the attempt.)
     const uint32_t mix = piece_mix(k0, k1);
     const uint32_t d3 = uint32_t(k1 >> 32);
-    PieceEntry* cand[2] = {const_cast<PieceEntry*>(P.slots) + piece_h(mix, 0, P.shift), const_cast<PieceEntry*>(P.slots) + piece_h(mix, 1, P.shift)};
-    uint32_t seen[2][4];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            seen[c][j] = __hip_atomic_load(reinterpret_cast<uint32_t*>(cand[c]) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t* slot = nullptr;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        if (seen[c][3] == kPieceBusy) return false;  // somebody is writing there, possibly this very piece: not now
-        if (seen[c][0] == uint32_t(k0) && seen[c][1] == uint32_t(k0 >> 32) && seen[c][2] == uint32_t(k1) && seen[c][3] == d3) return false;
+        if (slot) break;
+        uint32_t* cand = reinterpret_cast<uint32_t*>(const_cast<PieceEntry*>(P.slots) + piece_h(mix, c, P.shift));
+        const uint32_t old = atomicCAS(cand + 3, 0u, kPieceBusy);
+        if (old == 0u) {
+            slot = cand;
+        } else if (old == kPieceBusy) {
+            return false;
+        } else if (old == d3) {   // same length (and tail): this very piece?  (only then are its other dwords read)
+            if (__hip_atomic_load(cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == uint32_t(k0) &&
+                __hip_atomic_load(cand + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == uint32_t(k0 >> 32) &&
+                __hip_atomic_load(cand + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == uint32_t(k1))
+                return false;
+        }
     }
-    const int c = seen[0][3] == 0 ? 0 : (seen[1][3] == 0 ? 1 : -1);
-    if (c < 0) return false;
-    uint32_t* slot = reinterpret_cast<uint32_t*>(cand[c]);
-    if (atomicCAS(slot + 3, 0u, kPieceBusy) != 0u) return false;  // lost the slot (no second try: the winner may hold this piece)
+    if (!slot) return false;
     *reinterpret_cast<uint4*>(slot + 4) = uint4{uint32_t(tok[0]), uint32_t(tok[1]), uint32_t(tok[2]), piece_tag(mix, cnt)};
     *reinterpret_cast<uint4*>(slot) = uint4{uint32_t(k0), uint32_t(k0 >> 32), uint32_t(k1), d3};
     return true;
@@ -347,9 +351,8 @@ __device__ __forceinline__ int32_t store_id(const uint32_t (&pay)[8], int k) {  
 // here.  The caller has just looked the piece up and missed, so nothing is read first: one CAS per way tried.  (The first
 // version read every candidate with agent-scope loads before claiming one and kept an exact count of the room with a
 // returning atomic: five dependent round trips behind every merge chain -- with a store that still had room merge_kernel
-// took 78 us instead of 57.)  A slot that holds another piece of the same length and tail, or is being written, ends the
-// attempt: it may be this very piece, filed by another wave a moment ago; a duplicate in the second way would be harmless
-// (equal payloads) but wastes a slot.
+// took 78 us instead of 57.)  A slot that is being written, or holds this very piece (filed by another wave a moment ago: its
+// last key dword says whether that is worth checking), ends the attempt.
 template <bool NARROW>
 __device__ __forceinline__ bool store_insert(const PieceStoreDev& S, const uint32_t (&key)[8], uint32_t (&pay)[8], int cnt) {
     if (NARROW) pay[7] = (pay[7] & 0xFFFFu) | (store_tag16(pay, cnt) << 16);
@@ -361,8 +364,16 @@ __device__ __forceinline__ bool store_insert(const PieceStoreDev& S, const uint3
         if (slot) break;
         uint32_t* cand = reinterpret_cast<uint32_t*>(S.slots + store_h(mix, c, S.shift));
         const uint32_t old = atomicCAS(cand + 7, 0u, kPieceBusy);
-        if (old == 0u) slot = cand;
-        else if (old == kPieceBusy || old == key[7]) return false;
+        if (old == 0u) {
+            slot = cand;
+        } else if (old == kPieceBusy) {
+            return false;
+        } else if (old == key[7]) {   // same length (and tail): this very piece?  (only then are its other dwords read)
+            bool same = true;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) same = same && __hip_atomic_load(cand + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[j];
+            if (same) return false;
+        }
     }
     if (!slot) return false;
     *reinterpret_cast<uint4*>(slot + 8) = uint4{pay[0], pay[1], pay[2], pay[3]};
@@ -1164,12 +1175,13 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         }
         // the memo learns the batch's short results while it has room (one atomic per wave takes the room)
         if (T.pieces.room) {
+            int32_t* my_room = T.pieces.room + ((blockIdx.x + 5u * blockIdx.y + uint32_t(wave_in_block())) & T.pieces.room_mask) * kRoomStride;
             const unsigned long long km = __ballot(keep);
             int room_now = 0;
-            if (l == 0 && km) room_now = __hip_atomic_load(T.pieces.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l == 0 && km) room_now = __hip_atomic_load(my_room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (wave_readlane(room_now, 0) > 0) {
                 int left = 0;
-                if (l == 0) left = atomicAdd(T.pieces.room, -int(__popcll(km)));
+                if (l == 0) left = atomicAdd(my_room, -int(__popcll(km)));
                 left = wave_readlane(left, 0);
                 const int rank = __popcll(km & lanemask_lt());
                 bool added = false;
@@ -1180,7 +1192,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                     added = memo_insert(T.pieces, e.k0, e.k1, t3, f_cnt);
                 }
                 const int unused = __popcll(km) - __popcll(__ballot(added));  // room taken but not filled goes back
-                if (l == 0 && unused) atomicAdd(T.pieces.room, unused);
+                if (l == 0 && unused) atomicAdd(my_room, unused);
             }
         }
         // ids of the lane-per-piece results go to row_cnt: the 64 entries of a batch were flushed by ONE wave in

@@ -81,8 +81,14 @@ constexpr uint32_t kPieceBusy = 0xFF000000u;  // dword 3 of a key (length byte 2
 struct PieceTableDev {
     const PieceEntry* slots;  // nullptr: no memo (every piece takes the merge path)
     uint32_t shift;           // 32 - log2(capacity)
-    int32_t* room;            // entries merge_kernel may still add (cache_capacity at create); nullptr: a fixed table
+    int32_t* room;            // entries merge_kernel may still add (cache_capacity at create); nullptr: a fixed table.
+                              // kRoomShards counters, kRoomStride ints apart (one per 128-byte line), that share the capacity:
+                              // every wave-batch with something to file takes its room with a RETURNING add (that is what keeps
+                              // `learned <= cache_capacity` exact), and 3 700 of those per launch on ONE address are most of a
+                              // 50-us kernel (a capacity that never fills: 0.125 -> 0.166 ms per step at cache_capacity = 200 000)
+    uint32_t room_mask;       // kRoomShards - 1, or 0 for small capacities (one counter holds it all)
 };
+constexpr int kRoomShards = 16, kRoomStride = 32;
 // ---- the piece store: the memo's second level, probed by merge_kernel only (never by the lookup kernels).
 // The first level above is sized for an XCD's L2 and for ONE round trip in the hot loop: 15-byte keys, 3 ids, the
 // vocabulary's own tokens plus cache_capacity learned pieces.  What it does not hold reaches merge_kernel as a deferred
