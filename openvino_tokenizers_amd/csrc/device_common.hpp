@@ -112,6 +112,16 @@ __device__ __forceinline__ void stream_store(T* p, T v) {
 #endif
 }
 
+// Bits [sh, sh + 32) of the 64-bit value hi:lo, sh in 0..31 -- ONE v_alignbit_b32.  Written as a 64-bit shift the compiler
+// emits v_lshrrev_b64 on a register pair it first has to assemble; the scanners and the key fetch do this for every dword.
+__device__ __forceinline__ uint32_t funnel_shr(uint32_t lo, uint32_t hi, int sh) {
+#ifdef OVTK_SIMT_EMULATOR
+    return uint32_t(((static_cast<unsigned long long>(hi) << 32) | lo) >> sh);
+#else
+    return __builtin_amdgcn_alignbit(hi, lo, uint32_t(sh));
+#endif
+}
+
 // Publishing data to other workgroups of the same launch (MI355X_MICROARCH.md "inter-workgroup visibility"): the
 // producer's plain stores -> __syncthreads() -> ONE lane: agent-scope release + vmcnt drain -> device-scope atomic
 // ticket; the block that draws the last ticket does an agent-scope acquire -> __syncthreads() -> plain loads.

@@ -194,8 +194,8 @@ __device__ __forceinline__ void piece_key(uint64_t raw0, uint64_t raw1, int plen
 __device__ __forceinline__ void lds_bytes16(const uint32_t* words, int off, uint64_t& r0, uint64_t& r1) {
     const int a = off >> 2, sh = (off & 3) * 8;
     const uint32_t w0 = words[a], w1 = words[a + 1], w2 = words[a + 2], w3 = words[a + 3], w4 = words[a + 4];
-    const uint32_t d0 = uint32_t(((uint64_t(w1) << 32) | w0) >> sh), d1 = uint32_t(((uint64_t(w2) << 32) | w1) >> sh);
-    const uint32_t d2 = uint32_t(((uint64_t(w3) << 32) | w2) >> sh), d3 = uint32_t(((uint64_t(w4) << 32) | w3) >> sh);
+    const uint32_t d0 = funnel_shr(w0, w1, sh), d1 = funnel_shr(w1, w2, sh);
+    const uint32_t d2 = funnel_shr(w2, w3, sh), d3 = funnel_shr(w3, w4, sh);
     r0 = (uint64_t(d1) << 32) | d0;
     r1 = (uint64_t(d3) << 32) | d2;
 }

@@ -209,7 +209,7 @@ __device__ __forceinline__ bool load_words16(const uint8_t* p, int len, const ui
     for (int j = 0; j < 5; ++j) r[j] = j < nw ? q[j] : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t x = uint32_t(((static_cast<unsigned long long>(r[j + 1]) << 32) | r[j]) >> sh);
+        const uint32_t x = funnel_shr(r[j], r[j + 1], sh);
         const int have = len - 4 * j;
         w[j] = have >= 4 ? x : (have <= 0 ? 0u : (x & ((1u << (8 * have)) - 1u)));
     }

@@ -243,7 +243,7 @@ template <class WS>
 __device__ __forceinline__ uint32_t decode_lead(const WS& ws, int skew, int i, uint32_t b, int wlen) {
     const int off = kTextPad + skew + i;
     const int a = off >> 2, sh = (off & 3) * 8;
-    const uint32_t x = uint32_t(((static_cast<unsigned long long>(ws.text_w[a + 1]) << 32) | ws.text_w[a]) >> sh);
+    const uint32_t x = funnel_shr(ws.text_w[a], ws.text_w[a + 1], sh);
     const int n = b >= 0xF0u ? 4 : (b >= 0xE0u ? 3 : 2);
     const int have = wlen - i < n ? wlen - i : n;
     uint32_t cp = b & (0xFFu >> (n + 1));
@@ -600,7 +600,7 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WS& ws, int skew, i
     for (int j = 1; j <= LB; ++j) {
         const int have = nv - 4 * (j - 1);  // bytes of dword j that exist
         const uint32_t m = have >= 4 ? ~0u : (have <= 0 ? 0u : ((1u << (8 * have)) - 1u));
-        x[j] = uint32_t(((static_cast<unsigned long long>(r[j]) << 32) | r[j - 1]) >> sh) & m;
+        x[j] = funnel_shr(r[j - 1], r[j], sh) & m;
         V[j] = m & kB7;
         any |= x[j];
     }
@@ -766,7 +766,7 @@ __device__ __forceinline__ bool llama3_packed_starts(WS& ws, const SplitDev& sp,
     for (int j = 0; j < LB; ++j) {
         const int have = nv - 4 * j;
         const uint32_t m = have >= 4 ? ~0u : (have <= 0 ? 0u : ((1u << (8 * have)) - 1u));
-        const uint32_t xx = uint32_t(((static_cast<unsigned long long>(r[j + 1]) << 32) | r[j]) >> sh) & m;
+        const uint32_t xx = funnel_shr(r[j], r[j + 1], sh) & m;
         const int a = j + 2;
         x[a] = xx;
         V[a] = m & kB7;
@@ -1008,7 +1008,7 @@ __device__ __forceinline__ bool class_packed_starts(WS& ws, const SplitDev& sp, 
     for (int j = 1; j <= LB; ++j) {
         const int have = nv - 4 * (j - 1);
         const uint32_t m = have >= 4 ? ~0u : (have <= 0 ? 0u : ((1u << (8 * have)) - 1u));
-        x[j] = uint32_t(((static_cast<unsigned long long>(r[j]) << 32) | r[j - 1]) >> sh) & m;
+        x[j] = funnel_shr(r[j - 1], r[j], sh) & m;
         V[j] = m & kB7;
         any |= x[j];
     }
