@@ -94,7 +94,10 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     ovtk_ragged_i32_out out{ob.data(), oe.data(), ids.data(), cap, 0, 0};
     if (int rc = run_encode(nullptr, h, &in, nullptr, &out, OVTK_MEM_HOST, nullptr)) return rc;
     PieceTableHost host;
-    build_piece_table(view_of(vocab), ob.data(), oe.data(), ids.data(), host);
+    // (sized for the learned entries too, up to a couple per vocabulary token: a larger cache_capacity still counts, its entries
+    // just compete for the buckets there are)
+    build_piece_table(view_of(vocab), ob.data(), oe.data(), ids.data(), host,
+                      size_t(std::min<int64_t>(std::max<int64_t>(cache_capacity, 0), 2 * V + 65536)));
     if (int rc = h->pieces.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
     // The dynamic part (memo_insert in encode_kernels.hpp): up to cache_capacity further pieces, the ones the vocabulary
     // needs more than one token for, kept the first time merge_kernel computes them -- the reference's rule, its numbers.

@@ -216,14 +216,13 @@ struct MemoFetch {
 };
 __device__ __forceinline__ MemoFetch memo_fetch(const PieceTableDev& P, uint64_t k0, uint64_t k1) {
     const uint32_t mix = piece_mix(k0, k1);
-    const uint4* e0 = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, 0, P.shift));
-    const uint4* e1 = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, 1, P.shift));
+    const uint4* e0 = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, 0, P.shift));   // the bucket: 64 bytes, two entries
     MemoFetch f;
     f.mix = mix;
     f.k[0] = e0[0];
     f.p[0] = e0[1];
-    f.k[1] = e1[0];
-    f.p[1] = e1[1];
+    f.k[1] = e0[2];
+    f.p[1] = e0[3];
 #ifndef OVTK_SIMT_EMULATOR
     // all four loads are in flight before anything looks at a result
     asm volatile("" : "+v"(f.p[0].x), "+v"(f.p[0].y), "+v"(f.p[0].z), "+v"(f.p[0].w), "+v"(f.p[1].x), "+v"(f.p[1].y), "+v"(f.p[1].z),

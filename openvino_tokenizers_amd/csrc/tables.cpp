@@ -208,8 +208,11 @@ int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView
 
 // ------------------------------------------------------------------------------- piece memo
 void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
-                       PieceTableHost& out) {
-    std::unordered_map<std::string, PieceEntry> uniq;  // a repeated string keeps its first entry
+                       PieceTableHost& out, size_t extra) {
+    // in the order of the input (for a vocabulary: ascending id, i.e. roughly descending frequency -- the pieces a full
+    // bucket refuses are the late, rare ones); a repeated string keeps its first entry
+    std::unordered_map<std::string, size_t> seen;
+    std::vector<PieceEntry> list;
     for (int64_t i = 0; i < pieces.n; ++i) {
         const int len = pieces.ends[i] - pieces.begins[i], cnt = id_ends[i] - id_begins[i];
         if (!(len >= 1 && len <= kPieceKeyBytes && cnt >= 0 && cnt <= kPieceMaxIds)) continue;
@@ -221,28 +224,22 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
         std::memcpy(&e.k1, kb + 8, 8);
         e.tag = piece_tag(piece_mix(e.k0, e.k1), cnt);
         for (int k = 0; k < cnt; ++k) e.tok[k] = ids[id_begins[i] + k];
-        uniq.emplace(std::string(reinterpret_cast<const char*>(kb), 16), e);
+        if (seen.emplace(std::string(reinterpret_cast<const char*>(kb), 16), list.size()).second) list.push_back(e);
     }
-    // Cuckoo table: 2 hash functions x 1 entry (load < 0.5; the loop doubles the table until every key is placed).
-    for (uint32_t cap = std::max<uint32_t>(4, pow2_at_least(uint64_t(uniq.size()) + uniq.size() / 5 + 1));; cap *= 2) {
-        out.shift = 32 - log2u(cap);
-        out.slots.assign(size_t(cap), PieceEntry{0, 0, {0, 0, 0}, 0});
-        uint64_t rng = 0x9E3779B97F4A7C15ull;
-        bool ok = true;
-        const uint32_t shift = out.shift;
-        for (const auto& kv : uniq) {
-            ok = cuckoo_insert<PieceEntry, 2>(
-                out.slots, kv.second,
-                [shift](const PieceEntry& e, uint32_t* idx) {
-                    const uint32_t mix = piece_mix(e.k0, e.k1);
-                    for (int c = 0; c < 2; ++c) idx[c] = piece_h(mix, c, shift);
-                },
-                [](const PieceEntry& e) { return e.k1 == 0; }, rng);
-            if (!ok) break;
-        }
-        if (ok) break;
+    // buckets of two entries, one hash, no relocation: at a quarter full (entries / slots) two or three buckets in a
+    // thousand overflow
+    const uint32_t buckets = std::max<uint32_t>(4, pow2_at_least(uint64_t(list.size() + extra) * 2));
+    out.shift = 32 - log2u(buckets);
+    out.slots.assign(size_t(buckets) * 2, PieceEntry{0, 0, {0, 0, 0}, 0});
+    out.stored = out.refused = 0;
+    for (const PieceEntry& e : list) {
+        const uint32_t mix = piece_mix(e.k0, e.k1);
+        PieceEntry* b = out.slots.data() + piece_h(mix, 0, out.shift);
+        if (b[0].k1 == 0) b[0] = e;
+        else if (b[1].k1 == 0) b[1] = e;
+        else { ++out.refused; continue; }
+        ++out.stored;
     }
-    out.stored = uniq.size();
 }
 
 // ------------------------------------------------------------------------------- WordPiece

@@ -194,8 +194,14 @@ __host__ __device__ inline uint32_t piece_mix(uint64_t k0, uint64_t k1) {
     return h ^ (h >> 13);
 }
 __host__ __device__ inline uint32_t piece_tag(uint32_t mix, int cnt) { return (mix & 0xFFFFFF00u) | 0x80u | uint32_t(cnt); }
-__host__ __device__ inline uint32_t piece_h(uint32_t mix, int which, uint32_t shift) {  // shift = 32 - log2(capacity)
-    return (which == 0 ? mix : stir24(mix ^ (mix >> 11), 0xD6E8FFu, 0xA0761Du)) >> shift;
+// A piece's two candidate entries are the halves of ONE 64-byte bucket (round 3).  With two independent candidates every
+// lookup touched two cache lines, and the one that did not hold the piece was a cold line of a table the text stream keeps
+// pushing out of the L2: half of the lookup kernels' fetched bytes.  One bucket = one line, one hash,
+// four loads at consecutive addresses.  The price is placement freedom: a bucket whose two entries are taken refuses a third
+// piece (on the host too: the table is sized so that this hits a few vocabulary tokens in a thousand -- the ones with the
+// highest ids, which come last -- and such a piece simply stays a miss: merge path / piece store, same result).
+__host__ __device__ inline uint32_t piece_h(uint32_t mix, int which, uint32_t shift) {  // shift = 32 - log2(buckets)
+    return ((mix >> shift) << 1) | uint32_t(which);
 }
 // Hash of a byte string, four bytes per step (little-endian words, the last one zero-padded), the same function on host
 // (table build) and device (probe).  The device feeds it words it already holds in registers: hash_words().
@@ -252,12 +258,13 @@ int build_bpe(const StringsView& vocab, const StringsView& merges_left, const St
 // The piece memo from (piece string, its ids) pairs: pieces of 1..kPieceKeyBytes bytes with at most
 // kPieceMaxIds ids are stored (a repeated string keeps its first entry -- all entries of one string are equal).
 struct PieceTableHost {
-    std::vector<PieceEntry> slots;
-    uint32_t shift = 30;
-    size_t stored = 0;
+    std::vector<PieceEntry> slots;   // 2 x buckets
+    uint32_t shift = 30;             // 32 - log2(buckets)
+    size_t stored = 0, refused = 0;  // refused: pieces whose bucket was full (they stay misses)
 };
+// extra: entries the device may add later (cache_capacity): the table is sized for stored + extra.
 void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
-                       PieceTableHost& out);
+                       PieceTableHost& out, size_t extra = 0);
 
 int build_wordpiece(const StringsView& vocab, const std::string& suffix_indicator, TrieHost& root, TrieHost& sub,
                     std::string& err);
