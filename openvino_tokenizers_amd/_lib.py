@@ -119,6 +119,9 @@ _cache = {}
 
 def load(path: os.PathLike | str | None = None) -> C.CDLL:
     """Loads the HIP library (default) or an explicitly given build.  Raises if it is missing."""
+    product = path is None
+    if product and os.environ.get("OVTK_AMD_LIB"):   # another build of the same HIP library (A/B runs of tools/)
+        path = os.environ["OVTK_AMD_LIB"]
     p = Path(path) if path is not None else DEFAULT_LIB
     key = str(p)
     if key in _cache:
@@ -126,7 +129,7 @@ def load(path: os.PathLike | str | None = None) -> C.CDLL:
     if not p.exists():
         raise OvtkError(E_HIP, f"{p} not found: build it with `make -C {_HERE / 'csrc'}` "
                                f"(__graft_entry__.build()); there is no CPU fallback")
-    if path is None:
+    if product:
         # Share the process' HIP runtime with PyTorch (same SONAME libamdhip64.so.7): import torch first.
         try:
             import torch  # noqa: F401

@@ -199,6 +199,8 @@ template <class Kernel>
 inline int resident_blocks_per_cu(Kernel kernel, int cap = 6) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlockThreads, 0) != hipSuccess || n <= 0) n = 4;
+    static const int env_cap = [] { const char* e = std::getenv("OVTK_BLOCKS_PER_CU"); return e ? std::atoi(e) : 0; }();
+    if (env_cap > 0) cap = std::min(cap, env_cap);   // experiments only
     return std::min(n, cap);
 }
 inline int grid_rows(int device, int n_rows, int blocks_per_cu) {
