@@ -635,7 +635,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            },
                            /*self_alloc=*/true,
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
-                                  : split->dev.kind == kSplitLlama3 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>)
+                                  : split->dev.kind == kSplitLlama3 ? (OVTK_L3_BLOCKS == 4 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>) : resident_blocks_per_cu(lookup_rows_kernel<kRowsLlama3>))
                                   : split->dev.kind <= kSplitGpt2Digits && !row_tickets().load(std::memory_order_relaxed)
                                       ? resident_blocks_per_cu(lookup_ascii_kernel<false>, 6)
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),

@@ -140,6 +140,15 @@ __device__ __forceinline__ void drain_vmem() {
 __device__ __forceinline__ void publish_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 
 __device__ __forceinline__ unsigned long long lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+// Set bits of `m` below this lane's: the lane's rank among the lanes of a ballot (v_mbcnt_lo / _hi: two instructions, where
+// popcount(m & lanemask_lt()) is two ANDs and two counts)
+__device__ __forceinline__ int rank_below(unsigned long long m) {
+#ifndef OVTK_SIMT_EMULATOR
+    return int(__builtin_amdgcn_mbcnt_hi(uint32_t(m >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(m), 0u)));
+#else
+    return __popcll(m & lanemask_lt());
+#endif
+}
 
 // ---- DPP building blocks (VALU-speed cross-lane moves; __shfl goes through the LDS crossbar) ----
 constexpr int kDppRowShl = 0x100, kDppRowShr = 0x110, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;

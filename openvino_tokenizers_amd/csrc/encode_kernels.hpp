@@ -454,7 +454,7 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     const unsigned long long mm = __ballot(miss);
     if (mm) {
         if (n_miss + __popcll(mm) > kMissBuf) flush_misses(mb, n_miss, n_miss, w);  // (rare: a batch with > 32 misses)
-        if (miss) mb.e[n_miss + __popcll(mm & lanemask_lt())] = DeferredPiece{k0, k1, pos, st.row, abs_begin, plen};
+        if (miss) mb.e[n_miss + rank_below(mm)] = DeferredPiece{k0, k1, pos, st.row, abs_begin, plen};
         n_miss += __popcll(mm);
         wave_sync();
         if (n_miss >= kWave) flush_misses(mb, n_miss, kWave, w);
@@ -798,8 +798,11 @@ __device__ __forceinline__ void lds_fetch_words(const uint8_t* ga, int nwords, u
 // SCAN: which packed-byte scanner reads the window -- the GPT-2 rules, the same with every digit on its own, or the BERT words
 // (white space dropped, every delimiter character a word: the fused WordPiece path; `T` then holds nothing but the word memo).
 enum RowsScan : int { kRowsGpt2 = 0, kRowsGpt2Digits = 1, kRowsBertWords = 2, kRowsLlama3 = 3 };
+#ifndef OVTK_L3_BLOCKS
+#define OVTK_L3_BLOCKS 4   // resident blocks per CU the Llama-3 instance is compiled for (A/B builds)
+#endif
 template <int SCAN>
-static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? 4 : 6) void lookup_rows_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? OVTK_L3_BLOCKS : 6) void lookup_rows_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ uint32_t text_all[kWavesPerBlock][2][kWinBytes / 4];
     __shared__ uint16_t pstart_all[kWavesPerBlock][kChunk + 2];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
@@ -965,7 +968,7 @@ static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? 4 : 6) 
         if (l == 0) base = atomicAdd(&w.status->n_pending, n_pending);
         base = wave_readlane(base, 0);
         const unsigned long long pm = __ballot(l < nr && rec_used == kRowPending);
-        if (w.pending_rows && ((pm >> l) & 1ull)) w.pending_rows[base + __popcll(pm & lanemask_lt())] = row0 + l;
+        if (w.pending_rows && ((pm >> l) & 1ull)) w.pending_rows[base + rank_below(pm)] = row0 + l;
     }
 }
 
@@ -1182,7 +1185,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 int left = 0;
                 if (l == 0) left = atomicAdd(my_room, -int(__popcll(km)));
                 left = wave_readlane(left, 0);
-                const int rank = __popcll(km & lanemask_lt());
+                const int rank = rank_below(km);
                 bool added = false;
                 if (keep && rank < left) {
                     int32_t t3[kPieceMaxIds];
@@ -1220,7 +1223,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         unsigned long long lm = __ballot(is_l);
         while (lm) {
             uint8_t* long_src = long_src_all[wave_in_block()];
-            const int rank = __popcll(lm & lanemask_lt());
+            const int rank = rank_below(lm);
             const int cnt = __popcll(lm) < kWave / 2 ? __popcll(lm) : kWave / 2;
             wave_sync();  // the previous user of the LDS arrays (path F / the previous group) is done
             if (((lm >> l) & 1ull) && rank < kWave / 2) long_src[rank] = uint8_t(l);
@@ -1301,7 +1304,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         if (xm) {
             int idx = 0;
             if (l == 0) idx = atomicAdd(&w.status->n_exact, __popcll(xm));
-            idx = __shfl(idx, 0) + __popcll(xm & lanemask_lt());
+            idx = __shfl(idx, 0) + rank_below(xm);
             if (is_x) {
                 if (idx < w.exact_cap) w.exact[idx] = ExactPiece{e.begin, e.len, e.stage_pos, e.row};
                 else atomicOr(&w.status->flags, kFlagExactOverflow);
@@ -1456,14 +1459,14 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, co
             for (int k = 0; k < kCompactChunks; ++k) {
                 if (k * kWave < used[q]) {
                     const unsigned long long m = __ballot(v[q][k] != kEmptyId);
-                    if (v[q][k] != kEmptyId) sink.id(o[q] + run + __popcll(m & lanemask_lt()), v[q][k]);
+                    if (v[q][k] != kEmptyId) sink.id(o[q] + run + rank_below(m), v[q][k]);
                     run += __popcll(m);
                 }
             }
             for (int b = kCompactChunks * kWave; b < used[q]; b += kWave) {
                 const int x = (b + l < used[q]) ? w.stage[base[q] + b + l] : kEmptyId;
                 const unsigned long long m = __ballot(x != kEmptyId);
-                if (x != kEmptyId) sink.id(o[q] + run + __popcll(m & lanemask_lt()), x);
+                if (x != kEmptyId) sink.id(o[q] + run + rank_below(m), x);
                 run += __popcll(m);
             }
         }
@@ -1551,7 +1554,7 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
                         const bool keep = j < np && !(ws.pstart[j] & kPieceDropped);
                         const unsigned long long km = __ballot(keep);
                         if (keep)
-                            emit(in_string + __popcll(km & lanemask_lt()), c0 + int(ws.pstart[j] & kPiecePosMask),
+                            emit(in_string + rank_below(km), c0 + int(ws.pstart[j] & kPiecePosMask),
                                  c0 + int(ws.pstart[j + 1] & kPiecePosMask));
                         in_string += __popcll(km);
                     }

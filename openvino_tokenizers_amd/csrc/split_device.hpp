@@ -1114,7 +1114,7 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                         Mask m = wave_readlane(start0, w);
                         if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
                         if (h0 - w * 64 < 64) m &= (1ull << (h0 - w * 64)) - 1ull;
-                        if (((m >> l) & 1ull) && ws.pstart[np0 + __popcll(m & lanemask_lt())] != uint16_t(w * 64 + l - lo)) same = false;
+                        if (((m >> l) & 1ull) && ws.pstart[np0 + rank_below(m)] != uint16_t(w * 64 + l - lo)) same = false;
                         np0 += __popcll(m);
                     }
                     if (np0 != np) same = false;
@@ -1134,7 +1134,7 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                         Mask m = wave_readlane(start, w);
                         if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
                         if (h2 - w * 64 < 64) m &= (1ull << (h2 - w * 64)) - 1ull;
-                        if ((m >> l) & 1ull) ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t(w * 64 + l - lo);
+                        if ((m >> l) & 1ull) ws.pstart[np + rank_below(m)] = uint16_t(w * 64 + l - lo);
                         np += __popcll(m);
                     }
                 }
@@ -1192,7 +1192,7 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                 if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
                 if (hi - w * 64 < 64) m &= (1ull << (hi - w * 64)) - 1ull;
                 if ((m >> l) & 1ull)
-                    ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t((w * 64 + l - lo) | (((d >> l) & 1ull) ? kPieceDropped : 0));
+                    ws.pstart[np + rank_below(m)] = uint16_t((w * 64 + l - lo) | (((d >> l) & 1ull) ? kPieceDropped : 0));
                 np += __popcll(m);
             }
             }
@@ -1205,7 +1205,7 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
                 Mask m = wave_readlane(start, w);
                 if (w == (lo >> 6)) m = (m & ~((1ull << (lo & 63)) - 1ull)) | (1ull << (lo & 63));
                 if (hi - w * 64 < 64) m &= (1ull << (hi - w * 64)) - 1ull;
-                if ((m >> l) & 1ull) ws.pstart[np + __popcll(m & lanemask_lt())] = uint16_t(w * 64 + l - lo);
+                if ((m >> l) & 1ull) ws.pstart[np + rank_below(m)] = uint16_t(w * 64 + l - lo);
                 np += __popcll(m);
             }
         }

@@ -90,6 +90,23 @@ def test_llama3_fused(backend):
     assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [tok.pattern_u8()], tok.consts), backend.host, "fused llama3")
 
 
+@pytest.mark.parametrize("kind", ["mixed", "zipf"])
+def test_llama3_rows_around_the_window_sizes(backend, kind):
+    """Rows of 513 .. 768 bytes through lookup_rows_kernel's Llama-3 instance (the three-dwords-per-lane form of the scanner),
+    shorter rows (two dwords per lane) and longer ones (left to the generic kernel) in the same batch.  More than 256 rows:
+    not the one-launch small-batch kernel."""
+    tok = BpeTok.load("llama3_small")
+    n = 300 if backend.name == "emu" else 6000
+    b, e, c = TextModel(11, kind).batch(n, 640)
+    lens = e - b
+    assert ((lens > 512) & (lens <= 768)).sum() > n // 2 and (lens <= 512).any() and (lens > 768).any()
+    rb, re_ = ragged_rows(len(b))
+    ref = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(rb, re_, b, e, c)[:5])
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    for _ in range(2):   # (the second call: memo and store warm)
+        assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [tok.pattern_u8()], tok.consts), backend.host, "fused llama3, rows around 512 / 768 bytes")
+
+
 def run_all_paths(backend, tok, inputs, skips=None, pattern=None):
     """Oracle result + the three product paths (split op, BPE op on its pieces, fused) compared bit for bit."""
     pattern = pattern or tok.pattern
