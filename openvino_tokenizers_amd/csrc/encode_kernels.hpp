@@ -190,14 +190,22 @@ __device__ __forceinline__ void piece_key(uint64_t raw0, uint64_t raw1, int plen
     }
     k1 |= uint64_t(plen) << 56;
 }
-// 16 bytes at byte offset `off` of a dword array in LDS (aligned reads + funnel shift).
+// 16 bytes at byte offset `off` of a dword array in LDS: ONE ds_read_b128 at a byte address (gfx950 reads LDS at any alignment;
+// `tools/lds_unaligned_probe.hip` checks that on the box).  Until r03 five aligned dword reads and four funnel shifts.
+struct __attribute__((packed, aligned(1))) LdsBytes16 { uint64_t lo, hi; };
 __device__ __forceinline__ void lds_bytes16(const uint32_t* words, int off, uint64_t& r0, uint64_t& r1) {
+#ifndef OVTK_LDS_ALIGNED_READS
+    const LdsBytes16 v = *reinterpret_cast<const LdsBytes16*>(reinterpret_cast<const uint8_t*>(words) + off);
+    r0 = v.lo;
+    r1 = v.hi;
+#else
     const int a = off >> 2, sh = (off & 3) * 8;
     const uint32_t w0 = words[a], w1 = words[a + 1], w2 = words[a + 2], w3 = words[a + 3], w4 = words[a + 4];
     const uint32_t d0 = funnel_shr(w0, w1, sh), d1 = funnel_shr(w1, w2, sh);
     const uint32_t d2 = funnel_shr(w2, w3, sh), d3 = funnel_shr(w3, w4, sh);
     r0 = (uint64_t(d1) << 32) | d0;
     r1 = (uint64_t(d3) << 32) | d2;
+#endif
 }
 // The piece's bytes from global memory (pre-split pieces: any alignment, may end at the buffer's end).
 __device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint64_t& r0, uint64_t& r1) {

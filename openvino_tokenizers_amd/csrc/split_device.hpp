@@ -562,6 +562,26 @@ __device__ __forceinline__ void class_start_mask(const WaveScratch& ws, const Sp
     dropped = (sp.drop == 1 ? m : (sp.drop == 2 ? ~m : 0ull)) & cs;
 }
 
+// The LB + 1 aligned dwords that cover a lane's LB text dwords at byte offset `off` of the LDS window -- or (default) the LB
+// dwords themselves, read at their byte address: r[j] and r[j + 1] then funnel-shift to themselves (sh = 0 below).
+template <int N>
+struct __attribute__((packed, aligned(1))) LdsDwords { uint32_t d[N]; };
+template <int LB>
+__device__ __forceinline__ int lds_lane_dwords(const uint32_t* text_w, int off, uint32_t (&r)[LB + 1]) {
+#ifndef OVTK_LDS_ALIGNED_READS
+    const LdsDwords<LB> v = *reinterpret_cast<const LdsDwords<LB>*>(reinterpret_cast<const uint8_t*>(text_w) + off);
+#pragma unroll
+    for (int j = 0; j < LB; ++j) r[j] = v.d[j];
+    r[LB] = 0;
+    return 0;
+#else
+    const int a = off >> 2;
+#pragma unroll
+    for (int j = 0; j <= LB; ++j) r[j] = text_w[a + j];
+    return (off & 3) * 8;
+#endif
+}
+
 // ---- packed-byte (SWAR) path: ASCII windows (at most kChunk bytes) -------------------------------
 // All values are 4 packed bytes with one flag per byte in bit 7.  Inputs must be < 0x80 per byte (no carries).
 constexpr uint32_t kB7 = 0x80808080u;
@@ -589,12 +609,10 @@ __device__ __forceinline__ bool gpt2_start_flags_ascii(const WS& ws, int skew, i
     constexpr int LBy = 4 * LB;
     const int l = lane_id();
     const int off = kTextPad + skew + LBy * l;  // byte offset of the lane's first byte in text_w
-    const int a = off >> 2, sh = (off & 3) * 8;
     int nv = wlen - LBy * l;  // how many of the lane's bytes exist
     nv = nv < 0 ? 0 : (nv > LBy ? LBy : nv);
     uint32_t x[LB + 1], V[LB + 1], r[LB + 1];
-#pragma unroll
-    for (int j = 0; j <= LB; ++j) r[j] = ws.text_w[a + j];
+    const int sh = lds_lane_dwords<LB>(&ws.text_w[0], off, r);
     uint32_t any = 0;
 #pragma unroll
     for (int j = 1; j <= LB; ++j) {
@@ -752,14 +770,12 @@ __device__ __forceinline__ bool llama3_packed_starts(WS& ws, const SplitDev& sp,
     constexpr int LBy = 4 * LB, M = LB + 4, AL = LB + 1;  // own dwords at [2 .. AL]
     const int l = lane_id();
     const int off = kTextPad + skew + LBy * l;
-    const int a0 = off >> 2, sh = (off & 3) * 8;
     int nv = wlen - LBy * l;
     nv = nv < 0 ? 0 : (nv > LBy ? LBy : nv);
     uint32_t r[LB + 1], x[M], V[M], L[M], N[M], W[M], NL[M], SP[M], CT[M], AP[M];
     x[0] = x[1] = x[M - 2] = x[M - 1] = 0;
     AP[0] = AP[1] = AP[M - 2] = AP[M - 1] = 0;
-#pragma unroll
-    for (int j = 0; j <= LB; ++j) r[j] = ws.text_w[a0 + j];
+    const int sh = lds_lane_dwords<LB>(&ws.text_w[0], off, r);
     uint32_t leads = 0;  // bit k: own byte k is a lead byte (>= 0xC0)
     bool odd = false;
 #pragma unroll
@@ -997,12 +1013,10 @@ __device__ __forceinline__ bool class_packed_starts(WS& ws, const SplitDev& sp, 
     constexpr int LBy = 4 * LB;
     const int l = lane_id();
     const int off = kTextPad + skew + LBy * l;
-    const int a = off >> 2, sh = (off & 3) * 8;
     int nv = wlen - LBy * l;
     nv = nv < 0 ? 0 : (nv > LBy ? LBy : nv);
     uint32_t x[LB + 1], V[LB + 1], r[LB + 1];
-#pragma unroll
-    for (int j = 0; j <= LB; ++j) r[j] = ws.text_w[a + j];
+    const int sh = lds_lane_dwords<LB>(&ws.text_w[0], off, r);
     uint32_t any = 0;
 #pragma unroll
     for (int j = 1; j <= LB; ++j) {

@@ -855,6 +855,16 @@ class FusedDetokenizer:
 
     def __init__(self, decoder: VocabDecoder, byte_fallback=False):
         self.decoder, self.byte_fallback = decoder, bool(byte_fallback)
+        self._side = {}   # (device, n) -> the HIP streams evaluate_chunked spreads its chunks over
+
+    def _side_streams(self, m, n):
+        """The same streams for every call: torch's caching allocator keeps freed blocks PER STREAM, and a chunk's output is
+        2 GB -- with fresh streams per call every pass allocated its chunks anew (hipMalloc, and hipFree once the card was
+        full: config 5 then took 400-740 ms per pass instead of 15)."""
+        key = (str(m.device), int(n))
+        if key not in self._side:
+            self._side[key] = [m.t.cuda.Stream(m.device) for _ in range(int(n))]
+        return self._side[key]
 
     def evaluate(self, inputs, chars_capacity=None):
         d = self.decoder
@@ -909,7 +919,7 @@ class FusedDetokenizer:
         est = float(bytes_per_id) if bytes_per_id else max(d.mean_token_len, 0.25)
         row_cap = max(1, ((1 << 31) - 2) // max(S, 1))   # batch * seq_len must fit int32 as well (vocab_decoder.cpp:45-46)
         m0 = _Mem(ids)
-        side = [m0.t.cuda.Stream(m0.device) for _ in range(max(int(streams), 1))] if m0.torch else []
+        side = self._side_streams(m0, max(int(streams), 1)) if m0.torch else []
         done, inflight, n_launched = [], [], 0
         self.chunk_log = []   # (row_begin, row_end, capacity, bytes or None when it overflowed): how the batch was cut
         lo, pending_rows = 0, []   # pending_rows: re-cut chunks (row ranges) that go before the rest of the batch
