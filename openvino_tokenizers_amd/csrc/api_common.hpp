@@ -281,6 +281,7 @@ public:
     void enable_small() { small_ok_ = true; }
     // Called with the status block of the attempt that completed the run (finish(), the caller's thread).
     void on_status(std::function<void(const RunStatus&)> f) { on_status_ = std::move(f); }
+    void enable_stage16() { stage16_ = true; }   // the middle's kernels write / read the staging entries as u16 (EncodeWork::stage16)
     // The result leaves in the row-shard exchange's wire form (device memory) instead of begins / ends / ids.
     void output_to_wire(const WireSink& wire) {
         wire_ = wire;
@@ -406,6 +407,7 @@ private:
         w.tile_off = ws.tiles.as<long long>();
         w.stage = ws.stage.as<int32_t>();
         w.stage_cap = int32_t(stage_cap_);
+        w.stage16 = stage16_ ? 1 : 0;
         w.deferred = ws.deferred.as<DeferredPiece>();
         w.shard_cap = int32_t(std::min<int64_t>(shard_cap_, INT32_MAX / kShards));
         w.exact = ws.exact.as<ExactPiece>();
@@ -443,11 +445,12 @@ private:
         if (!w.fold_tail)
             OVTK_LAUNCH(ws.marks, "count_scan", count_scan_kernel, std::min((n_tiles_ + 3) / 4, kTicketBlocks), kBlockThreads, s_,
                         n_rows_, w, (long long)out_.data_capacity);
-        if (wire_.hdr)
-            OVTK_LAUNCH(ws.marks, "compact", compact_kernel<WireSink>, grid_lookup(device_, n_rows_), kBlockThreads, s_, n_rows_, w, wire_);
-        else
-            OVTK_LAUNCH(ws.marks, "compact", compact_kernel<RaggedSink>, grid_lookup(device_, n_rows_), kBlockThreads, s_, n_rows_, w,
-                        RaggedSink{d_ids_, d_begins_, d_ends_});
+        const int cgrid = grid_lookup(device_, n_rows_);
+        const RaggedSink rsink{d_ids_, d_begins_, d_ends_};
+        if (wire_.hdr && stage16_) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<WireSink, true>), cgrid, kBlockThreads, s_, n_rows_, w, wire_);
+        else if (wire_.hdr) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<WireSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, wire_);
+        else if (stage16_) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<RaggedSink, true>), cgrid, kBlockThreads, s_, n_rows_, w, rsink);
+        else OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<RaggedSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, rsink);
         OVTK_HIP(hipMemcpyAsync(ws.host_status, ws.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s_));
         OVTK_HIP(hipEventRecord(ws.done, s_));
         return OVTK_OK;
@@ -469,6 +472,7 @@ private:
     WorkspaceLease ws_;
     bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
     bool small_ok_ = false, small_ = false;
+    bool stage16_ = false;
     WireSink wire_{};
     std::function<void(const RunStatus&)> on_status_;
     RowsIn d_in_{};

@@ -64,6 +64,7 @@ struct ovtk_bpe {
     size_t memo_entries = 0;
     int32_t memo_capacity = 0;  // entries the device may add (cache_capacity)
     bool narrow_ids = false;  // every token id < 65536: merge_kernel keeps ids as u16 in LDS
+    bool stage16 = false;     // every token id < 65535: the staging entries of a call are u16 (0xFFFF = unused entry)
     // calls that still leave the piece store out: set to 32 after four calls in a row in which fewer than one probe in eight
     // hit (then the store is asked again, and so on -- text changes)
     mutable std::atomic<int> store_pause{0}, store_low{0};  // store_low: calls in a row with that little use of it
@@ -341,6 +342,9 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     h->narrow_ids = p->vocab.n <= 65536;
     for (int64_t i = 0; i < p->added_tokens.n && p->added_ids; ++i)
         if (p->added_ids[i] < 0 || p->added_ids[i] > 65535) h->narrow_ids = false;
+    h->stage16 = h->narrow_ids && p->vocab.n <= 65535;
+    for (int64_t i = 0; i < p->added_tokens.n && p->added_ids; ++i)
+        if (p->added_ids[i] > 65534) h->stage16 = false;
     int e = 0;
     e = e ? e : h->root.upload(host.trie.root.data(), host.trie.root.size() * sizeof(I2));
     e = e ? e : h->edges.upload(host.trie.edges.data(), host.trie.edges.size() * sizeof(TrieEdge));
@@ -656,6 +660,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
             }
         });
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
+    if (bpe->stage16) r->enable_stage16();
     if (wire) r->output_to_wire(*wire);
     if (int rc = r->start()) return rc;
     run = std::move(r);

@@ -82,8 +82,10 @@ struct EncodeWork {
                             //           before merge_kernel's additions (a copy: merge blocks sum it while others add)
     int32_t* row_used;      // [n_rows]     staging entries the row occupies (> row_cnt: it has unused entries)
     long long* tile_off;    // [n_tiles]    output offset of each tile of kRowTile rows
-    int32_t* stage;
+    int32_t* stage;         // staging entries: i32 -- or u16 in the same buffer (stage16) --, kEmptyId / 0xFFFF = unused
     int32_t stage_cap;
+    int32_t stage16;        // every id the call can produce is below 65535 (BPE handles with narrow ids): the staged ids cross HBM
+                            // as two bytes each way instead of four (stage_put / stage_get)
     DeferredPiece* deferred;  // kShards regions of shard_cap entries
     int32_t shard_cap;
     ExactPiece* exact;
@@ -94,6 +96,23 @@ struct EncodeWork {
 };
 
 constexpr uint32_t kFatalFlags = kFlagRange | kFlagStageOverflow;
+
+// One staging entry (w.stage16 is a kernel argument: the branch is scalar).
+__device__ __forceinline__ void stage_put(const EncodeWork& w, int pos, int32_t id) {
+    if (w.stage16) reinterpret_cast<uint16_t*>(w.stage)[pos] = uint16_t(id);
+    else w.stage[pos] = id;
+}
+__device__ __forceinline__ void stage_clear(const EncodeWork& w, int pos) {
+    if (w.stage16) reinterpret_cast<uint16_t*>(w.stage)[pos] = uint16_t(0xFFFFu);
+    else w.stage[pos] = kEmptyId;
+}
+__device__ __forceinline__ int32_t stage_get(const EncodeWork& w, int pos) {
+    if (w.stage16) {
+        const uint32_t x = reinterpret_cast<const uint16_t*>(w.stage)[pos];
+        return x == 0xFFFFu ? kEmptyId : int32_t(x);
+    }
+    return w.stage[pos];
+}
 
 // out[i] = i: the ragged dimension of a batch of plain strings (one string per row).
 static __global__ __launch_bounds__(kBlockThreads) void iota_kernel(int n, int32_t* out) {
@@ -456,7 +475,7 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     if (hit) {
 #pragma unroll
         for (int k = 0; k < kPieceMaxIds; ++k)
-            if (k < cnt) w.stage[pos + k] = tok[k];   // (not a streaming store: compact_kernel reads it back within microseconds -- measured: 21.7 -> 26.5 us for compact with the hint)
+            if (k < cnt) stage_put(w, pos + k, tok[k]);   // (not a streaming store: compact_kernel reads it back within microseconds -- measured: 21.7 -> 26.5 us for compact with the hint)
     }
     const bool miss = valid && !hit;
     const unsigned long long mm = __ballot(miss);
@@ -985,17 +1004,22 @@ __device__ __forceinline__ void exact_one(const RowsIn& in, const BpeDev& T, con
     const int SL = T.suffix_len;
     const ExactPiece p = w.exact[i];
     const int ntext = p.len + SL;
-    const uint32_t bytes = (bpe_exact_scratch_bytes(uint32_t(ntext)) + 15u) & ~15u;
+    // (+ ntext i32 ids behind the working arrays when the staging entries are u16)
+    const uint32_t bytes = ((bpe_exact_scratch_bytes(uint32_t(ntext)) + 15u) & ~15u) + (w.stage16 ? 4u * ((uint32_t(ntext) + 3u) & ~3u) : 0u);
     const uint32_t off = atomicAdd(&w.status->scratch_used, bytes);
     if (off > w.scratch_cap || bytes > w.scratch_cap - off) {
         atomicOr(&w.status->flags, kFlagScratchOverflow);
         return;
     }
     const uint8_t* text = in.chars + p.begin;
-    int32_t* out = w.stage + p.stage_pos;
+    // (bpe_exact_piece writes i32 ids: straight into the staging entries, or -- u16 staging -- into the words behind its scratch)
+    int32_t* out = w.stage16 ? reinterpret_cast<int32_t*>(w.scratch + off + bytes - 4u * ((uint32_t(ntext) + 3u) & ~3u)) : w.stage + p.stage_pos;
     const int cnt = bpe_exact_piece(
         T, [&](int k) -> uint32_t { return k < p.len ? text[k] : T.suffix[k - p.len]; }, ntext, w.scratch + off, out);
-    for (int k = cnt; k < ntext; ++k) out[k] = kEmptyId;
+    if (w.stage16) {
+        for (int k = 0; k < cnt; ++k) stage_put(w, p.stage_pos + k, out[k]);
+    }
+    for (int k = cnt; k < ntext; ++k) stage_clear(w, p.stage_pos + k);
     if (cnt) {
         atomicAdd(&w.row_cnt[p.row], cnt);
         if (w.tile_cnt) atomicAdd(&w.tile_cnt[p.row / kRowTile], cnt);
@@ -1103,7 +1127,6 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
 #else
 #define PHASE(slot)
 #endif
-        int32_t* out = w.stage + e.stage_pos;
         int f_cnt = 0;
         // The piece store first (tables.hpp): a piece it holds is one round trip, not a merge chain.
         constexpr int kStoreIds = NARROW ? kStoreIds16 : kStoreIds32;
@@ -1120,8 +1143,8 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 f_cnt = c;
 #pragma unroll
                 for (int k = 0; k < kStoreIds; ++k)
-                    if (k < c) out[k] = store_id<NARROW>(pay, k);
-                for (int k = c; k < need; ++k) out[k] = kEmptyId;
+                    if (k < c) stage_put(w, e.stage_pos + k, store_id<NARROW>(pay, k));
+                for (int k = c; k < need; ++k) stage_clear(w, e.stage_pos + k);
             }
         }
         // A SAMPLE of the waves says what the store did for this call (it decides whether the next calls ask it): one wave in 64.
@@ -1164,8 +1187,8 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
             if (res < 0) {
                 is_x = true;
             } else {
-                for (int k = 0; k < res; ++k) out[k] = int32_t(fid[k * kWave + l]);
-                for (int k = res; k < need; ++k) out[k] = kEmptyId;
+                for (int k = 0; k < res; ++k) stage_put(w, e.stage_pos + k, int32_t(fid[k * kWave + l]));
+                for (int k = res; k < need; ++k) stage_clear(w, e.stage_pos + k);
                 f_cnt = res;
                 keep = res <= kPieceMaxIds;
             }
@@ -1248,9 +1271,8 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                     [&](int k, int tok) { fid[k * (kWave / 2) + l] = IdT(tok); });
                 res = bpe_merge_lane<IdT, kLongSyms, kWave / 2>(T, fid, fkey, fnid, n);
                 if (res >= 0) {
-                    int32_t* o = w.stage + s_pos;
-                    for (int k = 0; k < res; ++k) o[k] = int32_t(fid[k * (kWave / 2) + l]);
-                    for (int k = res; k < s_need; ++k) o[k] = kEmptyId;
+                    for (int k = 0; k < res; ++k) stage_put(w, s_pos + k, int32_t(fid[k * (kWave / 2) + l]));
+                    for (int k = res; k < s_need; ++k) stage_clear(w, s_pos + k);
                     if (res) {
                         atomicAdd(&w.row_cnt[s_row], res);
                         if (w.tile_cnt) atomicAdd(&w.tile_cnt[s_row / kRowTile], res);
@@ -1299,8 +1321,10 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
             if (res < 0) {
                 if (l == src) is_x = true;
             } else {
-                int32_t* o = w.stage + s_pos;
-                for (int k = l; k < s_need; k += kWave) o[k] = k < res ? int32_t(id[k]) : kEmptyId;
+                for (int k = l; k < s_need; k += kWave) {
+                    if (k < res) stage_put(w, s_pos + k, int32_t(id[k]));
+                    else stage_clear(w, s_pos + k);
+                }
                 if (l == src && res) {
                     atomicAdd(&w.row_cnt[e.row], res);
                     if (w.tile_cnt) atomicAdd(&w.tile_cnt[e.row / kRowTile], res);
@@ -1422,7 +1446,16 @@ struct WireSink {
     }
 };
 
-template <class Sink>
+// S16: the staging entries are u16 (w.stage16) -- a template flag, so that the loads of a work item still leave together.
+template <bool S16>
+__device__ __forceinline__ int32_t stage_get_t(const EncodeWork& w, int pos) {
+    if (S16) {
+        const uint32_t x = reinterpret_cast<const uint16_t*>(w.stage)[pos];
+        return x == 0xFFFFu ? kEmptyId : int32_t(x);
+    }
+    return w.stage[pos];
+}
+template <class Sink, bool S16 = false>
 __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, const Sink& sink, bool solo = false) {
     // kFlagTailPending: merge_kernel's folded tail left the exact pieces and the tile scan to a second attempt -- tile_off
     // and parts of the staging buffer hold whatever the previous call left there
@@ -1456,7 +1489,7 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, co
         for (int q = 0; q < kCompactRows; ++q)
 #pragma unroll
             for (int k = 0; k < kCompactChunks; ++k)
-                v[q][k] = (k * kWave + l < used[q]) ? w.stage[base[q] + k * kWave + l] : kEmptyId;
+                v[q][k] = (k * kWave + l < used[q]) ? stage_get_t<S16>(w, base[q] + k * kWave + l) : kEmptyId;
 #pragma unroll
         for (int q = 0; q < kCompactRows; ++q) {
             const int row = tile * kRowTile + sub * kCompactRows + q;
@@ -1472,7 +1505,7 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, co
                 }
             }
             for (int b = kCompactChunks * kWave; b < used[q]; b += kWave) {
-                const int x = (b + l < used[q]) ? w.stage[base[q] + b + l] : kEmptyId;
+                const int x = (b + l < used[q]) ? stage_get_t<S16>(w, base[q] + b + l) : kEmptyId;
                 const unsigned long long m = __ballot(x != kEmptyId);
                 if (x != kEmptyId) sink.id(o[q] + run + rank_below(m), x);
                 run += __popcll(m);
@@ -1482,9 +1515,9 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, co
     sink.finish(n_rows, w.status);
 }
 
-template <class Sink>
+template <class Sink, bool S16 = false>
 static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_rows, EncodeWork w, Sink sink) {
-    compact_body(n_rows, w, sink);
+    compact_body<Sink, S16>(n_rows, w, sink);
 }
 
 // ---- a small batch in ONE launch (BASELINE config 1: 32 x 128-byte strings; any batch of a few hundred short rows).
@@ -1503,7 +1536,8 @@ static __global__ __launch_bounds__(kBlockThreads) void encode_small_kernel(Rows
     if (threadIdx.x == 0) publish_release();
     __syncthreads();
     publish_acquire();
-    compact_body(in.n_rows, w, RaggedSink{w.out_ids, w.out_begins, w.out_ends}, /*solo=*/true);
+    if (w.stage16) compact_body<RaggedSink, true>(in.n_rows, w, RaggedSink{w.out_ids, w.out_begins, w.out_ends}, /*solo=*/true);
+    else compact_body<RaggedSink, false>(in.n_rows, w, RaggedSink{w.out_ids, w.out_begins, w.out_ends}, /*solo=*/true);
     __syncthreads();
     uint32_t* src = reinterpret_cast<uint32_t*>(w.status);
     uint32_t* dst = reinterpret_cast<uint32_t*>(w.host_status);
