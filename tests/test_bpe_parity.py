@@ -275,6 +275,29 @@ def test_heap_tie_vocabulary(backend):
     assert_same(ref, got, backend.host, "tie vocabulary")
 
 
+@pytest.mark.parametrize("n_vocab", [65535, 65536, 65537])
+def test_highest_ids_around_the_u16_limits(backend, n_vocab):
+    """The library narrows what it may: 16-bit staging entries while every id is below 65535 (0xFFFF marks an unused entry),
+    16-bit ids in merge_kernel's LDS while every id is below 65536.  Vocabularies whose LAST tokens -- ids 65534, 65535,
+    65536 -- are what the text merges to."""
+    if backend.name == "emu":
+        pytest.skip("a 65 536-token vocabulary: the emulator takes five minutes per handle to fill its memo (it passes there)")
+    filler = [b"\x01f%05d" % i for i in range(n_vocab - 6)]
+    vocab = [b"a", b"b", b"c"] + filler + [b"ab", b"abc", b"ca"]          # ids n-3, n-2, n-1
+    merges = [(b"a", b"b"), (b"ab", b"c"), (b"c", b"a")]
+    assert len(vocab) == n_vocab
+    tok = BpeTok(vocab, merges, None, None)
+    rows = [[b"abc", b"ab", b"ca", b"cab", b"abcabc" * 40], [b"c" * 3, b"ababab"], [], [b"caca" * 100]]
+    rows += [[b"abcab" * int(k) for k in range(1, 40)] for _ in range(70)]   # (more than 256 rows in all: the ordinary launches too)
+    rows += [[b"ab"]] * 300
+    inputs = pieces_inputs(rows)
+    ref = tok.oracle()(*inputs)
+    assert int(np.max(ref[2])) == n_vocab - 1
+    bpe = BPETokenizer(**tok.attrs, lib=backend.lib)
+    for _ in range(2):
+        assert_same(ref, bpe.evaluate(backend.data(inputs) + tok.consts), backend.host, f"V = {n_vocab}")
+
+
 def test_unk_byte_fallback_suffix(backend):
     """Non-byte-level vocabulary: unknown bytes -> <0xHH> byte tokens, then unk, else dropped; end_suffix appended
     to every piece (also to empty ones); text-form merges ("a b" lines, 11-input form)."""
