@@ -342,7 +342,8 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     h->narrow_ids = p->vocab.n <= 65536;
     for (int64_t i = 0; i < p->added_tokens.n && p->added_ids; ++i)
         if (p->added_ids[i] < 0 || p->added_ids[i] > 65535) h->narrow_ids = false;
-    h->stage16 = h->narrow_ids && p->vocab.n <= 65535;
+    static const bool allow16 = [] { const char* e = std::getenv("OVTK_STAGE16"); return !e || std::atoi(e) != 0; }();   // (=0: i32 staging, A/B runs)
+    h->stage16 = allow16 && h->narrow_ids && p->vocab.n <= 65535;
     for (int64_t i = 0; i < p->added_tokens.n && p->added_ids; ++i)
         if (p->added_ids[i] > 65534) h->stage16 = false;
     int e = 0;

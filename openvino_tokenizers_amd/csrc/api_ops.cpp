@@ -97,6 +97,7 @@ struct ovtk_wordpiece {
     DevBuf memo_buf, store, store_room;
     int32_t store_capacity = 0;
     PieceTableDev memo{nullptr, 30, nullptr, 0};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
+    int64_t n_vocab = 0;   // ids are vocabulary indices: below 65535 (and unk_token_id too), a call stages u16 entries
 };
 
 struct ovtk_vocab_encoder {
@@ -132,6 +133,7 @@ int ovtk_wordpiece_create(const ovtk_wordpiece_params* p, ovtk_wordpiece** out) 
     if (int rc = h->sub.upload(sub, h->dev.sub)) return rc;
     OVTK_HIP(hipStreamSynchronize(nullptr));
     h->dev.max_bytes = p->max_bytes_per_word;
+    h->n_vocab = p->vocab.n;
     // Word memo for ovtk_wordpiece_encode_run: WordPiece(t) of every vocabulary string t taken as a word, computed by the
     // device op itself (one word per row).  No entry depends on unk_token_id: a word that needs unk is simply not stored.
     if (p->vocab.n > 0) {
@@ -237,11 +239,17 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                } else {
                                    OVTK_LAUNCH(ws.marks, "lookup_words", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp, memo_only, w);
                                }
-                               OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel,
-                                           dim3(grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * 8 / kShards), kShards),
-                                           kBlockThreads, s, d_in, wdev, unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
+                               const dim3 dgrid(grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * 8 / kShards), kShards);
+                               if (w.stage16)
+                                   OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel<true>, dgrid, kBlockThreads, s, d_in, wdev,
+                                               unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
+                               else
+                                   OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel<false>, dgrid, kBlockThreads, s, d_in, wdev,
+                                               unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
                            },
                            /*self_alloc=*/true, resident_blocks_per_cu(lookup_kernel<kFused>), /*tail_in_middle=*/true);
+    static const bool allow16 = [] { const char* e = std::getenv("OVTK_STAGE16"); return !e || std::atoi(e) != 0; }();   // (=0: i32 staging, A/B runs)
+    if (allow16 && h->n_vocab > 0 && h->n_vocab <= 65535 && unk_token_id >= 0 && unk_token_id <= 65534) r->enable_stage16();
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;

@@ -21,27 +21,49 @@ struct WordpieceDev {
 };
 
 // WordPiece of one word (wordpiece_tokenizer.cpp:100-126) into slot[0..): returns the id count (>= 1).
-template <class GetByte>
+// The staging entries of one word / piece: i32, or u16 (S16) when the call stages two bytes per id (EncodeWork::stage16) -- a
+// template flag: with a run-time branch in every put wordpiece_deferred_kernel took 54 us instead of 50.
+template <bool S16>
+struct StageSlot {
+    const EncodeWork& w;
+    int pos;
+    __device__ __forceinline__ void put(int k, int32_t id) const {
+        if (S16) reinterpret_cast<uint16_t*>(w.stage)[pos + k] = uint16_t(id);
+        else w.stage[pos + k] = id;
+    }
+    __device__ __forceinline__ void clear(int k) const {
+        if (S16) reinterpret_cast<uint16_t*>(w.stage)[pos + k] = uint16_t(0xFFFFu);
+        else w.stage[pos + k] = kEmptyId;
+    }
+    __device__ __forceinline__ int32_t get(int k) const {
+        if (S16) {
+            const uint32_t x = reinterpret_cast<const uint16_t*>(w.stage)[pos + k];
+            return x == 0xFFFFu ? kEmptyId : int32_t(x);
+        }
+        return w.stage[pos + k];
+    }
+};
+template <class GetByte, class Slot>
 __device__ __forceinline__ int wordpiece_word(const WordpieceDev& T, const I2* root_lds, const I2* sub_lds, GetByte&& getb,
-                                              int len, int32_t unk_id, int32_t* slot) {
+                                              int len, int32_t unk_id, const Slot& slot) {
     if (len > T.max_bytes || len <= 0) {  // strict > (:100-103); an empty word is undefined in the reference
-        slot[0] = unk_id;
+        slot.put(0, unk_id);
         return 1;
     }
     int idx = 0, cnt = 0;
     int tok = trie_longest(T.root, root_lds, getb, len, idx);
     if (tok == -1) {
-        slot[0] = unk_id;
+        slot.put(0, unk_id);
         return 1;
     }
-    slot[cnt++] = tok;
+    slot.put(cnt++, tok);
     while (idx < len) {
         tok = trie_longest(T.sub, sub_lds, getb, len, idx);
         if (tok == -1) {  // :118-123 the whole word becomes one unk
-            slot[0] = unk_id;
+            slot.put(0, unk_id);
             return 1;
         }
-        slot[cnt++] = tok;
+        slot.put(cnt++, tok);
     }
     return cnt;
 }
@@ -70,12 +92,12 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn 
             if (valid) { sb = in.begins[col]; len = in.ends[col] - sb; }
             const int units = valid ? (len > 0 ? len : 1) : 0;
             const int incl = wave_incl_sum(units);
-            int32_t* slot = w.stage + base + bytepos + incl - units;
+            const StageSlot<false> slot{w, base + bytepos + incl - units};   // (the op alone stages i32)
             int cnt = 0;
             if (valid) {
                 const uint8_t* s = in.chars + sb;
                 cnt = wordpiece_word(T, root_lds, sub_lds, [&](int i) -> uint32_t { return s[i]; }, len, unk_id, slot);
-                for (int k = cnt; k < units; ++k) slot[k] = kEmptyId;
+                for (int k = cnt; k < units; ++k) slot.clear(k);
             }
             emitted += wave_sum(cnt);
             bytepos += __shfl(incl, kWave - 1);
@@ -92,6 +114,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_kernel(RowsIn 
 // The words the fused BERT path could not resolve through the memo (encode_kernels.hpp lookup_kernel with the
 // kSplitBertWords scanner): dense batches of 64 deferred words, one lane per word.
 // tail_rows > 0: like merge_kernel, the block that finishes last also scans the per-tile id counts (no count_scan launch).
+template <bool S16>
 static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kernel(RowsIn in, WordpieceDev T, int32_t unk_id,
                                                                                  EncodeWork w, int tail_rows, long long out_cap) {
     __shared__ I2 root_lds[256];
@@ -118,7 +141,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
         // The word store first (the piece store of tables.hpp, keyed by the word): a word it holds is one probe instead of a
         // trie walk of one dependent load per byte.  What is filed there never depends on unk_token_id -- a word that came out
         // as unk is not stored --, so the table stays valid whatever input 8 says on the next call.
-        int32_t* out = w.stage + e.stage_pos;
+        const StageSlot<S16> out{w, e.stage_pos};
         uint32_t skey[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const bool keyed = T.store.slots && valid && e.len >= 1 && e.len <= kStoreKeyBytes;
         bool stored = false;
@@ -133,13 +156,13 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                 if (T.store.narrow) {
 #pragma unroll
                     for (int k = 0; k < kStoreIds16; ++k)
-                        if (k < c) out[k] = store_id<true>(pay, k);
+                        if (k < c) out.put(k, store_id<true>(pay, k));
                 } else {
 #pragma unroll
                     for (int k = 0; k < kStoreIds32; ++k)
-                        if (k < c) out[k] = store_id<false>(pay, k);
+                        if (k < c) out.put(k, store_id<false>(pay, k));
                 }
-                for (int k = c; k < e.len; ++k) out[k] = kEmptyId;
+                for (int k = c; k < e.len; ++k) out.clear(k);
             }
         }
         if (valid && !stored) {
@@ -153,18 +176,18 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                 const uint8_t* s = in.chars + e.begin;
                 cnt = wordpiece_word(T, root_lds, sub_lds, [&](int i) -> uint32_t { return s[i]; }, e.len, unk_id, out);
             }
-            for (int k = cnt; k < e.len; ++k) out[k] = kEmptyId;
+            for (int k = cnt; k < e.len; ++k) out.clear(k);
         }
         if (store_open) {  // file what was walked: its ids come back from the lane's own staging entries
             const int max_ids = T.store.narrow ? kStoreIds16 : kStoreIds32;
-            const bool want = keyed && !stored && cnt <= max_ids && !(cnt == 1 && out[0] == unk_id);
+            const bool want = keyed && !stored && cnt <= max_ids && !(cnt == 1 && out.get(0) == unk_id);
             if (__ballot(want)) {
                 bool added = false;
                 if (want) {
                     uint32_t pay[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                     for (int k = 0; k < kStoreIds16; ++k) {
-                        const uint32_t v = k < cnt ? uint32_t(out[k]) : 0u;
+                        const uint32_t v = k < cnt ? uint32_t(out.get(k)) : 0u;
                         if (T.store.narrow) pay[k >> 1] |= v << (16 * (k & 1));
                         else if (k < kStoreIds32) pay[k] = v;
                     }
