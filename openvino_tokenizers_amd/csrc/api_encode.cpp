@@ -771,22 +771,38 @@ int ovtk_encode_enqueue_packed(ovtk_regex_split* split, ovtk_bpe* bpe, const uin
     OVTK_HIP(hipSetDevice(bpe->device));
     auto p = std::make_unique<ovtk_pending>();
     p->out = *out;
+    if (batch == 0 || total == 0) {
+        // No text at all: the result follows from the header (start_encode's empty-batch paths read no tensor and launch
+        // nothing), so nothing is uploaded and no workspace is leased -- a lease handed back with a copy or a kernel still in
+        // flight would be another thread's input buffer a moment later.
+        const ovtk_ragged_strings none{nullptr, nullptr, batch, ovtk_strings{nullptr, nullptr, nullptr, batch, 0}};
+        if (int rc = start_encode(split, bpe, &none, nullptr, &p->out, out_mem, stream, p->run)) return rc;
+        *pending = p.release();
+        return OVTK_OK;
+    }
     // ONE copy over PCIe; the decomposed tensors are views of the device copy (begin_ids = words 1.., end_ids = words 2..,
     // utils.cpp:26-27), the rows are the strings (ragged_begins = 0, 1, ..; ragged_ends = 1, 2, ..: one table, read at +0 and +1)
     auto ws = std::make_shared<WorkspaceLease>(bpe->device);
     Workspace& w = *ws->ws;
+    // From here on work is queued on `s` into the leased buffers: every return that does not hand the lease to a run first waits
+    // for the stream (the lease's buffers, and the caller's `packed`, may be reused as soon as this function has returned).
+    auto fail = [&](int rc) {
+        (void)hipStreamSynchronize(s);
+        return rc;
+    };
     const size_t used = 8 + 4 * size_t(batch) + size_t(total);
-    if (int rc = w.in_chars.upload(packed, used, s)) return rc;
-    if (int rc = w.in_rb.ensure((size_t(batch) + 1) * 4)) return rc;
-    if (batch > 0)
-        hipLaunchKernelGGL(iota_kernel, dim3(std::min<int>((batch + kBlockThreads) / kBlockThreads, 1024)), dim3(kBlockThreads), 0, s,
-                           batch + 1, w.in_rb.as<int32_t>());  // (this lease is held until the run is over: finish() has waited by then)
+    if (int rc = w.in_chars.upload(packed, used, s)) return fail(rc);
+    if (int rc = w.in_rb.ensure((size_t(batch) + 1) * 4)) return fail(rc);
+    hipLaunchKernelGGL(iota_kernel, dim3(std::min<int>((batch + kBlockThreads) / kBlockThreads, 1024)), dim3(kBlockThreads), 0, s,
+                       batch + 1, w.in_rb.as<int32_t>());  // (this lease is held until the run is over: finish() has waited by then)
+    if (hipGetLastError() != hipSuccess) return fail(set_error(OVTK_E_HIP, "iota_kernel launch failed"));
     const uint8_t* d = w.in_chars.as<uint8_t>();
     const int32_t* iota = w.in_rb.as<int32_t>();
     const ovtk_ragged_strings in{iota, iota + 1, batch,
                                  ovtk_strings{reinterpret_cast<const int32_t*>(d + 4), reinterpret_cast<const int32_t*>(d + 8),
                                               d + 8 + 4 * size_t(batch), batch, total}};
-    if (int rc = start_encode(split, bpe, &in, nullptr, &p->out, out_mem, stream, p->run, nullptr, ws)) return rc;
+    if (int rc = start_encode(split, bpe, &in, nullptr, &p->out, out_mem, stream, p->run, nullptr, ws)) return fail(rc);
+    if (!p->run) (void)hipStreamSynchronize(s);   // (not reachable with total > 0; kept so that an empty run never strands queued work)
     *pending = p.release();
     return OVTK_OK;
 }

@@ -233,79 +233,58 @@ __device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint6
     for (int i = 0; i < plen && i < 8; ++i) r0 |= uint64_t(p[i]) << (8 * i);
     for (int i = 8; i < plen; ++i) r1 |= uint64_t(p[i]) << (8 * (i - 8));
 }
-// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.  Both candidate entries
-// (cuckoo table, no probe chain) are fetched with four independent 16-byte loads issued together and chosen by selects:
-// written with `if (key matches) take the payload`, the compiler sinks the payload load behind the key compare and a
-// lookup costs two dependent round trips instead of one.
+// Returns the id count (0..kPieceMaxIds) and fills tok, or -1 when the piece is not in the memo.  The piece's one candidate
+// entry (direct-mapped table, tables.hpp piece_h) is fetched with two independent 16-byte loads issued together: written with
+// `if (key matches) take the payload`, the compiler sinks the payload load behind the key compare and a lookup costs two
+// dependent round trips instead of one.
 struct MemoFetch {
-    uint4 k[2], p[2];  // key halves {k0, k1} and payload {tok[3], tag} of the two candidates
+    uint4 k, p;  // key {k0, k1} and payload {tok[3], tag} of the candidate
     uint32_t mix;
 };
 __device__ __forceinline__ MemoFetch memo_fetch(const PieceTableDev& P, uint64_t k0, uint64_t k1) {
     const uint32_t mix = piece_mix(k0, k1);
-    const uint4* e0 = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, 0, P.shift));   // the bucket: 64 bytes, two entries
+    const uint4* e = reinterpret_cast<const uint4*>(P.slots + piece_h(mix, P.shift));
     MemoFetch f;
     f.mix = mix;
-    f.k[0] = e0[0];
-    f.p[0] = e0[1];
-    f.k[1] = e0[2];
-    f.p[1] = e0[3];
+    f.k = e[0];
+    f.p = e[1];
 #ifndef OVTK_SIMT_EMULATOR
-    // all four loads are in flight before anything looks at a result
-    asm volatile("" : "+v"(f.p[0].x), "+v"(f.p[0].y), "+v"(f.p[0].z), "+v"(f.p[0].w), "+v"(f.p[1].x), "+v"(f.p[1].y), "+v"(f.p[1].z),
-                 "+v"(f.p[1].w));
+    // both loads are in flight before anything looks at a result
+    asm volatile("" : "+v"(f.p.x), "+v"(f.p.y), "+v"(f.p.z), "+v"(f.p.w));
 #endif
     return f;
 }
 __device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
     const uint32_t a = uint32_t(k0), b = uint32_t(k0 >> 32), c = uint32_t(k1), d = uint32_t(k1 >> 32);
     // the payload's tag with the expected one folded out: the id count (0..3) when the payload is this key's
-    const uint32_t expect = piece_tag(f.mix, 0);
-    const uint32_t c0 = f.p[0].w ^ expect, c1 = f.p[1].w ^ expect;
-    // (differences OR-ed into one word and ONE compare per entry: written as four `==` joined by `&&` the compiler turned every
-    // compare into a 0/1 value and combined them with 16-bit shifts and ors -- 15 vector instructions per entry instead of 5)
-    uint32_t x0 = (f.k[0].x ^ a) | (f.k[0].y ^ b) | (f.k[0].z ^ c) | (f.k[0].w ^ d);
-    uint32_t x1 = (f.k[1].x ^ a) | (f.k[1].y ^ b) | (f.k[1].z ^ c) | (f.k[1].w ^ d);
+    const uint32_t c0 = f.p.w ^ piece_tag(f.mix, 0);
+    // (differences OR-ed into one word and ONE compare: written as four `==` joined by `&&` the compiler turned every
+    // compare into a 0/1 value and combined them with 16-bit shifts and ors -- 15 vector instructions instead of 5)
+    uint32_t x = (f.k.x ^ a) | (f.k.y ^ b) | (f.k.z ^ c) | (f.k.w ^ d);
 #ifndef OVTK_SIMT_EMULATOR
-    asm volatile("" : "+v"(x0), "+v"(x1));   // (or the optimiser turns `(x ^ a | ...) == 0` back into the four compares)
+    asm volatile("" : "+v"(x));   // (or the optimiser turns `(x ^ a | ...) == 0` back into the four compares)
 #endif
-    const bool m0 = x0 == 0u && c0 <= uint32_t(kPieceMaxIds);
-    const bool m1 = x1 == 0u && c1 <= uint32_t(kPieceMaxIds);
-    tok[0] = int32_t(m1 ? f.p[1].x : f.p[0].x);
-    tok[1] = int32_t(m1 ? f.p[1].y : f.p[0].y);
-    tok[2] = int32_t(m1 ? f.p[1].z : f.p[0].z);
-    return m1 ? int(c1) : (m0 ? int(c0) : -1);
+    tok[0] = int32_t(f.p.x);
+    tok[1] = int32_t(f.p.y);
+    tok[2] = int32_t(f.p.z);
+    return (x == 0u && c0 <= uint32_t(kPieceMaxIds)) ? int(c0) : -1;
 }
 // merge_kernel's side of the memo -- the reference's piece cache (bpe_tokenizer.cpp:197-205, 331-338: a piece's ids are
 // kept the first time it is seen, while the cache holds fewer than cache_capacity entries; nothing is ever evicted).
-// This lane's piece (1..15 bytes, `cnt` <= kPieceMaxIds ids) goes into one of its two candidate slots if that slot is
-// free: no entry ever moves or changes, so a concurrent reader sees a slot either free, or claimed (kPieceBusy never
-// equals a key), or complete (payload checked by its tag).  A piece whose slots are both taken stays a miss.
-// `granted`: this lane may take one entry of the remaining room.  Returns false when nothing was added.
+// This lane's piece (1..15 bytes, `cnt` <= kPieceMaxIds ids) goes into its slot if that slot is free: no entry ever moves
+// or changes, so a concurrent reader sees a slot either free, or claimed (kPieceBusy never equals a key), or complete
+// (payload checked by its tag).  A piece whose slot is taken stays a miss.  Returns false when nothing was added.
 __device__ __forceinline__ bool memo_insert(const PieceTableDev& P, uint64_t k0, uint64_t k1, const int32_t (&tok)[kPieceMaxIds], int cnt) {
-    // (the lookup kernel has just missed this piece; nothing is read first -- one CAS per candidate tried.  A candidate that is
-    // being written, or holds this very piece -- filed by another wave a moment ago -- ends the attempt.)
+    // (the lookup kernel has just missed this piece; nothing is read first -- one CAS.  A slot that is being written, or holds
+    // this very piece -- filed by another wave a moment ago --, or any other piece ends the attempt.)
     const uint32_t mix = piece_mix(k0, k1);
     const uint32_t d3 = uint32_t(k1 >> 32);
-    uint32_t* slot = nullptr;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        if (slot) break;
-        uint32_t* cand = reinterpret_cast<uint32_t*>(const_cast<PieceEntry*>(P.slots) + piece_h(mix, c, P.shift));
-        const uint32_t old = atomicCAS(cand + 3, 0u, kPieceBusy);
-        if (old == 0u) {
-            slot = cand;
-        } else if (old == kPieceBusy) {
-            return false;
-        } else if (old == d3) {   // same length (and tail): this very piece?  (only then are its other dwords read)
-            if (__hip_atomic_load(cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == uint32_t(k0) &&
-                __hip_atomic_load(cand + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == uint32_t(k0 >> 32) &&
-                __hip_atomic_load(cand + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == uint32_t(k1))
-                return false;
-        }
-    }
-    if (!slot) return false;
+    uint32_t* slot = reinterpret_cast<uint32_t*>(const_cast<PieceEntry*>(P.slots) + piece_h(mix, P.shift));
+    if (atomicCAS(slot + 3, 0u, kPieceBusy) != 0u) return false;
     *reinterpret_cast<uint4*>(slot + 4) = uint4{uint32_t(tok[0]), uint32_t(tok[1]), uint32_t(tok[2]), piece_tag(mix, cnt)};
+    // (the payload is ordered before the key that makes it reachable; a reader that still meets the key first sees a tag that
+    // does not match -- a zeroed payload lacks the valid bit -- and takes the miss path, with the same result)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     *reinterpret_cast<uint4*>(slot) = uint4{uint32_t(k0), uint32_t(k0 >> 32), uint32_t(k1), d3};
     return true;
 }
@@ -413,6 +392,7 @@ __device__ __forceinline__ bool store_insert(const PieceStoreDev& S, const uint3
     if (!slot) return false;
     *reinterpret_cast<uint4*>(slot + 8) = uint4{pay[0], pay[1], pay[2], pay[3]};
     *reinterpret_cast<uint4*>(slot + 12) = uint4{pay[4], pay[5], pay[6], pay[7]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the payload before the key that makes it reachable (the tag's checksum stays as the second line of defence)
     *reinterpret_cast<uint4*>(slot) = uint4{key[0], key[1], key[2], key[3]};
     *reinterpret_cast<uint4*>(slot + 4) = uint4{key[4], key[5], key[6], key[7]};  // (replaces kPieceBusy: the entry is complete)
     return true;
@@ -464,18 +444,7 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     uint64_t k0 = 0, k1 = 0;
     if (valid && plen >= 1 && plen <= kPieceKeyBytes) {
         piece_key(r0, r1, plen, k0, k1);
-#if defined(OVTK_ABLATE) && OVTK_ABLATE == 2   // counter build: no hash, no probe -- every piece "hits" with one id
-        cnt = 1;
-        tok[0] = int32_t(k0 & 0xFF);
-#elif defined(OVTK_ABLATE) && OVTK_ABLATE == 3   // counter build: hash and loads, no compare / select
-        {
-            const MemoFetch f = memo_fetch(T.pieces, k0, k1);
-            cnt = 1;
-            tok[0] = int32_t(f.p[0].x ^ f.p[1].x ^ f.k[0].x ^ f.k[1].x);
-        }
-#else
         if (T.pieces.slots) cnt = memo_lookup(T.pieces, k0, k1, tok);
-#endif
     }
     const bool hit = cnt >= 0;
     const int need = valid ? (hit ? cnt : plen + SL) : 0;
@@ -960,10 +929,6 @@ static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? OVTK_L3
         if (l == 0) ws.pstart[np] = uint16_t(slen);
         wave_sync();
         RowState st{cursor, 0, 0, row};
-#if defined(OVTK_ABLATE) && OVTK_ABLATE == 1   // counter build: the scan alone (no batches)
-        st.used = np;
-        np = 0;
-#endif
         for (int jb = 0; jb < np; jb += kWave) {
             const int j = jb + l;
             bool valid = j < np;

@@ -227,19 +227,15 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
         for (int k = 0; k < cnt; ++k) e.tok[k] = ids[id_begins[i] + k];
         if (seen.emplace(std::string(reinterpret_cast<const char*>(kb), 16), list.size()).second) list.push_back(e);
     }
-    // buckets of two entries, one hash, no relocation: at a quarter full (entries / slots) two or three buckets in a
-    // thousand overflow
-    // (half the table at twice the fill was measured: the same kernel time, 1.9 % instead of 0.5 % of the vocabulary refused)
-    const uint32_t buckets = std::max<uint32_t>(4, pow2_at_least(uint64_t(list.size() + extra) * 2));
-    out.shift = 32 - log2u(buckets);
-    out.slots.assign(size_t(buckets) * 2, PieceEntry{0, 0, {0, 0, 0}, 0});
+    // direct-mapped, no relocation: at 1/12 full about three entries in a hundred find their slot taken (tables.hpp piece_h)
+    const uint32_t slots = std::max<uint32_t>(8, pow2_at_least(uint64_t(list.size() + extra) * 12));
+    out.shift = 32 - log2u(slots);
+    out.slots.assign(size_t(slots), PieceEntry{0, 0, {0, 0, 0}, 0});
     out.stored = out.refused = 0;
     for (const PieceEntry& e : list) {
-        const uint32_t mix = piece_mix(e.k0, e.k1);
-        PieceEntry* b = out.slots.data() + piece_h(mix, 0, out.shift);
-        if (b[0].k1 == 0) b[0] = e;
-        else if (b[1].k1 == 0) b[1] = e;
-        else { ++out.refused; continue; }
+        PieceEntry& b = out.slots[piece_h(piece_mix(e.k0, e.k1), out.shift)];
+        if (b.k1 != 0) { ++out.refused; continue; }
+        b = e;
         ++out.stored;
     }
 }

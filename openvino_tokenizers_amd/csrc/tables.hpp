@@ -80,7 +80,7 @@ struct alignas(32) PieceEntry {
 constexpr uint32_t kPieceBusy = 0xFF000000u;  // dword 3 of a key (length byte 255) while a writer fills the slot it claimed
 struct PieceTableDev {
     const PieceEntry* slots;  // nullptr: no memo (every piece takes the merge path)
-    uint32_t shift;           // 32 - log2(capacity)
+    uint32_t shift;           // 32 - log2(slots)
     int32_t* room;            // entries merge_kernel may still add (cache_capacity at create); nullptr: a fixed table.
                               // kRoomShards counters, kRoomStride ints apart (one per 128-byte line), that share the capacity:
                               // every wave-batch with something to file takes its room with a RETURNING add (that is what keeps
@@ -198,14 +198,15 @@ __host__ __device__ inline uint32_t piece_mix(uint64_t k0, uint64_t k1) {
 #endif
 }
 __host__ __device__ inline uint32_t piece_tag(uint32_t mix, int cnt) { return (mix & 0xFFFFFF00u) | 0x80u | uint32_t(cnt); }
-// A piece's two candidate entries are the halves of ONE 64-byte bucket (round 3).  With two independent candidates every
-// lookup touched two cache lines, and the one that did not hold the piece was a cold line of a table the text stream keeps
-// pushing out of the L2: half of the lookup kernels' fetched bytes.  One bucket = one line, one hash,
-// four loads at consecutive addresses.  The price is placement freedom: a bucket whose two entries are taken refuses a third
-// piece (on the host too: the table is sized so that this hits a few vocabulary tokens in a thousand -- the ones with the
-// highest ids, which come last -- and such a piece simply stays a miss: merge path / piece store, same result).
-__host__ __device__ inline uint32_t piece_h(uint32_t mix, int which, uint32_t shift) {  // shift = 32 - log2(buckets)
-    return ((mix >> shift) << 1) | uint32_t(which);
+// A piece has ONE candidate entry (round 4): its 32-byte slot, two 16-byte loads at consecutive addresses, one key compare.
+// History: two independent candidates (cuckoo, r01: two cache lines per lookup, one of them cold), then the two halves of one
+// 64-byte bucket (r03: one line, four loads), now a direct-mapped table eight times sparser.  The lookup kernels are bound by
+// instruction issue and by the texture addresser's per-instruction cost of divergent loads: the second candidate was two
+// loads and ~12 vector instructions of every probe for the sake of a few hundred vocabulary tokens.  The price is placement
+// freedom, paid in table size: at 1/12 full ~3 % of the entries find their slot taken (on the host too; they are the late,
+// rare ones -- a vocabulary is placed in ascending id order) and simply stay misses: merge path / piece store, same result.
+__host__ __device__ inline uint32_t piece_h(uint32_t mix, uint32_t shift) {  // shift = 32 - log2(slots)
+    return mix >> shift;
 }
 // Hash of a byte string, four bytes per step (little-endian words, the last one zero-padded), the same function on host
 // (table build) and device (probe).  The device feeds it words it already holds in registers: hash_words().
@@ -262,9 +263,9 @@ int build_bpe(const StringsView& vocab, const StringsView& merges_left, const St
 // The piece memo from (piece string, its ids) pairs: pieces of 1..kPieceKeyBytes bytes with at most
 // kPieceMaxIds ids are stored (a repeated string keeps its first entry -- all entries of one string are equal).
 struct PieceTableHost {
-    std::vector<PieceEntry> slots;   // 2 x buckets
-    uint32_t shift = 30;             // 32 - log2(buckets)
-    size_t stored = 0, refused = 0;  // refused: pieces whose bucket was full (they stay misses)
+    std::vector<PieceEntry> slots;   // direct-mapped: piece_h() is the slot
+    uint32_t shift = 30;             // 32 - log2(slots)
+    size_t stored = 0, refused = 0;  // refused: pieces whose slot was taken (they stay misses)
 };
 // extra: entries the device may add later (cache_capacity): the table is sized for stored + extra.
 void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
