@@ -13,6 +13,7 @@
 
 #include "api_common.hpp"
 #include "encode_kernels.hpp"
+#include "span_kernel.hpp"
 #include "runtime.hpp"
 #include "tables.hpp"
 #include "unicode_tables.inc"
@@ -593,15 +594,20 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // (marked in row_used) goes through the generic one
                                    // (consecutive rows per wave, headers by one vector load, the next row's text requested
                                    // ahead into LDS: lookup_rows_kernel; OVTK_LOOKUP_STRIDED=1 keeps the round-2 kernel, for A/B runs)
-                                   static const bool strided = std::getenv("OVTK_LOOKUP_STRIDED") != nullptr;
                                    EncodeWork w1 = w;
                                    w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
-                                   const bool ahead = !strided && w1.rows_per_wave <= kWave;
-                                   if (ahead && split->dev.kind == kSplitGpt2Digits)
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsGpt2Digits>, grid, kBlockThreads, s, d_in,
+                                   const bool ahead = w1.rows_per_wave <= kWave;
+                                   // several rows per scan block: lookup_span_kernel (it probes the memo for every piece: a handle
+                                   // without one -- cache_capacity = 0 -- keeps the row-per-scan kernel)
+                                   if (ahead && T.pieces.slots && split->dev.kind == kSplitGpt2Digits)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<true>, grid, kBlockThreads, s, d_in, T, w1);
+                                   else if (ahead && T.pieces.slots)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<false>, grid, kBlockThreads, s, d_in, T, w1);
+                                   else if (ahead && split->dev.kind == kSplitGpt2Digits)
+                                       OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsGpt2Digits>, grid, kBlockThreads, s, d_in,
                                                    split->dev, T, w1);
                                    else if (ahead)
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsGpt2>, grid, kBlockThreads, s, d_in, split->dev,
+                                       OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsGpt2>, grid, kBlockThreads, s, d_in, split->dev,
                                                    T, w1);
                                    else if (split->dev.kind == kSplitGpt2Digits)
                                        OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<true>, grid, kBlockThreads, s, d_in, T, w);
@@ -642,7 +648,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
                                   : split->dev.kind == kSplitLlama3 ? (OVTK_L3_BLOCKS == 4 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>) : resident_blocks_per_cu(lookup_rows_kernel<kRowsLlama3>))
                                   : split->dev.kind <= kSplitGpt2Digits && !row_tickets().load(std::memory_order_relaxed)
-                                      ? resident_blocks_per_cu(lookup_ascii_kernel<false>, 6)
+                                      ? resident_blocks_per_cu(lookup_span_kernel<false>, 6)
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (pieces_ws) {

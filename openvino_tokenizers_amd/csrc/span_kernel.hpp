@@ -1,0 +1,495 @@
+// span_kernel.hpp -- lookup_span_kernel: the GPT-2 family's lookup stage with SEVERAL ROWS PER SCAN (round 4).
+//
+// lookup_rows_kernel scans one row per pass: a 512-byte row is 8 bytes per lane, and everything that is paid once per pass
+// whatever the lane holds -- neighbour exchange, the prefix sum of the piece starts, the piece list, row bookkeeping, the last
+// partly filled 64-piece batch -- is paid per row: 599 vector instructions per 512-byte row, 250 of them in the scan, at
+// ~1.4 batches' worth of pieces in 2.2 batches.  The kernel is bound by instruction issue, so here a pass covers a
+// BLOCK: as many consecutive whole rows as fit 2 048 bytes, 32 bytes per lane.
+//   * rows that follow each other in the chars tensor (begins[i + 1] == ends[i]: what StringTensorUnpack produces) are one
+//     contiguous stretch of text: every lane loads its 32 bytes straight from global memory into registers (two 16-byte loads
+//     at a byte address -- gfx950 takes them at any alignment, tools/unaligned_probe.hip), the NEXT block's while this one is
+//     worked on; the registers are the scanner's input, and one copy goes to LDS for the key reads of the lookup rounds;
+//   * the row starts inside a block are one more per-byte flag (`rs`): they force a piece start and cut every look-ahead and
+//     look-behind of the rules, so that a row's pieces are exactly those of the row scanned alone (src/regex_split.cpp:205-324
+//     runs the pattern per string);
+//   * the rules are gpt2_start_flags_ascii's, the flags of a lane's 8 dwords packed into 32 bits by eight v_dot4_u32_u8;
+//   * the pieces of ALL rows of the block form one list, looked up 64 at a time in full rounds, the probe loads of round r + 1
+//     in flight while round r is resolved; staging positions run through the block (the wave's rows are staged back to back),
+//     the per-row records are read off the running sums at the rows' first pieces;
+//   * misses are noted in LDS as {staging position, begin, length, row} and become DeferredPiece entries (key bytes re-read
+//     from the text) when 64 have collected or the wave is through.
+// Rows that are not one non-empty string inside the chars tensor, rows longer than a block, blocks with non-ASCII bytes: marked
+// kRowPending and listed for lookup_kernel<kFused>, exactly as lookup_rows_kernel does.
+#pragma once
+
+#include "encode_kernels.hpp"
+
+namespace ovtk {
+
+constexpr int kSpanLane = 32;                    // text bytes per lane
+constexpr int kSpanDwords = kSpanLane / 4;
+constexpr int kSpanBytes = kWave * kSpanLane;    // bytes per block
+constexpr int kSpanMiss = 64;                    // misses noted per wave before they are written out
+
+struct SpanWave {
+    uint32_t text[kSpanBytes / 4 + 8];           // the block's text (+ 32 bytes: the 16-byte key read of a piece at its end)
+    uint16_t pstart[kSpanBytes + 4];             // piece starts, block-relative, np + 1 of them (every byte may start one)
+    uint4 miss[kSpanMiss];                       // {staging position, begin in chars, length | wave row << 16, -}
+};
+
+struct __attribute__((packed, aligned(1))) Bytes16 { uint32_t x, y, z, w; };
+typedef uint32_t U32x4 __attribute__((ext_vector_type(4)));
+typedef U32x4 U32x4Unaligned __attribute__((aligned(1)));
+struct __attribute__((packed, aligned(1))) Bytes4 { uint32_t v; };
+
+// `sval` (wave-uniform) into lane `lane` (wave-uniform) of a per-lane value
+__device__ __forceinline__ int wave_writelane(int old, int sval, int lane) { return lane_id() == lane ? sval : old; }
+// sum of the four bytes of `a` times the four bytes of `b`, plus c -- v_dot4_u32_u8
+__device__ __forceinline__ uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef OVTK_SIMT_EMULATOR
+    for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
+    return c;
+#else
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#endif
+}
+// 4 flag bits -> 4 bytes with the flag in bit 7
+__device__ __forceinline__ uint32_t nibble_to_b7(uint32_t nib) {
+    // bit k of nib lands at 7 + 7k + k = 8k + 7 for the three low bits (24-bit multiply); bit 3 is placed by hand
+    return ((mul24(nib & 7u, 0x204080u) & 0x00808080u) | ((nib & 8u) << 28));
+}
+
+// The 32 bytes of lane l of the block that starts at chars[sb] and is blen bytes long (lanes behind its end: zeros).
+__device__ __forceinline__ void span_load(const RowsIn& in, int sb, int blen, uint32_t (&x)[kSpanDwords]) {
+    const int l = lane_id();
+    const long long at = (long long)sb + kSpanLane * l;
+#pragma unroll
+    for (int j = 0; j < kSpanDwords; ++j) x[j] = 0;
+    if (kSpanLane * l < blen) {
+        if (at + kSpanLane <= in.n_chars) {
+#if defined(OVTK_SIMT_EMULATOR)
+            const Bytes16* p = reinterpret_cast<const Bytes16*>(in.chars + at);
+            const Bytes16 a = p[0], b = p[1];
+#else
+            const U32x4Unaligned* p = reinterpret_cast<const U32x4Unaligned*>(in.chars + at);
+            const U32x4 a = __builtin_nontemporal_load(p), b = __builtin_nontemporal_load(p + 1);   // (read once: do not age the tables' lines)
+#endif
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+            x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        } else {   // the last lane of the chars tensor: byte by byte
+            const int n = int(in.n_chars - at);
+            for (int k = 0; k < n; ++k) x[k >> 2] |= uint32_t(in.chars[at + k]) << (8 * (k & 3));
+        }
+    }
+}
+
+// Piece-start flags of the lane's 32 bytes (bit k = byte 32 l + k starts a piece) under the GPT-2 rules of split_device.hpp
+// (gpt2_start_flags_ascii: the same algebra), streamed dword by dword so that only three dwords' classes are live, with the
+// flags of two dwords packed into 8 bits by one v_dot4_u32_u8 each.  Two things are decided on the packed flags afterwards,
+// where they cost a handful of instructions per lane instead of some per dword:
+//  * the row starts `rs` (bit k: byte 32 l + k is the first of a row, or the first behind the block).  Such a byte starts a piece
+//    whatever stands in front of it; and the one rule that looks AHEAD across it -- the last character of a white-space run
+//    starts a piece when a non-space follows, `\s+(?!\S)` backing off -- must not: a row's trailing run is one piece;
+//  * contractions: apostrophes are few, so a lane walks its own (usually none, rarely two) and reads the letters behind them
+//    from the LDS copy of the text.
+// false (wave-uniform): the block holds a non-ASCII byte.
+struct SpanClasses { uint32_t L, N, S, SP, O; };
+template <bool DIGITS>
+__device__ __forceinline__ SpanClasses span_classify(uint32_t v) {
+    SpanClasses c;
+    c.L = swar_range(v | 0x20202020u, 'a', 'z');
+    c.N = swar_range(v, '0', '9');
+    c.SP = swar_eq(v, 0x20);
+    c.S = c.SP | swar_range(v, 9, 13);
+    c.O = kB7 & ~(c.L | c.N | c.S);
+    return c;
+}
+template <bool DIGITS>
+__device__ __forceinline__ bool span_flags(uint32_t (&x)[kSpanDwords], uint32_t rs, uint32_t vm, const uint8_t* text, uint32_t& flags) {
+    constexpr int D = kSpanDwords;
+    const int l = lane_id();
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) any |= x[j];
+    if (__ballot((any & kB7) != 0)) {
+        // a lane's bytes behind the block's end are the next row's (or whatever follows in the tensor): look again, at the block's own
+        uint32_t bad = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const uint32_t own = nibble_to_b7((vm >> (4 * j)) & 0xFu);
+            bad |= x[j] & own;
+            x[j] &= ~(kB7 & ~own);   // (a byte >= 0x80 would carry into its neighbours in the packed arithmetic below)
+        }
+        if (__ballot(bad != 0)) return false;
+    }
+    // the lane's last dword first: its classes are the "dword before" of lane l + 1; then the first: "not white space" of lane l - 1's look-ahead
+    const SpanClasses last = span_classify<DIGITS>(x[D - 1]);
+    SpanClasses prev{lane_prev(last.L), lane_prev(last.N), lane_prev(last.S), lane_prev(last.SP), lane_prev(last.O)};
+    SpanClasses cur = span_classify<DIGITS>(x[0]);
+    const uint32_t ns_behind = lane_next(kB7 & ~cur.S);
+    uint32_t f_acc[D / 2], s_acc[D / 2], a_acc[D / 2];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        SpanClasses nxt = cur;
+        uint32_t ns_next = ns_behind;
+        if (j + 1 < D) {
+            nxt = j + 1 == D - 1 ? last : span_classify<DIGITS>(x[j + 1]);
+            ns_next = kB7 & ~nxt.S;
+        }
+        const uint32_t pL = swar_before<1>(prev.L, cur.L), pN = swar_before<1>(prev.N, cur.N);
+        const uint32_t pS = swar_before<1>(prev.S, cur.S), pO = swar_before<1>(prev.O, cur.O);
+        const uint32_t pSP = swar_before<1>(prev.SP, cur.SP);
+        const uint32_t same = (cur.L & pL) | (cur.N & pN) | (cur.S & pS) | (cur.O & pO);
+        const uint32_t attaches = ~cur.S & (DIGITS ? ~cur.N : ~0u);
+        uint32_t st = ~same & ~(pSP & attaches);
+        const uint32_t next_nonspace = swar_after<1>(kB7 & ~cur.S, ns_next);
+        st |= same & ((cur.S & next_nonspace) | (DIGITS ? cur.N : 0u));
+        st &= kB7;
+        const uint32_t ap = swar_eq(x[j], 0x27);
+        // 0x80 flags of two dwords -> 128 x (8 flag bits): byte k of the dword times 1 << k (or 16 << k)
+        if ((j & 1) == 0) {
+            f_acc[j >> 1] = dot4_u8(st, 0x08040201u, 0u);
+            s_acc[j >> 1] = dot4_u8(cur.S, 0x08040201u, 0u);
+            a_acc[j >> 1] = dot4_u8(ap, 0x08040201u, 0u);
+        } else {
+            f_acc[j >> 1] = dot4_u8(st, 0x80402010u, f_acc[j >> 1]);
+            s_acc[j >> 1] = dot4_u8(cur.S, 0x80402010u, s_acc[j >> 1]);
+            a_acc[j >> 1] = dot4_u8(ap, 0x80402010u, a_acc[j >> 1]);
+        }
+        prev = cur;
+        cur = nxt;
+    }
+    flags = (f_acc[0] >> 7) | (f_acc[1] << 1) | (f_acc[2] << 9) | (f_acc[3] << 17);
+    const uint32_t sbits = (s_acc[0] >> 7) | (s_acc[1] << 1) | (s_acc[2] << 9) | (s_acc[3] << 17);
+    uint32_t apbits = ((a_acc[0] >> 7) | (a_acc[1] << 1) | (a_acc[2] << 9) | (a_acc[3] << 17)) & vm;
+    // ---- row starts
+    const uint32_t rs_next = lane_next(rs);
+    {
+        const uint32_t ends_row = (rs >> 1) | (rs_next << 31);                    // the byte behind this one is another row's (or none)
+        const uint32_t s_before = (sbits << 1) | (lane_prev(sbits) >> 31);       // the byte in front of this one is white space
+        flags = (flags & ~(ends_row & sbits & s_before)) | rs;
+    }
+    // ---- contractions: 's 't 'm 'd 're 've 'll at an apostrophe that itself starts a piece; the letter(s) stay with it, the byte
+    // behind them starts a piece.  Bits 32.. of the masks belong to lane l + 1.
+    if (__ballot(apbits != 0)) {
+        const uint64_t rs64 = uint64_t(rs) | (uint64_t(rs_next) << 32);
+        uint64_t set = 0, clr = 0;
+        apbits &= flags;   // (an apostrophe behind a class-O character or a space does not start a piece: nothing fires there)
+        while (apbits) {
+            const int k = __ffs(apbits) - 1;
+            apbits &= apbits - 1;
+            const uint32_t w4 = reinterpret_cast<const Bytes4*>(text + kSpanLane * l + k)->v;   // ' c1 c2 ..
+            const uint32_t c1 = (w4 >> 8) & 0xFFu, c2 = (w4 >> 16) & 0xFFu;
+            const bool r1 = (rs64 >> (k + 1)) & 1ull, r2 = (rs64 >> (k + 2)) & 1ull;   // the letters must be of this row
+            const bool one = !r1 && (c1 == 's' || c1 == 't' || c1 == 'm' || c1 == 'd');
+            const bool two = !r1 && !r2 && (((c1 == 'r' || c1 == 'v') && c2 == 'e') || (c1 == 'l' && c2 == 'l'));
+            if (one || two) {
+                clr |= 1ull << (k + 1);
+                set |= 1ull << (k + (one ? 2 : 3));
+            }
+        }
+        const uint32_t set_in = lane_prev(uint32_t(set >> 32)), clr_in = lane_prev(uint32_t(clr >> 32));
+        flags = ((flags | uint32_t(set) | set_in) & ~(uint32_t(clr) | clr_in)) | rs;
+    }
+    flags &= vm;
+    return true;
+}
+
+// Writes the n (<= kSpanMiss) noted misses of the wave to its shard of the deferred list.
+__device__ __forceinline__ void span_flush(const SpanWave& sw, int n, const RowsIn& in, const EncodeWork& w, int row0,
+                                           const uint4* mask_tab) {
+    const int l = lane_id();
+    const int shard = int(blockIdx.x) % kShards;
+    int idx = 0;
+    if (l == 0) idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
+    idx = wave_readlane(idx, 0);
+    if (l < n) {
+        const uint4 e = sw.miss[l];
+        const int begin = int(e.y), len = int(e.z & 0xFFFFu);
+        uint64_t k0 = 0, k1 = 0;
+        if (len <= kPieceKeyBytes) {
+            Bytes16 r{0, 0, 0, 0};
+            if ((long long)begin + 16 <= in.n_chars) {
+                r = *reinterpret_cast<const Bytes16*>(in.chars + begin);
+            } else {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < len; ++k) t[k >> 2] |= uint32_t(in.chars[begin + k]) << (8 * (k & 3));
+                r = Bytes16{t[0], t[1], t[2], t[3]};
+            }
+            const uint4 m = mask_tab[len];
+            k0 = uint64_t(r.x & m.x) | (uint64_t(r.y & m.y) << 32);
+            k1 = uint64_t(r.z & m.z) | (uint64_t((r.w & m.w) | (uint32_t(len) << 24)) << 32);
+        }
+        if (idx + l < w.shard_cap)
+            w.deferred[(long long)shard * w.shard_cap + idx + l] = DeferredPiece{k0, k1, int32_t(e.x), row0 + int(e.z >> 16), begin, len};
+        else
+            atomicOr(&w.status->flags, kFlagDeferOverflow);
+    }
+}
+
+// One round's probe: the piece of lane l (none: plen == 0), its masked key dwords, and the candidate entry on its way.
+struct SpanProbe {
+    uint4 k, p;
+    uint32_t a, b, c, d, mix;
+    int plen, ps;
+};
+
+template <bool DIGITS>
+static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(RowsIn in, BpeDev T, EncodeWork w) {
+    __shared__ SpanWave sw_all[kWavesPerBlock];
+    __shared__ uint4 mask_tab[16];   // [n]: byte masks of the four key dwords of an n-byte piece (n = 0: nothing)
+    if (threadIdx.x < 16) {
+        const int n = int(threadIdx.x);
+        uint32_t m[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int keep = n - 4 * d;
+            m[d] = keep >= 4 ? ~0u : (keep <= 0 ? 0u : ((1u << (8 * keep)) - 1u));
+        }
+        mask_tab[n] = uint4{m[0], m[1], m[2], m[3]};
+    }
+    __syncthreads();
+    if (w.status->flags & kFatalFlags) return;
+    SpanWave& sw = sw_all[wave_in_block()];
+    const uint8_t* text = reinterpret_cast<const uint8_t*>(sw.text);
+    const int l = lane_id();
+    const int wave = wave_uniform(int(blockIdx.x) * kWavesPerBlock + wave_in_block());
+    const int R = w.rows_per_wave;  // <= kWave
+    const int row0 = wave * R;
+    if (row0 >= in.n_rows) return;
+    const int nr = in.n_rows - row0 < R ? in.n_rows - row0 : R;
+    const int SL = T.suffix_len, mul = SL + 1;
+    // ---- the headers of all my rows: lane i = row row0 + i
+    int h_sb = 0, h_len = 0;
+    bool h_simple = false;
+    if (l < nr) {
+        const int cb = in.ragged_begins[row0 + l], ce = in.ragged_ends[row0 + l];
+        if (ce == cb + 1 && cb >= 0 && cb < in.n_strings && !(in.skips && in.skips[cb])) {
+            h_sb = in.begins[cb];
+            h_len = in.ends[cb] - h_sb;
+            h_simple = h_len > 0 && h_len <= kSpanBytes && h_sb >= 0 && (long long)h_sb + h_len <= in.n_chars;
+        }
+    }
+    if (!h_simple) h_len = 0;
+    // row l continues the stretch of text of row l - 1
+    const int prev_end = int(lane_prev(uint32_t(h_sb + h_len)));
+    const unsigned long long simple_m = __ballot(h_simple);
+    const unsigned long long link_m = __ballot(h_simple && l > 0 && ((simple_m >> (l > 0 ? l - 1 : 0)) & 1ull) && h_sb == prev_end);
+    const int incl = wave_incl_sum(h_len);   // bytes of rows 0..l
+    const int excl = incl - h_len;
+    // ---- staging: ONE reservation for all my rows (rows that end up pending leave theirs unused)
+    int cursor = 0;
+    bool dead = false;
+    {
+        const int total = wave_readlane(incl, kWave - 1) * mul;
+        const int shard = wave % kShards;
+        int base = 0;
+        if (l == 0 && total > 0) base = atomicAdd(&w.status->stage_top[shard * kCounterStride], total);
+        base = wave_readlane(base, 0);
+        if (base < 0 || base > w.stage_region - total) {
+            if (l == 0) atomicOr(&w.status->flags, kFlagStageOverflow);
+            dead = true;   // the host grows the buffer and reruns
+        }
+        cursor = shard * w.stage_region + base;
+    }
+    unsigned long long pending_m = dead ? ~0ull : ~simple_m;   // (bits >= nr are ignored below)
+    // the rows' records collect in lane i for row i and leave with one store per array at the end
+    int rec_stage = 0, rec_cnt = 0, rec_used = 0;
+    int n_miss = 0;
+    // ---- blocks: rows [bi, bj) -- a run of linked rows of at most kSpanBytes bytes
+    auto next_block = [&](int from, int& bi, int& bj, int& b_sb, int& b_len) {
+        // first simple row at or behind `from`
+        const unsigned long long cand = simple_m & ~((from >= 64 ? ~0ull : (1ull << from)) - 1ull);
+        bi = (dead || !cand || from >= nr) ? nr : __ffsll(cand) - 1;
+        bj = bi;
+        b_sb = b_len = 0;
+        if (bi >= nr) { bi = bj = nr; return; }
+        const int ex = wave_readlane(excl, bi);
+        const unsigned long long over = __ballot(incl - ex > kSpanBytes);
+        const unsigned long long above = bi >= 63 ? 0ull : ~((2ull << bi) - 1ull);
+        const unsigned long long stop = (~link_m | over) & above;
+        bj = stop ? __ffsll(stop) - 1 : kWave;
+        b_sb = wave_readlane(h_sb, bi);
+        b_len = wave_readlane(incl, bj - 1) - ex;
+    };
+    int bi, bj, b_sb, b_len;
+    next_block(0, bi, bj, b_sb, b_len);
+    uint32_t xa[kSpanDwords];
+    span_load(in, b_sb, b_len, xa);
+    while (bi < nr) {
+        bi = wave_uniform(bi); bj = wave_uniform(bj); b_sb = wave_uniform(b_sb); b_len = wave_uniform(b_len);
+        // ---- the text into LDS (the key reads of the rounds, the letters behind an apostrophe), the scan from the registers
+        wave_sync();   // the previous block's rounds are done with the LDS text and piece list
+        {
+            uint4* tw = reinterpret_cast<uint4*>(sw.text) + 2 * l;
+            tw[0] = uint4{xa[0], xa[1], xa[2], xa[3]};
+            tw[1] = uint4{xa[4], xa[5], xa[6], xa[7]};
+        }
+        const int ex0 = wave_readlane(excl, bi);
+        uint32_t rs = 0;
+        for (int k = bi; k <= bj; ++k) {   // k == bj: the first byte behind the block
+            const int p = k < bj ? wave_readlane(excl, k < bj ? k : 0) - ex0 : b_len;
+            if (l == (p >> 5)) rs |= 1u << (p & 31);
+        }
+        const int nv = b_len - kSpanLane * l;
+        const uint32_t vm = nv >= kSpanLane ? ~0u : (nv <= 0 ? 0u : ((1u << nv) - 1u));
+        wave_sync();
+        uint32_t fl = 0;
+        const bool fast = span_flags<DIGITS>(xa, rs, vm, text, fl);
+        // ---- the next block's text: in flight while this block's pieces are looked up
+        int ni, nj, n_sb, n_len;
+        next_block(bj, ni, nj, n_sb, n_len);
+        span_load(in, n_sb, n_len, xa);
+        if (fast) {
+            const int cnt = __popc(fl);
+            const int p_incl = wave_incl_sum(cnt);
+            const int at0 = p_incl - cnt;
+            const int np = wave_readlane(p_incl, kWave - 1);
+            {
+                uint32_t f = fl;
+                uint16_t* at = sw.pstart + at0;
+                while (f) {
+                    *at++ = uint16_t(kSpanLane * l + __ffs(f) - 1);
+                    f &= f - 1;
+                }
+            }
+            if (l < 2) sw.pstart[np + l] = uint16_t(b_len);   // (two of them: lane j >= np reads a piece of no bytes)
+            // first piece of every row of the block (lane k - bi: row k)
+            int rowfirst = 0;
+            for (int k = bi; k < bj; ++k) {
+                const int p = wave_readlane(excl, k) - ex0;
+                const int ln = p >> 5;
+                const uint32_t fk = uint32_t(wave_readlane(int(fl), ln));
+                const int first = wave_readlane(at0, ln) + __popc(fk & ((1u << (p & 31)) - 1u));
+                rowfirst = wave_writelane(rowfirst, first, k - bi);
+            }
+            wave_sync();
+            // ---- rounds of 64 pieces; the probe of the next round is in flight while this one is resolved
+            int emitted = 0;            // ids written by hits since the block's start
+            int next_row = 0;           // rows of the block whose first piece has been seen
+            int next_first = 0;         // first piece of row bi + next_row (the block's first row starts at piece 0)
+            const int n_block_rows = bj - bi;
+            auto fetch = [&](int jb) -> SpanProbe {
+                SpanProbe q;
+                const int j = jb + l < np ? jb + l : np;
+                const uint32_t pp = reinterpret_cast<const Bytes4*>(sw.pstart + j)->v;
+                q.ps = int(pp & 0xFFFFu);
+                q.plen = int(pp >> 16) - q.ps;
+                const Bytes16 r = *reinterpret_cast<const Bytes16*>(text + q.ps);
+                const uint4 m = mask_tab[q.plen < 15 ? q.plen : 15];
+                q.a = r.x & m.x;
+                q.b = r.y & m.y;
+                q.c = r.z & m.z;
+                q.d = (r.w & m.w) | (uint32_t(q.plen) << 24);
+                q.mix = piece_mix((uint64_t(q.b) << 32) | q.a, (uint64_t(q.d) << 32) | q.c);
+                const uint4* e = reinterpret_cast<const uint4*>(T.pieces.slots + piece_h(q.mix, T.pieces.shift));
+                q.k = e[0];
+                q.p = e[1];
+                return q;
+            };
+            auto resolve = [&](const SpanProbe& q, int jb) {
+                const bool valid = q.plen >= 1;
+                uint32_t xk = (q.k.x ^ q.a) | (q.k.y ^ q.b) | (q.k.z ^ q.c) | (q.k.w ^ q.d);
+#ifndef OVTK_SIMT_EMULATOR
+                asm volatile("" : "+v"(xk));   // (one compare, not four: memo_resolve)
+#endif
+                const uint32_t c0 = q.p.w ^ piece_tag(q.mix, 0);
+                const bool hit = valid && q.plen <= kPieceKeyBytes && xk == 0u && c0 <= uint32_t(kPieceMaxIds);
+                const int cnt_ids = hit ? int(c0) : 0;
+                const int need = hit ? cnt_ids : (valid ? q.plen + SL : 0);
+                const int v = need | (cnt_ids << 16);
+                const int s_incl = wave_incl_sum(v);
+                const int s_excl = s_incl - v;
+                const int pos = cursor + (s_excl & 0xFFFF);
+                if (hit) {
+                    if (w.stage16) {
+                        uint16_t* st16 = reinterpret_cast<uint16_t*>(w.stage) + pos;
+                        if (cnt_ids > 0) st16[0] = uint16_t(q.p.x);
+                        if (cnt_ids > 1) st16[1] = uint16_t(q.p.y);
+                        if (cnt_ids > 2) st16[2] = uint16_t(q.p.z);
+                    } else {
+                        int32_t* st32 = w.stage + pos;
+                        if (cnt_ids > 0) st32[0] = int32_t(q.p.x);
+                        if (cnt_ids > 1) st32[1] = int32_t(q.p.y);
+                        if (cnt_ids > 2) st32[2] = int32_t(q.p.z);
+                    }
+                }
+                // rows whose first piece lies in this round: their records are the running sums at that piece
+                int row_here = 0;   // rows that start at or before this lane's piece, counted from the round's first
+                while (next_row < n_block_rows && next_first < jb + kWave) {
+                    const int ln = next_first - jb;
+                    const uint32_t at = uint32_t(wave_readlane(s_excl, ln));
+                    rec_stage = wave_writelane(rec_stage, cursor + int(at & 0xFFFFu), bi + next_row);
+                    rec_cnt = wave_writelane(rec_cnt, emitted + int(at >> 16), bi + next_row);
+                    row_here += l >= ln ? 1 : 0;
+                    next_row = wave_uniform(next_row + 1);
+                    next_first = wave_readlane(rowfirst, next_row < kWave ? next_row : 0);
+                }
+                const bool miss = valid && !hit;
+                const unsigned long long mm = __ballot(miss);
+                if (mm) {
+                    const int add = __popcll(mm);
+                    if (n_miss + add > kSpanMiss) {
+                        wave_sync();
+                        span_flush(sw, n_miss, in, w, row0, mask_tab);
+                        wave_sync();
+                        n_miss = 0;
+                    }
+                    // (the piece's row: the last row seen before this round, plus those that start at or before the piece)
+                    const int rowidx = bi + next_row - 1 - (wave_readlane(row_here, kWave - 1) - row_here);
+                    if (miss) sw.miss[n_miss + rank_below(mm)] = uint4{uint32_t(pos), uint32_t(b_sb + q.ps), uint32_t(q.plen) | (uint32_t(rowidx) << 16), 0u};
+                    n_miss += add;
+                }
+                const uint32_t tot = uint32_t(wave_readlane(s_incl, kWave - 1));
+                cursor += int(tot & 0xFFFFu);
+                emitted += int(tot >> 16);
+            };
+            // (two probes in turn, so that "the next one" never has to be copied into "this one")
+            SpanProbe qa = fetch(0), qb = qa;
+            for (int jb = 0; jb < np; jb += 2 * kWave) {
+                if (jb + kWave < np) qb = fetch(jb + kWave);
+                resolve(qa, jb);
+                if (jb + kWave < np) {
+                    if (jb + 2 * kWave < np) qa = fetch(jb + 2 * kWave);
+                    resolve(qb, jb + kWave);
+                }
+            }
+            // ---- the rows' records: used = up to the next row's first entry, ids = the hits' ids in between
+            {
+                const bool mine = l >= bi && l < bj;
+                const int nx_stage = int(lane_next(uint32_t(rec_stage))), nx_cnt = int(lane_next(uint32_t(rec_cnt)));
+                const int end_stage = l == bj - 1 ? cursor : nx_stage;
+                const int end_cnt = l == bj - 1 ? emitted : nx_cnt;
+                if (mine) {
+                    rec_used = end_stage - rec_stage;
+                    rec_cnt = end_cnt - rec_cnt;
+                }
+            }
+        } else {
+            for (int k = bi; k < bj; ++k) pending_m |= 1ull << k;
+        }
+        bi = ni; bj = nj; b_sb = n_sb; b_len = n_len;
+    }
+    if (n_miss > 0) {
+        wave_sync();
+        span_flush(sw, n_miss, in, w, row0, mask_tab);
+    }
+    const bool is_pending = l < nr && ((pending_m >> l) & 1ull);
+    if (l < nr) {
+        w.row_used[row0 + l] = is_pending ? kRowPending : rec_used;
+        if (!is_pending) {
+            w.row_stage[row0 + l] = rec_stage;
+            w.row_cnt[row0 + l] = rec_cnt;
+            if (w.row_emit) w.row_emit[row0 + l] = rec_cnt;
+        }
+    }
+    const unsigned long long pm = __ballot(is_pending);
+    if (pm) {   // the rows left to the generic kernel: counted, and listed for it
+        int base = 0;
+        if (l == 0) base = atomicAdd(&w.status->n_pending, int(__popcll(pm)));
+        base = wave_readlane(base, 0);
+        if (w.pending_rows && is_pending) w.pending_rows[base + rank_below(pm)] = row0 + l;
+    }
+}
+
+}  // namespace ovtk

@@ -1,0 +1,199 @@
+"""lookup_span_kernel (csrc/span_kernel.hpp): several rows per scan block, GPT-2 family.
+
+Every case is the fused encode (RegexSplit `isolate` + BPETokenizer, `ovtk_encode_run`) against the oracle chain, on batches
+large enough to leave the one-launch small-batch kernel (> 256 rows or > 64 KiB of text) and small enough for the emulator's
+two blocks to own at most 64 rows per wave (<= 512 rows) -- the condition under which the launch code picks the span kernel.
+What is probed: the block edges (rows of 1 .. 2 048 bytes, blocks that end exactly at 2 048), row starts inside a lane's 32
+bytes, the rules' look-ahead / look-behind at row boundaries (white space, apostrophes, contractions cut by a row end), rows
+the kernel must leave to the generic one (empty, longer than a block, non-ASCII, skipped, not contiguous), dense piece lists,
+and miss-heavy text (the LDS miss list filling up and being written out mid-block).
+Reference behaviour: src/regex_split.cpp:205-324 runs the pattern per string; src/bpe_tokenizer.cpp:47-164.
+"""
+import numpy as np
+import pytest
+
+from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
+from oracle import oracle as O
+from tests.util import BpeTok, assert_same
+from tools.harness import pack_strings
+from tools.workloads import TextModel, ragged_rows
+
+DIGITS_PATTERN = r"'s|'t|'re|'ve|'m|'ll|'d| ?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+"
+
+
+def fused_vs_oracle(backend, tok, inputs, skips=None, pattern=None, what="fused"):
+    pattern = pattern or tok.pattern
+    pat = np.frombuffer(pattern.encode(), np.uint8)
+    o_in = [np.asarray(x) for x in inputs]
+    sp_ref = O.RegexSplit(pattern, "isolate")(*o_in, skips=skips)
+    ref = tok.oracle()(*sp_ref[:5])
+    data = backend.data(inputs)
+    sk = backend.data([np.asarray(skips, np.uint8)]) if skips is not None else []
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    got = fused.evaluate(data + sk + [pat], tok.consts)
+    assert_same(ref, got, backend.host, what)
+    return ref
+
+
+def rows_of(strings):
+    b, e, c = pack_strings(strings)
+    rb, re_ = ragged_rows(len(b))
+    return [rb, re_, b, e, c]
+
+
+@pytest.mark.parametrize("kind,n,target", [("zipf", 400, 128), ("zipf", 288, 512), ("uniform", 320, 200), ("zipf", 300, 40)])
+def test_text_models(backend, kind, n, target):
+    b, e, c = TextModel(41, kind).batch(n, target)
+    rb, re_ = ragged_rows(n)
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), [rb, re_, b, e, c], what=f"{kind} {n} x {target}")
+
+
+def test_digits_variant(backend):
+    b, e, c = TextModel(42, "zipf").batch(300, 160)
+    rb, re_ = ragged_rows(300)
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), [rb, re_, b, e, c], pattern=DIGITS_PATTERN, what="individual digits")
+
+
+def _filler(rng, n):
+    """n bytes of word-like ASCII text."""
+    words = [b"the", b"of", b"and", b"token", b"7", b"2024", b"don't", b"we'll", b"it's", b"I'm", b"x", b"  ", b"\n", b"\t", b"!?", b"'", b"''s",
+             b"they've", b"you're", b"he'd", b"'t", b"a1b2", b"--", b"(", b")", b"e.g.", b" "]
+    out = bytearray()
+    while len(out) < n:
+        out += words[int(rng.integers(len(words)))]
+        if rng.random() < 0.8:
+            out += b" "
+    return bytes(out[:n])
+
+
+def test_row_lengths_around_the_block_edges(backend):
+    """Rows of 1 .. 2 049 bytes in an order that makes blocks end exactly at, just before and just behind 2 048 bytes."""
+    rng = np.random.default_rng(7)
+    lens = [1, 2, 31, 32, 33, 63, 64, 65, 1, 1, 1, 2047, 1, 2048, 2049, 1, 1024, 1024, 1023, 1025, 1000, 1048, 1, 2046, 2, 2045, 3, 1,
+            700, 700, 648, 700, 700, 649, 512, 512, 512, 512, 512, 512, 512, 511, 1, 3000, 5, 4096, 7]
+    lens = lens + [int(x) for x in rng.integers(1, 700, size=300 - len(lens))]
+    strings = [_filler(rng, n) for n in lens]
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), rows_of(strings), what="block edges")
+
+
+def test_rules_at_row_boundaries(backend):
+    """What the rules look at across a byte must not be looked at across a row boundary: trailing / leading white space,
+    an apostrophe at a row's end with contraction letters at the next row's start, contractions at a row's start, a space
+    in front of a row that begins with a letter, digits runs cut by a row end."""
+    ends = [b"abc ", b"abc  ", b"abc\n", b"abc \n ", b"abc'", b"abc 'l", b"abc'r", b"abc'", b"12", b"x 1", b"it'", b"!!", b"a\t", b" ", b"  ", b"'"]
+    starts = [b"s next", b"ll be", b"e there", b"t", b" x", b"  x", b"'s", b"'ll go", b"34", b"d", b"m", b"ve", b"re", b"!", b"\nq", b" "]
+    strings = []
+    for a in ends:
+        for s in starts:
+            strings.append(a)
+            strings.append(s)
+    strings = strings[:500]
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), rows_of(strings), what="row boundaries")
+
+
+def test_rows_left_to_the_generic_kernel(backend):
+    """Empty rows, rows longer than a block, rows with non-ASCII text and skipped rows between ordinary ones."""
+    rng = np.random.default_rng(11)
+    strings, skips = [], []
+    for i in range(360):
+        r = i % 12
+        if r == 3:
+            s = b""
+        elif r == 5:
+            s = _filler(rng, 2300 + i)
+        elif r == 7:
+            s = "naïve café über straße — ok".encode() + _filler(rng, 40)
+        elif r == 9:
+            s = _filler(rng, 20) + "日本語のテキスト".encode() + _filler(rng, 30)
+        else:
+            s = _filler(rng, int(rng.integers(1, 400)))
+        strings.append(s)
+        skips.append(1 if r == 10 else 0)
+    tok = BpeTok.load("gpt2_small")
+    fused_vs_oracle(backend, tok, rows_of(strings), what="mixed rows")
+    fused_vs_oracle(backend, tok, rows_of(strings), skips=np.asarray(skips, np.uint8), what="mixed rows with skips")
+
+
+def test_rows_that_are_not_contiguous(backend):
+    """begins / ends that leave gaps, overlap, or run backwards through the chars tensor: no block may span such a seam."""
+    rng = np.random.default_rng(13)
+    chars = np.frombuffer(_filler(rng, 60000), np.uint8).copy()
+    n = 300
+    b = np.zeros(n, np.int32)
+    e = np.zeros(n, np.int32)
+    at = 0
+    for i in range(n):
+        ln = int(rng.integers(1, 300))
+        kind = i % 5
+        if kind == 1:
+            at += int(rng.integers(1, 9))        # a gap
+        elif kind == 2:
+            at = max(0, at - int(rng.integers(1, 20)))   # overlaps the previous row
+        elif kind == 3 and i % 10 == 3:
+            at = int(rng.integers(0, 50000))     # somewhere else entirely
+        if at + ln > len(chars):
+            at = int(rng.integers(0, 1000))
+        b[i], e[i] = at, at + ln
+        at += ln
+    rb, re_ = ragged_rows(n)
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), [rb, re_, b, e, chars], what="seams")
+    # two strings per row here and there: never a span row
+    rb2 = np.arange(0, n, 2, dtype=np.int32)
+    re2 = rb2 + 2
+    re2[::7] -= 1
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), [rb2, np.minimum(re2, n).astype(np.int32), b, e, chars], what="two strings per row")
+
+
+def test_dense_piece_lists(backend):
+    """Every byte (or every other byte) a piece: 2 048 resp. 1 024 pieces in one block."""
+    strings = []
+    for i in range(280):
+        r = i % 4
+        if r == 0:
+            strings.append(b"a!" * 300)
+        elif r == 1:
+            strings.append(b" a" * 500)
+        elif r == 2:
+            strings.append(b"1,2;3.4" * 120)
+        else:
+            strings.append(b"!a" * 1024)
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), rows_of(strings), what="dense pieces")
+
+
+def test_miss_heavy_text(backend):
+    """Pieces the memo does not hold, many per round: the wave's LDS miss list is written out in the middle of a block;
+    pieces of 16 bytes and more (no key) among them."""
+    rng = np.random.default_rng(17)
+    alphabet = np.frombuffer(b"qzxjkvwpy", np.uint8)
+    strings = []
+    for i in range(300):
+        words = []
+        for _ in range(int(rng.integers(5, 60))):
+            words.append(bytes(alphabet[rng.integers(0, len(alphabet), size=int(rng.integers(3, 24)))]))
+        strings.append(b" ".join(words))
+    tok = BpeTok.load("gpt2_small")
+    fused_vs_oracle(backend, tok, rows_of(strings), what="misses")
+    tok.attrs = dict(tok.attrs, cache_capacity=0)   # no memo at all: every piece is a miss
+    fused_vs_oracle(backend, tok, rows_of(strings[:280]), what="no memo")
+
+
+def test_last_row_ends_the_chars_tensor(backend):
+    """The last block's lanes may not read past the end of the chars tensor (byte-wise loads there)."""
+    rng = np.random.default_rng(19)
+    for tail in (1, 5, 17, 31, 32, 33):
+        strings = [_filler(rng, int(rng.integers(1, 200))) for _ in range(299)] + [_filler(rng, tail)]
+        fused_vs_oracle(backend, BpeTok.load("gpt2_small"), rows_of(strings), what=f"tail {tail}")
+
+
+def test_contractions_at_every_lane_offset(backend):
+    """An apostrophe at every offset of a lane's 32 bytes -- the letters behind it, and the piece start behind those, may
+    belong to the next lane -- for every contraction, a near miss of each, and with the row ending inside the contraction."""
+    tails = [b"'s x", b"'t", b"'m.", b"'d1", b"'re ", b"'ve!", b"'ll", b"'l", b"'r", b"'v ", b"'S", b"'lL x", b"''s", b" 's", b"!'t", b"7'd", b"\t'm", b"'", b"'s's'll're"]
+    strings = []
+    for off in range(0, 67):
+        for i, t in enumerate(tails):
+            if (off + i) % 3 == 0:
+                strings.append(b"ab cd "[: off % 6] + b"x" * (off - off % 6) + t)
+    strings = strings[:500]
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), rows_of(strings), what="contractions")
+    fused_vs_oracle(backend, BpeTok.load("gpt2_small"), rows_of(strings), pattern=DIGITS_PATTERN, what="contractions, digits variant")

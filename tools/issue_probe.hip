@@ -67,6 +67,24 @@ __global__ __launch_bounds__(256) void probe(uint32_t* out, int iters, uint32_t 
         if (OP == 14)  // 64 v_mbcnt pairs (32 lo + 32 hi)
             asm volatile(REP16("v_mbcnt_lo_u32_b32 %0, %4, 0\n v_mbcnt_hi_u32_b32 %0, %5, %0\n v_mbcnt_lo_u32_b32 %1, %4, 0\n v_mbcnt_hi_u32_b32 %1, %5, %1\n")
                          : "+v"(a), "+v"(b) : "s"(uint32_t(s0)), "s"(uint32_t(s1)));
+
+        if (OP == 20) asm volatile(REP16("v_and_b32 %0, %0, %1\n v_and_b32 %1, %1, %2\n v_and_b32 %2, %2, %3\n v_and_b32 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 21) asm volatile(REP16("v_xor_b32 %0, %0, %1\n v_xor_b32 %1, %1, %2\n v_xor_b32 %2, %2, %3\n v_xor_b32 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 22) asm volatile(REP16("v_lshlrev_b32 %0, 3, %1\n v_lshlrev_b32 %1, 5, %2\n v_lshrrev_b32 %2, 3, %3\n v_lshrrev_b32 %3, 1, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 23) asm volatile(REP16("v_sub_u32 %0, %0, %1\n v_sub_u32 %1, %1, %2\n v_sub_u32 %2, %2, %3\n v_sub_u32 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 24) asm volatile(REP16("v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %0, vcc\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");
+        if (OP == 25) asm volatile(REP16("v_alignbit_b32 %0, %0, %1, 8\n v_alignbit_b32 %1, %1, %2, 8\n v_alignbit_b32 %2, %2, %3, 24\n v_alignbit_b32 %3, %3, %0, 8\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 26) asm volatile(REP16("v_and_or_b32 %0, %0, %1, %2\n v_and_or_b32 %1, %1, %2, %3\n v_and_or_b32 %2, %2, %3, %0\n v_and_or_b32 %3, %3, %0, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 27) asm volatile(REP16("v_or3_b32 %0, %0, %1, %2\n v_or3_b32 %1, %1, %2, %3\n v_or3_b32 %2, %2, %3, %0\n v_or3_b32 %3, %3, %0, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 28) asm volatile(REP16("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x36\n v_bitop3_b32 %1, %1, %2, %3 bitop3:0x36\n v_bitop3_b32 %2, %2, %3, %0 bitop3:0x36\n v_bitop3_b32 %3, %3, %0, %1 bitop3:0x36\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 29) asm volatile(REP16("v_mad_u32_u24 %0, %0, %1, %2\n v_mad_u32_u24 %1, %1, %2, %3\n v_mad_u32_u24 %2, %2, %3, %0\n v_mad_u32_u24 %3, %3, %0, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 30) asm volatile(REP16("v_add3_u32 %0, %0, %1, %2\n v_add3_u32 %1, %1, %2, %3\n v_add3_u32 %2, %2, %3, %0\n v_add3_u32 %3, %3, %0, %1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 31) asm volatile(REP16("v_cmp_lt_u32 vcc, %0, %1\n v_cmp_eq_u32 vcc, %1, %2\n v_cmp_lt_u32 vcc, %2, %3\n v_cmp_eq_u32 vcc, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "vcc");
+        if (OP == 32) asm volatile(REP16("v_add_u32 %0, 0x1f1f1f1f, %1\n v_add_u32 %1, 0x50505050, %2\n v_add_u32 %2, 0x77777777, %3\n v_add_u32 %3, 0x20202020, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 33) asm volatile(REP16("v_pk_add_u16 %0, %0, %1\n v_pk_add_u16 %1, %1, %2\n v_pk_add_u16 %2, %2, %3\n v_pk_add_u16 %3, %3, %0\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 34) asm volatile(REP16("v_dot4_u32_u8 %0, %1, %2, %0\n v_dot4_u32_u8 %1, %2, %3, %1\n v_dot4_u32_u8 %2, %3, %0, %2\n v_dot4_u32_u8 %3, %0, %1, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 35) asm volatile(REP16("v_add_u32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %1, %2, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %2, %3, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_u32_dpp %3, %0, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        if (OP == 36) asm volatile(REP16("v_ffbl_b32 %0, %1\n v_bcnt_u32_b32 %1, %2, %1\n v_ffbl_b32 %2, %3\n v_bcnt_u32_b32 %3, %0, %3\n") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ addr ^ uint32_t(s0) ^ uint32_t(s1);
 }
@@ -92,7 +110,7 @@ void run(const char* name, int waves_per_simd) {
 }
 
 int main() {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {4, 8}) {
         run<0>("64 v_add_u32 (4 chains)", w);
         run<7>("64 v_add_u32 (1 chain)", w);
         run<1>("64 SALU b64", w);
@@ -108,6 +126,23 @@ int main() {
         run<12>("32 v_readlane + 32 s_add", w);
         run<13>("64 v_bfe_u32", w);
         run<14>("64 v_mbcnt", w);
+        run<20>("64 v_and_b32", w);
+        run<21>("64 v_xor_b32", w);
+        run<22>("64 v_lshl/lshr_b32 imm", w);
+        run<23>("64 v_sub_u32", w);
+        run<24>("64 v_cndmask_b32", w);
+        run<25>("64 v_alignbit_b32", w);
+        run<26>("64 v_and_or_b32", w);
+        run<27>("64 v_or3_b32", w);
+        run<28>("64 v_bitop3_b32", w);
+        run<29>("64 v_mad_u32_u24", w);
+        run<30>("64 v_add3_u32", w);
+        run<31>("64 v_cmp -> vcc", w);
+        run<32>("64 v_add_u32 literal", w);
+        run<33>("64 v_pk_add_u16", w);
+        run<34>("64 v_dot4_u32_u8", w);
+        run<35>("64 v_add_u32_dpp", w);
+        run<36>("64 v_ffbl/v_bcnt", w);
     }
     return 0;
 }
