@@ -445,15 +445,17 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 emitted += int(tot >> 16);
             };
             // (two probes in turn, so that "the next one" never has to be copied into "this one")
-            SpanProbe qa = fetch(0), qb = qa;
-            for (int jb = 0; jb < np; jb += 2 * kWave) {
-                if (jb + kWave < np) qb = fetch(jb + kWave);
+            // (a fetch behind the list's end finds pieces of no bytes: inside the loop nothing is conditional, so that no wait for
+            // "a load that may still be on its way" ends up in front of the next fetch)
+            SpanProbe qa = fetch(0);
+            int jb = 0;
+            for (; jb + kWave < np; jb += 2 * kWave) {
+                const SpanProbe qb = fetch(jb + kWave);
                 resolve(qa, jb);
-                if (jb + kWave < np) {
-                    if (jb + 2 * kWave < np) qa = fetch(jb + 2 * kWave);
-                    resolve(qb, jb + kWave);
-                }
+                qa = fetch(jb + 2 * kWave);
+                resolve(qb, jb + kWave);
             }
+            if (jb < np) resolve(qa, jb);
             // ---- the rows' records: used = up to the next row's first entry, ids = the hits' ids in between
             {
                 const bool mine = l >= bi && l < bj;
