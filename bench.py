@@ -673,21 +673,24 @@ def cpu_one_core(wl, n_s):
     return ref, cdt, units, what, passes
 
 
-def cpu_all_cores(wl, seconds=8.0):
-    """Every host core on a contiguous row shard of batch 0, ONE tokenizer object shared by all threads (its piece cache
-    behind a shared_mutex as in the reference): what OpenVINO's THROUGHPUT streams do with one compiled tokenizer
-    (benchmark/benchmark.py:301-302).  The oracle calls release the GIL (ctypes)."""
+def cpu_all_cores(wl, seconds=8.0, threads=None, private=False):
+    """`threads` host threads (default: every host core), each on a contiguous row shard of batch 0.
+    private=False: ONE tokenizer object shared by all threads (its piece cache behind a shared_mutex as in the reference): what
+    OpenVINO's THROUGHPUT streams do with one compiled tokenizer (benchmark/benchmark.py:301-302).
+    private=True: a tokenizer -- tables and piece cache -- of its own per thread: what the same cores give when nothing is
+    shared (N independent processes).  The oracle calls release the GIL (ctypes)."""
     if not hasattr(wl, "cpu_chain"):
         return None
     chain, what = wl.cpu_chain()
     rb, re_, b, e, c = wl.batches.host[0]
-    threads = max(1, os.cpu_count() or 1)
+    threads = max(1, threads or os.cpu_count() or 1)
     rows = len(rb)
-    per = max(1, rows // threads)
+    per = max(1, min(rows // threads, 4096))   # (a shard of a few thousand rows per pass: the short legs still complete passes)
     threads = min(threads, rows // per)
     chain(rb[:1024], re_[:1024], b[:1024], e[:1024], c)  # warm cache
     done = [0] * threads
-    stop = time.perf_counter() + seconds
+    ready = threading.Barrier(threads + 1)
+    t_stop = [0.0]
 
     def work(t):
         # the thread's shard as a tensor of its own (rebased offsets, its slice of the chars): the op sizes its outputs by
@@ -698,22 +701,45 @@ def cpu_all_cores(wl, seconds=8.0):
         ret = (re_[lo:hi] - rb[lo]).astype(np.int32)
         bt, et, ct = (b[lo:hi] - c0).astype(np.int32), (e[lo:hi] - c0).astype(np.int32), c[c0:c1].copy()
         nbytes = c1 - c0
-        while time.perf_counter() < stop:
-            chain(rbt, ret, bt, et, ct)
+        mine = chain
+        if private:
+            mine, _ = wl.cpu_chain()
+            mine(rbt[:256], ret[:256], bt[:256], et[:256], ct)   # its own cache, warm
+        ready.wait()
+        while time.perf_counter() < t_stop[0]:
+            mine(rbt, ret, bt, et, ct)
             done[t] += nbytes
 
     ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
-    t0 = time.perf_counter()
     for t in ts:
         t.start()
+    t_stop[0] = time.perf_counter() + seconds + 3600.0
+    ready.wait()   # every thread has its shard (and, private, its tokenizer)
+    t0 = time.perf_counter()
+    t_stop[0] = t0 + seconds
     for t in ts:
         t.join()
     dt = time.perf_counter() - t0
+    how = ("a tokenizer and piece cache of its own per thread (nothing shared)" if private else
+           "ONE shared tokenizer as under OpenVINO's THROUGHPUT streams (the piece cache sits behind a std::shared_mutex taken per piece, "
+           "bpe_tokenizer.cpp:197-205: the reader lock's cache line is what the threads contend for)")
     return {"value": round(sum(done) / dt / 1e6, 2), "unit": "MB/s", "cores": threads, "kind": "port",
-            "sample": f"{threads} threads x {per} rows of batch 0 each, ONE shared tokenizer as under OpenVINO's THROUGHPUT streams (the piece "
-                      f"cache sits behind a std::shared_mutex taken per piece, bpe_tokenizer.cpp:197-205: the reader lock's cache line is "
-                      f"what the threads contend for), repeated for {dt:.1f} s ({sum(done)} bytes in all), {what}",
+            "sample": f"{threads} threads x {per} rows of batch 0 each, {how}, repeated for {dt:.1f} s ({sum(done)} bytes in all), {what}",
             "host_cpus": os.cpu_count()}
+
+
+def cpu_thread_curve(wl):
+    """The shared-tokenizer rate at 1 / 8 / 32 / 64 / all threads (3 s each): whether the flat all-cores figure is the lock or
+    the cores."""
+    if not hasattr(wl, "cpu_chain"):
+        return None
+    n = os.cpu_count() or 1
+    out = {}
+    for t in sorted({1, 8, 32, 64, n}):
+        if t <= n:
+            r = cpu_all_cores(wl, seconds=3.0, threads=t)
+            out[str(r["cores"])] = r["value"]
+    return {"unit": "MB/s", "shared_tokenizer_by_threads": out}
 
 
 def end_to_end_leg(wl, lib, dev, n_streams=4, steps=64, depth=3):
@@ -1058,6 +1084,7 @@ def main():
 
     # ---- parity spot-check + CPU baselines (oracle = "port" of the reference's algorithm) + extra legs, rank 0, N = 1
     cpu_baseline, cpu_all, parity, stress, e2e = None, None, None, None, None
+    cpu_all_private, cpu_curve = None, None
     if world == 1 and not args.no_cpu_baseline:
         n_s = wl.sample_rows
         ref, cdt, sample_units, what, passes = cpu_one_core(wl, n_s)
@@ -1080,6 +1107,8 @@ def main():
             if affinity0:
                 os.sched_setaffinity(0, affinity0)   # this leg uses every host core
             cpu_all = cpu_all_cores(wl)
+            cpu_all_private = cpu_all_cores(wl, seconds=6.0, private=True)
+            cpu_curve = cpu_thread_curve(wl)
     if world == 1 and not args.no_extras and args.config == "2" and args.text == "zipf" and not args.no_memo:
         stress = {}
         for name, kw in (("uniform_text", dict(kind="uniform")), ("no_memo", dict(kind="zipf", no_memo=True)),
@@ -1123,7 +1152,8 @@ def main():
                                                                     f"{'all-gather' if exchange.transport == 'allgather' else 'grouped direct send/recv'} of ragged ids over RCCL, {exchange.id_bytes}-byte ids on the wire, "
                                                                     f"{'written by the encode itself (compact_kernel), ' if to_wire else 'packed by shard_pack_kernel, '}"
                                                                     f"gather overlapped with the next encode, unpack one batch later ({exchange.regathers} re-gathers)"))},
-        "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all, "stress": stress, "end_to_end": e2e,
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all, "cpu_baseline_all_cores_private": cpu_all_private,
+        "cpu_baseline_thread_curve": cpu_curve, "stress": stress, "end_to_end": e2e,
         "parity_prefix_bit_exact": parity,
         "parity_per_chunk": (wl.parity_per_chunk() if hasattr(wl, "parity_per_chunk") and world == 1 and not args.no_cpu_baseline else None),
         "kernel_ms": kernels,

@@ -14,6 +14,12 @@ models, tests/tokenizers_test.py:563,728,795; hub models are not reachable offli
   golden_wordpiece_bert.npz   the full V = 30 522 `bert` tokenizer (BASELINE config 3) rebuilt as an HF WordPiece model from
         the committed vocabulary: strings -> ids.
 
+  golden_bpe_{gpt2,llama3}.npz   (round 4) the HEADLINE tokenizers -- V = 50 257 of BASELINE config 2, V = 128 256 of config 4 --
+        rebuilt as HF `models.BPE(vocab, merges)` + `Split(Regex(pattern), "isolated")` + ByteLevel from the committed
+        tok_gpt2.npz / tok_llama3.npz: 2 100 rows each of zipf / mixed-script / uniform text at the configurations' ~512 bytes
+        -> HF ids.  Pins the oracle (CPU tier) and the kernels (GPU tier) on the very tables bench.py measures with; the
+        reference's counterpart is tests/tokenizers_test.py:563 (hub models against HF).
+
 Run here (needs `tokenizers`); the .npz files are committed:    python -m tests.gen_golden_pins
 """
 import json
@@ -173,7 +179,42 @@ def main_wordpiece_full():
     print("bert", len(strings), "strings", len(ids), "ids")
 
 
+def main_headline_bpe():
+    from tokenizers import Regex
+    from tools.make_tokenizers import gpt2_char_to_byte
+    b2c = {b: c for c, b in gpt2_char_to_byte().items()}
+
+    def chars(raw: bytes) -> str:
+        return "".join(b2c[x] for x in raw)
+
+    for name in ("gpt2", "llama3"):
+        t = load_tokenizer(name)
+        vocab = {}
+        for i, tokb in enumerate(t["vocab"]):
+            vocab.setdefault(chars(tokb), i)
+        merges = [(chars(a), chars(b)) for a, b in t["merges"]]
+        tok = Tokenizer(models.BPE(vocab=vocab, merges=merges))
+        tok.pre_tokenizer = pre_tokenizers.Sequence([
+            pre_tokenizers.Split(Regex(t["pattern"]), behavior="isolated", invert=False),
+            pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+        strings = []
+        for kind, seed in (("zipf", 81), ("mixed", 82), ("uniform", 83)):
+            b, e, c = TextModel(seed, kind).batch(700, 512)
+            raw = c.tobytes()
+            strings += [raw[x:y] for x, y in zip(b.tolist(), e.tolist())]
+        rows = [tok.encode(s.decode("utf-8"), add_special_tokens=False).ids for s in strings]
+        sb, se, sc = pack(strings)
+        ib, ie, ids = _ragged(rows)
+        np.savez_compressed(G / f"golden_bpe_{name}.npz", begins=sb, ends=se, chars=sc, id_begins=ib, id_ends=ie, ids=ids.astype(np.int32),
+                            meta=_meta(tokenizer=f"tok_{name}.npz", what="models.BPE(vocab, merges) + Split(Regex(pattern), isolated) + "
+                                       "ByteLevel(use_regex=False); 700 rows each of TextModel(81,'zipf') / (82,'mixed') / (83,'uniform') at 512 bytes"))
+        print(name, len(strings), "strings ->", len(ids), "ids")
+
+
 if __name__ == "__main__":
+    main_headline_bpe()
+    if "--headline-only" in __import__("sys").argv:
+        raise SystemExit(0)
     main_detok()
     main_spbpe()
     main_wordpiece_full()
