@@ -924,6 +924,8 @@ class FusedDetokenizer:
         self.chunk_log = []   # (row_begin, row_end, capacity, bytes or None when it overflowed): how the batch was cut
         lo, pending_rows = 0, []   # pending_rows: re-cut chunks (row ranges) that go before the rest of the batch
 
+        forced_cap = {}   # (row_begin, row_end) -> capacity to launch it with (a single row that overflowed its estimate)
+
         def next_range():
             nonlocal lo
             if pending_rows:
@@ -940,6 +942,7 @@ class FusedDetokenizer:
             nonlocal n_launched
             a, b = r
             cap = int(min(chunk_chars, (b - a) * S * est * 1.12 + 4096))
+            cap = forced_cap.pop((a, b), cap)
             part = [ids[a:b]] + tail
             if m0.torch:
                 st = side[n_launched % len(side)]
@@ -972,8 +975,12 @@ class FusedDetokenizer:
             if rc == L.E_CAPACITY:
                 need = int(out.n_chars)
                 self.chunk_log.append((a, b, cap, None))
-                if b - a == 1 and cap >= chunk_chars:
-                    d._chk(rc)   # one row alone is beyond the chunk size: nothing to cut
+                if b - a == 1:
+                    if cap >= chunk_chars or need >= (1 << 31) - 1:
+                        d._chk(rc)   # one row alone is beyond the chunk size (or beyond int32 offsets): nothing to cut
+                    forced_cap[(a, b)] = chunk_chars   # once more, with all the room a chunk may have
+                    pending_rows[:0] = [(a, b)]
+                    return
                 # cut again: as many pieces as the reported need asks for (at least two); the estimate learns from it
                 if 0 < need < (1 << 31) - 1:
                     est = max(est, need / max((b - a) * S, 1))
@@ -999,25 +1006,31 @@ class FusedDetokenizer:
         # Chunks complete in launch order, so `done` is in row order as long as a re-cut chunk is relaunched before anything
         # behind it completes: on an overflow everything in flight behind it is completed first only AFTER its pieces --
         # simplest: drain the pipeline, relaunch the pieces, go on.
-        while True:
-            r = next_range()
-            if r is None and not inflight:
-                break
-            if r is not None:
-                inflight.append(launch(r))
-            while inflight and (len(inflight) > depth or r is None or not m0.torch):
-                item = inflight.pop(0)
-                before = len(pending_rows)
-                complete(item)
-                if len(pending_rows) > before and inflight:   # overflow: what was launched behind it is redone after its pieces
-                    redo = [it[0] for it in inflight]
-                    for it in inflight:
-                        if it[8] is not None:
-                            d._lib.ovtk_detokenize_finish(it[7], C.byref(it[6]))   # (result dropped)
-                    inflight.clear()
-                    pending_rows.extend(redo)
-                    pending_rows.sort()
+        def drop(items):   # calls in flight whose results are not wanted: finished all the same (the library owns them until then)
+            for it in items:
+                if it[8] is not None:
+                    d._lib.ovtk_detokenize_finish(it[7], C.byref(it[6]))
+            items.clear()
+
+        try:
+            while True:
+                r = next_range()
+                if r is None and not inflight:
                     break
+                if r is not None:
+                    inflight.append(launch(r))
+                while inflight and (len(inflight) > depth or r is None or not m0.torch):
+                    item = inflight.pop(0)
+                    before = len(pending_rows)
+                    complete(item)
+                    if len(pending_rows) > before and inflight:   # overflow: what was launched behind it is redone after its pieces
+                        redo = [it[0] for it in inflight]
+                        drop(inflight)
+                        pending_rows.extend(redo)
+                        pending_rows.sort()
+                        break
+        finally:
+            drop(inflight)   # (an error in the middle of the pipeline: nothing stays queued behind the caller's back)
         return len(done) if sink is not None else done
 
 

@@ -420,3 +420,44 @@ def test_encode_to_wire_exchange_rccl_one_rank(hip_lib):
                 assert np.array_equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+def _wire_worker_rccl(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from openvino_tokenizers_amd import _lib as L
+        q.put((rank,) + _wire_mode_run(L.load(), dev, rank, world, n_rows=3001, nbytes=200, n_batches=4))
+    except BaseException as exc:
+        q.put((rank, repr(exc), None, 0))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_encode_to_wire_exchange_rccl_two_ranks(hip_lib):
+    """The N > 1 path on real hardware, as far as this pool goes: TWO processes, one GPU each, RCCL over xGMI -- every rank's
+    fused encode writes its send wire (ovtk_encode_enqueue_wire), ShardExchange gathers, each rank's result equals the
+    one-process encode of the whole batch, through a pad that had to grow.  Skipped on a one-GPU box (the driver's 8-GPU node
+    runs it without a new round)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wire_worker_rccl, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert all(isinstance(r[1], list) for r in results), [r[1] for r in results]
+    for _, got, want, regathers in results:
+        assert len(got) == len(want) == 4 and regathers >= 1
+        for g, w in zip(got, want):
+            for a, b in zip(g, w):
+                assert np.array_equal(a, b)

@@ -173,6 +173,72 @@ def test_detokenize_full_size(hip_lib):
     assert np.array_equal(ofz[1], fused[1][:k].cpu().numpy()) and np.array_equal(obf[2][: int(ofz[1][-1])], fused[2][: int(ofz[1][-1])].cpu().numpy())
 
 
+def test_detokenize_config5_as_stated(hip_lib):
+    """BASELINE config 5 as stated: 1 048 576 x 2 048 token ids on one MI355X (8.6 GB of ids in, ~13 GB of text out), through
+    FusedDetokenizer.evaluate_chunked(sink=...) -- row chunks below 2^31 output bytes each (the reference counts chars in
+    int32, src/vocab_decoder.cpp:62-80), three HIP streams.  Per chunk: offsets ascending and gap-free from 0 to the chunk's
+    byte count; EVERY row's length = the sum of its tokens' lengths; byte checksums of the chunk's first and last 4 096 rows =
+    the sums over their tokens; the oracle chain bit for bit on the chunk's first 8 and last 2 rows."""
+    import torch
+    tok = BpeTok.load("gpt2")
+    rows, S, V = 1048576, 2048, len(tok.vocab)
+    pad = V - 1
+    g = torch.Generator(device="cuda")
+    g.manual_seed(55)
+    ids = torch.empty((rows, S), dtype=torch.int32, device="cuda")
+    for a in range(0, rows, 65536):   # (in slices: the int64 / float temporaries of the whole tensor would be 25 GB)
+        part = torch.randint(0, V - 1, (65536, S), dtype=torch.int64, device="cuda", generator=g)
+        part[torch.rand((65536, S), device="cuda", generator=g) < 0.01] = pad
+        ids[a:a + 65536] = part.to(torch.int32)
+        del part
+    vconst = list(pack_strings(tok.vocab))
+    lens = (vconst[1] - vconst[0]).astype(np.int64)
+    sums = np.add.reduceat(np.concatenate([vconst[2].astype(np.int64), [0]]), vconst[0].astype(np.int64)) * (lens > 0)
+    lens[pad] = 0
+    sums[pad] = 0
+    d_lens, d_sums = torch.as_tensor(lens, device="cuda"), torch.as_tensor(sums, device="cuda")
+    fused = FusedDetokenizer(VocabDecoder(skip_tokens=[pad], lib=hip_lib), byte_fallback=True)
+    seen = []
+
+    def row_sums(table, a, b):
+        out = torch.empty(b - a, dtype=torch.int64, device="cuda")
+        for x in range(a, b, 16384):
+            y = min(x + 16384, b)
+            out[x - a:y - a] = table[ids[x:y].long()].sum(dim=1)
+        return out
+
+    def check_bytes(cb, ce, cc, a, lo, hi):   # rows [lo, hi) of the chunk that starts at batch row a
+        c0, c1 = int(cb[lo]), int(ce[hi - 1])
+        csum = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(cc[c0:c1].to(torch.int64), 0)])
+        got = csum[(ce[lo:hi].long() - c0)] - csum[(cb[lo:hi].long() - c0)]
+        assert torch.equal(got, row_sums(d_sums, a + lo, a + hi)), f"byte checksums differ in rows {a + lo}..{a + hi}"
+
+    def oracle_rows(cb, ce, cc, a, lo, hi):
+        o = O.vocab_decoder(ids[a + lo:a + hi].cpu().numpy(), tok.vocab, [pad])
+        obf = O.byte_fallback(*o[2:5])
+        ofz = O.fuze(o[0], o[1], obf[0], obf[1])
+        c0 = int(cb[lo])
+        assert np.array_equal(ofz[1] - ofz[0], (ce[lo:hi] - cb[lo:hi]).cpu().numpy())
+        assert np.array_equal(obf[2][int(ofz[0][0]):int(ofz[1][-1])], cc[c0:int(ce[hi - 1])].cpu().numpy()), f"chunk at row {a}: oracle differs"
+
+    def sink(a, b, cb, ce, cc):
+        n = b - a
+        assert int(cb[0]) == 0 and int(ce[-1]) == cc.numel() and cc.numel() <= (1 << 31) - 2
+        assert torch.equal(cb[1:], ce[:-1]), "offsets are not gap-free"
+        assert torch.equal((ce - cb).long(), row_sums(d_lens, a, b)), f"row lengths differ in chunk {a}..{b}"
+        k = min(4096, n)
+        check_bytes(cb, ce, cc, a, 0, k)
+        check_bytes(cb, ce, cc, a, n - k, n)
+        oracle_rows(cb, ce, cc, a, 0, min(8, n))
+        oracle_rows(cb, ce, cc, a, max(n - 2, 0), n)
+        seen.append((a, b, cc.numel()))
+
+    n_chunks = fused.evaluate_chunked([ids] + vconst, sink=sink)
+    assert n_chunks == len(seen) and n_chunks >= 6
+    assert seen[0][0] == 0 and seen[-1][1] == rows and all(x[1] == y[0] for x, y in zip(seen, seen[1:])), "chunks do not tile the batch"
+    assert sum(x[2] for x in seen) > 8 * (1 << 30)
+
+
 @pytest.mark.parametrize("rows", [300000, 420000])
 def test_many_short_rows(hip_lib, rows):
     """300 000 rows (more than the folded tail of merge_kernel takes: the separate exact / count_scan launches run; 49
