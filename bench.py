@@ -152,8 +152,11 @@ class EncodeWorkload:
 
 
 class BpeEncode(EncodeWorkload):
-    def __init__(self, args, lib, dev, rank, tokenizer, kind, rows, nbytes, seed0, no_memo=False, n_batches=None, cache_capacity=None):
+    def __init__(self, args, lib, dev, rank, tokenizer, kind, rows, nbytes, seed0, no_memo=False, n_batches=None, cache_capacity=None,
+                 pattern=None):
         self.tok = BpeTok.load(tokenizer)
+        if pattern:   # the same tables behind another model's split pattern (tools/workloads.py MODEL_PATTERNS)
+            self.tok.pattern = pattern
         model = TextModel(1234, kind)
         nb = n_batches or args.batches
         super().__init__(lib, dev, TextBatches(model, rows, nbytes, [seed0 + 100 * rank + 7 * j for j in range(nb)], dev))
@@ -244,7 +247,9 @@ def make_workload(args, lib, dev, rank):
     """-> (workload object or dict, description pieces)."""
     cfg = args.config
     if cfg == "2":
+        from tools.workloads import MODEL_PATTERNS
         w = BpeEncode(args, lib, dev, rank, args.tokenizer, args.text, args.rows, args.bytes, 1000, no_memo=args.no_memo,
+                      pattern=MODEL_PATTERNS.get(args.pattern),
                       cache_capacity=getattr(args, "cache_capacity", None))
         w.metric = "input MB/s encoded (GPT-2 BPE, 512-byte strings)"
         w.dominant_hint = "lookup_ascii"
@@ -256,7 +261,8 @@ def make_workload(args, lib, dev, rank):
         return w
     if cfg == "4":
         rows = args.rows if args.rows != 65536 else 131072  # 1 M rows / 8 GPUs
-        w = BpeEncode(args, lib, dev, rank, "llama3", "mixed", rows, args.bytes, 4000)
+        from tools.workloads import MODEL_PATTERNS
+        w = BpeEncode(args, lib, dev, rank, "llama3", "mixed", rows, args.bytes, 4000, pattern=MODEL_PATTERNS.get(args.pattern))
         w.metric = "input MB/s encoded (Llama-3 BPE, 512-byte mixed-script strings)"
         w.dominant_hint = "lookup_fused"
         w.workload = (f"config 4 shard: Llama-3-shaped byte-level BPE (V=128256, 127999 merges, trained in-process), {rows} x "
@@ -847,6 +853,8 @@ def main():
     ap.add_argument("--batches", type=int, default=8, help="distinct input batches rotated through the timed loop")
     ap.add_argument("--text", default="zipf", choices=["zipf", "uniform", "mixed"])
     ap.add_argument("--tokenizer", default="gpt2")
+    ap.add_argument("--pattern", default=None, choices=["qwen2", "cl100k", "o200k", "deepseek-v3"],
+                    help="configs 2 / 4: run the tokenizer's tables behind this model's split pattern instead of its own")
     ap.add_argument("--no-memo", action="store_true", help="config 2: BPETokenizer with cache_capacity=0 (no piece memo)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the all-gather (rank-local consumer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

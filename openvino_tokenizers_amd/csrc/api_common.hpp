@@ -281,6 +281,9 @@ public:
     void enable_small() { small_ok_ = true; }
     // Called with the status block of the attempt that completed the run (finish(), the caller's thread).
     void on_status(std::function<void(const RunStatus&)> f) { on_status_ = std::move(f); }
+    // Kernels of another workspace run in front of this run's on the same stream (a split into device buffers): once this
+    // run's event has completed, so have they.
+    void also_settles(std::shared_ptr<WorkspaceLease> other) { other_ = std::move(other); }
     void enable_stage16() { stage16_ = true; }   // the middle's kernels write / read the staging entries as u16 (EncodeWork::stage16)
     // The result leaves in the row-shard exchange's wire form (device memory) instead of begins / ends / ids.
     void output_to_wire(const WireSink& wire) {
@@ -330,6 +333,10 @@ public:
             OVTK_HIP(hipEventSynchronize(ws_->done));
             ws_->marks.settled();
             Profiler::get().resolve(ws_->marks);
+            if (other_) {
+                other_->ws->marks.settled();
+                Profiler::get().resolve(other_->ws->marks);
+            }
             OVTK_HIP(hipGetLastError());
             const RunStatus& st = *ws_->host_status;
             if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
@@ -465,6 +472,7 @@ private:
     int mem_, in_mem_;
     bool direct_out_ = false;      // host-memory call whose output buffers are pinned: the kernels write them (no D2H copy)
     std::shared_ptr<void> keep_;
+    std::shared_ptr<WorkspaceLease> other_;
     hipStream_t s_;
     Middle middle_;
     bool self_alloc_;

@@ -27,6 +27,14 @@ const char kGpt2DigitsPattern[] = "'s|'t|'re|'ve|'m|'ll|'d| ?\\p{L}+|\\p{N}| ?[^
 // the split pattern of Llama-3's tokenizer.json (tiktoken cl100k family); reaches RegexSplit through hf_parser's Split step
 const char kLlama3Pattern[] =
     "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}{1,3}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+// two more of that family (what separates them from Llama-3's: SplitDev::l3_digits1 / l3_tail_ws): Qwen2's tokenizer.json,
+// and cl100k_base as tiktoken writes it (possessive quantifiers -- which change nothing where the repeated class and what
+// follows it are disjoint, as in every place here --, `\s++$`, and `\s*[\r\n]` for `\s*[\r\n]+`: the greedy `\s*` in front leaves
+// both at the run's last line break)
+const char kQwen2Pattern[] =
+    "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+const char kCl100kPattern[] =
+    "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}++|\\p{N}{1,3}+| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*+|\\s++$|\\s*[\\r\\n]|\\s+(?!\\S)|\\s+";
 // tokenizer_pipeline.py:392-426 (bert_whitespace_splitter / bert_keep_delimeters_splitter)
 const char kBertWhitespacePattern[] = "\\s+";
 const char kBertDelimitersPattern[] =
@@ -232,6 +240,8 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
     if (eff == kGpt2Pattern && h->mode == 1) h->dev.kind = kSplitGpt2;
     else if (eff == kGpt2DigitsPattern && h->mode == 1) h->dev.kind = kSplitGpt2Digits;
     else if (eff == kLlama3Pattern && h->mode == 1) h->dev.kind = kSplitLlama3;
+    else if (eff == kQwen2Pattern && h->mode == 1) { h->dev.kind = kSplitLlama3; h->dev.l3_digits1 = 1; }
+    else if (eff == kCl100kPattern && h->mode == 1) { h->dev.kind = kSplitLlama3; h->dev.l3_tail_ws = 1; }
     else if (eff == kBertWhitespacePattern && h->mode <= 1) h->dev.kind = kSplitWhitespace;
     else if (eff == kBertDelimitersPattern && h->mode <= 1) h->dev.kind = kSplitBertPunct;
     if (h->dev.kind >= kSplitWhitespace && h->dev.kind != kSplitGeneral)
@@ -265,6 +275,7 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
         r.sym_eot = prog.sym_eot;
         r.sym_final_nl = prog.sym_final_nl;
         r.n_ctx = prog.n_ctx;
+        r.cp_blocks_bytes = int32_t(prog.cp_blocks.size());
         std::memcpy(r.start, prog.start, sizeof r.start);
         r.mode = h->mode;
         r.invert = h->invert ? 1 : 0;
@@ -532,8 +543,28 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
         e = e ? e : sw.gen[3].ensure(size_t(cap) * 4);
         if (e) return e;
         int64_t n_pieces = 0;
-        if (int rc = split_on_device(split, sw, d_in, s, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(), sw.gen[2].as<int32_t>(),
-                                     sw.gen[3].as<int32_t>(), nullptr, cap, &n_pieces))
+        if (split->dev.kind == kSplitGeneral) {
+            // the compiled DFA in one pass: every row's pieces in a region of its own inside the buffers of the reference's
+            // capacity, the ragged begins / ends pointing there -- nothing is counted, the host does not wait (regex_device.hpp)
+            if (int rc = sw.status.ensure(sizeof(RunStatus))) return rc;
+            OVTK_HIP(hipMemsetAsync(sw.status.as<void>(), 0, sizeof(RunStatus), s));
+            const int lane_grid = (d_in.n_rows + kBlockThreads - 1) / kBlockThreads;
+            const RegexSparseLds lay = regex_sparse_layout(split->regex.n_states * split->regex.n_syms, split->regex.cp_blocks_bytes);
+            note_launch(sw.marks, s);
+            Profiler& pf = Profiler::get();
+            if (pf.enabled()) pf.begin("regex_split", s, sw.marks);
+            if (split->mode == 1 && split->max_splits == -1)
+                hipLaunchKernelGGL(regex_sparse_kernel<true>, dim3(lane_grid), dim3(kBlockThreads), size_t(lay.total), s, d_in, split->regex,
+                                   &sw.status.as<RunStatus>()->n_out, (long long)cap, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
+                                   sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>());
+            else
+                hipLaunchKernelGGL(regex_sparse_kernel<false>, dim3(lane_grid), dim3(kBlockThreads), size_t(lay.total), s, d_in, split->regex,
+                                   &sw.status.as<RunStatus>()->n_out, (long long)cap, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
+                                   sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>());
+            if (pf.enabled()) pf.end(s, sw.marks);
+            n_pieces = cap;   // (the offsets index the whole buffers)
+        } else if (int rc = split_on_device(split, sw, d_in, s, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(), sw.gen[2].as<int32_t>(),
+                                            sw.gen[3].as<int32_t>(), nullptr, cap, &n_pieces))
             return rc;
         pieces = ovtk_ragged_strings{sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(), in->n_rows,
                                      ovtk_strings{sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>(), d_in.chars, n_pieces,
@@ -652,6 +683,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (pieces_ws) {
+        r->also_settles(pieces_ws);
         r->input_on_device(std::make_shared<std::pair<std::shared_ptr<void>, std::shared_ptr<void>>>(pieces_ws, device_inputs));
     } else if (device_inputs) {
         r->input_on_device(device_inputs);

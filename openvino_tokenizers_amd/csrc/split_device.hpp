@@ -54,6 +54,10 @@ struct SplitDev {
     const uint16_t* uc_index;  // [0x110000 >> 7]
     const uint8_t* uc_blocks;  // [n_blocks * 64]
     int32_t drop;              // class patterns: 0 keep every piece, 1 drop the matches, 2 drop the gaps
+    // kSplitLlama3: what separates the patterns of its family from Llama-3's own (api_encode.cpp picks them by pattern text)
+    int32_t l3_digits1;        // 1: `\p{N}` -- every digit a piece (Qwen2) -- instead of `\p{N}{1,3}`
+    int32_t l3_tail_ws;        // 1: `\s++$` in front of the white-space alternatives (tiktoken's cl100k_base): the white-space run
+                               //    that ends the string is ONE piece, line breaks inside it or not
 };
 constexpr uint16_t kPieceDropped = 0x8000;  // flag in WaveScratch::pstart: the piece is not emitted
 constexpr uint16_t kPiecePosMask = 0x7FFF;
@@ -164,7 +168,7 @@ __device__ __forceinline__ int llama3_match_end(const SplitDev& sp, const uint8_
     // \p{N}{1,3}
     if (c0.cls == kClsN) {
         int q = p + c0.len;
-        for (int k = 1; k < 3 && q < slen; ++k) {
+        for (int k = 1; k < (sp.l3_digits1 ? 1 : 3) && q < slen; ++k) {
             const SeqChar c = seq_char(sp, s, q, slen);
             if (c.cls != kClsN) break;
             q += c.len;
@@ -196,6 +200,7 @@ __device__ __forceinline__ int llama3_match_end(const SplitDev& sp, const uint8_
         e += c.len;
         if (is_line_break(c.cp)) after_last_break = e;
     }
+    if (sp.l3_tail_ws && e == slen) return e;   // \s++$ (tried before \s*[\r\n])
     if (after_last_break >= 0) return after_last_break;
     if (e == slen) return e;
     if (last_char > p) return last_char;
@@ -427,7 +432,9 @@ __device__ __forceinline__ Mask llama3_start_mask(const WaveScratch& ws, const S
             if (l == w) F = f;
         }
     }
-    if (any_n) {
+    if (any_n && sp.l3_digits1) {
+        G = mN;   // `\p{N}`: every digit starts a piece
+    } else if (any_n) {
         int k_prev = 0;  // digits in the last group of the previous word when its run reaches the word's end, else 0
         for (int w = 0; w < nwords; ++w) {
             const Mask Nw = readlane_mask(mNd, w), Sw = readlane_mask(seedN, w);
@@ -478,7 +485,21 @@ __device__ __forceinline__ Mask llama3_start_mask(const WaveScratch& ws, const S
     const Mask supW = sW & pO & mNL;
     const Mask endNL = mNL & ~mask_from_after<1>(mNL);
     const Mask b_abs = mask_from_before<1>(F & endNL) & mW;                // behind the line breaks an O piece took
-    const Mask b_ln = mask_from_before<1>(mNL & ~mask_from_after<1>(D)) & mW;  // behind the run's last line break
+    Mask b_ln = mask_from_before<1>(mNL & ~mask_from_after<1>(D)) & mW;  // behind the run's last line break
+    if (sp.l3_tail_ws && at_end && any_nl) {
+        // `\s++$`: the run that ends the string is not cut behind its last line break.  T = the white-space bytes from which the
+        // string's end is reached through white space only (a ripple down from the last byte)
+        Mask T = 0;
+        bool c = false;
+        const int v = wlen - 1;
+        for (int w = nwords - 1; w >= 0; --w) {
+            const Mask Ww = readlane_mask(mW, w);
+            const Mask seed = (w == (v >> 6)) ? ((1ull << (v & 63)) & Ww) : 0ull;
+            const Mask r = __brevll(ripple_up(__brevll(Ww), __brevll(seed), c));
+            if (l == w) T = r;
+        }
+        b_ln &= ~T;
+    }
     const Mask last_w = to_lead(endW & mask_from_after<1>(mV), mCONT);     // last char of a W run that is followed by a char
     const Mask b_last = last_w & mW & ~mNL & pW & ~pNL;
     const Mask b_con = mask_from_before<2>(fire1) | mask_from_before<3>(fire2);
@@ -869,7 +890,10 @@ __device__ __forceinline__ bool llama3_packed_starts(WS& ws, const SplitDev& sp,
     for (int a = 0; a < M; ++a) G[a] = FE[a] = LN[a] = 0;
     bool far = false;
     const bool any_n = __ballot(nd_any != 0) != 0, any_nl = __ballot(nl_any != 0) != 0;
-    if (any_n) {
+    if (any_n && sp.l3_digits1) {
+#pragma unroll
+        for (int a = 2; a <= AL; ++a) G[a] = N[a];   // `\p{N}`: every digit starts a piece
+    } else if (any_n) {
 #pragma unroll
         for (int a = 2; a <= AL; ++a) {
             const uint32_t n1 = l3_bk<1>(Nd, a), n2 = l3_bk<2>(Nd, a), n3 = l3_bk<3>(Nd, a), n4 = l3_bk<4>(Nd, a), n5 = l3_bk<5>(Nd, a),
@@ -949,6 +973,8 @@ __device__ __forceinline__ bool llama3_packed_starts(WS& ws, const SplitDev& sp,
     }
     uint32_t flags = 0;
     uint32_t nonw = 0;
+    uint32_t ln_only = 0;   // l3_tail_ws: starts that exist for no other reason than "behind the run's last line break"
+    const bool tail_ws = sp.l3_tail_ws && at_end && any_nl;
 #pragma unroll
     for (int a = 2; a <= AL; ++a) {
         const uint32_t pL = l3_bk<1>(L, a), pW = l3_bk<1>(W, a), pO = l3_bk<1>(O, a), pSP = l3_bk<1>(SP, a), pNL = l3_bk<1>(NL, a);
@@ -967,11 +993,29 @@ __device__ __forceinline__ bool llama3_packed_starts(WS& ws, const SplitDev& sp,
         const uint32_t last_w = ~CT[a] & (ew0 | (c1 & ew1) | (c2 & ew2) | (c3 & ew3));
         const uint32_t b_last = last_w & W[a] & ~NL[a] & pW & ~pNL;
         const uint32_t b_con = ((f1[a] << 16) | (f1[a - 1] >> 16)) | ((f2[a] << 24) | (f2[a - 1] >> 8));
-        const uint32_t st = ((sL & ~supL) | G[a] | (sO[a] & ~supO) | (sW & ~supW) | b_abs | b_ln | b_last | b_con) & V[a] & ~CT[a];
+        const uint32_t st_else = ((sL & ~supL) | G[a] | (sO[a] & ~supO) | (sW & ~supW) | b_abs | b_last | b_con) & V[a] & ~CT[a];
+        const uint32_t st = st_else | (b_ln & V[a] & ~CT[a]);
         const uint32_t t = st >> 7;
         flags |= ((t | (t >> 7) | (t >> 14) | (t >> 21)) & 0xFu) << (4 * (a - 2));
+        if (tail_ws) {
+            const uint32_t q = (st & ~st_else) >> 7;
+            ln_only |= ((q | (q >> 7) | (q >> 14) | (q >> 21)) & 0xFu) << (4 * (a - 2));
+        }
         const uint32_t u = (V[a] & ~W[a]) >> 7;
         nonw |= ((u | (u >> 7) | (u >> 14) | (u >> 21)) & 0xFu) << (4 * (a - 2));
+    }
+    if (tail_ws) {
+        // `\s++$`: the white-space run that ends the string is one piece -- no start behind its last line break
+        const unsigned long long nwl = __ballot(nonw != 0);
+        int nonw_end = 0;  // window position behind the last byte that is not white space
+        if (nwl) {
+            const int hl = 63 - __clzll(nwl);
+            nonw_end = hl * LBy + (32 - __clz(wave_readlane(int(nonw), hl)));
+        }
+        int k0 = nonw_end - LBy * l;   // the lane's bytes from k0 on belong to that run
+        k0 = k0 < 0 ? 0 : (k0 > LBy ? LBy : k0);
+        const uint32_t run = k0 >= 32 ? 0u : ~((1u << k0) - 1u);
+        flags &= ~(ln_only & run);
     }
     // ---- how far the window decides (llama3_start_mask's rule)
     undecided = 0x7FFFFFFF;

@@ -166,7 +166,7 @@ def test_rows_with_several_strings_and_skips(backend):
         assert_same(ref[:4] + [ref[5]], list(got[:4]) + [got[5]], backend.host, pat)
 
 
-@pytest.mark.parametrize("name", ["qwen2", "cl100k-tiktoken"])
+@pytest.mark.parametrize("name", ["qwen2", "cl100k-tiktoken", "o200k", "deepseek-v3", "clip"])
 def test_fused_encode_with_compiled_pattern(backend, name):
     """ovtk_encode_run with a pattern that has no scanner: RegexSplit (DFA) -> BPETokenizer inside one call = the oracle
     chain."""
@@ -181,3 +181,69 @@ def test_fused_encode_with_compiled_pattern(backend, name):
     fused = FusedSplitBPE(RegexSplit(beh, lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
     got = fused.evaluate(backend.data([rb, re_, b, e, c]) + [np.frombuffer(pat.encode(), np.uint8)], tok.consts)
     assert_same(ref, got, backend.host, "fused with compiled pattern")
+
+
+@pytest.mark.parametrize("name", ["qwen2", "cl100k-tiktoken"])
+def test_llama3_family_fused(backend, name):
+    """Qwen2's and tiktoken-cl100k's patterns run on the Llama-3 scanners (SplitDev::l3_digits1 / l3_tail_ws), not on the DFA:
+    the fused encode on batches that take lookup_rows_kernel<kRowsLlama3> (> 256 rows) and on the one-launch small-batch kernel,
+    text with digit runs of every length and white-space runs with line breaks at the strings' ends -- where the patterns part
+    from Llama-3's own -- against PCRE2 + the BPE oracle."""
+    from tools.workloads import TextModel, ragged_rows
+    pat = MODEL_PATTERNS[name]
+    tok = BpeTok.load("llama3_small")
+    rng = np.random.default_rng(23)
+    tails = ["", " ", "  ", "\n", " \n", "\n ", " \n  ", "\n\n", " \r\n \n", "\t\n\t", "!\n  ", "!\n\n", "x \n", "1\n 2", "  \n\n  \n ", "é \n ", " \n é"]
+    nums = ["1", "12", "123", "1234", "12345", "1234567", "123456789", "1234567890123", "١٢٣", "7x8", "3.14", "1,000,000"]
+    b, e, c = TextModel(31, "mixed").batch(300, 120)
+    raw = c.tobytes()
+    strings = []
+    for i in range(300):
+        s = raw[b[i]:e[i]].decode("utf-8", "ignore")
+        k = int(rng.integers(0, len(s) + 1))
+        strings.append(s[:k] + " " + nums[i % len(nums)] + s[k:] + tails[i % len(tails)])
+    inputs = one_string_per_row(strings)
+    ref = tok.oracle()(*O.RegexSplit(pat, "isolate")(*[np.asarray(x) for x in inputs])[:5])
+    pu8 = np.frombuffer(pat.encode(), np.uint8)
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    assert_same(ref, fused.evaluate(backend.data(inputs) + [pu8], tok.consts), backend.host, f"{name}: 300 rows")
+    small = one_string_per_row(strings[:40])
+    ref2 = tok.oracle()(*O.RegexSplit(pat, "isolate")(*[np.asarray(x) for x in small])[:5])
+    assert_same(ref2, fused.evaluate(backend.data(small) + [pu8], tok.consts), backend.host, f"{name}: 40 rows")
+
+
+@pytest.mark.parametrize("behaviour,invert,max_splits", [("remove", False, -1), ("remove", True, -1), ("isolate", True, 3), ("isolate", False, 1),
+                                                         ("mergedwithprevious", False, -1), ("mergedwithnext", True, -1),
+                                                         ("mergedwithnext", False, 2), ("contiguous", False, -1)])
+def test_fused_encode_one_pass_split(backend, behaviour, invert, max_splits):
+    """The one-pass form of the compiled split inside the fused encode (regex_sparse_kernel: every row's pieces in a region of
+    its own, no count pass, no host wait): every behaviour, invert, max_splits, rows of zero / one / several strings in any
+    order, skipped strings, empty strings -- against RegexSplit (PCRE2) -> BPETokenizer of the oracle."""
+    tok = BpeTok.load("gpt2_small")
+    rng = np.random.default_rng(29)
+    words = ["hello", "World", "it's", "12345", " ", "  ", "\n", "x", "camelCaseWord", "HTTPServer", "naïve", "日本語", "!?", "a1b2", "'ll", "", "tail\n"]
+    strs = ["".join(rng.choice(words, size=int(k))) + (" " if k % 3 == 0 else "") for k in rng.integers(0, 9, size=90)]
+    b, e, c = O.pack_strings(strs)
+    order = rng.permutation(len(strs))
+    b, e = b[order], e[order]
+    cuts = np.sort(rng.integers(0, len(strs) + 1, size=39))
+    rb = np.concatenate([[0], cuts]).astype(np.int32)
+    re_ = np.concatenate([cuts, [len(strs)]]).astype(np.int32)
+    skips = (rng.random(len(strs)) < 0.15).astype(np.uint8)
+    for pat in (O200K, r"\w+|[^\w\s]+", DEEPSEEK_V3):
+        ref_pat = REF_PATTERN.get(pat, pat)
+        for sk in (None, skips):
+            sp = O.RegexSplit(ref_pat, behaviour, invert, max_splits)(rb, re_, b, e, c, skips=sk)
+            fused = FusedSplitBPE(RegexSplit(behaviour, invert, max_splits, lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+            ins = backend.data([rb, re_, b, e, c] + ([sk] if sk is not None else []))
+            try:
+                ref = tok.oracle()(*sp[:5])
+            except O.OracleError:
+                # max_splits stretches a piece to the string's end and goes on splitting behind it: the pieces overlap, and their
+                # ids can outgrow the buffer BPETokenizer sizes by the chars tensor (bpe_tokenizer.cpp:135,156) -- an error there too
+                with pytest.raises(L.OvtkError) as ei:
+                    fused.evaluate(ins + [np.frombuffer(pat.encode(), np.uint8)], tok.consts)
+                assert ei.value.code == L.E_CAPACITY
+                continue
+            got = fused.evaluate(ins + [np.frombuffer(pat.encode(), np.uint8)], tok.consts)
+            assert_same(ref, got, backend.host, f"{behaviour} invert={invert} max_splits={max_splits} skips={sk is not None} {pat[:20]}")

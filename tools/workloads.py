@@ -186,3 +186,16 @@ def ragged_rows(n_rows: int):
     """ragged_begins/ends for one string per row (tokenizer_pipeline.py:1668-1676)."""
     r = np.arange(n_rows + 1, dtype=np.int32)
     return r[:-1].copy(), r[1:].copy()
+
+
+# Split patterns of current tokenizer.json files (the tables of a shaped tokenizer can be run behind any of them: bench.py --pattern).
+MODEL_PATTERNS = {
+    "cl100k": (r"'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}++|\p{N}{1,3}+| ?[^\s\p{L}\p{N}]++[\r\n]*+|\s++$|\s*[\r\n]|"
+               r"\s+(?!\S)|\s+"),
+    "qwen2": r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+",
+    "o200k": (r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?|"
+              r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?|\p{N}{1,3}|"
+              r" ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+"),
+    "deepseek-v3": (r"""[!"#$%&'()*+,\-./:;<=>?@\[\\\]^_`{|}~][A-Za-z]+|[^\r\n\p{L}\p{P}\p{S}]?[\p{L}\p{M}]+| ?[\p{P}\p{S}]+[\r\n]*|"""
+                    r"\s*[\r\n]+|\s+(?!\S)|\s+"),
+}
