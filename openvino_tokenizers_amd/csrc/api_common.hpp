@@ -199,14 +199,22 @@ template <class Kernel>
 inline int resident_blocks_per_cu(Kernel kernel, int cap = 6) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kBlockThreads, 0) != hipSuccess || n <= 0) n = 4;
-    static const int env_cap = [] { const char* e = std::getenv("OVTK_BLOCKS_PER_CU"); return e ? std::atoi(e) : 0; }();
-    if (env_cap > 0) cap = std::min(cap, env_cap);   // experiments only
     return std::min(n, cap);
 }
 inline int grid_rows(int device, int n_rows, int blocks_per_cu) {
     return std::max(1, std::min((n_rows + kWavesPerBlock - 1) / kWavesPerBlock, device_cu_count(device) * blocks_per_cu));
 }
 inline int grid_lookup(int device, int n_rows) { return grid_rows(device, n_rows, 6); }
+// Grid of the kernels whose waves own CONSECUTIVE rows (lookup_span_kernel, lookup_rows_kernel): the persistent grid with
+// ceil(n_rows / waves) rows per wave -- or, where that would be more than the 64 a wave's lanes can hold headers for (hundreds of
+// thousands of short rows), 64 rows per wave and as many blocks as that takes: the surplus runs as later rounds.
+inline int rows_grid(int n_rows, int persistent_grid, int32_t& rows_per_wave) {
+    const int waves = persistent_grid * kWavesPerBlock;
+    rows_per_wave = (n_rows + waves - 1) / waves;
+    if (rows_per_wave <= kWave) return persistent_grid;
+    rows_per_wave = kWave;
+    return (n_rows + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
+}
 // Blocks per shard of the kernels that work through the deferred list (merge_kernel, wordpiece_deferred_kernel): the
 // resident number, but no more than the list can give work to -- a piece has at least one byte, a wave takes 64 pieces.
 // Every block draws a "last block done" ticket from one counter (~90 atomics per microsecond on one address), so a
@@ -285,6 +293,10 @@ public:
     // run's event has completed, so have they.
     void also_settles(std::shared_ptr<WorkspaceLease> other) { other_ = std::move(other); }
     void enable_stage16() { stage16_ = true; }   // the middle's kernels write / read the staging entries as u16 (EncodeWork::stage16)
+    // The middle's first kernel takes staging for ALL its rows before it knows which of them it will leave to the kernel behind it
+    // (lookup_span_kernel: one reservation per wave), and that kernel takes its own: room for both, or every call with left-over
+    // rows would overflow, grow and run twice.
+    void stage_twice() { stage_twice_ = true; }
     // The result leaves in the row-shard exchange's wire form (device memory) instead of begins / ends / ids.
     void output_to_wire(const WireSink& wire) {
         wire_ = wire;
@@ -321,6 +333,7 @@ public:
         }
         grid_ = grid_rows(device_, n_rows_, blocks_per_cu_);
         n_tiles_ = (n_rows_ + kRowTile - 1) / kRowTile;
+        if (stage_twice_) stage_cap_ = std::min<int64_t>(stage_cap_ * 2, INT32_MAX - 1);
         if (self_alloc_)  // every wave may leave one chunk partly unused
             stage_cap_ = std::min<int64_t>(stage_cap_ + int64_t(grid_ * kWavesPerBlock + kShards) * kStageChunk, INT32_MAX - 1);
         small_ = small_ok_ && self_alloc_ && fold_tail_ && n_rows_ <= kSmallRows && in_.strings.n_chars <= kSmallChars;
@@ -480,7 +493,7 @@ private:
     WorkspaceLease ws_;
     bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
     bool small_ok_ = false, small_ = false;
-    bool stage16_ = false;
+    bool stage16_ = false, stage_twice_ = false;
     WireSink wire_{};
     std::function<void(const RunStatus&)> on_status_;
     RowsIn d_in_{};

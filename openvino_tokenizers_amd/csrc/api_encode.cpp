@@ -354,8 +354,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     h->narrow_ids = p->vocab.n <= 65536;
     for (int64_t i = 0; i < p->added_tokens.n && p->added_ids; ++i)
         if (p->added_ids[i] < 0 || p->added_ids[i] > 65535) h->narrow_ids = false;
-    static const bool allow16 = [] { const char* e = std::getenv("OVTK_STAGE16"); return !e || std::atoi(e) != 0; }();   // (=0: i32 staging, A/B runs)
-    h->stage16 = allow16 && h->narrow_ids && p->vocab.n <= 65535;
+    h->stage16 = h->narrow_ids && p->vocab.n <= 65535;
     for (int64_t i = 0; i < p->added_tokens.n && p->added_ids; ++i)
         if (p->added_ids[i] > 65534) h->stage16 = false;
     int e = 0;
@@ -602,54 +601,40 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFusedLlama3, true>), grid, kBlockThreads, s, d_in,
                                                split->dev, T, w);
                                else if (llama3) {
-                                   static const bool strided = std::getenv("OVTK_LOOKUP_STRIDED") != nullptr;
+                                   // consecutive rows per wave (lookup_rows_kernel); what it leaves goes through the generic kernel
                                    EncodeWork w1 = w;
-                                   w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
-                                   if (!strided && w1.rows_per_wave <= kWave) {   // as for the GPT-2 family below
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_rows_kernel<kRowsLlama3>, grid, kBlockThreads, s, d_in, split->dev,
-                                                   T, w1);
-                                       EncodeWork w2 = w;
-                                       w2.only_pending = 1;
-                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
-                                                   T, w2);
-                                   } else {
-                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in,
-                                                   split->dev, T, w);
-                                   }
+                                   const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
+                                   OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsLlama3>, grid1, kBlockThreads, s, d_in, split->dev,
+                                               T, w1);
+                                   EncodeWork w2 = w;
+                                   w2.only_pending = 1;
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
+                                               T, w2);
                                }
                                else if (split && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFused, true>), grid, kBlockThreads, s, d_in,
                                                split->dev, T, w);
                                else if (split && split->dev.kind <= kSplitGpt2Digits) {
-                                   // rows that are one ASCII scan window: the specialised kernel; whatever it leaves
-                                   // (marked in row_used) goes through the generic one
-                                   // (consecutive rows per wave, headers by one vector load, the next row's text requested
-                                   // ahead into LDS: lookup_rows_kernel; OVTK_LOOKUP_STRIDED=1 keeps the round-2 kernel, for A/B runs)
-                                   EncodeWork w1 = w;
-                                   w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
-                                   const bool ahead = w1.rows_per_wave <= kWave;
                                    // several rows per scan block: lookup_span_kernel (it probes the memo for every piece: a handle
-                                   // without one -- cache_capacity = 0 -- keeps the row-per-scan kernel)
-                                   if (ahead && T.pieces.slots && split->dev.kind == kSplitGpt2Digits)
-                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<true>, grid, kBlockThreads, s, d_in, T, w1);
-                                   else if (ahead && T.pieces.slots)
-                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<false>, grid, kBlockThreads, s, d_in, T, w1);
-                                   else if (ahead && split->dev.kind == kSplitGpt2Digits)
-                                       OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsGpt2Digits>, grid, kBlockThreads, s, d_in,
-                                                   split->dev, T, w1);
-                                   else if (ahead)
-                                       OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsGpt2>, grid, kBlockThreads, s, d_in, split->dev,
-                                                   T, w1);
+                                   // without one -- cache_capacity = 0 -- takes the row-per-scan kernel); whatever they leave
+                                   // (marked in row_used, listed in pending_rows) goes through the generic kernel
+                                   EncodeWork w1 = w;
+                                   const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
+                                   if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<true>, grid1, kBlockThreads, s, d_in, T, w1);
+                                   else if (T.pieces.slots)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<false>, grid1, kBlockThreads, s, d_in, T, w1);
                                    else if (split->dev.kind == kSplitGpt2Digits)
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<true>, grid, kBlockThreads, s, d_in, T, w);
+                                       OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsGpt2Digits>, grid1, kBlockThreads, s, d_in,
+                                                   split->dev, T, w1);
                                    else
-                                       OVTK_LAUNCH(ws.marks, "lookup_ascii", lookup_ascii_kernel<false>, grid, kBlockThreads, s, d_in, T, w);
+                                       OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsGpt2>, grid1, kBlockThreads, s, d_in, split->dev,
+                                                   T, w1);
                                    // what it left: the generic kernel (it returns at once when nothing was left).  A smaller stand-by
                                    // grid for handles whose last call left no row was measured: nothing gained on all-ASCII text
                                    // (6.0 vs 6.2 us), and the rows that do turn up then wait for 64 blocks to walk every row's flag
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
-                                   if (!ahead) w2.pending_rows = nullptr;   // (lookup_ascii_kernel marks its rows in row_used only)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
                                                T, w2);
                                } else if (split)
@@ -677,7 +662,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            },
                            /*self_alloc=*/true,
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
-                                  : split->dev.kind == kSplitLlama3 ? (OVTK_L3_BLOCKS == 4 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>) : resident_blocks_per_cu(lookup_rows_kernel<kRowsLlama3>))
+                                  : split->dev.kind == kSplitLlama3 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>)
                                   : split->dev.kind <= kSplitGpt2Digits && !row_tickets().load(std::memory_order_relaxed)
                                       ? resident_blocks_per_cu(lookup_span_kernel<false>, 6)
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
@@ -700,6 +685,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
         });
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
     if (bpe->stage16) r->enable_stage16();
+    if (split && split->dev.kind <= kSplitGpt2Digits && T.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)
     if (wire) r->output_to_wire(*wire);
     if (int rc = r->start()) return rc;
     run = std::move(r);

@@ -227,11 +227,10 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                // rows that are one ASCII window: lookup_rows_kernel (consecutive rows per wave, the next row's text
                                    // requested ahead: encode_kernels.hpp); what it leaves -- marked in row_used -- goes through the
                                    // generic kernel
-                               static const bool strided = std::getenv("OVTK_LOOKUP_STRIDED") != nullptr;
                                EncodeWork w1 = w;
-                               w1.rows_per_wave = (d_in.n_rows + grid * kWavesPerBlock - 1) / (grid * kWavesPerBlock);
-                               if (!strided && w1.rows_per_wave <= kWave && !w.rows_per_ticket) {
-                                   OVTK_LAUNCH(ws.marks, "lookup_words", lookup_rows_kernel<kRowsBertWords>, grid, kBlockThreads, s, d_in, sp,
+                               const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
+                               if (!w.rows_per_ticket) {
+                                   OVTK_LAUNCH(ws.marks, "lookup_words", lookup_rows_kernel<kRowsBertWords>, grid1, kBlockThreads, s, d_in, sp,
                                                memo_only, w1);
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
@@ -248,8 +247,7 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                                unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
                            },
                            /*self_alloc=*/true, resident_blocks_per_cu(lookup_kernel<kFused>), /*tail_in_middle=*/true);
-    static const bool allow16 = [] { const char* e = std::getenv("OVTK_STAGE16"); return !e || std::atoi(e) != 0; }();   // (=0: i32 staging, A/B runs)
-    if (allow16 && h->n_vocab > 0 && h->n_vocab <= 65535 && unk_token_id >= 0 && unk_token_id <= 65534) r->enable_stage16();
+    if (h->n_vocab > 0 && h->n_vocab <= 65535 && unk_token_id >= 0 && unk_token_id <= 65534) r->enable_stage16();
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;

@@ -31,7 +31,7 @@ struct RunStatus {
     uint32_t flags;        // kFlag*
     uint32_t ticket[2];    // "last block done" tickets of prep_rows_kernel / count_scan_kernel
     uint32_t rows_done;    // bit s: row-ticket shard s is exhausted (lookup_kernel)
-    int32_t n_pending;     // rows lookup_ascii_kernel left to lookup_kernel<kFused> (not a single ASCII window)
+    int32_t n_pending;     // rows the span / rows kernel left to lookup_kernel<kFused>
     int32_t n_store_probe; // deferred pieces merge_kernel looked up in the piece store (a sample: one wave in 64 counts) ...
     int32_t n_store_hit;   // ... and found there
     int32_t pad[20];
@@ -93,11 +93,11 @@ __device__ __forceinline__ T uniform_load(const T* p) {
 
 // Streaming accesses -- the text a row is read from once, the staged ids a later kernel reads once -- carry the non-temporal
 // hint (global_load / global_store ... nt): they do not age the lines the XCD's 4 MiB L2 should keep, the memo and merge
-// tables every wave probes.  (Counted in round 3, tools/fetch_calib.hip for the units: lookup_ascii_kernel fetched 118 MB to
+// tables every wave probes.  (Counted in round 3, tools/fetch_calib.hip for the units: the round-2 lookup kernel fetched 118 MB to
 // read 34.6 MB of text -- the rest were memo probes whose lines the streams had pushed out.)
 template <typename T>
 __device__ __forceinline__ T stream_load(const T* p) {
-#if defined(OVTK_SIMT_EMULATOR) || defined(OVTK_NO_NT)
+#if defined(OVTK_SIMT_EMULATOR)
     return *p;
 #else
     return __builtin_nontemporal_load(p);
@@ -105,7 +105,7 @@ __device__ __forceinline__ T stream_load(const T* p) {
 }
 template <typename T>
 __device__ __forceinline__ void stream_store(T* p, T v) {
-#if defined(OVTK_SIMT_EMULATOR) || defined(OVTK_NO_NT)
+#if defined(OVTK_SIMT_EMULATOR)
     *p = v;
 #else
     __builtin_nontemporal_store(v, p);

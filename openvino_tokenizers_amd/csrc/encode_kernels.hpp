@@ -54,12 +54,12 @@ constexpr int kMissBuf = 96;   // per-wave LDS buffer of deferred pieces: flushe
                                // (3 KB per wave instead of 4: with the 2.3 KB scan window a seventh block fits a CU's LDS)
 
 constexpr int kRowTile = 64;  // rows per tile of the final offset scan
-constexpr int32_t kRowPending = -1;  // row_used: lookup_ascii_kernel left the row to lookup_kernel<kFused>
+constexpr int32_t kRowPending = -1;  // row_used: lookup_span_kernel / lookup_rows_kernel left the row to lookup_kernel<kFused>
 
 struct EncodeWork {
     int32_t fold_tail;      // merge_kernel's last block also runs exact pieces + the row scan (no exact / count_scan launches)
     long long out_cap;      // caller's ids capacity (the folded tail's capacity check)
-    int32_t only_pending;   // lookup_kernel<kFused>: take only the rows lookup_ascii_kernel marked kRowPending in row_used
+    int32_t only_pending;   // lookup_kernel<kFused>: take only the rows the span / rows kernel marked kRowPending in row_used
     int32_t small;          // the whole call is ONE launch of encode_small_kernel (one block): the fields below are set
     int32_t* out_ids;       //   caller's ids / begins / ends (device pointers) ...
     int32_t* out_begins;
@@ -213,18 +213,9 @@ __device__ __forceinline__ void piece_key(uint64_t raw0, uint64_t raw1, int plen
 // `tools/lds_unaligned_probe.hip` checks that on the box).  Until r03 five aligned dword reads and four funnel shifts.
 struct __attribute__((packed, aligned(1))) LdsBytes16 { uint64_t lo, hi; };
 __device__ __forceinline__ void lds_bytes16(const uint32_t* words, int off, uint64_t& r0, uint64_t& r1) {
-#ifndef OVTK_LDS_ALIGNED_READS
     const LdsBytes16 v = *reinterpret_cast<const LdsBytes16*>(reinterpret_cast<const uint8_t*>(words) + off);
     r0 = v.lo;
     r1 = v.hi;
-#else
-    const int a = off >> 2, sh = (off & 3) * 8;
-    const uint32_t w0 = words[a], w1 = words[a + 1], w2 = words[a + 2], w3 = words[a + 3], w4 = words[a + 4];
-    const uint32_t d0 = funnel_shr(w0, w1, sh), d1 = funnel_shr(w1, w2, sh);
-    const uint32_t d2 = funnel_shr(w2, w3, sh), d3 = funnel_shr(w3, w4, sh);
-    r0 = (uint64_t(d1) << 32) | d0;
-    r1 = (uint64_t(d3) << 32) | d2;
-#endif
 }
 // The piece's bytes from global memory (pre-split pieces: any alignment, may end at the buffer's end).
 __device__ __forceinline__ void global_bytes16(const uint8_t* p, int plen, uint64_t& r0, uint64_t& r1) {
@@ -548,7 +539,7 @@ __device__ __forceinline__ void lookup_body(const RowsIn& in, const SplitDev& sp
     __shared__ WaveScratch ws_all[kWavesPerBlock];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
     if (w.status->flags & kFatalFlags) return;
-    if (w.only_pending && w.status->n_pending == 0) return;  // lookup_ascii_kernel took every row
+    if (w.only_pending && w.status->n_pending == 0) return;  // the span / rows kernel took every row
     WaveScratch& ws = ws_all[wave_in_block()];
     WaveMiss& mb = miss_all[wave_in_block()];
     const int l = lane_id();
@@ -611,7 +602,7 @@ __device__ __forceinline__ void lookup_body(const RowsIn& in, const SplitDev& sp
     int list_at = wave;
     if (listed) row = list_at < n_listed ? uniform_load(w.pending_rows + list_at) : -1;
     while (row >= 0 && row < in.n_rows) {
-        if (!TICKETS && !listed && w.only_pending && uniform_load(w.row_used + row) != kRowPending) {  // done by lookup_ascii_kernel
+        if (!TICKETS && !listed && w.only_pending && uniform_load(w.row_used + row) != kRowPending) {  // done by the span / rows kernel
             row += n_waves;
             continue;
         }
@@ -697,97 +688,17 @@ static __global__ __launch_bounds__(kBlockThreads, MODE == kFusedLlama3 ? 4 : 5)
 }
 
 
-// ---- the GPT-2 family's common case as a kernel of its own: rows of ONE string that is ONE ASCII scan window.
-// The same work as lookup_kernel<kFused> does for such a row (stage the text in LDS, packed-byte scanner, 64-piece
-// batches through the memo) without the generic kernel's other paths -- several strings per row, skips, chunked strings,
-// the ballot scanner, the class patterns, row tickets --, whose live state costs the generic kernel 68 spilled SGPRs and
-// a fifth of its instructions.  Any other row is marked kRowPending in row_used and left to lookup_kernel<kFused>
-// (launched right behind with only_pending set; it returns at once when nothing was left).
-template <bool DIGITS>
-static __global__ __launch_bounds__(kBlockThreads, 6) void lookup_ascii_kernel(RowsIn in, BpeDev T, EncodeWork w) {
-    __shared__ WaveScratch ws_all[kWavesPerBlock];
-    __shared__ WaveMiss miss_all[kWavesPerBlock];
-    if (w.status->flags & kFatalFlags) return;
-    WaveScratch& ws = ws_all[wave_in_block()];
-    WaveMiss& mb = miss_all[wave_in_block()];
-    const int l = lane_id();
-    const int n_waves = w.n_waves;
-    const int wave = wave_uniform(int(blockIdx.x) * kWavesPerBlock + wave_in_block());
-    const int mul = T.suffix_len + 1;
-    int n_miss = 0, n_pending = 0;
-    int cursor = 0, limit = 0;
-    bool dead = false;  // staging exhausted: the host grows the buffer and reruns
-    for (int row = wave; row < in.n_rows; row += n_waves) {
-        const RowHdr h = load_row_string(in, load_row_range(in, row));
-        bool fast = h.simple && !dead;
-        int np = 0, skew = 0;
-        if (fast) {
-            wave_sync();  // the previous row's batches are done with the LDS window
-            skew = stage_window(ws, in.chars + h.sb, h.slen, 0, h.slen, in.chars, in.chars + in.n_chars);
-            wave_sync();
-            fast = h.slen <= 64 * 4 * (kLaneDwords - 1) ? gpt2_packed_starts<kLaneDwords - 1>(ws, skew, h.slen, DIGITS, 0, h.slen, np)
-                                                        : gpt2_packed_starts<kLaneDwords>(ws, skew, h.slen, DIGITS, 0, h.slen, np);
-        }
-        if (fast) {
-            const int cap = h.slen * mul;  // (h.simple: the offsets lie inside the chars tensor)
-            if (cursor + cap > limit) {
-                const int size = cap > kStageChunk ? cap : kStageChunk;
-                const int shard = wave % kShards;
-                int base = 0;
-                if (l == 0) base = atomicAdd(&w.status->stage_top[shard * kCounterStride], size);
-                base = wave_readlane(base, 0);
-                if (base < 0 || base > w.stage_region - size) {
-                    if (l == 0) atomicOr(&w.status->flags, kFlagStageOverflow);
-                    dead = true;
-                    fast = false;
-                } else {
-                    cursor = shard * w.stage_region + base;
-                    limit = cursor + size;
-                }
-            }
-        }
-        if (!fast) {
-            if (l == 0) w.row_used[row] = kRowPending;
-            ++n_pending;
-            continue;
-        }
-        if (l == 0) ws.pstart[np] = uint16_t(h.slen);
-        wave_sync();
-        RowState st{cursor, 0, 0, row};
-        for (int jb = 0; jb < np; jb += kWave) {
-            const int j = jb + l;
-            const bool valid = j < np;
-            int ps = 0, plen = 0;
-            uint64_t r0 = 0, r1 = 0;
-            if (valid) {
-                ps = int(ws.pstart[j]);
-                plen = int(ws.pstart[j + 1]) - ps;
-                if (plen <= kPieceKeyBytes) lds_bytes16(ws.text_w, kTextPad + ps + skew, r0, r1);
-            }
-            lookup_batch(T, st, w, mb, n_miss, valid, r0, r1, plen, h.sb + ps);
-        }
-        if (l == 0) {
-            w.row_stage[row] = cursor;
-            w.row_cnt[row] = st.emitted;
-            if (w.row_emit) w.row_emit[row] = st.emitted;
-            w.row_used[row] = st.used;
-        }
-        cursor += st.used;
-    }
-    if (n_miss > 0) flush_misses(mb, n_miss, n_miss, w);
-    if (n_pending && l == 0) atomicAdd(&w.status->n_pending, n_pending);
-}
-
-// ---- lookup_ascii_kernel with the memory latency of a row taken out of its critical path (round 3).
-// lookup_ascii_kernel pays four dependent round trips per row -- the row's header (scalar loads), its text, and two batches of
-// memo probes -- and a wave's rows are n_waves apart, so every header load is a scalar-cache miss.  Here a wave owns
-// rows_per_wave CONSECUTIVE rows:
+// ---- lookup_rows_kernel: one row per scan, the rows of a wave consecutive (round 3).  The Llama-3 family, the fused WordPiece path
+// (BERT words) and GPT-2-family handles without a memo run it; GPT-2-family handles with a memo take lookup_span_kernel
+// (span_kernel.hpp: several rows per scan).  A row that is ONE string that is ONE scan window is scanned with the packed-byte
+// scanner of its pattern and looked up in 64-piece batches; any other row is marked kRowPending in row_used, listed in
+// pending_rows, and left to lookup_kernel<kFused> (launched right behind with only_pending set; it returns at once when nothing
+// was left).  A wave owns rows_per_wave CONSECUTIVE rows:
 //  * their headers arrive with ONE vector load (lane i = row i of the range), two dependent round trips per wave instead of
 //    two per row;
 //  * the text of row i + 1 is requested while row i is scanned, straight into LDS (global_load_lds: no registers in between),
 //    into the second of two windows -- by the time row i's batches are through it has landed.
-// Everything else is lookup_ascii_kernel: the packed-byte scanner, 64-piece batches through the memo, staging chunks from the
-// bump allocators, rows that are not one ASCII window marked kRowPending for lookup_kernel<kFused>.
+// Staging chunks come from the bump allocators.
 __device__ __forceinline__ void lds_fetch_words(const uint8_t* ga, int nwords, uint32_t* dst) {
     const int l = lane_id();
 #if defined(OVTK_SIMT_EMULATOR)
@@ -803,18 +714,11 @@ __device__ __forceinline__ void lds_fetch_words(const uint8_t* ga, int nwords, u
 // SCAN: which packed-byte scanner reads the window -- the GPT-2 rules, the same with every digit on its own, or the BERT words
 // (white space dropped, every delimiter character a word: the fused WordPiece path; `T` then holds nothing but the word memo).
 enum RowsScan : int { kRowsGpt2 = 0, kRowsGpt2Digits = 1, kRowsBertWords = 2, kRowsLlama3 = 3 };
-#ifndef OVTK_L3_BLOCKS
-#define OVTK_L3_BLOCKS 4   // resident blocks per CU the Llama-3 instance is compiled for (A/B builds)
-#endif
 template <int SCAN>
-static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? OVTK_L3_BLOCKS : 6) void lookup_rows_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? 4 : 6) void lookup_rows_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     __shared__ uint32_t text_all[kWavesPerBlock][2][kWinBytes / 4];
     __shared__ uint16_t pstart_all[kWavesPerBlock][kChunk + 2];
     __shared__ WaveMiss miss_all[kWavesPerBlock];
-#ifdef OVTK_LOOKUP_PAD_LDS
-    __shared__ uint32_t lds_pad[OVTK_LOOKUP_PAD_LDS / 4];   // ablation build, see merge_body
-    if (T.unk_id == -12345) lds_pad[threadIdx.x] = 1;
-#endif
     if (w.status->flags & kFatalFlags) return;
     WaveMiss& mb = miss_all[wave_in_block()];
     const int l = lane_id();
@@ -1043,11 +947,6 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     __shared__ I2 root_lds[256];
     __shared__ uint8_t long_src_all[kWavesPerBlock][kWave / 2];  // path L: source lane of the piece lane t works on
     __shared__ int pushed_exact;  // this block stored exact-list entries (plain stores the tail block must see)
-#ifdef OVTK_MERGE_PAD_LDS
-    // ablation build ("tables in LDS"): what the kernel would pay in occupancy for an LDS-resident table of this size
-    __shared__ uint32_t lds_pad[OVTK_MERGE_PAD_LDS / 4];
-    if (T.unk_id == -12345) lds_pad[threadIdx.x] = 1;
-#endif
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
     if (threadIdx.x == 0) pushed_exact = 0;
     __syncthreads();

@@ -589,18 +589,11 @@ template <int N>
 struct __attribute__((packed, aligned(1))) LdsDwords { uint32_t d[N]; };
 template <int LB>
 __device__ __forceinline__ int lds_lane_dwords(const uint32_t* text_w, int off, uint32_t (&r)[LB + 1]) {
-#ifndef OVTK_LDS_ALIGNED_READS
     const LdsDwords<LB> v = *reinterpret_cast<const LdsDwords<LB>*>(reinterpret_cast<const uint8_t*>(text_w) + off);
 #pragma unroll
     for (int j = 0; j < LB; ++j) r[j] = v.d[j];
     r[LB] = 0;
     return 0;
-#else
-    const int a = off >> 2;
-#pragma unroll
-    for (int j = 0; j <= LB; ++j) r[j] = text_w[a + j];
-    return (off & 3) * 8;
-#endif
 }
 
 // ---- packed-byte (SWAR) path: ASCII windows (at most kChunk bytes) -------------------------------

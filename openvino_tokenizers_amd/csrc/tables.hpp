@@ -180,22 +180,16 @@ __host__ __device__ inline uint32_t merge_h2(uint64_t key, uint32_t shift) { ret
 // Memo hashing with 24-bit multiplies only.  A full 32-bit multiply (v_mul_lo_u32) issues at a quarter of the vector rate
 // on CDNA; v_mul_u32_u24 / v_mad_u32_u24 (the low 32 bits of a 24 x 24-bit product, what the compiler selects for operands
 // it knows to be 24 bits wide) issue at the full rate.  The 16 key bytes are taken as six overlapping 24-bit chunks, each
-// times an odd 24-bit constant; two more such products stir the sum; the second cuckoo function is one more pair.
-// (lookup_ascii_kernel: 7 v_mul_lo_u32 became 15 24-bit multiplies / multiply-adds, 100.4 -> 98.8 us; the tables fill as before.)
+// times an odd 24-bit constant.
+// (round 2: 7 v_mul_lo_u32 became 15 24-bit multiplies / multiply-adds, 100.4 -> 98.8 us; the tables fill as before.)
 __host__ __device__ inline uint32_t mul24(uint32_t a, uint32_t k) { return (a & 0xFFFFFFu) * (k & 0xFFFFFFu); }
-__host__ __device__ inline uint32_t stir24(uint32_t h, uint32_t ka, uint32_t kb) { return mul24(h, ka) + mul24(h >> 8, kb); }
 __host__ __device__ inline uint32_t piece_mix(uint64_t k0, uint64_t k1) {
     const uint32_t d0 = uint32_t(k0), d1 = uint32_t(k0 >> 32), d2 = uint32_t(k1), d3 = uint32_t(k1 >> 32);
     const uint32_t c1 = (d0 >> 24) | (d1 << 8), c2 = (d1 >> 16) | (d2 << 16);   // funnel shifts; bits above 24 are ignored
     uint32_t h = mul24(d0, 0x9E3779u) + mul24(c1, 0x85EBCBu) + mul24(c2, 0xC2B2AFu) + mul24(d2 >> 8, 0x27D4EBu) +
                  mul24(d3, 0x165667u) + mul24(d3 >> 8, 0xD6E8FFu);
-#ifdef OVTK_MIX_STIR   // (round 3: the two stirring products bought nothing the bucket index needs -- refused vocabulary tokens
-    h ^= h >> 15;      // gpt2 268 vs 258, llama3 1101 vs 1180, bert 897 vs 896 with / without)
-    h = stir24(h, 0x2C1B3Du, 0x9E3779u);
-    return h ^ (h >> 13);
-#else
+    // (two more stirring products were measured and dropped in round 3: they bought nothing the slot index needs)
     return h ^ (h >> 15);
-#endif
 }
 __host__ __device__ inline uint32_t piece_tag(uint32_t mix, int cnt) { return (mix & 0xFFFFFF00u) | 0x80u | uint32_t(cnt); }
 // A piece has ONE candidate entry (round 4): its 32-byte slot, two 16-byte loads at consecutive addresses, one key compare.

@@ -242,8 +242,8 @@ def test_detokenize_config5_as_stated(hip_lib):
 @pytest.mark.parametrize("rows", [300000, 420000])
 def test_many_short_rows(hip_lib, rows):
     """300 000 rows (more than the folded tail of merge_kernel takes: the separate exact / count_scan launches run; 49
-    consecutive rows per wave of lookup_rows_kernel) and 420 000 (more than 64 rows per wave: the strided lookup_ascii_kernel
-    takes over) of ~24 bytes: halves back to back = the whole batch, offsets gap-free, the oracle on a prefix."""
+    consecutive rows per wave of lookup_span_kernel) and 420 000 (more than 64 rows per wave on the persistent grid: the grid
+    grows instead, 64 rows per wave) of ~24 bytes: halves back to back = the whole batch, offsets gap-free, the oracle on a prefix."""
     import torch
     tok = BpeTok.load("gpt2")
     b, e, c = TextModel(99, "zipf").batch(rows, 24, seed=5)

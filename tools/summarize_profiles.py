@@ -14,7 +14,7 @@ from pathlib import Path
 import pandas as pd
 
 ROOT = Path(__file__).resolve().parent.parent
-TAG = {"lookup_ascii_kernel": "lookup_ascii", "lookup_rows_kernel": "lookup_ascii", "regex_split_kernel<0>": "regex_count", "regex_split_kernel<1>": "regex_write",
+TAG = {"lookup_span_kernel": "lookup_span", "lookup_rows_kernel": "lookup_rows", "regex_sparse_kernel": "regex_split", "regex_split_kernel<0>": "regex_count", "regex_split_kernel<1>": "regex_write",
        "ragged_to_dense_kernel": "ragged_to_dense", "vocab_encoder_kernel": "vocab_encoder",
        "lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "lookup_kernel<2>": "lookup_fused",
        "merge_kernel": "bpe_merge",
@@ -82,7 +82,7 @@ def main(prefix):
                 write = float(g[g.Counter_Name == "WRITE_SIZE"].mean_KB.sum())
                 per[tag_of(k)] = int((2 * fetch + write) * 1024)
             if cfg == 3:   # bench.py's name for the lookup kernel run with the BERT words scanner (lookup_rows_kernel since r03)
-                per["lookup_words"] = per.pop("lookup_ascii") if "lookup_ascii" in per else per.get("lookup_fused", 0)
+                per["lookup_words"] = per.pop("lookup_rows") if "lookup_rows" in per else per.get("lookup_fused", 0)
             pmc_json[f"config{cfg}"] = per
     (ROOT / "profiles" / "latest_pmc.json").write_text(json.dumps(pmc_json, indent=1, sort_keys=True) + "\n")
     print(json.dumps(pmc_json, indent=1))
