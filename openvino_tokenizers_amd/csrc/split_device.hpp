@@ -270,7 +270,11 @@ __device__ __forceinline__ Mask mask_from_after(Mask v) { return (v >> K) | (row
 // Piece-start mask of the window [w0, w1) staged at `skew`: lane w returns the bits of window bytes
 // [64w, 64w+64).  Bit i <=> "a piece starts at string position w0 + i" according to the GPT-2 family rules;
 // positions w0 + i == 0 and chunk starts are forced by the caller.  Wave-uniform call.
-__device__ __forceinline__ Mask gpt2_start_mask(const WaveScratch& ws, const SplitDev& sp, int skew, int wlen, bool digits) {
+__device__ __forceinline__ const uint8_t* text_bytes(const WsView& ws) {
+    return reinterpret_cast<const uint8_t*>(ws.text_w) + kTextPad;
+}
+template <class WS>
+__device__ __forceinline__ Mask gpt2_start_mask(const WS& ws, const SplitDev& sp, int skew, int wlen, bool digits) {
     const int l = lane_id();
     const uint8_t* t = text_bytes(ws) + skew;
     Mask mL = 0, mN = 0, mS = 0, mSP = 0, mCONT = 0, mAP = 0, mX1 = 0, mX2 = 0, mXE = 0, mXL = 0;

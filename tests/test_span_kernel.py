@@ -41,7 +41,8 @@ def rows_of(strings):
     return [rb, re_, b, e, c]
 
 
-@pytest.mark.parametrize("kind,n,target", [("zipf", 400, 128), ("zipf", 288, 512), ("uniform", 320, 200), ("zipf", 300, 40)])
+@pytest.mark.parametrize("kind,n,target", [("zipf", 400, 128), ("zipf", 288, 512), ("uniform", 320, 200), ("zipf", 300, 40),
+                                           ("mixed", 300, 300), ("mixed", 280, 900)])
 def test_text_models(backend, kind, n, target):
     b, e, c = TextModel(41, kind).batch(n, target)
     rb, re_ = ragged_rows(n)
@@ -92,7 +93,8 @@ def test_rules_at_row_boundaries(backend):
 
 
 def test_rows_left_to_the_generic_kernel(backend):
-    """Empty rows, rows longer than a block, rows with non-ASCII text and skipped rows between ordinary ones."""
+    """Empty rows, rows longer than a block, and skipped rows between ordinary ones; rows with non-ASCII text (those stay: the
+    block takes the ballot form of the rules -- unless one of its rows is longer than 1 024 bytes)."""
     rng = np.random.default_rng(11)
     strings, skips = [], []
     for i in range(360):
@@ -102,7 +104,7 @@ def test_rows_left_to_the_generic_kernel(backend):
         elif r == 5:
             s = _filler(rng, 2300 + i)
         elif r == 7:
-            s = "naïve café über straße — ok".encode() + _filler(rng, 40)
+            s = "naïve café über straße — ok".encode() + _filler(rng, 40 if i % 24 else 1100)
         elif r == 9:
             s = _filler(rng, 20) + "日本語のテキスト".encode() + _filler(rng, 30)
         else:
