@@ -88,9 +88,11 @@ typedef struct ovtk_ragged_i32_out {
  * (csrc/regex_compile.cpp: the PCRE2 subset listed in regex_compile.hpp -- classes, \p{..} by General_Category,
  * groups, alternation, greedy / lazy / possessive repeats, anchors, one-character look-around) and run one lane
  * per row; only constructs outside that subset (back-references, atomic groups, recursion, script properties ...)
- * are OVTK_E_UNSUPPORTED -- never an approximation, never a CPU fallback.  A split that the fused encode has no
- * scanner for (compiled DFA, class patterns, max_splits) runs as its own pass inside ovtk_encode_* and the host
- * waits once for the piece count: ovtk_encode_enqueue / _host / _wire block for that pass with such patterns.
+ * are OVTK_E_UNSUPPORTED -- never an approximation, never a CPU fallback.  The GPT-2 family, the Llama-3 family
+ * (Llama-3's own pattern, Qwen2's, tiktoken's cl100k_base) are scanned inside the fused encode's lookup kernels; a
+ * compiled DFA runs as one pass of its own in front of them on the same stream (no host wait: ovtk_encode_enqueue
+ * returns before the split has finished); only the class patterns (\s+, the BERT delimiters) in front of a BPETokenizer,
+ * and scanner patterns with max_splits, still take the op's count + write passes with one host wait for the piece count.
  * Inputs 0-4 (+5 skips) of the op = `in` (+ `skips`); input "pattern" and attributes = params. */
 typedef struct ovtk_regex_split_params {
     const char* pattern;
