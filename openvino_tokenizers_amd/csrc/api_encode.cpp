@@ -621,9 +621,9 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
                                    if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits)
-                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<true>, grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<kSpanGpt2Digits>, grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (T.pieces.slots)
-                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<false>, grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<kSpanGpt2>, grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (split->dev.kind == kSplitGpt2Digits)
                                        OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsGpt2Digits>, grid1, kBlockThreads, s, d_in,
                                                    split->dev, T, w1);
@@ -664,7 +664,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
                                   : split->dev.kind == kSplitLlama3 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>)
                                   : split->dev.kind <= kSplitGpt2Digits && !row_tickets().load(std::memory_order_relaxed)
-                                      ? resident_blocks_per_cu(lookup_span_kernel<false>, 6)
+                                      ? resident_blocks_per_cu(lookup_span_kernel<kSpanGpt2>, 6)
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (pieces_ws) {

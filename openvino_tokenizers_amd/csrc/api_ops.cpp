@@ -12,6 +12,7 @@
 
 #include "api_common.hpp"
 #include "ops_kernels.hpp"
+#include "span_kernel.hpp"
 #include "runtime.hpp"
 #include "tables.hpp"
 
@@ -230,8 +231,13 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                EncodeWork w1 = w;
                                const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
                                if (!w.rows_per_ticket) {
-                                   OVTK_LAUNCH(ws.marks, "lookup_words", lookup_rows_kernel<kRowsBertWords>, grid1, kBlockThreads, s, d_in, sp,
-                                               memo_only, w1);
+                                   // several rows per scan block (span_kernel.hpp) where there is a word memo to probe
+                                   if (memo_only.pieces.slots)
+                                       OVTK_LAUNCH(ws.marks, "lookup_words", lookup_span_kernel<kSpanBertWords>, grid1, kBlockThreads, s, d_in, sp,
+                                                   memo_only, w1);
+                                   else
+                                       OVTK_LAUNCH(ws.marks, "lookup_words", lookup_rows_kernel<kRowsBertWords>, grid1, kBlockThreads, s, d_in, sp,
+                                                   memo_only, w1);
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp, memo_only, w2);
@@ -246,8 +252,11 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                    OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel<false>, dgrid, kBlockThreads, s, d_in, wdev,
                                                unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
                            },
-                           /*self_alloc=*/true, resident_blocks_per_cu(lookup_kernel<kFused>), /*tail_in_middle=*/true);
+                           /*self_alloc=*/true,
+                           memo_only.pieces.slots ? resident_blocks_per_cu(lookup_span_kernel<kSpanBertWords>) : resident_blocks_per_cu(lookup_kernel<kFused>),
+                           /*tail_in_middle=*/true);
     if (h->n_vocab > 0 && h->n_vocab <= 65535 && unk_token_id >= 0 && unk_token_id <= 65534) r->enable_stage16();
+    if (memo_only.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;

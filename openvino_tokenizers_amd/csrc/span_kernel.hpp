@@ -94,6 +94,7 @@ __device__ __forceinline__ void span_load(const RowsIn& in, int sb, int blen, ui
 //  * contractions: apostrophes are few, so a lane walks its own (usually none, rarely two) and reads the letters behind them
 //    from the LDS copy of the text.
 // false (wave-uniform): the block holds a non-ASCII byte.
+enum SpanScan : int { kSpanGpt2 = 0, kSpanGpt2Digits = 1, kSpanBertWords = 2 };
 struct SpanClasses { uint32_t L, N, S, SP, O; };
 template <bool DIGITS>
 __device__ __forceinline__ SpanClasses span_classify(uint32_t v) {
@@ -196,6 +197,56 @@ __device__ __forceinline__ bool span_flags(uint32_t (&x)[kSpanDwords], uint32_t 
     return true;
 }
 
+// The BERT words of the fused WordPiece path (class_packed_starts with kSplitBertWords: `\s+` removed, then every delimiter
+// character -- bert_delimiter() below 0x80 -- isolated): a piece starts where white-space-ness changes, at every delimiter and
+// behind every delimiter; white-space pieces are dropped (`dropped`: bit k = byte 32 l + k is white space).  Nothing looks ahead,
+// so a row start only forces a start.  false (wave-uniform): the block holds a non-ASCII byte (\p{P}, the CJK blocks: the
+// generic kernel's table form).
+__device__ __forceinline__ bool span_flags_bert(uint32_t (&x)[kSpanDwords], uint32_t rs, uint32_t vm, uint32_t& flags, uint32_t& dropped) {
+    constexpr int D = kSpanDwords;
+    uint32_t any = 0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) any |= x[j];
+    if (__ballot((any & kB7) != 0)) {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const uint32_t own = nibble_to_b7((vm >> (4 * j)) & 0xFu);
+            bad |= x[j] & own;
+            x[j] &= ~(kB7 & ~own);
+        }
+        if (__ballot(bad != 0)) return false;
+    }
+    auto classes = [](uint32_t v, uint32_t& S, uint32_t& P) {
+        S = swar_eq(v, 0x20) | swar_range(v, 9, 13);
+        P = swar_range(v, 0x21, 0x2F) | swar_range(v, 0x3A, 0x40) | swar_range(v, 0x5B, 0x60) | swar_range(v, 0x7B, 0x7E);
+    };
+    uint32_t lS, lP;
+    classes(x[D - 1], lS, lP);
+    uint32_t pSd = lane_prev(lS), pPd = lane_prev(lP);   // the dword in front of the lane's first
+    uint32_t f_acc[D / 2], s_acc[D / 2];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        uint32_t S, P;
+        if (j == D - 1) { S = lS; P = lP; }
+        else classes(x[j], S, P);
+        const uint32_t pS = swar_before<1>(pSd, S), pP = swar_before<1>(pPd, P);
+        const uint32_t st = ((S ^ pS) | P | pP) & kB7;
+        if ((j & 1) == 0) {
+            f_acc[j >> 1] = dot4_u8(st, 0x08040201u, 0u);
+            s_acc[j >> 1] = dot4_u8(S, 0x08040201u, 0u);
+        } else {
+            f_acc[j >> 1] = dot4_u8(st, 0x80402010u, f_acc[j >> 1]);
+            s_acc[j >> 1] = dot4_u8(S, 0x80402010u, s_acc[j >> 1]);
+        }
+        pSd = S;
+        pPd = P;
+    }
+    flags = (((f_acc[0] >> 7) | (f_acc[1] << 1) | (f_acc[2] << 9) | (f_acc[3] << 17)) | rs) & vm;
+    dropped = (s_acc[0] >> 7) | (s_acc[1] << 1) | (s_acc[2] << 9) | (s_acc[3] << 17);
+    return true;
+}
+
 // Writes the n (<= kSpanMiss) noted misses of the wave to its shard of the deferred list.
 __device__ __forceinline__ void span_flush(const SpanWave& sw, int n, const RowsIn& in, const EncodeWork& w, int row0,
                                            const uint4* mask_tab) {
@@ -235,8 +286,11 @@ struct SpanProbe {
     int plen, ps;
 };
 
-template <bool DIGITS>
+// SCAN: kSpanGpt2 / kSpanGpt2Digits (RegexSplit + BPETokenizer), kSpanBertWords (the fused WordPiece path: `T` then holds nothing but the
+// word memo, misses go to wordpiece_deferred_kernel through the same deferred list).
+template <int SCAN>
 static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
+    constexpr bool DIGITS = SCAN == kSpanGpt2Digits;
     __shared__ SpanWave sw_all[kWavesPerBlock];
     __shared__ uint4 mask_tab[16];   // [n]: byte masks of the four key dwords of an n-byte piece (n = 0: nothing)
     if (threadIdx.x < 16) {
@@ -338,8 +392,8 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         const int nv = b_len - kSpanLane * l;
         const uint32_t vm = nv >= kSpanLane ? ~0u : (nv <= 0 ? 0u : ((1u << nv) - 1u));
         wave_sync();
-        uint32_t fl = 0;
-        const bool fast = span_flags<DIGITS>(xa, rs, vm, text, fl);
+        uint32_t fl = 0, dropped = 0;
+        const bool fast = SCAN == kSpanBertWords ? span_flags_bert(xa, rs, vm, fl, dropped) : span_flags<DIGITS>(xa, rs, vm, text, fl);
         // ---- the next block's text: in flight while this block's pieces are looked up
         int ni, nj, n_sb, n_len;
         next_block(bj, ni, nj, n_sb, n_len);
@@ -356,7 +410,8 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 uint32_t f = fl;
                 uint16_t* at = sw.pstart + at0;
                 while (f) {
-                    *at++ = uint16_t(kSpanLane * l + __ffs(f) - 1);
+                    const int bit = __ffs(f) - 1;
+                    *at++ = uint16_t((kSpanLane * l + bit) | (SCAN == kSpanBertWords && ((dropped >> bit) & 1u) ? kPieceDropped : 0));
                     f &= f - 1;
                 }
             }
@@ -367,7 +422,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 const int first = wave_readlane(at0, ln) + __popc(fk & ((1u << (p & 31)) - 1u));
                 rowfirst = wave_writelane(rowfirst, first, k - bi);
             }
-        } else if (longest <= 16 * kWave) {
+        } else if (SCAN != kSpanBertWords && longest <= 16 * kWave) {
             // A block with non-ASCII text: its rows one by one through the ballot form of the rules (gpt2_start_mask: a byte per lane
             // and 64-byte word, code points through the Unicode tables, masks of up to 16 words) -- four times the instructions of
             // the packed form per byte, but the rows stay in this kernel, the lookup rounds below are the same, and nothing is
@@ -399,8 +454,8 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 SpanProbe q;
                 const int j = jb + l < np ? jb + l : np;
                 const uint32_t pp = reinterpret_cast<const Bytes4*>(sw.pstart + j)->v;
-                q.ps = int(pp & 0xFFFFu);
-                q.plen = int(pp >> 16) - q.ps;
+                q.ps = int(pp & kPiecePosMask);
+                q.plen = (pp & kPieceDropped) ? 0 : int((pp >> 16) & kPiecePosMask) - q.ps;   // (a dropped piece: nothing to look up)
                 const Bytes16 r = *reinterpret_cast<const Bytes16*>(text + q.ps);
                 const uint4 m = mask_tab[q.plen < 15 ? q.plen : 15];
                 q.a = r.x & m.x;

@@ -199,3 +199,41 @@ def test_contractions_at_every_lane_offset(backend):
     strings = strings[:500]
     fused_vs_oracle(backend, BpeTok.load("gpt2_small"), rows_of(strings), what="contractions")
     fused_vs_oracle(backend, BpeTok.load("gpt2_small"), rows_of(strings), pattern=DIGITS_PATTERN, what="contractions, digits variant")
+
+
+def test_bert_words_through_the_span_kernel(backend):
+    """The fused WordPiece path on lookup_span_kernel<kSpanBertWords>: white space and delimiters at every row boundary and lane
+    offset, rows of nothing but white space / delimiters, rows around the block edges, non-ASCII and over-long rows (left to the
+    generic kernel), words longer than a memo key -- against the two RegexSplit ops + WordpieceTokenizer of the oracle, cold and on
+    the word store's second call."""
+    from openvino_tokenizers_amd.ops import FusedSplitWordpiece, WordpieceTokenizer
+    from tests.test_ops_parity import BERT_PUNCT, BERT_WS, bert_words, wp_consts
+    from tools.make_tokenizers import load_tokenizer
+    tok = load_tokenizer("bert_small")
+    rng = np.random.default_rng(37)
+    frag = ["the", "token", "izer", "un", "affable", "hello", "world", "x", "a1", "2024", ",", ".", "!?", "(", ")", "--", " ", "  ", "\t", "\n", " , ",
+            "word" * 5, "q" * 17, "don't", "e.g.", "[", "]", "{~}", "^_`"]
+    strings = []
+    for i in range(330):
+        r = i % 15
+        if r == 11:
+            s = "   \t\n  " * int(rng.integers(1, 9))
+        elif r == 12:
+            s = ",.;:!?" * int(rng.integers(1, 30))
+        elif r == 13:
+            s = "naïve café 元気 — " + "".join(rng.choice(frag, size=6))
+        elif r == 14:
+            s = " ".join(rng.choice(frag, size=700))[: 2100 + i]
+        else:
+            s = "".join(rng.choice(frag, size=int(rng.integers(1, 90)))) + (" " if i % 2 else "")
+            if r == 3:
+                s = s[: int(rng.choice([1, 31, 32, 33, 63, 64, 65]))]
+        strings.append(s)
+    inputs = rows_of([s.encode() for s in strings])
+    ws_pat, pu_pat = np.frombuffer(BERT_WS.encode(), np.uint8), np.frombuffer(BERT_PUNCT.encode(), np.uint8)
+    ref = O.WordpieceTokenizer(tok["vocab"], tok["suffix_indicator"], tok["max_bytes_per_word"])(*bert_words(inputs), tok["unk_id"])
+    fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
+                                WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], lib=backend.lib))
+    for call in range(2):
+        got = fused.evaluate(backend.data(inputs), ws_pat, pu_pat, wp_consts(tok))
+        assert_same(ref, got, backend.host, f"BERT words, call {call}")
