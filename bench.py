@@ -50,7 +50,7 @@ from tools.workloads import TextModel, ragged_rows  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 KERNEL_NAMES = {"lookup_span": "lookup_span_kernel", "lookup_rows": "lookup_rows_kernel", "regex_split": "regex_sparse_kernel", "lookup_fused": "lookup_kernel<kFused>", "lookup_pieces": "lookup_kernel<kPieces>", "shard_pack": "shard_pack_kernel",
                 "shard_unpack": "shard_unpack_kernel", "scan_rows": "scan_kernel", "lookup_flat": "piece_lookup_kernel",
-                "lookup_words": "lookup_rows_kernel<BERT words>", "wordpiece_deferred": "wordpiece_deferred_kernel",
+                "lookup_words": "lookup_span_kernel<BERT words>", "wordpiece_deferred": "wordpiece_deferred_kernel",
                 "bpe_merge": "merge_kernel", "bpe_exact": "exact_kernel", "compact": "compact_kernel",
                 "prep_rows": "prep_rows_kernel", "count_scan": "count_scan_kernel", "split_count": "split_kernel<0>",
                 "split_write": "split_kernel<1>", "ragged_to_dense": "ragged_to_dense_kernel", "vocab_encoder": "vocab_encoder_kernel",
@@ -1135,9 +1135,8 @@ def main():
                  "fixed_memo_only": "zipf text with cache_capacity=1: the memo holds the vocabulary's own tokens and learns "
                                     "nothing from the text (every multi-token word is merged every time)",
                  "mixed_script_text": "config 4's text (30 % of the words Greek / Cyrillic / CJK / kana / emoji, rows of 700-1000 "
-                                      "bytes) through THIS tokenizer: rows with a non-ASCII byte leave lookup_span_kernel for "
-                                      "the generic lookup_kernel<kFused> (ballot scanner), and random non-Latin words never hit "
-                                      "the memo",
+                                      "bytes) through THIS tokenizer: blocks with a non-ASCII byte take the ballot form of the rules inside "
+                                      "lookup_span_kernel, and random non-Latin words never hit the memo",
                  "first_sight": "zipf text never encoded before: 20 timed batches, each seen for the first time, on a handle that has seen 4 others "
                                 "(the memo's learned part fills within the first batch, the piece store keeps learning)",
                  "rows_2048_bytes": "rows of ~2048 bytes (half of them longer than lookup_span_kernel's 2048-byte block: those take the generic kernel's windows)",

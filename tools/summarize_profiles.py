@@ -82,9 +82,12 @@ def main(prefix):
                 write = float(g[g.Counter_Name == "WRITE_SIZE"].mean_KB.sum())
                 per[tag_of(k)] = int((2 * fetch + write) * 1024)
             if cfg == 3:   # bench.py's name for the lookup kernel run with the BERT words scanner (lookup_rows_kernel since r03)
-                per["lookup_words"] = per.pop("lookup_rows") if "lookup_rows" in per else per.get("lookup_fused", 0)
+                per["lookup_words"] = per.pop("lookup_span") if "lookup_span" in per else (per.pop("lookup_rows") if "lookup_rows" in per else per.get("lookup_fused", 0))
             pmc_json[f"config{cfg}"] = per
-    (ROOT / "profiles" / "latest_pmc.json").write_text(json.dumps(pmc_json, indent=1, sort_keys=True) + "\n")
+    latest = ROOT / "profiles" / "latest_pmc.json"
+    if latest.exists():   # a run over some of the configurations (CONFIGS=3 ...) keeps the others' entries
+        pmc_json = {**json.loads(latest.read_text()), **pmc_json}
+    latest.write_text(json.dumps(pmc_json, indent=1, sort_keys=True) + "\n")
     print(json.dumps(pmc_json, indent=1))
 
 
