@@ -538,7 +538,8 @@ __device__ __forceinline__ bool bert_delimiter(uint32_t cp, uint32_t nibble) {
            (cp - 0x2B740u) < 0xE0u || (cp - 0x2B820u) < 0x1690u || (cp - 0xF900u) < 0x200u || (cp - 0x2F800u) < 0x220u;
 }
 // Piece starts and "dropped piece" flags of the window for the class patterns; lane w = window bytes [64w, 64w+64).
-__device__ __forceinline__ void class_start_mask(const WaveScratch& ws, const SplitDev& sp, int skew, int wlen, Mask& start,
+template <class WS>
+__device__ __forceinline__ void class_start_mask(const WS& ws, const SplitDev& sp, int skew, int wlen, Mask& start,
                                                  Mask& dropped) {
     const int l = lane_id();
     const uint8_t* t = text_bytes(ws) + skew;

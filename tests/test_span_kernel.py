@@ -116,6 +116,39 @@ def test_rows_left_to_the_generic_kernel(backend):
     fused_vs_oracle(backend, tok, rows_of(strings), skips=np.asarray(skips, np.uint8), what="mixed rows with skips")
 
 
+def _long_rows(rng):
+    """Rows longer than a scan block: ASCII, with non-ASCII text, with pieces longer than a block or a ballot window."""
+    jp = "日本語のテキストを分割する。".encode()
+    mixed = lambda n: b"".join((_filler(rng, int(rng.integers(5, 200))) + ("naïve café — ".encode() if rng.random() < 0.5 else jp)) for _ in range(n // 100 + 1))[:n].decode(errors="ignore").encode()   # (cut at a character boundary)
+    rows = [_filler(rng, 3000), _filler(rng, 5000), _filler(rng, 10000), _filler(rng, 2048 * 3), _filler(rng, 2048 * 2 + 8), _filler(rng, 2040 * 2),
+            mixed(3000), mixed(5000), mixed(9000), mixed(1024), mixed(1025), mixed(2047), mixed(2049),
+            b"a" * 3000, b" " * 5000, b"\n" * 2100 + b"x", "日".encode() * 1000, "日".encode() * 3000, b"7" * 4000, b"!" * 2048, b"!" * 2049,
+            _filler(rng, 700) + b"b" * 2500 + _filler(rng, 700), _filler(rng, 2040) + b"c" * 40 + _filler(rng, 100),
+            _filler(rng, 2030) + b" " * 30 + _filler(rng, 100), _filler(rng, 2041) + b"don't" + _filler(rng, 100),
+            _filler(rng, 100) + "é".encode() * 1200 + _filler(rng, 100), jp * 40 + b"d" * 1100 + jp * 3,
+            mixed(900) + b" " * 1500 + "ü".encode() + _filler(rng, 50), _filler(rng, 1500) + b"'" + b"l" * 3000, b"'" * 2500,
+            _filler(rng, 2044) + b"'ll " + _filler(rng, 50), _filler(rng, 2046) + b"'re" + _filler(rng, 50), b" " * 2047 + b"x", b" " * 2048 + b"x",
+            b"x" + b" " * 2047, b"x" * 2047 + b" ", mixed(2000) + "\U0001F600\U0001F601".encode() + _filler(rng, 300), "\U0001F600".encode() * 600]
+    return rows
+
+
+def test_rows_longer_than_a_block(backend):
+    """Rows of 2 049 .. 10 000 bytes slide through the kernel's blocks: every block stops at the last piece start it can decide.
+    Pieces longer than a block (3 000 letters, 5 000 blanks, 3 000 CJK characters, 4 000 digits) take the literal matcher and go
+    to the deferred list directly; blocks with non-ASCII text take the ballot form window by window."""
+    rng = np.random.default_rng(53)
+    long_rows = _long_rows(rng)
+    strings = []
+    for i in range(300):
+        strings.append(long_rows[(i // 3) % len(long_rows)] if i % 3 == 0 else _filler(rng, int(rng.integers(1, 300))))
+    tok = BpeTok.load("gpt2_small")
+    fused_vs_oracle(backend, tok, rows_of(strings), what="long rows")
+    fused_vs_oracle(backend, tok, rows_of(strings), pattern=DIGITS_PATTERN, what="long rows, digits variant")
+    # nothing but long rows, back to back (chains of them)
+    only = [long_rows[i % len(long_rows)] for i in range(290)]
+    fused_vs_oracle(backend, tok, rows_of(only), what="only long rows")
+
+
 def test_rows_that_are_not_contiguous(backend):
     """begins / ends that leave gaps, overlap, or run backwards through the chars tensor: no block may span such a seam."""
     rng = np.random.default_rng(13)
@@ -237,3 +270,28 @@ def test_bert_words_through_the_span_kernel(backend):
     for call in range(2):
         got = fused.evaluate(backend.data(inputs), ws_pat, pu_pat, wp_consts(tok))
         assert_same(ref, got, backend.host, f"BERT words, call {call}")
+
+
+def test_bert_long_rows(backend):
+    """BERT words of the fused WordPiece path over rows longer than a block, words longer than a block, white space runs longer
+    than a block (dropped), non-ASCII blocks."""
+    from openvino_tokenizers_amd.ops import FusedSplitWordpiece, WordpieceTokenizer
+    from tests.test_ops_parity import BERT_PUNCT, BERT_WS, bert_words, wp_consts
+    from tools.make_tokenizers import load_tokenizer
+    tok = load_tokenizer("bert_small")
+    rng = np.random.default_rng(59)
+    frag = ["the", "token", "izer", "un", "affable", "hello", "world", ",", ".", "!?", "(", " ", "  ", "\t", "\n", "don't", "e.g.", "naïve", "元気", "—", "straße"]
+    ascii_frag = [f for f in frag if f.isascii()]
+    text = lambda n, fr: " ".join(rng.choice(fr, size=n))[:n]
+    long_rows = [text(3000, ascii_frag), text(9000, ascii_frag), text(3000, frag), text(7000, frag), "a" * 3000, " " * 5000, "x" + " " * 4100 + "y",
+                 "," * 2500, "日" * 1500, text(2040, ascii_frag) + "w" * 50 + " z", text(2040, ascii_frag) + " " * 50 + "z", text(500, frag) + "é" * 1300 + " ok",
+                 text(1000, frag) + "\u3000" * 900 + text(100, frag), "q" * 2047 + ",", "q" * 2048 + ",", " " * 2048 + "," + " " * 2048]
+    strings = [long_rows[(i // 3) % len(long_rows)] if i % 3 == 0 else text(int(rng.integers(1, 300)), frag) for i in range(300)]
+    inputs = rows_of([s.encode() for s in strings])
+    ws_pat, pu_pat = np.frombuffer(BERT_WS.encode(), np.uint8), np.frombuffer(BERT_PUNCT.encode(), np.uint8)
+    ref = O.WordpieceTokenizer(tok["vocab"], tok["suffix_indicator"], tok["max_bytes_per_word"])(*bert_words(inputs), tok["unk_id"])
+    fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
+                                WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], lib=backend.lib))
+    for call in range(2):
+        got = fused.evaluate(backend.data(inputs), ws_pat, pu_pat, wp_consts(tok))
+        assert_same(ref, got, backend.host, f"BERT long rows, call {call}")
