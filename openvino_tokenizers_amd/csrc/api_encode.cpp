@@ -620,10 +620,14 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // (marked in row_used, listed in pending_rows) goes through the generic kernel
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
-                                   if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits)
-                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<kSpanGpt2Digits>, grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits && w1.stage16)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanGpt2Digits, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   else if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanGpt2Digits, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   else if (T.pieces.slots && w1.stage16)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanGpt2, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (T.pieces.slots)
-                                       OVTK_LAUNCH(ws.marks, "lookup_span", lookup_span_kernel<kSpanGpt2>, grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanGpt2, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (split->dev.kind == kSplitGpt2Digits)
                                        OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsGpt2Digits>, grid1, kBlockThreads, s, d_in,
                                                    split->dev, T, w1);
@@ -664,7 +668,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
                                   : split->dev.kind == kSplitLlama3 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>)
                                   : split->dev.kind <= kSplitGpt2Digits && !row_tickets().load(std::memory_order_relaxed)
-                                      ? resident_blocks_per_cu(lookup_span_kernel<kSpanGpt2>, 6)
+                                      ? resident_blocks_per_cu(lookup_span_kernel<kSpanGpt2, true>, 6)
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (pieces_ws) {

@@ -232,8 +232,11 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
                                if (!w.rows_per_ticket) {
                                    // several rows per scan block (span_kernel.hpp) where there is a word memo to probe
-                                   if (memo_only.pieces.slots)
-                                       OVTK_LAUNCH(ws.marks, "lookup_words", lookup_span_kernel<kSpanBertWords>, grid1, kBlockThreads, s, d_in, sp,
+                                   if (memo_only.pieces.slots && w1.stage16)
+                                       OVTK_LAUNCH(ws.marks, "lookup_words", (lookup_span_kernel<kSpanBertWords, true>), grid1, kBlockThreads, s, d_in, sp,
+                                                   memo_only, w1);
+                                   else if (memo_only.pieces.slots)
+                                       OVTK_LAUNCH(ws.marks, "lookup_words", (lookup_span_kernel<kSpanBertWords, false>), grid1, kBlockThreads, s, d_in, sp,
                                                    memo_only, w1);
                                    else
                                        OVTK_LAUNCH(ws.marks, "lookup_words", lookup_rows_kernel<kRowsBertWords>, grid1, kBlockThreads, s, d_in, sp,
@@ -253,7 +256,7 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                                unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
                            },
                            /*self_alloc=*/true,
-                           memo_only.pieces.slots ? resident_blocks_per_cu(lookup_span_kernel<kSpanBertWords>) : resident_blocks_per_cu(lookup_kernel<kFused>),
+                           memo_only.pieces.slots ? resident_blocks_per_cu(lookup_span_kernel<kSpanBertWords, true>) : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (h->n_vocab > 0 && h->n_vocab <= 65535 && unk_token_id >= 0 && unk_token_id <= 65534) r->enable_stage16();
     if (memo_only.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)

@@ -188,8 +188,9 @@ __host__ __device__ inline uint32_t piece_mix(uint64_t k0, uint64_t k1) {
     const uint32_t c1 = (d0 >> 24) | (d1 << 8), c2 = (d1 >> 16) | (d2 << 16);   // funnel shifts; bits above 24 are ignored
     uint32_t h = mul24(d0, 0x9E3779u) + mul24(c1, 0x85EBCBu) + mul24(c2, 0xC2B2AFu) + mul24(d2 >> 8, 0x27D4EBu) +
                  mul24(d3, 0x165667u) + mul24(d3 >> 8, 0xD6E8FFu);
-    // (two more stirring products were measured and dropped in round 3: they bought nothing the slot index needs)
-    return h ^ (h >> 15);
+    // (two more stirring products were measured and dropped in round 3, the closing h ^ (h >> 15) in round 4: the slot index is the
+    // sum's top bits, the tag only has to be a function of the key)
+    return h;
 }
 __host__ __device__ inline uint32_t piece_tag(uint32_t mix, int cnt) { return (mix & 0xFFFFFF00u) | 0x80u | uint32_t(cnt); }
 // A piece has ONE candidate entry (round 4): its 32-byte slot, two 16-byte loads at consecutive addresses, one key compare.
