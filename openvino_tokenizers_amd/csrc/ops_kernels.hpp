@@ -18,6 +18,8 @@ struct WordpieceDev {
     TrieDev root, sub;
     int32_t max_bytes;
     PieceStoreDev store;  // word -> ids of the words wordpiece_deferred_kernel had to walk the tries for (tables.hpp "piece store")
+    PieceTableDev memo;   // the fused path's first-level word memo (lookup_span_kernel probes it): wordpiece_deferred_kernel files
+                          // the short words it resolves there while memo.room lasts, so that they stop being deferred
 };
 
 // WordPiece of one word (wordpiece_tokenizer.cpp:100-126) into slot[0..): returns the id count (>= 1).
@@ -133,6 +135,11 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
     const int stride = int(gridDim.x) * kBlockThreads;
     const bool store_open = T.store.slots && wave_uniform(__hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > 0;
+    int32_t* my_room = nullptr;   // the word memo's room, looked at once (a look per batch was a memory round trip per batch)
+    if (T.memo.room) {
+        my_room = T.memo.room + ((blockIdx.x + 5u * blockIdx.y + uint32_t(wave_in_block())) & T.memo.room_mask) * kRoomStride;
+        if (wave_uniform(__hip_atomic_load(my_room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) my_room = nullptr;
+    }
     for (int base = (int(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kWave; base < count; base += stride) {
         const bool valid = base + l < count;
         DeferredPiece e{};
@@ -195,6 +202,29 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                 }
                 const int n_added = __popcll(__ballot(added));
                 if (l == 0 && n_added) atomicAdd(T.store.room, -n_added);
+            }
+        }
+        // The word memo learns them too (encode_kernels.hpp memo_insert, as merge_kernel does for the BPE pieces): a word of up to 15
+        // bytes and three ids that is not unk is a hit of the lookup kernel from the next call
+        // on, and no longer crosses the deferred list at all.  One atomic per wave takes the room.
+        if (my_room) {
+            // (not the words the store knew: they were offered to the memo when they were walked, and found their slot taken)
+            const bool keep = valid && !stored && e.len >= 1 && e.len <= kPieceKeyBytes && cnt >= 1 && cnt <= kPieceMaxIds &&
+                              !(cnt == 1 && out.get(0) == unk_id);
+            const unsigned long long km = __ballot(keep);
+            if (km) {
+                int left = 0;
+                if (l == 0) left = atomicAdd(my_room, -int(__popcll(km)));
+                left = wave_readlane(left, 0);
+                bool added = false;
+                if (keep && rank_below(km) < left) {
+                    int32_t t3[kPieceMaxIds];
+#pragma unroll
+                    for (int k = 0; k < kPieceMaxIds; ++k) t3[k] = k < cnt ? out.get(k) : 0;
+                    added = memo_insert(T.memo, e.k0, e.k1, t3, cnt);
+                }
+                const int unused = __popcll(km) - __popcll(__ballot(added));  // room taken but not filled goes back
+                if (l == 0 && unused) atomicAdd(my_room, unused);
             }
         }
         const int incl = wave_incl_sum(cnt);

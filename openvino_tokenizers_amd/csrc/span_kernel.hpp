@@ -29,6 +29,8 @@ namespace ovtk {
 constexpr int kSpanLane = 32;                    // text bytes per lane
 constexpr int kSpanDwords = kSpanLane / 4;
 constexpr int kSpanBytes = kWave * kSpanLane;    // bytes per block
+// an entry of the piece list (BERT words; the GPT-2 family's entries are positions and nothing else)
+constexpr uint32_t kSpanPosMask = 0x0FFFu, kSpanOneBefore = 0x4000u, kSpanDropped = 0x8000u;
 constexpr int kSpanMiss = 48;                    // misses noted per wave before they are written out
 
 struct SpanMiss {
@@ -540,6 +542,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
             // ---- the block's piece list: np pieces, the last one ends at q_end (= where the next block starts); rowfirst: the list
             // index of my row's first piece, if that is one of them
             int np = 0, q_end = 0, rowfirst = 0x7FFFFFFF;
+            uint32_t end_flag = 0;   // BERT words: the sentinel's kSpanOneBefore (below)
 #if defined(OVTK_SPAN_ABLATE) && OVTK_SPAN_ABLATE >= 3
             if (fast) {
                 q_end = b_len - (at_end ? 0 : kSpanHalo);
@@ -547,6 +550,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
 #endif
             if (fast) {
                 q_end = b_len;
+                const uint32_t fl_all = fl;
                 if (!at_end) {   // the last start the block can decide ends its last whole piece
                     const int dk = b_len - kSpanHalo - kSpanLane * l;
                     fl &= dk >= kSpanLane ? ~0u : (dk <= 0 ? 0u : ((1u << dk) - 1u));
@@ -557,6 +561,18 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                     fl &= qk >= kSpanLane ? ~0u : (qk <= 0 ? 0u : ((1u << qk) - 1u));
                 }
                 if (q_end > 0) {
+                    // BERT words: the one blank between two words is most of the dropped pieces, and half of all pieces.  A white-space
+                    // piece of one byte with a word or delimiter in front of it gets no entry; the entry behind it says so
+                    // (kSpanOneBefore: the piece in front ends one byte early).  `dropped` = the white-space bytes.
+                    uint32_t one_before = 0;
+                    if (BERT) {
+                        const uint32_t s_prev = (dropped << 1) | (lane_prev(dropped) >> 31);
+                        const uint32_t f_next = (fl_all >> 1) | (lane_next(fl_all) << 31);   // (fl_all: the flags before q_end cut them)
+                        const uint32_t omit = fl_all & dropped & ~s_prev & f_next;
+                        one_before = (omit << 1) | (lane_prev(omit) >> 31);
+                        fl &= ~omit;
+                        if (q_end < kSpanBytes) end_flag = (uint32_t(wave_readlane(int(one_before), q_end >> 5)) >> (q_end & 31)) & 1u;
+                    }
                     const int cnt = __popc(fl);
                     const int p_incl = wave_incl_sum(cnt);
                     const int at0 = p_incl - cnt;
@@ -566,7 +582,9 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                         uint16_t* at = sw.pstart + at0;
                         while (f) {
                             const int bit = __ffs(f) - 1;
-                            *at++ = uint16_t((kSpanLane * l + bit) | (BERT && ((dropped >> bit) & 1u) ? kPieceDropped : 0));
+                            uint32_t e = uint32_t(kSpanLane * l + bit);
+                            if (BERT) e |= (((dropped >> bit) & 1u) ? kSpanDropped : 0u) | (((one_before >> bit) & 1u) ? kSpanOneBefore : 0u);
+                            *at++ = uint16_t(e);
                             f &= f - 1;
                         }
                     }
@@ -613,7 +631,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                         const Mask m = wave_readlane(start, wd);
                         const Mask dm = BERT ? wave_readlane(drop, wd) : 0ull;
                         if ((m >> l) & 1ull)
-                            sw.pstart[np + rank_below(m)] = uint16_t((a + wd * 64 + l) | (((dm >> l) & 1ull) ? kPieceDropped : 0));
+                            sw.pstart[np + rank_below(m)] = uint16_t((a + wd * 64 + l) | (((dm >> l) & 1ull) ? kSpanDropped : 0u));
                         np += __popcll(m);
                     }
                     a += q;
@@ -650,7 +668,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
 #if defined(OVTK_SPAN_ABLATE)   // (1: without the lookup rounds; 2: and without the scan; 3: and without the piece list)
             np = 0;
 #endif
-            if (l < 2) sw.pstart[np + l] = uint16_t(q_end);   // (two of them: lane j >= np reads a piece of no bytes)
+            if (l < 2) sw.pstart[np + l] = uint16_t(uint32_t(q_end) | (l == 0 ? end_flag * kSpanOneBefore : 0u));   // (two: lane j >= np reads a piece of no bytes)
             // ---- the next block's text: in flight while this block's pieces are looked up
             {
                 const int nx = pos + q_end;
@@ -666,8 +684,9 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 const int j = jb + l < np ? jb + l : np;
                 const uint32_t pp = reinterpret_cast<const Bytes4*>(sw.pstart + j)->v;
                 if (BERT) {
-                    q.ps = int(pp & kPiecePosMask);
-                    q.plen = (pp & kPieceDropped) ? 0 : int((pp >> 16) & kPiecePosMask) - q.ps;   // (a dropped piece: nothing to look up)
+                    q.ps = int(pp & kSpanPosMask);
+                    const int end = int((pp >> 16) & kSpanPosMask) - int((pp >> 30) & 1u);   // (kSpanOneBefore of the next entry)
+                    q.plen = (pp & kSpanDropped) ? 0 : end - q.ps;   // (a dropped piece: nothing to look up)
                 } else {
                     q.ps = int(pp & 0xFFFFu);
                     q.plen = int(pp >> 16) - q.ps;
@@ -740,6 +759,10 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 resolve(qb, jb + kWave);
             }
             if (jb < np) resolve(qa, jb);
+            if (BERT && rowfirst == np) {   // a row whose pieces in this block got no entry (blanks): its records are the sums behind the list
+                rec_stage = cursor;
+                rec_cnt = emitted;
+            }
             pos += q_end;
             SPAN_T(5);
         }

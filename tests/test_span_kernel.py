@@ -253,6 +253,8 @@ def test_bert_words_through_the_span_kernel(backend):
             s = "   \t\n  " * int(rng.integers(1, 9))
         elif r == 12:
             s = ",.;:!?" * int(rng.integers(1, 30))
+        elif r == 10:
+            s = [" ", "\t", " ,", ", ", "x ", " x", "  "][i % 7]   # (a blank between two words gets no entry in the piece list)
         elif r == 13:
             s = "naïve café 元気 — " + "".join(rng.choice(frag, size=6))
         elif r == 14:
@@ -295,3 +297,26 @@ def test_bert_long_rows(backend):
     for call in range(2):
         got = fused.evaluate(backend.data(inputs), ws_pat, pu_pat, wp_consts(tok))
         assert_same(ref, got, backend.host, f"BERT long rows, call {call}")
+
+
+def test_bert_row_whose_only_piece_in_a_block_is_an_omitted_blank(backend):
+    """The piece list of the BERT words leaves out the one blank between two words.  Row B starts with such a blank, one byte in front
+    of where block 0 stops (its last decided piece start), behind exactly 640 entries: B's first piece of that block is `entry 640`
+    of 640 -- no lane of any lookup round holds it."""
+    from openvino_tokenizers_amd.ops import FusedSplitWordpiece, WordpieceTokenizer
+    from tests.test_ops_parity import BERT_PUNCT, BERT_WS, bert_words, wp_consts
+    from tools.make_tokenizers import load_tokenizer
+    tok = load_tokenizer("bert_small")
+    rng = np.random.default_rng(61)
+    for n_words in (640, 639, 641, 576):
+        a = "ab " * (n_words - 1) + "q" * (2025 - 3 * (n_words - 1))
+        b = " " + "c" * 30 + " the end"
+        assert len(a) == 2025
+        strings = [a, b] + [" ".join(rng.choice(["the", "token", "izer", ","], size=int(rng.integers(1, 40)))) for _ in range(300)]
+        inputs = rows_of([x.encode() for x in strings])
+        ws_pat, pu_pat = np.frombuffer(BERT_WS.encode(), np.uint8), np.frombuffer(BERT_PUNCT.encode(), np.uint8)
+        ref = O.WordpieceTokenizer(tok["vocab"], tok["suffix_indicator"], tok["max_bytes_per_word"])(*bert_words(inputs), tok["unk_id"])
+        fused = FusedSplitWordpiece(RegexSplit("remove", lib=backend.lib), RegexSplit("isolate", lib=backend.lib),
+                                    WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], lib=backend.lib))
+        got = fused.evaluate(backend.data(inputs), ws_pat, pu_pat, wp_consts(tok))
+        assert_same(ref, got, backend.host, f"{n_words} entries in front of the blank")
