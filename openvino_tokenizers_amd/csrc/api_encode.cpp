@@ -604,6 +604,9 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // consecutive rows per wave (lookup_rows_kernel); what it leaves goes through the generic kernel
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
+                                   // (lookup_span_kernel with the Llama-3 scanners window by window was measured in round 4 -- 470 us against
+                                   // this kernel's 360: a 2 048-byte block cuts the rows into more, emptier windows than one row at a time,
+                                   // and the scanner's cost is per window; profiles/r04/experiments/llama3_on_span_kernel.patch)
                                    OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsLlama3>, grid1, kBlockThreads, s, d_in, split->dev,
                                                T, w1);
                                    EncodeWork w2 = w;

@@ -320,3 +320,38 @@ def test_bert_row_whose_only_piece_in_a_block_is_an_omitted_blank(backend):
                                     WordpieceTokenizer(tok["suffix_indicator"], tok["max_bytes_per_word"], lib=backend.lib))
         got = fused.evaluate(backend.data(inputs), ws_pat, pu_pat, wp_consts(tok))
         assert_same(ref, got, backend.host, f"{n_words} entries in front of the blank")
+
+
+def _l3_rows(rng, n):
+    """Rows for the Llama-3 family: digit runs of every length, line breaks inside white space, contractions in both cases,
+    non-ASCII letters / digits / white space, U+017F, rows cut at any byte of those."""
+    frag = ["the", "Token", "izer", " ", "  ", "\n", " \n", "\n\n", "\r\n", " \n  ", "\t", "1", "12", "123", "1234", "12345678", "1234567890123", "3.14", "don't", "DON'T", "we'LL",
+            "I'm", "'s", "'", "''re", "!?", "--", "(x)", "e.g.", "naïve", "straße", "Ωμέγα", "привет", "日本語", "テキスト", "😀", "١٢٣", "ſ", "\u00a0", "\u3000", "a1b2", "x ", " y",
+            "#include <stdio.h>\n", "    return 0;\n}\n", "http://a.b/c?d=1&e=2"]
+    rows = []
+    for i in range(n):
+        k = int(rng.integers(1, 60)) if i % 7 else int(rng.integers(150, 500))
+        t = "".join(rng.choice(frag, size=k))
+        if i % 5 == 0:
+            t = t[: int(rng.integers(1, len(t) + 1))]
+        rows.append(t.encode())
+    return rows
+
+
+@pytest.mark.parametrize("name", ["llama3", "qwen2", "cl100k"])
+def test_llama3_family_long_and_ragged_rows(backend, name):
+    """The Llama-3 family through the fused encode (lookup_rows_kernel<kRowsLlama3>: llama3_packed_starts, the ballot form where that
+    one declines -- long digit runs, many line breaks --, the literal matcher where neither decides -- non-ASCII digits, U+017F):
+    the same rows as the span kernel's tests, rows of any length, pieces longer than a window.  (Round 4 ran these through
+    lookup_span_kernel with the Llama-3 scanners window by window: bit-exact, but slower than a row at a time)"""
+    from tools.workloads import MODEL_PATTERNS
+    tok = BpeTok.load("llama3_small")
+    pattern = MODEL_PATTERNS.get(name, tok.pattern)
+    rng = np.random.default_rng(67)
+    fused_vs_oracle(backend, tok, rows_of(_l3_rows(rng, 300)), pattern=pattern, what=f"{name}: fragments")
+    b, e, c = TextModel(43, "mixed").batch(300, 700)
+    rb, re_ = ragged_rows(300)
+    fused_vs_oracle(backend, tok, [rb, re_, b, e, c], pattern=pattern, what=f"{name}: mixed text, rows of ~700 bytes")
+    long_rows = _long_rows(rng) + [b"1" * 3000, b"\n" * 3000, b" \n" * 1200 + b"x", ("é" * 900 + " ").encode() * 3, b"9" * 600 + b" " + b"8" * 700]
+    strings = [long_rows[(i // 3) % len(long_rows)] if i % 3 == 0 else _filler(rng, int(rng.integers(1, 300))) for i in range(300)]
+    fused_vs_oracle(backend, tok, rows_of(strings), pattern=pattern, what=f"{name}: long rows")
