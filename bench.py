@@ -1136,11 +1136,11 @@ def main():
                                     "nothing from the text (every multi-token word is merged every time)",
                  "mixed_script_text": "config 4's text (30 % of the words Greek / Cyrillic / CJK / kana / emoji, rows of 700-1000 "
                                       "bytes) through THIS tokenizer: blocks with a non-ASCII byte take the ballot form of the rules inside "
-                                      "lookup_span_kernel, and random non-Latin words never hit the memo",
+                                      "lookup_span_kernel (window by window), and random non-Latin words never hit the memo: half of the step is merge_kernel",
                  "first_sight": "zipf text never encoded before: 20 timed batches, each seen for the first time, on a handle that has seen 4 others "
                                 "(the memo's learned part fills within the first batch, the piece store keeps learning)",
-                 "rows_2048_bytes": "rows of ~2048 bytes (half of them longer than lookup_span_kernel's 2048-byte block: those take the generic kernel's windows)",
-                 "rows_8192_bytes": "rows of ~8192 bytes: every row goes through the generic kernel, 768-byte windows",
+                 "rows_2048_bytes": "rows of ~2048 bytes: lookup_span_kernel's 2048-byte blocks slide along the row (a block starts where the one before stopped)",
+                 "rows_8192_bytes": "rows of ~8192 bytes: four to five sliding blocks of lookup_span_kernel per row",
                  "pattern_qwen2": "Qwen2's pattern (\\p{N} for \\p{N}{1,3}): the Llama-3 scanners with l3_digits1",
                  "pattern_cl100k": "tiktoken's cl100k_base pattern (possessive, \\s++$): the Llama-3 scanners with l3_tail_ws",
                  "pattern_o200k": "o200k_base's pattern: the compiled DFA, one pass inside the fused encode (regex_sparse_kernel), lookup_kernel<kPieces> behind it",
