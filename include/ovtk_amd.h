@@ -181,7 +181,9 @@ int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned);
  * this library, not by cache_capacity: that attribute bounds the host memory of the reference's std::string cache, an entry
  * here is 64 bytes of HBM.  cache_capacity == 0 still means "no memo at all".  `entries`: capacity of the store of handles
  * created afterwards (default 1048576, and never more than four entries per vocabulary token; 0 = no store: the memo is then exactly the reference's cache_capacity entries).
- * Process-wide; ovtk_bpe_store_entries reports a handle's count (waits for the device). */
+ * A setting of the CALLING THREAD (the handles it creates afterwards); memory: 3 x 64 bytes per entry of capacity, rounded up to a
+ * power of two (GPT-2: 64 MB, Llama-3: 128 MB), allocated and cleared at create; ovtk_bpe_store_entries reports a handle's count
+ * and capacity (waits for the device). */
 int ovtk_set_memo_store(int64_t entries);
 int ovtk_bpe_store_entries(ovtk_bpe* h, int64_t* stored, int64_t* capacity);
 

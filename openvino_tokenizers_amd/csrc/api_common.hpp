@@ -38,10 +38,11 @@ inline int use_device(int device) {
 
 inline StringsView view_of(const ovtk_strings& s) { return StringsView{s.begins, s.ends, s.chars, s.n}; }
 
-// Entries the piece store (tables.hpp) of handles created from now on may take; 0: no store.  Process-wide, like
-// ovtk_set_row_tickets: the reference's attribute list has no room for it (cache_capacity keeps its meaning: 0 = no memo at all).
-inline std::atomic<int64_t>& memo_store_entries() {
-    static std::atomic<int64_t> v{1048576};
+// Entries the piece store (tables.hpp) of the handles THIS THREAD creates from now on may take; 0: no store.  The reference's
+// attribute list has no room for it (cache_capacity keeps its meaning: 0 = no memo at all), so it is a setting of the creating
+// thread: a create on another thread never sees a value somebody else is in the middle of changing.
+inline int64_t& memo_store_entries() {
+    static thread_local int64_t v = 1048576;
     return v;
 }
 // A handle's piece store: the table (zeroed), its room counter, the device view.  A piece's two candidate slots are the
@@ -51,7 +52,7 @@ inline std::atomic<int64_t>& memo_store_entries() {
 inline int alloc_piece_store(DevBuf& table, DevBuf& room, int64_t vocab_n, bool narrow, PieceStoreDev& dev, int32_t& capacity) {
     dev = PieceStoreDev{nullptr, 30, nullptr, 0};
     capacity = 0;
-    const int64_t want = std::min<int64_t>({memo_store_entries().load(std::memory_order_relaxed), int64_t(1) << 22,
+    const int64_t want = std::min<int64_t>({memo_store_entries(), int64_t(1) << 22,
                                             std::max<int64_t>(8192, 4 * vocab_n)});
     if (want <= 0) return OVTK_OK;
     const uint32_t slots = std::max<uint32_t>(1024, pow2_at_least(uint64_t(want) * 3));

@@ -407,7 +407,7 @@ int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned) {
 
 int ovtk_set_memo_store(int64_t entries) {
     if (entries < 0 || entries > (int64_t(1) << 22)) return set_error(OVTK_E_ARG, "memo store: 0 (off) .. 4194304 entries");
-    memo_store_entries().store(entries, std::memory_order_relaxed);
+    memo_store_entries() = entries;
     return OVTK_OK;
 }
 
