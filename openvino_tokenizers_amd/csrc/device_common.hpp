@@ -39,6 +39,7 @@ struct RunStatus {
     int32_t stage_top[kShards * kCounterStride];    // [s * kCounterStride] = staging entries handed out in region s
     int32_t row_ticket[kShards * kCounterStride];   // [s * kCounterStride] = rows of range s handed to waves (lookup_kernel)
     int32_t batch_ticket[kShards * kCounterStride]; // [s * kCounterStride] = 64-piece batches of shard s handed out (merge_kernel)
+    uint32_t done_ticket[kShards * kCounterStride]; // [s * kCounterStride] = blocks of shard s that are through (last_block_done_sharded)
 };
 constexpr uint32_t kFlagItemsOverflow = 1u;     // more work items than the workspace holds
 constexpr uint32_t kFlagStageOverflow = 2u;     // staging buffer too small

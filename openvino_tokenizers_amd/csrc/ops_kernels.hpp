@@ -121,25 +121,32 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                                                                                  EncodeWork w, int tail_rows, long long out_cap) {
     __shared__ I2 root_lds[256];
     __shared__ I2 sub_lds[256];
+    // Everything the kernel has to know before it can start, asked for together: most of its blocks find no batch, and the ones
+    // that do are one chain of memory round trips from here to their ticket -- five of them used to stand in front of the first
+    // word (the tables' roots, the flags, the shard's count, the store's room, the memo's room: one wait each).
+    const int l = lane_id();
+    const int shard = int(blockIdx.y);
+    const uint32_t flags0 = __hip_atomic_load(&w.status->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int count = __hip_atomic_load(&w.status->shard_count[shard * kCounterStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int store_room = T.store.slots ? __hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    int32_t* my_room = nullptr;   // the word memo's room, looked at once (a look per batch was a memory round trip per batch)
+    int memo_room = 0;
+    if (T.memo.room) {
+        my_room = T.memo.room + ((blockIdx.x + 5u * blockIdx.y + uint32_t(wave_in_block())) & T.memo.room_mask) * kRoomStride;
+        memo_room = __hip_atomic_load(my_room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) {
         root_lds[i] = T.root.root[i];
         sub_lds[i] = T.sub.root[i];
     }
     __syncthreads();
-    if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
+    if (flags0 & (kFatalFlags | kFlagDeferOverflow)) return;
     if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows);
-    const int l = lane_id();
-    const int shard = int(blockIdx.y);
-    int count = w.status->shard_count[shard * kCounterStride];
     if (count > w.shard_cap) count = w.shard_cap;
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
     const int stride = int(gridDim.x) * kBlockThreads;
-    const bool store_open = T.store.slots && wave_uniform(__hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > 0;
-    int32_t* my_room = nullptr;   // the word memo's room, looked at once (a look per batch was a memory round trip per batch)
-    if (T.memo.room) {
-        my_room = T.memo.room + ((blockIdx.x + 5u * blockIdx.y + uint32_t(wave_in_block())) & T.memo.room_mask) * kRoomStride;
-        if (wave_uniform(__hip_atomic_load(my_room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) <= 0) my_room = nullptr;
-    }
+    const bool store_open = wave_uniform(store_room) > 0;
+    if (wave_uniform(memo_room) <= 0) my_room = nullptr;
     for (int base = (int(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kWave; base < count; base += stride) {
         const bool valid = base + l < count;
         DeferredPiece e{};
@@ -239,7 +246,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
     }
     if (tail_rows <= 0) return;
     __syncthreads();
-    if (!last_block_done(&w.status->ticket[0], gridDim.x * gridDim.y, /*release=*/false)) return;  // only atomics to hand over
+    if (!last_block_done_sharded(w.status, int(blockIdx.y), gridDim.x, /*release=*/false)) return;  // only atomics to hand over (grid: blocks per shard x kShards)
     scan_tiles_one_block(tail_rows, w, out_cap);
 }
 
