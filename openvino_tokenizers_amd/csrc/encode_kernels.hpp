@@ -363,6 +363,24 @@ __device__ __forceinline__ int store_lookup(const PieceStoreDev& S, const uint32
         }
         any = any || m;
     }
+    // the lines behind a full one (tables.hpp kStoreOverflow): rare, one more round trip each, for the lanes concerned
+    bool full = !any;
+#pragma unroll
+    for (int c = 0; c < kStoreWays; ++c) full = full && k1[c].w != 0u;
+    for (int step = 1; step <= kStoreOverflow && full; ++step) {   // (a lane's own loop: callers sit in divergent code)
+#pragma unroll
+        for (int c = 0; c < kStoreWays; ++c) {
+            const uint4* e = reinterpret_cast<const uint4*>(S.slots + store_h_next(store_h(mix, c, S.shift), step, S.shift));
+            const uint4 a = e[0], b = e[1];
+            if (!any && store_key_eq(a, b, key)) {
+                any = true;
+                q0 = e[2];
+                q1 = e[3];
+            }
+            full = full && b.w != 0u;
+        }
+        full = full && !any;
+    }
     pay[0] = q0.x; pay[1] = q0.y; pay[2] = q0.z; pay[3] = q0.w;
     pay[4] = q1.x; pay[5] = q1.y; pay[6] = q1.z; pay[7] = q1.w;
     if (!any) return -1;
@@ -390,20 +408,22 @@ __device__ __forceinline__ bool store_insert(const PieceStoreDev& S, const uint3
     else pay[7] = store_tag32(pay, cnt);
     const uint32_t mix = store_mix(key);
     uint32_t* slot = nullptr;
+    for (int step = 0; step <= kStoreOverflow && !slot; ++step) {   // the piece's line, then the lines behind it while they are full
 #pragma unroll
-    for (int c = 0; c < kStoreWays; ++c) {
-        if (slot) break;
-        uint32_t* cand = reinterpret_cast<uint32_t*>(S.slots + store_h(mix, c, S.shift));
-        const uint32_t old = atomicCAS(cand + 7, 0u, kPieceBusy);
-        if (old == 0u) {
-            slot = cand;
-        } else if (old == kPieceBusy) {
-            return false;
-        } else if (old == key[7]) {   // same length (and tail): this very piece?  (only then are its other dwords read)
-            bool same = true;
+        for (int c = 0; c < kStoreWays; ++c) {
+            if (slot) break;
+            uint32_t* cand = reinterpret_cast<uint32_t*>(S.slots + store_h_next(store_h(mix, c, S.shift), step, S.shift));
+            const uint32_t old = atomicCAS(cand + 7, 0u, kPieceBusy);
+            if (old == 0u) {
+                slot = cand;
+            } else if (old == kPieceBusy) {
+                return false;
+            } else if (old == key[7]) {   // same length (and tail): this very piece?  (only then are its other dwords read)
+                bool same = true;
 #pragma unroll
-            for (int j = 0; j < 7; ++j) same = same && __hip_atomic_load(cand + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[j];
-            if (same) return false;
+                for (int j = 0; j < 7; ++j) same = same && __hip_atomic_load(cand + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[j];
+                if (same) return false;
+            }
         }
     }
     if (!slot) return false;

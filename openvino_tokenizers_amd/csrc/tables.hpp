@@ -127,6 +127,16 @@ constexpr int kStoreWays = 2;  // candidate slots of a piece: the two halves of 
 __host__ __device__ inline uint32_t store_h(uint32_t mix, int which, uint32_t shift) {  // shift = 32 - log2(lines)
     return (((mix * 0x2C1B3C6Du) >> shift) << 1) | uint32_t(which);
 }
+// A piece whose line is full goes to the first of the next kStoreOverflow lines that has room, and a lookup follows it there --
+// but only past lines it has seen FULL (entries never leave: a line with a free slot ends the search).  Nearly every lookup is still
+// the one line; what this buys is that no piece is left without a place: at a table a tenth full one insert in a hundred found its
+// line taken, and every later call sent exactly those pieces down the slow path -- a dozen dependent probes of one lane, which
+// is what merge_kernel and wordpiece_deferred_kernel then took as a whole (round 4).
+constexpr int kStoreOverflow = 3;
+__host__ __device__ inline uint32_t store_h_next(uint32_t slot, int step, uint32_t shift) {  // slot `which` of the step-th line behind slot's
+    const uint32_t lines = 1u << (32u - shift);
+    return ((((slot >> 1) + uint32_t(step)) & (lines - 1u)) << 1) | (slot & 1u);
+}
 // tag of a payload: valid bit | id count | checksum of the ids (a payload that is not completely there does not pass)
 __host__ __device__ inline uint32_t store_fold(const uint32_t (&pay)[8], bool narrow) {
     uint32_t x = pay[0] ^ pay[1] * 3u ^ pay[2] * 5u ^ pay[3] * 7u ^ pay[4] * 11u ^ pay[5] * 13u ^ pay[6] * 17u ^
