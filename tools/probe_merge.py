@@ -14,7 +14,7 @@ import bench
 lib = L.load(ROOT / "tools" / "build" / "libovtk_probe.so")
 ap = argparse.ArgumentParser(); ap.add_argument("--config", default="2"); ap.add_argument("--no-memo", action="store_true")
 a = ap.parse_args()
-args = SimpleNamespace(config=a.config, tokenizer="gpt2", text="zipf", rows=65536 if a.config != "4" else 131072, bytes=512, batches=4, no_memo=a.no_memo)
+args = SimpleNamespace(config=a.config, tokenizer="gpt2", text="zipf", rows=65536 if a.config != "4" else 131072, bytes=512, batches=4, no_memo=a.no_memo, pattern=None, cache_capacity=None)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 wl = bench.make_workload(args, lib, dev, 0)
@@ -41,4 +41,6 @@ for i in range(4):
     m = live & (ts[:, 8] > 0)
     print(f"batch {i}: waves {live.sum()}; start {stat(0)}; folded {stat(1)}; out of the batch loop {stat(4)}\n"
           f"  per wave, summed over its batches: entries + symbols (F) {phase(2)}; merges (F) {phase(3)}; path L {phase(10)}; path W {phase(11)}\n"
-          f"  largest symbol count per wave p50 {np.median(ts[m, 8])}; merge steps per wave (last batch) p50 {np.median(ts[m, 9])} max {ts[m, 9].max()}")
+          + (f"  largest symbol count per wave p50 {np.median(ts[m, 8])}; merge steps per wave (last batch) p50 {np.median(ts[m, 9])} max {ts[m, 9].max()}"
+             if m.any() else "  no wave had anything to merge: every deferred piece was in the store")
+          + f"\n  tail (last block): start {stat(5)}; scan done {stat(6)}")
