@@ -119,7 +119,7 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     if (int rc = h->memo_room.upload(rooms.data(), rooms.size() * sizeof(int32_t))) return rc;
     h->memo_capacity = room;
     OVTK_HIP(hipStreamSynchronize(nullptr));
-    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), room_mask};
+    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), room_mask, 0};
     h->memo_entries = host.stored;
     // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.
     if (int rc = alloc_piece_store(h->store, h->store_room, V, h->narrow_ids, h->dev.store, h->store_capacity)) return rc;
@@ -372,7 +372,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     d.trie.edge_shift = host.trie.edge_shift;
     d.merges = h->merges.as<MergeBucket>();
     d.bucket_shift = host.bucket_shift;
-    d.pieces = PieceTableDev{nullptr, 30, nullptr, 0};
+    d.pieces = PieceTableDev{nullptr, 30, nullptr, 0, 0};
     d.store = PieceStoreDev{nullptr, 30, nullptr, 0};
     d.new_id = h->new_id.as<int32_t>();
     d.byte_fallback_id = h->bf.as<int32_t>();

@@ -97,7 +97,7 @@ struct ovtk_wordpiece {
     TrieBufs root, sub;
     DevBuf memo_buf, memo_room, store, store_room;
     int32_t store_capacity = 0;
-    PieceTableDev memo{nullptr, 30, nullptr, 0};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
+    PieceTableDev memo{nullptr, 30, nullptr, 0, 0};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
     int64_t n_vocab = 0;   // ids are vocabulary indices: below 65535 (and unk_token_id too), a call stages u16 entries
 };
 
@@ -150,21 +150,22 @@ int ovtk_wordpiece_create(const ovtk_wordpiece_params* p, ovtk_wordpiece** out) 
         ovtk_ragged_i32_out o{ob.data(), oe.data(), ids.data(), cap, 0, 0};
         const int32_t marker = INT32_MIN + 1;  // stands for unk while the memo is built
         if (int rc = ovtk_wordpiece_run(h.get(), &in, marker, &o, OVTK_MEM_HOST, nullptr)) return rc;
-        for (size_t i = 0; i < V; ++i)  // drop the words that produced unk (an entry with 4+ ids is never stored)
+        const bool packed6 = p->vocab.n <= 65535;   // ids are vocabulary indices: six u16 ids per memo entry instead of three i32
+        for (size_t i = 0; i < V; ++i)  // drop the words that produced unk (an entry with more ids than the table takes is never stored)
             for (int32_t k = ob[i]; k < oe[i]; ++k)
-                if (ids[size_t(k)] == marker) { oe[i] = ob[i] + kPieceMaxIds + 1; break; }
+                if (ids[size_t(k)] == marker) { oe[i] = ob[i] + kPieceMaxIds6 + 1; break; }
         // ... and room for as many words again that the text brings along (up to three ids, up to 15 bytes: wordpiece_deferred_kernel
         // files them the first time it resolves them; the reference has no counterpart -- it walks its tries for every word,
         // wordpiece_tokenizer.cpp:94-130 -- and the result is the same function of the word either way)
-        const int32_t learn = int32_t(std::min<int64_t>(std::max<int64_t>(p->vocab.n, 32768), 1 << 20));
+        const int32_t learn = int32_t(std::min<int64_t>(std::max<int64_t>(4 * p->vocab.n, 32768), 1 << 20));   // (as many as the word store may hold: a lexicon has more words of several pieces than the vocabulary has words)
         PieceTableHost host;
-        build_piece_table(view_of(p->vocab), ob.data(), oe.data(), ids.data(), host, size_t(learn));
+        build_piece_table(view_of(p->vocab), ob.data(), oe.data(), ids.data(), host, size_t(learn), packed6);
         if (int rc = h->memo_buf.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
         std::vector<int32_t> rooms(size_t(kRoomShards) * kRoomStride, 0);
         for (int k = 0; k < kRoomShards; ++k) rooms[size_t(k) * kRoomStride] = learn / kRoomShards + (k < learn % kRoomShards ? 1 : 0);
         if (int rc = h->memo_room.upload(rooms.data(), rooms.size() * sizeof(int32_t))) return rc;
         OVTK_HIP(hipStreamSynchronize(nullptr));
-        h->memo = PieceTableDev{h->memo_buf.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), uint32_t(kRoomShards - 1)};
+        h->memo = PieceTableDev{h->memo_buf.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), uint32_t(kRoomShards - 1), packed6 ? 1u : 0u};
         h->dev.memo = h->memo;
         // the words the fused path has to walk the tries for are filed in a store of the handle's own (tables.hpp "piece store")
         if (int rc = alloc_piece_store(h->store, h->store_room, p->vocab.n, p->vocab.n <= 65535, h->dev.store, h->store_capacity)) return rc;
@@ -1248,3 +1249,16 @@ int ovtk_encode_tail_run(const ovtk_encode_tail_params* p, int32_t* out_ids, uin
 }
 
 }  // extern "C"
+
+#ifdef OVTK_PROBE
+// tools/probe_deferred.py: the wave clocks of wordpiece_deferred_kernel (this translation unit's copy of g_ts; a debug build only).
+extern "C" __attribute__((visibility("default"))) int ovtk_debug_probe_ops(unsigned long long* out, int reset) {
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ts), sizeof(unsigned long long) * 8192 * 12);
+    if (reset) {
+        void* p = nullptr;
+        (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_ts));
+        (void)hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 12);
+    }
+    return 0;
+}
+#endif

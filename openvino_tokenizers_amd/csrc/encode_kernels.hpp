@@ -271,7 +271,9 @@ __device__ __forceinline__ MemoFetch memo_fetch(const PieceTableDev& P, uint64_t
 #endif
     return f;
 }
-__device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
+// (P.packed6 tables -- the word memo of the fused WordPiece path -- hold up to six u16 ids per entry; the kernels that come through
+// here take the entries of up to three and leave the longer ones to the deferred path: lookup_span_kernel reads all six.)
+__device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds], bool packed6 = false) {
     const uint32_t a = uint32_t(k0), b = uint32_t(k0 >> 32), c = uint32_t(k1), d = uint32_t(k1 >> 32);
     // the payload's tag with the expected one folded out: the id count (0..3) when the payload is this key's
     const uint32_t c0 = f.p.w ^ piece_tag(f.mix, 0);
@@ -281,9 +283,9 @@ __device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uin
 #ifndef OVTK_SIMT_EMULATOR
     asm volatile("" : "+v"(x));   // (or the optimiser turns `(x ^ a | ...) == 0` back into the four compares)
 #endif
-    tok[0] = int32_t(f.p.x);
-    tok[1] = int32_t(f.p.y);
-    tok[2] = int32_t(f.p.z);
+    tok[0] = packed6 ? int32_t(f.p.x & 0xFFFFu) : int32_t(f.p.x);
+    tok[1] = packed6 ? int32_t(f.p.x >> 16) : int32_t(f.p.y);
+    tok[2] = packed6 ? int32_t(f.p.y & 0xFFFFu) : int32_t(f.p.z);
     return (x == 0u && c0 <= uint32_t(kPieceMaxIds)) ? int(c0) : -1;
 }
 // merge_kernel's side of the memo -- the reference's piece cache (bpe_tokenizer.cpp:197-205, 331-338: a piece's ids are
@@ -291,6 +293,7 @@ __device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uin
 // This lane's piece (1..15 bytes, `cnt` <= kPieceMaxIds ids) goes into its slot if that slot is free: no entry ever moves
 // or changes, so a concurrent reader sees a slot either free, or claimed (kPieceBusy never equals a key), or complete
 // (payload checked by its tag).  A piece whose slot is taken stays a miss.  Returns false when nothing was added.
+// tok: the payload's three dwords as the table wants them -- three i32 ids, or six u16 ids (P.packed6).
 __device__ __forceinline__ bool memo_insert(const PieceTableDev& P, uint64_t k0, uint64_t k1, const int32_t (&tok)[kPieceMaxIds], int cnt) {
     // (the lookup kernel has just missed this piece; nothing is read first -- one CAS.  A slot that is being written, or holds
     // this very piece -- filed by another wave a moment ago --, or any other piece ends the attempt.)
@@ -306,7 +309,7 @@ __device__ __forceinline__ bool memo_insert(const PieceTableDev& P, uint64_t k0,
     return true;
 }
 __device__ __forceinline__ int memo_lookup(const PieceTableDev& P, uint64_t k0, uint64_t k1, int32_t (&tok)[kPieceMaxIds]) {
-    return memo_resolve(memo_fetch(P, k0, k1), k0, k1, tok);
+    return memo_resolve(memo_fetch(P, k0, k1), k0, k1, tok, P.packed6 != 0);
 }
 
 // ---- the piece store (tables.hpp): the memo's second level, merge_kernel's own ------------------------------------

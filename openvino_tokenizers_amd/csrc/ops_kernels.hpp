@@ -126,6 +126,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
     // word (the tables' roots, the flags, the shard's count, the store's room, the memo's room: one wait each).
     const int l = lane_id();
     const int shard = int(blockIdx.y);
+    PROBE(0);
     const uint32_t flags0 = __hip_atomic_load(&w.status->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int count = __hip_atomic_load(&w.status->shard_count[shard * kCounterStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int store_room = T.store.slots ? __hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
@@ -140,8 +141,10 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
         sub_lds[i] = T.sub.root[i];
     }
     __syncthreads();
+    PROBE(1);
     if (flags0 & (kFatalFlags | kFlagDeferOverflow)) return;
     if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows);
+    PROBE(2);
     if (count > w.shard_cap) count = w.shard_cap;
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
     const int stride = int(gridDim.x) * kBlockThreads;
@@ -155,6 +158,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
         // The word store first (the piece store of tables.hpp, keyed by the word): a word it holds is one probe instead of a
         // trie walk of one dependent load per byte.  What is filed there never depends on unk_token_id -- a word that came out
         // as unk is not stored --, so the table stays valid whatever input 8 says on the next call.
+        PROBE(3);   // (the batch's entries are here)
         const StageSlot<S16> out{w, e.stage_pos};
         uint32_t skey[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const bool keyed = T.store.slots && valid && e.len >= 1 && e.len <= kStoreKeyBytes;
@@ -164,6 +168,9 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
             else store_key_long(in.chars + e.begin, e.len, skey);
             uint32_t pay[8];
             const int c = T.store.narrow ? store_lookup<true>(T.store, skey, pay) : store_lookup<false>(T.store, skey, pay);
+#ifdef OVTK_PROBE
+            if (c >= 1 || c < 1) PROBE(8);   // (the lookup's loads are back: lanes in divergent code, lane 0 of the wave stamps if it is here)
+#endif
             if (c >= 1) {
                 stored = true;
                 cnt = c;
@@ -179,6 +186,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                 for (int k = c; k < e.len; ++k) out.clear(k);
             }
         }
+        PROBE(4);   // (the store has answered)
         if (valid && !stored) {
             if (e.len >= 1 && e.len <= kPieceKeyBytes) {
                 const uint64_t k0 = e.k0, k1 = e.k1;
@@ -216,7 +224,8 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
         // on, and no longer crosses the deferred list at all.  One atomic per wave takes the room.
         if (my_room) {
             // (not the words the store knew: they were offered to the memo when they were walked, and found their slot taken)
-            const bool keep = valid && !stored && e.len >= 1 && e.len <= kPieceKeyBytes && cnt >= 1 && cnt <= kPieceMaxIds &&
+            const int memo_ids = T.memo.packed6 ? kPieceMaxIds6 : kPieceMaxIds;
+            const bool keep = valid && !stored && e.len >= 1 && e.len <= kPieceKeyBytes && cnt >= 1 && cnt <= memo_ids &&
                               !(cnt == 1 && out.get(0) == unk_id);
             const unsigned long long km = __ballot(keep);
             if (km) {
@@ -225,9 +234,15 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                 left = wave_readlane(left, 0);
                 bool added = false;
                 if (keep && rank_below(km) < left) {
-                    int32_t t3[kPieceMaxIds];
+                    int32_t t3[kPieceMaxIds] = {0, 0, 0};
+                    if (T.memo.packed6) {
 #pragma unroll
-                    for (int k = 0; k < kPieceMaxIds; ++k) t3[k] = k < cnt ? out.get(k) : 0;
+                        for (int k = 0; k < kPieceMaxIds6; ++k)
+                            if (k < cnt) t3[k >> 1] |= int32_t(uint32_t(out.get(k) & 0xFFFF) << (16 * (k & 1)));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kPieceMaxIds; ++k) t3[k] = k < cnt ? out.get(k) : 0;
+                    }
                     added = memo_insert(T.memo, e.k0, e.k1, t3, cnt);
                 }
                 const int unused = __popcll(km) - __popcll(__ballot(added));  // room taken but not filled goes back
@@ -244,10 +259,14 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
             if (w.tile_cnt) atomicAdd(&w.tile_cnt[e.row / kRowTile], incl - seg_base);
         }
     }
+    PROBE(5);   // (out of the batch loop)
     if (tail_rows <= 0) return;
     __syncthreads();
-    if (!last_block_done_sharded(w.status, int(blockIdx.y), gridDim.x, /*release=*/false)) return;  // only atomics to hand over (grid: blocks per shard x kShards)
+    const bool last_ = last_block_done_sharded(w.status, int(blockIdx.y), gridDim.x, /*release=*/false);  // only atomics to hand over (grid: blocks per shard x kShards)
+    PROBE(6);   // (ticket drawn)
+    if (!last_) return;
     scan_tiles_one_block(tail_rows, w, out_cap);
+    PROBE(7);
 }
 
 // =============================================================================================

@@ -713,14 +713,38 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 asm volatile("" : "+v"(xk));   // (one compare, not four: memo_resolve)
 #endif
                 const uint32_t c0 = q.p.w ^ piece_tag(q.mix, 0);
-                const bool hit = valid && q.plen <= kPieceKeyBytes && xk == 0u && c0 <= uint32_t(kPieceMaxIds);
+                const bool packed6 = BERT && T.pieces.packed6 != 0;   // (the word memo: six u16 ids per entry; wave-uniform)
+                const bool hit = valid && q.plen <= kPieceKeyBytes && xk == 0u && c0 <= uint32_t(packed6 ? kPieceMaxIds6 : kPieceMaxIds);
                 const int cnt_ids = hit ? int(c0) : 0;
                 const int need = hit ? cnt_ids : (valid ? q.plen + SL : 0);
                 const int v = need | (cnt_ids << 16);
                 const int s_incl = wave_incl_sum(v);
                 const int s_excl = s_incl - v;
                 const int at = cursor + (s_excl & 0xFFFF);
-                if (hit) {
+                if (hit && packed6) {
+                    const uint32_t i0 = q.p.x & 0xFFFFu, i1 = q.p.x >> 16, i2 = q.p.y & 0xFFFFu, i3 = q.p.y >> 16, i4 = q.p.z & 0xFFFFu, i5 = q.p.z >> 16;
+                    if (S16) {
+                        uint16_t* st16 = reinterpret_cast<uint16_t*>(w.stage) + at;
+                        if (cnt_ids > 0) st16[0] = uint16_t(i0);
+                        if (cnt_ids > 1) st16[1] = uint16_t(i1);
+                        if (cnt_ids > 2) st16[2] = uint16_t(i2);
+                        if (cnt_ids > 3) {
+                            st16[3] = uint16_t(i3);
+                            if (cnt_ids > 4) st16[4] = uint16_t(i4);
+                            if (cnt_ids > 5) st16[5] = uint16_t(i5);
+                        }
+                    } else {
+                        int32_t* st32 = w.stage + at;
+                        if (cnt_ids > 0) st32[0] = int32_t(i0);
+                        if (cnt_ids > 1) st32[1] = int32_t(i1);
+                        if (cnt_ids > 2) st32[2] = int32_t(i2);
+                        if (cnt_ids > 3) {
+                            st32[3] = int32_t(i3);
+                            if (cnt_ids > 4) st32[4] = int32_t(i4);
+                            if (cnt_ids > 5) st32[5] = int32_t(i5);
+                        }
+                    }
+                } else if (hit) {
                     if (S16) {   // (the staging entries are u16: EncodeWork::stage16, a template flag here -- one branch less per round)
                         uint16_t* st16 = reinterpret_cast<uint16_t*>(w.stage) + at;
                         if (cnt_ids > 0) st16[0] = uint16_t(q.p.x);

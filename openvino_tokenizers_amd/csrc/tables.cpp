@@ -209,14 +209,15 @@ int build_bpe(const StringsView& vocab, const StringsView& ml, const StringsView
 
 // ------------------------------------------------------------------------------- piece memo
 void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
-                       PieceTableHost& out, size_t extra) {
+                       PieceTableHost& out, size_t extra, bool packed6) {
+    const int max_ids = packed6 ? kPieceMaxIds6 : kPieceMaxIds;
     // in the order of the input (for a vocabulary: ascending id, i.e. roughly descending frequency -- the pieces a full
     // bucket refuses are the late, rare ones); a repeated string keeps its first entry
     std::unordered_map<std::string, size_t> seen;
     std::vector<PieceEntry> list;
     for (int64_t i = 0; i < pieces.n; ++i) {
         const int len = pieces.ends[i] - pieces.begins[i], cnt = id_ends[i] - id_begins[i];
-        if (!(len >= 1 && len <= kPieceKeyBytes && cnt >= 0 && cnt <= kPieceMaxIds)) continue;
+        if (!(len >= 1 && len <= kPieceKeyBytes && cnt >= 0 && cnt <= max_ids)) continue;
         uint8_t kb[16] = {0};
         std::memcpy(kb, pieces.chars + pieces.begins[i], size_t(len));
         kb[15] = uint8_t(len);
@@ -224,7 +225,11 @@ void build_piece_table(const StringsView& pieces, const int32_t* id_begins, cons
         std::memcpy(&e.k0, kb, 8);
         std::memcpy(&e.k1, kb + 8, 8);
         e.tag = piece_tag(piece_mix(e.k0, e.k1), cnt);
-        for (int k = 0; k < cnt; ++k) e.tok[k] = ids[id_begins[i] + k];
+        for (int k = 0; k < cnt; ++k) {
+            const int32_t id = ids[id_begins[i] + k];
+            if (packed6) e.tok[k >> 1] |= int32_t(uint32_t(id & 0xFFFF) << (16 * (k & 1)));   // (the caller vouches: every id < 65 536)
+            else e.tok[k] = id;
+        }
         if (seen.emplace(std::string(reinterpret_cast<const char*>(kb), 16), list.size()).second) list.push_back(e);
     }
     // direct-mapped, no relocation: at 1/12 full about three entries in a hundred find their slot taken (tables.hpp piece_h)

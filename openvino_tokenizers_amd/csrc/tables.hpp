@@ -62,6 +62,8 @@ struct alignas(16) MergeSlot {
 
 constexpr int kPieceKeyBytes = 15;  // longest piece the memo table can key
 constexpr int kPieceMaxIds = 3;     // longest id sequence it stores
+constexpr int kPieceMaxIds6 = 6;    // ... of a table whose ids are u16 pairs (PieceTableDev::packed6: the fused WordPiece path's word memo,
+                                    // every id a vocabulary index below 65 536): tok[] holds six u16 ids
 struct alignas(32) PieceEntry {
     uint64_t k0, k1;  // piece bytes 0..7 / 8..14 (little endian, zero padded) | length << 56; k1 == 0: free (length >= 1)
     int32_t tok[kPieceMaxIds];
@@ -87,6 +89,7 @@ struct PieceTableDev {
                               // `learned <= cache_capacity` exact), and 3 700 of those per launch on ONE address are most of a
                               // 50-us kernel (a capacity that never fills: 0.125 -> 0.166 ms per step at cache_capacity = 200 000)
     uint32_t room_mask;       // kRoomShards - 1, or 0 for small capacities (one counter holds it all)
+    uint32_t packed6;         // 1: tok[] of every entry is six u16 ids (id 2k in the low half of tok[k]), up to kPieceMaxIds6 of them
 };
 constexpr int kRoomShards = 16, kRoomStride = 32;
 // ---- the piece store: the memo's second level, probed by merge_kernel only (never by the lookup kernels).
@@ -274,7 +277,7 @@ struct PieceTableHost {
 };
 // extra: entries the device may add later (cache_capacity): the table is sized for stored + extra.
 void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
-                       PieceTableHost& out, size_t extra = 0);
+                       PieceTableHost& out, size_t extra = 0, bool packed6 = false);
 
 int build_wordpiece(const StringsView& vocab, const std::string& suffix_indicator, TrieHost& root, TrieHost& sub,
                     std::string& err);
