@@ -972,15 +972,3 @@ extern "C" __attribute__((visibility("default"))) int ovtk_debug_probe(unsigned 
     return 0;
 }
 #endif
-
-#ifdef OVTK_SPAN_TIMERS
-// tools/span_sections.sh: the section timers of lookup_span_kernel (a debug build of the library only).
-extern "C" int ovtk_debug_span_timers(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(ovtk::g_span_timers), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(ovtk::g_span_timers), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif

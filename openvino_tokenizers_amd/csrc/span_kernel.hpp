@@ -343,19 +343,6 @@ __device__ __forceinline__ void span_flush(const SpanWave& sw, int n, const Enco
     }
 }
 
-// Section timers of lookup_span_kernel (tools/span_sections.sh builds a copy of the library with -DOVTK_SPAN_TIMERS; never in the product
-// build): shader-clock ticks per section, summed over all waves.
-#ifdef OVTK_SPAN_TIMERS
-static __device__ unsigned long long g_span_timers[16];   // (one per translation unit: api_encode.cpp's is the one read)
-#define SPAN_T_DECL long long t_last_ = clock64(); unsigned int t_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define SPAN_T(i) do { const long long now_ = clock64(); t_acc_[i] += (unsigned int)(now_ - t_last_); t_last_ = now_; } while (0)
-#define SPAN_T_END do { if (lane_id() == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_span_timers[i_], (unsigned long long)t_acc_[i_]); } } while (0)
-#else
-#define SPAN_T_DECL
-#define SPAN_T(i)
-#define SPAN_T_END
-#endif
-
 // One round's probe: the piece of lane l (none: plen == 0), its masked key dwords, and the candidate entry on its way.
 struct SpanProbe {
     uint4 k, p;
@@ -413,7 +400,6 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
     const bool fatal = (w.status->flags & kFatalFlags) != 0;
     __syncthreads();
     if (fatal || nr <= 0) return;
-    SPAN_T_DECL
     SpanWave& sw = sw_all[wave_in_block()];
     const uint8_t* text = reinterpret_cast<const uint8_t*>(sw.text + 1);
     const int SL = T.suffix_len, mul = SL + 1;
@@ -501,7 +487,6 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
             done += take;
         }
     };
-    SPAN_T(0);
     while (have_chain && !dead) {
         const bool in_chain = l >= ci && l < cj;
         const int Rl = excl32 - ex0;   // where my row starts in the chain
@@ -530,15 +515,13 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
             const int nv = b_len - kSpanLane * l;
             const uint32_t vm = nv >= kSpanLane ? ~0u : (nv <= 0 ? 0u : ((1u << nv) - 1u));
             wave_sync();
-            SPAN_T(1);
             uint32_t fl = 0, dropped = 0;
-#if defined(OVTK_SPAN_ABLATE) && OVTK_SPAN_ABLATE >= 2   // (tools/span_sections.sh: what the kernel costs without the scan)
+#if defined(OVTK_SPAN_ABLATE) && OVTK_SPAN_ABLATE >= 2   // (tools/span_ablate.sh: what the kernel costs without the scan)
             const bool fast = true;
             fl = (0x08102041u | rs) & vm;
 #else
             const bool fast = BERT ? span_flags_bert(xa, rs, vm, fl, dropped) : span_flags<DIGITS>(xa, rs, vm, text, fl);
 #endif
-            SPAN_T(2);
             // ---- the block's piece list: np pieces, the last one ends at q_end (= where the next block starts); rowfirst: the list
             // index of my row's first piece, if that is one of them
             int np = 0, q_end = 0, rowfirst = 0x7FFFFFFF;
@@ -667,7 +650,6 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 span_load(in, chain_sb + pos, chain_len - pos < kSpanBytes ? chain_len - pos : kSpanBytes, xa);
                 continue;
             }
-            SPAN_T(3);
 #if defined(OVTK_SPAN_ABLATE)   // (1: without the lookup rounds; 2: and without the scan; 3: and without the piece list)
             np = 0;
 #endif
@@ -776,7 +758,6 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
             };
             // (a fetch behind the list's end finds pieces of no bytes: inside the loop nothing is conditional, so that no wait for
             // "a load that may still be on its way" ends up in front of the next fetch)
-            SPAN_T(4);
             SpanProbe qa = fetch(0);
             int jb = 0;
             for (; jb + kWave < np; jb += 2 * kWave) {
@@ -791,7 +772,6 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 rec_cnt = emitted;
             }
             pos += q_end;
-            SPAN_T(5);
         }
         // ---- the chain's rows: entries used = up to the next row's first entry, ids = the hits' ids in between
         {
@@ -828,8 +808,6 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         base = wave_readlane(base, 0);
         if (w.pending_rows && is_pending) w.pending_rows[base + rank_below(pm)] = row0 + l;
     }
-    SPAN_T(6);
-    SPAN_T_END;
 }
 
 }  // namespace ovtk
