@@ -302,9 +302,12 @@ __device__ __forceinline__ bool memo_insert(const PieceTableDev& P, uint64_t k0,
     uint32_t* slot = reinterpret_cast<uint32_t*>(const_cast<PieceEntry*>(P.slots) + piece_h(mix, P.shift));
     if (atomicCAS(slot + 3, 0u, kPieceBusy) != 0u) return false;
     *reinterpret_cast<uint4*>(slot + 4) = uint4{uint32_t(tok[0]), uint32_t(tok[1]), uint32_t(tok[2]), piece_tag(mix, cnt)};
-    // (the payload is ordered before the key that makes it reachable; a reader that still meets the key first sees a tag that
-    // does not match -- a zeroed payload lacks the valid bit -- and takes the miss path, with the same result)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // The payload has COMPLETED at the L2 before the key that makes it reachable is sent (a workgroup-scope release: s_waitcnt
+    // vmcnt(0)).  Both stores land in the same line of the same L2 and a line leaves an L2 whole, so no reader -- on this XCD or
+    // another -- can meet the key without the payload; and one that did would see a tag that does not match (a zeroed payload lacks
+    // the valid bit) and take the miss path, with the same result.  An agent-scope release here also wrote the XCD's dirty lines
+    // back: tens of microseconds in every launch that learns (first sight of a text).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     *reinterpret_cast<uint4*>(slot) = uint4{uint32_t(k0), uint32_t(k0 >> 32), uint32_t(k1), d3};
     return true;
 }
@@ -432,7 +435,7 @@ __device__ __forceinline__ bool store_insert(const PieceStoreDev& S, const uint3
     if (!slot) return false;
     *reinterpret_cast<uint4*>(slot + 8) = uint4{pay[0], pay[1], pay[2], pay[3]};
     *reinterpret_cast<uint4*>(slot + 12) = uint4{pay[4], pay[5], pay[6], pay[7]};
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the payload before the key that makes it reachable (the tag's checksum stays as the second line of defence)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the payload has completed at the L2 before the key that makes it reachable is sent (memo_insert says why not agent scope; the tag's checksum stays as the second line of defence)
     *reinterpret_cast<uint4*>(slot) = uint4{key[0], key[1], key[2], key[3]};
     *reinterpret_cast<uint4*>(slot + 4) = uint4{key[4], key[5], key[6], key[7]};  // (replaces kPieceBusy: the entry is complete)
     return true;
