@@ -247,7 +247,11 @@ int ovtk_wordpiece_run(ovtk_wordpiece* h, const ovtk_ragged_strings* in, int32_t
                        ovtk_ragged_i32_out* out, int mem, void* stream);
 /* Fused RegexSplit(\s+, remove) -> RegexSplit(BERT delimiters, isolate) -> WordpieceTokenizer: the sub-graph
  * tokenizer_pipeline.py:392-435 (bert_splitter) + :641-659 builds for BERT models; same result as chaining the three ops,
- * without the word begins/ends round trips through HBM.  Any other pair of split handles is OVTK_E_UNSUPPORTED. */
+ * without the word begins/ends round trips through HBM.  Any other pair of split handles is OVTK_E_UNSUPPORTED.
+ * The handle memoises words -> ids as it meets them (a first-level table of the vocabulary's own words plus up to 4 V learned
+ * ones of at most 15 bytes and 6 ids, a second-level store sized like the BPE handle's: ovtk_set_memo_store): pure memoisation of
+ * wordpiece_tokenizer.cpp:94-130, no result depends on it or on the calls before; a word that came out as unk_token_id is never
+ * kept, so input 8 may differ from call to call.  Calls on one handle may run concurrently (tables are insert-only). */
 int ovtk_wordpiece_encode_run(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk_regex_split* delimiters,
                               const ovtk_ragged_strings* in, int32_t unk_token_id, ovtk_ragged_i32_out* out, int mem,
                               void* stream);
