@@ -378,10 +378,16 @@ __device__ __forceinline__ int store_lookup(const PieceStoreDev& S, const uint32
         for (int c = 0; c < kStoreWays; ++c) {
             const uint4* e = reinterpret_cast<const uint4*>(S.slots + store_h_next(store_h(mix, c, S.shift), step, S.shift));
             const uint4 a = e[0], b = e[1];
+            uint4 c2 = e[2], c3 = e[3];
+#ifndef OVTK_SIMT_EMULATOR
+            // (all four loads in flight before anything looks at a result: written as "if the key matches, take the payload" the
+            // payload is a second round trip -- memo_fetch)
+            asm volatile("" : "+v"(c2.x), "+v"(c2.y), "+v"(c2.z), "+v"(c2.w), "+v"(c3.x), "+v"(c3.y), "+v"(c3.z), "+v"(c3.w));
+#endif
             if (!any && store_key_eq(a, b, key)) {
                 any = true;
-                q0 = e[2];
-                q1 = e[3];
+                q0 = c2;
+                q1 = c3;
             }
             full = full && b.w != 0u;
         }
