@@ -143,6 +143,8 @@ def test_rows_longer_than_a_block(backend):
         strings.append(long_rows[(i // 3) % len(long_rows)] if i % 3 == 0 else _filler(rng, int(rng.integers(1, 300))))
     tok = BpeTok.load("gpt2_small")
     fused_vs_oracle(backend, tok, rows_of(strings), what="long rows")
+    if backend.name == "emu":   # (the emulator takes ten seconds per leg: the other two run on the GPU tier)
+        return
     fused_vs_oracle(backend, tok, rows_of(strings), pattern=DIGITS_PATTERN, what="long rows, digits variant")
     # nothing but long rows, back to back (chains of them)
     only = [long_rows[i % len(long_rows)] for i in range(290)]
@@ -349,6 +351,8 @@ def test_llama3_family_long_and_ragged_rows(backend, name):
     pattern = MODEL_PATTERNS.get(name, tok.pattern)
     rng = np.random.default_rng(67)
     fused_vs_oracle(backend, tok, rows_of(_l3_rows(rng, 300)), pattern=pattern, what=f"{name}: fragments")
+    if backend.name == "emu" and name != "llama3":   # (thirty seconds per pattern on the emulator: the other legs of the two variants run on the GPU tier)
+        return
     b, e, c = TextModel(43, "mixed").batch(300, 700)
     rb, re_ = ragged_rows(300)
     fused_vs_oracle(backend, tok, [rb, re_, b, e, c], pattern=pattern, what=f"{name}: mixed text, rows of ~700 bytes")
