@@ -1,25 +1,29 @@
-// span_kernel.hpp -- lookup_span_kernel: the GPT-2 family's lookup stage with SEVERAL ROWS PER SCAN (round 4).
+// span_kernel.hpp -- lookup_span_kernel: the lookup stage of the GPT-2 family and of the fused WordPiece path (the BERT words), a
+// 2 048-BYTE BLOCK OF TEXT PER SCAN whatever the rows are (round 4).
 //
 // lookup_rows_kernel scans one row per pass: a 512-byte row is 8 bytes per lane, and everything that is paid once per pass
 // whatever the lane holds -- neighbour exchange, the prefix sum of the piece starts, the piece list, row bookkeeping, the last
-// partly filled 64-piece batch -- is paid per row: 599 vector instructions per 512-byte row, 250 of them in the scan, at
-// ~1.4 batches' worth of pieces in 2.2 batches.  The kernel is bound by instruction issue, so here a pass covers a
-// BLOCK: as many consecutive whole rows as fit 2 048 bytes, 32 bytes per lane.
+// partly filled 64-piece batch -- is paid per row: 599 vector instructions per 512-byte row.  The kernels are bound by instruction
+// issue, so here a pass covers a BLOCK, 32 bytes per lane:
 //   * rows that follow each other in the chars tensor (begins[i + 1] == ends[i]: what StringTensorUnpack produces) are one
-//     contiguous stretch of text: every lane loads its 32 bytes straight from global memory into registers (two 16-byte loads
-//     at a byte address -- gfx950 takes them at any alignment, tools/unaligned_probe.hip), the NEXT block's while this one is
-//     worked on; the registers are the scanner's input, and one copy goes to LDS for the key reads of the lookup rounds;
+//     stretch of text, a CHAIN, and a block starts where the block before stopped -- the last piece start it could decide: whole
+//     rows, the tail of one and the head of the next, or a slice of a 10 000-byte row alike.  Every lane loads its 32 bytes
+//     straight from global memory into registers (two 16-byte loads at a byte address -- gfx950 takes them at any alignment,
+//     tools/unaligned_probe.hip), the NEXT block's before this one's lookup rounds; the registers are the scanner's input, and
+//     one copy goes to LDS for the key reads of the rounds;
 //   * the row starts inside a block are one more per-byte flag (`rs`): they force a piece start and cut every look-ahead and
 //     look-behind of the rules, so that a row's pieces are exactly those of the row scanned alone (src/regex_split.cpp:205-324
 //     runs the pattern per string);
-//   * the rules are gpt2_start_flags_ascii's, the flags of a lane's 8 dwords packed into 32 bits by eight v_dot4_u32_u8;
-//   * the pieces of ALL rows of the block form one list, looked up 64 at a time in full rounds, the probe loads of round r + 1
-//     in flight while round r is resolved; staging positions run through the block (the wave's rows are staged back to back),
-//     the per-row records are read off the running sums at the rows' first pieces;
-//   * misses are noted in LDS as {staging position, begin, length, row} and become DeferredPiece entries (key bytes re-read
-//     from the text) when 64 have collected or the wave is through.
-// Rows that are not one non-empty string inside the chars tensor, rows longer than a block, blocks with non-ASCII bytes: marked
-// kRowPending and listed for lookup_kernel<kFused>, exactly as lookup_rows_kernel does.
+//   * the rules are gpt2_start_flags_ascii's (span_flags) / the BERT words' (span_flags_bert), the flags of a lane's 8 dwords
+//     packed into 32 bits by eight v_dot4_u32_u8; a block with non-ASCII text takes the ballot form of the same rules, window by
+//     window on the block's LDS text; a piece longer than a block is matched literally by lane 0;
+//   * the pieces of the block form one list, looked up 64 at a time, the probe loads of round r + 1 in flight while round r is
+//     resolved; staging positions run through the block (the wave's rows are staged back to back), a row's record is the
+//     running sums at its first piece -- pulled by the row's lane from the piece's lane;
+//   * misses are noted in LDS as {memo key, staging position, begin, length, byte position among the wave's rows} and become
+//     DeferredPiece entries when the list fills or the wave is through.
+// Rows that are not one non-empty string inside the chars tensor (empty, skipped, several strings) are marked kRowPending and
+// listed for lookup_kernel<kFused>, exactly as lookup_rows_kernel does.  DESIGN.md 3.3 has the longer account.
 #pragma once
 
 #include "encode_kernels.hpp"
