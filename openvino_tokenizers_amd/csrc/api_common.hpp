@@ -408,14 +408,16 @@ private:
         e = e ? e : ws.tiles.ensure(size_t(n_tiles_ + 1) * sizeof(long long));
         const bool fold = fold_tail_ && n_rows_ <= kFoldTailRows;
         const size_t status_bytes = sizeof(RunStatus) + (fold ? size_t(n_tiles_) * 4 : 0);  // + tile_cnt, zeroed with the status
-        e = e ? e : ws.status.ensure(status_bytes);
+        const size_t status_stride = (status_bytes + 255) & ~size_t(255);   // two blocks: this call's, and the one compact_kernel zeroes for the next
+        e = e ? e : ws.status.ensure(2 * status_stride);
         if (fold) e = e ? e : ws.gen[4].ensure(size_t(n_rows_) * 4);
         if (self_alloc_) e = e ? e : ws.gen[5].ensure(size_t(n_rows_) * 4);
         if (e) return e;
         EncodeWork w{};
         w.n_waves = grid_ * kWavesPerBlock;
         w.fold_tail = fold;
-        w.tile_cnt = fold ? reinterpret_cast<int32_t*>(ws.status.as<uint8_t>() + sizeof(RunStatus)) : nullptr;
+        uint8_t* const status_base = ws.status.as<uint8_t>();
+        w.tile_cnt = fold ? reinterpret_cast<int32_t*>(status_base + sizeof(RunStatus)) : nullptr;   // (the one-launch path: block 0; the large path moves both below)
         w.row_emit = fold ? ws.gen[4].as<int32_t>() : nullptr;
         w.pending_rows = self_alloc_ ? ws.gen[5].as<int32_t>() : nullptr;
         w.out_cap = out_.data_capacity;
@@ -459,7 +461,21 @@ private:
             return OVTK_OK;
         }
         ws.clean_status = nullptr;  // (the ordinary launches below leave their counters in the status block)
-        OVTK_HIP(hipMemsetAsync(w.status, 0, status_bytes, s_));
+        // This call's status block: the one the workspace's last large call zeroed from its compact_kernel, if that was the lease
+        // right before this one and nothing moved; else either block, after a memset.
+        ws.status_half ^= 1;
+        uint8_t* mine = status_base + size_t(ws.status_half) * status_stride;
+        uint8_t* other = status_base + size_t(ws.status_half ^ 1) * status_stride;
+        w.status = reinterpret_cast<RunStatus*>(mine);
+        w.tile_cnt = fold ? reinterpret_cast<int32_t*>(mine + sizeof(RunStatus)) : nullptr;
+        w.next_status = reinterpret_cast<RunStatus*>(other);
+        w.host_status = ws.host_status;
+        w.status_words = int32_t(status_bytes / 4);
+        if (ws.zeroed_status != mine || ws.zeroed_bytes < status_bytes || ws.zeroed_after_lease + 1 != ws.lease_count)
+            OVTK_HIP(hipMemsetAsync(w.status, 0, status_bytes, s_));
+        ws.zeroed_status = nullptr;   // (until this call's compact_kernel is on its way)
+        std::memset(ws.host_status, 0, sizeof(RunStatus));   // compact_kernel fills the scalar fields and the shards' counts
+        ws.host_status->flags = kFlagStageOverflow;           // overwritten by the kernel; one that did not run leaves an error
         if (!self_alloc_)
             OVTK_LAUNCH(ws.marks, "prep_rows", prep_rows_kernel, std::min(grid_, kTicketBlocks), kBlockThreads, s_, d_in_, mul_, w);
         middle_(ws, d_in_, w, grid_);
@@ -472,7 +488,9 @@ private:
         else if (wire_.hdr) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<WireSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, wire_);
         else if (stage16_) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<RaggedSink, true>), cgrid, kBlockThreads, s_, n_rows_, w, rsink);
         else OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<RaggedSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, rsink);
-        OVTK_HIP(hipMemcpyAsync(ws.host_status, ws.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s_));
+        ws.zeroed_status = other;   // compact_kernel is launched: the other block will be clean for the next lease of this workspace
+        ws.zeroed_bytes = status_bytes;
+        ws.zeroed_after_lease = ws.lease_count;
         OVTK_HIP(hipEventRecord(ws.done, s_));
         return OVTK_OK;
     }

@@ -99,6 +99,11 @@ struct Workspace {
     const void* clean_status = nullptr;
     size_t clean_bytes = 0;
     uint64_t lease_count = 0, clean_after_lease = ~0ull;
+    // the large path's two status blocks (RowsRun::launch): compact_kernel zeroes the one its call does not use
+    const void* zeroed_status = nullptr;   // the block the last large call's compact_kernel zeroed ...
+    size_t zeroed_bytes = 0;               // ... that many bytes of it ...
+    uint64_t zeroed_after_lease = ~0ull;   // ... valid for the lease right behind that call's
+    int status_half = 0;
     hipEvent_t done = nullptr;         // end of the call in flight (RowsRun)
     LaunchLog marks;
     ~Workspace();
