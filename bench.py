@@ -264,7 +264,7 @@ def make_workload(args, lib, dev, rank):
         from tools.workloads import MODEL_PATTERNS
         w = BpeEncode(args, lib, dev, rank, "llama3", "mixed", rows, args.bytes, 4000, pattern=MODEL_PATTERNS.get(args.pattern))
         w.metric = "input MB/s encoded (Llama-3 BPE, 512-byte mixed-script strings)"
-        w.dominant_hint = "lookup_rows"
+        w.dominant_hint = "lookup_span"
         w.workload = (f"config 4 shard: Llama-3-shaped byte-level BPE (V=128256, 127999 merges, trained in-process), {rows} x "
                       f"~{args.bytes}-byte mixed-script strings per GPU and batch, {w.batches.n} distinct batches in rotation "
                       f"({sum(w.batches.n_chars) / 1e6:.0f} MB of text), fused RegexSplit (tiktoken-style pattern) + BPETokenizer, "

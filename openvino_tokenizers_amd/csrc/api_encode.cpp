@@ -43,9 +43,9 @@ const char kBertDelimitersPattern[] =
 
 // Unicode property tables, one copy per device.
 struct UnicodeTables {
-    DevBuf index, blocks;
+    DevBuf index, blocks, flat;
 };
-int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks) {
+int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks, const uint8_t** flat = nullptr) {
     static std::mutex mu;
     static std::map<int, std::unique_ptr<UnicodeTables>> per_device;
     std::lock_guard<std::mutex> lk(mu);
@@ -54,11 +54,20 @@ int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks) {
         auto fresh = std::make_unique<UnicodeTables>();
         if (int rc = fresh->index.upload(kUcIndex, sizeof kUcIndex)) return rc;
         if (int rc = fresh->blocks.upload(kUcBlocks, sizeof kUcBlocks)) return rc;
+        // the class bits of planes 0 and 1 flat (SplitDev::uc_flat, span_l3.hpp kUcFlatLimit), from the same two-level table
+        std::vector<uint8_t> f(0x20000 / 4, 0);
+        for (uint32_t cp = 0; cp < 0x20000u; ++cp) {
+            const uint32_t b = kUcBlocks[size_t(kUcIndex[cp >> 7]) * 64 + ((cp & 127) >> 1)];
+            const uint32_t nib = (cp & 1) ? (b >> 4) : (b & 15u);
+            f[cp >> 2] |= uint8_t((nib & 3u) << (2 * (cp & 3u)));
+        }
+        if (int rc = fresh->flat.upload(f.data(), f.size())) return rc;
         OVTK_HIP(hipStreamSynchronize(nullptr));
         t = std::move(fresh);
     }
     *index = t->index.as<uint16_t>();
     *blocks = t->blocks.as<uint8_t>();
+    if (flat) *flat = t->flat.as<uint8_t>();
     return OVTK_OK;
 }
 
@@ -254,7 +263,7 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
     }
     if (int rc = use_device(p->device)) return rc;
     h->device = p->device;
-    if (int rc = unicode_tables(p->device, &h->dev.uc_index, &h->dev.uc_blocks)) return rc;
+    if (int rc = unicode_tables(p->device, &h->dev.uc_index, &h->dev.uc_blocks, &h->dev.uc_flat)) return rc;
     if (h->dev.kind == kSplitGeneral) {
         int e = 0;
         e = e ? e : h->r_trans.upload(prog.trans.data(), prog.trans.size() * sizeof(uint16_t));
@@ -601,14 +610,18 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFusedLlama3, true>), grid, kBlockThreads, s, d_in,
                                                split->dev, T, w);
                                else if (llama3) {
-                                   // consecutive rows per wave (lookup_rows_kernel); what it leaves goes through the generic kernel
+                                   // several rows per scan block, the rule algebra on bit masks (lookup_span_kernel<kSpanLlama3>, span_l3.hpp;
+                                   // round 4's row-per-scan kernel stays for handles without a memo); what it leaves goes through the
+                                   // generic kernel
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
-                                   // (lookup_span_kernel with the Llama-3 scanners window by window was measured in round 4 -- 470 us against
-                                   // this kernel's 360: a 2 048-byte block cuts the rows into more, emptier windows than one row at a time,
-                                   // and the scanner's cost is per window; profiles/r04/experiments/llama3_on_span_kernel.patch)
-                                   OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsLlama3>, grid1, kBlockThreads, s, d_in, split->dev,
-                                               T, w1);
+                                   if (T.pieces.slots && w1.stage16)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanLlama3, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   else if (T.pieces.slots)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanLlama3, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   else
+                                       OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsLlama3>, grid1, kBlockThreads, s, d_in, split->dev,
+                                                   T, w1);
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
@@ -669,7 +682,10 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            },
                            /*self_alloc=*/true,
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
-                                  : split->dev.kind == kSplitLlama3 ? resident_blocks_per_cu(lookup_kernel<kFusedLlama3>)
+                                  : split->dev.kind == kSplitLlama3
+                                      ? (T.pieces.slots && !row_tickets().load(std::memory_order_relaxed)
+                                             ? resident_blocks_per_cu(lookup_span_kernel<kSpanLlama3, false>)
+                                             : resident_blocks_per_cu(lookup_kernel<kFusedLlama3>))
                                   : split->dev.kind <= kSplitGpt2Digits && !row_tickets().load(std::memory_order_relaxed)
                                       ? resident_blocks_per_cu(lookup_span_kernel<kSpanGpt2, true>, 6)
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
@@ -692,7 +708,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
         });
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
     if (bpe->stage16) r->enable_stage16();
-    if (split && split->dev.kind <= kSplitGpt2Digits && T.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)
+    if (split && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3) && T.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)
     if (wire) r->output_to_wire(*wire);
     if (int rc = r->start()) return rc;
     run = std::move(r);

@@ -27,6 +27,7 @@
 #pragma once
 
 #include "encode_kernels.hpp"
+#include "span_l3.hpp"
 
 namespace ovtk {
 
@@ -56,15 +57,6 @@ struct __attribute__((packed, aligned(1))) Bytes4 { uint32_t v; };
 
 // `sval` (wave-uniform) into lane `lane` (wave-uniform) of a per-lane value
 __device__ __forceinline__ int wave_writelane(int old, int sval, int lane) { return lane_id() == lane ? sval : old; }
-// sum of the four bytes of `a` times the four bytes of `b`, plus c -- v_dot4_u32_u8
-__device__ __forceinline__ uint32_t dot4_u8(uint32_t a, uint32_t b, uint32_t c) {
-#ifdef OVTK_SIMT_EMULATOR
-    for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 0xFFu) * ((b >> (8 * i)) & 0xFFu);
-    return c;
-#else
-    return __builtin_amdgcn_udot4(a, b, c, false);
-#endif
-}
 // 4 flag bits -> 4 bytes with the flag in bit 7
 __device__ __forceinline__ uint32_t nibble_to_b7(uint32_t nib) {
     // bit k of nib lands at 7 + 7k + k = 8k + 7 for the three low bits (24-bit multiply); bit 3 is placed by hand
@@ -105,7 +97,7 @@ __device__ __forceinline__ void span_load(const RowsIn& in, int sb, int blen, ui
 //  * contractions: apostrophes are few, so a lane walks its own (usually none, rarely two) and reads the letters behind them
 //    from the LDS copy of the text.
 // false (wave-uniform): the block holds a non-ASCII byte.
-enum SpanScan : int { kSpanGpt2 = 0, kSpanGpt2Digits = 1, kSpanBertWords = 2 };
+enum SpanScan : int { kSpanGpt2 = 0, kSpanGpt2Digits = 1, kSpanBertWords = 2, kSpanLlama3 = 3 };
 struct SpanClasses { uint32_t L, N, S, SP, O; };
 template <bool DIGITS>
 __device__ __forceinline__ SpanClasses span_classify(uint32_t v) {
@@ -186,7 +178,9 @@ __device__ __forceinline__ bool span_flags(uint32_t (&x)[kSpanDwords], uint32_t 
     // ---- contractions: 's 't 'm 'd 're 've 'll at an apostrophe that itself starts a piece; the letter(s) stay with it, the byte
     // behind them starts a piece.  Bits 32.. of the masks belong to lane l + 1.
     if (__ballot(apbits != 0)) {
-        const uint64_t rs64 = uint64_t(rs) | (uint64_t(rs_next) << 32);
+        // (the letters must be of this row AND of this block: behind a last block of exactly 2 048 bytes there is no row-start bit to
+        // stop them, and the LDS bytes behind the block's text are whatever the last launch left there -- ADVICE r04)
+        const uint64_t rs64 = (uint64_t(rs) | (uint64_t(rs_next) << 32)) | ~(uint64_t(vm) | (uint64_t(lane_next(vm)) << 32));
         uint64_t set = 0, clr = 0;
         apbits &= flags;   // (an apostrophe behind a class-O character or a space does not start a piece: nothing fires there)
         while (apbits) {
@@ -370,6 +364,7 @@ template <int SCAN, bool S16>
 static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(RowsIn in, SplitDev sp, BpeDev T, EncodeWork w) {
     constexpr bool DIGITS = SCAN == kSpanGpt2Digits;
     constexpr bool BERT = SCAN == kSpanBertWords;
+    constexpr bool L3 = SCAN == kSpanLlama3;   // the Llama-3 family (span_l3.hpp)
     __shared__ SpanWave sw_all[kWavesPerBlock];
     __shared__ uint4 mask_tab[16];   // [n]: byte masks of the four key dwords of an n-byte piece (n = 0: nothing)
     const int l = lane_id();
@@ -520,26 +515,46 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
             const uint32_t vm = nv >= kSpanLane ? ~0u : (nv <= 0 ? 0u : ((1u << nv) - 1u));
             wave_sync();
             uint32_t fl = 0, dropped = 0;
-#if defined(OVTK_SPAN_ABLATE) && OVTK_SPAN_ABLATE >= 2   // (tools/span_ablate.sh: what the kernel costs without the scan)
-            const bool fast = true;
-            fl = (0x08102041u | rs) & vm;
-#else
-            const bool fast = BERT ? span_flags_bert(xa, rs, vm, fl, dropped) : span_flags<DIGITS>(xa, rs, vm, text, fl);
+            int lim = b_len - kSpanHalo;   // a block that was cut: starts from here on may depend on what follows it
+            bool fast = true;
+            if constexpr (L3) {
+                // the rule algebra on bit masks, whatever the script; what it does not cover (a non-ASCII digit, U+017F): lane 0, literally
+                uint32_t* fl_words = rs_words + kWave;   // (the piece list's room is still free: kSpanL3Scratch bytes of it)
+                static_assert(kWave * 4 + kSpanL3Scratch <= int(sizeof(SpanWave::pstart)), "the Llama-3 scanner's scratch lives in the piece list's room");
+                if (!span_flags_l3(xa, rs, vm, text, fl_words, sp, at_end, b_len, fl, lim)) span_flags_l3_literal(rs_words, fl_words, text, sp, at_end, b_len, fl, lim);
+#ifdef OVTK_SIMT_EMULATOR
+                else {   // the emulator build checks the algebra against the literal matcher on every block
+                    uint32_t fl0 = 0;
+                    int lim0 = 0;
+                    span_flags_l3_literal(rs_words, fl_words, text, sp, at_end, b_len, fl0, lim0);
+                    const int dk = lim - kSpanLane * l;
+                    const uint32_t below = dk >= kSpanLane ? ~0u : (dk <= 0 ? 0u : ((1u << dk) - 1u));
+                    const unsigned long long bad = __ballot(((fl ^ fl0) & below) != 0);
+                    if (bad || lim > lim0) {
+                        const int bl = bad ? __ffsll(bad) - 1 : 0;
+                        const uint32_t a = uint32_t(wave_readlane(int(fl), bl)), b = uint32_t(wave_readlane(int(fl0), bl));
+                        if (l == 0) {
+                            printf("span_flags_l3 differs from the literal matcher: b_len %d at_end %d und %d / %d lane %d flags %08x / %08x\n", b_len, int(at_end), lim, lim0, bl, a, b);
+                            printf("  text of the lane and its neighbours:");
+                            for (int i = (bl > 0 ? bl - 1 : 0) * 32; i < (bl + 2) * 32 && i < b_len; ++i) printf(" %02x", text[i]);
+                            printf("\n");
+                        }
+                        __builtin_trap();
+                    }
+                }
 #endif
+            } else {
+                fast = BERT ? span_flags_bert(xa, rs, vm, fl, dropped) : span_flags<DIGITS>(xa, rs, vm, text, fl);
+            }
             // ---- the block's piece list: np pieces, the last one ends at q_end (= where the next block starts); rowfirst: the list
             // index of my row's first piece, if that is one of them
             int np = 0, q_end = 0, rowfirst = 0x7FFFFFFF;
             uint32_t end_flag = 0;   // BERT words: the sentinel's kSpanOneBefore (below)
-#if defined(OVTK_SPAN_ABLATE) && OVTK_SPAN_ABLATE >= 3
-            if (fast) {
-                q_end = b_len - (at_end ? 0 : kSpanHalo);
-            } else
-#endif
             if (fast) {
                 q_end = b_len;
                 const uint32_t fl_all = fl;
                 if (!at_end) {   // the last start the block can decide ends its last whole piece
-                    const int dk = b_len - kSpanHalo - kSpanLane * l;
+                    const int dk = lim - kSpanLane * l;
                     fl &= dk >= kSpanLane ? ~0u : (dk <= 0 ? 0u : ((1u << dk) - 1u));
                     const unsigned long long nz = __ballot(fl != 0);
                     const int hl = 63 - __clzll(nz);   // (lane 0 holds the block's first byte: never empty)
@@ -580,7 +595,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                     const int first = __shfl(at0, ln) + __popc(uint32_t(__shfl(int(fl), ln)) & ((1u << (my_p & 31)) - 1u));
                     if (starts_here && my_p < q_end) rowfirst = first;
                 }
-            } else {
+            } else if constexpr (!L3) {
                 // A block with non-ASCII text: row by row, window by window (slices of a long row) through the ballot form of the rules on
                 // the block's LDS text -- a byte per lane and 64-byte word, code points through the Unicode tables, windows of up to
                 // 1 024 bytes: four times the packed form's instructions per byte.  Every window starts at a true piece start and
@@ -638,7 +653,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 const uint8_t* row_text = in.chars + wave_readlane(h_sb, k);
                 bool drop1 = false;
                 int e = 0;
-                if (l == 0) e = BERT ? bert_match_end(sp, row_text, rlen, p, drop1) : gpt2_match_end(sp, row_text, rlen, p, DIGITS);
+                if (l == 0) e = BERT ? bert_match_end(sp, row_text, rlen, p, drop1) : (L3 ? llama3_match_end(sp, row_text, rlen, p) : gpt2_match_end(sp, row_text, rlen, p, DIGITS));
                 e = wave_readlane(e, 0);
                 drop1 = wave_readlane(int(drop1), 0) != 0;
                 const int plen = e - p;
@@ -647,16 +662,21 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                     rec_cnt = wave_writelane(rec_cnt, emitted, k);
                 }
                 if (!drop1) {
-                    note_miss(l == 0, 1ull, cursor, chain_sb + pos, plen, ex0 + pos, 0u, 0u, 0u, 0u);
+                    // (longer than a block as a rule; but a block that starts inside a long white-space run decides nothing but its
+                    // first byte, and what starts there may be `\n` alone: a piece short enough for a memo key carries it)
+                    uint64_t k0 = 0, k1 = 0;
+                    if (plen <= kPieceKeyBytes && l == 0) {
+                        uint64_t r0 = 0, r1 = 0;
+                        global_bytes16(row_text + p, plen, r0, r1);
+                        piece_key(r0, r1, plen, k0, k1);
+                    }
+                    note_miss(l == 0, 1ull, cursor, chain_sb + pos, plen, ex0 + pos, uint32_t(k0), uint32_t(k0 >> 32), uint32_t(k1), uint32_t(k1 >> 32));
                     cursor += plen + SL;
                 }
                 pos += plen;
                 span_load(in, chain_sb + pos, chain_len - pos < kSpanBytes ? chain_len - pos : kSpanBytes, xa);
                 continue;
             }
-#if defined(OVTK_SPAN_ABLATE)   // (1: without the lookup rounds; 2: and without the scan; 3: and without the piece list)
-            np = 0;
-#endif
             if (l < 2) sw.pstart[np + l] = uint16_t(uint32_t(q_end) | (l == 0 ? end_flag * kSpanOneBefore : 0u));   // (two: lane j >= np reads a piece of no bytes)
             // ---- the next block's text: in flight while this block's pieces are looked up
             {
@@ -793,9 +813,6 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         wave_sync();
         span_flush(sw, n_miss, w, row0, incl32);
     }
-#if defined(OVTK_SPAN_ABLATE)
-    rec_used = rec_cnt = rec_stage = 0;   // (no row got its records)
-#endif
     const bool is_pending = l < nr && ((pending_m >> l) & 1ull);
     if (l < nr) {
         w.row_used[row0 + l] = is_pending ? kRowPending : rec_used;

@@ -53,6 +53,8 @@ struct SplitDev {
     int32_t kind;
     const uint16_t* uc_index;  // [0x110000 >> 7]
     const uint8_t* uc_blocks;  // [n_blocks * 64]
+    const uint8_t* uc_flat;    // [0x20000 / 4] the two class bits of the code points of planes 0 and 1, four to a byte: ONE load per
+                               // character (span_l3.hpp)
     int32_t drop;              // class patterns: 0 keep every piece, 1 drop the matches, 2 drop the gaps
     // kSplitLlama3: what separates the patterns of its family from Llama-3's own (api_encode.cpp picks them by pattern text)
     int32_t l3_digits1;        // 1: `\p{N}` -- every digit a piece (Qwen2) -- instead of `\p{N}{1,3}`
