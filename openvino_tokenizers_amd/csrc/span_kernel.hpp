@@ -253,46 +253,6 @@ __device__ __forceinline__ bool span_flags_bert(uint32_t (&x)[kSpanDwords], uint
     return true;
 }
 
-// ---- one piece matched literally: the piece that starts at byte p of the string s[0, slen) (p a true piece start), alternatives
-// in the pattern's order.  Only for pieces longer than a scan block (the block scan finds no second start to end them with).
-//   's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+      (digits: \p{N} for " ?\p{N}+")
-__device__ __forceinline__ int gpt2_match_end(const SplitDev& sp, const uint8_t* s, int slen, int p, bool digits) {
-    const SeqChar c0 = seq_char(sp, s, p, slen);
-    if (c0.cp == '\'' && p + 1 < slen) {
-        const uint32_t a = s[p + 1], b = p + 2 < slen ? s[p + 2] : 0u;
-        if (a == 's' || a == 't' || a == 'm' || a == 'd') return p + 2;
-        if (((a == 'r' || a == 'v') && b == 'e') || (a == 'l' && b == 'l')) return p + 3;
-    }
-    int q = -1, cls = -1;   // a run of class `cls` from q on, behind an optional U+0020
-    if (c0.cls != kClsS) {
-        q = p;
-        cls = c0.cls;
-    } else if (c0.cp == ' ' && p + 1 < slen) {
-        const SeqChar c1 = seq_char(sp, s, p + 1, slen);
-        if (c1.cls != kClsS && !(digits && c1.cls == kClsN)) {
-            q = p + 1;
-            cls = c1.cls;
-        }
-    }
-    if (q >= 0) {
-        if (digits && cls == kClsN) return q + seq_char(sp, s, q, slen).len;
-        while (q < slen) {
-            const SeqChar c = seq_char(sp, s, q, slen);
-            if (c.cls != cls) break;
-            q += c.len;
-        }
-        return q;
-    }
-    int e = p, last_char = p;   // white space: all of the run at the string's end, else all but its last character (or that one alone)
-    while (e < slen) {
-        const SeqChar c = seq_char(sp, s, e, slen);
-        if (c.cls != kClsS) break;
-        last_char = e;
-        e += c.len;
-    }
-    if (e == slen || last_char == p) return e;
-    return last_char;
-}
 // The BERT words: one delimiter character, or a run of white space (`dropped`), or a run of anything else.
 __device__ __forceinline__ int bert_match_end(const SplitDev& sp, const uint8_t* s, int slen, int p, bool& dropped) {
     auto kind = [&](int at, int& len) -> int {   // 0 word character, 1 white space, 2 delimiter
@@ -519,8 +479,8 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
             bool fast = true;
             if constexpr (L3) {
                 // the rule algebra on bit masks, whatever the script; what it does not cover (a non-ASCII digit, U+017F): lane 0, literally
-                uint32_t* fl_words = rs_words + kWave;   // (the piece list's room is still free: kSpanL3Scratch bytes of it)
-                static_assert(kWave * 4 + kSpanL3Scratch <= int(sizeof(SpanWave::pstart)), "the Llama-3 scanner's scratch lives in the piece list's room");
+                uint32_t* fl_words = rs_words + kWave;   // (the piece list's room is still free: kSpanClassScratch bytes of it)
+                static_assert(kWave * 4 + kSpanClassScratch <= int(sizeof(SpanWave::pstart)), "the Llama-3 scanner's scratch lives in the piece list's room");
                 if (!span_flags_l3(xa, rs, vm, text, fl_words, sp, at_end, b_len, fl, lim)) span_flags_l3_literal(rs_words, fl_words, text, sp, at_end, b_len, fl, lim);
 #ifdef OVTK_SIMT_EMULATOR
                 else {   // the emulator build checks the algebra against the literal matcher on every block
@@ -545,6 +505,12 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
 #endif
             } else {
                 fast = BERT ? span_flags_bert(xa, rs, vm, fl, dropped) : span_flags<DIGITS>(xa, rs, vm, text, fl);
+                if constexpr (!BERT) {
+                    // a block with non-ASCII text: the same rules on bit masks, the characters classified by the wave (span_l3.hpp;
+                    // until round 5 the ballot form window by window: four times the packed form's instructions per byte)
+                    if (!fast) span_flags_gpt2m<DIGITS>(xa, rs, vm, text, rs_words + kWave, sp, at_end, b_len, fl);
+                    fast = true;
+                }
             }
             // ---- the block's piece list: np pieces, the last one ends at q_end (= where the next block starts); rowfirst: the list
             // index of my row's first piece, if that is one of them
@@ -595,7 +561,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                     const int first = __shfl(at0, ln) + __popc(uint32_t(__shfl(int(fl), ln)) & ((1u << (my_p & 31)) - 1u));
                     if (starts_here && my_p < q_end) rowfirst = first;
                 }
-            } else if constexpr (!L3) {
+            } else if constexpr (BERT) {
                 // A block with non-ASCII text: row by row, window by window (slices of a long row) through the ballot form of the rules on
                 // the block's LDS text -- a byte per lane and 64-byte word, code points through the Unicode tables, windows of up to
                 // 1 024 bytes: four times the packed form's instructions per byte.  Every window starts at a true piece start and

@@ -112,18 +112,28 @@ __device__ __forceinline__ uint32_t flood_down(uint32_t link, uint32_t seed, uin
 // SplitDev::uc_flat holds the two class bits (kClsO / kClsL / kClsN / kClsS) of the code points below kUcFlatLimit, four to a byte: planes
 // 0 and 1 (every script in use, the emoji, the mathematical alphabets); the rest goes through the two-level table.
 constexpr uint32_t kUcFlatLimit = 0x20000u;
-constexpr int kSpanL3Scratch = 3 * kWave * 4 + 1024 * 2;   // three 64-word bit masks and up to 1 024 lead bytes (a block of two-byte characters)
+constexpr int kSpanClassScratch = 4 * kWave * 4 + 1024 * 2;   // four 64-word bit masks and up to 1 024 lead bytes (a block of two-byte characters)
 struct __attribute__((packed, aligned(1))) L3Bytes4 { uint32_t v; };
 
-// Piece starts of the block's bytes (flags bit i = byte 32 l + i starts a piece) under the Llama-3 family's rules.
+// The class masks of the block's bytes: bit i of a lane's word = byte 32 l + i is of the class; a character's class stands on ALL its
+// bytes, so that runs are runs of bytes.
 //   x      the lane's 32 bytes (bytes behind the block: anything)          vm    bit i: byte 32 l + i belongs to the block
 //   rs     row starts: bit i = byte 32 l + i is the first byte of a row    text  the block's bytes in LDS (the same bytes)
 //   at_end the block ends where its text ends (else: it was cut at 2 048 bytes and more follows)
-//   scratch kSpanL3Scratch bytes of LDS (the characters' list and class masks of a block with non-ASCII text)
-//   und    (out) starts at positions >= und may depend on what follows the block: they are not to be used
-// false (wave-uniform): the block holds a character the algebra does not cover (`odd` above); flags / und are not set.
-__device__ __forceinline__ bool span_flags_l3(const uint32_t (&x)[8], uint32_t rs, uint32_t vm, const uint8_t* text, uint32_t* scratch,
-                                              const SplitDev& sp, bool at_end, int b_len, uint32_t& flags, int& und) {
+//   scratch kSpanClassScratch bytes of LDS (the characters' list and class masks of a block with non-ASCII text)
+struct SpanClassMasks {
+    uint32_t L, N, W, SP, NL, AP;   // \p{L}, \p{N}, \s, U+0020, \r \n, the apostrophe
+    uint32_t INS;                   // bytes of a character behind its first
+    uint32_t V;                     // the block's bytes
+    uint32_t p[7];                  // bit planes 0..6 of the bytes (plane k, bit i = bit k of byte i)
+    uint32_t asc;                   // V and below 0x80
+    bool any_hi;                    // (wave-uniform) the block holds a byte >= 0x80
+};
+// STRICT_N (the Llama-3 family): false (wave-uniform) when the block holds a non-ASCII \p{N} or U+017F -- what that family's algebra
+// does not cover; else a non-ASCII \p{N} is of class N like any digit (the GPT-2 family: ` ?\p{N}+`, or every N character a piece).
+template <bool STRICT_N>
+__device__ __forceinline__ bool span_class_masks(const uint32_t (&x)[8], uint32_t rs, uint32_t vm, const uint8_t* text, uint32_t* scratch,
+                                                 const SplitDev& sp, bool at_end, int b_len, SpanClassMasks& cm) {
     const int l = lane_id();
     uint32_t pl[8];
     span_bit_planes(x, pl);
@@ -134,14 +144,14 @@ __device__ __forceinline__ bool span_flags_l3(const uint32_t (&x)[8], uint32_t r
     const uint32_t hn0 = asc & ~(p6 | p5 | p4);                                   // 0x00 .. 0x0F
     const uint32_t low5_gt26 = p4 & p3 & (p2 | (p1 & p0));
     uint32_t L = asc & p6 & (p0 | p1 | p2 | p3 | p4) & ~low5_gt26;                // 0x41..0x5A, 0x61..0x7A
-    const uint32_t N = asc & ~p6 & p5 & p4 & ~(p3 & (p2 | p1));                    // 0x30..0x39
+    uint32_t N = asc & ~p6 & p5 & p4 & ~(p3 & (p2 | p1));                          // 0x30..0x39
     const uint32_t SP = asc & ~p6 & p5 & ~(p4 | p3 | p2 | p1 | p0);               // 0x20
     const uint32_t NL = hn0 & p3 & (p1 ^ p0) & (p2 ^ p1);                          // 0x0A, 0x0D
     uint32_t W = SP | (hn0 & p3 & (p0 | p1 | p2) & ~(p2 & p1));                    // 0x09..0x0D, 0x20
     const uint32_t AP = asc & ~p6 & p5 & ~(p4 | p3) & p2 & p1 & p0;               // 0x27
-    // ---- non-ASCII characters: every lane its own lead bytes
+    // ---- non-ASCII characters
     const uint32_t HI = V & p7;
-    uint32_t INS = 0;   // bytes of a character behind its first
+    uint32_t INS = 0;
     const bool any_hi = __ballot(HI != 0) != 0;
     if (any_hi) {
         // A lane's own loop over its lead bytes -- code point, table, class, one after the other -- runs as long as the lane with the
@@ -153,11 +163,12 @@ __device__ __forceinline__ bool span_flags_l3(const uint32_t (&x)[8], uint32_t r
         const uint32_t lead = HI & p6;
         const uint32_t brk = rs | ~V;   // a row begins here, or the block is over
         const unsigned long long brk64 = (unsigned long long)brk | ((unsigned long long)(lane_next(rs) | ~lane_next(V)) << 32);
-        uint32_t* cw = scratch;                                           // [3][64]: L, W, INS
-        uint16_t* list = reinterpret_cast<uint16_t*>(scratch + 3 * kWave);   // [<= 1024]
+        uint32_t* cw = scratch;                                           // [4][64]: L, W, INS, N
+        uint16_t* list = reinterpret_cast<uint16_t*>(scratch + 4 * kWave);   // [<= 1024]
         cw[l] = 0;
         cw[kWave + l] = 0;
         cw[2 * kWave + l] = 0;
+        if (!STRICT_N) cw[3 * kWave + l] = 0;
         const int cnt = __popc(lead);
         const int incl = wave_incl_sum(cnt);
         const int n_lead = wave_readlane(incl, kWave - 1);
@@ -196,12 +207,12 @@ __device__ __forceinline__ bool span_flags_l3(const uint32_t (&x)[8], uint32_t r
                 uint32_t cls;
                 if (cp < kUcFlatLimit) cls = (uint32_t(sp.uc_flat[cp >> 2]) >> (2 * (cp & 3u))) & 3u;
                 else cls = uc_nibble(sp, cp) & 3u;
-                if ((cls == kClsN || cp == 0x17Fu) && !cut) odd = true;
+                if (STRICT_N && (cls == kClsN || cp == 0x17Fu) && !cut) odd = true;
                 const unsigned long long m = ((1ull << have) - 1ull) << (p & 31);
                 const uint32_t m_lo = uint32_t(m), m_hi = uint32_t(m >> 32);
                 const int word = p >> 5;
-                if (cls == kClsL || cls == kClsS) {
-                    uint32_t* dst = cw + (cls == kClsS ? kWave : 0) + word;
+                if (cls == kClsL || cls == kClsS || (!STRICT_N && cls == kClsN)) {
+                    uint32_t* dst = cw + (cls == kClsS ? kWave : (cls == kClsN ? 3 * kWave : 0)) + word;
                     atomicOr(dst, m_lo);
                     if (m_hi) atomicOr(dst + 1, m_hi);
                 }
@@ -210,12 +221,30 @@ __device__ __forceinline__ bool span_flags_l3(const uint32_t (&x)[8], uint32_t r
                 if (m_hi) atomicOr(cw + 2 * kWave + word + 1, m_hi);
             }
         }
-        if (__ballot(odd)) return false;
+        if (STRICT_N && __ballot(odd)) return false;
         wave_sync();
         L = (L | cw[l]) & V;
         W = (W | cw[kWave + l]) & V;
         INS = cw[2 * kWave + l] & V;
+        if (!STRICT_N) N = (N | cw[3 * kWave + l]) & V;
     }
+    cm.L = L; cm.N = N; cm.W = W; cm.SP = SP; cm.NL = NL; cm.AP = AP; cm.INS = INS; cm.V = V; cm.asc = asc; cm.any_hi = any_hi;
+    cm.p[0] = p0; cm.p[1] = p1; cm.p[2] = p2; cm.p[3] = p3; cm.p[4] = p4; cm.p[5] = p5; cm.p[6] = p6;
+    return true;
+}
+
+// Piece starts of the block's bytes (flags bit i = byte 32 l + i starts a piece) under the Llama-3 family's rules; the arguments are
+// span_class_masks'.
+//   und    (out) starts at positions >= und may depend on what follows the block: they are not to be used
+// false (wave-uniform): the block holds a character the algebra does not cover (`odd` above); flags / und are not set.
+__device__ __forceinline__ bool span_flags_l3(const uint32_t (&x)[8], uint32_t rs, uint32_t vm, const uint8_t* text, uint32_t* scratch,
+                                              const SplitDev& sp, bool at_end, int b_len, uint32_t& flags, int& und) {
+    const int l = lane_id();
+    SpanClassMasks cm;
+    if (!span_class_masks<true>(x, rs, vm, text, scratch, sp, at_end, b_len, cm)) return false;
+    const uint32_t L = cm.L, N = cm.N, W = cm.W, SP = cm.SP, NL = cm.NL, AP = cm.AP, INS = cm.INS, V = cm.V, asc = cm.asc;
+    const uint32_t p0 = cm.p[0], p1 = cm.p[1], p2 = cm.p[2], p3 = cm.p[3], p4 = cm.p[4], p6 = cm.p[6];
+    const bool any_hi = cm.any_hi;
     const uint32_t O = V & ~(L | N | W);
     // ---- the neighbours' words; "the byte before / behind, in my row"
     const uint32_t rs_n = lane_next(rs), V_n = lane_next(V);
@@ -329,6 +358,53 @@ __device__ __forceinline__ bool span_flags_l3(const uint32_t (&x)[8], uint32_t r
         if (nonw_end < b_len - 3 && nonw_end + 1 < und) und = nonw_end + 1;
     }
     return true;
+}
+
+// ---- the GPT-2 family on the same masks (a block with non-ASCII text: span_kernel.hpp's span_flags is the ASCII form)
+//   's|'t|'re|'ve|'m|'ll|'d | ?\p{L}+ | ?\p{N}+ | ?[^\s\p{L}\p{N}]+ | \s+(?!\S) | \s+        (DIGITS: `\p{N}` for ` ?\p{N}+`)
+// gpt2_start_mask's rules (split_device.hpp): every look is at most one character ahead and two letters, so a cut block decides all
+// but its last kSpanHalo bytes; a non-ASCII \p{N} is a digit like any other.
+template <bool DIGITS>
+__device__ __forceinline__ void span_flags_gpt2m(const uint32_t (&x)[8], uint32_t rs, uint32_t vm, const uint8_t* text, uint32_t* scratch,
+                                                 const SplitDev& sp, bool at_end, int b_len, uint32_t& flags) {
+    SpanClassMasks cm;
+    span_class_masks<false>(x, rs, vm, text, scratch, sp, at_end, b_len, cm);
+    const uint32_t L = cm.L, N = cm.N, S = cm.W, SP = cm.SP, AP = cm.AP, INS = cm.INS, V = cm.V;
+    const uint32_t O = V & ~(L | N | S);
+    const uint32_t rs_n = lane_next(rs), V_n = lane_next(V);
+    const uint32_t re = bm_after<1>(rs, rs_n) | ~bm_after<1>(V, V_n);   // the last byte of its row (or of the block)
+    const uint32_t pL = bm_before<1>(L, lane_prev(L)) & ~rs, pN = bm_before<1>(N, lane_prev(N)) & ~rs, pS = bm_before<1>(S, lane_prev(S)) & ~rs;
+    const uint32_t pO = bm_before<1>(O, lane_prev(O)) & ~rs, pSP = bm_before<1>(SP, lane_prev(SP)) & ~rs;
+    const uint32_t same = (L & pL) | (N & pN) | (S & pS) | (O & pO);
+    const uint32_t attaches = ~S & (DIGITS ? ~N : ~0u);
+    uint32_t st = ~same & ~(pSP & attaches);
+    // the last character of a white-space run that something follows (\s+(?!\S) backing off)
+    uint32_t next_nonspace = bm_after<1>(V & ~S, V_n & ~lane_next(S)) & ~re;   // the byte behind is of my row and not white space ...
+    if (cm.any_hi) {   // ... asked at the character's last byte
+        const uint32_t INS_n = lane_next(INS), q_n = lane_next(next_nonspace);
+        const uint32_t i1 = bm_after<1>(INS, INS_n), i2 = bm_after<2>(INS, INS_n), i3 = bm_after<3>(INS, INS_n);
+        next_nonspace = (~i1 & next_nonspace) | (i1 & ~i2 & bm_after<1>(next_nonspace, q_n)) | (i1 & i2 & ~i3 & bm_after<2>(next_nonspace, q_n)) |
+                        (i1 & i2 & i3 & bm_after<3>(next_nonspace, q_n));
+    }
+    st |= same & ((S & next_nonspace) | (DIGITS ? N : 0u));
+    // contractions: an apostrophe that starts a piece (what stands in front of it is neither of class O nor U+0020) and s|t|m|d or
+    // re|ve|ll behind it in its row; the letters stay with it, the byte behind them starts a piece
+    if (__ballot(AP != 0)) {
+        const uint32_t p0 = cm.p[0], p1 = cm.p[1], p2 = cm.p[2], p3 = cm.p[3], p4 = cm.p[4];
+        const uint32_t low = cm.asc & cm.p[6] & cm.p[5];   // 0x60..0x7F
+        const uint32_t X1 = low & ((p4 & ~p3 & ~p2 & p1 & p0) | (p4 & ~p3 & p2 & ~p1 & ~p0) | (~p4 & p3 & p2 & ~p1 & p0) | (~p4 & ~p3 & p2 & ~p1 & ~p0));  // s t m d
+        const uint32_t X2 = low & p4 & ~p3 & p1 & ~p0;         // r (10010) v (10110)
+        const uint32_t XE = low & ~p4 & ~p3 & p2 & ~p1 & p0;   // e (00101)
+        const uint32_t XL = low & ~p4 & p3 & p2 & ~p1 & ~p0;   // l (01100)
+        const uint32_t Y = (X2 & bm_after<1>(XE, lane_next(XE)) & ~re) | (XL & bm_after<1>(XL, lane_next(XL)) & ~re);   // re|ve|ll begins here
+        const uint32_t blocked = pO | pSP;
+        const uint32_t f1 = AP & bm_after<1>(X1, lane_next(X1)) & ~re & ~blocked, f2 = AP & bm_after<1>(Y, lane_next(Y)) & ~re & ~blocked;
+        const uint32_t f1_p = lane_prev(f1), f2_p = lane_prev(f2);
+        st |= bm_before<2>(f1, f1_p) | bm_before<3>(f2, f2_p);
+        st &= ~bm_before<1>(f1 | f2, f1_p | f2_p);
+    }
+    flags = (st & V & ~INS) | (rs & V);
+    if (lane_id() == 0) flags |= 1u;
 }
 
 // The same by the literal matcher, on lane 0 (wave-uniform call): the blocks span_flags_l3 does not cover -- and, in the emulator

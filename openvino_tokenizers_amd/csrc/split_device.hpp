@@ -209,6 +209,47 @@ __device__ __forceinline__ int llama3_match_end(const SplitDev& sp, const uint8_
     return e;
 }
 
+// ---- the GPT-2 family's pattern matched literally: the piece that starts at byte p of the string s[0, slen) (p a true piece start),
+// alternatives in the pattern's order.  For pieces longer than a scan block of lookup_span_kernel (the block scan finds no second start to
+// end them with), and what the bit-mask form of the rules (span_l3.hpp) is fuzzed against.
+//   's|'t|'re|'ve|'m|'ll|'d| ?\p{L}+| ?\p{N}+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+      (digits: \p{N} for " ?\p{N}+")
+__device__ __forceinline__ int gpt2_match_end(const SplitDev& sp, const uint8_t* s, int slen, int p, bool digits) {
+    const SeqChar c0 = seq_char(sp, s, p, slen);
+    if (c0.cp == '\'' && p + 1 < slen) {
+        const uint32_t a = s[p + 1], b = p + 2 < slen ? s[p + 2] : 0u;
+        if (a == 's' || a == 't' || a == 'm' || a == 'd') return p + 2;
+        if (((a == 'r' || a == 'v') && b == 'e') || (a == 'l' && b == 'l')) return p + 3;
+    }
+    int q = -1, cls = -1;   // a run of class `cls` from q on, behind an optional U+0020
+    if (c0.cls != kClsS) {
+        q = p;
+        cls = c0.cls;
+    } else if (c0.cp == ' ' && p + 1 < slen) {
+        const SeqChar c1 = seq_char(sp, s, p + 1, slen);
+        if (c1.cls != kClsS && !(digits && c1.cls == kClsN)) {
+            q = p + 1;
+            cls = c1.cls;
+        }
+    }
+    if (q >= 0) {
+        if (digits && cls == kClsN) return q + seq_char(sp, s, q, slen).len;
+        while (q < slen) {
+            const SeqChar c = seq_char(sp, s, q, slen);
+            if (c.cls != cls) break;
+            q += c.len;
+        }
+        return q;
+    }
+    int e = p, last_char = p;   // white space: all of the run at the string's end, else all but its last character (or that one alone)
+    while (e < slen) {
+        const SeqChar c = seq_char(sp, s, e, slen);
+        if (c.cls != kClsS) break;
+        last_char = e;
+        e += c.len;
+    }
+    if (e == slen || last_char == p) return e;
+    return last_char;
+}
 // Stage bytes [w0, w1) of the string at `str` (global) into ws.text_w.  Returns the skew: string
 // byte p lives at text_bytes(ws)[p - w0 + skew].  Whole aligned dwords are fetched; a dword that straddles an end of
 // the string is masked down to the string's own bytes (the others are staged as zeros) -- it is still one load as long

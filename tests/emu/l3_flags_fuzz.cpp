@@ -1,6 +1,7 @@
-// tests/emu/l3_flags_fuzz.cpp -- TEST INFRASTRUCTURE: differential fuzz of span_flags_l3 (csrc/span_l3.hpp, the Llama-3 family's rule
-// algebra on bit masks) against the literal matcher llama3_match_end (csrc/split_device.hpp; itself pinned against PCRE2 by
-// tests/test_split_rules.py), on the SIMT emulator.
+// tests/emu/l3_flags_fuzz.cpp -- TEST INFRASTRUCTURE: differential fuzz of span_flags_l3 and span_flags_gpt2m (csrc/span_l3.hpp: the rule
+// algebra of the Llama-3 and GPT-2 families on bit masks) against the literal matchers llama3_match_end / gpt2_match_end
+// (csrc/split_device.hpp; the first pinned against PCRE2 by tests/test_split_rules.py, the second by the fused-encode tests of
+// tests/test_span_kernel.py), on the SIMT emulator.
 //
 // One wave per case, as lookup_span_kernel calls it: a block of up to 2 048 bytes that holds whole rows, may begin inside a row (at a
 // true piece start) and may be cut inside its last row (at_end = false: exactly 2 048 bytes, more text follows).  The truth is the
@@ -27,11 +28,12 @@ struct Case {
     uint32_t* flags;        // [64] out
     int* und;               // out
     int* covered;           // out: 0 = the algebra declined (odd)
+    int family;             // 0: the Llama-3 family (span_flags_l3), 1 / 2: the GPT-2 family (span_flags_gpt2m<false / true>)
 };
 
 static __global__ void l3_case_kernel(Case c, SplitDev sp) {
     __shared__ uint32_t text_w[kWave * 8 + 16];
-    __shared__ uint32_t scratch[kSpanL3Scratch / 4];
+    __shared__ uint32_t scratch[kSpanClassScratch / 4];
     const int l = lane_id();
     uint32_t x[8];
     for (int j = 0; j < 8; ++j) {
@@ -45,7 +47,14 @@ static __global__ void l3_case_kernel(Case c, SplitDev sp) {
     const uint32_t vm = nv >= 32 ? ~0u : (nv <= 0 ? 0u : ((1u << nv) - 1u));
     uint32_t fl = 0;
     int und = 0;
-    const bool ok = span_flags_l3(x, c.rs[l], vm, reinterpret_cast<const uint8_t*>(text_w), scratch, sp, c.at_end != 0, c.b_len, fl, und);
+    bool ok = true;
+    if (c.family == 0) {
+        ok = span_flags_l3(x, c.rs[l], vm, reinterpret_cast<const uint8_t*>(text_w), scratch, sp, c.at_end != 0, c.b_len, fl, und);
+    } else {
+        if (c.family == 1) span_flags_gpt2m<false>(x, c.rs[l], vm, reinterpret_cast<const uint8_t*>(text_w), scratch, sp, c.at_end != 0, c.b_len, fl);
+        else span_flags_gpt2m<true>(x, c.rs[l], vm, reinterpret_cast<const uint8_t*>(text_w), scratch, sp, c.at_end != 0, c.b_len, fl);
+        und = c.at_end ? c.b_len : c.b_len - 8;   // (lookup_span_kernel's kSpanHalo)
+    }
     c.flags[l] = fl;
     if (l == 0) {
         *c.und = und;
@@ -110,12 +119,13 @@ static std::string make_row(Rng& r, int target, int odd_pct, int bad_pct) {
 }
 
 // piece starts of the row s from byte `from` (a true piece start) on
+static int g_family = 0;
 static void truth_starts(const SplitDev& sp, const std::string& s, int from, std::vector<uint8_t>& is_start) {
     is_start.assign(s.size() + 1, 0);
     const uint8_t* p = reinterpret_cast<const uint8_t*>(s.data());
     for (int q = from; q < int(s.size());) {
         is_start[q] = 1;
-        q = llama3_match_end(sp, p, int(s.size()), q);
+        q = g_family == 0 ? llama3_match_end(sp, p, int(s.size()), q) : gpt2_match_end(sp, p, int(s.size()), q, g_family == 2);
     }
 }
 
@@ -126,6 +136,7 @@ int main(int argc, char** argv) {
         Rng r(0x9E3779B97F4A7C15ull * uint64_t(seed + 1));
         for (int it = 0; it < per_seed; ++it) {
             const SplitDev sp = make_split(r.chance(25), r.chance(30));
+            g_family = r.below(3) == 0 ? 1 + r.below(2) : 0;   // a third of the cases: the GPT-2 family's mask form
             const int odd_pct = r.chance(15) ? 3 : 0, bad_pct = r.chance(15) ? 4 : 0;
             // rows until the block is full (or, for a block that ends with its text, until a random length)
             const bool want_cut = r.chance(45);
@@ -175,7 +186,7 @@ int main(int argc, char** argv) {
                 for (int q = b_len; q < b_len + 64; ++q) chars[q] = uint8_t("el 'stx\n1\xA9\xC3"[r.below(11)]);
             uint32_t flags[64];
             int und = -1, covered = -1;
-            Case c{chars.data(), b_len, at_end ? 1 : 0, rs, flags, &und, &covered};
+            Case c{chars.data(), b_len, at_end ? 1 : 0, rs, flags, &und, &covered, g_family};
             hipLaunchKernelGGL(l3_case_kernel, 1, 64, 0, nullptr, c, sp);
             ++n_cases;
             if (!covered) {
@@ -201,7 +212,7 @@ int main(int argc, char** argv) {
                 }
             }
             if (bad) {
-                printf("DIFFERENCE seed %d case %d: b_len %d at_end %d und %d digits1 %d tail_ws %d at byte %d (got %d)\n", seed, it, b_len, int(at_end), und,
+                printf("DIFFERENCE seed %d case %d family %d: b_len %d at_end %d und %d digits1 %d tail_ws %d at byte %d (got %d)\n", seed, it, g_family, b_len, int(at_end), und,
                        sp.l3_digits1, sp.l3_tail_ws, where, where >= 0 ? int((flags[where >> 5] >> (where & 31)) & 1u) : -1);
                 if (where >= 0) {
                     const int a = where > 24 ? where - 24 : 0, b = where + 48 < int(chars.size()) ? where + 48 : int(chars.size());
