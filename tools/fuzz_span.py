@@ -1,6 +1,7 @@
 """GPU fuzz of lookup_span_kernel against the oracle: random batches of rows built from fragments that stress the block logic (rows of
 every length from 1 byte to several blocks, blanks and delimiters at row edges, contractions, non-ASCII text, giant pieces), through
-the fused GPT-2 / individual-digits / BERT-words paths, two calls per batch (cold tables, then what they learned).
+the fused GPT-2 / individual-digits / BERT-words paths and (round 5) the Llama-3 family's three patterns (Llama-3, Qwen2, tiktoken
+cl100k: lookup_span_kernel<kSpanLlama3>, csrc/span_l3.hpp), two calls per batch (cold tables, then what they learned).
     python tools/fuzz_span.py [first_seed] [last_seed]
 Prints one line per seed; exits 1 at the first difference."""
 import sys
@@ -19,28 +20,31 @@ from tests.test_span_kernel import DIGITS_PATTERN, rows_of  # noqa: E402
 from tests.util import BpeTok  # noqa: E402
 from tools.make_tokenizers import load_tokenizer  # noqa: E402
 
+L3_FRAG = ["\n", "\n\n", "\r\n", " \n", "\n    ", "\n\t", "123", "1234567", "12345678901234567890123456789012345", "'S", "'LL", "I'M", "they'Re", "\u00a0", "\u3000", "\u2028",
+           "x²", "١٢٣", "ſ", "'ſ", "!\n\n", "...\n", "}\n\n", " \n \n  \n"]
 FRAG = ["the", "token", "izer", " ", " ", " ", "  ", "\n", "\t", "a", "x", ",", ".", "!?", "don't", "we'll", "'", "'s", "I'm", "12", "2024", "1", "a1b2", "--", "(", ")",
         "naïve", "straße", "日本語", "Ωμέγα", "😀", "hello", "world", "un", "affable", "e.g.", " , ", "q" * 17, "word" * 5]
 
 
-def rows(rng, n):
+def rows(rng, n, frag=None):
+    frag = frag or FRAG
     out = []
     for _ in range(n):
         k = int(rng.integers(0, 9))
         if k == 0:
             s = rng.choice([" ", "", "\n", ",", "a", " a", "a ", "  "])
         elif k == 1:
-            s = "".join(rng.choice(FRAG, size=int(rng.integers(1, 6))))
+            s = "".join(rng.choice(frag, size=int(rng.integers(1, 6))))
         elif k == 2:
             s = " ".join(rng.choice(FRAG[:20], size=int(rng.integers(1, 80))))
         elif k == 3:
-            s = "".join(rng.choice(FRAG, size=int(rng.integers(200, 900))))
+            s = "".join(rng.choice(frag, size=int(rng.integers(200, 900))))
         elif k == 4:
-            s = rng.choice(["a", " ", "7", "日", ","]) * int(rng.integers(1, 4200))
+            s = rng.choice(["a", " ", "7", "日", ",", "\n"]) * int(rng.integers(1, 4200))
         elif k == 5:
             s = "ab " * int(rng.integers(1, 800))
         else:
-            s = "".join(rng.choice(FRAG, size=int(rng.integers(1, 120))))
+            s = "".join(rng.choice(frag, size=int(rng.integers(1, 120))))
         out.append(s.encode())
     return out
 
@@ -56,7 +60,8 @@ def check(ref, got, what):
 def main():
     lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 20)
     lib = L.load()
-    gpt2, bert = BpeTok.load("gpt2_small"), load_tokenizer("bert_small")
+    from tools.workloads import MODEL_PATTERNS
+    gpt2, bert, llama3 = BpeTok.load("gpt2_small"), load_tokenizer("bert_small"), BpeTok.load("llama3_small")
     ws_pat, pu_pat = np.frombuffer(BERT_WS.encode(), np.uint8), np.frombuffer(BERT_PUNCT.encode(), np.uint8)
     for seed in range(lo, hi):
         rng = np.random.default_rng(seed)
@@ -72,7 +77,15 @@ def main():
                                  WordpieceTokenizer(bert["suffix_indicator"], bert["max_bytes_per_word"], lib=lib))
         for call in range(3):
             check(ref, fw.evaluate(dev, ws_pat, pu_pat, wp_consts(bert)), f"seed {seed} BERT call {call}")
-        print(f"seed {seed}: {len(inputs[0])} rows, {len(inputs[4])} bytes ok", flush=True)
+        inputs3 = rows_of(rows(rng, int(rng.integers(300, 700)), FRAG + L3_FRAG))
+        dev3 = [torch.as_tensor(a, device="cuda") for a in inputs3]
+        for name in ("llama3", "qwen2", "cl100k"):
+            pattern = MODEL_PATTERNS.get(name, llama3.pattern)
+            ref = llama3.oracle()(*O.RegexSplit(pattern, "isolate")(*inputs3)[:5])
+            fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**llama3.attrs, lib=lib))
+            for call in range(2):
+                check(ref, fused.evaluate(dev3 + [np.frombuffer(pattern.encode(), np.uint8)], llama3.consts), f"seed {seed} {name} call {call}")
+        print(f"seed {seed}: {len(inputs[0])} + {len(inputs3[0])} rows, {len(inputs[4])} + {len(inputs3[4])} bytes ok", flush=True)
 
 
 if __name__ == "__main__":
