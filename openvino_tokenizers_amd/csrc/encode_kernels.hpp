@@ -1022,8 +1022,18 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     IdT* fnid = fid + kFastSyms * kWave;                                      // path F
     const int l = lane_id();
     const int SL = T.suffix_len;
-    // the piece store takes entries while its room counter is positive (a few more may slip in: every wave reads it once)
-    const bool store_open = T.store.slots && wave_uniform(__hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) > 0;
+    // The piece store takes entries while its room counter is positive.  Every wave reads the counter ONCE (a look per batch is a
+    // round trip on every batch's chain) -- and until round 5 a wave that found it positive filed for its whole life: a launch whose
+    // ten million pieces are all new (uniform random text) left a store made for 200 000 entries with every one of its million slots
+    // taken, and every later lookup of a new piece walked the overflow lines of a full table (stress.uniform_text 67.6 -> 59.4 GB/s).
+    // Now the room a wave finds is shared out: a wave files at most its share of it, so a LAUNCH files at most the room it found,
+    // whatever its text (launches that overlap on several streams may each find the same room: a small multiple at worst).
+    int store_budget = 0;
+    if (T.store.slots) {
+        const int room = wave_uniform(__hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int n_waves_grid = (solo ? 1 : int(gridDim.x) * int(gridDim.y)) * kWavesPerBlock;
+        store_budget = room > 0 ? (room + n_waves_grid - 1) / n_waves_grid : 0;
+    }
     {  // (x is the fastest-varying block index: blocks that become resident late are spread over all shards; solo: the
        // small batch's blocks filed everything under shard 0)
     const int shard = solo ? 0 : int(blockIdx.x);
@@ -1094,10 +1104,11 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         // What the batch had to merge is offered to the store while it has room (`store_open`, read once per wave at the
         // kernel's start: the count is kept with returnless adds, nothing here waits for an atomic's answer).
         auto store_offer = [&](bool want, const uint32_t (&key)[8], uint32_t (&pay)[8], int cnt) {
-            if (!store_open || !__ballot(want)) return;
+            if (store_budget <= 0 || !__ballot(want)) return;
             const bool added = want && store_insert<NARROW>(T.store, key, pay, cnt);
             const int n_added = __popcll(__ballot(added));
             if (l == 0 && n_added) atomicAdd(T.store.room, -n_added);
+            store_budget -= n_added;
         };
         const bool is_f = valid && !stored && e.len >= 1 && e.len <= kPieceKeyBytes && need <= kFastSyms;
         const bool is_l = valid && !stored && !is_f && e.len >= 1 && need <= kLongSyms;

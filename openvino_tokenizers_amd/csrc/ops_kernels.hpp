@@ -148,7 +148,13 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
     if (count > w.shard_cap) count = w.shard_cap;
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
     const int stride = int(gridDim.x) * kBlockThreads;
-    const bool store_open = wave_uniform(store_room) > 0;
+    // (a wave files at most its share of the room it found: merge_body says why)
+    int store_budget = 0;
+    {
+        const int room = wave_uniform(store_room);
+        const int n_waves_grid = int(gridDim.x) * int(gridDim.y) * kWavesPerBlock;
+        store_budget = room > 0 ? (room + n_waves_grid - 1) / n_waves_grid : 0;
+    }
     if (wave_uniform(memo_room) <= 0) my_room = nullptr;
     for (int base = (int(blockIdx.x) * kWavesPerBlock + wave_in_block()) * kWave; base < count; base += stride) {
         const bool valid = base + l < count;
@@ -200,7 +206,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
             }
             for (int k = cnt; k < e.len; ++k) out.clear(k);
         }
-        if (store_open) {  // file what was walked: its ids come back from the lane's own staging entries
+        if (store_budget > 0) {  // file what was walked: its ids come back from the lane's own staging entries
             const int max_ids = T.store.narrow ? kStoreIds16 : kStoreIds32;
             const bool want = keyed && !stored && cnt <= max_ids && !(cnt == 1 && out.get(0) == unk_id);
             if (__ballot(want)) {
@@ -217,6 +223,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                 }
                 const int n_added = __popcll(__ballot(added));
                 if (l == 0 && n_added) atomicAdd(T.store.room, -n_added);
+                store_budget -= n_added;
             }
         }
         // The word memo learns them too (encode_kernels.hpp memo_insert, as merge_kernel does for the BPE pieces): a word of up to 15
