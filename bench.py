@@ -42,7 +42,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 from openvino_tokenizers_amd import _lib as L  # noqa: E402
-from openvino_tokenizers_amd.ops import (BPETokenizer, RegexSplit, VocabDecoder, VocabEncoder, WordpieceTokenizer)  # noqa: E402
+from openvino_tokenizers_amd.ops import (BPETokenizer, RegexSplit, SpecialTokensSplit, VocabDecoder, VocabEncoder, WordpieceTokenizer)  # noqa: E402
 from tools.harness import BERT_PUNCT, BERT_WS, BpeTok, pack_strings  # noqa: E402
 from tools.make_tokenizers import load_tokenizer  # noqa: E402
 from tools.workloads import TextModel, ragged_rows  # noqa: E402
@@ -153,11 +153,11 @@ class EncodeWorkload:
 
 class BpeEncode(EncodeWorkload):
     def __init__(self, args, lib, dev, rank, tokenizer, kind, rows, nbytes, seed0, no_memo=False, n_batches=None, cache_capacity=None,
-                 pattern=None):
+                 pattern=None, model=None):
         self.tok = BpeTok.load(tokenizer)
         if pattern:   # the same tables behind another model's split pattern (tools/workloads.py MODEL_PATTERNS)
             self.tok.pattern = pattern
-        model = TextModel(1234, kind)
+        model = model or TextModel(1234, kind)
         nb = n_batches or args.batches
         super().__init__(lib, dev, TextBatches(model, rows, nbytes, [seed0 + 100 * rank + 7 * j for j in range(nb)], dev))
         self.split = RegexSplit("isolate", device=dev.index, lib=lib)
@@ -207,6 +207,121 @@ class BpeEncode(EncodeWorkload):
         from oracle import oracle as O
         orc, ors = self.tok.oracle(), O.RegexSplit(self.tok.pattern, "isolate")
         return (lambda rb, re_, b, e, c: orc(*ors(rb, re_, b, e, c)[:5])), "RegexSplit(PCRE2 JIT)+BPETokenizer restatement, piece cache warm"
+
+
+class SpecialTextModel(TextModel):
+    """The zipf text with a special token written over the middle of one row in a hundred (same offsets: 13 bytes replaced)."""
+    TOKEN = b"<|endoftext|>"
+
+    def batch(self, n_rows, target_len, seed=None):
+        b, e, c = super().batch(n_rows, target_len, seed=seed)
+        rng = np.random.default_rng(0 if seed is None else seed + 1)
+        tok = np.frombuffer(self.TOKEN, np.uint8)
+        for i in np.flatnonzero(rng.random(n_rows) < 0.01):
+            if e[i] - b[i] > 2 * len(tok):
+                at = int(b[i]) + int(rng.integers(0, e[i] - b[i] - len(tok)))
+                c[at:at + len(tok)] = tok
+        return b, e, c
+
+
+class PipelineEncode(BpeEncode):
+    """The graph a converted GPT-2 tokenizer runs (python/openvino_tokenizers/tokenizer_pipeline.py:1613-1636) from
+    the decomposed string tensor on: SpecialTokensSplit -> RegexSplit -> BPETokenizer (one call: ovtk_encode_special_enqueue) ->
+    Truncate(max_length 1024) -> CombineSegments -> RaggedToDense x 2 = input_ids [B, T] and attention_mask [B, T], T = the batch's
+    longest row (the PaddingStep's ReduceMax) -- ONE library call per batch (ovtk_encode_dense_enqueue / _finish: the encode's last
+    pass writes the dense tensors, no ragged ids tensor), or with --pipeline-calls 2 the encode and ovtk_encode_tail_run."""
+    MAX_LENGTH = 1024
+
+    def __init__(self, args, lib, dev, rank):
+        super().__init__(args, lib, dev, rank, "gpt2", "zipf", args.rows, args.bytes, 1000, model=SpecialTextModel(1234, "zipf"))
+        self.special_pattern = r"(\<\|endoftext\|\>)"   # what SpecialTokensSplitStep builds for this token (tokenizer_pipeline.py:138-159, quote_meta)
+        self.special = SpecialTokensSplit(device=dev.index, lib=lib)
+        self.special._ensure(np.frombuffer(self.special_pattern.encode(), np.uint8))
+        self.pad_id = int(self.tok.added[b"<|endoftext|>"])
+        rows = self.batches.rows
+        self.tcap = 256 if args.bytes <= 600 else self.MAX_LENGTH   # room per row in the dense outputs (a row of n bytes has at most n ids)
+        self.dense = [(torch.empty(rows * self.tcap, dtype=torch.int32, device=dev), torch.empty(rows * self.tcap, dtype=torch.uint8, device=dev))
+                      for _ in range(self.out.SETS)]
+        self.dk = 0
+        self.seg_ids = np.zeros(1, np.int32)
+        self.width = {}
+        self.two_calls = getattr(args, "pipeline_calls", 1) == 2
+
+    def run(self, rs, o, st):
+        return self.lib.ovtk_encode_special_run(self.special._h, self.split._h, self.bpe._h, C.byref(rs), None, C.byref(o), L.MEM_DEVICE, st)
+
+    def launch(self, rs, o, st, pending):
+        return self.lib.ovtk_encode_special_enqueue(self.special._h, self.split._h, self.bpe._h, C.byref(rs), None, C.byref(o), st, C.byref(pending))
+
+    def _tail(self, k, res, st):
+        b, e, ids = res
+        rows = self.batches.rows
+        seg = (L.RaggedI32 * 1)(L.RaggedI32(b.data_ptr(), e.data_ptr(), ids.data_ptr(), rows, len(ids)))
+        p = L.EncodeTailParams(C.cast(seg, C.c_void_p), 1, self.seg_ids.ctypes.data_as(C.c_void_p), 0, -1, C.c_int32(self.MAX_LENGTH), b"right",
+                               b"longest_first", -1, self.pad_id, 0, 1)
+        d_ids, d_mask = self.dense[self.dk % len(self.dense)]
+        self.dk += 1
+        T = C.c_int32(0)
+        L.check(self.lib, self.lib.ovtk_encode_tail_run(C.byref(p), C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_mask.data_ptr()), None,
+                                                        C.c_int64(rows * self.tcap), C.byref(T), L.MEM_DEVICE, self.dev.index, st or self.stream0))
+        self.width[k] = int(T.value)
+        n = rows * int(T.value)
+        return d_ids[:n].view(rows, int(T.value)), d_mask[:n].view(rows, int(T.value))
+
+    def step(self, i):
+        if self.two_calls:
+            return self._tail(i % self.batches.n, super().step(i), self.stream0)
+        return self.enqueue(i)()
+
+    def enqueue(self, i, st=None):
+        if self.two_calls:   # (--pipeline-calls 2: the ragged ids between two library calls, as rounds 1-4 could do it)
+            fin = super().enqueue(i, st)
+            return lambda: self._tail(i % self.batches.n, fin(), st)
+        k = i % self.batches.n
+        rows = self.batches.rows
+        d_ids, d_mask = self.dense[self.dk % len(self.dense)]
+        self.dk += 1
+        p = L.DenseParams(C.c_int32(self.MAX_LENGTH), 0, 1, self.pad_id, -1, None, 0, None, 0)
+        pending = C.c_void_p()
+        L.check(self.lib, self.lib.ovtk_encode_dense_enqueue(self.special._h, self.split._h, self.bpe._h, C.byref(self.batches.rs[k]), None, C.byref(p),
+                                                             C.c_void_p(d_ids.data_ptr()), C.c_void_p(d_mask.data_ptr()), C.c_int64(rows * self.tcap),
+                                                             st or self.stream0, C.byref(pending)))
+
+        def finish(_keep=p):
+            width, n_ids = C.c_int32(0), C.c_int64(0)
+            L.check(self.lib, self.lib.ovtk_encode_dense_finish(pending, C.byref(width), C.byref(n_ids)))
+            self.n_out[k] = int(n_ids.value)
+            self.width[k] = int(width.value)
+            n = rows * int(width.value)
+            return d_ids[:n].view(rows, int(width.value)), d_mask[:n].view(rows, int(width.value))
+        return finish
+
+    def algo(self):
+        """The fused encode's algorithmic bytes + the dense outputs: 5 bytes per cell of input_ids / attention_mask."""
+        ks = sorted(self.n_out)
+        return float(np.mean([self.batches.n_chars[k] + 4 * self.n_out[k] + 16 * self.batches.rows + 5 * self.batches.rows * self.width.get(k, 0)
+                              for k in ks]))
+
+    def cpu_chain(self):
+        from oracle import oracle as O
+        orc, ors, osp = self.tok.oracle(), O.RegexSplit(self.tok.pattern, "isolate"), O.SpecialTokensSplit(self.special_pattern)
+
+        def chain(rb, re_, b, e, c):
+            s = osp(rb, re_, b, e, c)
+            ob, oe, ids = orc(*ors(*s[:5], skips=s[5])[:5])
+            (tb, te), = O.truncate([(ob, oe)], self.MAX_LENGTH, "right", "longest_first")
+            return tb, te, ids
+        return chain, "SpecialTokensSplit + RegexSplit (PCRE2 JIT) + BPETokenizer restatement + Truncate, piece cache warm"
+
+    def check(self, ref, res):
+        """The oracle chain's ragged ids of the first rows against the dense outputs: ids, padding, mask."""
+        tb, te, ids = ref
+        dense, mask = (x.cpu().numpy() for x in res)
+        for i in range(len(tb)):
+            n = int(te[i] - tb[i])
+            if not (np.array_equal(dense[i, :n], ids[tb[i]:te[i]]) and (dense[i, n:] == self.pad_id).all() and mask[i, :n].all() and not mask[i, n:].any()):
+                return False
+        return True
 
 
 class WordpieceEncode(EncodeWorkload):
@@ -270,6 +385,17 @@ def make_workload(args, lib, dev, rank):
                       f"({sum(w.batches.n_chars) / 1e6:.0f} MB of text), fused RegexSplit (tiktoken-style pattern) + BPETokenizer, "
                       f"inputs and outputs in HBM")
         w.sample_rows = min(rows, 16384)
+        return w
+    if cfg == "pipeline":
+        w = PipelineEncode(args, lib, dev, rank)
+        w.metric = "input MB/s through the tokenizer graph (GPT-2 BPE, 512-byte strings -> input_ids, attention_mask)"
+        w.dominant_hint = "lookup_span"
+        w.workload = (f"the converted GPT-2 graph (tokenizer_pipeline.py:1613-1636): SpecialTokensSplit (<|endoftext|>, in one row of a hundred) "
+                      f"-> RegexSplit -> BPETokenizer (V=50257) -> Truncate({w.MAX_LENGTH}) -> CombineSegments -> RaggedToDense x 2, "
+                      f"{args.rows} x ~{args.bytes}-byte strings per GPU and batch, {w.batches.n} distinct batches in rotation, "
+                      + ("two library calls per batch (ovtk_encode_special_enqueue / _finish, ovtk_encode_tail_run)" if w.two_calls else
+                         "one library call per batch (ovtk_encode_dense_enqueue / _finish: no ragged ids tensor)") + ", inputs and outputs in HBM")
+        w.sample_rows = args.rows
         return w
     if cfg == "3":
         w = WordpieceEncode(args, lib, dev, rank)
@@ -847,7 +973,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="2", choices=["1", "2", "3", "4", "5", "r2d", "vocab_encoder"])
+    ap.add_argument("--config", default="2", choices=["1", "2", "3", "4", "5", "r2d", "vocab_encoder", "pipeline"])
     ap.add_argument("--rows", type=int, default=65536)
     ap.add_argument("--bytes", type=int, default=512)
     ap.add_argument("--batches", type=int, default=8, help="distinct input batches rotated through the timed loop")
@@ -873,6 +999,7 @@ def main():
                     help="N > 1, fused BPE: 1 = the encode writes the exchange's send wire itself (compact_kernel narrows the ids; no "
                          "ragged int32 ids, no pack kernel), 0 = encode to ragged ids, then ovtk_shard_pack")
     ap.add_argument("--exchange-stream", type=int, default=1, help="1: pack/unpack of the exchange on a HIP stream of their own")
+    ap.add_argument("--pipeline-calls", type=int, default=1, choices=[1, 2], help="--config pipeline: 1 = ovtk_encode_dense_* (the whole graph in one call), 2 = encode + ovtk_encode_tail_run")
     ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
@@ -1102,6 +1229,8 @@ def main():
             parity = bool(np.array_equal(ref[0], res[0][: len(ref[0])].cpu().numpy()))
         elif isinstance(wl, VocabEncoderBench):
             parity = bool(np.array_equal(ref[0], res[0][: len(ref[0])].cpu().numpy()))
+        elif isinstance(wl, PipelineEncode):
+            parity = bool(wl.check(ref, res))
         else:
             b, e, payload = res
             n_chk = len(ref[1])

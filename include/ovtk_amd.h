@@ -206,6 +206,41 @@ int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_st
 int ovtk_set_row_tickets(int rows_per_ticket);
 
 typedef struct ovtk_pending ovtk_pending;
+/* SpecialTokensSplit -> RegexSplit -> BPETokenizer in one call: the sub-graph every converted HF byte-level BPE tokenizer runs
+ * (python/openvino_tokenizers/tokenizer_pipeline.py:1613-1636; SpecialTokensSplit::evaluate src/special_tokens_split.cpp:61-162 in
+ * front of RegexSplit::evaluate src/regex_split.cpp:124-324 and BPETokenizer::evaluate src/bpe_tokenizer.cpp:47-164).  The split
+ * strings and their skip flags stay in device buffers of the reference's capacity between the stages; nothing waits in between.
+ * `in` / `skips`: SpecialTokensSplit's inputs 0-4 (+ 5 of the 7-input form, or NULL); `out`: BPETokenizer's outputs.  Same result
+ * as ovtk_special_tokens_split_run followed by ovtk_encode_run on its outputs.  run: blocking, buffers in `mem`; enqueue: device
+ * buffers, completed by ovtk_encode_finish like ovtk_encode_enqueue. */
+int ovtk_encode_special_run(ovtk_special_tokens_split* special, ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in,
+                            const uint8_t* skips, ovtk_ragged_i32_out* out, int mem, void* stream);
+int ovtk_encode_special_enqueue(ovtk_special_tokens_split* special, ovtk_regex_split* split, ovtk_bpe* bpe,
+                                const ovtk_ragged_strings* in, const uint8_t* skips, const ovtk_ragged_i32_out* out, void* stream,
+                                ovtk_pending** pending);
+/* The whole graph of a converted byte-level BPE tokenizer behind StringTensorUnpack, in ONE call and without the ragged ids tensor
+ * (tokenizer_pipeline.py:1613-1636 + TruncationStep / CombineSegmentsStep / PaddingStep): [SpecialTokensSplit ->] RegexSplit ->
+ * BPETokenizer -> Truncate (src/truncate.cpp:37-150, one input) -> CombineSegments with constant ids in front / behind
+ * (src/combine_segments.cpp:36-134: the post-processor's BOS / EOS) -> RaggedToDense x 2 (src/ragged_to_dense.cpp:70-174) =
+ * input_ids i32[n_rows, T] and attention_mask u8[n_rows, T].  The encode's last pass writes the dense tensors itself.  Same values as
+ * ovtk_encode_special_run (or ovtk_encode_run) followed by ovtk_encode_tail_run.  special may be NULL.  Device buffers; completed by
+ * ovtk_encode_dense_finish, which reports T (target_dim < 0: the longest row) and the number of ids before truncation; OVTK_E_CAPACITY
+ * when n_rows * T exceeds `capacity` cells (*width = the T it needs). */
+typedef struct {
+    int32_t max_length;        /* Truncate: ids of a row that stay */
+    int trunc_left;            /* 0 "right": the first max_length stay; 1 "left": the last */
+    int pad_right;             /* RaggedToDense pad_right */
+    int32_t pad_value;         /* input_ids padding (attention_mask pads with 0) */
+    int32_t target_dim;        /* row width; < 0: the longest row (the PaddingStep's ReduceMax) */
+    const int32_t* prefix;     /* HOST memory: constant ids in front of every row's ids (at most 4) */
+    int n_prefix;
+    const int32_t* suffix;     /* ... and behind them (at most 4) */
+    int n_suffix;
+} ovtk_dense_params;
+int ovtk_encode_dense_enqueue(ovtk_special_tokens_split* special, ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in,
+                              const uint8_t* skips, const ovtk_dense_params* params, int32_t* out_ids, uint8_t* out_mask, int64_t capacity,
+                              void* stream, ovtk_pending** pending);
+int ovtk_encode_dense_finish(ovtk_pending* pending, int32_t* width, int64_t* n_ids);
 int ovtk_encode_enqueue(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                         const ovtk_ragged_i32_out* out, void* stream, ovtk_pending** pending);
 int ovtk_encode_finish(ovtk_pending* pending, ovtk_ragged_i32_out* out);

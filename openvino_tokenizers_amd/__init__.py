@@ -6,5 +6,5 @@ Compute happens only in csrc/build/libovtk_amd.so (hand-written HIP for gfx950) 
 include/ovtk_amd.h; see DESIGN.md and INTEGRATION.md.
 """
 from ._lib import OvtkError, load  # noqa: F401
-from .ops import (BPETokenizer, ByteFallback, CombineSegments, FusedDetokenizer, FusedEncodeTail, FusedSplitBPE, FusedSplitWordpiece, FuzeRagged, RaggedToDense,  # noqa: F401
+from .ops import (BPETokenizer, ByteFallback, CombineSegments, FusedDetokenizer, FusedEncodeDense, FusedEncodeTail, FusedSpecialSplitBPE, FusedSplitBPE, FusedSplitWordpiece, FuzeRagged, RaggedToDense,  # noqa: F401
                   RegexSplit, SpecialTokensSplit, StringTensorPack, StringTensorUnpack, TrieTokenizer, Truncate, UTF8Validate, VocabDecoder, VocabEncoder, WordpieceTokenizer)

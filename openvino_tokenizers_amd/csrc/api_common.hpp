@@ -259,6 +259,7 @@ struct ovtk_pending {
     ovtk_ragged_i32_out out{};
     std::unique_ptr<ovtk::PendingStrings> strings;
     ovtk_strings_out strings_out{};
+    std::shared_ptr<int32_t> dense_width;   // ovtk_encode_dense_enqueue: the row width, known when the run has finished
 };
 namespace ovtk {
 
@@ -292,7 +293,10 @@ public:
     void on_status(std::function<void(const RunStatus&)> f) { on_status_ = std::move(f); }
     // Kernels of another workspace run in front of this run's on the same stream (a split into device buffers): once this
     // run's event has completed, so have they.
-    void also_settles(std::shared_ptr<WorkspaceLease> other) { other_ = std::move(other); }
+    void also_settles(std::shared_ptr<WorkspaceLease> other) { others_.push_back(std::move(other)); }
+    // Asked once this run's event has completed, before its own status is looked at: what a stage in front of it (another
+    // workspace's kernels on the same stream) has to say; non-zero ends finish() with that code.
+    void front_check(std::function<int()> f) { front_check_ = std::move(f); }
     void enable_stage16() { stage16_ = true; }   // the middle's kernels write / read the staging entries as u16 (EncodeWork::stage16)
     // The middle's first kernel takes staging for ALL its rows before it knows which of them it will leave to the kernel behind it
     // (lookup_span_kernel: one reservation per wave), and that kernel takes its own: room for both, or every call with left-over
@@ -301,6 +305,12 @@ public:
     // The result leaves in the row-shard exchange's wire form (device memory) instead of begins / ends / ids.
     void output_to_wire(const WireSink& wire) {
         wire_ = wire;
+        small_ok_ = false;
+    }
+    // The result leaves as input_ids / attention_mask [n_rows, T] (device memory): DenseSink, the graph's tail in compact_kernel.
+    void output_dense(const DenseSink& dense) {
+        dense_ = dense;
+        dense_on_ = true;
         small_ok_ = false;
     }
 
@@ -314,7 +324,7 @@ public:
                                         int64_t(ws_->deferred.size() / sizeof(DeferredPiece) / kShards)});
         exact_cap_ = std::max<int64_t>(4096, int64_t(ws_->exact.size() / sizeof(ExactPiece)));
         scratch_cap_ = std::max<int64_t>(ws_->scratch.size(), int64_t(16) << 20);
-        if (!wire_.hdr) {
+        if (!wire_.hdr && !dense_on_) {
             if (mem_ == OVTK_MEM_HOST) {  // pinned output buffers are written by the kernels themselves
                 void* pb = mapped_host_pointer(out_.begins, size_t(n_rows_) * 4);
                 void* pe = mapped_host_pointer(out_.ends, size_t(n_rows_) * 4);
@@ -347,11 +357,13 @@ public:
             OVTK_HIP(hipEventSynchronize(ws_->done));
             ws_->marks.settled();
             Profiler::get().resolve(ws_->marks);
-            if (other_) {
-                other_->ws->marks.settled();
-                Profiler::get().resolve(other_->ws->marks);
+            for (auto& o : others_) {
+                o->ws->marks.settled();
+                Profiler::get().resolve(o->ws->marks);
             }
             OVTK_HIP(hipGetLastError());
+            if (front_check_)
+                if (int rc = front_check_()) return rc;
             const RunStatus& st = *ws_->host_status;
             if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
             if (st.flags & kFlagStageOverflow) {
@@ -373,12 +385,13 @@ public:
                 fold_tail_ = false;  // more exact pieces than the folded tail takes: once more with their own launches
                 small_ = false;
             } else {
-                if (st.flags & kFlagOutCapacity)
-                    return set_error(OVTK_E_CAPACITY, op_ + ": output ids buffer too small (" + std::to_string(st.n_out) +
-                                                          " ids, capacity " + std::to_string(out_.data_capacity) + ")");
                 out->n_data = st.n_out;
                 if (on_status_) on_status_(st);
-                if (wire_.hdr) return OVTK_OK;  // (device memory: the wire is complete)
+                if (st.flags & kFlagOutCapacity)
+                    return set_error(OVTK_E_CAPACITY, dense_on_ ? op_ + ": dense outputs too small (row width " + std::to_string(st.width) + ")"
+                                                                : op_ + ": output ids buffer too small (" + std::to_string(st.n_out) +
+                                                                      " ids, capacity " + std::to_string(out_.data_capacity) + ")");
+                if (wire_.hdr || dense_on_) return OVTK_OK;  // (device memory: the wire / the dense tensors are complete)
                 if (direct_out_) return OVTK_OK;  // the kernels wrote the caller's pinned buffers
                 if (int rc = copy_back(out_.begins, d_begins_, size_t(n_rows_) * 4, mem_, s_)) return rc;
                 if (int rc = copy_back(out_.ends, d_ends_, size_t(n_rows_) * 4, mem_, s_)) return rc;
@@ -484,7 +497,11 @@ private:
                         n_rows_, w, (long long)out_.data_capacity);
         const int cgrid = grid_lookup(device_, n_rows_);
         const RaggedSink rsink{d_ids_, d_begins_, d_ends_};
-        if (wire_.hdr && stage16_) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<WireSink, true>), cgrid, kBlockThreads, s_, n_rows_, w, wire_);
+        if (dense_on_) {
+            OVTK_LAUNCH(ws.marks, "row_width", row_width_kernel, std::min(64, (n_rows_ + kBlockThreads - 1) / kBlockThreads), kBlockThreads, s_, n_rows_, w, dense_);
+            if (stage16_) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<DenseSink, true>), cgrid, kBlockThreads, s_, n_rows_, w, dense_);
+            else OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<DenseSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, dense_);
+        } else if (wire_.hdr && stage16_) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<WireSink, true>), cgrid, kBlockThreads, s_, n_rows_, w, wire_);
         else if (wire_.hdr) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<WireSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, wire_);
         else if (stage16_) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<RaggedSink, true>), cgrid, kBlockThreads, s_, n_rows_, w, rsink);
         else OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<RaggedSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, rsink);
@@ -504,7 +521,8 @@ private:
     int mem_, in_mem_;
     bool direct_out_ = false;      // host-memory call whose output buffers are pinned: the kernels write them (no D2H copy)
     std::shared_ptr<void> keep_;
-    std::shared_ptr<WorkspaceLease> other_;
+    std::vector<std::shared_ptr<WorkspaceLease>> others_;
+    std::function<int()> front_check_;
     hipStream_t s_;
     Middle middle_;
     bool self_alloc_;
@@ -514,6 +532,8 @@ private:
     bool small_ok_ = false, small_ = false;
     bool stage16_ = false, stage_twice_ = false;
     WireSink wire_{};
+    DenseSink dense_{};
+    bool dense_on_ = false;
     std::function<void(const RunStatus&)> on_status_;
     RowsIn d_in_{};
     int n_rows_ = 0, grid_ = 0, n_tiles_ = 0;

@@ -317,12 +317,26 @@ int ovtk_special_tokens_split_create(const char* pattern, int64_t pattern_len, i
         tb.push_back(int32_t(chars.size()));
         chars += t;
         te.push_back(int32_t(chars.size()));
+        chars.append((16 - chars.size() % 16) % 16 + 16, '\0');   // (token_at compares 16 bytes at a time: SpecialDev::tok_padded)
         const uint8_t b = uint8_t(t[0]);
         h->dev.first_bytes[b >> 5] |= 1u << (b & 31);
     }
     if (any_strip_left)  // a match may start with \\s (PCRE2_UCP): tab..CR, space, and the lead bytes of U+0085, U+00A0, U+1680,
                          // U+2000-200A / 2028 / 2029 / 202F / 205F, U+3000
         for (uint8_t b : {9, 10, 11, 12, 13, 32, 0xC2, 0xE1, 0xE2, 0xE3}) h->dev.first_bytes[b >> 5] |= 1u << (b & 31);
+    h->dev.tok_padded = 1;
+    h->dev.any_strip_left = any_strip_left ? 1 : 0;
+    {   // the two byte sets as lists (split_seq_device.hpp: the 16-bytes-at-a-time filters)
+        std::vector<uint8_t> tf, all;
+        for (const auto& t : tokens)
+            if (std::find(tf.begin(), tf.end(), uint8_t(t[0])) == tf.end()) tf.push_back(uint8_t(t[0]));
+        for (int b = 0; b < 256; ++b)
+            if ((h->dev.first_bytes[b >> 5] >> (b & 31)) & 1u) all.push_back(uint8_t(b));
+        h->dev.n_tok_first = tf.size() <= sizeof h->dev.tok_first ? int32_t(tf.size()) : -1;
+        for (size_t i = 0; h->dev.n_tok_first > 0 && i < tf.size(); ++i) h->dev.tok_first[i] = tf[i];
+        h->dev.n_first = all.size() <= sizeof h->dev.first ? int32_t(all.size()) : -1;
+        for (size_t i = 0; h->dev.n_first > 0 && i < all.size(); ++i) h->dev.first[i] = all[i];
+    }
     int e = 0;
     e = e ? e : h->tb.upload(tb.data(), tb.size() * 4);
     e = e ? e : h->te.upload(te.data(), te.size() * 4);
@@ -337,6 +351,8 @@ int ovtk_special_tokens_split_create(const char* pattern, int64_t pattern_len, i
     h->dev.group_first = h->gf.as<int32_t>();
     h->dev.group_flags = h->gfl.as<uint8_t>();
     h->dev.n_groups = int32_t(group_flags.size());
+    h->dev.n_tokens = int32_t(tb.size());
+    h->dev.n_tok_chars = int32_t(chars.size());
     h->dev.uc.kind = kSplitWhitespace;
     if (int rc = unicode_tables(device, &h->dev.uc.uc_index, &h->dev.uc.uc_blocks)) return rc;
     *out = h.release();
@@ -496,11 +512,42 @@ bool fusable(const ovtk_regex_split* split) {
     return split->max_splits == -1 && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3);
 }
 
+// SpecialTokensSplit's passes into device buffers (count, offsets, write): launched on `s`, nobody waits.  The workspace's row_cnt /
+// wave_off / tiles / status serve them; the number of output strings stays on the device (status->n_out).
+int special_on_device(const ovtk_special_tokens_split* h, Workspace& sw, const RowsIn& d_in, hipStream_t s, int32_t* d_rb, int32_t* d_re,
+                      int32_t* d_b, int32_t* d_e, uint8_t* d_sk, long long capacity) {
+    const int n_rows = d_in.n_rows;
+    const int grid = grid_lookup(h->device, n_rows);
+    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
+    int e = 0;
+    e = e ? e : sw.row_cnt.ensure(size_t(n_rows) * 4);
+    e = e ? e : sw.wave_off.ensure(size_t(grid * kWavesPerBlock + 1) * sizeof(long long));
+    e = e ? e : sw.tiles.ensure(size_t(n_tiles + 1) * sizeof(long long));
+    e = e ? e : sw.status.ensure(sizeof(RunStatus));
+    if (e) return e;
+    EncodeWork w{};
+    w.n_waves = grid * kWavesPerBlock;
+    w.wave_off = sw.wave_off.as<long long>();
+    w.row_cnt = sw.row_cnt.as<int32_t>();
+    w.tile_off = sw.tiles.as<long long>();
+    w.stage_cap = INT32_MAX;
+    w.status = sw.status.as<RunStatus>();
+    OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
+    OVTK_LAUNCH(sw.marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);  // offset validation
+    const int seq_grid = (n_rows + kBlockThreads - 1) / kBlockThreads;
+    OVTK_LAUNCH(sw.marks, "special_count", special_split_kernel<0>, seq_grid, kBlockThreads, s, d_in, h->dev, w, (int32_t*)nullptr,
+                (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
+    OVTK_LAUNCH(sw.marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s, n_rows, w, capacity);
+    OVTK_LAUNCH(sw.marks, "special_write", special_split_kernel<1>, seq_grid, kBlockThreads, s, d_in, h->dev, w, d_rb, d_re, d_b, d_e, d_sk);
+    return OVTK_OK;
+}
+
 // RegexSplit [+] BPETokenizer.  split == nullptr: `in` already holds pieces (the BPETokenizer op).
 // Launches the kernels; `run` stays empty when the result was complete without any (empty batches).
 int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ovtk_ragged_strings* in, const uint8_t* skips,
                  ovtk_ragged_i32_out* out, int mem, void* stream, std::unique_ptr<PendingRun>& run, const WireSink* wire = nullptr,
-                 std::shared_ptr<void> device_inputs = nullptr) {
+                 std::shared_ptr<void> device_inputs = nullptr, const ovtk_special_tokens_split* special = nullptr,
+                 const DenseSink* dense = nullptr, std::shared_ptr<int32_t> dense_width = nullptr) {
     // device_inputs: `in` names device memory whatever `mem` says about the outputs (ovtk_encode_enqueue_packed: the packed
     // batch was copied to the device by the caller of this function); the object owns that memory until the run is over.
     const int in_mem = device_inputs ? OVTK_MEM_DEVICE : mem;
@@ -531,6 +578,43 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     if (in->n_rows == 0) return OVTK_OK;
 
     const int dev = bpe->device;
+    // SpecialTokensSplit in front (the graph of tokenizer_pipeline.py:1613-1636: SpecialTokensSplit -> RegexSplit -> BPETokenizer):
+    // its passes write the split strings and their skip flags into device buffers of the reference's capacity, the kernels below
+    // read them from there on the same stream -- the string count stays on the device (the lookup kernels want a bound, not the
+    // number), and the host waits for nothing in between.
+    std::shared_ptr<WorkspaceLease> special_ws;
+    ovtk_ragged_strings special_out{};
+    if (special) {
+        if (special->device != dev) return set_error(OVTK_E_ARG, "special-tokens and bpe handles live on different devices");
+        special_ws = std::make_shared<WorkspaceLease>(dev);
+        Workspace& sw = *special_ws->ws;
+        if (!sw.host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
+        RowsIn d_in{};
+        if (int rc = stage_input(sw, in, skips, in_mem, s, d_in)) return rc;
+        // special_tokens_split.cpp:88-92, + skipped empty strings -- behind one entry per row (special_sparse_kernel's layout)
+        const int64_t cap_extra = in->strings.n_chars + in->strings.n;
+        const int64_t cap = in->n_rows + cap_extra;
+        if (cap >= INT32_MAX) return set_error(OVTK_E_ARG, "tensor sizes must fit int32 offsets");
+        int e = 0;
+        e = e ? e : sw.gen[0].ensure(size_t(d_in.n_rows) * 4);
+        e = e ? e : sw.gen[1].ensure(size_t(d_in.n_rows) * 4);
+        e = e ? e : sw.gen[2].ensure(size_t(cap) * 4);
+        e = e ? e : sw.gen[3].ensure(size_t(cap) * 4);
+        e = e ? e : sw.gen[4].ensure(size_t(cap));
+        if (e) return e;
+        // one pass, a wave per 64 rows, every wave's strings in a region of their own (special_sparse_kernel)
+        if (int rc = sw.status.ensure(sizeof(RunStatus))) return rc;
+        OVTK_HIP(hipMemsetAsync(sw.status.as<void>(), 0, sizeof(RunStatus), s));
+        OVTK_LAUNCH(sw.marks, "special_split", special_sparse_kernel, (d_in.n_rows + kWave - 1) / kWave, kBlockThreads, s, d_in,
+                    special->dev, sw.status.as<RunStatus>(), (long long)cap_extra, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
+                    sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>(), sw.gen[4].as<uint8_t>());
+        OVTK_HIP(hipMemcpyAsync(sw.host_status, sw.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s));   // (read at finish)
+        special_out = ovtk_ragged_strings{sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(), in->n_rows,
+                                          ovtk_strings{sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>(), d_in.chars, cap, in->strings.n_chars}};
+        in = &special_out;
+        skips = sw.gen[4].as<uint8_t>();
+    }
+    const int in_mem2 = special ? OVTK_MEM_DEVICE : in_mem;
     // A split the lookup kernel has no scanner for (the compiled DFA, the class patterns, max_splits): the pieces are
     // produced in device memory first -- the chain RegexSplit -> BPETokenizer inside one call; the piece offsets make
     // one round trip through HBM and the host waits once for their count.
@@ -541,7 +625,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
         Workspace& sw = *pieces_ws->ws;
         if (!sw.host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
         RowsIn d_in{};
-        if (int rc = stage_input(sw, in, skips, in_mem, s, d_in)) return rc;
+        if (int rc = stage_input(sw, in, skips, in_mem2, s, d_in)) return rc;
         const int64_t cap = in->strings.n_chars + in->strings.n;  // regex_split.cpp:182
         if (cap >= INT32_MAX) return set_error(OVTK_E_ARG, "tensor sizes must fit int32 offsets");
         int e = 0;
@@ -690,14 +774,25 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                       ? resident_blocks_per_cu(lookup_span_kernel<kSpanGpt2, true>, 6)
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
-    if (pieces_ws) {
-        r->also_settles(pieces_ws);
-        r->input_on_device(std::make_shared<std::pair<std::shared_ptr<void>, std::shared_ptr<void>>>(pieces_ws, device_inputs));
-    } else if (device_inputs) {
-        r->input_on_device(device_inputs);
+    if (pieces_ws) r->also_settles(pieces_ws);
+    if (special_ws) {
+        r->also_settles(special_ws);
+        r->front_check([special_ws]() -> int {
+            const RunStatus& st = *special_ws->ws->host_status;
+            if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+            if (st.flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "SpecialTokensSplit: more strings than the reference's capacity");
+            return OVTK_OK;
+        });
     }
-    if (T.store.slots)   // what the store did for this call decides whether the next ones ask it at all
-        r->on_status([bpe](const RunStatus& st) {
+    if (pieces_ws || special_ws)
+        r->input_on_device(std::make_shared<std::tuple<std::shared_ptr<void>, std::shared_ptr<void>, std::shared_ptr<void>>>(pieces_ws, special_ws, device_inputs));
+    else if (device_inputs)
+        r->input_on_device(device_inputs);
+    const bool has_store = T.store.slots != nullptr;
+    if (has_store || dense_width)   // what the store did for this call decides whether the next ones ask it at all
+        r->on_status([bpe, has_store, dense_width](const RunStatus& st) {
+            if (dense_width) *dense_width = st.width;
+            if (!has_store) return;
             if (st.n_store_probe < 256) return;   // (counted by one wave in 64)
             // (a cold store misses everything too: only a run of such calls says that the text is the reason)
             if (st.n_store_hit * 8 >= st.n_store_probe) bpe->store_low.store(0, std::memory_order_relaxed);
@@ -710,6 +805,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     if (bpe->stage16) r->enable_stage16();
     if (split && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3) && T.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)
     if (wire) r->output_to_wire(*wire);
+    if (dense) r->output_dense(*dense);
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;
@@ -739,6 +835,94 @@ int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_st
                     ovtk_ragged_i32_out* out, int mem, void* stream) {
     if (int rc = check_fused(split)) return rc;
     return run_encode(split, bpe, in, skips, out, mem, stream);
+}
+
+int ovtk_encode_special_run(ovtk_special_tokens_split* special, ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in,
+                            const uint8_t* skips, ovtk_ragged_i32_out* out, int mem, void* stream) {
+    if (!special) return set_error(OVTK_E_ARG, "null special-tokens handle");
+    if (int rc = check_fused(split)) return rc;
+    std::unique_ptr<PendingRun> run;
+    if (int rc = start_encode(split, bpe, in, skips, out, mem, stream, run, nullptr, nullptr, special)) return rc;
+    return run ? run->finish(out) : OVTK_OK;
+}
+
+int ovtk_encode_special_enqueue(ovtk_special_tokens_split* special, ovtk_regex_split* split, ovtk_bpe* bpe,
+                                const ovtk_ragged_strings* in, const uint8_t* skips, const ovtk_ragged_i32_out* out, void* stream,
+                                ovtk_pending** pending) {
+    if (!pending || !out || !special) return set_error(OVTK_E_ARG, "null argument");
+    if (int rc = check_fused(split)) return rc;
+    auto p = std::make_unique<ovtk_pending>();
+    p->out = *out;
+    if (int rc = start_encode(split, bpe, in, skips, &p->out, OVTK_MEM_DEVICE, stream, p->run, nullptr, nullptr, special)) return rc;
+    *pending = p.release();
+    return OVTK_OK;
+}
+
+int ovtk_encode_dense_enqueue(ovtk_special_tokens_split* special, ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_strings* in,
+                              const uint8_t* skips, const ovtk_dense_params* params, int32_t* out_ids, uint8_t* out_mask, int64_t capacity,
+                              void* stream, ovtk_pending** pending) {
+    if (!pending || !params || !out_ids || !in || capacity < 0) return set_error(OVTK_E_ARG, "null argument");
+    if (int rc = check_fused(split)) return rc;
+    if (params->n_prefix < 0 || params->n_prefix > kDenseAffix || params->n_suffix < 0 || params->n_suffix > kDenseAffix ||
+        (params->n_prefix && !params->prefix) || (params->n_suffix && !params->suffix) || params->max_length < 0)
+        return set_error(OVTK_E_ARG, "encode_dense: at most 4 constant ids in front / behind, max_length >= 0");
+    if (int rc = check_rows(in)) return rc;
+    DenseSink d{};
+    d.ids = out_ids;
+    d.mask = out_mask;
+    d.capacity = capacity;
+    d.max_length = params->max_length;
+    d.trunc_left = params->trunc_left ? 1 : 0;
+    d.pad_right = params->pad_right ? 1 : 0;
+    d.pad_value = params->pad_value;
+    d.target_dim = params->target_dim;
+    d.n_pre = params->n_prefix;
+    d.n_suf = params->n_suffix;
+    for (int i = 0; i < d.n_pre; ++i) d.pre[i] = params->prefix[i];
+    for (int i = 0; i < d.n_suf; ++i) d.suf[i] = params->suffix[i];
+    auto p = std::make_unique<ovtk_pending>();
+    p->dense_width = std::make_shared<int32_t>(params->target_dim < 0 ? 0 : params->target_dim);
+    p->out = ovtk_ragged_i32_out{nullptr, nullptr, nullptr, INT32_MAX - 2, 0, 0};   // (no ragged ids: nothing of that kind overflows)
+    if (in->strings.n_chars == 0 || in->n_rows == 0) {
+        // no text (the all-empty quirk of regex_split.cpp:129-143 is the ragged tensor's; the dense tensors keep their rows): every row is
+        // the constant segments and padding -- T cells of which the host knows everything
+        const int32_t len = d.n_pre + d.n_suf, T = d.target_dim < 0 ? len : d.target_dim;
+        *p->dense_width = T;
+        if (in->n_rows * int64_t(T) > capacity) return set_error(OVTK_E_CAPACITY, "encode_dense: output too small");
+        if (T > 0 && in->n_rows > 0) {
+            std::vector<int32_t> row(size_t(T), d.pad_value);
+            std::vector<uint8_t> mrow(size_t(T), 0);
+            const int col0 = d.pad_right ? 0 : std::max(0, T - len);
+            for (int k = 0; k < len && col0 + k < T; ++k) {
+                row[size_t(col0 + k)] = k < d.n_pre ? d.pre[k] : d.suf[k - d.n_pre];
+                mrow[size_t(col0 + k)] = 1;
+            }
+            hipStream_t s = static_cast<hipStream_t>(stream);
+            OVTK_HIP(hipSetDevice(bpe ? bpe->device : 0));
+            for (int64_t r = 0; r < in->n_rows; ++r) {
+                OVTK_HIP(hipMemcpyAsync(out_ids + r * T, row.data(), size_t(T) * 4, hipMemcpyHostToDevice, s));
+                if (out_mask) OVTK_HIP(hipMemcpyAsync(out_mask + r * T, mrow.data(), size_t(T), hipMemcpyHostToDevice, s));
+            }
+            OVTK_HIP(hipStreamSynchronize(s));
+        }
+        p->out.n_rows = in->n_rows;
+        *pending = p.release();
+        return OVTK_OK;
+    }
+    if (int rc = start_encode(split, bpe, in, skips, &p->out, OVTK_MEM_DEVICE, stream, p->run, nullptr, nullptr, special, &d, p->dense_width))
+        return rc;
+    *pending = p.release();
+    return OVTK_OK;
+}
+
+int ovtk_encode_dense_finish(ovtk_pending* pending, int32_t* width, int64_t* n_ids) {
+    if (!pending) return set_error(OVTK_E_ARG, "null pending call");
+    std::unique_ptr<ovtk_pending> p(pending);
+    int rc = OVTK_OK;
+    if (p->run) rc = p->run->finish(&p->out);
+    if (width) *width = p->dense_width ? *p->dense_width : 0;
+    if (n_ids) *n_ids = p->out.n_data;
+    return rc;
 }
 
 int ovtk_set_row_tickets(int rows_per_ticket) {
@@ -927,14 +1111,7 @@ int ovtk_special_tokens_split_run(ovtk_special_tokens_split* h, const ovtk_ragge
     RowsIn d_in{};
     if (int rc = stage_input(*ws.ws, in, skips, mem, s, d_in)) return rc;
     const int n_rows = d_in.n_rows;
-    const int grid = grid_lookup(h->device, n_rows);
-    const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
     int e = 0;
-    e = e ? e : ws->row_cnt.ensure(size_t(n_rows) * 4);
-    e = e ? e : ws->wave_off.ensure(size_t(grid * kWavesPerBlock + 1) * sizeof(long long));
-    e = e ? e : ws->tiles.ensure(size_t(n_tiles + 1) * sizeof(long long));
-    e = e ? e : ws->status.ensure(sizeof(RunStatus));
-    if (e) return e;
     int32_t *d_rb = nullptr, *d_re = nullptr, *d_b = nullptr, *d_e = nullptr;
     uint8_t* d_sk = nullptr;
     e = e ? e : out_target(ws->out_a, out->ragged_begins, size_t(n_rows) * 4, mem, &d_rb);
@@ -943,22 +1120,7 @@ int ovtk_special_tokens_split_run(ovtk_special_tokens_split* h, const ovtk_ragge
     e = e ? e : out_target(ws->out_d, out->ends, size_t(out->capacity) * 4, mem, &d_e);
     e = e ? e : out_target(ws->out_e, out->skips, size_t(out->capacity), mem, &d_sk);
     if (e) return e;
-    EncodeWork w{};
-    w.n_waves = grid * kWavesPerBlock;
-    w.wave_off = ws->wave_off.as<long long>();
-    w.row_cnt = ws->row_cnt.as<int32_t>();
-    w.tile_off = ws->tiles.as<long long>();
-    w.stage_cap = INT32_MAX;
-    w.status = ws->status.as<RunStatus>();
-    OVTK_HIP(hipMemsetAsync(w.status, 0, sizeof(RunStatus), s));
-    OVTK_LAUNCH(ws->marks, "prep_rows", prep_rows_kernel, std::min(grid, kTicketBlocks), kBlockThreads, s, d_in, 1, w);  // offset validation
-    const int seq_grid = (n_rows + kBlockThreads - 1) / kBlockThreads;
-    OVTK_LAUNCH(ws->marks, "special_count", special_split_kernel<0>, seq_grid, kBlockThreads, s, d_in, h->dev, w, (int32_t*)nullptr,
-                (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
-    OVTK_LAUNCH(ws->marks, "count_scan", count_scan_kernel, std::min((n_tiles + 3) / 4, kTicketBlocks), kBlockThreads, s, n_rows,
-                w, (long long)out->capacity);
-    OVTK_LAUNCH(ws->marks, "special_write", special_split_kernel<1>, seq_grid, kBlockThreads, s, d_in, h->dev, w, d_rb, d_re, d_b, d_e,
-                d_sk);
+    if (int rc = special_on_device(h, *ws.ws, d_in, s, d_rb, d_re, d_b, d_e, d_sk, (long long)out->capacity)) return rc;
     if (int rc = finish_status(*ws.ws, s)) return rc;
     const RunStatus& st = *ws->host_status;
     if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");

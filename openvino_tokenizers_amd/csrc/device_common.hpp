@@ -34,7 +34,9 @@ struct RunStatus {
     int32_t n_pending;     // rows the span / rows kernel left to lookup_kernel<kFused>
     int32_t n_store_probe; // deferred pieces merge_kernel looked up in the piece store (a sample: one wave in 64 counts) ...
     int32_t n_store_hit;   // ... and found there
-    int32_t pad[20];
+    int32_t width;         // dense output (ovtk_encode_dense_*): the row width row_width_kernel settled on
+    uint32_t width_ticket; // ... and its "last block done" ticket
+    int32_t pad[18];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
     int32_t stage_top[kShards * kCounterStride];    // [s * kCounterStride] = staging entries handed out in region s
     int32_t row_ticket[kShards * kCounterStride];   // [s * kCounterStride] = rows of range s handed to waves (lookup_kernel)

@@ -1362,20 +1362,87 @@ constexpr int kCompactChunks = 3;  // 64-entry chunks of a row held in registers
 // beyond the wire's pad are dropped (the header's n_ids says so: the receivers ask for a larger pad).
 struct RaggedSink {
     int32_t *ids, *begins, *ends;
+    __device__ __forceinline__ void start(const RunStatus*) {}
     __device__ __forceinline__ void row(int r, int b, int e) const {
         begins[r] = b;
         ends[r] = e;
     }
-    __device__ __forceinline__ void id(int pos, int32_t v) const { ids[pos] = v; }
+    // id number j of row r (which has cnt of them), position pos of the ragged output
+    __device__ __forceinline__ void id(int, int, int, int pos, int32_t v) const { ids[pos] = v; }
+    __device__ __forceinline__ void row_done(int, int) const {}   // (every lane of the wave)
     __device__ __forceinline__ void finish(int, const RunStatus*) const {}
 };
+// DenseSink: the graph's tail in the encode's last pass (ovtk_encode_dense_*) -- Truncate (src/truncate.cpp:37-150, one input) ->
+// CombineSegments with constant segments in front and behind (src/combine_segments.cpp:36-134: the post-processor's BOS / EOS)
+// -> RaggedToDense twice (src/ragged_to_dense.cpp:70-174): input_ids [n_rows, T] and attention_mask [n_rows, T].  No ragged ids
+// tensor exists.  T = RunStatus::width (row_width_kernel, launched in front).
+constexpr int kDenseAffix = 4;   // constant ids in front / behind, at most
+struct DenseSink {
+    int32_t* ids;        // [n_rows * T]
+    uint8_t* mask;       // [n_rows * T] or nullptr
+    int64_t capacity;    // cells
+    int32_t max_length;  // Truncate: ids of a row that stay
+    int32_t trunc_left;  // 0: the first max_length stay, 1: the last
+    int32_t pad_right, pad_value;
+    int32_t target_dim;  // < 0: the longest row
+    int32_t n_pre, n_suf;
+    int32_t pre[kDenseAffix], suf[kDenseAffix];
+    int32_t T;           // (set by start)
+    __device__ __forceinline__ void start(const RunStatus* st) { T = st->width; }
+    __device__ __forceinline__ void row(int, int, int) const {}
+    __device__ __forceinline__ void id(int r, int cnt, int j, int, int32_t v) const {
+        const int keep = cnt < max_length ? cnt : max_length, first = trunc_left ? cnt - keep : 0;
+        if (j < first || j >= first + keep) return;
+        const int len = keep + n_pre + n_suf;
+        const int col = (pad_right ? 0 : (T > len ? T - len : 0)) + n_pre + (j - first);
+        if (col < T) ids[(long long)r * T + col] = v;   // (a target_dim below a row's length cuts the row, as RaggedToDense does: :120-135)
+    }
+    __device__ __forceinline__ void row_done(int r, int cnt) const {   // every lane: the cells that are not the row's own ids
+        const int keep = cnt < max_length ? cnt : max_length;
+        const int len = keep + n_pre + n_suf;
+        const int col0 = pad_right ? 0 : (T > len ? T - len : 0);
+        for (int c = lane_id(); c < T; c += kWave) {
+            const int k = c - col0;
+            const bool inside = k >= 0 && k < len;
+            if (mask) mask[(long long)r * T + c] = inside ? uint8_t(1) : uint8_t(0);
+            if (!inside) ids[(long long)r * T + c] = pad_value;
+            else if (k < n_pre) ids[(long long)r * T + c] = pre[k];
+            else if (k >= n_pre + keep) ids[(long long)r * T + c] = suf[k - n_pre - keep];
+        }
+    }
+    __device__ __forceinline__ void finish(int, const RunStatus*) const {}
+};
+// T of a dense output: target_dim, or the longest row after Truncate and the constant segments; more cells than the caller has room
+// for: kFlagOutCapacity (compact_kernel then writes nothing).
+static __global__ __launch_bounds__(kBlockThreads) void row_width_kernel(int n_rows, EncodeWork w, DenseSink d) {
+    int m = 0;
+    if (d.target_dim < 0) {
+        for (int r = int(blockIdx.x) * kBlockThreads + int(threadIdx.x); r < n_rows; r += int(gridDim.x) * kBlockThreads) {
+            const int c = w.row_cnt[r];
+            const int len = (c < d.max_length ? c : d.max_length) + d.n_pre + d.n_suf;
+            m = len > m ? len : m;
+        }
+        m = wave_max(m);
+        if (lane_id() == 0 && m > 0) atomicMax(&w.status->width, m);
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        w.status->width = d.target_dim;
+    }
+    // the last block to arrive checks the room
+    if (!last_block_done(&w.status->width_ticket, gridDim.x, false)) return;
+    if (threadIdx.x == 0) {
+        const int T = __hip_atomic_load(&w.status->width, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((long long)T * n_rows > d.capacity) atomicOr(&w.status->flags, kFlagOutCapacity);
+    }
+}
 struct WireSink {
     int32_t* hdr;      // i32 n_ids, i32 n_rows, 0, 0
     int32_t* ends;     // [max_rows]
     void* ids;         // [pad_ids] u16 or i32
     int32_t pad_ids, max_rows, id_bytes;
+    __device__ __forceinline__ void start(const RunStatus*) {}
     __device__ __forceinline__ void row(int r, int, int e) const { ends[r] = e; }
-    __device__ __forceinline__ void id(int pos, int32_t v) const {
+    __device__ __forceinline__ void row_done(int, int) const {}
+    __device__ __forceinline__ void id(int, int, int, int pos, int32_t v) const {
         if (pos >= pad_ids) return;
         if (id_bytes == 2) static_cast<uint16_t*>(ids)[pos] = uint16_t(v);
         else static_cast<int32_t*>(ids)[pos] = v;
@@ -1401,12 +1468,13 @@ __device__ __forceinline__ int32_t stage_get_t(const EncodeWork& w, int pos) {
     return w.stage[pos];
 }
 template <class Sink, bool S16 = false>
-__device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, const Sink& sink, bool solo = false) {
+__device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Sink sink, bool solo = false) {
     // kFlagTailPending: merge_kernel's folded tail left the exact pieces and the tile scan to a second attempt -- tile_off
     // and parts of the staging buffer hold whatever the previous call left there
     if (w.status->flags & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
                            kFlagTailPending))
         return;
+    sink.start(w.status);
     const int l = lane_id();
     const int n_waves = (solo ? 1 : int(gridDim.x)) * kWavesPerBlock;
     constexpr int kSubs = kRowTile / kCompactRows;
@@ -1445,16 +1513,23 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, co
             for (int k = 0; k < kCompactChunks; ++k) {
                 if (k * kWave < used[q]) {
                     const unsigned long long m = __ballot(v[q][k] != kEmptyId);
-                    if (v[q][k] != kEmptyId) sink.id(o[q] + run + rank_below(m), v[q][k]);
+                    if (v[q][k] != kEmptyId) {
+                        const int j = run + rank_below(m);
+                        sink.id(row, cnt[q], j, o[q] + j, v[q][k]);
+                    }
                     run += __popcll(m);
                 }
             }
             for (int b = kCompactChunks * kWave; b < used[q]; b += kWave) {
                 const int x = (b + l < used[q]) ? stage_get_t<S16>(w, base[q] + b + l) : kEmptyId;
                 const unsigned long long m = __ballot(x != kEmptyId);
-                if (x != kEmptyId) sink.id(o[q] + run + rank_below(m), x);
+                if (x != kEmptyId) {
+                    const int j = run + rank_below(m);
+                    sink.id(row, cnt[q], j, o[q] + j, x);
+                }
                 run += __popcll(m);
             }
+            sink.row_done(row, cnt[q]);
         }
     }
     sink.finish(n_rows, w.status);
@@ -1611,7 +1686,11 @@ static __global__ __launch_bounds__(kBlockThreads) void special_split_kernel(Row
         const uint8_t* s = in.chars + sb;
         const int slen = se - sb;
         int start = 0, mb = 0, gb = 0, ge = 0, me = 0;
-        while (start < slen && special_next_match(T, s, slen, start, mb, gb, ge, me)) {  // :127-141
+        if (!string_may_hold_token(T, s, slen)) {   // no token's first byte in it: the string passes as it is
+            if (slen > 0) put(sb, se, 0);
+            continue;
+        }
+        while (start < slen && special_next_match(T, special_tabs(T), s, slen, start, mb, gb, ge, me)) {  // :127-141
             if (start < mb) put(sb + start, sb + mb, 0);
             put(sb + gb, sb + ge, 1);
             start = me;
@@ -1619,6 +1698,197 @@ static __global__ __launch_bounds__(kBlockThreads) void special_split_kernel(Row
         if (start < slen) put(sb + start, sb + slen, 0);  // :143-147
     }
     if (!WRITE) w.row_cnt[row] = count;
+}
+
+// ---- SpecialTokensSplit inside the fused encode (ovtk_encode_special_* / ovtk_encode_dense_*): ONE pass, a wave per 64 rows.
+// The op's contract is dense outputs behind a count pass (two launches of the kernel above, an offset scan between them, one lane
+// walking each row).  The encode kernels only dereference offsets, so here -- as in regex_sparse_kernel -- every wave's strings go
+// to a region of their own inside buffers of the reference's capacity (one atomic per wave takes it) and the rows' ragged begins /
+// ends point there.  And nearly every row holds no special token at all: when the wave's 64 rows are one stretch of text (one
+// string per row, each continuing the one before: what StringTensorUnpack produces), the wave first sweeps that stretch with
+// coalesced 16-byte loads for the tokens' first bytes; only the rows in which one turns up are walked by their lane.
+static __global__ __launch_bounds__(kBlockThreads) void special_sparse_kernel(RowsIn in, SpecialDev T_in, RunStatus* status, long long cap,
+                                                                              int32_t* out_rb, int32_t* out_re, int32_t* out_begins,
+                                                                              int32_t* out_ends, uint8_t* out_skips) {
+    // The token lists in LDS when they are small (they nearly always are: a handful of special tokens): a lane that walks a row reads
+    // them one dependent load after the other -- group flags, token range, offsets, first byte -- and from global memory that chain
+    // was most of the kernel (52 us for config 2's batch with one row in a hundred holding a token).
+    constexpr int kLdsTokens = 64, kLdsChars = 2048, kLdsGroups = 8;
+    __shared__ int32_t tb_s[kLdsTokens], te_s[kLdsTokens], gf_s[kLdsGroups + 1];
+    __shared__ uint8_t gfl_s[kLdsGroups];
+    __shared__ __attribute__((aligned(16))) uint8_t tc_s[kLdsChars];
+    if (T_in.n_groups <= kLdsGroups && T_in.n_tokens <= kLdsTokens && T_in.n_tok_chars <= kLdsChars) {
+        for (int i = int(threadIdx.x); i < T_in.n_tokens; i += kBlockThreads) {
+            tb_s[i] = T_in.tok_begins[i];
+            te_s[i] = T_in.tok_ends[i];
+        }
+        for (int i = int(threadIdx.x); i <= T_in.n_groups; i += kBlockThreads) gf_s[i] = T_in.group_first[i];
+        for (int i = int(threadIdx.x); i < T_in.n_groups; i += kBlockThreads) gfl_s[i] = T_in.group_flags[i];
+        for (int i = int(threadIdx.x); i < T_in.n_tok_chars; i += kBlockThreads) tc_s[i] = T_in.tok_chars[i];
+        __syncthreads();
+    }
+    const SpecialDev& T = T_in;
+    SpecialTabs tabs = special_tabs(T_in);
+    if (T_in.n_groups <= kLdsGroups && T_in.n_tokens <= kLdsTokens && T_in.n_tok_chars <= kLdsChars)
+        tabs = SpecialTabs{tb_s, te_s, tc_s, gf_s, gfl_s};
+    // A BLOCK per 64 rows: its four waves read the rows' headers alike (lane i = row i) and sweep a quarter of the stretch each --
+    // one wave per 64 rows was one wave per SIMD with nothing to hide its memory round trips behind (49 us for config 2's batch
+    // without a single token in it) --, then the first wave goes on alone with the rows' lanes.
+    __shared__ uint32_t cand_s[2];
+    __shared__ int32_t wlo_s[kWave], whi_s[kWave];
+    if (threadIdx.x < 2) cand_s[threadIdx.x] = 0u;
+    if (threadIdx.x < kWave) {
+        wlo_s[threadIdx.x] = 0x7FFFFFFF;
+        whi_s[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const int l = lane_id();
+    const int wq = wave_in_block();
+    const int row = int(blockIdx.x) * kWave + l;
+    const bool valid = row < in.n_rows;
+    int cb = 0, ce = 0;
+    bool ok = valid;
+    if (valid) {
+        cb = in.ragged_begins[row];
+        ce = in.ragged_ends[row];
+        if (cb < ce && (cb < 0 || ce > in.n_strings)) ok = false;
+    }
+    const bool one = ok && ce == cb + 1 && !(in.skips && in.skips[cb]);
+    int sb = 0, se = 0;
+    if (one) {
+        sb = in.begins[cb];
+        se = in.ends[cb];
+        if (sb < 0 || se < sb || (long long)se > in.n_chars) ok = false;
+    }
+    if (valid && !ok && wq == 0) atomicOr(&status->flags, kFlagRange);
+    // one stretch of text?  (every row of the wave one string, each beginning where the one before ends)
+    const int prev_se = int(lane_prev(uint32_t(se)));
+    const bool chain = __ballot(valid && !(one && ok && (l == 0 || sb == prev_se))) == 0ull;
+    bool cand = true;   // the row may hold a token
+    bool swept = false;   // ... and the sweep said where: [w_lo, w_hi) of its string
+    int w_lo = 0x7FFFFFFF, w_hi = 0;
+    if (chain && T.n_tok_first > 0) {
+        const unsigned long long vm = __ballot(valid);
+        const int last = 63 - __clzll(vm);
+        const long long t0 = wave_readlane(sb, 0), t1 = wave_readlane(se, last);
+        unsigned long long cand_rows = 0;
+        constexpr int U = 4;   // 16-byte loads in flight per lane (one after the other they were 32 memory round trips per wave)
+        for (long long base = t0 + (long long)wq * U * kWave * 16; base < t1; base += (long long)kWavesPerBlock * U * kWave * 16) {
+            SeqBytes16 v[U];
+            bool in_text[U], whole[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long at = base + (u * kWave + l) * 16;
+                in_text[u] = at < t1;
+                whole[u] = in_text[u] && at + 16 <= in.n_chars;
+                v[u] = SeqBytes16{{0u, 0u, 0u, 0u}};
+                if (whole[u]) v[u] = *reinterpret_cast<const SeqBytes16*>(in.chars + at);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                uint32_t any = 0;
+                for (int i = 0; i < T.n_tok_first; ++i) {
+                    const uint32_t c = T.tok_first[i] * 0x01010101u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t t = v[u].d[j] ^ c;
+                        any |= (t - 0x01010101u) & ~t;   // (bit 7 of some byte is set iff some byte of t is zero)
+                    }
+                }
+                // (bytes behind t1 may hit too: a row walked for nothing; the tensor's last bytes: their row is walked)
+                const bool hit = in_text[u] && (!whole[u] || (any & 0x80808080u) != 0u);
+                unsigned long long hm = __ballot(hit);
+                while (hm) {
+                    const int src = __ffsll(hm) - 1;
+                    hm &= hm - 1ull;
+                    const long long lo = base + (u * kWave + src) * 16, hi = lo + 16;
+                    const bool mine = valid && (long long)sb < hi && (long long)se > lo;
+                    if (mine) {   // the window of my row in which the tokens' first bytes stand
+                        const int a = int(lo - sb) > 0 ? int(lo - sb) : 0, b2 = int(hi - sb);
+                        w_lo = a < w_lo ? a : w_lo;
+                        w_hi = b2 > w_hi ? b2 : w_hi;
+                    }
+                    cand_rows |= __ballot(mine);
+                }
+            }
+        }
+        // the four waves' findings together
+        if (l == 0 && cand_rows) {
+            atomicOr(&cand_s[0], uint32_t(cand_rows));
+            atomicOr(&cand_s[1], uint32_t(cand_rows >> 32));
+        }
+        if ((cand_rows >> l) & 1ull) {
+            atomicMin(&wlo_s[l], w_lo);
+            atomicMax(&whi_s[l], w_hi);
+        }
+        __syncthreads();
+        if (wq != 0) return;
+        cand = ((l < 32 ? cand_s[0] >> l : cand_s[1] >> (l - 32)) & 1u) != 0u;
+        w_lo = wlo_s[l];
+        w_hi = whi_s[l];
+        swept = true;
+    } else if (wq != 0) {
+        return;
+    }
+    // the row's strings: `emit(begin, end, skip)` for each (special_tokens_split.cpp:104-147)
+    auto walk = [&](auto&& emit) {
+        if (!ok) return;
+        if (one && !cand) {
+            if (se > sb) emit(sb, se, 0);
+            return;
+        }
+        for (int col = cb; col < ce; ++col) {
+            const int b = in.begins[col], e = in.ends[col];
+            if (b < 0 || e < b || (long long)e > in.n_chars) {
+                atomicOr(&status->flags, kFlagRange);
+                return;
+            }
+            if (in.skips && in.skips[col]) {   // :110-113
+                emit(b, e, 1);
+                continue;
+            }
+            const uint8_t* s = in.chars + b;
+            const int slen = e - b;
+            if (!swept && !string_may_hold_token(T, s, slen)) {
+                if (slen > 0) emit(b, e, 0);
+                continue;
+            }
+            int start = 0, mb = 0, gb = 0, ge = 0, me = 0;
+            while (start < slen && special_next_match(T, tabs, s, slen, start, mb, gb, ge, me, swept ? w_lo : 0, swept ? w_hi : 0x7FFFFFFF)) {   // :127-141
+                if (start < mb) emit(b + start, b + mb, 0);
+                emit(b + gb, b + ge, 1);
+                start = me;
+            }
+            if (start < slen) emit(b + start, b + slen, 0);   // :143-147
+        }
+    };
+    // Where the strings go: a row of at most one string (nearly every row) has entry `row` of the buffers -- no counter, and the
+    // encode kernels' guess "row i is string i" holds --; the strings of the other rows follow behind the n_rows entries, taken with
+    // one atomic per block that has any.
+    int count = 0;
+    walk([&](int, int, int) { ++count; });
+    const int extra = count > 1 ? count : 0;
+    const int incl = wave_incl_sum(extra);
+    const int total = wave_readlane(incl, kWave - 1);
+    int base = 0;
+    if (l == 0 && total > 0) base = atomicAdd(&status->n_out, total);
+    base = wave_readlane(base, 0);
+    if ((long long)base + total > cap) {
+        if (l == 0) atomicOr(&status->flags, kFlagOutCapacity);
+        if (valid) out_rb[row] = out_re[row] = 0;
+        return;
+    }
+    int o = count > 1 ? in.n_rows + base + incl - extra : row;
+    if (valid) {
+        out_rb[row] = o;
+        out_re[row] = o + count;
+    }
+    walk([&](int b, int e, int skip) {
+        out_begins[o] = b;
+        out_ends[o] = e;
+        out_skips[o] = uint8_t(skip);
+        ++o;
+    });
 }
 
 }  // namespace ovtk

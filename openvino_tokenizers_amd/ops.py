@@ -395,6 +395,106 @@ class FusedSplitBPE:
         return ticket
 
 
+class FusedSpecialSplitBPE:
+    """SpecialTokensSplit -> RegexSplit -> BPETokenizer in one call (ovtk_encode_special_run / _enqueue): the sub-graph
+    tokenizer_pipeline.py:1613-1636 builds for a byte-level BPE model, the split strings and skip flags never leaving the device.
+    Same result as chaining SpecialTokensSplit.evaluate and FusedSplitBPE.evaluate."""
+
+    def __init__(self, special: SpecialTokensSplit, split: RegexSplit, bpe: BPETokenizer):
+        self.special, self.split, self.bpe = special, split, bpe
+
+    def _prep(self, special_inputs, split_pattern, bpe_constant_inputs):
+        has_skips = len(special_inputs) == 7
+        self.special._ensure(special_inputs[5 + has_skips])
+        self.split._ensure(split_pattern)
+        self.bpe._ensure(list(special_inputs[:5]) + list(bpe_constant_inputs))
+        m = _Mem(special_inputs[4])
+        rs, (rb, _, _, _, c) = _ragged_in(m, special_inputs)
+        _, pskips = (m.inp(special_inputs[5], "bool") if has_skips else (None, None))
+        ob, pob = m.alloc(len(rb), "i32")
+        oe, poe = m.alloc(len(rb), "i32")
+        cap = len(c)
+        ids, pids = m.alloc(cap, "i32")
+        return m, rs, pskips, (ob, oe, ids), L.RaggedI32Out(pob, poe, pids, cap, 0, 0)
+
+    def evaluate(self, special_inputs, split_pattern, bpe_constant_inputs):
+        """special_inputs: the 6/7 inputs of SpecialTokensSplit; split_pattern: RegexSplit's pattern; bpe_constant_inputs: inputs 5..
+        of BPETokenizer."""
+        m, rs, pskips, (ob, oe, ids), out = self._prep(special_inputs, split_pattern, bpe_constant_inputs)
+        lib = self.bpe._lib
+        L.check(lib, lib.ovtk_encode_special_run(self.special._h, self.split._h, self.bpe._h, C.byref(rs), pskips, C.byref(out), m.mem, m.stream))
+        return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+
+    def enqueue(self, special_inputs, split_pattern, bpe_constant_inputs):
+        m, rs, pskips, (ob, oe, ids), out = self._prep(special_inputs, split_pattern, bpe_constant_inputs)
+        if not m.torch:
+            raise L.OvtkError(L.E_ARG, "enqueue() needs device-resident (torch CUDA) inputs")
+        lib = self.bpe._lib
+        pending = C.c_void_p()
+        L.check(lib, lib.ovtk_encode_special_enqueue(self.special._h, self.split._h, self.bpe._h, C.byref(rs), pskips, C.byref(out), m.stream,
+                                                     C.byref(pending)))
+
+        def ticket(_keep=m):
+            L.check(lib, lib.ovtk_encode_finish(pending, C.byref(out)))
+            return [ob[:out.n_rows], oe[:out.n_rows], ids[:out.n_data]]
+        return ticket
+
+
+class FusedEncodeDense:
+    """[SpecialTokensSplit ->] RegexSplit -> BPETokenizer -> Truncate -> CombineSegments (constant ids in front / behind) ->
+    RaggedToDense x 2 in one call (ovtk_encode_dense_enqueue / _finish): input_ids [B, T] and attention_mask [B, T] of a converted
+    byte-level BPE tokenizer (tokenizer_pipeline.py:1613-1636 + TruncationStep / CombineSegmentsStep / PaddingStep) straight from
+    the encode's last pass -- the ragged ids tensor never exists.  Device tensors (torch CUDA; host arrays with the emulator build)."""
+
+    def __init__(self, split: RegexSplit, bpe: BPETokenizer, special: SpecialTokensSplit = None, max_length=2**31 - 1, trunc_side="right",
+                 pad_right=True, pad_value=0, prefix=(), suffix=()):
+        self.split, self.bpe, self.special = split, bpe, special
+        self.max_length, self.trunc_left, self.pad_right, self.pad_value = int(max_length), trunc_side == "left", bool(pad_right), int(pad_value)
+        self.prefix, self.suffix = np.asarray(list(prefix), np.int32), np.asarray(list(suffix), np.int32)
+
+    def enqueue(self, ragged_inputs, split_pattern, bpe_constant_inputs, special_pattern=None, target_dim=None, row_capacity=None, stream=None):
+        """ragged_inputs: ragged_begins, ragged_ends, begins, ends, chars [, skips].  row_capacity: cells per row the outputs are
+        allocated with (default: max_length + the constant ids, or the longest string's bytes if that is less)."""
+        has_skips = len(ragged_inputs) == 6
+        lib = self.bpe._lib
+        if self.special is not None:
+            self.special._ensure(special_pattern)
+        self.split._ensure(split_pattern)
+        self.bpe._ensure(list(ragged_inputs[:5]) + list(bpe_constant_inputs))
+        m = _Mem(ragged_inputs[4])
+        if not m.torch and not hasattr(lib, "ovtk_emulator_build"):   # the emulator build's device memory IS host memory (tests)
+            raise L.OvtkError(L.E_ARG, "FusedEncodeDense needs device-resident (torch CUDA) inputs")
+        rs, (rb, _, b, e, c) = _ragged_in(m, ragged_inputs)
+        _, pskips = (m.inp(ragged_inputs[5], "bool") if has_skips else (None, None))
+        rows = len(rb)
+        extra = len(self.prefix) + len(self.suffix)
+        if row_capacity is None:
+            row_capacity = (int(target_dim) if target_dim is not None else min(self.max_length, max(len(c), 1)) + extra)
+        cap = max(rows * int(row_capacity), 1)
+        ids, pids = m.alloc(cap, "i32")
+        mask, pmask = m.alloc(cap, "bool")
+        p = L.DenseParams(C.c_int32(min(self.max_length, 2**31 - 1)), int(self.trunc_left), int(self.pad_right), self.pad_value,
+                          -1 if target_dim is None else int(target_dim), self.prefix.ctypes.data_as(C.c_void_p), len(self.prefix),
+                          self.suffix.ctypes.data_as(C.c_void_p), len(self.suffix))
+        pending = C.c_void_p()
+        st = C.c_void_p(stream) if isinstance(stream, int) else (stream if stream is not None else m.stream)
+        L.check(lib, lib.ovtk_encode_dense_enqueue(self.special._h if self.special is not None else None, self.split._h, self.bpe._h, C.byref(rs),
+                                                   pskips, C.byref(p), pids, pmask, C.c_int64(cap), st, C.byref(pending)))
+
+        def ticket(_keep=(m, p)):
+            width, n_ids = C.c_int32(0), C.c_int64(0)
+            L.check(lib, lib.ovtk_encode_dense_finish(pending, C.byref(width), C.byref(n_ids)))
+            n = rows * int(width.value)
+            shape = (rows, int(width.value))
+            if m.torch:
+                return [ids[:n].reshape(shape), mask[:n].reshape(shape).bool()]
+            return [ids[:n].reshape(shape), mask[:n].reshape(shape).astype(bool)]
+        return ticket
+
+    def evaluate(self, *args, **kw):
+        return self.enqueue(*args, **kw)()
+
+
 class WordpieceTokenizer(_Op):
     """Reference: src/wordpiece_tokenizer.cpp (evaluate :49-133).  Inputs: ragged strings (5), vocab (3),
     unk_token_id (i32 scalar, read every call).  Outputs: begins, ends, ids."""

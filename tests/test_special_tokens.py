@@ -80,3 +80,58 @@ def test_unsupported_patterns(backend):
         with pytest.raises(L.OvtkError) as ei:
             SpecialTokensSplit(lib=backend.lib).evaluate(backend.data(one_string_per_row(["x"])) + [u8(pat) if pat else np.zeros(0, np.uint8)])
         assert ei.value.code == L.E_UNSUPPORTED
+
+
+def _texts_with_specials(rng, n, every=7):
+    """Text rows of the zipf model, one row in `every` with special tokens inside (also first / last, and two in a row)."""
+    from tools.workloads import TextModel
+    b, e, c = TextModel(int(rng.integers(1 << 30)), "zipf").batch(n, 200)
+    rows = [bytes(c[b[i]:e[i]]) for i in range(n)]
+    sp = b"<|endoftext|>"
+    for i in range(0, n, every):
+        k = i // every % 5
+        r = rows[i]
+        cut = int(rng.integers(0, len(r) + 1))
+        rows[i] = [r[:cut] + sp + r[cut:], sp + r, r + sp, r[:cut] + sp + sp + r[cut:], sp][k]
+    rows[1] = b"a < b <| c <|endoftext| d <|endoftext|"   # the token's first bytes without the token
+    return rows
+
+
+@pytest.mark.parametrize("n_rows", [40, 320])
+def test_fused_special_split_bpe(backend, n_rows):
+    """ovtk_encode_special_run (SpecialTokensSplit -> RegexSplit -> BPETokenizer in one call, tokenizer_pipeline.py:1613-1636) = the
+    oracle chain = the three ops one after the other; small batches (one launch) and batches that take the span kernel; blocking and
+    in two halves (device tensors)."""
+    from openvino_tokenizers_amd.ops import FusedSpecialSplitBPE
+    tok = BpeTok.load("gpt2_small")
+    pat = O.special_tokens_pattern([("<|endoftext|>", False, False)])
+    rng = np.random.default_rng(n_rows)
+    inputs = one_string_per_row(_texts_with_specials(rng, n_rows))
+    s_ref = O.SpecialTokensSplit(pat)(*inputs)
+    r_ref = O.RegexSplit(tok.pattern, "isolate")(*s_ref[:5], skips=s_ref[5])
+    ref = tok.oracle()(*r_ref[:5])
+    assert (ref[2] == tok.added[b"<|endoftext|>"]).sum() >= n_rows // 7
+    fused = FusedSpecialSplitBPE(SpecialTokensSplit(lib=backend.lib), RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    data = backend.data(inputs)
+    for call in range(2):
+        assert_same(ref, fused.evaluate(data + [u8(pat)], tok.pattern_u8(), tok.consts), backend.host, f"fused special -> split -> bpe, call {call}")
+    if backend.name == "hip-device":
+        assert_same(ref, fused.enqueue(data + [u8(pat)], tok.pattern_u8(), tok.consts)(), backend.host, "the same in two halves")
+    # strip_left / strip_right tokens, and a skips input (7-input form)
+    pat2 = O.special_tokens_pattern([("<|endoftext|>", False, False), ("<pad>", True, True)])
+    strings = [b"hello <|endoftext|> world", b"<pad>", b"", b"  <pad>  x<|endoftext|>", b"keep <|endoftext|> whole"] * (n_rows // 5)
+    inputs2 = one_string_per_row(strings)
+    skips = (np.arange(len(strings)) % 5 == 4).astype(np.uint8)
+    s_ref = O.SpecialTokensSplit(pat2)(*inputs2, skips=skips)
+    ref2 = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(*s_ref[:5], skips=s_ref[5])[:5])
+    fused2 = FusedSpecialSplitBPE(SpecialTokensSplit(lib=backend.lib), RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    assert_same(ref2, fused2.evaluate(backend.data(inputs2 + [skips]) + [u8(pat2)], tok.pattern_u8(), tok.consts), backend.host, "strip flags + skips input")
+    # rows of several strings, an empty row, strings that are not one stretch of text (the wave's sweep does not apply)
+    strings3 = [b"hello <|endoftext|> world", b"<pad>", b"", b"  <pad>  x<|endoftext|>", b"keep <|endoftext|> whole", b"tail"] * 50
+    b3, e3, c3 = O.pack_strings(strings3)
+    b3, e3 = b3[::-1].copy(), e3[::-1].copy()   # (reversed: string i + 1 lies in front of string i)
+    rb3 = np.arange(0, 300, 3, dtype=np.int32)
+    re3 = rb3 + np.asarray([3, 0, 2, 3] * 25, np.int32)
+    s_ref = O.SpecialTokensSplit(pat2)(rb3, re3, b3, e3, c3)
+    ref3 = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(*s_ref[:5], skips=s_ref[5])[:5])
+    assert_same(ref3, fused2.evaluate(backend.data([rb3, re3, b3, e3, c3]) + [u8(pat2)], tok.pattern_u8(), tok.consts), backend.host, "ragged rows, scattered strings")

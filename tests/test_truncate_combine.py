@@ -185,3 +185,57 @@ def test_fused_encode_tail(backend, shape):
     dsegs = [tuple(backend.data(list(s))) for s in segs]
     got = op.evaluate(dsegs, cfg["ids"], truncated=cfg["trunc"], pad_value=9, type_pad_value=4, target_dim=cfg["T"])
     assert_same([want_ids, want_mask.astype(bool), want_types], got, backend.host, "FusedEncodeTail")
+
+
+@pytest.mark.parametrize("with_special", [False, True])
+def test_encode_dense_equals_the_chain(backend, with_special):
+    """ovtk_encode_dense_*: [SpecialTokensSplit ->] RegexSplit -> BPETokenizer -> Truncate -> CombineSegments (constant BOS / EOS) ->
+    RaggedToDense x 2 in one call, the dense tensors written by the encode's last pass = the oracle's ragged ids through the oracle's
+    truncate / combine_segments / ragged_to_dense (src/truncate.cpp:37-150, src/combine_segments.cpp:36-134,
+    src/ragged_to_dense.cpp:70-174).  Both truncation sides, both padding sides, longest-row and fixed target_dim (also one below
+    the longest row), batches of one launch and of the span kernel's size."""
+    from openvino_tokenizers_amd.ops import BPETokenizer, FusedEncodeDense, RegexSplit, SpecialTokensSplit
+    from tests.test_special_tokens import _texts_with_specials, u8
+    from tests.util import BpeTok, one_string_per_row
+    if backend.name == "hip-host":
+        pytest.skip("device tensors only")
+    tok = BpeTok.load("gpt2_small")
+    pat = O.special_tokens_pattern([("<|endoftext|>", False, False)])
+    rng = np.random.default_rng(3 + with_special)
+    for n_rows in (24, 300):
+        strings = _texts_with_specials(rng, n_rows) if with_special else [s.replace(b"<|endoftext|>", b"") for s in _texts_with_specials(rng, n_rows)]
+        strings[2] = b""
+        inputs = one_string_per_row(strings)
+        if with_special:
+            s_ref = O.SpecialTokensSplit(pat)(*inputs)
+            rb, re_, ids = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(*s_ref[:5], skips=s_ref[5])[:5])
+        else:
+            rb, re_, ids = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(*inputs)[:5])
+        for max_length, side, pad_right, target, pre, suf in [(1 << 20, "right", True, None, (), ()), (20, "right", True, None, (7,), (9, 11)),
+                                                              (33, "left", False, None, (5,), ()), (16, "right", False, 40, (), (3,)),
+                                                              (64, "left", True, 30, (1, 2), (3, 4))]:
+            (tb, te), = O.truncate([(rb, re_)], max_length, side, "longest_first")
+            segs = []
+            if pre:
+                segs.append((np.zeros(1, np.int32), np.full(1, len(pre), np.int32), np.asarray(pre, np.int32)))
+            segs.append((tb, te, ids))
+            if suf:
+                segs.append((np.zeros(1, np.int32), np.full(1, len(suf), np.int32), np.asarray(suf, np.int32)))
+            cb, ce, cdata = O.combine_segments(segs, list(range(len(segs))))[:3]
+            width = int((ce - cb).max()) if target is None else target
+            ref_ids, ref_mask = O.ragged_to_dense(cb, ce, cdata, width, 50256, pad_right=pad_right)
+            op = FusedEncodeDense(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib),
+                                  SpecialTokensSplit(lib=backend.lib) if with_special else None, max_length=max_length, trunc_side=side,
+                                  pad_right=pad_right, pad_value=50256, prefix=pre, suffix=suf)
+            got = op.evaluate(backend.data(inputs), tok.pattern_u8(), tok.consts, special_pattern=u8(pat) if with_special else None, target_dim=target,
+                              row_capacity=max(width, 1))
+            what = f"dense: special {with_special}, {n_rows} rows, max_length {max_length} {side}, pad_right {pad_right}, target {target}"
+            assert backend.host(got[0]).shape == ref_ids.shape, what
+            assert np.array_equal(backend.host(got[0]), ref_ids), what
+            assert np.array_equal(backend.host(got[1]), ref_mask.astype(bool)), what
+    # too little room: OVTK_E_CAPACITY
+    from openvino_tokenizers_amd import _lib as L
+    op = FusedEncodeDense(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    with pytest.raises(L.OvtkError) as ei:
+        op.evaluate(backend.data(inputs), tok.pattern_u8(), tok.consts, row_capacity=3)
+    assert ei.value.code == L.E_CAPACITY
