@@ -45,7 +45,7 @@ def test_bench_json_line():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("config", ["1", "5", "r2d", "vocab_encoder"])
+@pytest.mark.parametrize("config", ["1", "5", "r2d", "vocab_encoder", "pipeline"])
 def test_bench_other_configs(config):
     d = _run("--config", config, "--no-extras")
     assert d["value"] > 0 and d["parity_prefix_bit_exact"] is True and 0 < d["roofline"]["frac"] < 1

@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
-for cfg in ${CONFIGS:-2 3 4 5 r2d vocab_encoder}; do
+for cfg in ${CONFIGS:-2 3 4 5 r2d vocab_encoder pipeline}; do
   rm -rf "$OUT/prof_c$cfg" "$OUT/pmc_fetch_c$cfg" "$OUT/pmc_write_c$cfg"
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_c$cfg" -- \
       python bench.py --config $cfg --no-cpu-baseline --no-extras --no-alone-leg > "$OUT/prof_c$cfg.log" 2>&1

@@ -19,7 +19,7 @@ TAG = {"lookup_span_kernel": "lookup_span", "lookup_rows_kernel": "lookup_rows",
        "lookup_kernel<0>": "lookup_fused", "lookup_kernel<1>": "lookup_pieces", "lookup_kernel<2>": "lookup_fused",
        "merge_kernel": "bpe_merge",
        "split_seq_kernel<0>": "split_count", "split_seq_kernel<1>": "split_write",
-       "exact_kernel": "bpe_exact", "compact_kernel": "compact", "prep_rows_kernel": "prep_rows",
+       "exact_kernel": "bpe_exact", "compact_kernel": "compact", "special_sparse_kernel": "special_split", "row_width_kernel": "row_width", "prep_rows_kernel": "prep_rows",
        "count_scan_kernel": "count_scan", "wordpiece_deferred_kernel": "wordpiece_deferred",
        "decode_count_kernel": "decode_count", "decode_write_kernel": "detokenize"}
 
@@ -47,7 +47,7 @@ def main(prefix):
     out_dir.mkdir(parents=True, exist_ok=True)
     stem = Path(prefix).name
     pmc_json = {}
-    for cfg in (2, 3, 4, 5, "r2d", "vocab_encoder"):
+    for cfg in (2, 3, 4, 5, "r2d", "vocab_encoder", "pipeline"):
         st = newest(str(ROOT / f"gpurun_out/prof_c{cfg}/*/*kernel_stats.csv"))
         if st:
             d = pd.read_csv(st)
