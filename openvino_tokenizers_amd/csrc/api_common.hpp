@@ -413,7 +413,7 @@ private:
         e = e ? e : ws.row_stage.ensure(size_t(n_rows_) * 4);
         e = e ? e : ws.row_cnt.ensure(size_t(n_rows_) * 4);
         e = e ? e : ws.row_used.ensure(size_t(n_rows_) * 4);
-        e = e ? e : ws.stage.ensure(size_t(stage_cap_) * 4);
+        e = e ? e : ws.stage.ensure(size_t(stage_cap_) * 4 + 64);   // (+ slack: compact_flat's 16-byte loads may read behind the last entry)
         e = e ? e : ws.deferred.ensure(size_t(shard_cap_) * kShards * sizeof(DeferredPiece));
         e = e ? e : ws.exact.ensure(size_t(exact_cap_) * sizeof(ExactPiece));
         e = e ? e : ws.scratch.ensure(size_t(scratch_cap_));
@@ -495,7 +495,9 @@ private:
         if (!w.fold_tail)
             OVTK_LAUNCH(ws.marks, "count_scan", count_scan_kernel, std::min((n_tiles_ + 3) / 4, kTicketBlocks), kBlockThreads, s_,
                         n_rows_, w, (long long)out_.data_capacity);
-        const int cgrid = grid_lookup(device_, n_rows_);
+        // (compact_kernel's waves take work items of kCompactRows rows: a wave per item where the chip holds that many -- the kernel is a chain
+        // of memory round trips per item, not a matter of instructions)
+        const int cgrid = std::max(1, std::min((n_rows_ + kCompactRows * kWavesPerBlock - 1) / (kCompactRows * kWavesPerBlock), device_cu_count(device_) * 16));
         const RaggedSink rsink{d_ids_, d_begins_, d_ends_};
         if (dense_on_) {
             OVTK_LAUNCH(ws.marks, "row_width", row_width_kernel, std::min(64, (n_rows_ + kBlockThreads - 1) / kBlockThreads), kBlockThreads, s_, n_rows_, w, dense_);

@@ -87,122 +87,10 @@ __device__ __forceinline__ void span_load(const RowsIn& in, int sb, int blen, ui
     }
 }
 
-// Piece-start flags of the lane's 32 bytes (bit k = byte 32 l + k starts a piece) under the GPT-2 rules of split_device.hpp
-// (gpt2_start_flags_ascii: the same algebra), streamed dword by dword so that only three dwords' classes are live, with the
-// flags of two dwords packed into 8 bits by one v_dot4_u32_u8 each.  Two things are decided on the packed flags afterwards,
-// where they cost a handful of instructions per lane instead of some per dword:
-//  * the row starts `rs` (bit k: byte 32 l + k is the first of a row, or the first behind the block).  Such a byte starts a piece
-//    whatever stands in front of it; and the one rule that looks AHEAD across it -- the last character of a white-space run
-//    starts a piece when a non-space follows, `\s+(?!\S)` backing off -- must not: a row's trailing run is one piece;
-//  * contractions: apostrophes are few, so a lane walks its own (usually none, rarely two) and reads the letters behind them
-//    from the LDS copy of the text.
-// false (wave-uniform): the block holds a non-ASCII byte.
+// The scans: the GPT-2 family and the Llama-3 family run their rules on bit masks (span_l3.hpp: span_flags_gpt2m, span_flags_l3 -- until
+// round 5 the GPT-2 family had a packed-byte form for ASCII blocks here, 3 % slower than the masks on the headline text and blind to
+// non-ASCII text); the BERT words keep the packed-byte form below.
 enum SpanScan : int { kSpanGpt2 = 0, kSpanGpt2Digits = 1, kSpanBertWords = 2, kSpanLlama3 = 3 };
-struct SpanClasses { uint32_t L, N, S, SP, O; };
-template <bool DIGITS>
-__device__ __forceinline__ SpanClasses span_classify(uint32_t v) {
-    SpanClasses c;
-    c.L = swar_range(v | 0x20202020u, 'a', 'z');
-    c.N = swar_range(v, '0', '9');
-    c.SP = swar_eq(v, 0x20);
-    c.S = c.SP | swar_range(v, 9, 13);
-    c.O = kB7 & ~(c.L | c.N | c.S);
-    return c;
-}
-template <bool DIGITS>
-__device__ __forceinline__ bool span_flags(uint32_t (&x)[kSpanDwords], uint32_t rs, uint32_t vm, const uint8_t* text, uint32_t& flags) {
-    constexpr int D = kSpanDwords;
-    const int l = lane_id();
-    uint32_t any = 0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) any |= x[j];
-    if (__ballot((any & kB7) != 0)) {
-        // a lane's bytes behind the block's end are the next row's (or whatever follows in the tensor): look again, at the block's own
-        uint32_t bad = 0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const uint32_t own = nibble_to_b7((vm >> (4 * j)) & 0xFu);
-            bad |= x[j] & own;
-            x[j] &= ~(kB7 & ~own);   // (a byte >= 0x80 would carry into its neighbours in the packed arithmetic below)
-        }
-        if (__ballot(bad != 0)) return false;
-    }
-    // the lane's last dword first: its classes are the "dword before" of lane l + 1; then the first: "not white space" of lane l - 1's look-ahead
-    const SpanClasses last = span_classify<DIGITS>(x[D - 1]);
-    SpanClasses prev{lane_prev(last.L), lane_prev(last.N), lane_prev(last.S), lane_prev(last.SP), lane_prev(last.O)};
-    SpanClasses cur = span_classify<DIGITS>(x[0]);
-    const uint32_t ns_behind = lane_next(kB7 & ~cur.S);
-    uint32_t f_acc[D / 2], s_acc[D / 2], a_acc[D / 2];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        SpanClasses nxt = cur;
-        uint32_t ns_next = ns_behind;
-        if (j + 1 < D) {
-            nxt = j + 1 == D - 1 ? last : span_classify<DIGITS>(x[j + 1]);
-            ns_next = kB7 & ~nxt.S;
-        }
-        const uint32_t pL = swar_before<1>(prev.L, cur.L), pN = swar_before<1>(prev.N, cur.N);
-        const uint32_t pS = swar_before<1>(prev.S, cur.S), pO = swar_before<1>(prev.O, cur.O);
-        const uint32_t pSP = swar_before<1>(prev.SP, cur.SP);
-        const uint32_t same = (cur.L & pL) | (cur.N & pN) | (cur.S & pS) | (cur.O & pO);
-        const uint32_t attaches = ~cur.S & (DIGITS ? ~cur.N : ~0u);
-        uint32_t st = ~same & ~(pSP & attaches);
-        const uint32_t next_nonspace = swar_after<1>(kB7 & ~cur.S, ns_next);
-        st |= same & ((cur.S & next_nonspace) | (DIGITS ? cur.N : 0u));
-        st &= kB7;
-        const uint32_t ap = swar_eq(x[j], 0x27);
-        // 0x80 flags of two dwords -> 128 x (8 flag bits): byte k of the dword times 1 << k (or 16 << k)
-        if ((j & 1) == 0) {
-            f_acc[j >> 1] = dot4_u8(st, 0x08040201u, 0u);
-            s_acc[j >> 1] = dot4_u8(cur.S, 0x08040201u, 0u);
-            a_acc[j >> 1] = dot4_u8(ap, 0x08040201u, 0u);
-        } else {
-            f_acc[j >> 1] = dot4_u8(st, 0x80402010u, f_acc[j >> 1]);
-            s_acc[j >> 1] = dot4_u8(cur.S, 0x80402010u, s_acc[j >> 1]);
-            a_acc[j >> 1] = dot4_u8(ap, 0x80402010u, a_acc[j >> 1]);
-        }
-        prev = cur;
-        cur = nxt;
-    }
-    flags = (f_acc[0] >> 7) | (f_acc[1] << 1) | (f_acc[2] << 9) | (f_acc[3] << 17);
-    const uint32_t sbits = (s_acc[0] >> 7) | (s_acc[1] << 1) | (s_acc[2] << 9) | (s_acc[3] << 17);
-    uint32_t apbits = ((a_acc[0] >> 7) | (a_acc[1] << 1) | (a_acc[2] << 9) | (a_acc[3] << 17)) & vm;
-    // ---- row starts
-    const uint32_t rs_next = lane_next(rs);
-    {
-        const uint32_t ends_row = (rs >> 1) | (rs_next << 31);                    // the byte behind this one is another row's (or none)
-        const uint32_t s_before = (sbits << 1) | (lane_prev(sbits) >> 31);       // the byte in front of this one is white space
-        flags = (flags & ~(ends_row & sbits & s_before)) | rs;
-        if (l == 0) flags |= 1u;   // the block's first byte starts a piece: a row's first, or where the block before stopped
-    }
-    // ---- contractions: 's 't 'm 'd 're 've 'll at an apostrophe that itself starts a piece; the letter(s) stay with it, the byte
-    // behind them starts a piece.  Bits 32.. of the masks belong to lane l + 1.
-    if (__ballot(apbits != 0)) {
-        // (the letters must be of this row AND of this block: behind a last block of exactly 2 048 bytes there is no row-start bit to
-        // stop them, and the LDS bytes behind the block's text are whatever the last launch left there -- ADVICE r04)
-        const uint64_t rs64 = (uint64_t(rs) | (uint64_t(rs_next) << 32)) | ~(uint64_t(vm) | (uint64_t(lane_next(vm)) << 32));
-        uint64_t set = 0, clr = 0;
-        apbits &= flags;   // (an apostrophe behind a class-O character or a space does not start a piece: nothing fires there)
-        while (apbits) {
-            const int k = __ffs(apbits) - 1;
-            apbits &= apbits - 1;
-            const uint32_t w4 = reinterpret_cast<const Bytes4*>(text + kSpanLane * l + k)->v;   // ' c1 c2 ..
-            const uint32_t c1 = (w4 >> 8) & 0xFFu, c2 = (w4 >> 16) & 0xFFu;
-            const bool r1 = (rs64 >> (k + 1)) & 1ull, r2 = (rs64 >> (k + 2)) & 1ull;   // the letters must be of this row
-            const bool one = !r1 && (c1 == 's' || c1 == 't' || c1 == 'm' || c1 == 'd');
-            const bool two = !r1 && !r2 && (((c1 == 'r' || c1 == 'v') && c2 == 'e') || (c1 == 'l' && c2 == 'l'));
-            if (one || two) {
-                clr |= 1ull << (k + 1);
-                set |= 1ull << (k + (one ? 2 : 3));
-            }
-        }
-        const uint32_t set_in = lane_prev(uint32_t(set >> 32)), clr_in = lane_prev(uint32_t(clr >> 32));
-        flags = ((flags | uint32_t(set) | set_in) & ~(uint32_t(clr) | clr_in)) | rs;
-    }
-    flags &= vm;
-    return true;
-}
-
 // The BERT words of the fused WordPiece path (class_packed_starts with kSplitBertWords: `\s+` removed, then every delimiter
 // character -- bert_delimiter() below 0x80 -- isolated): a piece starts where white-space-ness changes, at every delimiter and
 // behind every delimiter; white-space pieces are dropped (`dropped`: bit k = byte 32 l + k is white space).  Nothing looks ahead,
@@ -504,13 +392,9 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 }
 #endif
             } else {
-                fast = BERT ? span_flags_bert(xa, rs, vm, fl, dropped) : span_flags<DIGITS>(xa, rs, vm, text, fl);
-                if constexpr (!BERT) {
-                    // a block with non-ASCII text: the same rules on bit masks, the characters classified by the wave (span_l3.hpp;
-                    // until round 5 the ballot form window by window: four times the packed form's instructions per byte)
-                    if (!fast) span_flags_gpt2m<DIGITS>(xa, rs, vm, text, rs_words + kWave, sp, at_end, b_len, fl);
-                    fast = true;
-                }
+                if constexpr (BERT) fast = span_flags_bert(xa, rs, vm, fl, dropped);
+                else span_flags_gpt2m<DIGITS>(xa, rs, vm, text, rs_words + kWave, sp, at_end, b_len, fl);   // (any text: the characters of a
+                                                                                                            // non-ASCII block are classified by the wave)
             }
             // ---- the block's piece list: np pieces, the last one ends at q_end (= where the next block starts); rowfirst: the list
             // index of my row's first piece, if that is one of them
