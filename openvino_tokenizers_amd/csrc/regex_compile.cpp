@@ -8,7 +8,10 @@
 #include <utility>
 
 #include "../../include/ovtk_amd.h"
+#include <cctype>
+
 #include "unicode_gc.inc"
+#include "unicode_scripts.inc"
 
 namespace ovtk {
 namespace {
@@ -63,12 +66,33 @@ int gc_of(uint32_t cp) {
     const unsigned* p = std::upper_bound(kGcStart, kGcStart + kGcRanges + 1, cp);
     return kGcValue[(p - kGcStart) - 1];
 }
+// Script / Script_Extensions of a script name (long name or ISO 15924 code, matched loosely as PCRE2 does: case, `_`, `-` and spaces do
+// not count); false: no such script.  unicode_scripts.inc (Unicode 16.0; tools/gen_unicode_scripts.py).
+bool script_set(const std::string& loose_name, bool extensions, CharSet& out);
+
 CharSet gc_set(uint32_t mask) {
     CharSet s;
     for (unsigned i = 0; i < kGcRanges; ++i)
         if (mask >> kGcValue[i] & 1u) s.add(kGcStart[i], kGcStart[i + 1] - 1);
     s.normalize();
     return s;
+}
+
+bool script_set(const std::string& loose_name, bool extensions, CharSet& out) {
+    auto loose = [](const char* t) {
+        std::string r;
+        for (; *t; ++t)
+            if (*t != '_' && *t != '-' && *t != ' ') r.push_back(char(std::tolower(static_cast<unsigned char>(*t))));
+        return r;
+    };
+    for (unsigned i = 0; i < kScriptCount; ++i) {
+        if (loose(kScriptNames[i][0]) != loose_name && loose(kScriptNames[i][1]) != loose_name) continue;
+        const unsigned* offs = extensions ? kScxOffsets : kScOffsets;
+        const unsigned* rs = extensions ? kScxRanges : kScRanges;
+        for (unsigned k = offs[i]; k < offs[i + 1]; ++k) out.add(rs[2 * k], rs[2 * k + 1] - 1);
+        return true;
+    }
+    return false;
 }
 CharSet hspace_set() {  // PCRE2 \h
     CharSet s;
@@ -320,7 +344,22 @@ private:
         else {
             for (int g = 0; g < kGcCount; ++g)
                 if (key == kGcNames[g]) mask = gc_bit(g);
-            if (!mask) throw Unsupported{"\\p{" + name + "}: only General_Category properties are supported"};
+            if (!mask) {
+                // a script: \p{Han} is Script_Extensions since PCRE2 10.40 (the reference pins 10.46), \p{sc:Han} / \p{script=Han} the
+                // Script property, \p{scx:Han} / \p{scriptextensions=Han} the extensions by name
+                std::string low;
+                for (char c : key) low.push_back(char(std::tolower(static_cast<unsigned char>(c))));
+                bool ext = true;
+                const size_t sep = low.find_first_of(":=");
+                if (sep != std::string::npos) {
+                    const std::string prop = low.substr(0, sep);
+                    if (prop == "sc" || prop == "script") ext = false;
+                    else if (prop != "scx" && prop != "scriptextensions") throw Unsupported{"\\p{" + name + "}: unknown property"};
+                    low = low.substr(sep + 1);
+                }
+                if (!script_set(low, ext, s)) throw Unsupported{"\\p{" + name + "}: neither a General_Category nor a script of Unicode 16.0"};
+                direct = true;
+            }
         }
         // \p{Lu} \p{Ll} \p{Lt} match any cased letter under PCRE2's caseless rules: not reproduced
         const uint32_t cased = gc_bit(Lu) | gc_bit(Ll) | gc_bit(Lt);

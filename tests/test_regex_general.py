@@ -126,7 +126,7 @@ def test_fuzzed_patterns(backend):
     assert compared >= 20
 
 
-@pytest.mark.parametrize("pattern", [r"(a)\1", r"(?>a+)b", r"\p{Han}+", r"\p{Greek}", r"a(?=bc)", r"(?<=ab)c", r"(?m)^a", r"(?x) a b", r"\R",
+@pytest.mark.parametrize("pattern", [r"(a)\1", r"(?>a+)b", r"\p{Hann}+", r"\p{foo:Greek}", r"a(?=bc)", r"(?<=ab)c", r"(?m)^a", r"(?x) a b", r"\R",
                                      r"\X", r"a\Kb", r"(?|a|b)", r"(?R)", r"(?(1)a|b)", r"(?i)é", r"(?i)[à-ý]", r"(a|b)++c", r"a**",
                                      r"(?i)\p{Lu}x", r"[[:punct:]]", r"(*UTF)a", r"(", r"a)", r"[a", r"\p{Foo}", "\\"])
 def test_outside_the_subset_is_refused(backend, pattern):
@@ -134,6 +134,65 @@ def test_outside_the_subset_is_refused(backend, pattern):
     with pytest.raises(L.OvtkError) as ei:
         RegexSplit("isolate", lib=backend.lib).evaluate(backend.data(one_string_per_row(["ab"])) + [np.frombuffer(pattern.encode(), np.uint8)])
     assert ei.value.code == L.E_UNSUPPORTED
+
+
+def _spelled(mask_fn, names):
+    """A character class of explicit ranges for the code points `mask_fn(name)` flags, any of `names`."""
+    import regex
+    cps = [cp for cp in range(0x110000) if not 0xD800 <= cp < 0xE000 and any(mask_fn(n).match(chr(cp)) for n in names)]
+    out, i = [], 0
+    while i < len(cps):
+        j = i
+        while j + 1 < len(cps) and cps[j + 1] == cps[j] + 1:
+            j += 1
+        out.append(f"\\x{{{cps[i]:X}}}-\\x{{{cps[j]:X}}}" if j > i else f"\\x{{{cps[i]:X}}}")
+        i = j + 1
+    return "[" + "".join(out) + "]"
+
+
+SCRIPT_TEXT = ["漢字とひらがなカタカナ、。「」ー々〆", "Ελληνικά και Кириллица mixed", "abc 日本語 def", "ｶﾀｶﾅ ㍿ ㈱ 〜", "العربية ـ ، ؛", "देवनागरी । ॥ ᳐",
+               "한국어 ㄱ ㆍ", "a、b。c", "", "ゝゞヽヾ ｰ ﾞ", "͂ ̀ ͅ ᾿", "၊ ။", "𠀀𠀁 𪜀"]
+
+
+@pytest.mark.parametrize("prop, pattern", [("sc", r"\p{sc:Han}+|\p{script=Hiragana}+|\p{sc:Kana}+"), ("sc", r"[\p{sc:Greek}\p{sc:Cyrl}]+|\P{sc:Latin}"),
+                                           ("scx", r"\p{Han}+"), ("scx", r"\p{Hiragana}+|\p{Katakana}+|\p{scx:Hang}+"),
+                                           ("scx", r"[\p{Greek}\p{Cyrillic}]+| ?\p{Arabic}+|\p{Deva}+|\p{ Myanmar }")])
+def test_script_properties(backend, prop, pattern):
+    r"""\p{Han} and friends (round 5; the reference hands them to PCRE2 10.46, src/utils.cpp:256-272, where a bare script name means
+    Script_Extensions and \p{sc:..} the Script property).  The image's PCRE2 is 10.39 -- a bare name is the Script property there, of
+    Unicode 14 --, so the oracle runs the pattern with every script property SPELLED OUT as the ranges of Unicode 16.0's Script /
+    Python `regex`'s Script_Extensions (the table's own sources, tools/gen_unicode_scripts.py): what is checked is the compiler and
+    the kernels, and -- below -- that the two properties differ where Unicode says they do."""
+    import re
+    import regex
+    spelled = pattern
+    for m in sorted(set(re.findall(r"\\[pP]\{[^}]*\}", pattern)), key=len, reverse=True):
+        name = m[3:-1].replace(" ", "").split(":")[-1].split("=")[-1]
+        ext = not (m[3:-1].replace(" ", "").lower().startswith(("sc:", "script=")))
+        rx = (lambda n, e=ext: regex.compile(r"\p{%s=%s}" % ("Script_Extensions" if e else "Script", n)))
+        cls = _spelled(rx, [name])
+        if m[1] == "P":
+            cls = "[^" + cls[1:]
+        # (inside a class the brackets go)
+        spelled = spelled.replace("[" + m, "[" + cls[1:-1]).replace(m + "]", cls[1:-1] + "]").replace(m, cls)
+    inputs = one_string_per_row(SCRIPT_TEXT)
+    ref = O.RegexSplit(spelled, "isolate")(*inputs)
+    got = RegexSplit("isolate", lib=backend.lib).evaluate(backend.data(inputs) + [np.frombuffer(pattern.encode(), np.uint8)])
+    assert_same(ref[:4], got[:4], backend.host, pattern)
+
+
+def test_script_extensions_are_not_script(backend):
+    """U+3001 IDEOGRAPHIC COMMA: Script=Common, Script_Extensions holds Han, Hiragana, Katakana ...; U+30FC (the long-vowel mark): Script
+    Common, extensions Hiragana Katakana; U+0640 TATWEEL: Common, extensions Arabic, Syriac, ...  PCRE2 10.46: \\p{Han} takes U+3001,
+    \\p{sc:Han} does not."""
+    def pieces(pattern, text):
+        got = RegexSplit("isolate", lib=backend.lib).evaluate(backend.data(one_string_per_row([text])) + [np.frombuffer(pattern.encode(), np.uint8)])
+        b, e, c = (backend.host(x) for x in got[2:5])
+        return [bytes(c[x:y]).decode() for x, y in zip(b, e)]
+    assert pieces(r"\p{Han}+", "漢、字") == ["漢、字"] and pieces(r"\p{sc:Han}+", "漢、字") == ["漢", "、", "字"]
+    assert pieces(r"\p{Katakana}+", "カーa") == ["カー", "a"] and pieces(r"\p{sc:Katakana}+", "カーa") == ["カ", "ーa"]
+    assert pieces(r"\p{Arabic}+", "بـb") == ["بـ", "b"] and pieces(r"\p{script=Arabic}+", "بـb") == ["ب", "ـb"]
+    assert pieces(r"\p{Hani}+|\p{hira}+", "漢ひ") == ["漢", "ひ"]   # ISO 15924 codes, any case
 
 
 def test_word_class_follows_pcre2_10_46(backend):

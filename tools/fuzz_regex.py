@@ -19,8 +19,13 @@ ATOMS = ["a", "b", "c", " ", r"\n", ".", r"\s", r"\S", r"\d", r"\w", r"\W", "[ab
 if "wide" in sys.argv[3:]:
     ATOMS = ATOMS[:18] + ["A", r"\h", r"\v", r"\N", "[[:alpha:]]", r"\p{Lu}", r"\p{Ll}", "元", r"(?s:.)", "_", r"[^\r\n]", r"\r", r"\t", r"[\p{L}\p{N}]",
                          r"[^\s\p{L}\p{N}]", "'", r"\b", r"\B", "^", "$", r"\z", r"\Z", r"\A"]
+if "scripts" in sys.argv[3:]:
+    # script properties (round 5).  The oracle's PCRE2 10.39 reads a bare name as the Script property, the product (10.46's meaning)
+    # as Script_Extensions: the alphabet holds only characters on which the two agree (letters of ONE script)
+    ATOMS = ATOMS[:18] + [r"\p{Greek}", r"\p{Cyrillic}", r"\P{Greek}", r"[\p{Greek}\p{Han}]", r"\p{Han}", r"[^\p{Cyrillic}a]", r"\b", r"\B", "^", "$", r"\z", r"\A"]
 QUANT = ["", "", "", "*", "+", "?", "{1,2}", "{2}", "{0,2}", "*?", "+?", "??", "*+", "++", "?+", "{1,2}?", "{1,2}+"]
-ALPHA = ["a", "b", "c", " ", "\n", "1", "é", "A"] + (["元", "\r", "\t", "_", "'"] if "wide" in sys.argv[3:] else [])
+ALPHA = ["a", "b", "c", " ", "\n", "1", "é", "A"] + (["元", "\r", "\t", "_", "'"] if "wide" in sys.argv[3:] else []) + \
+        (["α", "я", "元"] if "scripts" in sys.argv[3:] else [])
 
 
 def gen(rng, depth=0):
