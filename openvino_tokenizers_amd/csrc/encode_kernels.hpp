@@ -1468,13 +1468,12 @@ __device__ __forceinline__ int32_t stage_get_t(const EncodeWork& w, int pos) {
     return w.stage[pos];
 }
 // The flat form of a work item (round 5; RaggedSink): the item's four rows nearly always lie back to back in the staging buffer (one
-// wave of the lookup kernel staged them), and their ids back to back in the output.  So the item is ONE stretch of up to 1 024 staging
-// entries: every lane takes eight of them (four when they are i32) with one 16-byte load, the valid ones are squeezed through an LDS
-// buffer (a prefix sum over the lanes' counts), and leave 16 bytes per lane and store.  A row at a time -- a lane per entry, three
+// wave of the lookup kernel staged them), and their ids back to back in the output.  So the item is ONE stretch of staging entries,
+// worked through 512 (u16) or 256 (i32) at a time: every lane takes eight (four) of them with one 16-byte load, the valid ones are
+// squeezed through an LDS buffer (a prefix sum over the lanes' counts), and leave 16 bytes per lane and store.  A row at a time -- a lane per entry, three
 // 2-byte loads, a ballot and a 4-byte store per lane for a row of 112 ids -- cost 60 instructions per row; this costs about as much
 // per FOUR rows (compact_kernel 7.0 M -> see DESIGN 6 quad-cycles of a config-2 step's 45 M).
-constexpr int kFlatLoads = 2;                       // 16-byte loads per lane and item
-constexpr int kFlatIds = kFlatLoads * kWave * 8;    // ids the LDS buffer holds
+constexpr int kFlatIds = kWave * 8;    // ids the LDS buffer holds: one 16-byte load per lane of 2-byte entries
 struct __attribute__((packed, aligned(1))) FlatBytes16 { uint32_t d[4]; };
 template <bool S16>
 __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSink& sink, int32_t* buf, const int (&cnt)[4], const int (&o)[4],
@@ -1483,58 +1482,58 @@ __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSi
     const int l = lane_id();
     const int total_used = used[0] + used[1] + used[2] + used[3];
     if (used[0] < 0 || used[1] < 0 || used[2] < 0 || used[3] < 0 || base[1] != base[0] + used[0] || base[2] != base[1] + used[1] ||
-        base[3] != base[2] + used[2] || total_used > kFlatLoads * kWave * E)
+        base[3] != base[2] + used[2])
         return false;
     if (l < 4) {
         const int oo = l == 0 ? o[0] : (l == 1 ? o[1] : (l == 2 ? o[2] : o[3])), cc = l == 0 ? cnt[0] : (l == 1 ? cnt[1] : (l == 2 ? cnt[2] : cnt[3]));
         sink.row(row0 + l, oo, oo + cc);
     }
     const uint8_t* stage_bytes = reinterpret_cast<const uint8_t*>(w.stage) + (long long)base[0] * (S16 ? 2 : 4);
-    FlatBytes16 v[kFlatLoads];
-#pragma unroll
-    for (int k = 0; k < kFlatLoads; ++k) {   // (both loads leave before anything is looked at)
-        const int idx = (k * kWave + l) * E;
-        v[k] = FlatBytes16{{0u, 0u, 0u, 0u}};
-        if (idx < total_used) v[k] = *reinterpret_cast<const FlatBytes16*>(stage_bytes + idx * (S16 ? 2 : 4));   // (may read up to 14 bytes behind the
-                                                                                                                // stretch: the buffer has the slack)
-    }
-    int total = 0;
-#pragma unroll
-    for (int k = 0; k < kFlatLoads; ++k) {
-        const int idx = (k * kWave + l) * E;
-        if (k * kWave * E >= total_used) break;   // (wave-uniform)
-        const int n_here = total_used - idx;      // entries of the lane that exist (<= 0: none)
+    int32_t* out = sink.ids + o[0];
+    // the stretch in steps of 64 x 16 bytes (rows of any length: a row of 8 KB is a dozen steps); the next step's load leaves before
+    // this step's entries are looked at
+    auto fetch = [&](int off) -> FlatBytes16 {
+        const int idx = off + l * E;
+        if (idx < total_used) return *reinterpret_cast<const FlatBytes16*>(stage_bytes + idx * (S16 ? 2 : 4));   // (may read up to 14 bytes behind
+                                                                                                                // the stretch: the buffer has the slack)
+        return FlatBytes16{{0u, 0u, 0u, 0u}};
+    };
+    FlatBytes16 v = fetch(0);
+    for (int off = 0; off < total_used; off += kWave * E) {
+        const FlatBytes16 nxt = fetch(off + kWave * E);
+        const int n_here = total_used - (off + l * E);   // entries of the lane that exist (<= 0: none)
         int32_t e[E];
         uint32_t valid = 0;
 #pragma unroll
         for (int i = 0; i < E; ++i) {
             if (S16) {
-                const uint32_t x = (v[k].d[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const uint32_t x = (v.d[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
                 e[i] = int32_t(x);
                 if (i < n_here && x != 0xFFFFu) valid |= 1u << i;
             } else {
-                e[i] = int32_t(v[k].d[i]);
+                e[i] = int32_t(v.d[i]);
                 if (i < n_here && e[i] != kEmptyId) valid |= 1u << i;
             }
         }
         const int c = __popc(valid);
         const int incl = wave_incl_sum(c);
-        int at = total + incl - c;
+        int at = incl - c;
 #pragma unroll
         for (int i = 0; i < E; ++i)
             if ((valid >> i) & 1u) buf[at++] = e[i];
-        total += wave_readlane(incl, kWave - 1);
-    }
-    wave_sync();
-    int32_t* out = sink.ids + o[0];
-    for (int t = 4 * l; t < total; t += 4 * kWave) {
-        if (t + 4 <= total) {
-            *reinterpret_cast<FlatBytes16*>(out + t) = *reinterpret_cast<const FlatBytes16*>(buf + t);
-        } else {
-            for (int i = t; i < total; ++i) out[i] = buf[i];
+        const int total = wave_readlane(incl, kWave - 1);
+        wave_sync();
+        for (int t = 4 * l; t < total; t += 4 * kWave) {
+            if (t + 4 <= total) {
+                *reinterpret_cast<FlatBytes16*>(out + t) = *reinterpret_cast<const FlatBytes16*>(buf + t);
+            } else {
+                for (int i = t; i < total; ++i) out[i] = buf[i];
+            }
         }
+        out += total;
+        v = nxt;
+        wave_sync();   // (the buffer is the next step's)
     }
-    wave_sync();   // (the buffer is the next item's)
     return true;
 }
 
