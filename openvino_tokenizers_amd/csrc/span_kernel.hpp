@@ -538,9 +538,10 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
             const int b_begin = chain_sb + pos, b_wpos = ex0 + pos;
             const char* slots = reinterpret_cast<const char*>(T.pieces.slots);
             const uint32_t slot_shift = T.pieces.shift - 5u;   // (slot index x 32 bytes: a table has at most 2^27 slots)
-            auto fetch = [&](int jb) -> SpanProbe {
+            // The probe of list entry j (an index behind the list's end finds a piece of no bytes: the sentinel entries).
+            auto fetch_at = [&](int j_raw) -> SpanProbe {
                 SpanProbe q;
-                const int j = jb + l < np ? jb + l : np;
+                const int j = j_raw < np ? j_raw : np;
                 const uint32_t pp = reinterpret_cast<const Bytes4*>(sw.pstart + j)->v;
                 if (BERT) {
                     q.ps = int(pp & kSpanPosMask);
@@ -562,21 +563,20 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 q.p = e[1];
                 return q;
             };
-            auto resolve = [&](const SpanProbe& q, int jb) {
+            const bool packed6 = BERT && T.pieces.packed6 != 0;   // (the word memo: six u16 ids per entry; wave-uniform)
+            // hit or miss, the ids a hit brings, the staging entries the piece takes
+            auto classify = [&](const SpanProbe& q, bool& hit, int& cnt_ids, int& need) {
                 const bool valid = q.plen >= 1;
                 uint32_t xk = (q.k.x ^ q.a) | (q.k.y ^ q.b) | (q.k.z ^ q.c) | (q.k.w ^ q.d);
 #ifndef OVTK_SIMT_EMULATOR
                 asm volatile("" : "+v"(xk));   // (one compare, not four: memo_resolve)
 #endif
                 const uint32_t c0 = q.p.w ^ piece_tag(q.mix, 0);
-                const bool packed6 = BERT && T.pieces.packed6 != 0;   // (the word memo: six u16 ids per entry; wave-uniform)
-                const bool hit = valid && q.plen <= kPieceKeyBytes && xk == 0u && c0 <= uint32_t(packed6 ? kPieceMaxIds6 : kPieceMaxIds);
-                const int cnt_ids = hit ? int(c0) : 0;
-                const int need = hit ? cnt_ids : (valid ? q.plen + SL : 0);
-                const int v = need | (cnt_ids << 16);
-                const int s_incl = wave_incl_sum(v);
-                const int s_excl = s_incl - v;
-                const int at = cursor + (s_excl & 0xFFFF);
+                hit = valid && q.plen <= kPieceKeyBytes && xk == 0u && c0 <= uint32_t(packed6 ? kPieceMaxIds6 : kPieceMaxIds);
+                cnt_ids = hit ? int(c0) : 0;
+                need = hit ? cnt_ids : (valid ? q.plen + SL : 0);
+            };
+            auto put_ids = [&](const SpanProbe& q, bool hit, int cnt_ids, int at) {
                 if (hit && packed6) {
                     const uint32_t i0 = q.p.x & 0xFFFFu, i1 = q.p.x >> 16, i2 = q.p.y & 0xFFFFu, i3 = q.p.y >> 16, i4 = q.p.z & 0xFFFFu, i5 = q.p.z >> 16;
                     if (S16) {
@@ -613,6 +613,19 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                         if (cnt_ids > 2) st32[2] = int32_t(q.p.z);
                     }
                 }
+            };
+            // (rounds of 128 pieces, two per lane, were measured in round 5 and lose: 60 registers of probes in flight cost a wave per SIMD;
+            // profiles/r05/experiments/two_pieces_per_lane.*)
+            {
+            auto resolve = [&](const SpanProbe& q, int jb) {
+                bool hit;
+                int cnt_ids, need;
+                classify(q, hit, cnt_ids, need);
+                const int v = need | (cnt_ids << 16);
+                const int s_incl = wave_incl_sum(v);
+                const int s_excl = s_incl - v;
+                const int at = cursor + (s_excl & 0xFFFF);
+                put_ids(q, hit, cnt_ids, at);
                 // a row whose first piece lies in this round: its records are the running sums at that piece (lane = row pulls them
                 // from lane = piece)
                 {
@@ -623,7 +636,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                         rec_cnt = emitted + int(sums >> 16);
                     }
                 }
-                const bool miss = valid && !hit;
+                const bool miss = q.plen >= 1 && !hit;
                 const unsigned long long mm = __ballot(miss);
                 if (mm) note_miss(miss, mm, at, b_begin + q.ps, q.plen, b_wpos + q.ps, q.a, q.b, q.c, q.d);
                 const uint32_t tot = uint32_t(wave_readlane(s_incl, kWave - 1));
@@ -632,15 +645,16 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
             };
             // (a fetch behind the list's end finds pieces of no bytes: inside the loop nothing is conditional, so that no wait for
             // "a load that may still be on its way" ends up in front of the next fetch)
-            SpanProbe qa = fetch(0);
+            SpanProbe qa = fetch_at(l);
             int jb = 0;
             for (; jb + kWave < np; jb += 2 * kWave) {
-                const SpanProbe qb = fetch(jb + kWave);
+                const SpanProbe qb = fetch_at(jb + kWave + l);
                 resolve(qa, jb);
-                qa = fetch(jb + 2 * kWave);
+                qa = fetch_at(jb + 2 * kWave + l);
                 resolve(qb, jb + kWave);
             }
             if (jb < np) resolve(qa, jb);
+            }
             if (BERT && rowfirst == np) {   // a row whose pieces in this block got no entry (blanks): its records are the sums behind the list
                 rec_stage = cursor;
                 rec_cnt = emitted;
