@@ -203,7 +203,13 @@ void launch(K kernel, dim3 grid, dim3 block, A... args) {
                     }
                     if (live && b.progress == before) {
                         std::fprintf(stderr, "emu: deadlock -- a collective was not reached by every lane "
-                                             "(block %u, %u fibers stuck)\n", bx, live);
+                                             "(block %u, %u fibers stuck; the first: thread", bx, live);
+                        for (unsigned t = 0, shown = 0; t < block.x && shown < 4; ++t)
+                            if (!b.fibers[t].done) {
+                                std::fprintf(stderr, " %u", t);
+                                ++shown;
+                            }
+                        std::fprintf(stderr, ")\n");
                         std::abort();
                     }
                 }
