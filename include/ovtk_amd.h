@@ -162,6 +162,7 @@ typedef struct ovtk_bpe_params {
     int byte_fallback;
     int64_t cache_capacity;
     int device;
+    int64_t memo_store;   /* entries of the handle's piece store (below): 0 = the library's default (ovtk_set_memo_store), < 0 = none */
 } ovtk_bpe_params;
 
 typedef struct ovtk_bpe ovtk_bpe;
@@ -181,9 +182,11 @@ int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned);
  * this library, not by cache_capacity: that attribute bounds the host memory of the reference's std::string cache, an entry
  * here is 64 bytes of HBM.  cache_capacity == 0 still means "no memo at all".  `entries`: capacity of the store of handles
  * created afterwards (default 1048576, and never more than four entries per vocabulary token; 0 = no store: the memo is then exactly the reference's cache_capacity entries).
- * A setting of the CALLING THREAD (the handles it creates afterwards); memory: 3 x 64 bytes per entry of capacity, rounded up to a
- * power of two (GPT-2: 64 MB, Llama-3: 128 MB), allocated and cleared at create; ovtk_bpe_store_entries reports a handle's count
- * and capacity (waits for the device). */
+ * The PROCESS-WIDE default for handles created afterwards on any thread (round 5; until then a setting of the calling thread, which a
+ * host that configures on one thread and creates on another never saw); a handle's own value: ovtk_bpe_params::memo_store /
+ * ovtk_wordpiece_params::memo_store.  Memory: 3 x 64 bytes per entry of capacity, rounded up to a power of two (GPT-2: 64 MB,
+ * Llama-3: 128 MB), allocated and cleared at create; ovtk_bpe_store_entries reports a handle's count and capacity (waits for the
+ * device). */
 int ovtk_set_memo_store(int64_t entries);
 int ovtk_bpe_store_entries(ovtk_bpe* h, int64_t* stored, int64_t* capacity);
 
@@ -275,6 +278,7 @@ typedef struct ovtk_wordpiece_params {
     int64_t suffix_indicator_len;
     int max_bytes_per_word;
     int device;
+    int64_t memo_store;   /* entries of the handle's word store (ovtk_wordpiece_encode_run): 0 = the library's default, < 0 = none */
 } ovtk_wordpiece_params;
 typedef struct ovtk_wordpiece ovtk_wordpiece;
 int ovtk_wordpiece_create(const ovtk_wordpiece_params* params, ovtk_wordpiece** out);

@@ -53,12 +53,12 @@ class BpeParams(C.Structure):
                 ("added_ids", C.c_void_p), ("unk_token", C.c_char_p), ("unk_token_len", C.c_int64),
                 ("fuse_unk", C.c_int), ("suffix_indicator", C.c_char_p), ("suffix_indicator_len", C.c_int64),
                 ("end_suffix", C.c_char_p), ("end_suffix_len", C.c_int64), ("byte_fallback", C.c_int),
-                ("cache_capacity", C.c_int64), ("device", C.c_int)]
+                ("cache_capacity", C.c_int64), ("device", C.c_int), ("memo_store", C.c_int64)]
 
 
 class WordpieceParams(C.Structure):
     _fields_ = [("vocab", Strings), ("suffix_indicator", C.c_char_p), ("suffix_indicator_len", C.c_int64),
-                ("max_bytes_per_word", C.c_int), ("device", C.c_int)]
+                ("max_bytes_per_word", C.c_int), ("device", C.c_int), ("memo_store", C.c_int64)]
 
 
 class VocabEncoderParams(C.Structure):

@@ -38,21 +38,24 @@ inline int use_device(int device) {
 
 inline StringsView view_of(const ovtk_strings& s) { return StringsView{s.begins, s.ends, s.chars, s.n}; }
 
-// Entries the piece store (tables.hpp) of the handles THIS THREAD creates from now on may take; 0: no store.  The reference's
-// attribute list has no room for it (cache_capacity keeps its meaning: 0 = no memo at all), so it is a setting of the creating
-// thread: a create on another thread never sees a value somebody else is in the middle of changing.
-inline int64_t& memo_store_entries() {
-    static thread_local int64_t v = 1048576;
+// Entries the piece store (tables.hpp) of the handles created from now on may take unless their create parameters say otherwise
+// (ovtk_bpe_params::memo_store); 0: no store.  The reference's attribute list has no room for it (cache_capacity keeps its meaning:
+// 0 = no memo at all).  Process-wide and atomic (as a thread_local it was silently ignored by handles created on
+// another thread than the one that set it).
+inline std::atomic<int64_t>& memo_store_entries() {
+    static std::atomic<int64_t> v{1048576};
     return v;
 }
+// what a create call's `memo_store` parameter means: 0 = the default above, < 0 = none
+inline int64_t resolve_memo_store(int64_t param) { return param == 0 ? memo_store_entries().load(std::memory_order_relaxed) : (param < 0 ? 0 : param); }
 // A handle's piece store: the table (zeroed), its room counter, the device view.  A piece's two candidate slots are the
 // halves of one 128-byte line and nothing is relocated on the device: the table is kept below a third full (an insert finds
 // its line taken a few times in a hundred then).  No more than a few entries per vocabulary token: a 3 000-token test vocabulary
 // does not need 32 MiB of table.
-inline int alloc_piece_store(DevBuf& table, DevBuf& room, int64_t vocab_n, bool narrow, PieceStoreDev& dev, int32_t& capacity) {
+inline int alloc_piece_store(DevBuf& table, DevBuf& room, int64_t vocab_n, bool narrow, PieceStoreDev& dev, int32_t& capacity, int64_t entries) {
     dev = PieceStoreDev{nullptr, 30, nullptr, 0};
     capacity = 0;
-    const int64_t want = std::min<int64_t>({memo_store_entries(), int64_t(1) << 22,
+    const int64_t want = std::min<int64_t>({entries, int64_t(1) << 22,
                                             std::max<int64_t>(8192, 4 * vocab_n)});
     if (want <= 0) return OVTK_OK;
     const uint32_t slots = std::max<uint32_t>(1024, pow2_at_least(uint64_t(want) * 3));
@@ -345,8 +348,12 @@ public:
         grid_ = grid_rows(device_, n_rows_, blocks_per_cu_);
         n_tiles_ = (n_rows_ + kRowTile - 1) / kRowTile;
         if (stage_twice_) stage_cap_ = std::min<int64_t>(stage_cap_ * 2, INT32_MAX - 1);
-        if (self_alloc_)  // every wave may leave one chunk partly unused
-            stage_cap_ = std::min<int64_t>(stage_cap_ + int64_t(grid_ * kWavesPerBlock + kShards) * kStageChunk, INT32_MAX - 1);
+        if (self_alloc_) {  // every wave may leave one chunk partly unused -- the waves that are LAUNCHED: lookup_rows_kernel's grid grows
+                           // beyond the persistent one when a wave would own more than 64 rows (rows_grid(); ADVICE r04: with the persistent
+                           // grid's slack a batch of a million short rows overflowed at its first attempt and ran twice)
+            const int64_t waves = std::max<int64_t>(int64_t(grid_) * kWavesPerBlock, (int64_t(n_rows_) + kWave - 1) / kWave);
+            stage_cap_ = std::min<int64_t>(stage_cap_ + (waves + kShards) * kStageChunk, INT32_MAX - 1);
+        }
         small_ = small_ok_ && self_alloc_ && fold_tail_ && n_rows_ <= kSmallRows && in_.strings.n_chars <= kSmallChars;
         return launch();
     }
@@ -365,6 +372,19 @@ public:
             if (front_check_)
                 if (int rc = front_check_()) return rc;
             const RunStatus& st = *ws_->host_status;
+            if (st.flags & kFlagDidNotRun) return set_error(OVTK_E_HIP, op_ + ": the call's last kernel did not run (an earlier launch failed)");
+            if (pending_clean_) {   // the one-launch kernel has run: it left the status block zeroed behind itself
+                ws_->clean_status = pending_clean_;
+                ws_->clean_bytes = pending_clean_bytes_;
+                ws_->clean_after_lease = ws_->lease_count;
+                pending_clean_ = nullptr;
+            }
+            if (pending_zeroed_) {   // compact_kernel has run: it zeroed the workspace's other status block
+                ws_->zeroed_status = pending_zeroed_;
+                ws_->zeroed_bytes = pending_zeroed_bytes_;
+                ws_->zeroed_after_lease = ws_->lease_count;
+                pending_zeroed_ = nullptr;
+            }
             if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
             if (st.flags & kFlagStageOverflow) {
                 const int64_t need = self_alloc_ ? stage_cap_ * 2 : int64_t(st.stage_need);  // the allocators do not know the total
@@ -464,11 +484,11 @@ private:
             // the kernel leaves the device-side status zeroed behind itself: the memset is for a workspace it has not seen
             if (ws.clean_status != w.status || ws.clean_bytes < status_bytes || ws.clean_after_lease + 1 != ws.lease_count)
                 OVTK_HIP(hipMemsetAsync(w.status, 0, status_bytes, s_));
-            ws.clean_status = w.status;
-            ws.clean_bytes = status_bytes;
-            ws.clean_after_lease = ws.lease_count;
+            ws.clean_status = nullptr;   // (clean again once this call's kernel has run: finish())
+            pending_clean_ = w.status;
+            pending_clean_bytes_ = status_bytes;
             std::memset(ws.host_status, 0, sizeof(RunStatus));  // the kernel fills the scalar fields and shard_count[0] only
-            ws.host_status->flags = kFlagStageOverflow;          // overwritten by the kernel; one that did not run leaves an error
+            ws.host_status->flags = kFlagDidNotRun;              // overwritten by the kernel; one that did not run leaves this (finish: OVTK_E_HIP)
             middle_(ws, d_in_, w, blocks);
             OVTK_HIP(hipEventRecord(ws.done, s_));
             return OVTK_OK;
@@ -488,7 +508,7 @@ private:
             OVTK_HIP(hipMemsetAsync(w.status, 0, status_bytes, s_));
         ws.zeroed_status = nullptr;   // (until this call's compact_kernel is on its way)
         std::memset(ws.host_status, 0, sizeof(RunStatus));   // compact_kernel fills the scalar fields and the shards' counts
-        ws.host_status->flags = kFlagStageOverflow;           // overwritten by the kernel; one that did not run leaves an error
+        ws.host_status->flags = kFlagDidNotRun;               // overwritten by the kernel; one that did not run leaves this (finish: OVTK_E_HIP)
         if (!self_alloc_)
             OVTK_LAUNCH(ws.marks, "prep_rows", prep_rows_kernel, std::min(grid_, kTicketBlocks), kBlockThreads, s_, d_in_, mul_, w);
         middle_(ws, d_in_, w, grid_);
@@ -507,9 +527,11 @@ private:
         else if (wire_.hdr) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<WireSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, wire_);
         else if (stage16_) OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<RaggedSink, true>), cgrid, kBlockThreads, s_, n_rows_, w, rsink);
         else OVTK_LAUNCH(ws.marks, "compact", (compact_kernel<RaggedSink, false>), cgrid, kBlockThreads, s_, n_rows_, w, rsink);
-        ws.zeroed_status = other;   // compact_kernel is launched: the other block will be clean for the next lease of this workspace
-        ws.zeroed_bytes = status_bytes;
-        ws.zeroed_after_lease = ws.lease_count;
+        // (the other status block is clean for the next lease of this workspace once this call's compact_kernel has RUN: noted in
+        // finish(), after the event -- ADVICE r04: noted here, a run that was dropped without finish(), or whose launch failed
+        // afterwards, left the next lease without its memset)
+        pending_zeroed_ = other;
+        pending_zeroed_bytes_ = status_bytes;
         OVTK_HIP(hipEventRecord(ws.done, s_));
         return OVTK_OK;
     }
@@ -533,6 +555,10 @@ private:
     bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
     bool small_ok_ = false, small_ = false;
     bool stage16_ = false, stage_twice_ = false;
+    const void* pending_zeroed_ = nullptr;
+    size_t pending_zeroed_bytes_ = 0;
+    const void* pending_clean_ = nullptr;
+    size_t pending_clean_bytes_ = 0;
     WireSink wire_{};
     DenseSink dense_{};
     bool dense_on_ = false;

@@ -97,7 +97,7 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
 // while encoding, up to cache_capacity pieces that take several tokens.  It is the parallel-machine form of the
 // reference's piece cache (bpe_tokenizer.cpp:197-205,331-338): the same pure function piece -> ids, so results never
 // depend on what was encoded before; only the time does.
-int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
+int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity, int64_t memo_store) {
     const int64_t V = vocab.n;
     if (V == 0) return OVTK_OK;
     const size_t nv = size_t(V);
@@ -131,7 +131,7 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity) {
     h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), room_mask, 0};
     h->memo_entries = host.stored;
     // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.
-    if (int rc = alloc_piece_store(h->store, h->store_room, V, h->narrow_ids, h->dev.store, h->store_capacity)) return rc;
+    if (int rc = alloc_piece_store(h->store, h->store_room, V, h->narrow_ids, h->dev.store, h->store_capacity, resolve_memo_store(memo_store))) return rc;
     return OVTK_OK;
 }
 }  // namespace
@@ -198,7 +198,7 @@ bool parse_special_pattern(const std::string& pat, std::vector<std::string>& tok
 extern "C" {
 
 const char* ovtk_last_error(void) { return last_error(); }
-int ovtk_abi_version(void) { return 1000; }
+int ovtk_abi_version(void) { return 1001; }   // (1001: ovtk_bpe_params / ovtk_wordpiece_params::memo_store, the dense / special encode calls)
 
 const char* ovtk_device_name(void) {
     static std::string name;
@@ -408,7 +408,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     // cache_capacity == 0 disables the reference's piece cache (bpe_tokenizer.cpp:331: size() < capacity); here it
     // disables the memo the same way.  Results are identical either way.
     if (p->cache_capacity != 0)
-        if (int rc = build_memo(h.get(), p->vocab, p->cache_capacity)) return rc;
+        if (int rc = build_memo(h.get(), p->vocab, p->cache_capacity, p->memo_store)) return rc;
     *out = h.release();
     return OVTK_OK;
 }
@@ -432,7 +432,7 @@ int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned) {
 
 int ovtk_set_memo_store(int64_t entries) {
     if (entries < 0 || entries > (int64_t(1) << 22)) return set_error(OVTK_E_ARG, "memo store: 0 (off) .. 4194304 entries");
-    memo_store_entries() = entries;
+    memo_store_entries().store(entries, std::memory_order_relaxed);
     return OVTK_OK;
 }
 
@@ -619,6 +619,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     // produced in device memory first -- the chain RegexSplit -> BPETokenizer inside one call; the piece offsets make
     // one round trip through HBM and the host waits once for their count.
     std::shared_ptr<WorkspaceLease> pieces_ws;
+    bool sparse_status = false;   // the split stage left a status block to look at when the run has finished
     ovtk_ragged_strings pieces{};
     if (split && !fusable(split)) {
         pieces_ws = std::make_shared<WorkspaceLease>(dev);
@@ -647,13 +648,15 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
             if (pf.enabled()) pf.begin("regex_split", s, sw.marks);
             if (split->mode == 1 && split->max_splits == -1)
                 hipLaunchKernelGGL(regex_sparse_kernel<true>, dim3(lane_grid), dim3(kBlockThreads), size_t(lay.total), s, d_in, split->regex,
-                                   &sw.status.as<RunStatus>()->n_out, (long long)cap, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
+                                   sw.status.as<RunStatus>(), (long long)cap, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
                                    sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>());
             else
                 hipLaunchKernelGGL(regex_sparse_kernel<false>, dim3(lane_grid), dim3(kBlockThreads), size_t(lay.total), s, d_in, split->regex,
-                                   &sw.status.as<RunStatus>()->n_out, (long long)cap, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
+                                   sw.status.as<RunStatus>(), (long long)cap, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
                                    sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>());
             if (pf.enabled()) pf.end(s, sw.marks);
+            OVTK_HIP(hipMemcpyAsync(sw.host_status, sw.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s));   // (read at finish)
+            sparse_status = true;
             n_pieces = cap;   // (the offsets index the whole buffers)
         } else if (int rc = split_on_device(split, sw, d_in, s, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(), sw.gen[2].as<int32_t>(),
                                             sw.gen[3].as<int32_t>(), nullptr, cap, &n_pieces))
@@ -775,12 +778,18 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                       : resident_blocks_per_cu(lookup_kernel<kFused>),
                            /*tail_in_middle=*/true);
     if (pieces_ws) r->also_settles(pieces_ws);
-    if (special_ws) {
-        r->also_settles(special_ws);
-        r->front_check([special_ws]() -> int {
-            const RunStatus& st = *special_ws->ws->host_status;
-            if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
-            if (st.flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "SpecialTokensSplit: more strings than the reference's capacity");
+    if (special_ws) r->also_settles(special_ws);
+    if (special_ws || sparse_status) {
+        std::shared_ptr<WorkspaceLease> sparse_ws = sparse_status ? pieces_ws : nullptr;
+        r->front_check([special_ws, sparse_ws]() -> int {
+            if (special_ws) {
+                const RunStatus& st = *special_ws->ws->host_status;
+                if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+                if (st.flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "SpecialTokensSplit: more strings than the reference's capacity");
+            }
+            if (sparse_ws && (sparse_ws->ws->host_status->flags & kFlagOutCapacity))
+                return set_error(OVTK_E_CAPACITY, "RegexSplit: the strings overlap -- their pieces need more room than the reference's n_chars + n_strings "
+                                                  "(regex_split.cpp:182)");
             return OVTK_OK;
         });
     }

@@ -168,7 +168,7 @@ int ovtk_wordpiece_create(const ovtk_wordpiece_params* p, ovtk_wordpiece** out) 
         h->memo = PieceTableDev{h->memo_buf.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), uint32_t(kRoomShards - 1), packed6 ? 1u : 0u};
         h->dev.memo = h->memo;
         // the words the fused path has to walk the tries for are filed in a store of the handle's own (tables.hpp "piece store")
-        if (int rc = alloc_piece_store(h->store, h->store_room, p->vocab.n, p->vocab.n <= 65535, h->dev.store, h->store_capacity)) return rc;
+        if (int rc = alloc_piece_store(h->store, h->store_room, p->vocab.n, p->vocab.n <= 65535, h->dev.store, h->store_capacity, resolve_memo_store(p->memo_store))) return rc;
     }
     *out = h.release();
     return OVTK_OK;

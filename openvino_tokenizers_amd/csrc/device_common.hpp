@@ -50,6 +50,7 @@ constexpr uint32_t kFlagScratchOverflow = 8u;   // exact kernel scratch pool too
 constexpr uint32_t kFlagOutCapacity = 16u;      // caller's output buffer too small
 constexpr uint32_t kFlagRange = 32u;            // an input offset left its buffer
 constexpr uint32_t kFlagExactOverflow = 64u;    // exact-path piece list too small
+constexpr uint32_t kFlagDidNotRun = 0x80000000u;  // host side only: what the pinned status block holds until compact_kernel has written it
 constexpr uint32_t kFlagTailPending = 128u;     // merge_kernel's folded tail left the exact pieces / row scan to separate launches
 
 __device__ __forceinline__ int lane_id() { return int(threadIdx.x) & (kWave - 1); }

@@ -217,9 +217,10 @@ __host__ __device__ inline RegexSparseLds regex_sparse_layout(int n_trans, int c
 // PLAIN: behaviour `isolate` without max_splits (what every tokenizer.json Split step of a BPE model asks for): a piece is stored
 // as it is found -- none of add_split's cases is compiled in.
 template <bool PLAIN>
-static __global__ __launch_bounds__(kBlockThreads) void regex_sparse_kernel(RowsIn in, RegexDev R, int* bump, long long capacity,
+static __global__ __launch_bounds__(kBlockThreads) void regex_sparse_kernel(RowsIn in, RegexDev R, RunStatus* status, long long capacity,
                                                                             int32_t* out_rb, int32_t* out_re, int32_t* out_begins,
                                                                             int32_t* out_ends) {
+    int* bump = &status->n_out;
     // dynamic LDS (regex_sparse_lds_bytes): transitions | ASCII classes | code-point index | code-point blocks -- whatever of it
     // fits; with two waves per SIMD (a lane per row) every table read is on the critical path, and a non-ASCII character is two
     // dependent ones
@@ -273,7 +274,11 @@ static __global__ __launch_bounds__(kBlockThreads) void regex_sparse_kernel(Rows
         if (l == 0 && total > 0) b0 = atomicAdd(bump, int(total < INT32_MAX ? total : INT32_MAX));
         b0 = wave_readlane(b0, 0);
         base = (long long)b0 + incl - cap;
-        if (b0 < 0 || (long long)b0 + total > capacity) bad = true;   // (overlapping strings can ask for more than n_chars + n_strings)
+        if (b0 < 0 || (long long)b0 + total > capacity) {   // (overlapping strings can ask for more than n_chars + n_strings)
+            // said as what it is (the rows' begin of -1 alone made the BPE stage report "offset outside tensor")
+            if (l == 0) atomicOr(&status->flags, kFlagOutCapacity);
+            bad = true;
+        }
     }
     if (!valid) return;
     if (bad) {
