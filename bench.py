@@ -296,11 +296,8 @@ class PipelineEncode(BpeEncode):
             return d_ids[:n].view(rows, int(width.value)), d_mask[:n].view(rows, int(width.value))
         return finish
 
-    def algo(self):
-        """The fused encode's algorithmic bytes + the dense outputs: 5 bytes per cell of input_ids / attention_mask."""
-        ks = sorted(self.n_out)
-        return float(np.mean([self.batches.n_chars[k] + 4 * self.n_out[k] + 16 * self.batches.rows + 5 * self.batches.rows * self.width.get(k, 0)
-                              for k in ks]))
+    # (algo(): the fused encode's algorithmic bytes, SURVEY 8d -- the roofline fields stay comparable with config 2's; the dense
+    # tensors are 5 bytes per cell of [rows, T] on top, written by compact_kernel<DenseSink>, not by the dominant kernel)
 
     def cpu_chain(self):
         from oracle import oracle as O
