@@ -35,6 +35,15 @@ const char kQwen2Pattern[] =
     "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
 const char kCl100kPattern[] =
     "'(?i:[sdmt]|ll|ve|re)|[^\\r\\n\\p{L}\\p{N}]?+\\p{L}++|\\p{N}{1,3}+| ?[^\\s\\p{L}\\p{N}]++[\\r\\n]*+|\\s++$|\\s*[\\r\\n]|\\s+(?!\\S)|\\s+";
+// Two patterns the compiled DFA runs for every caller but the fused encode, which has a scan for them (span_fam.hpp): o200k_base as
+// tiktoken and the tokenizer.json files of its family write it, and the last Split of DeepSeek-V3's tokenizer.json
+const char kO200kPattern[] =
+    "[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]*[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?|"
+    "[^\\r\\n\\p{L}\\p{N}]?[\\p{Lu}\\p{Lt}\\p{Lm}\\p{Lo}\\p{M}]+[\\p{Ll}\\p{Lm}\\p{Lo}\\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?|\\p{N}{1,3}|"
+    " ?[^\\s\\p{L}\\p{N}]+[\\r\\n/]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
+const char kDeepSeekV3Pattern[] =
+    "[!\"#$%&'()*+,\\-./:;<=>?@\\[\\\\\\]^_`{|}~][A-Za-z]+|[^\\r\\n\\p{L}\\p{P}\\p{S}]?[\\p{L}\\p{M}]+| ?[\\p{P}\\p{S}]+[\\r\\n]*|"
+    "\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
 // tokenizer_pipeline.py:392-426 (bert_whitespace_splitter / bert_keep_delimeters_splitter)
 const char kBertWhitespacePattern[] = "\\s+";
 const char kBertDelimitersPattern[] =
@@ -43,9 +52,9 @@ const char kBertDelimitersPattern[] =
 
 // Unicode property tables, one copy per device.
 struct UnicodeTables {
-    DevBuf index, blocks, flat;
+    DevBuf index, blocks, flat, cls4;
 };
-int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks, const uint8_t** flat = nullptr) {
+int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks, const uint8_t** flat = nullptr, const uint8_t** cls4 = nullptr) {
     static std::mutex mu;
     static std::map<int, std::unique_ptr<UnicodeTables>> per_device;
     std::lock_guard<std::mutex> lk(mu);
@@ -62,12 +71,25 @@ int unicode_tables(int device, const uint16_t** index, const uint8_t** blocks, c
             f[cp >> 2] |= uint8_t((nib & 3u) << (2 * (cp & 3u)));
         }
         if (int rc = fresh->flat.upload(f.data(), f.size())) return rc;
+        // four class bits per code point for the scans of span_fam.hpp (SplitDev::uc_cls4): General_Category folded to seven classes, white
+        // space from the \s bit of the table above
+        std::vector<uint8_t> gc;
+        unicode_general_categories(gc);
+        std::vector<uint8_t> c4(0x110000 / 2, 0);
+        for (uint32_t cp = 0; cp < 0x110000u; ++cp) {
+            const uint32_t b = kUcBlocks[size_t(kUcIndex[cp >> 7]) * 64 + ((cp & 127) >> 1)];
+            const uint32_t nib = (cp & 1) ? (b >> 4) : (b & 15u);
+            const uint32_t c = (nib & 3u) == kClsS ? kC4Space : uint32_t(kGcToC4[gc[cp]]);
+            c4[cp >> 1] |= uint8_t(c << (4 * (cp & 1u)));
+        }
+        if (int rc = fresh->cls4.upload(c4.data(), c4.size())) return rc;
         OVTK_HIP(hipStreamSynchronize(nullptr));
         t = std::move(fresh);
     }
     *index = t->index.as<uint16_t>();
     *blocks = t->blocks.as<uint8_t>();
     if (flat) *flat = t->flat.as<uint8_t>();
+    if (cls4) *cls4 = t->cls4.as<uint8_t>();
     return OVTK_OK;
 }
 
@@ -253,6 +275,8 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
     else if (eff == kCl100kPattern && h->mode == 1) { h->dev.kind = kSplitLlama3; h->dev.l3_tail_ws = 1; }
     else if (eff == kBertWhitespacePattern && h->mode <= 1) h->dev.kind = kSplitWhitespace;
     else if (eff == kBertDelimitersPattern && h->mode <= 1) h->dev.kind = kSplitBertPunct;
+    if (h->dev.kind == kSplitGeneral && h->mode == 1 && eff == kO200kPattern) h->dev.family = kFamO200k;
+    if (h->dev.kind == kSplitGeneral && h->mode == 1 && eff == kDeepSeekV3Pattern) h->dev.family = kFamDs3;
     if (h->dev.kind >= kSplitWhitespace && h->dev.kind != kSplitGeneral)
         // regex_split.cpp:244-284: "remove" drops the pieces flagged `invert`: the matches, or the gaps when invert is set
         h->dev.drop = h->mode == 0 ? (h->invert ? 2 : 1) : 0;
@@ -263,7 +287,7 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
     }
     if (int rc = use_device(p->device)) return rc;
     h->device = p->device;
-    if (int rc = unicode_tables(p->device, &h->dev.uc_index, &h->dev.uc_blocks, &h->dev.uc_flat)) return rc;
+    if (int rc = unicode_tables(p->device, &h->dev.uc_index, &h->dev.uc_blocks, &h->dev.uc_flat, &h->dev.uc_cls4)) return rc;
     if (h->dev.kind == kSplitGeneral) {
         int e = 0;
         e = e ? e : h->r_trans.upload(prog.trans.data(), prog.trans.size() * sizeof(uint16_t));
@@ -508,8 +532,12 @@ int split_on_device(const ovtk_regex_split* h, Workspace& ws, const RowsIn& d_in
 }
 
 // The split runs inside lookup_kernel (scanner -> pieces -> memo probe in one pass over the text).
-bool fusable(const ovtk_regex_split* split) {
-    return split->max_splits == -1 && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3);
+bool fusable(const ovtk_regex_split* split, const ovtk_bpe* bpe = nullptr) {
+    if (split->max_splits != -1) return false;
+    if (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3) return true;
+    // the families of span_fam.hpp: lookup_span_kernel scans them -- it probes the memo for every piece, a handle without one takes the
+    // compiled DFA like any other pattern
+    return split->dev.family != kFamNone && bpe && bpe->dev.pieces.slots;
 }
 
 // SpecialTokensSplit's passes into device buffers (count, offsets, write): launched on `s`, nobody waits.  The workspace's row_cnt /
@@ -621,7 +649,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     std::shared_ptr<WorkspaceLease> pieces_ws;
     bool sparse_status = false;   // the split stage left a status block to look at when the run has finished
     ovtk_ragged_strings pieces{};
-    if (split && !fusable(split)) {
+    if (split && !fusable(split, bpe)) {
         pieces_ws = std::make_shared<WorkspaceLease>(dev);
         Workspace& sw = *pieces_ws->ws;
         if (!sw.host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");
@@ -679,6 +707,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            [=](Workspace& ws, const RowsIn& d_in, const EncodeWork& w, int grid) {
                                const bool tickets = w.rows_per_ticket != 0;
                                const bool llama3 = split && split->dev.kind == kSplitLlama3;
+                               const int family = split ? split->dev.family : int(kFamNone);
                                if (w.small) {  // the whole call in one launch of one block
                                    const SplitDev sd = split ? split->dev : SplitDev{};
                                    const bool nar = bpe->narrow_ids;
@@ -688,6 +717,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
         else OVTK_LAUNCH(ws.marks, "encode_small", (encode_small_kernel<MODE, false>), grid, kBlockThreads, s, d_in, sd, T, w);    \
     } while (0)
                                    if (llama3) OVTK_SMALL(kFusedLlama3);
+                                   else if (family) OVTK_SMALL(kFusedSeq);
                                    else if (split) OVTK_SMALL(kFused);
                                    else OVTK_SMALL(kPieces);
 #undef OVTK_SMALL
@@ -713,6 +743,26 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    w2.only_pending = 1;
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
                                                T, w2);
+                               }
+                               else if (family && tickets)
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFusedSeq, true>), grid, kBlockThreads, s, d_in,
+                                               split->dev, T, w);
+                               else if (family) {
+                                   // DeepSeek-V3's pattern, o200k_base: the scan of span_fam.hpp on the span kernel's blocks; the rows it leaves
+                                   // (several strings, skipped ones) are matched literally, a lane per row's window
+                                   EncodeWork w1 = w;
+                                   const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
+                                   if (family == kFamDs3 && w1.stage16)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanDs3, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   else if (family == kFamDs3)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanDs3, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   else if (w1.stage16)
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanO200k, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   else
+                                       OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanO200k, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   EncodeWork w2 = w;
+                                   w2.only_pending = 1;
+                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedSeq>, grid, kBlockThreads, s, d_in, split->dev, T, w2);
                                }
                                else if (split && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFused, true>), grid, kBlockThreads, s, d_in,
@@ -769,6 +819,9 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                            },
                            /*self_alloc=*/true,
                            !split ? resident_blocks_per_cu(lookup_kernel<kPieces>)
+                                  : split->dev.family != kFamNone
+                                      ? (!row_tickets().load(std::memory_order_relaxed) ? resident_blocks_per_cu(lookup_span_kernel<kSpanO200k, false>)
+                                                                                        : resident_blocks_per_cu(lookup_kernel<kFusedSeq>))
                                   : split->dev.kind == kSplitLlama3
                                       ? (T.pieces.slots && !row_tickets().load(std::memory_order_relaxed)
                                              ? resident_blocks_per_cu(lookup_span_kernel<kSpanLlama3, false>)
@@ -812,7 +865,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
         });
     if (!row_tickets().load(std::memory_order_relaxed)) r->enable_small();
     if (bpe->stage16) r->enable_stage16();
-    if (split && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3) && T.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)
+    if (split && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3 || split->dev.family != kFamNone) && T.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)
     if (wire) r->output_to_wire(*wire);
     if (dense) r->output_dense(*dense);
     if (int rc = r->start()) return rc;

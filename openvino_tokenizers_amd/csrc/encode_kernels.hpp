@@ -522,7 +522,8 @@ __device__ __forceinline__ void lookup_batch(const BpeDev& T, RowState& st, cons
     st.emitted += __popcll(__ballot(c & 1)) + 2 * __popcll(__ballot(c & 2));
 }
 
-enum EncodeMode : int { kFused = 0, kPieces = 1, kFusedLlama3 = 2 };  // kFusedLlama3: kFused compiled for the Llama-3 scanner
+enum EncodeMode : int { kFused = 0, kPieces = 1, kFusedLlama3 = 2, kFusedSeq = 3 };  // kFusedLlama3: kFused compiled for the Llama-3 scanner;
+                                                                               // kFusedSeq: for the literal matchers of span_fam.hpp's families
 
 // Whole strings as pieces (kPieces mode, and skipped strings of the fused mode): cols [c_begin, c_end).
 __device__ __forceinline__ void lookup_whole_strings(const BpeDev& T, RowState& st, const EncodeWork& w, WaveMiss& mb,
@@ -702,7 +703,7 @@ __device__ __forceinline__ void lookup_body(const RowsIn& in, const SplitDev& sp
                 }
                 const int sb = h.simple ? h.sb : in.begins[col];
                 const int slen = h.simple ? h.slen : in.ends[col] - sb;
-                scan_string<MODE == kFusedLlama3>(
+                scan_string<(MODE == kFusedLlama3 ? kScanLlama3 : (MODE == kFusedSeq ? kScanFamLiteral : kScanGeneric))>(
                     ws, sp, in.chars + sb, slen, in.chars, in.chars + in.n_chars,
                     [&](int np, int c0, int w0, int skew) {
                         for (int jb = 0; jb < np; jb += kWave) {
@@ -1699,7 +1700,7 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
                 out_ends[o + count + idx] = (idx == max_splits) ? se : sb + e;
                 if (out_skips) out_skips[o + count + idx] = 0;
             };
-            scan_string<LLAMA3>(
+            scan_string<(LLAMA3 ? kScanLlama3 : kScanGeneric)>(
                 ws, sp, in.chars + sb, se - sb, in.chars, in.chars + in.n_chars,
                 [&](int np, int c0, int, int) {
                     for (int jb = 0; jb < np; jb += kWave) {

@@ -945,4 +945,10 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
     }
 }
 
+void unicode_general_categories(std::vector<uint8_t>& gc) {
+    gc.assign(0x110000, 0);
+    for (unsigned i = 0; i < kGcRanges; ++i)
+        for (unsigned cp = kGcStart[i]; cp < kGcStart[i + 1] && cp < 0x110000u; ++cp) gc[cp] = uint8_t(kGcValue[i]);
+}
+
 }  // namespace ovtk

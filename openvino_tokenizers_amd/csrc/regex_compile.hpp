@@ -56,4 +56,8 @@ struct RegexProgram {
 // 0, or OVTK_E_UNSUPPORTED with `err` naming what is outside the subset.
 int compile_regex(const std::string& pattern, RegexProgram& out, std::string& err);
 
+// General_Category of every code point, as its index in unicode_gc.inc's order (Cn Lu Ll Lt Lm Lo Mn Mc Me Nd Nl No Pc Pd Ps Pe Pi Pf Po
+// Sm Sc Sk So Zs Zl Zp Cc Cf Cs Co): gc[0x110000].  For the class table of span_fam.hpp's scans.
+void unicode_general_categories(std::vector<uint8_t>& gc);
+
 }  // namespace ovtk

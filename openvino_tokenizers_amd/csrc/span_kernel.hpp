@@ -28,6 +28,7 @@
 
 #include "encode_kernels.hpp"
 #include "span_l3.hpp"
+#include "span_fam.hpp"
 
 namespace ovtk {
 
@@ -90,7 +91,7 @@ __device__ __forceinline__ void span_load(const RowsIn& in, int sb, int blen, ui
 // The scans: the GPT-2 family and the Llama-3 family run their rules on bit masks (span_l3.hpp: span_flags_gpt2m, span_flags_l3 -- until
 // round 5 the GPT-2 family had a packed-byte form for ASCII blocks here, 3 % slower than the masks on the headline text and blind to
 // non-ASCII text); the BERT words keep the packed-byte form below.
-enum SpanScan : int { kSpanGpt2 = 0, kSpanGpt2Digits = 1, kSpanBertWords = 2, kSpanLlama3 = 3 };
+enum SpanScan : int { kSpanGpt2 = 0, kSpanGpt2Digits = 1, kSpanBertWords = 2, kSpanLlama3 = 3, kSpanDs3 = 4, kSpanO200k = 5 };
 // The BERT words of the fused WordPiece path (class_packed_starts with kSplitBertWords: `\s+` removed, then every delimiter
 // character -- bert_delimiter() below 0x80 -- isolated): a piece starts where white-space-ness changes, at every delimiter and
 // behind every delimiter; white-space pieces are dropped (`dropped`: bit k = byte 32 l + k is white space).  Nothing looks ahead,
@@ -213,6 +214,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
     constexpr bool DIGITS = SCAN == kSpanGpt2Digits;
     constexpr bool BERT = SCAN == kSpanBertWords;
     constexpr bool L3 = SCAN == kSpanLlama3;   // the Llama-3 family (span_l3.hpp)
+    constexpr int FAM = SCAN == kSpanDs3 ? int(kFamDs3) : (SCAN == kSpanO200k ? int(kFamO200k) : 0);   // DeepSeek-V3's pattern, o200k_base (span_fam.hpp)
     __shared__ SpanWave sw_all[kWavesPerBlock];
     __shared__ uint4 mask_tab[16];   // [n]: byte masks of the four key dwords of an n-byte piece (n = 0: nothing)
     const int l = lane_id();
@@ -391,6 +393,33 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                     }
                 }
 #endif
+            } else if constexpr (FAM != 0) {
+                uint32_t* fl_words = rs_words + kWave;
+                static_assert(kWave * 4 + kSpanFamScratch <= int(sizeof(SpanWave::pstart)), "the scanners' scratch lives in the piece list's room");
+                const bool covered = FAM == kFamDs3 ? span_flags_ds3(xa, rs, vm, text, fl_words, sp, at_end, b_len, fl, lim)
+                                                    : span_flags_o200k(xa, rs, vm, text, fl_words, sp, at_end, b_len, fl, lim);
+                if (!covered) span_flags_fam_literal<FAM>(rs_words, fl_words, text, sp, at_end, b_len, fl, lim);
+#ifdef OVTK_SIMT_EMULATOR
+                else {   // the emulator build checks the algebra against the literal matcher on every block
+                    uint32_t fl0 = 0;
+                    int lim0 = 0;
+                    span_flags_fam_literal<FAM>(rs_words, fl_words, text, sp, at_end, b_len, fl0, lim0);
+                    const int dk = lim - kSpanLane * l;
+                    const uint32_t below = dk >= kSpanLane ? ~0u : (dk <= 0 ? 0u : ((1u << dk) - 1u));
+                    const unsigned long long bad = __ballot(((fl ^ fl0) & below) != 0);
+                    if (bad || lim > lim0) {
+                        const int bl = bad ? __ffsll(bad) - 1 : 0;
+                        const uint32_t a = uint32_t(wave_readlane(int(fl), bl)), b = uint32_t(wave_readlane(int(fl0), bl));
+                        if (l == 0) {
+                            printf("span_flags of family %d differ from the literal matcher: b_len %d at_end %d und %d / %d lane %d flags %08x / %08x\n", FAM, b_len, int(at_end), lim, lim0, bl, a, b);
+                            printf("  text of the lane and its neighbours:");
+                            for (int i = (bl > 0 ? bl - 1 : 0) * 32; i < (bl + 2) * 32 && i < b_len; ++i) printf(" %02x", text[i]);
+                            printf("\n");
+                        }
+                        __builtin_trap();
+                    }
+                }
+#endif
             } else {
                 if constexpr (BERT) fast = span_flags_bert(xa, rs, vm, fl, dropped);
                 else span_flags_gpt2m<DIGITS>(xa, rs, vm, text, rs_words + kWave, sp, at_end, b_len, fl);   // (any text: the characters of a
@@ -503,7 +532,7 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 const uint8_t* row_text = in.chars + wave_readlane(h_sb, k);
                 bool drop1 = false;
                 int e = 0;
-                if (l == 0) e = BERT ? bert_match_end(sp, row_text, rlen, p, drop1) : (L3 ? llama3_match_end(sp, row_text, rlen, p) : gpt2_match_end(sp, row_text, rlen, p, DIGITS));
+                if (l == 0) e = BERT ? bert_match_end(sp, row_text, rlen, p, drop1) : (L3 ? llama3_match_end(sp, row_text, rlen, p) : (FAM != 0 ? fam_match_end<(FAM != 0 ? FAM : 1)>(sp, row_text, rlen, p) : gpt2_match_end(sp, row_text, rlen, p, DIGITS)));
                 e = wave_readlane(e, 0);
                 drop1 = wave_readlane(int(drop1), 0) != 0;
                 const int plen = e - p;

@@ -60,6 +60,10 @@ struct SplitDev {
     int32_t l3_digits1;        // 1: `\p{N}` -- every digit a piece (Qwen2) -- instead of `\p{N}{1,3}`
     int32_t l3_tail_ws;        // 1: `\s++$` in front of the white-space alternatives (tiktoken's cl100k_base): the white-space run
                                //    that ends the string is ONE piece, line breaks inside it or not
+    // kSplitGeneral with a pattern lookup_span_kernel has a scan for (span_fam.hpp: DeepSeek-V3's, o200k_base): the fused encode takes
+    // that scan, every other caller of the handle the compiled DFA
+    int32_t family;            // SpanFamily
+    const uint8_t* uc_cls4;    // [0x110000 / 2] four class bits per code point (fam_literal.hpp kC4*)
 };
 constexpr uint16_t kPieceDropped = 0x8000;  // flag in WaveScratch::pstart: the piece is not emitted
 constexpr uint16_t kPiecePosMask = 0x7FFF;
@@ -1159,6 +1163,10 @@ __device__ __forceinline__ bool class_packed_starts(WS& ws, const SplitDev& sp, 
     return true;
 }
 
+}  // namespace ovtk
+#include "fam_literal.hpp"
+namespace ovtk {
+
 // Scans string `str` (slen bytes) and hands complete pieces to the caller chunk by chunk.
 //   on_chunk(np, c0, w0, skew): pstart[0..np] (positions relative to c0, pstart[np] = end of the last piece)
 //                               describe np complete pieces; the LDS text covers them (string byte p at
@@ -1168,9 +1176,11 @@ __device__ __forceinline__ bool class_packed_starts(WS& ws, const SplitDev& sp, 
 //   on_long(b, e, dropped):     a piece of more than kChunk bytes, not staged in LDS.
 // [buf, buf_end): the chars tensor the string lies in (what may be read).
 // Wave-uniform; every lane must call it with the same arguments.
-// LLAMA3: the kernel is compiled for the Llama-3 pattern only / for every other pattern (the two families share no
-// scanner code, and either one alone fits the register budget of the lookup kernel).
-template <bool LLAMA3, class OnChunk, class OnLong>
+// SCANNER: the kernel is compiled for the Llama-3 pattern only (1) / for the GPT-2 family and the class patterns (0) -- the two share no
+// scanner code, and either one alone fits the register budget of the lookup kernel -- / for the families of span_fam.hpp, matched
+// literally by lane 0 (2: the rows lookup_span_kernel leaves to the generic kernel, calls of a few rows).
+constexpr int kScanGeneric = 0, kScanLlama3 = 1, kScanFamLiteral = 2;
+template <int SCANNER, class OnChunk, class OnLong>
 __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp, const uint8_t* str, int slen, const uint8_t* buf,
                                             const uint8_t* buf_end, OnChunk&& on_chunk, OnLong&& on_long) {
     const bool digits = sp.kind == kSplitGpt2Digits;
@@ -1194,7 +1204,29 @@ __device__ __forceinline__ void scan_string(WaveScratch& ws, const SplitDev& sp,
         // rank the starts of [c0, qlim) (window bytes [lo, hi)); c0 itself is a start by construction
         const int lo = c0 - w0, hi = qlim - w0;
         int np = 0;
-        if constexpr (LLAMA3) {
+        if constexpr (SCANNER == kScanFamLiteral) {
+            // lane 0 matches from the chunk start, as far as the pieces stay inside the staged text
+            int n_seq = 0, p = c0;
+            if (l == 0) {
+                while (p < slen && n_seq < kChunk) {
+                    const int e = sp.family == kFamDs3 ? ds3_match_end(sp, str, slen, p) : o200k_match_end(sp, str, slen, p);
+                    if (e > w1) break;
+                    ws.pstart[n_seq++] = uint16_t(p - c0);
+                    p = e;
+                }
+                ws.pstart[n_seq] = uint16_t(p - c0);
+                if (n_seq == 0) p = sp.family == kFamDs3 ? ds3_match_end(sp, str, slen, c0) : o200k_match_end(sp, str, slen, c0);  // a piece longer than the window
+            }
+            n_seq = wave_readlane(n_seq, 0);
+            p = wave_readlane(p, 0);
+            wave_sync();
+            if (n_seq) on_chunk(n_seq, c0, w0, skew);
+            else on_long(c0, p, false);
+            c0 = p;
+            (void)lo; (void)hi; (void)np; (void)digits;
+            continue;
+        }
+        if constexpr (SCANNER == kScanLlama3) {
             int und = 0;
             bool seq = false;
             // every lane its own 12 bytes (packed bytes); the windows that form does not cover: lane w = 64-byte word w (ballots)

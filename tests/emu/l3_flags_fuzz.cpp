@@ -15,7 +15,8 @@
 #include <random>
 #include <string>
 
-#include "span_l3.hpp"
+#include "span_fam.hpp"
+#include "unicode_gc.inc"
 #include "unicode_tables.inc"
 
 using namespace ovtk;
@@ -28,12 +29,13 @@ struct Case {
     uint32_t* flags;        // [64] out
     int* und;               // out
     int* covered;           // out: 0 = the algebra declined (odd)
-    int family;             // 0: the Llama-3 family (span_flags_l3), 1 / 2: the GPT-2 family (span_flags_gpt2m<false / true>)
+    int family;             // 0: the Llama-3 family (span_flags_l3), 1 / 2: the GPT-2 family (span_flags_gpt2m<false / true>),
+                            // 3: DeepSeek-V3's pattern (span_flags_ds3), 4: o200k_base (span_flags_o200k)
 };
 
 static __global__ void l3_case_kernel(Case c, SplitDev sp) {
     __shared__ uint32_t text_w[kWave * 8 + 16];
-    __shared__ uint32_t scratch[kSpanClassScratch / 4];
+    __shared__ uint32_t scratch[(kSpanFamScratch > kSpanClassScratch ? kSpanFamScratch : kSpanClassScratch) / 4];
     const int l = lane_id();
     uint32_t x[8];
     for (int j = 0; j < 8; ++j) {
@@ -48,7 +50,11 @@ static __global__ void l3_case_kernel(Case c, SplitDev sp) {
     uint32_t fl = 0;
     int und = 0;
     bool ok = true;
-    if (c.family == 0) {
+    if (c.family == 3) {
+        ok = span_flags_ds3(x, c.rs[l], vm, reinterpret_cast<const uint8_t*>(text_w), scratch, sp, c.at_end != 0, c.b_len, fl, und);
+    } else if (c.family == 4) {
+        ok = span_flags_o200k(x, c.rs[l], vm, reinterpret_cast<const uint8_t*>(text_w), scratch, sp, c.at_end != 0, c.b_len, fl, und);
+    } else if (c.family == 0) {
         ok = span_flags_l3(x, c.rs[l], vm, reinterpret_cast<const uint8_t*>(text_w), scratch, sp, c.at_end != 0, c.b_len, fl, und);
     } else {
         if (c.family == 1) span_flags_gpt2m<false>(x, c.rs[l], vm, reinterpret_cast<const uint8_t*>(text_w), scratch, sp, c.at_end != 0, c.b_len, fl);
@@ -62,7 +68,7 @@ static __global__ void l3_case_kernel(Case c, SplitDev sp) {
     }
 }
 
-static std::vector<uint8_t> g_flat;
+static std::vector<uint8_t> g_flat, g_cls4;
 static SplitDev make_split(int digits1, int tail_ws) {
     SplitDev sp{};
     sp.kind = kSplitLlama3;
@@ -77,6 +83,17 @@ static SplitDev make_split(int digits1, int tail_ws) {
         }
     }
     sp.uc_flat = g_flat.data();
+    if (g_cls4.empty()) {   // api_encode.cpp's unicode_tables(): General_Category folded to seven classes, white space from the \s bit
+        g_cls4.assign(0x110000 / 2, 0);
+        for (unsigned i = 0; i < kGcRanges; ++i)
+            for (unsigned cp = kGcStart[i]; cp < kGcStart[i + 1] && cp < 0x110000u; ++cp) {
+                const uint32_t b = kUcBlocks[size_t(kUcIndex[cp >> 7]) * 64 + ((cp & 127) >> 1)];
+                const uint32_t nib = (cp & 1) ? (b >> 4) : (b & 15u);
+                const uint32_t c = (nib & 3u) == kClsS ? kC4Space : uint32_t(kGcToC4[kGcValue[i]]);
+                g_cls4[cp >> 1] |= uint8_t(c << (4 * (cp & 1u)));
+            }
+    }
+    sp.uc_cls4 = g_cls4.data();
     sp.l3_digits1 = digits1;
     sp.l3_tail_ws = tail_ws;
     return sp;
@@ -92,8 +109,19 @@ static const char* kFrag[] = {
     "\xE6\x97\xA5\xE6\x9C\xAC\xE8\xAA\x9E", "\xE3\x81\xAE", "\xE3\x80\x82", "\xF0\x9F\x98\x80", "\xF0\x9F\x98\x80\xF0\x9F\x98\x81", "\xF0\x90\x90\x80", "\xE2\x84\xAA",
     "\xEF\xBC\x81", "\xD7\xA9\xD7\x9C\xD7\x95\xD7\x9D", "\xD8\xB3\xD9\x84\xD8\xA7\xD9\x85",
 };
+// what the families of span_fam.hpp tell apart and the others do not: case, marks (U+0301, U+20DD, U+0903), titlecase (U+01C5), modifier letters
+// (U+02B0), slashes behind line breaks, control and format characters, upper-case runs
+static const char* kFamFrag[] = {
+    "A", "B", "AB", "ABC", "HTTP", "Camel", "camelCase", "XMLHttpRequest", "iPhone", "aB", "Ab", "aBc", "ABc", "abC", "A1", "Z",
+    "\xCC\x81", "\xCC\x81\xCC\x81", "e\xCC\x81", "E\xCC\x81", "\xCC\x81" "a", "\xCC\x81" "A", "!\xCC\x81", "!!\xCC\x81", " \xCC\x81", "\xE2\x83\x9D", "\xE0\xA4\x83",
+    "\xC7\x85", "\xCA\xB0", "\xE6\x97\xA5", "\xE6\x97\xA5" "A", "A\xE6\x97\xA5", "A\xE6\x97\xA5" "B", "\xE6\x97\xA5" "Ab", "\xD0\x9F\xD1\x80", "\xD0\x9F\xD0\xA0", "\xD0\xBF\xD0\xA0",
+    "\xC3\x89", "\xC3\x89t\xC3\xA9", "\xCE\xA9", "'s", "'S", "'ll", "'LL", "A's", "a'T", "B'Re", "\xE6\x97\xA5's", "\xCC\x81's", "'\xCC\x81",
+    "/", "//", "\n/", "\n//", "!\n/", "*/\n/*", "/\n", "\n/\n", "\r\n/", "!\n/!\n/a", "*/", "/*",
+    "\x01", "\x7F", "\x1B[0m", "\xC2\xAD", "\xE2\x80\x8B", "\xE2\x80\x8D", "\xEF\xBB\xBF", "\xC2\x80", "\xF3\xA0\x80\x81",
+    "1a", "1A", "12ab", "a1", "\xC2\xAD" "a", "\xE2\x80\x8B" "B", "\x01" "a", "!a", "!ab", "!A", "!\xC3\xA9", "!a\xC3\xA9", "?b\xCC\x81", "#tag", "@user", "$x", "_id", "-v", "(a", " !a", "!!a", ".com",
+};
 // fragments the algebra does not cover (a non-ASCII \p{N}, U+017F) and broken UTF-8: rarer
-static const char* kOddFrag[] = {"\xC2\xB2", "\xD9\xA3", "\xEF\xBC\x91", "\xC5\xBF", "'\xC5\xBF", "\xC2\xBD"};
+static const char* kOddFrag[] = {"\xC2\xB2", "\xD9\xA3", "\xEF\xBC\x91", "\xC5\xBF", "'\xC5\xBF", "\xC2\xBD", "\xD9\xA3" "a", "a'\xC5\xBF"};
 static const char* kBadFrag[] = {"\x80", "\xBF\xBF", "\xC3", "\xE2\x82", "\xF0\x9F\x98", "\xFF", "\xC0\x80", "\xE2", "\xF8\x88\x80\x80"};
 
 struct Rng {
@@ -103,6 +131,7 @@ struct Rng {
     bool chance(int pct) { return below(100) < pct; }
 };
 
+static bool g_fam_frags = false;
 static std::string make_row(Rng& r, int target, int odd_pct, int bad_pct) {
     std::string s;
     const int style = r.below(8);
@@ -112,6 +141,8 @@ static std::string make_row(Rng& r, int target, int odd_pct, int bad_pct) {
         else if (style == 0) s += std::string(1 + r.below(40), "0123456789"[r.below(10)]);          // long digit runs
         else if (style == 1) s += std::string(1 + r.below(6), "\n\r \t"[r.below(4)]);               // white space of every kind
         else if (style == 2 && r.chance(50)) s += std::string(1 + r.below(70), " \n"[r.below(2)]);  // long runs
+        else if (style == 3 && r.chance(40)) s += std::string(1 + r.below(50), "ABCXYZ"[r.below(6)]);  // upper-case runs
+        else if (g_fam_frags && r.chance(55)) s += kFamFrag[r.below(sizeof kFamFrag / sizeof *kFamFrag)];
         else s += kFrag[r.below(sizeof kFrag / sizeof *kFrag)];
         if (style >= 5 && r.chance(60)) s += ' ';
     }
@@ -125,18 +156,27 @@ static void truth_starts(const SplitDev& sp, const std::string& s, int from, std
     const uint8_t* p = reinterpret_cast<const uint8_t*>(s.data());
     for (int q = from; q < int(s.size());) {
         is_start[q] = 1;
-        q = g_family == 0 ? llama3_match_end(sp, p, int(s.size()), q) : gpt2_match_end(sp, p, int(s.size()), q, g_family == 2);
+        q = g_family == 0 ? llama3_match_end(sp, p, int(s.size()), q)
+            : g_family == 3 ? ds3_match_end(sp, p, int(s.size()), q)
+            : g_family == 4 ? o200k_match_end(sp, p, int(s.size()), q)
+                            : gpt2_match_end(sp, p, int(s.size()), q, g_family == 2);
     }
 }
 
 int main(int argc, char** argv) {
     const int lo = argc > 1 ? atoi(argv[1]) : 0, hi = argc > 2 ? atoi(argv[2]) : 4, per_seed = argc > 3 ? atoi(argv[3]) : 300;
+    const int only = argc > 4 ? atoi(argv[4]) : -1;   // one family only (0..4)
     long long n_cases = 0, n_odd = 0, n_cut = 0, und_sum = 0;
     for (int seed = lo; seed < hi; ++seed) {
         Rng r(0x9E3779B97F4A7C15ull * uint64_t(seed + 1));
         for (int it = 0; it < per_seed; ++it) {
             const SplitDev sp = make_split(r.chance(25), r.chance(30));
-            g_family = r.below(3) == 0 ? 1 + r.below(2) : 0;   // a third of the cases: the GPT-2 family's mask form
+            {   // a quarter of the cases each: the GPT-2 family's mask form, DeepSeek-V3's pattern, o200k_base
+                const int pick = r.below(4);
+                g_family = pick == 0 ? 1 + r.below(2) : (pick == 1 ? 3 : (pick == 2 ? 4 : 0));
+                if (only >= 0) g_family = only;
+            }
+            g_fam_frags = g_family >= 3;
             const int odd_pct = r.chance(15) ? 3 : 0, bad_pct = r.chance(15) ? 4 : 0;
             // rows until the block is full (or, for a block that ends with its text, until a random length)
             const bool want_cut = r.chance(45);
