@@ -1269,8 +1269,8 @@ def main():
                  "rows_8192_bytes": "rows of ~8192 bytes: four to five sliding blocks of lookup_span_kernel per row",
                  "pattern_qwen2": "Qwen2's pattern (\\p{N} for \\p{N}{1,3}): the Llama-3 scanners with l3_digits1",
                  "pattern_cl100k": "tiktoken's cl100k_base pattern (possessive, \\s++$): the Llama-3 scanners with l3_tail_ws",
-                 "pattern_o200k": "o200k_base's pattern: the compiled DFA, one pass inside the fused encode (regex_sparse_kernel), lookup_kernel<kPieces> behind it",
-                 "pattern_deepseek_v3": "DeepSeek-V3's main pattern: the compiled DFA as for o200k"}
+                 "pattern_o200k": "o200k_base's pattern: its rules on bit masks in lookup_span_kernel<kSpanO200k> (csrc/span_fam.hpp; until round 5 the compiled DFA)",
+                 "pattern_deepseek_v3": "DeepSeek-V3's main pattern: lookup_span_kernel<kSpanDs3> (csrc/span_fam.hpp)"}
         for name, kw in legs:
             s_args = argparse.Namespace(**vars(args))
             nbytes = kw.get("nbytes", args.bytes)

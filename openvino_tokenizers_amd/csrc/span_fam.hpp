@@ -218,7 +218,7 @@ __device__ __forceinline__ int fam_und(const FamCtx& cx, uint32_t W, uint32_t ho
     if (nonw_end < b_len - 3 && nonw_end + 1 < und) und = nonw_end + 1;
     if (__ballot(hold != 0)) {
         const int nonh_end = end_of_last(((cx.V & ~hold) | row_last) & below);
-        if (nonh_end < b_len - 3 && nonh_end < und) und = nonh_end;
+        if (nonh_end < b_len - 3 && nonh_end < und) und = nonh_end > 1 ? nonh_end : 1;   // (the block's first byte starts a piece whatever follows)
     }
     return und;
 }
@@ -418,7 +418,7 @@ __device__ __forceinline__ void span_flags_fam_literal(const uint32_t* rs_words,
                 }
                 und0 = b_len > 8 ? b_len - 8 : 0;
                 if (nonw_end < slen - 3 && p + nonw_end + 1 < und0) und0 = p + nonw_end + 1;
-                if (FAM == kFamO200k && nonu_end < slen - 3 && p + nonu_end < und0) und0 = p + nonu_end;
+                if (FAM == kFamO200k && nonu_end < slen - 3 && p + nonu_end < und0) und0 = p + nonu_end > 1 ? p + nonu_end : 1;
             }
             p = e;
         }

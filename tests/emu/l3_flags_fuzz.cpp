@@ -241,7 +241,7 @@ int main(int argc, char** argv) {
                 ++n_cut;
                 und_sum += und;
             }
-            bool bad = und > b_len || (at_end && und != b_len) || und < 0;
+            bool bad = und > b_len || (at_end && und != b_len) || und < 1;   // (the first byte is always decided: the kernel counts on it)
             int where = -1;
             for (int q = 0; q < und && q < b_len && !bad; ++q) {
                 const int got = (flags[q >> 5] >> (q & 31)) & 1u;

@@ -22,6 +22,10 @@ from tools.make_tokenizers import load_tokenizer  # noqa: E402
 
 L3_FRAG = ["\n", "\n\n", "\r\n", " \n", "\n    ", "\n\t", "123", "1234567", "12345678901234567890123456789012345", "'S", "'LL", "I'M", "they'Re", "\u00a0", "\u3000", "\u2028",
            "x²", "١٢٣", "ſ", "'ſ", "!\n\n", "...\n", "}\n\n", " \n \n  \n"]
+# what DeepSeek-V3's pattern and o200k_base tell apart (span_fam.hpp): case, marks, slashes behind line breaks, control characters
+FAM_FRAG = ["A", "AB", "HTTP", "Camel", "camelCase", "XMLHttpRequest", "aB", "ABc", "\u0301", "e\u0301", "!\u0301", "!!\u0301", " \u0301", "\u20dd", "\u01c5", "\u02b0",
+            "日A", "A日B", "ПР", "пР", "A's", "a'T", "B'Re", "it's's", "\n/", "!\n/", "*/\n/*", "!\n/!\n/a", "\x01", "\x7f", "\u00ad", "\u200b", "1a", "12ab", "!ab", "!abé",
+            "#tag", "@user", "_id", ".com", " !a", "!!a", "A" * 40, "ABCDEFGH" * 300]
 FRAG = ["the", "token", "izer", " ", " ", " ", "  ", "\n", "\t", "a", "x", ",", ".", "!?", "don't", "we'll", "'", "'s", "I'm", "12", "2024", "1", "a1b2", "--", "(", ")",
         "naïve", "straße", "日本語", "Ωμέγα", "😀", "hello", "world", "un", "affable", "e.g.", " , ", "q" * 17, "word" * 5]
 
@@ -85,6 +89,14 @@ def main():
             fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**llama3.attrs, lib=lib))
             for call in range(2):
                 check(ref, fused.evaluate(dev3 + [np.frombuffer(pattern.encode(), np.uint8)], llama3.consts), f"seed {seed} {name} call {call}")
+        inputs4 = rows_of(rows(rng, int(rng.integers(300, 700)), FRAG + L3_FRAG + FAM_FRAG))
+        dev4 = [torch.as_tensor(a, device="cuda") for a in inputs4]
+        for name in ("deepseek-v3", "o200k"):
+            pattern = MODEL_PATTERNS[name]
+            ref = llama3.oracle()(*O.RegexSplit(pattern, "isolate")(*inputs4)[:5])
+            fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**llama3.attrs, lib=lib))
+            for call in range(2):
+                check(ref, fused.evaluate(dev4 + [np.frombuffer(pattern.encode(), np.uint8)], llama3.consts), f"seed {seed} {name} call {call}")
         print(f"seed {seed}: {len(inputs[0])} + {len(inputs3[0])} rows, {len(inputs[4])} + {len(inputs3[4])} bytes ok", flush=True)
 
 
