@@ -649,7 +649,10 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     std::shared_ptr<WorkspaceLease> pieces_ws;
     bool sparse_status = false;   // the split stage left a status block to look at when the run has finished
     ovtk_ragged_strings pieces{};
-    if (split && !fusable(split, bpe)) {
+    // (a family of span_fam.hpp behind other splits -- DeepSeek-V3's three in a row -- gets rows of several strings: the span kernel
+    // leaves those to the literal matcher, a lane per row, and the compiled DFA is the faster of the two for them)
+    const bool one_string_rows = special != nullptr || in->strings.n == in->n_rows;
+    if (split && (!fusable(split, bpe) || (split->dev.family != kFamNone && !one_string_rows))) {
         pieces_ws = std::make_shared<WorkspaceLease>(dev);
         Workspace& sw = *pieces_ws->ws;
         if (!sw.host_status) return set_error(OVTK_E_HIP, "pinned host allocation failed");

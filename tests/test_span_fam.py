@@ -19,7 +19,9 @@ import numpy as np
 import pytest
 
 from tests.test_span_kernel import _filler, fused_vs_oracle, rows_of
-from tests.util import BpeTok
+from openvino_tokenizers_amd.ops import BPETokenizer, FusedSplitBPE, RegexSplit
+from oracle import oracle as O
+from tests.util import BpeTok, assert_same
 from tools.workloads import MODEL_PATTERNS, TextModel, ragged_rows
 
 ROOT = Path(__file__).resolve().parent.parent
@@ -169,3 +171,24 @@ def test_a_handle_without_a_memo_takes_the_compiled_dfa(backend):
     rng = np.random.default_rng(35)
     rows = _random_rows(rng, 300, 20)
     fused_vs_oracle(backend, tok0, rows_of(rows), pattern=MODEL_PATTERNS["o200k"], what="o200k without a memo")
+
+
+def test_deepseek_v3_three_splits_in_a_row(backend):
+    """DeepSeek-V3's pre-tokenizer is a Sequence of three `Split`s (tokenizer.json: digits of 1-3, CJK runs, the main pattern; each
+    `isolated`), i.e. three RegexSplit nodes (tokenizer_pipeline.py:392-457 builds one per Split): the third one's rows hold SEVERAL
+    strings each, which the span kernel leaves to the compiled DFA (api_encode.cpp start_encode).  Oracle: the same three in a row."""
+    tok = BpeTok.load("llama3_small")
+    pats = [r"\p{N}{1,3}", "[一-龥぀-ゟ゠-ヿ]+", MODEL_PATTERNS["deepseek-v3"]]
+    rng = np.random.default_rng(36)
+    rows = [s.encode() for s in CRAFTED] + _random_rows(rng, 300, 30)
+    inputs = rows_of(rows)
+    ref = [np.asarray(x) for x in inputs]
+    got = backend.data(inputs)
+    for pat in pats[:2]:
+        ref = list(O.RegexSplit(pat, "isolate")(*ref[:5])[:5])
+        got = list(RegexSplit("isolate", lib=backend.lib).evaluate(list(got[:5]) + [np.frombuffer(pat.encode(), np.uint8)])[:5])
+    assert len(ref[2]) > len(rows)          # rows of several strings reach the third split
+    ref_ids = tok.oracle()(*O.RegexSplit(pats[2], "isolate")(*ref)[:5])
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    got_ids = fused.evaluate(list(got) + [np.frombuffer(pats[2].encode(), np.uint8)], tok.consts)
+    assert_same(ref_ids, got_ids, backend.host, "DeepSeek-V3: three splits in a row")
