@@ -153,7 +153,7 @@ class EncodeWorkload:
 
 class BpeEncode(EncodeWorkload):
     def __init__(self, args, lib, dev, rank, tokenizer, kind, rows, nbytes, seed0, no_memo=False, n_batches=None, cache_capacity=None,
-                 pattern=None, model=None):
+                 pattern=None, model=None, memo_learn=None):
         self.tok = BpeTok.load(tokenizer)
         if pattern:   # the same tables behind another model's split pattern (tools/workloads.py MODEL_PATTERNS)
             self.tok.pattern = pattern
@@ -167,18 +167,25 @@ class BpeEncode(EncodeWorkload):
         elif cache_capacity is not None:
             attrs["cache_capacity"] = cache_capacity
         self.cache_capacity = attrs.get("cache_capacity", 20000)
-        self.bpe = BPETokenizer(**attrs, device=dev.index, lib=lib)
+        # ovtk_bpe_params::memo_learn (include/ovtk_amd.h): 0 = the library's default, the first level learns up to
+        # max(cache_capacity, the store's capacity) pieces; -1 = exactly cache_capacity, the reference's count
+        self.memo_learn = int(memo_learn if memo_learn is not None else (getattr(args, "memo_learn", 0) or 0))
+        self.bpe = BPETokenizer(**attrs, device=dev.index, lib=lib, memo_learn=self.memo_learn)
         self.split._ensure(self.tok.pattern_u8())
         self.bpe._ensure(self.batches.d[0] + self.tok.consts)
         self.vocab = len(self.tok.vocab)
 
     def memo(self):
-        """Entries of the piece memo: from the vocabulary at create / learned from the text since (<= cache_capacity)."""
+        """Entries of the piece memo: from the vocabulary at create / learned from the text since (memo_learn says how many at most)."""
         fixed, learned = C.c_int64(), C.c_int64()
         L.check(self.lib, self.lib.ovtk_bpe_memo_entries(self.bpe._h, C.byref(fixed), C.byref(learned)))
         stored, cap = C.c_int64(), C.c_int64()
         L.check(self.lib, self.lib.ovtk_bpe_store_entries(self.bpe._h, C.byref(stored), C.byref(cap)))
         return {"fixed": int(fixed.value), "learned": int(learned.value), "cache_capacity": int(self.cache_capacity),
+                "memo_learn": self.memo_learn,
+                "note": ("memo_learn = 0, the library's default: the first level learns up to max(cache_capacity, the store's capacity) pieces of at most 15 bytes "
+                         "and 6 ids (3 when an id needs more than 16 bits); -1: exactly cache_capacity pieces, the reference's count -- the "
+                         "stress leg `reference_cache_count` runs the headline text that way (include/ovtk_amd.h ovtk_bpe_params)"),
                 "store": {"entries": int(stored.value), "capacity": int(cap.value),
                           "note": "second level, probed by merge_kernel only: pieces it had to merge once (include/ovtk_amd.h ovtk_set_memo_store)"}}
 
@@ -362,7 +369,7 @@ def make_workload(args, lib, dev, rank):
         from tools.workloads import MODEL_PATTERNS
         w = BpeEncode(args, lib, dev, rank, args.tokenizer, args.text, args.rows, args.bytes, 1000, no_memo=args.no_memo,
                       pattern=MODEL_PATTERNS.get(args.pattern),
-                      cache_capacity=getattr(args, "cache_capacity", None))
+                      cache_capacity=getattr(args, "cache_capacity", None), memo_learn=getattr(args, "memo_learn", None))
         w.metric = "input MB/s encoded (GPT-2 BPE, 512-byte strings)"
         w.dominant_hint = "lookup_span"
         w.workload = (f"config 2: GPT-2-shaped byte-level BPE (V=50257, 50000 merges, trained in-process), {args.rows} x "
@@ -1000,6 +1007,7 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="consecutive batches alternate between this many HIP streams (two-half calls)")
     ap.add_argument("--sync", action="store_true", help="one blocking ovtk_encode_run per step (no launch/complete overlap)")
     ap.add_argument("--force-exchange", action="store_true", help="N = 1: still run the exchange, in a one-rank RCCL group (debug)")
+    ap.add_argument("--memo-learn", type=int, default=None, help="config 2 / 4: ovtk_bpe_params::memo_learn (0 = the library's default, -1 = exactly cache_capacity)")
     ap.add_argument("--cache-capacity", type=int, default=None, help="config 2: the BPETokenizer attribute (debug; default: the converter's 20000)")
     ap.add_argument("--memo-store", type=int, default=-1, help="ovtk_set_memo_store(n) before the tokenizer is built (debug; default: the library's)")
     ap.add_argument("--e2e-child", action="store_true", help="internal: run only the end_to_end leg and print its JSON object")
@@ -1247,7 +1255,8 @@ def main():
         stress = {}
         from tools.workloads import MODEL_PATTERNS
         legs = [("uniform_text", dict(kind="uniform")), ("no_memo", dict(kind="zipf", no_memo=True)),
-                ("fixed_memo_only", dict(kind="zipf", cache_capacity=1)), ("mixed_script_text", dict(kind="mixed")),
+                ("fixed_memo_only", dict(kind="zipf", cache_capacity=1, memo_learn=-1)),
+                ("reference_cache_count", dict(kind="zipf", memo_learn=-1)), ("mixed_script_text", dict(kind="mixed")),
                 # first sight of every text: 20 distinct batches, none encoded before -- memo and store learn as they go
                 ("first_sight", dict(kind="zipf", fresh=True)),
                 # rows longer than a scan block (VERDICT r03 missing 3): the same bytes per batch in fewer, longer rows
@@ -1258,13 +1267,15 @@ def main():
                 ("pattern_deepseek_v3", dict(kind="mixed", tok="llama3", pattern="deepseek-v3"))]
         notes = {"uniform_text": "uniform-random printable bytes (SURVEY 8d stress text: cache-hostile, 3x the pieces)",
                  "no_memo": "zipf text with cache_capacity=0: every piece takes the merge path",
-                 "fixed_memo_only": "zipf text with cache_capacity=1: the memo holds the vocabulary's own tokens and learns "
-                                    "nothing from the text (every multi-token word is merged every time)",
+                 "fixed_memo_only": "zipf text with cache_capacity=1 and memo_learn=-1: the memo holds the vocabulary's own tokens and learns "
+                                    "nothing from the text (every multi-token word goes to merge_kernel every time, which finds it in the store)",
+                 "reference_cache_count": "the headline text with memo_learn=-1: the first level learns exactly cache_capacity = 20 000 pieces, the "
+                                          "reference's count (round 4's configuration); everything else goes to merge_kernel and its store every call",
                  "mixed_script_text": "config 4's text (30 % of the words Greek / Cyrillic / CJK / kana / emoji, rows of 700-1000 "
                                       "bytes) through THIS tokenizer: blocks with a non-ASCII byte take the ballot form of the rules inside "
                                       "lookup_span_kernel (window by window), and random non-Latin words never hit the memo: half of the step is merge_kernel",
                  "first_sight": "zipf text never encoded before: 20 timed batches, each seen for the first time, on a handle that has seen 4 others "
-                                "(the memo's learned part fills within the first batch, the piece store keeps learning)",
+                                "(the memo and the piece store keep learning)",
                  "rows_2048_bytes": "rows of ~2048 bytes: lookup_span_kernel's 2048-byte blocks slide along the row (a block starts where the one before stopped)",
                  "rows_8192_bytes": "rows of ~8192 bytes: four to five sliding blocks of lookup_span_kernel per row",
                  "pattern_qwen2": "Qwen2's pattern (\\p{N} for \\p{N}{1,3}): the Llama-3 scanners with l3_digits1",
@@ -1278,7 +1289,8 @@ def main():
             fresh = kw.get("fresh", False)
             n_b = 24 if fresh else 4
             w2 = BpeEncode(s_args, lib, dev, rank, kw.get("tok", args.tokenizer), kw["kind"], rows, nbytes, 5000, no_memo=kw.get("no_memo", False),
-                           n_batches=n_b, cache_capacity=kw.get("cache_capacity"), pattern=MODEL_PATTERNS.get(kw.get("pattern")))
+                           n_batches=n_b, cache_capacity=kw.get("cache_capacity"), pattern=MODEL_PATTERNS.get(kw.get("pattern")),
+                           memo_learn=kw.get("memo_learn"))
             run_pipelined(w2, 4, stream_ptrs, args.depth)
             n2 = 20 if fresh else 16
             d2 = timed(lambda: run_pipelined(w2, n2, stream_ptrs, args.depth, first=4))

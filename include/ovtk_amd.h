@@ -141,11 +141,17 @@ void ovtk_special_tokens_split_destroy(ovtk_special_tokens_split* h);
  * for the 11/15-input text form), last four (added tokens + ids; n_added = 0 if absent) and the attributes
  * unk_token, fuse_unk, suffix_indicator, end_suffix, byte_fallback, cache_capacity (bpe_tokenizer.hpp:220-228).
  * cache_capacity: the reference's piece cache is pure memoisation (bpe_tokenizer.cpp:197-205,331-338) and so is its
- * counterpart here, the piece memo: BPE of every vocabulary token as a whole piece, built at create, plus up to
- * cache_capacity pieces that take several tokens (at most 15 bytes and 3 ids each), kept by the device the first time
- * it merges them and while there is room -- the reference's rule (:335 `size() < capacity`, nothing is evicted).  0
- * disables the memo altogether, exactly as it disables the reference's cache.  Results are identical for every value
- * and every history of calls; a handle may be used from several streams at once. */
+ * counterpart here, the piece memo: BPE of every vocabulary token as a whole piece, built at create, plus pieces that
+ * take several tokens (at most 15 bytes; at most 6 ids when every id of the vocabulary fits 16 bits, 3 otherwise), kept by
+ * the device the first time it merges them and while there is room -- the reference's rule (:335 `size() < capacity`,
+ * nothing is evicted).  0 disables the memo altogether, exactly as it disables the reference's cache.  Results are
+ * identical for every value and every history of calls; a handle may be used from several streams at once.
+ * memo_learn: how many such pieces.  The attribute bounds the HOST memory of the reference's std::string cache; the tables
+ * here are allocated at create at a size that does not depend on what they come to hold, and the memo's second level (the
+ * piece store, below) is sized by this library already.  So by default (0) the first level learns up to
+ * max(cache_capacity, the store's capacity) pieces -- what the store would hold for every later call to fetch from
+ * merge_kernel is found by the lookup kernel instead --; < 0: exactly cache_capacity pieces, the reference's count;
+ * > 0: that many.  (Round 5: ABI 1002.  Until then the count was cache_capacity and an entry held 3 ids.) */
 typedef struct ovtk_bpe_params {
     ovtk_strings vocab;
     ovtk_strings merges;       /* text lines or left halves */
@@ -163,6 +169,7 @@ typedef struct ovtk_bpe_params {
     int64_t cache_capacity;
     int device;
     int64_t memo_store;   /* entries of the handle's piece store (below): 0 = the library's default (ovtk_set_memo_store), < 0 = none */
+    int64_t memo_learn;   /* pieces the first level may learn (above): 0 = max(cache_capacity, the store's capacity), < 0 = cache_capacity, > 0 = that many */
 } ovtk_bpe_params;
 
 typedef struct ovtk_bpe ovtk_bpe;
@@ -172,7 +179,8 @@ int ovtk_bpe_create(const ovtk_bpe_params* params, ovtk_bpe** out);
 int ovtk_bpe_run(ovtk_bpe* h, const ovtk_ragged_strings* in, ovtk_ragged_i32_out* out, int mem, void* stream);
 void ovtk_bpe_destroy(ovtk_bpe* h);
 /* Entries of the piece memo: built at create from the vocabulary (*fixed) and kept since by the device (*learned, at most
- * cache_capacity -- the size() of the reference's m_cache, bpe_tokenizer.hpp:150, which the reference does not expose).
+ * what memo_learn says; with memo_learn < 0 at most cache_capacity -- the size() of the reference's m_cache,
+ * bpe_tokenizer.hpp:150, which the reference does not expose).
  * Waits for the device. */
 int ovtk_bpe_memo_entries(ovtk_bpe* h, int64_t* fixed, int64_t* learned);
 /* The memo's second level, the piece store: what a handle had to MERGE once (a piece of up to 31 bytes that came to at most 15

@@ -53,7 +53,7 @@ class BpeParams(C.Structure):
                 ("added_ids", C.c_void_p), ("unk_token", C.c_char_p), ("unk_token_len", C.c_int64),
                 ("fuse_unk", C.c_int), ("suffix_indicator", C.c_char_p), ("suffix_indicator_len", C.c_int64),
                 ("end_suffix", C.c_char_p), ("end_suffix_len", C.c_int64), ("byte_fallback", C.c_int),
-                ("cache_capacity", C.c_int64), ("device", C.c_int), ("memo_store", C.c_int64)]
+                ("cache_capacity", C.c_int64), ("device", C.c_int), ("memo_store", C.c_int64), ("memo_learn", C.c_int64)]
 
 
 class WordpieceParams(C.Structure):

@@ -52,11 +52,14 @@ inline int64_t resolve_memo_store(int64_t param) { return param == 0 ? memo_stor
 // halves of one 128-byte line and nothing is relocated on the device: the table is kept below a third full (an insert finds
 // its line taken a few times in a hundred then).  No more than a few entries per vocabulary token: a 3 000-token test vocabulary
 // does not need 32 MiB of table.
+// entries a handle's store takes for a requested capacity (never more than four per vocabulary token)
+inline int64_t piece_store_capacity(int64_t vocab_n, int64_t entries) {
+    return std::max<int64_t>(0, std::min<int64_t>({entries, int64_t(1) << 22, std::max<int64_t>(8192, 4 * vocab_n)}));
+}
 inline int alloc_piece_store(DevBuf& table, DevBuf& room, int64_t vocab_n, bool narrow, PieceStoreDev& dev, int32_t& capacity, int64_t entries) {
     dev = PieceStoreDev{nullptr, 30, nullptr, 0};
     capacity = 0;
-    const int64_t want = std::min<int64_t>({entries, int64_t(1) << 22,
-                                            std::max<int64_t>(8192, 4 * vocab_n)});
+    const int64_t want = piece_store_capacity(vocab_n, entries);
     if (want <= 0) return OVTK_OK;
     const uint32_t slots = std::max<uint32_t>(1024, pow2_at_least(uint64_t(want) * 3));
     if (int rc = table.ensure(size_t(slots) * sizeof(StoreEntry))) return rc;
@@ -440,7 +443,7 @@ private:
         e = e ? e : ws.wave_off.ensure(size_t(grid_ * kWavesPerBlock + 1) * sizeof(long long));
         e = e ? e : ws.tiles.ensure(size_t(n_tiles_ + 1) * sizeof(long long));
         const bool fold = fold_tail_ && n_rows_ <= kFoldTailRows;
-        const size_t status_bytes = sizeof(RunStatus) + (fold ? size_t(n_tiles_) * 4 : 0);  // + tile_cnt, zeroed with the status
+        const size_t status_bytes = sizeof(RunStatus) + (fold ? size_t(n_tiles_) * 4 + 16 : 0);  // + tile_cnt, zeroed with the status (+ slack: compact_kernel reads it 16 bytes at a time)
         const size_t status_stride = (status_bytes + 255) & ~size_t(255);   // two blocks: this call's, and the one compact_kernel zeroes for the next
         e = e ? e : ws.status.ensure(2 * status_stride);
         if (fold) e = e ? e : ws.gen[4].ensure(size_t(n_rows_) * 4);
@@ -502,6 +505,7 @@ private:
         w.status = reinterpret_cast<RunStatus*>(mine);
         w.tile_cnt = fold ? reinterpret_cast<int32_t*>(mine + sizeof(RunStatus)) : nullptr;
         w.next_status = reinterpret_cast<RunStatus*>(other);
+        w.tile_sums = fold ? 1 : 0;   // (the large path: no ticket and no scan at the end of the middle's last kernel -- compact_kernel sums tile_cnt)
         w.host_status = ws.host_status;
         w.status_words = int32_t(status_bytes / 4);
         if (ws.zeroed_status != mine || ws.zeroed_bytes < status_bytes || ws.zeroed_after_lease + 1 != ws.lease_count)

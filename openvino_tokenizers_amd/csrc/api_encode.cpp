@@ -119,7 +119,11 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
 // while encoding, up to cache_capacity pieces that take several tokens.  It is the parallel-machine form of the
 // reference's piece cache (bpe_tokenizer.cpp:197-205,331-338): the same pure function piece -> ids, so results never
 // depend on what was encoded before; only the time does.
-int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity, int64_t memo_store) {
+// memo_learn (ovtk_bpe_params): what the first level may learn.  < 0: exactly cache_capacity entries, the reference's count;
+// 0: the larger of cache_capacity and the capacity of the handle's piece store -- the store holds what had to be merged once whatever
+// cache_capacity says, and a piece of at most 15 bytes and kPieceMaxIds (6 with u16 ids) ids that it would hold is kept where
+// the lookup kernels find it instead; > 0: that many.
+int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity, int64_t memo_store, int64_t memo_learn) {
     const int64_t V = vocab.n;
     if (V == 0) return OVTK_OK;
     const size_t nv = size_t(V);
@@ -137,12 +141,18 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity, i
     PieceTableHost host;
     // (sized for the learned entries too, up to a couple per vocabulary token: a larger cache_capacity still counts, its entries
     // just compete for the buckets there are)
+    // An entry's ids are six u16 when every id fits (PieceTableDev::packed6; lookup_span_kernel reads all six, the other lookup
+    // kernels the entries of up to three), three i32 otherwise.
+    const bool packed6 = h->stage16;
     build_piece_table(view_of(vocab), ob.data(), oe.data(), ids.data(), host,
-                      size_t(std::min<int64_t>(std::max<int64_t>(cache_capacity, 0), 2 * V + 65536)));
+                      size_t(std::min<int64_t>(std::max<int64_t>(cache_capacity, 0), 2 * V + 65536)), packed6);
     if (int rc = h->pieces.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
     // The dynamic part (memo_insert in encode_kernels.hpp): up to cache_capacity further pieces, the ones the vocabulary
     // needs more than one token for, kept the first time merge_kernel computes them -- the reference's rule, its numbers.
-    const int32_t room = int32_t(std::min<int64_t>(std::max<int64_t>(cache_capacity, 0), INT32_MAX / 2));
+    const int64_t store_cap = piece_store_capacity(V, resolve_memo_store(memo_store));
+    const int64_t learn = memo_learn < 0 ? cache_capacity : (memo_learn > 0 ? memo_learn : std::max<int64_t>(cache_capacity, store_cap));
+    // (never more than half the table's slots: direct-mapped, a piece whose slot is taken stays with the store)
+    const int32_t room = int32_t(std::min<int64_t>({std::max<int64_t>(learn, 0), int64_t(host.slots.size() / 2), int64_t(INT32_MAX / 2)}));
     const uint32_t room_mask = room >= 4096 ? uint32_t(kRoomShards - 1) : 0u;   // (a handful of entries: one counter)
     std::vector<int32_t> rooms(size_t(kRoomShards) * kRoomStride, 0);
     for (uint32_t k = 0; k <= room_mask; ++k)
@@ -150,7 +160,7 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity, i
     if (int rc = h->memo_room.upload(rooms.data(), rooms.size() * sizeof(int32_t))) return rc;
     h->memo_capacity = room;
     OVTK_HIP(hipStreamSynchronize(nullptr));
-    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), room_mask, 0};
+    h->dev.pieces = PieceTableDev{h->pieces.as<PieceEntry>(), host.shift, h->memo_room.as<int32_t>(), room_mask, packed6 ? 1u : 0u};
     h->memo_entries = host.stored;
     // The second level (tables.hpp "piece store"): empty at create, filled by merge_kernel.
     if (int rc = alloc_piece_store(h->store, h->store_room, V, h->narrow_ids, h->dev.store, h->store_capacity, resolve_memo_store(memo_store))) return rc;
@@ -220,7 +230,7 @@ bool parse_special_pattern(const std::string& pat, std::vector<std::string>& tok
 extern "C" {
 
 const char* ovtk_last_error(void) { return last_error(); }
-int ovtk_abi_version(void) { return 1001; }   // (1001: ovtk_bpe_params / ovtk_wordpiece_params::memo_store, the dense / special encode calls)
+int ovtk_abi_version(void) { return 1002; }   // (1001: ovtk_bpe_params / ovtk_wordpiece_params::memo_store, the dense / special encode calls; 1002: ovtk_bpe_params::memo_learn)
 
 const char* ovtk_device_name(void) {
     static std::string name;
@@ -432,7 +442,7 @@ int ovtk_bpe_create(const ovtk_bpe_params* p, ovtk_bpe** out) {
     // cache_capacity == 0 disables the reference's piece cache (bpe_tokenizer.cpp:331: size() < capacity); here it
     // disables the memo the same way.  Results are identical either way.
     if (p->cache_capacity != 0)
-        if (int rc = build_memo(h.get(), p->vocab, p->cache_capacity, p->memo_store)) return rc;
+        if (int rc = build_memo(h.get(), p->vocab, p->cache_capacity, p->memo_store, p->memo_learn)) return rc;
     *out = h.release();
     return OVTK_OK;
 }

@@ -43,6 +43,7 @@ struct RunStatus {
     int32_t batch_ticket[kShards * kCounterStride]; // [s * kCounterStride] = 64-piece batches of shard s handed out (merge_kernel)
     uint32_t done_ticket[kShards * kCounterStride]; // [s * kCounterStride] = blocks of shard s that are through (last_block_done_sharded)
 };
+static_assert(sizeof(RunStatus) % 16 == 0, "tile_cnt stands behind the status block and is read 16 bytes at a time (compact_kernel)");
 constexpr uint32_t kFlagItemsOverflow = 1u;     // more work items than the workspace holds
 constexpr uint32_t kFlagStageOverflow = 2u;     // staging buffer too small
 constexpr uint32_t kFlagDeferOverflow = 4u;     // deferred-piece list too small

@@ -58,6 +58,9 @@ constexpr int32_t kRowPending = -1;  // row_used: lookup_span_kernel / lookup_ro
 
 struct EncodeWork {
     int32_t fold_tail;      // merge_kernel's last block also runs exact pieces + the row scan (no exact / count_scan launches)
+    int32_t tile_sums;      // (with fold_tail, the large path) ... or nobody does: merge_kernel / wordpiece_deferred_kernel end without
+                            // a ticket, an exact piece is worked out by the lane that finds it, and compact_kernel derives a tile's
+                            // offset from tile_cnt itself (the sum of the counts in front of it) and the total in its block 0
     long long out_cap;      // caller's ids capacity (the folded tail's capacity check)
     int32_t only_pending;   // lookup_kernel<kFused>: take only the rows the span / rows kernel marked kRowPending in row_used
     int32_t small;          // the whole call is ONE launch of encode_small_kernel (one block): the fields below are set
@@ -940,9 +943,8 @@ static __global__ __launch_bounds__(kBlockThreads, SCAN == kRowsLlama3 ? 4 : 6) 
 }
 
 // ---- path X, one lane per piece.
-__device__ __forceinline__ void exact_one(const RowsIn& in, const BpeDev& T, const EncodeWork& w, int i) {
+__device__ __forceinline__ void exact_piece(const RowsIn& in, const BpeDev& T, const EncodeWork& w, const ExactPiece& p) {
     const int SL = T.suffix_len;
-    const ExactPiece p = w.exact[i];
     const int ntext = p.len + SL;
     // (+ ntext i32 ids behind the working arrays when the staging entries are u16)
     const uint32_t bytes = ((bpe_exact_scratch_bytes(uint32_t(ntext)) + 15u) & ~15u) + (w.stage16 ? 4u * ((uint32_t(ntext) + 3u) & ~3u) : 0u);
@@ -965,6 +967,8 @@ __device__ __forceinline__ void exact_one(const RowsIn& in, const BpeDev& T, con
         if (w.tile_cnt) atomicAdd(&w.tile_cnt[p.row / kRowTile], cnt);
     }
 }
+
+__device__ __forceinline__ void exact_one(const RowsIn& in, const BpeDev& T, const EncodeWork& w, int i) { exact_piece(in, T, w, w.exact[i]); }
 
 // Final offsets by ONE block (the folded tail of merge_kernel) -- count_scan_kernel without its launch: the per-tile
 // sums were accumulated in w.tile_cnt while the ids were produced, so only their scan is left.
@@ -1009,11 +1013,18 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     __shared__ I2 root_lds[256];
     __shared__ uint8_t long_src_all[kWavesPerBlock][kWave / 2];  // path L: source lane of the piece lane t works on
     __shared__ int pushed_exact;  // this block stored exact-list entries (plain stores the tail block must see)
+    // Everything the kernel has to know before it can start, asked for together (as wordpiece_deferred_kernel does): most of its
+    // blocks find no batch, and the ones that do are one chain of memory round trips from here to the kernel's end -- the tables'
+    // roots, the flags, the shard's count and the store's room used to be one wait each.
+    const uint32_t flags0 = __hip_atomic_load(&w.status->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int shard0 = solo ? 0 : int(blockIdx.x);
+    const int count0 = __hip_atomic_load(&w.status->shard_count[shard0 * kCounterStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int store_room0 = T.store.slots ? __hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     for (int i = int(threadIdx.x); i < 256; i += kBlockThreads) root_lds[i] = T.trie.root[i];
     if (threadIdx.x == 0) pushed_exact = 0;
     __syncthreads();
     PROBE(0);
-    if (w.status->flags & (kFatalFlags | kFlagDeferOverflow)) return;
+    if (flags0 & (kFatalFlags | kFlagDeferOverflow)) return;
     if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows, solo);
     PROBE(1);
     uint64_t* key = lds_all[wave_in_block()];                                 // path W
@@ -1031,14 +1042,14 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     // whatever its text (launches that overlap on several streams may each find the same room: a small multiple at worst).
     int store_budget = 0;
     if (T.store.slots) {
-        const int room = wave_uniform(__hip_atomic_load(T.store.room, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int room = wave_uniform(store_room0);
         const int n_waves_grid = (solo ? 1 : int(gridDim.x) * int(gridDim.y)) * kWavesPerBlock;
         store_budget = room > 0 ? (room + n_waves_grid - 1) / n_waves_grid : 0;
     }
     {  // (x is the fastest-varying block index: blocks that become resident late are spread over all shards; solo: the
        // small batch's blocks filed everything under shard 0)
-    const int shard = solo ? 0 : int(blockIdx.x);
-    int count = w.status->shard_count[shard * kCounterStride];
+    const int shard = shard0;
+    int count = wave_uniform(count0);
     if (count > w.shard_cap) count = w.shard_cap;
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
     // 64-piece batches of the shard: strided over its waves, or (w.rows_per_ticket != 0, see lookup_kernel: late blocks
@@ -1136,7 +1147,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 for (int k = 0; k < res; ++k) stage_put(w, e.stage_pos + k, int32_t(fid[k * kWave + l]));
                 for (int k = res; k < need; ++k) stage_clear(w, e.stage_pos + k);
                 f_cnt = res;
-                keep = res <= kPieceMaxIds;
+                keep = res <= (T.pieces.packed6 ? kPieceMaxIds6 : kPieceMaxIds);
             }
         }
         if (T.store.slots) {
@@ -1165,9 +1176,15 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
                 const int rank = rank_below(km);
                 bool added = false;
                 if (keep && rank < left) {
-                    int32_t t3[kPieceMaxIds];
+                    int32_t t3[kPieceMaxIds] = {0, 0, 0};
+                    if (T.pieces.packed6) {   // (six u16 ids: id 2k in the low half of tok[k])
 #pragma unroll
-                    for (int k = 0; k < kPieceMaxIds; ++k) t3[k] = k < f_cnt ? int32_t(fid[k * kWave + l]) : 0;
+                        for (int k = 0; k < kPieceMaxIds6; ++k)
+                            if (k < f_cnt) t3[k >> 1] |= int32_t((uint32_t(fid[k * kWave + l]) & 0xFFFFu) << (16 * (k & 1)));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < kPieceMaxIds; ++k) t3[k] = k < f_cnt ? int32_t(fid[k * kWave + l]) : 0;
+                    }
                     added = memo_insert(T.pieces, e.k0, e.k1, t3, f_cnt);
                 }
                 const int unused = __popcll(km) - __popcll(__ballot(added));  // room taken but not filled goes back
@@ -1279,7 +1296,11 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
         }
         PHASE(11);
         const unsigned long long xm = __ballot(is_x);
-        if (xm) {
+        if (xm && w.tile_sums && tail_rows > 0 && !solo) {
+            // no tail block to leave them to: the lane works its piece out here (rare: a tie in the merge heap, a piece of more than
+            // kChunkSyms symbols -- the tail ran them a thread each after everybody else was through, which was no faster)
+            if (is_x) exact_piece(in, T, w, ExactPiece{e.begin, e.len, e.stage_pos, e.row});
+        } else if (xm) {
             int idx = 0;
             if (l == 0) idx = atomicAdd(&w.status->n_exact, __popcll(xm));
             idx = __shfl(idx, 0) + rank_below(xm);
@@ -1292,6 +1313,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     }
     }
     if (tail_rows <= 0) return;
+    if (w.tile_sums && !solo) return;   // (compact_kernel sums tile_cnt itself: no ticket, no scan -- three dependent round trips less at the end of every call)
     // ---- folded tail: every block takes a ticket when its batches are done; the last one is alone on the data
     __syncthreads();
     PROBE(4);
@@ -1499,6 +1521,38 @@ __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSi
                                                                                                                 // the stretch: the buffer has the slack)
         return FlatBytes16{{0u, 0u, 0u, 0u}};
     };
+    if (total_used == cnt[0] + cnt[1] + cnt[2] + cnt[3]) {
+        // No unused entry in the stretch (no piece of these rows was deferred, or each came to exactly the entries it had reserved -- with
+        // the six-id memo entries of round 5 that is nearly every item): a widening copy.  Every step stands on its own -- no prefix
+        // sum, no LDS, four steps' loads in flight before the first store -- where the squeeze below is a chain of one memory round
+        // trip per step (rows of 8 KB: 14 steps per item).
+        constexpr int U = 4;
+        for (int off0 = 0; off0 < total_used; off0 += U * kWave * E) {
+            FlatBytes16 x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = fetch(off0 + u * kWave * E);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = off0 + u * kWave * E + l * E;
+                const int n_here = total_used - idx;
+                if (n_here <= 0) continue;
+                if (S16) {
+                    const FlatBytes16 lo{{x[u].d[0] & 0xFFFFu, x[u].d[0] >> 16, x[u].d[1] & 0xFFFFu, x[u].d[1] >> 16}};
+                    const FlatBytes16 hi{{x[u].d[2] & 0xFFFFu, x[u].d[2] >> 16, x[u].d[3] & 0xFFFFu, x[u].d[3] >> 16}};
+                    if (n_here >= E) {
+                        *reinterpret_cast<FlatBytes16*>(out + idx) = lo;
+                        *reinterpret_cast<FlatBytes16*>(out + idx + 4) = hi;
+                    } else {
+                        for (int i = 0; i < n_here; ++i) out[idx + i] = int32_t(i < 4 ? lo.d[i] : hi.d[i - 4]);
+                    }
+                } else {
+                    if (n_here >= E) *reinterpret_cast<FlatBytes16*>(out + idx) = x[u];
+                    else for (int i = 0; i < n_here; ++i) out[idx + i] = int32_t(x[u].d[i]);
+                }
+            }
+        }
+        return true;
+    }
     FlatBytes16 v = fetch(0);
     for (int off = 0; off < total_used; off += kWave * E) {
         const FlatBytes16 nxt = fetch(off + kWave * E);
@@ -1539,11 +1593,12 @@ __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSi
 }
 
 template <class Sink, bool S16 = false>
-__device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Sink sink, bool solo = false, int32_t* flat_buf = nullptr) {
+__device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Sink sink, bool solo = false, int32_t* flat_buf = nullptr,
+                                             uint32_t more_flags = 0u) {
     // kFlagTailPending: merge_kernel's folded tail left the exact pieces and the tile scan to a second attempt -- tile_off
     // and parts of the staging buffer hold whatever the previous call left there
-    if (w.status->flags & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
-                           kFlagTailPending))
+    if ((w.status->flags | more_flags) & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
+                                         kFlagTailPending))
         return;
     sink.start(w.status);
     const int l = lane_id();
@@ -1558,7 +1613,21 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
         const int sv = have ? w.row_stage[rj] : 0;
         const int uv = have ? w.row_used[rj] : 0;
         const int incl = wave_incl_sum(c);
-        const long long toff = w.tile_off[tile];
+        long long toff;
+        if (w.tile_sums && !solo) {
+            // the tile's offset = the counts of the tiles in front of it, summed here (tile_cnt: 4 bytes per 64 rows, hot in every L2;
+            // 16 bytes per lane and step -- the array has the slack).  What merge_kernel's last block did for everybody, at the price of
+            // a ticket and a scan on every call's chain.
+            int acc = 0;
+            for (int i0 = 0; i0 < tile; i0 += 4 * kWave) {
+                const int i = i0 + 4 * l;
+                const int4 v = *reinterpret_cast<const int4*>(w.tile_cnt + i);
+                acc += (i < tile ? v.x : 0) + (i + 1 < tile ? v.y : 0) + (i + 2 < tile ? v.z : 0) + (i + 3 < tile ? v.w : 0);
+            }
+            toff = wave_sum(acc);
+        } else {
+            toff = w.tile_off[tile];
+        }
         int cnt[kCompactRows], o[kCompactRows], base[kCompactRows], used[kCompactRows];
         int32_t v[kCompactRows][kCompactChunks];
 #pragma unroll
@@ -1568,6 +1637,11 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
             o[q] = int(toff + (wave_readlane(incl, j) - cnt[q]));
             base[q] = wave_readlane(sv, j);
             used[q] = wave_readlane(uv, j);
+        }
+        if constexpr (std::is_same<Sink, RaggedSink>::value) {
+            // (tile_sums: the total is block 0's to find out while everybody writes -- an item that would leave the caller's buffer
+            // writes nothing, the call ends with OVTK_E_CAPACITY either way)
+            if (w.tile_sums && !solo && (long long)o[kCompactRows - 1] + cnt[kCompactRows - 1] > w.out_cap) continue;
         }
         if constexpr (std::is_same<Sink, RaggedSink>::value && kCompactRows == 4) {
             const int row0 = tile * kRowTile + sub * kCompactRows;
@@ -1623,13 +1697,43 @@ static __global__ __launch_bounds__(kBlockThreads) void compact_kernel(int n_row
         constexpr int kShard0 = kHead;
         for (int i = int(threadIdx.x); i < kHead + kShards; i += kBlockThreads) {
             const int at = i < kHead ? i : kShard0 + (i - kHead) * kCounterStride;
+            if (w.tile_sums && (at == int(offsetof(RunStatus, n_out) / 4) || at == int(offsetof(RunStatus, flags) / 4))) continue;   // (thread 0, below)
             __hip_atomic_store(dst + at, __hip_atomic_load(src + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         uint32_t* nxt = reinterpret_cast<uint32_t*>(w.next_status);
         for (int i = int(threadIdx.x); i < w.status_words; i += kBlockThreads) nxt[i] = 0u;
     }
     __shared__ int32_t flat_all[std::is_same<Sink, RaggedSink>::value ? kWavesPerBlock * kFlatIds : 1];
-    compact_body<Sink, S16>(n_rows, w, sink, false, std::is_same<Sink, RaggedSink>::value ? flat_all + wave_in_block() * kFlatIds : nullptr);
+    __shared__ uint32_t over_s;   // block 0: kFlagOutCapacity as this launch found it (the block's threads must agree on it)
+    if (threadIdx.x == 0) over_s = 0u;
+    if (w.tile_sums && blockIdx.x == 0) {
+        // the call's total and its capacity check (merge_kernel's folded tail did both): the sum of every tile's count
+        __shared__ long long total_s[kWavesPerBlock];
+        const int n_tiles = (n_rows + kRowTile - 1) / kRowTile;
+        long long acc = 0;
+        for (int i = int(threadIdx.x); i < n_tiles; i += kBlockThreads) acc += w.tile_cnt[i];
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane_id() == 0) total_s[wave_in_block()] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long total = 0;
+            for (int k = 0; k < kWavesPerBlock; ++k) total += total_s[k];
+            const int32_t n_out = total > INT32_MAX ? INT32_MAX : int32_t(total);
+            const uint32_t over = total > w.out_cap ? kFlagOutCapacity : 0u;
+            w.status->n_out = n_out;   // (WireSink::finish reads it: the same thread)
+            // the two words of the caller's block that the copy above left out
+            if (w.next_status) {
+                __hip_atomic_store(&w.host_status->n_out, n_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&w.host_status->flags, __hip_atomic_load(&w.status->flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | over,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (over) atomicOr(&w.status->flags, over);
+            over_s = over;
+        }
+    }
+    __syncthreads();
+    compact_body<Sink, S16>(n_rows, w, sink, false, std::is_same<Sink, RaggedSink>::value ? flat_all + wave_in_block() * kFlatIds : nullptr, over_s);
 }
 
 // ---- a small batch in ONE launch (BASELINE config 1: 32 x 128-byte strings; any batch of a few hundred short rows).

@@ -267,7 +267,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
         }
     }
     PROBE(5);   // (out of the batch loop)
-    if (tail_rows <= 0) return;
+    if (tail_rows <= 0 || w.tile_sums) return;   // (tile_sums: compact_kernel sums tile_cnt itself, merge_body)
     __syncthreads();
     const bool last_ = last_block_done_sharded(w.status, int(blockIdx.y), gridDim.x, /*release=*/false);  // only atomics to hand over (grid: blocks per shard x kShards)
     PROBE(6);   // (ticket drawn)

@@ -592,7 +592,9 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 q.p = e[1];
                 return q;
             };
-            const bool packed6 = BERT && T.pieces.packed6 != 0;   // (the word memo: six u16 ids per entry; wave-uniform)
+            // six u16 ids per entry: the word memo when the vocabulary fits (wave-uniform), the BPE memo exactly when the staging
+            // entries are u16 (api_encode.cpp build_memo: packed6 = stage16 -- a template flag here)
+            const bool packed6 = BERT ? T.pieces.packed6 != 0 : S16;
             // hit or miss, the ids a hit brings, the staging entries the piece takes
             auto classify = [&](const SpanProbe& q, bool& hit, int& cnt_ids, int& need) {
                 const bool valid = q.plen >= 1;
@@ -606,7 +608,19 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 need = hit ? cnt_ids : (valid ? q.plen + SL : 0);
             };
             auto put_ids = [&](const SpanProbe& q, bool hit, int cnt_ids, int at) {
-                if (hit && packed6) {
+                if (!BERT && S16) {
+                    // The BPE memo's six u16 ids into u16 staging entries: a pair as one dword (at a 2-byte address: gfx950 stores
+                    // at any alignment), an odd count's last id alone; every store at a constant offset from ONE address (an offset
+                    // that depends on the count is a second 64-bit address: two registers this kernel does not have -- 97 VGPRs,
+                    // four waves per SIMD instead of five, twelve spilled SGPRs).  (cnt_ids == 0: a miss, nothing to store)
+                    uint16_t* st16 = reinterpret_cast<uint16_t*>(w.stage) + at;
+                    if (cnt_ids == 1) st16[0] = uint16_t(q.p.x);
+                    if (cnt_ids > 1) reinterpret_cast<Bytes4*>(st16)->v = q.p.x;
+                    if (cnt_ids == 3) st16[2] = uint16_t(q.p.y);
+                    if (cnt_ids > 3) reinterpret_cast<Bytes4*>(st16 + 2)->v = q.p.y;
+                    if (cnt_ids == 5) st16[4] = uint16_t(q.p.z);
+                    if (cnt_ids > 5) reinterpret_cast<Bytes4*>(st16 + 4)->v = q.p.z;
+                } else if (hit && packed6) {
                     const uint32_t i0 = q.p.x & 0xFFFFu, i1 = q.p.x >> 16, i2 = q.p.y & 0xFFFFu, i3 = q.p.y >> 16, i4 = q.p.z & 0xFFFFu, i5 = q.p.z >> 16;
                     if (S16) {
                         uint16_t* st16 = reinterpret_cast<uint16_t*>(w.stage) + at;

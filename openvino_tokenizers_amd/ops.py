@@ -216,8 +216,9 @@ class BPETokenizer(_Op):
     merges (3, or 3 + 3 for left/right halves), [added tokens (3) + ids (1)].  Outputs: begins, ends, ids."""
 
     def __init__(self, unk_token="", fuse_unk=False, suffix_indicator="", end_suffix="", byte_fallback=False,
-                 cache_capacity=20000, device=0, lib=None):
+                 cache_capacity=20000, device=0, lib=None, memo_store=0, memo_learn=0):
         super().__init__(device, lib)
+        self.memo_store, self.memo_learn = int(memo_store), int(memo_learn)   # (include/ovtk_amd.h ovtk_bpe_params: not attributes of the reference's op)
         self.unk_token, self.fuse_unk = unk_token, bool(fuse_unk)
         self.suffix_indicator, self.end_suffix = suffix_indicator, end_suffix
         self.byte_fallback, self.cache_capacity = bool(byte_fallback), int(cache_capacity)
@@ -246,7 +247,7 @@ class BPETokenizer(_Op):
             added, pids = L.Strings(None, None, None, 0, 0), None
         unk, si, es = _bytes_of(self.unk_token), _bytes_of(self.suffix_indicator), _bytes_of(self.end_suffix)
         p = L.BpeParams(vocab, merges, right, added, pids, unk, len(unk), int(self.fuse_unk), si, len(si), es, len(es),
-                        int(self.byte_fallback), self.cache_capacity, self.device)
+                        int(self.byte_fallback), self.cache_capacity, self.device, self.memo_store, self.memo_learn)
         self._chk(self._lib.ovtk_bpe_create(C.byref(p), C.byref(self._h)))
 
     def evaluate(self, inputs, ids_capacity=None):

@@ -209,7 +209,7 @@ void launch(K kernel, dim3 grid, dim3 block, A... args) {
                                 std::fprintf(stderr, " %u", t);
                                 ++shown;
                             }
-                        std::fprintf(stderr, ")\n");
+                        std::fprintf(stderr, ")\n  in %s\n", __PRETTY_FUNCTION__);
                         std::abort();
                     }
                 }

@@ -33,7 +33,7 @@ def test_header_and_ctypes_list_agree():
 def test_library_exports_every_declared_symbol(hip_build):
     for name in declared_functions():
         assert hasattr(hip_build, name), f"{name} is declared in include/ovtk_amd.h but not exported"
-    assert hip_build.ovtk_abi_version() == 1001
+    assert hip_build.ovtk_abi_version() == 1002
 
 
 def test_no_cpu_fallback_without_a_device(hip_build):

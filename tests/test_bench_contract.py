@@ -39,7 +39,10 @@ def test_bench_json_line():
     assert d["stress"]["uniform_text"]["value"] > 0 and d["stress"]["no_memo"]["ms_per_step"] > 0
     assert d["stress"]["fixed_memo_only"]["ms_per_step"] > 0 and d["stress"]["mixed_script_text"]["value"] > 0
     memo = d["config"]["piece_memo"]
-    assert memo["fixed"] > 1000 and 0 < memo["learned"] <= memo["cache_capacity"] == 20000
+    # (memo_learn = 0, the library's default: the first level learns up to max(cache_capacity, the store's capacity) pieces)
+    assert memo["fixed"] > 1000 and memo["cache_capacity"] == 20000 and memo["memo_learn"] == 0
+    assert 0 < memo["learned"] <= max(memo["cache_capacity"], memo["store"]["capacity"])
+    assert d["stress"]["reference_cache_count"]["value"] > 0
     assert d["end_to_end"]["value"] > 0 and "8 distinct batches" in d["config"]["workload"]
     assert d["parity_prefix_bit_exact"] is True
 

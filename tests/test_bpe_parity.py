@@ -540,7 +540,7 @@ def test_memo_learns_and_results_stay(backend, capacity):
     import ctypes as C
     tok = BpeTok.load("gpt2_small")
     attrs = dict(tok.attrs, cache_capacity=capacity)
-    bpe = BPETokenizer(**attrs, lib=backend.lib)
+    bpe = BPETokenizer(**attrs, memo_learn=-1, lib=backend.lib)   # (memo_learn < 0: the first level learns cache_capacity pieces, the reference's count)
     fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), bpe)
     orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
     pat = tok.pattern_u8()
@@ -564,6 +564,38 @@ def test_memo_learns_and_results_stay(backend, capacity):
     else:
         # the repeats add next to nothing (only pieces that lost a race for a slot the first time round, on the GPU)
         assert learned[0] > 20 and learned[1] > learned[0] and learned[1] <= learned[3] <= learned[1] * 1.15
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_memo_learn_default_and_six_id_entries(backend, wide):
+    """ovtk_bpe_params::memo_learn = 0 (the default): the first level learns up to max(cache_capacity, the store's capacity) pieces,
+    and -- every id below 65 535 -- pieces of up to SIX ids (PieceTableDev::packed6, read by lookup_span_kernel); `wide` (an added
+    token beyond 65 535): three i32 ids as ever.  cache_capacity = 7 here, so whatever is learned beyond 7 is the default's doing.
+    Every call equals the oracle: first sight, and the repeats that run on what was learned -- words of four to six tokens among
+    them (the vocabulary is small: most longer words are)."""
+    import ctypes as C
+    from tools.make_tokenizers import load_tokenizer
+    lib = backend.lib
+    t = load_tokenizer("gpt2_small")
+    added = dict(t["added"])
+    if wide:
+        added[b"<|far|>"] = 70000
+    tok = BpeTok(t["vocab"], t["merges"], added, t["pattern"], **dict(t["attrs"], cache_capacity=7))
+    orc, rs = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    pat = tok.pattern_u8()
+    n = 300 if backend.name == "emu" else 900   # (more than 256 rows: lookup_span_kernel)
+    b, e, c = TextModel(83, "zipf").batch(n, 200)
+    rb, re_ = ragged_rows(n)
+    ref = orc(*rs(rb, re_, b, e, c)[:5])
+    bpe = BPETokenizer(**tok.attrs, lib=lib)
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), bpe)
+    learned = []
+    for rep in range(3):
+        assert_same(ref, fused.evaluate(backend.data([rb, re_, b, e, c]) + [pat], tok.consts), backend.host, f"memo_learn default, call {rep}")
+        fixed, got = C.c_int64(), C.c_int64()
+        L.check(lib, lib.ovtk_bpe_memo_entries(bpe._h, C.byref(fixed), C.byref(got)))
+        learned.append(int(got.value))
+    assert learned[0] > 7 and learned[0] <= learned[1] <= learned[2] <= learned[0] * 1.15 + 2
 
 
 @pytest.mark.parametrize("wide", [False, True])
@@ -591,7 +623,7 @@ def test_piece_store_holds_what_was_merged(backend, wide):
     for entries in (4096, 0):
         L.check(lib, lib.ovtk_set_memo_store(C.c_int64(entries)))
         try:
-            bpe = BPETokenizer(**tok.attrs, lib=lib)
+            bpe = BPETokenizer(**tok.attrs, memo_learn=-1, lib=lib)   # (the first level keeps to cache_capacity = 7)
             fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), bpe)
             counts = []
             for rep in range(3):
