@@ -218,7 +218,15 @@ inline int grid_lookup(int device, int n_rows) { return grid_rows(device, n_rows
 inline int rows_grid(int n_rows, int persistent_grid, int32_t& rows_per_wave) {
     const int waves = persistent_grid * kWavesPerBlock;
     rows_per_wave = (n_rows + waves - 1) / waves;
-    if (rows_per_wave <= kWave) return persistent_grid;
+    // A multiple of compact_kernel's work item (kCompactRows = 4 rows) where a wave owns more than that: an item whose rows were staged by
+    // ONE wave is one stretch of the staging buffer (compact_flat); at 13 rows per wave three items in ten straddled two waves and went row
+    // by row.  (Config 2: 16 rows per wave, 4 096 of the 5 120 resident waves have rows -- lookup_span_kernel alone 58.2 -> 58.5 us, every
+    // block of a wave's chain full.)
+    if (rows_per_wave > 4) rows_per_wave = (rows_per_wave + 3) & ~3;
+    if (rows_per_wave <= kWave) {   // (no blocks whose waves have no rows)
+        const int rows_per_block = rows_per_wave * kWavesPerBlock;
+        return std::max(1, std::min(persistent_grid, (n_rows + rows_per_block - 1) / rows_per_block));
+    }
     rows_per_wave = kWave;
     return (n_rows + kWave * kWavesPerBlock - 1) / (kWave * kWavesPerBlock);
 }
@@ -272,6 +280,7 @@ namespace ovtk {
 // Up to this many rows the last block of merge_kernel sums the row counts itself (one block reads 4 bytes per row);
 // larger batches keep the parallel count_scan_kernel.
 constexpr int kFoldTailRows = 1 << 18;
+constexpr int kTileSumTiles = 1024;   // (65 536 rows)
 // A batch this small is one launch of one block (encode_small_kernel): BASELINE config 1 is 32 rows / 4 KB.
 constexpr int kSmallRows = 256;
 constexpr int64_t kSmallChars = 64 << 10;
@@ -505,7 +514,10 @@ private:
         w.status = reinterpret_cast<RunStatus*>(mine);
         w.tile_cnt = fold ? reinterpret_cast<int32_t*>(mine + sizeof(RunStatus)) : nullptr;
         w.next_status = reinterpret_cast<RunStatus*>(other);
-        w.tile_sums = fold ? 1 : 0;   // (the large path: no ticket and no scan at the end of the middle's last kernel -- compact_kernel sums tile_cnt)
+        // the large path, up to kTileSumTiles tiles: no ticket and no scan at the end of the middle's last kernel -- every wave of
+        // compact_kernel sums the counts in front of its tile (beyond that the sums cost compact_kernel more than the tail cost the
+        // middle: config 4's 2 048 tiles, compact 29.5 -> 32.7 us for merge_kernel 67 -> 62)
+        w.tile_sums = fold && n_tiles_ <= kTileSumTiles ? 1 : 0;
         w.host_status = ws.host_status;
         w.status_words = int32_t(status_bytes / 4);
         if (ws.zeroed_status != mine || ws.zeroed_bytes < status_bytes || ws.zeroed_after_lease + 1 != ws.lease_count)
@@ -521,7 +533,16 @@ private:
                         n_rows_, w, (long long)out_.data_capacity);
         // (compact_kernel's waves take work items of kCompactRows rows: a wave per item where the chip holds that many -- the kernel is a chain
         // of memory round trips per item, not a matter of instructions)
-        const int cgrid = std::max(1, std::min((n_rows_ + kCompactRows * kWavesPerBlock - 1) / (kCompactRows * kWavesPerBlock), device_cu_count(device_) * 16));
+        // Few, long rows (8 KB: an item is ~7 000 ids): several waves share an item -- where the item has no unused entry its copy is dealt out
+        // among them in steps of 1 024 ids.  (A row of n bytes has at most n ids, ~n / 4.5 on text: the split follows the bytes.)
+        int split = 1;
+        if (!dense_on_ && !wire_.hdr) {
+            const long long ids_per_item = (long long)kCompactRows * (in_.strings.n_chars / std::max<long long>(1, n_rows_)) / 4;
+            while (split < 16 && ids_per_item >= 2048ll * split && (long long)(n_rows_ / kCompactRows) * split * 2 <= std::max<long long>((long long)device_cu_count(device_) * 64, 1024)) split *= 2;
+        }
+        w.compact_split = split;
+        const long long units = ((long long)n_rows_ + kCompactRows - 1) / kCompactRows * split;
+        const int cgrid = int(std::max<long long>(1, std::min<long long>((units + kWavesPerBlock - 1) / kWavesPerBlock, (long long)device_cu_count(device_) * 16)));
         const RaggedSink rsink{d_ids_, d_begins_, d_ends_};
         if (dense_on_) {
             OVTK_LAUNCH(ws.marks, "row_width", row_width_kernel, std::min(64, (n_rows_ + kBlockThreads - 1) / kBlockThreads), kBlockThreads, s_, n_rows_, w, dense_);

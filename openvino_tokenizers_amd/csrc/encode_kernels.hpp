@@ -58,6 +58,7 @@ constexpr int32_t kRowPending = -1;  // row_used: lookup_span_kernel / lookup_ro
 
 struct EncodeWork {
     int32_t fold_tail;      // merge_kernel's last block also runs exact pieces + the row scan (no exact / count_scan launches)
+    int32_t compact_split;  // compact_kernel<RaggedSink>: waves that share a work item of kCompactRows rows (a power of two; > 1 for few, long rows)
     int32_t tile_sums;      // (with fold_tail, the large path) ... or nobody does: merge_kernel / wordpiece_deferred_kernel end without
                             // a ticket, an exact piece is worked out by the lane that finds it, and compact_kernel derives a tile's
                             // offset from tile_cnt itself (the sum of the counts in front of it) and the total in its block 0
@@ -1498,16 +1499,21 @@ __device__ __forceinline__ int32_t stage_get_t(const EncodeWork& w, int pos) {
 // per FOUR rows (compact_kernel 7.0 M -> see DESIGN 6 quad-cycles of a config-2 step's 45 M).
 constexpr int kFlatIds = kWave * 8;    // ids the LDS buffer holds: one 16-byte load per lane of 2-byte entries
 struct __attribute__((packed, aligned(1))) FlatBytes16 { uint32_t d[4]; };
+struct __attribute__((packed, aligned(1))) FlatBytes8 { uint32_t d[2]; };
+// part / split: EncodeWork::compact_split waves share an item (few, long rows); the copy's steps are dealt out among them, anything else
+// is part 0's.
 template <bool S16>
 __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSink& sink, int32_t* buf, const int (&cnt)[4], const int (&o)[4],
-                                             const int (&base)[4], const int (&used)[4], int row0) {
+                                             const int (&base)[4], const int (&used)[4], int row0, int part, int split) {
     constexpr int E = S16 ? 8 : 4;   // entries per 16 bytes
     const int l = lane_id();
     const int total_used = used[0] + used[1] + used[2] + used[3];
     if (used[0] < 0 || used[1] < 0 || used[2] < 0 || used[3] < 0 || base[1] != base[0] + used[0] || base[2] != base[1] + used[1] ||
         base[3] != base[2] + used[2])
         return false;
-    if (l < 4) {
+    const bool plain = total_used == cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (part != 0 && !plain) return true;   // (the squeeze is one wave's)
+    if (l < 4 && part == 0) {
         const int oo = l == 0 ? o[0] : (l == 1 ? o[1] : (l == 2 ? o[2] : o[3])), cc = l == 0 ? cnt[0] : (l == 1 ? cnt[1] : (l == 2 ? cnt[2] : cnt[3]));
         sink.row(row0 + l, oo, oo + cc);
     }
@@ -1521,33 +1527,40 @@ __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSi
                                                                                                                 // the stretch: the buffer has the slack)
         return FlatBytes16{{0u, 0u, 0u, 0u}};
     };
-    if (total_used == cnt[0] + cnt[1] + cnt[2] + cnt[3]) {
+    if (plain) {
         // No unused entry in the stretch (no piece of these rows was deferred, or each came to exactly the entries it had reserved -- with
-        // the six-id memo entries of round 5 that is nearly every item): a widening copy.  Every step stands on its own -- no prefix
-        // sum, no LDS, four steps' loads in flight before the first store -- where the squeeze below is a chain of one memory round
-        // trip per step (rows of 8 KB: 14 steps per item).
-        constexpr int U = 4;
-        for (int off0 = 0; off0 < total_used; off0 += U * kWave * E) {
-            FlatBytes16 x[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) x[u] = fetch(off0 + u * kWave * E);
+        // the six-id memo entries of round 5 that is nearly every item): a widening copy.  Every group of four entries stands on its own --
+        // no prefix sum, no LDS, a step's loads all in flight before its first store -- where the squeeze below is a chain of one memory
+        // round trip per step (rows of 8 KB: 14 steps per item).  A lane takes FOUR entries per load (8 bytes of u16 / 16 bytes of i32) and
+        // stores them as 16 bytes: every load and every store of the wave is one contiguous stretch (eight entries per lane and two
+        // stores 32 bytes apart were measured first: compact_kernel 19.9 -> 22.6 us).
+        constexpr int U = 4;   // groups of 4 x 64 entries in flight
+        for (int off0 = part * (U * kWave * 4); off0 < total_used; off0 += split * (U * kWave * 4)) {
+            uint32_t x[U][4];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int idx = off0 + u * kWave * E + l * E;
-                const int n_here = total_used - idx;
-                if (n_here <= 0) continue;
-                if (S16) {
-                    const FlatBytes16 lo{{x[u].d[0] & 0xFFFFu, x[u].d[0] >> 16, x[u].d[1] & 0xFFFFu, x[u].d[1] >> 16}};
-                    const FlatBytes16 hi{{x[u].d[2] & 0xFFFFu, x[u].d[2] >> 16, x[u].d[3] & 0xFFFFu, x[u].d[3] >> 16}};
-                    if (n_here >= E) {
-                        *reinterpret_cast<FlatBytes16*>(out + idx) = lo;
-                        *reinterpret_cast<FlatBytes16*>(out + idx + 4) = hi;
+                const int idx = off0 + (u * kWave + l) * 4;
+                x[u][0] = x[u][1] = x[u][2] = x[u][3] = 0u;
+                if (idx < total_used) {   // (may read up to 12 bytes behind the stretch: the buffer has the slack)
+                    if (S16) {
+                        const FlatBytes8 r = *reinterpret_cast<const FlatBytes8*>(stage_bytes + idx * 2);
+                        x[u][0] = r.d[0] & 0xFFFFu; x[u][1] = r.d[0] >> 16; x[u][2] = r.d[1] & 0xFFFFu; x[u][3] = r.d[1] >> 16;
                     } else {
-                        for (int i = 0; i < n_here; ++i) out[idx + i] = int32_t(i < 4 ? lo.d[i] : hi.d[i - 4]);
+                        const FlatBytes16 r = *reinterpret_cast<const FlatBytes16*>(stage_bytes + idx * 4);
+                        x[u][0] = r.d[0]; x[u][1] = r.d[1]; x[u][2] = r.d[2]; x[u][3] = r.d[3];
                     }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = off0 + (u * kWave + l) * 4;
+                const int n_here = total_used - idx;
+                if (n_here >= 4) {
+                    *reinterpret_cast<FlatBytes16*>(out + idx) = FlatBytes16{{x[u][0], x[u][1], x[u][2], x[u][3]}};
                 } else {
-                    if (n_here >= E) *reinterpret_cast<FlatBytes16*>(out + idx) = x[u];
-                    else for (int i = 0; i < n_here; ++i) out[idx + i] = int32_t(x[u].d[i]);
+                    if (n_here > 0) out[idx] = int32_t(x[u][0]);
+                    if (n_here > 1) out[idx + 1] = int32_t(x[u][1]);
+                    if (n_here > 2) out[idx + 2] = int32_t(x[u][2]);
                 }
             }
         }
@@ -1605,29 +1618,39 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
     const int n_waves = (solo ? 1 : int(gridDim.x)) * kWavesPerBlock;
     constexpr int kSubs = kRowTile / kCompactRows;
     const int n_items = ((n_rows + kRowTile - 1) / kRowTile) * kSubs;
-    for (int item = (solo ? 0 : int(blockIdx.x)) * kWavesPerBlock + wave_in_block(); item < n_items; item += n_waves) {
+    const int split = std::is_same<Sink, RaggedSink>::value && !solo && w.compact_split > 1 ? w.compact_split : 1;   // (a power of two)
+    for (int unit = (solo ? 0 : int(blockIdx.x)) * kWavesPerBlock + wave_in_block(); unit < n_items * split; unit += n_waves) {
+        const int item = unit / split, part = unit % split;
         const int tile = item / kSubs, sub = item % kSubs;
         const int rj = tile * kRowTile + l;
         const bool have = rj < n_rows;
         const int c = have ? w.row_cnt[rj] : 0;
         const int sv = have ? w.row_stage[rj] : 0;
         const int uv = have ? w.row_used[rj] : 0;
-        const int incl = wave_incl_sum(c);
         long long toff;
         if (w.tile_sums && !solo) {
             // the tile's offset = the counts of the tiles in front of it, summed here (tile_cnt: 4 bytes per 64 rows, hot in every L2;
-            // 16 bytes per lane and step -- the array has the slack).  What merge_kernel's last block did for everybody, at the price of
-            // a ticket and a scan on every call's chain.
+            // the array has the slack for 16-byte reads).  What merge_kernel's last block did for everybody, at the price of a ticket
+            // and a scan on every call's chain.  A lane takes sixteen tiles per step, its loads leave together with the row records'
+            // above -- before anything waits for those.
             int acc = 0;
-            for (int i0 = 0; i0 < tile; i0 += 4 * kWave) {
-                const int i = i0 + 4 * l;
-                const int4 v = *reinterpret_cast<const int4*>(w.tile_cnt + i);
-                acc += (i < tile ? v.x : 0) + (i + 1 < tile ? v.y : 0) + (i + 2 < tile ? v.z : 0) + (i + 3 < tile ? v.w : 0);
+            for (int i0 = 0; i0 < tile; i0 += 16 * kWave) {
+                const int i = i0 + 16 * l;
+                int4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    v[u] = i + 4 * u < tile ? *reinterpret_cast<const int4*>(w.tile_cnt + i + 4 * u) : int4{0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = i + 4 * u;
+                    acc += (j < tile ? v[u].x : 0) + (j + 1 < tile ? v[u].y : 0) + (j + 2 < tile ? v[u].z : 0) + (j + 3 < tile ? v[u].w : 0);
+                }
             }
             toff = wave_sum(acc);
         } else {
             toff = w.tile_off[tile];
         }
+        const int incl = wave_incl_sum(c);
         int cnt[kCompactRows], o[kCompactRows], base[kCompactRows], used[kCompactRows];
         int32_t v[kCompactRows][kCompactChunks];
 #pragma unroll
@@ -1645,8 +1668,9 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
         }
         if constexpr (std::is_same<Sink, RaggedSink>::value && kCompactRows == 4) {
             const int row0 = tile * kRowTile + sub * kCompactRows;
-            if (flat_buf && row0 + kCompactRows <= n_rows && compact_flat<S16>(w, sink, flat_buf, cnt, o, base, used, row0)) continue;
+            if (flat_buf && row0 + kCompactRows <= n_rows && compact_flat<S16>(w, sink, flat_buf, cnt, o, base, used, row0, part, split)) continue;
         }
+        if (part != 0) continue;   // (row by row: one wave's)
 #pragma unroll
         for (int q = 0; q < kCompactRows; ++q)
 #pragma unroll

@@ -151,6 +151,22 @@ def test_rows_longer_than_a_block(backend):
     fused_vs_oracle(backend, tok, rows_of(only), what="only long rows")
 
 
+def test_long_rows_share_a_work_item_of_compact_kernel(backend):
+    """Rows of ~4 300 bytes, 260 of them: compact_kernel's work items (four rows, ~4 000 ids) are shared by two waves
+    (EncodeWork::compact_split) -- where an item has no unused staging entry its copy is dealt out among them, an item with a deferred
+    piece is squeezed by the first alone.  Twice: the first call defers what the memo has not seen, the second runs on what was learned."""
+    rng = np.random.default_rng(54)
+    strings = [_filler(rng, 4300 + int(rng.integers(0, 64))) for _ in range(260)]
+    strings[17] = strings[17][:2000] + b"x" * 600 + strings[17][2600:]   # (a piece no memo entry holds: its item is squeezed on every call)
+    tok = BpeTok.load("gpt2_small")
+    pat = np.frombuffer(tok.pattern.encode(), np.uint8)
+    inputs = rows_of(strings)
+    ref = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(*[np.asarray(x) for x in inputs])[:5])
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
+    for call in range(2):
+        assert_same(ref, fused.evaluate(backend.data(inputs) + [pat], tok.consts), backend.host, f"long rows, call {call}")
+
+
 def test_rows_that_are_not_contiguous(backend):
     """begins / ends that leave gaps, overlap, or run backwards through the chars tensor: no block may span such a seam."""
     rng = np.random.default_rng(13)
