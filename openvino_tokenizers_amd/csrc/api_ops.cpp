@@ -813,9 +813,17 @@ int ovtk_trie_tokenizer_run(ovtk_trie_tokenizer* h, const ovtk_ragged_strings* i
     if (int rc = out_target(ws->out_a, out->begins, size_t(in->n_rows) * 4, mem, &d_b)) return rc;
     if (int rc = out_target(ws->out_b, out->ends, size_t(in->n_rows) * 4, mem, &d_e)) return rc;
     if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_i)) return rc;
-    if (int rc = scan_and_apply(*ws.ws, s, in->n_rows, TrieLen{r}, TrieApply{r, d_b, d_e, d_i},
+    // count walk (a lane per row) -> scan of the filed lengths -> write walk from the row's offset
+    if (int rc = ws->gen[6].ensure(size_t(in->n_rows) * 4)) return rc;
+    int32_t* lens = ws->gen[6].as<int32_t>();
+    const int each_grid = int((in->n_rows + kTileThreads - 1) / kTileThreads);
+    OVTK_LAUNCH(ws->marks, "trie_count", each_kernel<TrieCount>, each_grid, kTileThreads, s, (long long)in->n_rows, TrieCount{r, lens},
+                (const RunStatus*)nullptr, 0u);
+    if (int rc = scan_and_apply(*ws.ws, s, in->n_rows, FiledLen{lens}, RowOffsets{d_b, d_e, 0},
                                 (long long)std::min<int64_t>(out->data_capacity, INT32_MAX - 1), st, "trie_tokenizer"))
         return rc;
+    OVTK_LAUNCH(ws->marks, "trie_write", each_kernel<TrieWrite>, each_grid, kTileThreads, s, (long long)in->n_rows,
+                TrieWrite{r, d_b, d_i}, (const RunStatus*)st, kFlagOutCapacity | kFlagRange | kFlagItemsOverflow);
     if (int rc = finish_status(*ws.ws, s)) return rc;
     const uint32_t f = ws->host_status->flags;
     if (f & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
@@ -887,9 +895,12 @@ int ovtk_string_tensor_pack(const ovtk_strings* in, uint8_t* packed, int64_t cap
     if (in->n) {
         OVTK_LAUNCH(ws->marks, "check_strings", check_strings_kernel, grid_for_elems(in->n), kBlockThreads, s, in->begins, in->ends,
                     (long long)in->n, (long long)in->n_chars, st);
-        if (int rc = scan_and_apply(*ws.ws, s, in->n, PackLen{in->begins, in->ends, (long long)in->n_chars},
-                                    PackApply{in->begins, in->chars, header, d_packed + 8 + 4 * in->n}, cap, st, "string_pack"))
+        if (int rc = scan_and_apply(*ws.ws, s, in->n, PackLen{in->begins, in->ends, (long long)in->n_chars}, PackApply{header}, cap, st, "string_pack"))
             return rc;
+        // the bytes: a wave per string, 16 bytes per lane (until round 5 a lane per string, byte by byte, inside the scan's apply pass)
+        OVTK_LAUNCH(ws->marks, "string_pack_copy", each_wave_kernel<PackCopy>,
+                    int(std::min<long long>((in->n + kTileThreads / kWave - 1) / (kTileThreads / kWave), (long long)device_cu_count(device) * 16)), kTileThreads, s,
+                    (long long)in->n, PackCopy{in->begins, in->chars, header, d_packed + 8 + 4 * in->n}, (const RunStatus*)st, kFlagOutCapacity | kFlagRange);
     }
     if (int rc = finish_status(*ws.ws, s)) return rc;
     if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside the chars tensor");
@@ -1030,9 +1041,15 @@ int ovtk_utf8_validate(const ovtk_strings* in, int replace_mode, ovtk_strings_ou
     OVTK_LAUNCH(ws->marks, "check_strings", check_strings_kernel, grid_for_elems(in->n), kBlockThreads, s, b, e,
                 (long long)in->n, (long long)in->n_chars, st);
     const long long cap = std::min<long long>(out->chars_capacity, INT32_MAX - 1) - base;
-    if (int rc = scan_and_apply(*ws.ws, s, in->n, Utf8Len{b, e, c, (long long)in->n_chars, replace_mode != 0},
-                                Utf8Apply{b, e, c, d_b, d_e, d_c, (long long)base, replace_mode != 0}, cap, st, "utf8_validate"))
-        return rc;
+    // a wave per string counts (the walk as mask algebra, ops_kernels.hpp) -> scan of the filed lengths -> a wave per string writes
+    if (int rc = ws->gen[6].ensure(size_t(in->n) * 4)) return rc;
+    int32_t* lens = ws->gen[6].as<int32_t>();
+    const int wave_grid = int(std::min<long long>((in->n + kTileThreads / kWave - 1) / (kTileThreads / kWave), (long long)device_cu_count(device) * 16));
+    OVTK_LAUNCH(ws->marks, "utf8_count", each_wave_kernel<Utf8WaveCount>, wave_grid, kTileThreads, s, (long long)in->n,
+                Utf8WaveCount{b, e, c, (long long)in->n_chars, replace_mode != 0, lens}, (const RunStatus*)nullptr, 0u);
+    if (int rc = scan_and_apply(*ws.ws, s, in->n, FiledLen{lens}, RowOffsets{d_b, d_e, (long long)base}, cap, st, "utf8_validate")) return rc;
+    OVTK_LAUNCH(ws->marks, "utf8_write", each_wave_kernel<Utf8WaveWrite>, wave_grid, kTileThreads, s, (long long)in->n,
+                Utf8WaveWrite{b, e, c, d_b, d_c, replace_mode != 0}, (const RunStatus*)st, kFlagOutCapacity | kFlagRange);
     if (int rc = finish_status(*ws.ws, s)) return rc;
     if (ws->host_status->flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside the chars tensor");
     if (ws->host_status->flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "UTF8Validate: output chars buffer too small");

@@ -845,23 +845,36 @@ struct TrieRows {
         }
     }
 };
-struct TrieLen {
+// A lane per row, every row its own lane (each_kernel): the count walk files the row's length, the scan runs over the filed
+// lengths, the write walk starts at the row's offset -- two walks per row instead of the three the tile kernels made of it.
+struct TrieCount {
     TrieRows r;
-    __device__ long long operator()(long long row) const {
-        long long n = 0;
+    int32_t* lens;
+    __device__ void operator()(long long row) const {
+        int32_t n = 0;
         r.walk(row, [&](int) { ++n; });
-        return n;
+        lens[row] = n;
     }
 };
-struct TrieApply {
-    TrieRows r;
+struct FiledLen {
+    const int32_t* lens;
+    __device__ long long operator()(long long i) const { return lens[i]; }
+};
+struct RowOffsets {
     int32_t* out_begins;
     int32_t* out_ends;
+    long long base;
+    __device__ void operator()(long long i, long long off, long long len) const {
+        out_begins[i] = int32_t(base + off);
+        out_ends[i] = int32_t(base + off + len);
+    }
+};
+struct TrieWrite {
+    TrieRows r;
+    const int32_t* out_begins;
     int32_t* out_ids;
-    __device__ void operator()(long long row, long long off, long long len) const {
-        out_begins[row] = int32_t(off);
-        out_ends[row] = int32_t(off + len);
-        int32_t* dst = out_ids + off;
+    __device__ void operator()(long long row) const {
+        int32_t* dst = out_ids + out_begins[row];
         r.walk(row, [&](int tok) { *dst++ = tok; });
     }
 };
@@ -870,74 +883,111 @@ struct TrieApply {
 // src/utf8_validate.cpp:18-143 walked symbol by symbol instead of byte by byte: a lead byte promises `need`
 // continuation bytes; when one is missing (or the string ends) the symbol is replaced once and the offending byte
 // is read again as a lead (:93-104, :134-137); a complete but overlong symbol is replaced once per byte (:111-121).
-// sink.copy(j, k): k input bytes from offset j are kept; sink.bad(times): `times` U+FFFD (replace mode only).
-template <class Sink>
-__device__ __forceinline__ void utf8_walk(const uint8_t* s, int len, Sink& sink) {
-    int j = 0;
-    while (j < len) {
-        const uint32_t c = s[j];
-        if (c < 0x80) { sink.copy(j, 1); ++j; continue; }
-        const int need = (c >> 5) == 0x6 ? 1 : (c >> 4) == 0xE ? 2 : (c >> 3) == 0x1E ? 3 : 0;
-        if (need == 0) { sink.bad(1); ++j; continue; }
-        uint32_t cp = c & (0x3Fu >> need);
-        int t = 1;
-        for (; t <= need && j + t < len && (s[j + t] >> 6) == 0x2; ++t) cp = (cp << 6) | (s[j + t] & 0x3Fu);
-        if (t <= need) { sink.bad(1); j += t; continue; }
-        const uint32_t min_cp = need == 1 ? 0x80u : need == 2 ? 0x800u : 0x10000u;
-        if (cp < min_cp) sink.bad(need + 1); else sink.copy(j, need + 1);
-        j += need + 1;
+// (Until round 5 a lane walked its string that way, three times over -- count, count again, write --, four strings to a thread: 2.1 ms for
+// a config-2 batch.)
+// ---- that walk as arithmetic on bit masks, a wave per string, 64 bytes per step (round 5).
+// The walk only ever steps over continuation bytes (10xxxxxx) -- behind a lead, as many as the lead asks for and no more -- so every
+// other byte starts a symbol wherever the walk stood before, and what becomes of a byte is decided by the three bytes on either side
+// of it.  With C = the continuation bytes of a 64-byte window and L1 / L2 / L3 = the leads that ask for one / two / three of them
+// (bit i = byte i; bytes behind the string's end are in no mask):
+//   c_k = "the k bytes behind me are continuation bytes" = c_{k-1} & (C >> k), the next window's first three bits shifted in;
+//   complete = L1 & c1 | L2 & c2 | L3 & c3;  overlong (a complete symbol below its length's smallest code point, :111-121) is a
+//   property of the lead and the byte behind it: C0 / C1, E0 + a byte below A0, F0 + a byte below 90;
+//   a valid lead (complete, not overlong) and its continuation bytes are COPIED; an overlong one brings a replacement per byte and
+//   its continuation bytes nothing; an incomplete lead ONE replacement, and the continuation bytes it did find (c1, c2) nothing;
+//   a continuation byte none of them claims, and a byte F8..FF, one replacement each.
+// The masks live in scalar registers; a lane's share is its byte, two compares and -- in the write pass -- the counts below it.
+struct Utf8Window {
+    uint64_t copy, bad1, o1, o2, o3;   // bytes kept | positions worth one replacement | overlong leads of 1 / 2 / 3 continuation bytes
+};
+// f(w0, c, in, m): window [w0, w0 + 64) of the string, the lane's byte c (in: inside the string), the window's masks
+template <class F>
+__device__ __forceinline__ void utf8_windows(const uint8_t* s, int len, F&& f) {
+    const int l = lane_id();
+    bool in = l < len;
+    uint32_t c = in ? s[l] : 0u;
+    uint64_t carry_keep = 0, carry_drop = 0;
+    for (int w0 = 0; w0 < len; w0 += kWave) {
+        const int ni = w0 + kWave + l;
+        const bool in_n = ni < len;
+        const uint32_t c_n = in_n ? s[ni] : 0u;   // the next window's bytes: on their way while this one is worked out
+        const uint64_t C = __ballot(in && (c & 0xC0u) == 0x80u), Cn = __ballot(in_n && (c_n & 0xC0u) == 0x80u);
+        const uint64_t A = __ballot(in && c < 0x80u);
+        Utf8Window m;
+        if (wave_uniform(int(A == __ballot(in)))) {   // nothing but ASCII (and nothing carried into it: a carry needs a continuation byte here)
+            m = Utf8Window{A, 0, 0, 0, 0};
+            carry_keep = carry_drop = 0;
+        } else {
+            const bool is1 = in && (c >> 5) == 0x6u, is2 = in && (c >> 4) == 0xEu, is3 = in && (c >> 3) == 0x1Eu;
+            const uint64_t L1 = __ballot(is1), L2 = __ballot(is2), L3 = __ballot(is3), X = __ballot(in && c >= 0xF8u);
+            const uint32_t next0 = uint32_t(wave_readlane(int(c_n), 0));   // (the byte behind lane 63's: the next window's first, 0 behind the end)
+            uint32_t n1 = uint32_t(__shfl_down(int(c), 1));
+            if (l == kWave - 1) n1 = next0;
+            const bool over = (is1 && (c & 0x1Eu) == 0u) || (is2 && c == 0xE0u && n1 < 0xA0u) || (is3 && c == 0xF0u && n1 < 0x90u);
+            const uint64_t OV = __ballot(over);
+            const uint64_t c1 = (C >> 1) | (Cn << 63), c2 = c1 & ((C >> 2) | (Cn << 62)), c3 = c2 & ((C >> 3) | (Cn << 61));
+            const uint64_t complete = (L1 & c1) | (L2 & c2) | (L3 & c3);
+            const uint64_t I = (L1 | L2 | L3) & ~complete, O = complete & OV, V = complete & ~OV;
+            const uint64_t V23 = V & (L2 | L3), V3 = V & L3, O23 = O & (L2 | L3), O3 = O & L3, I1 = I & c1, I2 = I & c2;
+            const uint64_t keep = (V << 1) | (V23 << 2) | (V3 << 3) | carry_keep;
+            const uint64_t drop = (O << 1) | (O23 << 2) | (O3 << 3) | (I1 << 1) | (I2 << 2) | carry_drop;
+            carry_keep = (V >> 63) | (V23 >> 62) | (V3 >> 61);
+            carry_drop = (O >> 63) | (O23 >> 62) | (O3 >> 61) | (I1 >> 63) | (I2 >> 62);
+            m.copy = A | V | keep;
+            m.bad1 = X | I | (C & ~keep & ~drop);
+            m.o1 = O & L1;
+            m.o2 = O & L2;
+            m.o3 = O3;
+        }
+        f(w0, c, in, m);
+        c = c_n;
+        in = in_n;
     }
 }
-
-struct Utf8Count {
-    long long n = 0;
-    int replace;
-    __device__ void copy(int, int k) { n += k; }
-    __device__ void bad(int times) { n += replace ? 3 * times : 0; }
-};
-struct Utf8Write {
-    const uint8_t* src;
-    uint8_t* dst;
-    int replace;
-    __device__ void copy(int j, int k) {
-        for (int t = 0; t < k; ++t) dst[t] = src[j + t];
-        dst += k;
-    }
-    __device__ void bad(int times) {
-        if (!replace) return;
-        for (int t = 0; t < times; ++t) { dst[0] = 0xEF; dst[1] = 0xBF; dst[2] = 0xBD; dst += 3; }
-    }
-};
-
-struct Utf8Len {
+__device__ __forceinline__ int utf8_window_bytes(const Utf8Window& m, int replace) {
+    return __popcll(m.copy) + (replace ? 3 * (__popcll(m.bad1) + 2 * __popcll(m.o1) + 3 * __popcll(m.o2) + 4 * __popcll(m.o3)) : 0);
+}
+struct Utf8WaveCount {   // each_wave_kernel: the string's length after validation
     const int32_t* begins;
     const int32_t* ends;
     const uint8_t* chars;
     long long n_chars;
     int replace;
-    __device__ long long operator()(long long i) const {
+    int32_t* lens;
+    __device__ void operator()(long long i) const {
         const long long b = begins[i], e = ends[i];
-        if (b < 0 || e < b || e > n_chars) return 0;  // flagged by check_strings_kernel
-        Utf8Count sink{0, replace};
-        utf8_walk(chars + b, int(e - b), sink);
-        return sink.n;
+        int total = 0;
+        if (!(b < 0 || e < b || e > n_chars))   // (else: flagged by check_strings_kernel)
+            utf8_windows(chars + b, int(e - b), [&](int, uint32_t, bool, const Utf8Window& m) { total += utf8_window_bytes(m, replace); });
+        if (lane_id() == 0) lens[i] = total;
     }
 };
-struct Utf8Apply {
+struct Utf8WaveWrite {   // each_wave_kernel, behind the scan: the string's bytes to out_chars + out_begins[i]
     const int32_t* begins;
     const int32_t* ends;
     const uint8_t* chars;
-    int32_t* out_begins;
-    int32_t* out_ends;
+    const int32_t* out_begins;
     uint8_t* out_chars;
-    long long base;  // begins[0]: the reference's offsets start there (:46)
     int replace;
-    __device__ void operator()(long long i, long long off, long long len) const {
-        out_begins[i] = int32_t(base + off);
-        out_ends[i] = int32_t(base + off + len);
-        if (len == 0) return;
-        Utf8Write sink{chars + begins[i], out_chars + base + off, replace};
-        utf8_walk(chars + begins[i], ends[i] - begins[i], sink);
+    __device__ void operator()(long long i) const {
+        uint8_t* dst = out_chars + out_begins[i];
+        const int rep = replace;
+        utf8_windows(chars + begins[i], ends[i] - begins[i], [&](int, uint32_t c, bool, const Utf8Window& m) {
+            const int l = lane_id();
+            int at = rank_below(m.copy);
+            int times = 0;
+            if (rep) {
+                at += 3 * (rank_below(m.bad1) + 2 * rank_below(m.o1) + 3 * rank_below(m.o2) + 4 * rank_below(m.o3));
+                times = int((m.bad1 >> l) & 1ull) + 2 * int((m.o1 >> l) & 1ull) + 3 * int((m.o2 >> l) & 1ull) + 4 * int((m.o3 >> l) & 1ull);
+            }
+            if ((m.copy >> l) & 1ull) dst[at] = uint8_t(c);
+            for (int t = 0; t < times; ++t) {   // U+FFFD
+                dst[at + 3 * t] = 0xEF;
+                dst[at + 3 * t + 1] = 0xBF;
+                dst[at + 3 * t + 2] = 0xBD;
+            }
+            dst += utf8_window_bytes(m, rep);
+        });
     }
 };
 
@@ -1173,16 +1223,27 @@ struct PackLen {
         return (b < 0 || e < b || e > n_chars) ? 0 : e - b;  // flagged by check_strings_kernel
     }
 };
-struct PackApply {
+struct PackApply {   // the end offsets (the scan's apply pass); the bytes: PackCopy, a wave per string
+    int32_t* header;  // [n, begin_0, end_0 .. end_{n-1}]
+    __device__ void operator()(long long i, long long off, long long len) const { header[2 + i] = int32_t(off + len); }
+};
+struct __attribute__((packed, aligned(1))) CopyBytes16 { uint32_t d[4]; };
+// len bytes from src to dst by the 64 lanes of a wave: 16 bytes per lane and step at any alignment, the last bytes one by one
+__device__ __forceinline__ void wave_copy_bytes(const uint8_t* src, uint8_t* dst, long long len) {
+    const int l = lane_id();
+    long long k = 16ll * l;
+    for (; k + 16 <= len; k += 16 * kWave) *reinterpret_cast<CopyBytes16*>(dst + k) = *reinterpret_cast<const CopyBytes16*>(src + k);
+    if (k < len)   // (one lane: the first whose 16 bytes do not fit)
+        for (long long t = k; t < len; ++t) dst[t] = src[t];
+}
+struct PackCopy {
     const int32_t* begins;
     const uint8_t* chars;
-    int32_t* header;  // [n, begin_0, end_0 .. end_{n-1}]
+    const int32_t* header;
     uint8_t* bytes;
-    __device__ void operator()(long long i, long long off, long long len) const {
-        header[2 + i] = int32_t(off + len);
-        const uint8_t* src = chars + begins[i];
-        uint8_t* dst = bytes + off;
-        for (long long k = 0; k < len; ++k) dst[k] = src[k];
+    __device__ void operator()(long long i) const {
+        const long long off = header[1 + i], end = header[2 + i];   // (header[1] = 0: the first string's begin)
+        wave_copy_bytes(chars + begins[i], bytes + off, end - off);
     }
 };
 static __global__ __launch_bounds__(kWave) void pack_header_kernel(int32_t* header, int32_t n) {

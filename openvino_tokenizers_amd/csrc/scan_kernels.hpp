@@ -111,4 +111,21 @@ static __global__ __launch_bounds__(kTileThreads) void tile_apply_kernel(long lo
     }
 }
 
+// f(i) for every i < n: one LANE per element (an element's work is a serial walk: the tile kernels above give a thread
+// kScanPerThread elements in a row, a quarter of the lanes there could be), or one WAVE per element (all 64 lanes call f(i): an
+// element is a string whose bytes the lanes share).  Round 5: UTF8Validate, StringTensorPack and TrieTokenizer ran their walks
+// inside the tile kernels -- twice in the apply pass -- at 2.1 / 0.9 / 15.6 ms for a config-2 batch (tools/ops_timing.py).
+template <class F>
+static __global__ __launch_bounds__(kTileThreads) void each_kernel(long long n, F f, const RunStatus* status, uint32_t skip_flags) {
+    if (status && (status->flags & skip_flags)) return;
+    const long long i = (long long)blockIdx.x * kTileThreads + threadIdx.x;
+    if (i < n) f(i);
+}
+template <class F>
+static __global__ __launch_bounds__(kTileThreads) void each_wave_kernel(long long n, F f, const RunStatus* status, uint32_t skip_flags) {
+    if (status && (status->flags & skip_flags)) return;
+    const long long stride = (long long)gridDim.x * (kTileThreads / kWave);
+    for (long long i = (long long)blockIdx.x * (kTileThreads / kWave) + wave_in_block(); i < n; i += stride) f(i);
+}
+
 }  // namespace ovtk

@@ -69,3 +69,23 @@ def test_errors(backend):
     assert ei.value.code == L.E_RANGE
     out = UTF8Validate(lib=backend.lib).evaluate([np.zeros(0, np.int32), np.zeros(0, np.int32), c])
     assert out[0].size == 0 and out[2].size == 0
+
+
+@pytest.mark.parametrize("replace", [False, True])
+def test_symbols_across_the_64_byte_windows(backend, replace):
+    """The kernel works a string through in windows of 64 bytes (ops_kernels.hpp utf8_windows): every kind of symbol -- valid, overlong,
+    cut short, stray continuation bytes, leads behind leads -- at every offset around the window edges, and at the string's end."""
+    seqs = [b"\xc3\xa9", b"\xe5\x85\x83", b"\xf0\x9f\x98\x81", b"\xc0\xaf", b"\xc1\xbf", b"\xe0\x80\xaf", b"\xe0\x9f\xbf", b"\xe0\xa0\x80",
+            b"\xf0\x80\x80\xaf", b"\xf0\x8f\xbf\xbf", b"\xf0\x90\x80\x80", b"\xf7\xbf\xbf\xbf", b"\xc3", b"\xe5\x85", b"\xe5", b"\xf0\x9f\x98", b"\xf0\x9f",
+            b"\xf0", b"\x80", b"\x80\x80\x80\x80", b"\xc3\xa9\x80", b"\xe5\x85\x83\xbf\xbf", b"\xf8\x80", b"\xff", b"\xc3\xc3\xa9", b"\xe5\xc3\xa9",
+            b"\xf0\xe5\x85\x83", b"\xe5\x85\xc3", b"\xf0\x9f\x98\xf0\x9f\x98\x81", b"\xed\xa0\x80", b"\xf4\x90\x80\x80"]
+    strings = []
+    for k in list(range(57, 68)) + [0, 1, 124, 126, 127, 128, 191]:
+        for q in seqs:
+            strings.append(b"a" * k + q)                 # ... at the string's end
+            strings.append(b"a" * k + q + b"z" * 5)      # ... inside
+            strings.append(b"\xc3\xa9" * (k // 2) + b"b" * (k % 2) + q + b"\xe5\x85\x83")   # ... with carries on both sides
+    b, e, c = O.pack_strings(strings)
+    ref = O.utf8_validate(b, e, c, replace)
+    got = UTF8Validate(replace_mode=replace, lib=backend.lib).evaluate(backend.data([b, e, c]))
+    assert_same(list(ref), got, backend.host, "UTF8Validate at the window edges")

@@ -141,11 +141,12 @@ def main():
     t_out = timed("Truncate(max_length=64, right)", lambda: tc.evaluate([ib, ie, ids, np.array([max_len], np.int32), b"right", b"longest_first"]),
                   16 * n, lambda out: same(ref_t[0][:2], [to_np(out[0])[:k], to_np(out[1])[:k]]), "offsets only: the data tensor passes through")
     bos = (np.array([0], np.int32), np.array([1], np.int32), np.array([50256], np.int32))
+    bos_d = bos if args.emu else tuple(torch.as_tensor(x, device=dev) for x in bos)   # (constants of the graph: resident like everything else)
     cs = CombineSegments(lib=lib)
     seg_ids = np.array([0, 0, 0], np.int32)
     ref_c = O.combine_segments([bos, (ref_t[0][0], ref_t[0][1], idh), bos], seg_ids)
     kept = int(np.minimum(ieh - ibh, max_len).sum())
-    c_out = timed("CombineSegments(bos + truncated ids + eos)", lambda: cs.evaluate(list(bos) + [t_out[0], t_out[1], ids] + list(bos) + [seg_ids]),
+    c_out = timed("CombineSegments(bos + truncated ids + eos)", lambda: cs.evaluate(list(bos_d) + [t_out[0], t_out[1], ids] + list(bos_d) + [seg_ids]),
                   4 * kept + 2 * 4 * (kept + 2 * n) + 16 * n,
                   lambda out: same(ref_c[:2], [to_np(out[0])[:k], to_np(out[1])[:k]]) and same([ref_c[2]], [to_np(out[2])], upto=len(ref_c[2])),
                   "ids + segment ids out")
@@ -156,7 +157,7 @@ def main():
           4 * (kept + 2 * n) + 5 * n * T + 8 * n, lambda out: same([ref_d[0]], [to_np(out[0])[:k]]), f"T = {T}: input_ids i32 + mask u8")
     tail = FusedEncodeTail(max_length=max_len, lib=lib)
     timed("ovtk_encode_tail_run (Truncate -> CombineSegments -> RaggedToDense x 2)",
-          lambda: tail.evaluate([bos, (ib, ie, ids), bos], seg_ids, truncated=(1,), pad_value=50256, target_dim=T),
+          lambda: tail.evaluate([bos_d, (ib, ie, ids), bos_d], seg_ids, truncated=(1,), pad_value=50256, target_dim=T),
           4 * kept + 9 * n * T + 8 * n, lambda out: same([ref_d[0]], [to_np(out[0])[:k]]),
           "one call, one kernel behind the width measurement; input_ids + attention_mask + token_type_ids")
     print(json.dumps({"batch": {"rows": n, "text_bytes": n_c, "ids": n_t, "ids_kept_by_truncate": kept}}))
