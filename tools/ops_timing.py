@@ -114,6 +114,14 @@ def main():
     rs_out = timed("RegexSplit(isolate, GPT-2 pattern)", lambda: rs.evaluate(d + [pat]), n_c + 16 * n + 8 * (n_c // 4),
                    lambda out: same(ref_rs[:2], [to_np(out[0])[:k], to_np(out[1])[:k]]) and same([ref_rs[2], ref_rs[3]], [to_np(out[2]), to_np(out[3])], upto=len(ref_rs[2])),
                    "the op alone: pieces as begins / ends (inside the fused encode the pieces never exist)")
+    # ---- BPETokenizer, the op (src/bpe_tokenizer.cpp:47-164): the pieces of the RegexSplit above in, ragged ids out -- what a graph
+    # that is not fused runs behind RegexSplit
+    bpe_op = BPETokenizer(**tok.attrs, lib=lib)
+    ref_bpe = tok.oracle()(*ref_rs[:5])
+    n_pieces = len(rs_out[2])
+    timed("BPETokenizer (pre-split pieces)", lambda: bpe_op.evaluate(list(rs_out[:5]) + tok.consts), n_c + 8 * n_pieces + 16 * n + 4 * (n_c // 4),
+          lambda out: same(ref_bpe[:2], [to_np(out[0])[:k], to_np(out[1])[:k]]) and same([ref_bpe[2]], [to_np(out[2])], upto=len(ref_bpe[2])),
+          f"{n_pieces} pieces: lookup_kernel<kPieces> -> merge_kernel -> compact_kernel")
     del rs_out, sp_out
     # ---- StringTensorPack / Unpack (src/string_tensor_pack.cpp:40-86, string_tensor_unpack.cpp:45-78)
     pk = StringTensorPack(lib=lib)
