@@ -1413,6 +1413,10 @@ struct DenseSink {
     int32_t pre[kDenseAffix], suf[kDenseAffix];
     int32_t T;           // (set by start)
     __device__ __forceinline__ void start(const RunStatus* st) { T = st->width; }
+    // (constant subscripts only: indexed by a lane's value the arrays -- and with them the whole struct -- went to scratch memory, and
+    // every field was fetched from there again wherever it was used: 164 scratch loads in compact_kernel<DenseSink>)
+    __device__ __forceinline__ int32_t pre_at(int k) const { return k == 0 ? pre[0] : (k == 1 ? pre[1] : (k == 2 ? pre[2] : pre[3])); }
+    __device__ __forceinline__ int32_t suf_at(int k) const { return k == 0 ? suf[0] : (k == 1 ? suf[1] : (k == 2 ? suf[2] : suf[3])); }
     __device__ __forceinline__ void row(int, int, int) const {}
     __device__ __forceinline__ void id(int r, int cnt, int j, int, int32_t v) const {
         const int keep = cnt < max_length ? cnt : max_length, first = trunc_left ? cnt - keep : 0;
@@ -1430,8 +1434,8 @@ struct DenseSink {
             const bool inside = k >= 0 && k < len;
             if (mask) mask[(long long)r * T + c] = inside ? uint8_t(1) : uint8_t(0);
             if (!inside) ids[(long long)r * T + c] = pad_value;
-            else if (k < n_pre) ids[(long long)r * T + c] = pre[k];
-            else if (k >= n_pre + keep) ids[(long long)r * T + c] = suf[k - n_pre - keep];
+            else if (k < n_pre) ids[(long long)r * T + c] = pre_at(k);
+            else if (k >= n_pre + keep) ids[(long long)r * T + c] = suf_at(k - n_pre - keep);
         }
     }
     __device__ __forceinline__ void finish(int, const RunStatus*) const {}
@@ -1628,7 +1632,9 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
         const int sv = have ? w.row_stage[rj] : 0;
         const int uv = have ? w.row_used[rj] : 0;
         long long toff;
-        if (w.tile_sums && !solo) {
+        if constexpr (std::is_same<Sink, DenseSink>::value) {
+            toff = 0;   // (a dense cell's place follows from its row and column alone)
+        } else if (w.tile_sums && !solo) {
             // the tile's offset = the counts of the tiles in front of it, summed here (tile_cnt: 4 bytes per 64 rows, hot in every L2;
             // the array has the slack for 16-byte reads).  What merge_kernel's last block did for everybody, at the price of a ticket
             // and a scan on every call's chain.  A lane takes sixteen tiles per step, its loads leave together with the row records'

@@ -227,12 +227,13 @@ def test_encode_dense_equals_the_chain(backend, with_special):
             op = FusedEncodeDense(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib),
                                   SpecialTokensSplit(lib=backend.lib) if with_special else None, max_length=max_length, trunc_side=side,
                                   pad_right=pad_right, pad_value=50256, prefix=pre, suffix=suf)
-            got = op.evaluate(backend.data(inputs), tok.pattern_u8(), tok.consts, special_pattern=u8(pat) if with_special else None, target_dim=target,
-                              row_capacity=max(width, 1))
-            what = f"dense: special {with_special}, {n_rows} rows, max_length {max_length} {side}, pad_right {pad_right}, target {target}"
-            assert backend.host(got[0]).shape == ref_ids.shape, what
-            assert np.array_equal(backend.host(got[0]), ref_ids), what
-            assert np.array_equal(backend.host(got[1]), ref_mask.astype(bool)), what
+            for call in range(2):   # (the second call runs on what the memo learned: rows without unused staging entries take dense_row_direct)
+                got = op.evaluate(backend.data(inputs), tok.pattern_u8(), tok.consts, special_pattern=u8(pat) if with_special else None, target_dim=target,
+                                  row_capacity=max(width, 1))
+                what = f"dense: special {with_special}, {n_rows} rows, max_length {max_length} {side}, pad_right {pad_right}, target {target}, call {call}"
+                assert backend.host(got[0]).shape == ref_ids.shape, what
+                assert np.array_equal(backend.host(got[0]), ref_ids), what
+                assert np.array_equal(backend.host(got[1]), ref_mask.astype(bool)), what
     # too little room: OVTK_E_CAPACITY
     from openvino_tokenizers_amd import _lib as L
     op = FusedEncodeDense(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib))
