@@ -167,6 +167,25 @@ def test_long_rows_share_a_work_item_of_compact_kernel(backend):
         assert_same(ref, fused.evaluate(backend.data(inputs) + [pat], tok.consts), backend.host, f"long rows, call {call}")
 
 
+def test_apostrophe_and_one_letter_at_the_end_of_a_full_block(backend):
+    """a chain's LAST block of exactly 2 048 bytes that ends in an apostrophe and r / v / l -- the contraction rules
+    ('re, 've, 'll) look one byte further, which is behind the block AND behind the text: whatever stands there (an `e` or an `l` left by
+    the block before, in the packed-byte form of round 4) must not make the two bytes one piece.  Rows of exactly 2 048 bytes, chains of
+    rows that add up to 2 048 and to 4 096, each followed by rows that begin with the letters that would complete the contraction."""
+    rng = np.random.default_rng(55)
+    strings = []
+    for tail in (b"'r", b"'v", b"'l", b"'R", b"'L", b"x'"):
+        body = _filler(rng, 2048 - len(tail) - 1) + b" "
+        strings += [b"e" * 40 + b" l" * 30, body[:2048 - len(tail)] + tail, b"e", b"ll", b"le"]          # one row = one full block
+        strings += [body[:1000], body[1000:2048 - len(tail)] + tail, b"e e e", b"l"]                      # two rows = one full block
+        strings += [_filler(rng, 2048), body[:2048 - len(tail)] + tail, b"e"]                              # the chain's second block
+    strings += [_filler(rng, int(rng.integers(1, 200))) for _ in range(300 - len(strings))]
+    for s_ in strings:
+        assert len(s_) >= 1
+    tok = BpeTok.load("gpt2_small")
+    fused_vs_oracle(backend, tok, rows_of(strings), what="apostrophe + letter at a full block's end")
+
+
 def test_rows_that_are_not_contiguous(backend):
     """begins / ends that leave gaps, overlap, or run backwards through the chars tensor: no block may span such a seam."""
     rng = np.random.default_rng(13)
