@@ -102,7 +102,7 @@ struct ovtk_bpe {
     DevBuf root, edges, merges, new_id, bf, pieces, memo_room, store, store_room;
     int32_t store_capacity = 0;  // entries the piece store may take
     size_t memo_entries = 0;
-    int32_t memo_capacity = 0;  // entries the device may add (cache_capacity)
+    int32_t memo_capacity = 0;  // entries the device may add (memo_learn: cache_capacity, or as many as the store holds)
     bool narrow_ids = false;  // every token id < 65536: merge_kernel keeps ids as u16 in LDS
     bool stage16 = false;     // every token id < 65535: the staging entries of a call are u16 (0xFFFF = unused entry)
     // calls that still leave the piece store out: set to 32 after four calls in a row in which fewer than one probe in eight
@@ -116,7 +116,7 @@ int run_encode(const ovtk_regex_split* split, const ovtk_bpe* bpe, const ovtk_ra
 
 // The piece memo (tables.hpp PieceEntry): BPE(t) for every vocabulary token t used as a whole piece, computed by the
 // device BPE itself -- the handle (still without memo) encodes its own vocabulary, one token per row -- plus, filled
-// while encoding, up to cache_capacity pieces that take several tokens.  It is the parallel-machine form of the
+// while encoding, pieces that take several tokens (how many: memo_learn, below).  It is the parallel-machine form of the
 // reference's piece cache (bpe_tokenizer.cpp:197-205,331-338): the same pure function piece -> ids, so results never
 // depend on what was encoded before; only the time does.
 // memo_learn (ovtk_bpe_params): what the first level may learn.  < 0: exactly cache_capacity entries, the reference's count;
@@ -147,7 +147,7 @@ int build_memo(ovtk_bpe* h, const ovtk_strings& vocab, int64_t cache_capacity, i
     build_piece_table(view_of(vocab), ob.data(), oe.data(), ids.data(), host,
                       size_t(std::min<int64_t>(std::max<int64_t>(cache_capacity, 0), 2 * V + 65536)), packed6);
     if (int rc = h->pieces.upload(host.slots.data(), host.slots.size() * sizeof(PieceEntry))) return rc;
-    // The dynamic part (memo_insert in encode_kernels.hpp): up to cache_capacity further pieces, the ones the vocabulary
+    // The dynamic part (memo_insert in encode_kernels.hpp): up to `learn` further pieces, the ones the vocabulary
     // needs more than one token for, kept the first time merge_kernel computes them -- the reference's rule, its numbers.
     const int64_t store_cap = piece_store_capacity(V, resolve_memo_store(memo_store));
     const int64_t learn = memo_learn < 0 ? cache_capacity : (memo_learn > 0 ? memo_learn : std::max<int64_t>(cache_capacity, store_cap));

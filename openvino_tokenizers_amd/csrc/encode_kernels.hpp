@@ -17,6 +17,10 @@
 //   compact_kernel              row offset = tile offset + in-tile prefix (rebuilt by the wave), begins/ends, and
 //                               staging -> caller's ids buffer (unused entries = kEmptyId are squeezed out by ballot
 //                               compaction)
+// The fused encode of the pattern families (span_kernel.hpp) runs lookup_span_kernel -> lookup_kernel<kFused> (only_pending: the rows the
+// span kernel leaves) -> merge_kernel -> compact_kernel.  With EncodeWork::fold_tail the exact pieces and the row scan are merge_kernel's
+// last block's (no exact / count_scan launches); with EncodeWork::tile_sums (round 5: up to 1 024 tiles) there is no last block either --
+// an exact piece is its lane's, and compact_kernel derives a tile's offset from the tile counts itself.
 #pragma once
 
 #include <cstddef>
@@ -296,7 +300,7 @@ __device__ __forceinline__ int memo_resolve(const MemoFetch& f, uint64_t k0, uin
     return (x == 0u && c0 <= uint32_t(kPieceMaxIds)) ? int(c0) : -1;
 }
 // merge_kernel's side of the memo -- the reference's piece cache (bpe_tokenizer.cpp:197-205, 331-338: a piece's ids are
-// kept the first time it is seen, while the cache holds fewer than cache_capacity entries; nothing is ever evicted).
+// kept the first time it is seen, while the cache has room -- cache_capacity entries there, PieceTableDev::room here --; nothing is ever evicted).
 // This lane's piece (1..15 bytes, `cnt` <= kPieceMaxIds ids) goes into its slot if that slot is free: no entry ever moves
 // or changes, so a concurrent reader sees a slot either free, or claimed (kPieceBusy never equals a key), or complete
 // (payload checked by its tag).  A piece whose slot is taken stays a miss.  Returns false when nothing was added.

@@ -83,10 +83,11 @@ constexpr uint32_t kPieceBusy = 0xFF000000u;  // dword 3 of a key (length byte 2
 struct PieceTableDev {
     const PieceEntry* slots;  // nullptr: no memo (every piece takes the merge path)
     uint32_t shift;           // 32 - log2(slots)
-    int32_t* room;            // entries merge_kernel may still add (cache_capacity at create); nullptr: a fixed table.
+    int32_t* room;            // entries merge_kernel may still add (ovtk_bpe_params::memo_learn at create: cache_capacity, or as many as the
+                              // store holds); nullptr: a fixed table.
                               // kRoomShards counters, kRoomStride ints apart (one per 128-byte line), that share the capacity:
                               // every wave-batch with something to file takes its room with a RETURNING add (that is what keeps
-                              // `learned <= cache_capacity` exact), and 3 700 of those per launch on ONE address are most of a
+                              // `learned <= the room at create` exact), and 3 700 of those per launch on ONE address are most of a
                               // 50-us kernel (a capacity that never fills: 0.125 -> 0.166 ms per step at cache_capacity = 200 000)
     uint32_t room_mask;       // kRoomShards - 1, or 0 for small capacities (one counter holds it all)
     uint32_t packed6;         // 1: tok[] of every entry is six u16 ids (id 2k in the low half of tok[k]), up to kPieceMaxIds6 of them
@@ -94,7 +95,7 @@ struct PieceTableDev {
 constexpr int kRoomShards = 16, kRoomStride = 32;
 // ---- the piece store: the memo's second level, probed by merge_kernel only (never by the lookup kernels).
 // The first level above is sized for an XCD's L2 and for ONE round trip in the hot loop: 15-byte keys, 3 ids, the
-// vocabulary's own tokens plus cache_capacity learned pieces.  What it does not hold reaches merge_kernel as a deferred
+// vocabulary's own tokens plus the learned pieces (up to six u16 ids each where the ids fit; round 5).  What it does not hold reaches merge_kernel as a deferred
 // piece; before merging it, merge_kernel asks the store -- 64-byte entries, pieces up to 31 bytes, up to 15 ids (u16, every
 // id < 65536) or 7 ids (i32) -- and files there what it had to merge.  A hit costs the piece one round trip instead of a chain
 // of ~12 dependent ones.  Same pure function piece -> ids, same insert-only protocol as the first level (a slot is claimed
@@ -275,7 +276,7 @@ struct PieceTableHost {
     uint32_t shift = 30;             // 32 - log2(slots)
     size_t stored = 0, refused = 0;  // refused: pieces whose slot was taken (they stay misses)
 };
-// extra: entries the device may add later (cache_capacity): the table is sized for stored + extra.
+// extra: entries the table is sized for beyond the stored ones (cache_capacity; what is learned beyond that competes for the slots there are).
 void build_piece_table(const StringsView& pieces, const int32_t* id_begins, const int32_t* id_ends, const int32_t* ids,
                        PieceTableHost& out, size_t extra = 0, bool packed6 = false);
 
