@@ -70,7 +70,7 @@ def main():
         sents = [b" ".join(words[i:j]).decode("utf-8", "replace") + ("," if rng.random() < 0.3 else "") for i, j in zip(bounds[:-1], bounds[1:])]
         sin = one_string_per_row(sents)
         s1 = O.RegexSplit(BERT_WS, "remove")(*sin)
-        s2 = O.RegexSplit(bench.BERT_PUNCT, "isolate")(*s1[:5])
+        s2 = O.RegexSplit(BERT_PUNCT, "isolate")(*s1[:5])
         ref2 = O.WordpieceTokenizer(vocab, si.decode(), max_bytes)(*s2[:5], 0)
         try:
             fused = FusedSplitWordpiece(RegexSplit("remove", lib=lib), RegexSplit("isolate", lib=lib), WordpieceTokenizer(si.decode(), max_bytes, lib=lib))
