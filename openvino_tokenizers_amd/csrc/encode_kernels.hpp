@@ -1542,7 +1542,8 @@ __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSi
         // round trip per step (rows of 8 KB: 14 steps per item).  A lane takes FOUR entries per load (8 bytes of u16 / 16 bytes of i32) and
         // stores them as 16 bytes: every load and every store of the wave is one contiguous stretch (eight entries per lane and two
         // stores 32 bytes apart were measured first: compact_kernel 19.9 -> 22.6 us).
-        constexpr int U = 4;   // groups of 4 x 64 entries in flight
+        constexpr int U = 2;   // groups of 4 x 64 entries in flight (512 ids a step: config 2's items are ~450; four cost every item the
+                               // address arithmetic of two groups it does not have)
         for (int off0 = part * (U * kWave * 4); off0 < total_used; off0 += split * (U * kWave * 4)) {
             uint32_t x[U][4];
 #pragma unroll
@@ -1643,19 +1644,19 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
             // the array has the slack for 16-byte reads).  What merge_kernel's last block did for everybody, at the price of a ticket
             // and a scan on every call's chain.  A lane takes sixteen tiles per step, its loads leave together with the row records'
             // above -- before anything waits for those.
+            // (whole groups of sixteen in front of the tile unmasked -- a lane's group counts or it does not --, the up to fifteen tiles
+            // between the last whole group and the tile one to a lane: 22 vector instructions a step where masking every value took 64)
             int acc = 0;
-            for (int i0 = 0; i0 < tile; i0 += 16 * kWave) {
-                const int i = i0 + 16 * l;
+            const int whole = tile >> 4, rest = tile & 15;   // (wave-uniform)
+            for (int g0 = 0; g0 < whole; g0 += kWave) {
+                const int g = g0 + l;
                 int4 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    v[u] = i + 4 * u < tile ? *reinterpret_cast<const int4*>(w.tile_cnt + i + 4 * u) : int4{0, 0, 0, 0};
+                for (int u = 0; u < 4; ++u) v[u] = g < whole ? *reinterpret_cast<const int4*>(w.tile_cnt + 16 * g + 4 * u) : int4{0, 0, 0, 0};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int j = i + 4 * u;
-                    acc += (j < tile ? v[u].x : 0) + (j + 1 < tile ? v[u].y : 0) + (j + 2 < tile ? v[u].z : 0) + (j + 3 < tile ? v[u].w : 0);
-                }
+                for (int u = 0; u < 4; ++u) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
             }
+            acc += l < rest ? w.tile_cnt[16 * whole + l] : 0;
             toff = wave_sum(acc);
         } else {
             toff = w.tile_off[tile];
