@@ -596,6 +596,14 @@ def test_memo_learn_default_and_six_id_entries(backend, wide):
         L.check(lib, lib.ovtk_bpe_memo_entries(bpe._h, C.byref(fixed), C.byref(got)))
         learned.append(int(got.value))
     assert learned[0] > 7 and learned[0] <= learned[1] <= learned[2] <= learned[0] * 1.15 + 2
+    # an explicit count: memo_learn = 12 pieces, whatever cache_capacity and the store say
+    bpe12 = BPETokenizer(**tok.attrs, memo_learn=12, lib=lib)
+    fused12 = FusedSplitBPE(RegexSplit("isolate", lib=lib), bpe12)
+    for rep in range(2):
+        assert_same(ref, fused12.evaluate(backend.data([rb, re_, b, e, c]) + [pat], tok.consts), backend.host, f"memo_learn 12, call {rep}")
+    fixed, got = C.c_int64(), C.c_int64()
+    L.check(lib, lib.ovtk_bpe_memo_entries(bpe12._h, C.byref(fixed), C.byref(got)))
+    assert 8 <= got.value <= 12
 
 
 @pytest.mark.parametrize("wide", [False, True])
