@@ -211,9 +211,9 @@ def test_encode_dense_equals_the_chain(backend, with_special):
             rb, re_, ids = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(*s_ref[:5], skips=s_ref[5])[:5])
         else:
             rb, re_, ids = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(*inputs)[:5])
-        for max_length, side, pad_right, target, pre, suf in [(1 << 20, "right", True, None, (), ()), (20, "right", True, None, (7,), (9, 11)),
-                                                              (33, "left", False, None, (5,), ()), (16, "right", False, 40, (), (3,)),
-                                                              (64, "left", True, 30, (1, 2), (3, 4))]:
+        for case, (max_length, side, pad_right, target, pre, suf) in enumerate([(1 << 20, "right", True, None, (), ()), (20, "right", True, None, (7,), (9, 11)),
+                                                                                (33, "left", False, None, (5,), ()), (16, "right", False, 40, (), (3,)),
+                                                                                (64, "left", True, 30, (1, 2), (3, 4))]):
             (tb, te), = O.truncate([(rb, re_)], max_length, side, "longest_first")
             segs = []
             if pre:
@@ -227,7 +227,8 @@ def test_encode_dense_equals_the_chain(backend, with_special):
             op = FusedEncodeDense(RegexSplit("isolate", lib=backend.lib), BPETokenizer(**tok.attrs, lib=backend.lib),
                                   SpecialTokensSplit(lib=backend.lib) if with_special else None, max_length=max_length, trunc_side=side,
                                   pad_right=pad_right, pad_value=50256, prefix=pre, suffix=suf)
-            for call in range(2):   # (the second call runs on what the memo learned: rows without unused staging entries take dense_row_direct)
+            # (a second call runs on what the memo learned: rows without unused staging entries; on the emulator for two of the cases)
+            for call in range(2 if backend.name != "emu" or (n_rows == 300 and case in (1, 4)) else 1):
                 got = op.evaluate(backend.data(inputs), tok.pattern_u8(), tok.consts, special_pattern=u8(pat) if with_special else None, target_dim=target,
                                   row_capacity=max(width, 1))
                 what = f"dense: special {with_special}, {n_rows} rows, max_length {max_length} {side}, pad_right {pad_right}, target {target}, call {call}"
