@@ -278,6 +278,9 @@ def test_fused_encode_one_pass_split(backend, behaviour, invert, max_splits):
     """The one-pass form of the compiled split inside the fused encode (regex_sparse_kernel: every row's pieces in a region of
     its own, no count pass, no host wait): every behaviour, invert, max_splits, rows of zero / one / several strings in any
     order, skipped strings, empty strings -- against RegexSplit (PCRE2) -> BPETokenizer of the oracle."""
+    if backend.name == "emu" and (behaviour, invert, max_splits) in (("remove", False, -1), ("isolate", True, 3), ("mergedwithprevious", False, -1),
+                                                                      ("mergedwithnext", True, -1)):
+        pytest.skip("the emulator runs four of the eight combinations (16 s each); all eight run on the GPU tier")
     tok = BpeTok.load("gpt2_small")
     rng = np.random.default_rng(29)
     words = ["hello", "World", "it's", "12345", " ", "  ", "\n", "x", "camelCaseWord", "HTTPServer", "naïve", "日本語", "!?", "a1b2", "'ll", "", "tail\n"]
