@@ -992,6 +992,9 @@ def main():
     ap.add_argument("--hog", type=int, default=0, help="debug: occupy CU slots with N idle 512-thread blocks on a side stream during "
                                                         "every step (stands in for RCCL's all-gather kernel; tools/cu_hog.hip)")
     ap.add_argument("--row-tickets", type=int, default=-1, help="ovtk_set_row_tickets(n); default 0 (static row assignment)")
+    ap.add_argument("--short-path", type=int, default=1, choices=[0, 1, 2],
+                    help="ovtk_set_short_path(n): 1 (the library's default) = span -> compact where a handle's last calls say every piece is in its tables, "
+                         "0 = always span -> left-over rows -> merge -> compact (round 5's four launches), 2 = every call tries")
     ap.add_argument("--hog-lds", type=int, default=0, help="debug: dynamic LDS bytes per hog block")
     ap.add_argument("--lib", default=None, help="debug: load this build of libovtk_amd.so")
     ap.add_argument("--no-alone-leg", action="store_true", help="skip the one-stream leg behind `roofline` (profile runs of the "
@@ -1068,6 +1071,7 @@ def main():
     # lookup kernel of the next (per-launch durations grow, the step shrinks).  --sync: one blocking call per step.
     row_tickets = max(args.row_tickets, 0)
     L.check(lib, lib.ovtk_set_row_tickets(row_tickets))
+    L.check(lib, lib.ovtk_set_short_path(args.short_path))
     side_streams = [torch.cuda.Stream(dev) for _ in range(max(args.streams - 1, 0))]
     stream_ptrs = [C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)] + [C.c_void_p(x.cuda_stream) for x in side_streams]
     hog = None
@@ -1325,6 +1329,10 @@ def main():
         "parity_per_chunk": (wl.parity_per_chunk() if hasattr(wl, "parity_per_chunk") and world == 1 and not args.no_cpu_baseline else None),
         "kernel_ms": kernels,
     }
+    op_t, op_x = C.c_int64(), C.c_int64()
+    L.check(lib, lib.ovtk_short_path_stats(C.byref(op_t), C.byref(op_x)))
+    line["config"]["short_path"] = {"mode": args.short_path, "calls_tried": int(op_t.value), "calls_that_needed_no_other_kernel": int(op_x.value),
+                                    "note": "whole process (priming, warm-up, timed steps, stress legs): calls launched as lookup_span_kernel -> compact_kernel"}
     if hasattr(wl, "memo"):
         # the reference's piece cache (m_cache, cache_capacity = 20000) fills during ITS first calls too; here it is full
         # before the warm-up steps are over, so the timed steps run with the learned entries in place

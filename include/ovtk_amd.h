@@ -215,6 +215,17 @@ int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_st
  * resident late because another stream's kernel (RCCL's all-gather during the row-shard exchange) holds their CU take
  * less work instead of finishing last.  Results are identical either way. */
 int ovtk_set_row_tickets(int rows_per_ticket);
+/* The short path (round 6), process-wide: ovtk_encode_run / _enqueue (and the wire / dense forms) with a pattern the span kernel scans
+ * (the GPT-2, Llama-3, o200k and DeepSeek-V3 families) is TWO launches where every piece of the batch is in the handle's memo or piece
+ * store: lookup_span_kernel looks the pieces the memo does not hold up in the store itself, compact_kernel follows at once -- no
+ * launch of lookup_kernel for left-over rows (there are none), none of merge_kernel (nothing to merge).  When a wave of the span
+ * kernel reports a piece that is in neither table, or a row it left to the generic kernel, those kernels are launched after all
+ * (from ovtk_encode_finish / inside ovtk_encode_run).  Results are identical either way.
+ * 0: never; 1 (default): a handle tries, and after a call that needed the other kernels skips 1, 2, 4 ... 64 calls before it tries
+ * again (a text the tables are still learning); 2: every eligible call tries, small batches included (tests). */
+int ovtk_set_short_path(int mode);
+/* Process-wide counts since the library was loaded: calls launched as span -> compact, and those of them that needed no other kernel. */
+int ovtk_short_path_stats(int64_t* tried, int64_t* exact);
 
 typedef struct ovtk_pending ovtk_pending;
 /* SpecialTokensSplit -> RegexSplit -> BPETokenizer in one call: the sub-graph every converted HF byte-level BPE tokenizer runs

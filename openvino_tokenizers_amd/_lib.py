@@ -98,7 +98,7 @@ EXPORTS = [
     "ovtk_last_error", "ovtk_abi_version", "ovtk_device_name",
     "ovtk_regex_split_create", "ovtk_regex_split_run", "ovtk_regex_split_destroy",
     "ovtk_special_tokens_split_create", "ovtk_special_tokens_split_run", "ovtk_special_tokens_split_destroy",
-    "ovtk_bpe_create", "ovtk_bpe_run", "ovtk_bpe_destroy", "ovtk_bpe_memo_entries", "ovtk_set_memo_store", "ovtk_bpe_store_entries", "ovtk_encode_run", "ovtk_encode_special_run", "ovtk_encode_special_enqueue", "ovtk_encode_dense_enqueue", "ovtk_encode_dense_finish", "ovtk_encode_enqueue", "ovtk_encode_enqueue_host", "ovtk_encode_enqueue_packed", "ovtk_encode_enqueue_wire", "ovtk_encode_finish", "ovtk_set_row_tickets",
+    "ovtk_bpe_create", "ovtk_bpe_run", "ovtk_bpe_destroy", "ovtk_bpe_memo_entries", "ovtk_set_memo_store", "ovtk_bpe_store_entries", "ovtk_encode_run", "ovtk_encode_special_run", "ovtk_encode_special_enqueue", "ovtk_encode_dense_enqueue", "ovtk_encode_dense_finish", "ovtk_encode_enqueue", "ovtk_encode_enqueue_host", "ovtk_encode_enqueue_packed", "ovtk_encode_enqueue_wire", "ovtk_encode_finish", "ovtk_set_row_tickets", "ovtk_set_short_path", "ovtk_short_path_stats",
     "ovtk_wordpiece_create", "ovtk_wordpiece_run", "ovtk_wordpiece_encode_run", "ovtk_wordpiece_encode_enqueue", "ovtk_wordpiece_destroy",
     "ovtk_vocab_encoder_create", "ovtk_vocab_encoder_run", "ovtk_vocab_encoder_destroy",
     "ovtk_ragged_to_dense",

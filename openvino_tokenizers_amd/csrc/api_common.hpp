@@ -2,6 +2,7 @@
 #pragma once
 
 #include <atomic>
+#include <cstdlib>
 #include <functional>
 
 #include <hip/hip_runtime.h>
@@ -257,6 +258,19 @@ inline std::atomic<int>& row_tickets() {
     return v;
 }
 
+// ovtk_set_short_path(): 0 = never, 1 (default) = where a handle's last calls say it will work, 2 = every eligible call tries.
+inline std::atomic<int>& short_path_mode() {
+    static std::atomic<int> v{1};
+    return v;
+}
+
+// ovtk_short_path_stats(): calls launched as span -> compact / of them, calls that needed no other kernel.
+struct ShortPathCounts { std::atomic<int64_t> tried{0}, exact{0}; };
+inline ShortPathCounts& short_path_counts() {
+    static ShortPathCounts c;
+    return c;
+}
+
 struct PendingRun {
     virtual ~PendingRun() = default;
     virtual int finish(ovtk_ragged_i32_out* out) = 0;
@@ -312,6 +326,10 @@ public:
     // Asked once this run's event has completed, before its own status is looked at: what a stage in front of it (another
     // workspace's kernels on the same stream) has to say; non-zero ends finish() with that code.
     void front_check(std::function<int()> f) { front_check_ = std::move(f); }
+    // The middle's first kernel is lookup_span_kernel and may do the whole middle itself (EncodeWork::short_path, span_kernel.hpp "the
+    // short path"): launched with compact_kernel right behind it; the other kernels follow from finish() only when it reports waves
+    // that could not (n_inexact).
+    void enable_short_path() { short_ok_ = true; }
     void enable_stage16() { stage16_ = true; }   // the middle's kernels write / read the staging entries as u16 (EncodeWork::stage16)
     // The middle's first kernel takes staging for ALL its rows before it knows which of them it will leave to the kernel behind it
     // (lookup_span_kernel: one reservation per wave), and that kernel takes its own: room for both, or every call with left-over
@@ -416,9 +434,23 @@ public:
             } else if (st.flags & kFlagTailPending) {
                 fold_tail_ = false;  // more exact pieces than the folded tail takes: once more with their own launches
                 small_ = false;
+            } else if (phase_ == 1 && st.n_inexact > 0) {
+                short_path_counts().tried.fetch_add(1, std::memory_order_relaxed);
+                // the short path: some wave of the span kernel left pieces or rows to the kernels that were not launched, compact_kernel
+                // wrote nothing -- those kernels after all
+                if (int rc = launch_phase2()) return rc;
+                continue;
             } else {
+                if (phase_ == 1) {
+                    short_path_counts().tried.fetch_add(1, std::memory_order_relaxed);
+                    short_path_counts().exact.fetch_add(1, std::memory_order_relaxed);
+                }
                 out->n_data = st.n_out;
-                if (on_status_) on_status_(st);
+                if (on_status_) {
+                    RunStatus seen = st;
+                    seen.short_path = phase_ != 0 ? 1 : 0;
+                    on_status_(seen);
+                }
                 if (st.flags & kFlagOutCapacity)
                     return set_error(OVTK_E_CAPACITY, dense_on_ ? op_ + ": dense outputs too small (row width " + std::to_string(st.width) + ")"
                                                                 : op_ + ": output ids buffer too small (" + std::to_string(st.n_out) +
@@ -452,7 +484,11 @@ private:
         e = e ? e : ws.wave_off.ensure(size_t(grid_ * kWavesPerBlock + 1) * sizeof(long long));
         e = e ? e : ws.tiles.ensure(size_t(n_tiles_ + 1) * sizeof(long long));
         const bool fold = fold_tail_ && n_rows_ <= kFoldTailRows;
-        const size_t status_bytes = sizeof(RunStatus) + (fold ? size_t(n_tiles_) * 4 + 16 : 0);  // + tile_cnt, zeroed with the status (+ slack: compact_kernel reads it 16 bytes at a time)
+        size_t status_bytes = sizeof(RunStatus) + (fold ? size_t(n_tiles_) * 4 + 16 : 0);  // + tile_cnt, zeroed with the status (+ slack: compact_kernel reads it 16 bytes at a time)
+        // the short path: span -> compact (tile_cnt is summed by the span kernel's waves, every wave of compact_kernel sums the tiles in
+        // front of its own)
+        small_ = small_ && !(short_ok_ && short_path_mode().load(std::memory_order_relaxed) == 2);   // (mode 2: tests drive it with small batches)
+        const bool short_path = short_ok_ && !small_ && self_alloc_ && fold && short_path_mode().load(std::memory_order_relaxed) != 0;
         const size_t status_stride = (status_bytes + 255) & ~size_t(255);   // two blocks: this call's, and the one compact_kernel zeroes for the next
         e = e ? e : ws.status.ensure(2 * status_stride);
         if (fold) e = e ? e : ws.gen[4].ensure(size_t(n_rows_) * 4);
@@ -483,6 +519,7 @@ private:
         w.scratch = ws.scratch.as<uint8_t>();
         w.scratch_cap = uint32_t(std::min<int64_t>(scratch_cap_, 0xFFFFFFF0ll));
         w.status = ws.status.as<RunStatus>();
+        phase_ = 0;
 
         if (small_ && fold) {  // one launch: blocks look their rows up, the last one merges, compacts and reports
             w.small = 1;
@@ -517,7 +554,7 @@ private:
         // the large path, up to kTileSumTiles tiles: no ticket and no scan at the end of the middle's last kernel -- every wave of
         // compact_kernel sums the counts in front of its tile (beyond that the sums cost compact_kernel more than the tail cost the
         // middle: config 4's 2 048 tiles, compact 29.5 -> 32.7 us for merge_kernel 67 -> 62)
-        w.tile_sums = fold && n_tiles_ <= kTileSumTiles ? 1 : 0;
+        w.tile_sums = fold && (n_tiles_ <= kTileSumTiles || short_path) ? 1 : 0;
         w.host_status = ws.host_status;
         w.status_words = int32_t(status_bytes / 4);
         if (ws.zeroed_status != mine || ws.zeroed_bytes < status_bytes || ws.zeroed_after_lease + 1 != ws.lease_count)
@@ -527,7 +564,37 @@ private:
         ws.host_status->flags = kFlagDidNotRun;               // overwritten by the kernel; one that did not run leaves this (finish: OVTK_E_HIP)
         if (!self_alloc_)
             OVTK_LAUNCH(ws.marks, "prep_rows", prep_rows_kernel, std::min(grid_, kTicketBlocks), kBlockThreads, s_, d_in_, mul_, w);
+        if (short_path) {
+            w.short_path = 1;
+            w_ = w;
+            phase_ = 1;
+        }
         middle_(ws, d_in_, w, grid_);
+        return launch_tail(ws, w, other, status_bytes);
+    }
+
+    // The short path, after all: the span kernel has run and reported waves that left something to the kernels that were not
+    // launched.  The status block, the staging buffer, the row records and the deferred list are as the four-launch form's span kernel
+    // leaves them -- but for the tile sums, which the span kernel's waves have added to: merge_kernel sums what the lookup kernels
+    // emitted itself (fold_emitted_tile_sums).
+    int launch_phase2() {
+        OVTK_HIP(hipSetDevice(device_));
+        Workspace& ws = *ws_.ws;
+        EncodeWork w = w_;
+        w.short_path = 0;
+        w.phase2 = 1;
+        w.tile_sums = w.fold_tail && n_tiles_ <= kTileSumTiles ? 1 : 0;
+        if (w.tile_cnt) OVTK_HIP(hipMemsetAsync(w.tile_cnt, 0, size_t(n_tiles_) * 4, s_));
+        OVTK_HIP(hipMemsetAsync(&w.status->n_inexact, 0, 4, s_));
+        std::memset(ws.host_status, 0, sizeof(RunStatus));
+        ws.host_status->flags = kFlagDidNotRun;
+        middle_(ws, d_in_, w, grid_);
+        phase_ = 2;
+        return launch_tail(ws, w, zeroed_other_, zeroed_other_bytes_);
+    }
+
+    // count_scan (where the middle's last kernel does not fold it) and compact_kernel, the call's last kernel.
+    int launch_tail(Workspace& ws, EncodeWork& w, const void* other, size_t status_bytes) {
         if (!w.fold_tail)
             OVTK_LAUNCH(ws.marks, "count_scan", count_scan_kernel, std::min((n_tiles_ + 3) / 4, kTicketBlocks), kBlockThreads, s_,
                         n_rows_, w, (long long)out_.data_capacity);
@@ -557,6 +624,8 @@ private:
         // afterwards, left the next lease without its memset)
         pending_zeroed_ = other;
         pending_zeroed_bytes_ = status_bytes;
+        zeroed_other_ = other;
+        zeroed_other_bytes_ = status_bytes;
         OVTK_HIP(hipEventRecord(ws.done, s_));
         return OVTK_OK;
     }
@@ -580,6 +649,11 @@ private:
     bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
     bool small_ok_ = false, small_ = false;
     bool stage16_ = false, stage_twice_ = false;
+    bool short_ok_ = false;
+    int phase_ = 0;          // 1: the attempt in flight is the short path (span -> compact); 2: the other kernels were launched after all
+    EncodeWork w_{};         // the attempt's work description (phase 2 launches with it)
+    const void* zeroed_other_ = nullptr;
+    size_t zeroed_other_bytes_ = 0;
     const void* pending_zeroed_ = nullptr;
     size_t pending_zeroed_bytes_ = 0;
     const void* pending_clean_ = nullptr;

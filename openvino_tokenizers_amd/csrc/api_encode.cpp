@@ -108,6 +108,10 @@ struct ovtk_bpe {
     // calls that still leave the piece store out: set to 32 after four calls in a row in which fewer than one probe in eight
     // hit (then the store is asked again, and so on -- text changes)
     mutable std::atomic<int> store_pause{0}, store_low{0};  // store_low: calls in a row with that little use of it
+    // The short path (span_kernel.hpp): eligible calls that still go the four-launch way -- after a call whose span kernel reported
+    // inexact waves (a text the tables are still learning, pieces the store cannot hold) the next `short_backoff` calls do not try, then
+    // one does; the count doubles with every failure in a row (up to 64) and starts over with the first success.
+    mutable std::atomic<int> short_skip{0}, short_backoff{0};
 };
 
 namespace {
@@ -745,13 +749,15 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // generic kernel
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
-                                   if (T.pieces.slots && w1.stage16)
+                                   if (w.phase2) {}   // (the short path, after all: the span kernel has run)
+                                   else if (T.pieces.slots && w1.stage16)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanLlama3, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (T.pieces.slots)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanLlama3, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else
                                        OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsLlama3>, grid1, kBlockThreads, s, d_in, split->dev,
                                                    T, w1);
+                                   if (w.short_path) return;   // (the short path: compact_kernel follows at once)
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
@@ -765,7 +771,8 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // (several strings, skipped ones) are matched literally, a lane per row's window
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
-                                   if (family == kFamDs3 && w1.stage16)
+                                   if (w.phase2) {}
+                                   else if (family == kFamDs3 && w1.stage16)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanDs3, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (family == kFamDs3)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanDs3, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
@@ -773,6 +780,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanO200k, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanO200k, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
+                                   if (w.short_path) return;
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedSeq>, grid, kBlockThreads, s, d_in, split->dev, T, w2);
@@ -786,7 +794,8 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // (marked in row_used, listed in pending_rows) goes through the generic kernel
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
-                                   if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits && w1.stage16)
+                                   if (w.phase2) {}
+                                   else if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits && w1.stage16)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanGpt2Digits, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanGpt2Digits, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
@@ -803,6 +812,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // what it left: the generic kernel (it returns at once when nothing was left).  A smaller stand-by
                                    // grid for handles whose last call left no row was measured: nothing gained on all-ASCII text
                                    // (6.0 vs 6.2 us), and the rows that do turn up then wait for 64 blocks to walk every row's flag
+                                   if (w.short_path) return;
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
@@ -864,9 +874,30 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     else if (device_inputs)
         r->input_on_device(device_inputs);
     const bool has_store = T.store.slots != nullptr;
-    if (has_store || dense_width)   // what the store did for this call decides whether the next ones ask it at all
+    // The short path: span -> compact.  Where the call's first kernel is lookup_span_kernel and the handle's last attempts do not say
+    // otherwise.
+    bool short_path = split && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3 || split->dev.family != kFamNone) && T.pieces.slots &&
+                      !row_tickets().load(std::memory_order_relaxed) && short_path_mode().load(std::memory_order_relaxed) != 0;
+    if (short_path && short_path_mode().load(std::memory_order_relaxed) == 1) {
+        if (!has_store) short_path = false;   // (every miss of the memo would be an inexact wave)
+        else if (bpe->short_skip.load(std::memory_order_relaxed) > 0) {
+            bpe->short_skip.fetch_sub(1, std::memory_order_relaxed);
+            short_path = false;
+        }
+    }
+    if (short_path) r->enable_short_path();
+    if (has_store || dense_width || short_path)   // what the store did for this call decides whether the next ones ask it at all
         r->on_status([bpe, has_store, dense_width](const RunStatus& st) {
             if (dense_width) *dense_width = st.width;
+            if (st.short_path) {   // the call was launched as span -> compact
+                if (st.n_inexact > 0) {
+                    const int b = std::min(64, std::max(1, 2 * bpe->short_backoff.load(std::memory_order_relaxed)));
+                    bpe->short_backoff.store(b, std::memory_order_relaxed);
+                    bpe->short_skip.store(b, std::memory_order_relaxed);
+                } else {
+                    bpe->short_backoff.store(0, std::memory_order_relaxed);
+                }
+            }
             if (!has_store) return;
             if (st.n_store_probe < 256) return;   // (counted by one wave in 64)
             // (a cold store misses everything too: only a run of such calls says that the text is the reason)
@@ -998,6 +1029,18 @@ int ovtk_encode_dense_finish(ovtk_pending* pending, int32_t* width, int64_t* n_i
     if (width) *width = p->dense_width ? *p->dense_width : 0;
     if (n_ids) *n_ids = p->out.n_data;
     return rc;
+}
+
+int ovtk_set_short_path(int mode) {
+    if (mode < 0 || mode > 2) return set_error(OVTK_E_ARG, "short path: 0 (never), 1 (where a handle's last calls say it works), 2 (every eligible call tries)");
+    short_path_mode().store(mode, std::memory_order_relaxed);
+    return OVTK_OK;
+}
+
+int ovtk_short_path_stats(int64_t* tried, int64_t* exact) {
+    if (tried) *tried = short_path_counts().tried.load(std::memory_order_relaxed);
+    if (exact) *exact = short_path_counts().exact.load(std::memory_order_relaxed);
+    return OVTK_OK;
 }
 
 int ovtk_set_row_tickets(int rows_per_ticket) {

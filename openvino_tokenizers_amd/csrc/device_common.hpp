@@ -36,7 +36,11 @@ struct RunStatus {
     int32_t n_store_hit;   // ... and found there
     int32_t width;         // dense output (ovtk_encode_dense_*): the row width row_width_kernel settled on
     uint32_t width_ticket; // ... and its "last block done" ticket
-    int32_t pad[18];
+    int32_t n_inexact;     // the short path (EncodeWork::short_path): waves of lookup_span_kernel that left something to the kernels that were
+                           // not launched -- a piece neither the memo nor the store holds, a row for the generic kernel; > 0: compact_kernel
+                           // wrote nothing and the host launches lookup_kernel<kFused> / merge_kernel / compact_kernel after all
+    int32_t short_path;    // (host side: the attempt that completed the call was the short path's)
+    int32_t pad[16];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
     int32_t stage_top[kShards * kCounterStride];    // [s * kCounterStride] = staging entries handed out in region s
     int32_t row_ticket[kShards * kCounterStride];   // [s * kCounterStride] = rows of range s handed to waves (lookup_kernel)

@@ -104,6 +104,11 @@ struct EncodeWork {
     uint8_t* scratch;
     uint32_t scratch_cap;
     RunStatus* status;
+    // ---- the short path (round 6; span_kernel.hpp "the short path"): lookup_span_kernel looks the pieces the memo does not hold up in
+    // the piece store itself and sums its rows' counts into tile_cnt; compact_kernel follows at once -- no lookup_kernel<kFused>, no
+    // merge_kernel launch unless a wave reports that it could not (RunStatus::n_inexact: compact_kernel then writes nothing)
+    int32_t short_path;
+    int32_t phase2;          // (host side, the middle's launches) the span kernel has run and left inexact waves: launch what follows it
 };
 
 constexpr uint32_t kFatalFlags = kFlagRange | kFlagStageOverflow;
@@ -1510,23 +1515,13 @@ struct __attribute__((packed, aligned(1))) FlatBytes16 { uint32_t d[4]; };
 struct __attribute__((packed, aligned(1))) FlatBytes8 { uint32_t d[2]; };
 // part / split: EncodeWork::compact_split waves share an item (few, long rows); the copy's steps are dealt out among them, anything else
 // is part 0's.
+// A stretch of `total_used` staging entries from `stage_bytes` on -> i32 ids at `out`: a widening copy when no entry of it is unused
+// (`plain`), else the valid entries squeezed through `buf` (kFlatIds ids of LDS, the wave's own).  compact_flat's copy, and the tail of
+// lookup_span_kernel's one-pass form (the wave's whole stretch).
 template <bool S16>
-__device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSink& sink, int32_t* buf, const int (&cnt)[4], const int (&o)[4],
-                                             const int (&base)[4], const int (&used)[4], int row0, int part, int split) {
+__device__ __forceinline__ void flat_copy(const uint8_t* stage_bytes, int total_used, bool plain, int32_t* out, int32_t* buf, int part, int split) {
     constexpr int E = S16 ? 8 : 4;   // entries per 16 bytes
     const int l = lane_id();
-    const int total_used = used[0] + used[1] + used[2] + used[3];
-    if (used[0] < 0 || used[1] < 0 || used[2] < 0 || used[3] < 0 || base[1] != base[0] + used[0] || base[2] != base[1] + used[1] ||
-        base[3] != base[2] + used[2])
-        return false;
-    const bool plain = total_used == cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    if (part != 0 && !plain) return true;   // (the squeeze is one wave's)
-    if (l < 4 && part == 0) {
-        const int oo = l == 0 ? o[0] : (l == 1 ? o[1] : (l == 2 ? o[2] : o[3])), cc = l == 0 ? cnt[0] : (l == 1 ? cnt[1] : (l == 2 ? cnt[2] : cnt[3]));
-        sink.row(row0 + l, oo, oo + cc);
-    }
-    const uint8_t* stage_bytes = reinterpret_cast<const uint8_t*>(w.stage) + (long long)base[0] * (S16 ? 2 : 4);
-    int32_t* out = sink.ids + o[0];
     // the stretch in steps of 64 x 16 bytes (rows of any length: a row of 8 KB is a dozen steps); the next step's load leaves before
     // this step's entries are looked at
     auto fetch = [&](int off) -> FlatBytes16 {
@@ -1573,7 +1568,7 @@ __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSi
                 }
             }
         }
-        return true;
+        return;
     }
     FlatBytes16 v = fetch(0);
     for (int off = 0; off < total_used; off += kWave * E) {
@@ -1611,6 +1606,22 @@ __device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSi
         v = nxt;
         wave_sync();   // (the buffer is the next step's)
     }
+}
+template <bool S16>
+__device__ __forceinline__ bool compact_flat(const EncodeWork& w, const RaggedSink& sink, int32_t* buf, const int (&cnt)[4], const int (&o)[4],
+                                             const int (&base)[4], const int (&used)[4], int row0, int part, int split) {
+    const int l = lane_id();
+    const int total_used = used[0] + used[1] + used[2] + used[3];
+    if (used[0] < 0 || used[1] < 0 || used[2] < 0 || used[3] < 0 || base[1] != base[0] + used[0] || base[2] != base[1] + used[1] ||
+        base[3] != base[2] + used[2])
+        return false;
+    const bool plain = total_used == cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (part != 0 && !plain) return true;   // (the squeeze is one wave's)
+    if (l < 4 && part == 0) {
+        const int oo = l == 0 ? o[0] : (l == 1 ? o[1] : (l == 2 ? o[2] : o[3])), cc = l == 0 ? cnt[0] : (l == 1 ? cnt[1] : (l == 2 ? cnt[2] : cnt[3]));
+        sink.row(row0 + l, oo, oo + cc);
+    }
+    flat_copy<S16>(reinterpret_cast<const uint8_t*>(w.stage) + (long long)base[0] * (S16 ? 2 : 4), total_used, plain, sink.ids + o[0], buf, part, split);
     return true;
 }
 
@@ -1622,6 +1633,7 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
     if ((w.status->flags | more_flags) & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
                                          kFlagTailPending))
         return;
+    if (w.short_path && w.status->n_inexact != 0) return;   // (the short path: a wave of the span kernel left pieces or rows to the kernels that were not launched)
     sink.start(w.status);
     const int l = lane_id();
     const int n_waves = (solo ? 1 : int(gridDim.x)) * kWavesPerBlock;

@@ -201,6 +201,54 @@ constexpr int kSpanHalo = 8;          // bytes at the end of a block that is not
 constexpr int kSpanWindow = 16 * kWave;   // the ballot form's window (its masks travel inside a DPP row of 16 lanes)
 constexpr int kSpanWindowHalo = 16;
 
+// ---- the short path (round 6): span -> compact ------------------------------------------------------------------------------------
+// Until round 5 every call was four launches: this kernel, lookup_kernel<kFused> for the rows it leaves (none, as a rule: 5 us of a
+// kernel that finds nothing), merge_kernel for the pieces the memo does not hold (once the tables have learned a text: a few thousand
+// pieces that merge_kernel finds in the piece store, nothing to merge -- 13 us of launch, list, store probe and tile sums) and
+// compact_kernel.  With EncodeWork::short_path the span kernel does what is left of the two in the middle itself:
+//   * at its end a wave looks its noted misses up in the piece store (the memo's second level: one round trip, a lane per miss;
+//     store_lookup) and writes their ids into the staging entries it had reserved for them; what the store does not hold either is
+//     filed for merge_kernel as ever, and the wave is INEXACT -- as is a wave with a row it left to the generic kernel;
+//   * it adds its rows' id counts to their tiles' sums (tile_cnt: merge_kernel's fold_emitted_tile_sums);
+// and compact_kernel follows at once.  RunStatus::n_inexact > 0 makes that compact_kernel write nothing, and the host launches
+// lookup_kernel<kFused> / merge_kernel / compact_kernel after all (RowsRun::launch_phase2): the staging buffer, the row records and
+// the deferred list are as the four-launch form's span kernel leaves them.  Results are the same either way.
+// (Tried first and dropped, profiles/r06/a_one_pass_*: ONE launch -- a wave takes its output offset from a decoupled look-back over the
+// waves in front of it and copies its own staging stretch to the final ids.  A persistent grid's waves all end together, so every
+// wave waits for the slowest one in front of it, and waiting is not free: the waves that wait are the older waves of their SIMDs and
+// the issue arbiter serves the oldest first -- polls every 2 us slowed the waves still at work by a fifth, whoever polled what (every
+// wave its group's words; one wave per block with the others at a workgroup barrier) -- and the copies of all waves then leave in
+// one burst.  93-117 us alone where span + compact take 80.)
+
+// The store's answer for one noted miss: its ids into the staging entries the piece had reserved, the rest of them cleared.
+// -> the id count, or -1 (not in the store, or no key of it fits one).
+template <bool NARROW, bool S16>
+__device__ __forceinline__ int span_resolve_miss(const RowsIn& in, const BpeDev& T, const EncodeWork& w, const SpanMiss& e, int SL) {
+    const int len = int(e.info.z);
+    if (len < 1 || len > kStoreKeyBytes) return -1;
+    uint32_t skey[8];
+    if (len <= kPieceKeyBytes)
+        store_key_short(uint64_t(e.key.x) | (uint64_t(e.key.y) << 32), uint64_t(e.key.z) | (uint64_t(e.key.w) << 32), len, skey);
+    else
+        store_key_long(in.chars + e.info.y, len, skey);
+    uint32_t pay[8];
+    const int c = store_lookup<NARROW>(T.store, skey, pay);
+    if (c < 0 || c > len + SL) return -1;
+    const int pos = int(e.info.x), need = len + SL;
+    constexpr int kIds = NARROW ? kStoreIds16 : kStoreIds32;
+#pragma unroll
+    for (int k = 0; k < kIds; ++k)
+        if (k < c) {
+            if (S16) reinterpret_cast<uint16_t*>(w.stage)[pos + k] = uint16_t(store_id<NARROW>(pay, k));
+            else w.stage[pos + k] = store_id<NARROW>(pay, k);
+        }
+    for (int k = c; k < need; ++k) {
+        if (S16) reinterpret_cast<uint16_t*>(w.stage)[pos + k] = uint16_t(0xFFFFu);
+        else w.stage[pos + k] = kEmptyId;
+    }
+    return c;
+}
+
 // SCAN: kSpanGpt2 / kSpanGpt2Digits (RegexSplit + BPETokenizer), kSpanBertWords (the fused WordPiece path: `T` then holds nothing but the
 // word memo, misses go to wordpiece_deferred_kernel through the same deferred list).
 //
@@ -250,6 +298,8 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
     __syncthreads();
     if (fatal || nr <= 0) return;
     SpanWave& sw = sw_all[wave_in_block()];
+    PROBE(0);
+
     const uint8_t* text = reinterpret_cast<const uint8_t*>(sw.text + 1);
     const int SL = T.suffix_len, mul = SL + 1;
     int h_sb = 0, h_len = 0;
@@ -279,6 +329,13 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         total_bytes = (long long)wave_readlane(lo_incl, kWave - 1) + ((long long)wave_readlane(hi_incl, kWave - 1) << 20);
     }
     const int excl32 = incl32 - h_len;
+#ifdef OVTK_PROBE
+    if (lane_id() == 0 && wave < 8192) {   // where the wave runs: HW_ID (wave / SIMD / CU / SH / SE) and the XCC; the bytes of its rows
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        g_ts[wave][8] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        g_ts[wave][9] = (unsigned long long)total_bytes;
+    }
+#endif
     // ---- chains: rows [ci, cj) that continue one another; the first one's text is asked for before the staging reservation
     int ci = 0, cj = 0, chain_sb = 0, chain_len = 0, ex0 = 0;
     uint32_t xa[kSpanDwords];
@@ -328,6 +385,8 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
                 span_flush(sw, n_miss, w, row0, incl32);
                 wave_sync();
                 n_miss = 0;
+                // (the short path: these go to merge_kernel -- the call is inexact, said at once: nothing else has to remember it)
+                if (!BERT && w.short_path && l == 0) atomicAdd(&w.status->n_inexact, 1);
             }
             const int take = add - done < kSpanMiss - n_miss ? add - done : kSpanMiss - n_miss;
             if (mine && rank >= done && rank < done + take)
@@ -716,10 +775,47 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         }
         have_chain = next_chain(cj);
     }
+    PROBE(1);
+    bool exact = !dead;   // (the short path) every id of my rows stands in my staging stretch
+    if (!BERT && w.short_path && n_miss > 0 && T.store.slots && !dead) {
+        // ---- the short path: the noted misses through the piece store, a lane each
+        wave_sync();
+        const SpanMiss e = sw.miss[l < n_miss ? l : 0];
+        int row = 0;   // the row of my miss (span_flush's search)
+#pragma unroll
+        for (int step = kWave / 2; step >= 1; step >>= 1) {
+            const int t = row + step;
+            if (__shfl(incl32, t - 1) <= int(e.info.w)) row = t;
+        }
+        int c = -1;
+        if (l < n_miss) {
+            if (S16) c = span_resolve_miss<true, S16>(in, T, w, e, SL);
+            else if (T.store.narrow) c = span_resolve_miss<true, S16>(in, T, w, e, SL);
+            else c = span_resolve_miss<false, S16>(in, T, w, e, SL);
+        }
+        // the rows' id counts: through LDS (the piece list's room is free)
+        uint32_t* radd = reinterpret_cast<uint32_t*>(sw.pstart);
+        radd[l] = 0;
+        wave_sync();
+        if (c > 0) atomicAdd(&radd[row], uint32_t(c));
+        wave_sync();
+        rec_cnt += int(radd[l]);
+        // what the store does not hold: to the front of the list, and out to merge_kernel
+        const unsigned long long um = __ballot(l < n_miss && c < 0);
+        if (um) {
+            if (l < n_miss && c < 0) sw.miss[rank_below(um)] = e;   // (every lane holds its entry in registers: nothing is overwritten unread)
+            wave_sync();
+            span_flush(sw, __popcll(um), w, row0, incl32);
+            exact = false;
+        }
+        n_miss = 0;
+    }
     if (n_miss > 0) {
         wave_sync();
         span_flush(sw, n_miss, w, row0, incl32);
+        exact = false;
     }
+    PROBE(2);
     const bool is_pending = l < nr && ((pending_m >> l) & 1ull);
     if (l < nr) {
         w.row_used[row0 + l] = is_pending ? kRowPending : rec_used;
@@ -735,6 +831,20 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         if (l == 0) base = atomicAdd(&w.status->n_pending, int(__popcll(pm)));
         base = wave_readlane(base, 0);
         if (w.pending_rows && is_pending) w.pending_rows[base + rank_below(pm)] = row0 + l;
+    }
+    if constexpr (!BERT) {
+        if (w.short_path) {
+            // ---- the short path: my rows' id counts to their tiles' sums (R <= 64 consecutive rows: two tiles at most), and whether
+            // compact_kernel may go ahead
+            const int my_cnt = l < nr && !is_pending ? rec_cnt : 0;
+            const int t0 = row0 / kRowTile;
+            const int all = wave_sum(my_cnt), first = wave_sum((row0 + l) / kRowTile == t0 ? my_cnt : 0);
+            if (l == 0) {
+                if (first) atomicAdd(&w.tile_cnt[t0], first);
+                if (all - first) atomicAdd(&w.tile_cnt[t0 + 1], all - first);
+                if (!exact || pm) atomicAdd(&w.status->n_inexact, 1);
+            }
+        }
     }
 }
 

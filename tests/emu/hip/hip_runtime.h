@@ -128,7 +128,14 @@ inline int lane() { return int(thread_idx().x) & (WAVE - 1); }
 inline Rendezvous& my_wave() { return blk().wave_rdv[thread_idx().x / WAVE]; }
 
 inline void wave_barrier() { rendezvous(my_wave(), lane(), WAVE, 0); }
-inline void block_barrier() { rendezvous(blk().block_rdv, int(thread_idx().x), int(block_dim().x), 0); }
+// s_barrier waits on the SURVIVING waves only (a wave that has ended does not hold the others: GCN3 ISA, S_BARRIER): the
+// rendezvous counts the fibers that have not finished, and a fiber that finishes while others wait may be the one they waited for.
+inline int live_fibers() {
+    int n = 0;
+    for (const Fiber& f : blk().fibers) n += f.done ? 0 : 1;
+    return n;
+}
+inline void block_barrier() { rendezvous(blk().block_rdv, int(thread_idx().x), live_fibers(), 0); }
 inline unsigned long long ballot(int pred) {
     Rendezvous& r = my_wave();
     const int par = rendezvous(r, lane(), WAVE, pred ? 1 : 0);
@@ -153,6 +160,13 @@ inline void fiber_entry() {
     blk().body();
     cur_fiber().done = true;
     ++blk().progress;
+    {   // the fibers waiting at a block barrier were waiting for the survivors: this one is no longer among them
+        Rendezvous& r = blk().block_rdv;
+        if (r.arrived > 0 && r.arrived == live_fibers()) {
+            r.arrived = 0;
+            ++r.gen;
+        }
+    }
     swapcontext(&cur_fiber().ctx, &blk().sched);
 }
 
