@@ -1094,7 +1094,11 @@ def main():
             return res
         return exchange.submit_wire(*res) if to_wire else exchange.submit(*res)
 
-    def run_steps(first, n):
+    def run_steps(first, n, stamps=None):
+        def done(f):
+            complete(f)
+            if stamps is not None:
+                stamps.append(time.perf_counter())
         if two_half:
             inflight = []
             for i in range(first, first + n):
@@ -1103,12 +1107,12 @@ def main():
                 st = stream_ptrs[i % len(stream_ptrs)]
                 inflight.append(wl.enqueue_wire(i, st, exchange.lease_wire(), exchange) if to_wire else wl.enqueue(i, st))
                 if len(inflight) > args.depth:
-                    complete(inflight.pop(0))
+                    done(inflight.pop(0))
             while inflight:
-                complete(inflight.pop(0))
+                done(inflight.pop(0))
         else:
             for i in range(first, first + n):
-                complete(lambda i=i: wl.step(i))
+                done(lambda i=i: wl.step(i))
         if exchange is not None:
             exchange.flush()
 
@@ -1131,6 +1135,24 @@ def main():
     run_steps(args.warmup, args.steps)   # every one of the K batches is complete (and, N > 1, gathered on every rank) when it returns
     barrier()
     dt = time.perf_counter() - t0
+    # The same loop for 200 further steps: the K steps above are the reported region -- 1.3 ms of wall time at K = 20,
+    # of which one fill of the three-stream pipeline is a visible part --, this leg says what the loop settles at, and how evenly the
+    # batches complete (the host-side interval between two completions: its median, and the 90th percentile).
+    steady = None
+    if not latency_cfg and world == 1:
+        n_steady = 200
+        stamps = []
+        barrier()
+        ts0 = time.perf_counter()
+        run_steps(args.warmup + args.steps, n_steady, stamps)
+        barrier()
+        dts = time.perf_counter() - ts0
+        su = sum(wl.units(i) for i in range(args.warmup + args.steps, args.warmup + args.steps + n_steady))
+        gaps = np.diff(np.asarray(stamps)) * 1e3
+        steady = {"steps": n_steady, "ms_per_step": round(dts / n_steady * 1e3, 4),
+                  "value": round(su / dts / (1e9 if wl.unit == "GB/s" else 1e6), 1), "unit": wl.unit,
+                  "completion_interval_ms": {"p50": round(float(np.median(gaps)), 4), "p90": round(float(np.percentile(gaps, 90)), 4)},
+                  "note": "the same host loop for 200 further steps behind the reported region; not `value`"}
     # per-kernel wall times of the same loop (overlapped launches), collected in a leg of its own behind the timed region
     n_prof = min(args.steps, 48)
     lib.ovtk_profile_reset()
@@ -1199,7 +1221,10 @@ def main():
                     "launches_per_step": launches_per_step,
                     "bytes_note": ("algorithmic bytes of the whole pass (SURVEY 8d) over the dominant kernel's own time.  For the encode "
                                    "configurations that kernel reads all the text and stages all ids but those of the deferred pieces, "
-                                   "so its own algorithmic bytes are the same figure within ~5 %; `step` prices every kernel of the path"),
+                                   "so its own algorithmic bytes are the same figure within ~5 %; `step` prices every kernel of the path.  "
+                                   "`traffic` / `step_traffic` = 2 x FETCH_SIZE + WRITE_SIZE (profiles/latest_pmc.json): the guide calibrates the doubling "
+                                   "for wide streaming reads only (MI355X_MICROARCH.md, HBM counters), so on the 32-byte random probes of the memo -- "
+                                   "two thirds of this kernel's fetches -- it is an upper bound"),
                     "measured": (f"one-stream leg of {n_leg} batches behind the timed region (every kernel alone on the chip)" if alone
                                  else "the timed loop's own launches"),
                     "one_stream_kernel_ms": {k: round(v, 4) for k, v in sorted(per_launch.items())},
@@ -1323,6 +1348,7 @@ def main():
                                                                     f"{'all-gather' if exchange.transport == 'allgather' else 'grouped direct send/recv'} of ragged ids over RCCL, {exchange.id_bytes}-byte ids on the wire, "
                                                                     f"{'written by the encode itself (compact_kernel), ' if to_wire else 'packed by shard_pack_kernel, '}"
                                                                     f"gather overlapped with the next encode, unpack one batch later ({exchange.regathers} re-gathers)"))},
+        "value_steady": steady["value"] if steady else None, "steady": steady,
         "roofline": roofline, "cpu_baseline": cpu_baseline, "cpu_baseline_all_cores": cpu_all, "cpu_baseline_all_cores_private": cpu_all_private,
         "cpu_baseline_thread_curve": cpu_curve, "stress": stress, "end_to_end": e2e,
         "parity_prefix_bit_exact": parity,
