@@ -215,16 +215,19 @@ int ovtk_encode_run(ovtk_regex_split* split, ovtk_bpe* bpe, const ovtk_ragged_st
  * resident late because another stream's kernel (RCCL's all-gather during the row-shard exchange) holds their CU take
  * less work instead of finishing last.  Results are identical either way. */
 int ovtk_set_row_tickets(int rows_per_ticket);
-/* The short path (round 6), process-wide: ovtk_encode_run / _enqueue (and the wire / dense forms) with a pattern the span kernel scans
- * (the GPT-2, Llama-3, o200k and DeepSeek-V3 families) is TWO launches where every piece of the batch is in the handle's memo or piece
- * store: lookup_span_kernel looks the pieces the memo does not hold up in the store itself, compact_kernel follows at once -- no
- * launch of lookup_kernel for left-over rows (there are none), none of merge_kernel (nothing to merge).  When a wave of the span
- * kernel reports a piece that is in neither table, or a row it left to the generic kernel, those kernels are launched after all
- * (from ovtk_encode_finish / inside ovtk_encode_run).  Results are identical either way.
- * 0: never; 1 (default): a handle tries, and after a call that needed the other kernels skips 1, 2, 4 ... 64 calls before it tries
- * again (a text the tables are still learning); 2: every eligible call tries, small batches included (tests). */
+/* The short path (round 6), process-wide.  ovtk_encode_run / _enqueue (and the wire / dense / special forms) with a pattern the span kernel
+ * scans (the GPT-2, Llama-3, o200k and DeepSeek-V3 families) and ovtk_wordpiece_encode_* were four launches per call: the span kernel,
+ * lookup_kernel for the rows it leaves (rows of several strings, skipped strings: rare), merge_kernel / wordpiece_deferred_kernel for the
+ * pieces the memo does not hold, compact_kernel.  Now the span kernel looks those pieces up in the handle's piece store itself and
+ * counts what is in neither table, and the two kernels in the middle are launched only when the handle's last calls had work for them
+ * (every call that had sets a count of 16 calls, every call that had not takes one off; a new handle starts with merging expected).
+ * When a kernel was left out and had work after all, compact_kernel writes nothing and the kernel follows, with compact_kernel again,
+ * from ovtk_encode_finish / inside ovtk_encode_run.  Results are identical either way.
+ * 0: never (every call launches all four, round 5's form); 1 (default): as described; 2: every call leaves out both kernels of the
+ * middle first, small batches included (tests: the way to the second set of launches). */
 int ovtk_set_short_path(int mode);
-/* Process-wide counts since the library was loaded: calls launched as span -> compact, and those of them that needed no other kernel. */
+/* Process-wide counts since the library was loaded: calls whose first set of launches left a kernel of the middle out, and those of
+ * them that needed no second set. */
 int ovtk_short_path_stats(int64_t* tried, int64_t* exact);
 
 typedef struct ovtk_pending ovtk_pending;

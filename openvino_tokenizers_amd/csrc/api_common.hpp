@@ -2,6 +2,7 @@
 #pragma once
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 
@@ -241,6 +242,15 @@ inline int grid_deferred_per_shard(long long n_chars, long long n_strings, int r
     return int(std::max<long long>(1, std::min<long long>(blocks, resident_per_shard)));
 }
 
+// ... and, the short path (EncodeWork::span_sums: the list holds only what is in neither table), no more than a list of about
+// `hint` pieces can use -- the kernels' fixed cost follows their grid (a launch that finds 13 words: 18 us on the full grid).  The
+// batches are strided over whatever grid there is, so a list that turns out longer is worked through all the same, by fewer waves.
+inline int grid_deferred_hinted(int full_per_shard, int span_sums, int hint) {
+    if (!span_sums || hint < 0) return full_per_shard;
+    const long long blocks = (4ll * hint + 1024 + (long long)kShards * kBlockThreads - 1) / ((long long)kShards * kBlockThreads);
+    return int(std::max<long long>(std::min<long long>(4, full_per_shard), std::min<long long>(blocks, full_per_shard)));
+}
+
 // The "ragged strings in -> ragged i32 out" pipeline shared by BPETokenizer, the fused encode and
 // WordpieceTokenizer: prep (validation + per-wave staging arenas) -> middle(ws, d_in, w, grid) (the op's kernels: ids
 // into staging, per-row counts; the first one must be launched with `grid` blocks, the geometry prep summed over) ->
@@ -326,10 +336,17 @@ public:
     // Asked once this run's event has completed, before its own status is looked at: what a stage in front of it (another
     // workspace's kernels on the same stream) has to say; non-zero ends finish() with that code.
     void front_check(std::function<int()> f) { front_check_ = std::move(f); }
-    // The middle's first kernel is lookup_span_kernel and may do the whole middle itself (EncodeWork::short_path, span_kernel.hpp "the
-    // short path"): launched with compact_kernel right behind it; the other kernels follow from finish() only when it reports waves
-    // that could not (n_inexact).
-    void enable_short_path() { short_ok_ = true; }
+    // The middle's first kernel is lookup_span_kernel and does the middle's bookkeeping itself (EncodeWork::span_sums, span_kernel.hpp
+    // "the short path"); of the kernels behind it only those are launched that the handle expects to find work -- lookup_kernel<kFused>
+    // for left-over rows, merge_kernel / wordpiece_deferred_kernel for pieces that are in neither table.  What was left out and was
+    // needed after all follows from finish() (compact_kernel wrote nothing then).
+    // merge_hint: pieces the handle's last call left for merge_kernel / wordpiece_deferred_kernel (< 0: unknown) -- sizes that launch.
+    void enable_short_path(bool expect_pending, bool expect_merge, int64_t merge_hint) {
+        short_ok_ = true;
+        expect_pending_ = expect_pending;
+        expect_merge_ = expect_merge;
+        merge_hint_ = merge_hint;
+    }
     void enable_stage16() { stage16_ = true; }   // the middle's kernels write / read the staging entries as u16 (EncodeWork::stage16)
     // The middle's first kernel takes staging for ALL its rows before it knows which of them it will leave to the kernel behind it
     // (lookup_span_kernel: one reservation per wave), and that kernel takes its own: room for both, or every call with left-over
@@ -402,6 +419,13 @@ public:
             if (front_check_)
                 if (int rc = front_check_()) return rc;
             const RunStatus& st = *ws_->host_status;
+            static const bool debug_status = std::getenv("OVTK_DEBUG_STATUS") != nullptr;
+            if (debug_status) {   // (a debugging aid: what the kernels reported, one line per attempt)
+                long long deferred = 0;
+                for (int k = 0; k < kShards; ++k) deferred += st.shard_count[k * kCounterStride];
+                std::fprintf(stderr, "[ovtk] %s rows %d phase %d flags %#x n_out %d deferred %lld pending %d unresolved %d exact-list %d store probes %d hits %d\n", op_.c_str(),
+                             n_rows_, phase_, st.flags, st.n_out, deferred, st.n_pending, st.n_unresolved, st.n_exact, st.n_store_probe, st.n_store_hit);
+            }
             if (st.flags & kFlagDidNotRun) return set_error(OVTK_E_HIP, op_ + ": the call's last kernel did not run (an earlier launch failed)");
             if (pending_clean_) {   // the one-launch kernel has run: it left the status block zeroed behind itself
                 ws_->clean_status = pending_clean_;
@@ -434,21 +458,21 @@ public:
             } else if (st.flags & kFlagTailPending) {
                 fold_tail_ = false;  // more exact pieces than the folded tail takes: once more with their own launches
                 small_ = false;
-            } else if (phase_ == 1 && st.n_inexact > 0) {
+            } else if (phase_ == 1 && (((w_.skip_mask & kSkipPending) && st.n_pending > 0) || ((w_.skip_mask & kSkipMerge) && st.n_unresolved > 0))) {
                 short_path_counts().tried.fetch_add(1, std::memory_order_relaxed);
-                // the short path: some wave of the span kernel left pieces or rows to the kernels that were not launched, compact_kernel
-                // wrote nothing -- those kernels after all
-                if (int rc = launch_phase2()) return rc;
+                // the short path: rows or pieces were left to a kernel that was not launched, compact_kernel wrote nothing -- that kernel
+                // after all, and compact_kernel again
+                if (int rc = launch_phase2(st)) return rc;
                 continue;
             } else {
-                if (phase_ == 1) {
+                if (phase_ == 1 && w_.skip_mask) {
                     short_path_counts().tried.fetch_add(1, std::memory_order_relaxed);
                     short_path_counts().exact.fetch_add(1, std::memory_order_relaxed);
                 }
                 out->n_data = st.n_out;
                 if (on_status_) {
                     RunStatus seen = st;
-                    seen.short_path = phase_ != 0 ? 1 : 0;
+                    seen.short_path = force_long_ ? 3 : phase_;   // (3: started over the long way -- rows were left over behind a merge_kernel that had run)
                     on_status_(seen);
                 }
                 if (st.flags & kFlagOutCapacity)
@@ -485,10 +509,11 @@ private:
         e = e ? e : ws.tiles.ensure(size_t(n_tiles_ + 1) * sizeof(long long));
         const bool fold = fold_tail_ && n_rows_ <= kFoldTailRows;
         size_t status_bytes = sizeof(RunStatus) + (fold ? size_t(n_tiles_) * 4 + 16 : 0);  // + tile_cnt, zeroed with the status (+ slack: compact_kernel reads it 16 bytes at a time)
-        // the short path: span -> compact (tile_cnt is summed by the span kernel's waves, every wave of compact_kernel sums the tiles in
-        // front of its own)
-        small_ = small_ && !(short_ok_ && short_path_mode().load(std::memory_order_relaxed) == 2);   // (mode 2: tests drive it with small batches)
-        const bool short_path = short_ok_ && !small_ && self_alloc_ && fold && short_path_mode().load(std::memory_order_relaxed) != 0;
+        // the short path (span_kernel.hpp): tile_cnt is summed by the lookup kernels' waves, every wave of compact_kernel sums the tiles in
+        // front of its own
+        const int sp_mode = short_path_mode().load(std::memory_order_relaxed);
+        small_ = small_ && !(short_ok_ && sp_mode == 2);   // (mode 2: tests drive it with small batches)
+        const bool span_sums = short_ok_ && !small_ && self_alloc_ && fold && sp_mode != 0 && !force_long_;
         const size_t status_stride = (status_bytes + 255) & ~size_t(255);   // two blocks: this call's, and the one compact_kernel zeroes for the next
         e = e ? e : ws.status.ensure(2 * status_stride);
         if (fold) e = e ? e : ws.gen[4].ensure(size_t(n_rows_) * 4);
@@ -554,7 +579,7 @@ private:
         // the large path, up to kTileSumTiles tiles: no ticket and no scan at the end of the middle's last kernel -- every wave of
         // compact_kernel sums the counts in front of its tile (beyond that the sums cost compact_kernel more than the tail cost the
         // middle: config 4's 2 048 tiles, compact 29.5 -> 32.7 us for merge_kernel 67 -> 62)
-        w.tile_sums = fold && (n_tiles_ <= kTileSumTiles || short_path) ? 1 : 0;
+        w.tile_sums = fold && (n_tiles_ <= kTileSumTiles || span_sums) ? 1 : 0;
         w.host_status = ws.host_status;
         w.status_words = int32_t(status_bytes / 4);
         if (ws.zeroed_status != mine || ws.zeroed_bytes < status_bytes || ws.zeroed_after_lease + 1 != ws.lease_count)
@@ -564,8 +589,13 @@ private:
         ws.host_status->flags = kFlagDidNotRun;               // overwritten by the kernel; one that did not run leaves this (finish: OVTK_E_HIP)
         if (!self_alloc_)
             OVTK_LAUNCH(ws.marks, "prep_rows", prep_rows_kernel, std::min(grid_, kTicketBlocks), kBlockThreads, s_, d_in_, mul_, w);
-        if (short_path) {
-            w.short_path = 1;
+        w.launch_mask = kLaunchAll;
+        if (span_sums) {
+            w.span_sums = 1;
+            // (mode 2 leaves out everything it can, whatever the handle expects: the tests' way to the second set of launches)
+            w.skip_mask = sp_mode == 2 ? (kSkipPending | kSkipMerge) : ((expect_pending_ ? 0 : kSkipPending) | (expect_merge_ ? 0 : kSkipMerge));
+            w.launch_mask = kLaunchSpan | ((w.skip_mask & kSkipPending) ? 0 : kLaunchPending) | ((w.skip_mask & kSkipMerge) ? 0 : kLaunchMerge);
+            w.merge_hint = int32_t(std::min<int64_t>(merge_hint_, INT32_MAX));
             w_ = w;
             phase_ = 1;
         }
@@ -573,19 +603,27 @@ private:
         return launch_tail(ws, w, other, status_bytes);
     }
 
-    // The short path, after all: the span kernel has run and reported waves that left something to the kernels that were not
-    // launched.  The status block, the staging buffer, the row records and the deferred list are as the four-launch form's span kernel
-    // leaves them -- but for the tile sums, which the span kernel's waves have added to: merge_kernel sums what the lookup kernels
-    // emitted itself (fold_emitted_tile_sums).
-    int launch_phase2() {
+    // The short path, after all: a kernel of the middle that was left out had work.  The status block, the staging buffer, the row
+    // records, the deferred list and the tile sums are as the kernels that did run left them; what is launched now adds to them.
+    int launch_phase2(const RunStatus& st) {
         OVTK_HIP(hipSetDevice(device_));
         Workspace& ws = *ws_.ws;
+        const bool pending_now = (w_.skip_mask & kSkipPending) && st.n_pending > 0;
+        if (pending_now && !(w_.skip_mask & kSkipMerge)) {
+            // merge_kernel has been through a list that the left-over rows' kernel is about to add to: from the start, every kernel
+            force_long_ = true;
+            return launch();
+        }
         EncodeWork w = w_;
-        w.short_path = 0;
-        w.phase2 = 1;
-        w.tile_sums = w.fold_tail && n_tiles_ <= kTileSumTiles ? 1 : 0;
-        if (w.tile_cnt) OVTK_HIP(hipMemsetAsync(w.tile_cnt, 0, size_t(n_tiles_) * 4, s_));
-        OVTK_HIP(hipMemsetAsync(&w.status->n_inexact, 0, 4, s_));
+        w.merge_hint = st.n_unresolved;   // (counted by the kernels that have run; the left-over rows' kernel may add to it)
+        w.launch_mask = (pending_now ? kLaunchPending : 0) | ((w_.skip_mask & kSkipMerge) ? kLaunchMerge : 0);
+        w.skip_mask = pending_now || !(w_.skip_mask & kSkipPending) ? 0 : kSkipPending;   // (rows were left over or they were not: nothing is left out that had work)
+        // what the first set's last kernels left in the status block: the row width and the capacity verdict of row_width_kernel /
+        // compact_kernel (made from row records that lacked rows or pieces) and the ticket they drew
+        static_assert(offsetof(RunStatus, width_ticket) == offsetof(RunStatus, width) + 4, "width and width_ticket are cleared together");
+        OVTK_HIP(hipMemsetAsync(&w.status->width, 0, 8, s_));
+        OVTK_HIP(hipMemsetAsync(&w.status->flags, 0, 4, s_));   // (no other flag is set: finish() came here past every one of them)
+        OVTK_HIP(hipMemsetAsync(&w.status->n_out, 0, 4, s_));
         std::memset(ws.host_status, 0, sizeof(RunStatus));
         ws.host_status->flags = kFlagDidNotRun;
         middle_(ws, d_in_, w, grid_);
@@ -649,8 +687,9 @@ private:
     bool fold_tail_;  // the middle's last kernel finishes the row scan itself (BPE: merge_kernel) while the batch is small
     bool small_ok_ = false, small_ = false;
     bool stage16_ = false, stage_twice_ = false;
-    bool short_ok_ = false;
-    int phase_ = 0;          // 1: the attempt in flight is the short path (span -> compact); 2: the other kernels were launched after all
+    bool short_ok_ = false, expect_pending_ = false, expect_merge_ = true, force_long_ = false;
+    int64_t merge_hint_ = -1;
+    int phase_ = 0;          // 1: the attempt in flight is the short path's first set of launches; 2: what it had left out was launched after all
     EncodeWork w_{};         // the attempt's work description (phase 2 launches with it)
     const void* zeroed_other_ = nullptr;
     size_t zeroed_other_bytes_ = 0;

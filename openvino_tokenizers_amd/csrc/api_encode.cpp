@@ -108,10 +108,11 @@ struct ovtk_bpe {
     // calls that still leave the piece store out: set to 32 after four calls in a row in which fewer than one probe in eight
     // hit (then the store is asked again, and so on -- text changes)
     mutable std::atomic<int> store_pause{0}, store_low{0};  // store_low: calls in a row with that little use of it
-    // The short path (span_kernel.hpp): eligible calls that still go the four-launch way -- after a call whose span kernel reported
-    // inexact waves (a text the tables are still learning, pieces the store cannot hold) the next `short_backoff` calls do not try, then
-    // one does; the count doubles with every failure in a row (up to 64) and starts over with the first success.
-    mutable std::atomic<int> short_skip{0}, short_backoff{0};
+    // The short path (span_kernel.hpp): calls during which the kernels of the middle are still launched whatever the last call said --
+    // lookup_kernel<kFused> for left-over rows, merge_kernel for pieces in neither table.  Set to 16 by every call that had such rows /
+    // pieces, counted down by every call that had none; a new handle's tables are empty: its first calls merge.
+    mutable std::atomic<int> expect_pending{0}, expect_merge{16};
+    mutable std::atomic<int> last_unresolved{-1};   // pieces the last such call left for merge_kernel (sizes its launch)
 };
 
 namespace {
@@ -749,7 +750,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // generic kernel
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
-                                   if (w.phase2) {}   // (the short path, after all: the span kernel has run)
+                                   if (!(w.launch_mask & kLaunchSpan)) {}   // (the short path's second set of launches: the span kernel has run)
                                    else if (T.pieces.slots && w1.stage16)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanLlama3, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (T.pieces.slots)
@@ -757,11 +758,11 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    else
                                        OVTK_LAUNCH(ws.marks, "lookup_rows", lookup_rows_kernel<kRowsLlama3>, grid1, kBlockThreads, s, d_in, split->dev,
                                                    T, w1);
-                                   if (w.short_path) return;   // (the short path: compact_kernel follows at once)
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
-                                               T, w2);
+                                   if (w.launch_mask & kLaunchPending)
+                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedLlama3>, grid, kBlockThreads, s, d_in, split->dev,
+                                                   T, w2);
                                }
                                else if (family && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFusedSeq, true>), grid, kBlockThreads, s, d_in,
@@ -771,7 +772,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // (several strings, skipped ones) are matched literally, a lane per row's window
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
-                                   if (w.phase2) {}
+                                   if (!(w.launch_mask & kLaunchSpan)) {}
                                    else if (family == kFamDs3 && w1.stage16)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanDs3, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (family == kFamDs3)
@@ -780,10 +781,10 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanO200k, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanO200k, false>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
-                                   if (w.short_path) return;
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedSeq>, grid, kBlockThreads, s, d_in, split->dev, T, w2);
+                                   if (w.launch_mask & kLaunchPending)
+                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFusedSeq>, grid, kBlockThreads, s, d_in, split->dev, T, w2);
                                }
                                else if (split && tickets)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", (lookup_kernel<kFused, true>), grid, kBlockThreads, s, d_in,
@@ -794,7 +795,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // (marked in row_used, listed in pending_rows) goes through the generic kernel
                                    EncodeWork w1 = w;
                                    const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
-                                   if (w.phase2) {}
+                                   if (!(w.launch_mask & kLaunchSpan)) {}
                                    else if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits && w1.stage16)
                                        OVTK_LAUNCH(ws.marks, "lookup_span", (lookup_span_kernel<kSpanGpt2Digits, true>), grid1, kBlockThreads, s, d_in, split->dev, T, w1);
                                    else if (T.pieces.slots && split->dev.kind == kSplitGpt2Digits)
@@ -812,11 +813,11 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                    // what it left: the generic kernel (it returns at once when nothing was left).  A smaller stand-by
                                    // grid for handles whose last call left no row was measured: nothing gained on all-ASCII text
                                    // (6.0 vs 6.2 us), and the rows that do turn up then wait for 64 blocks to walk every row's flag
-                                   if (w.short_path) return;
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
-                                               T, w2);
+                                   if (w.launch_mask & kLaunchPending)
+                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, split->dev,
+                                                   T, w2);
                                } else if (split)
                                    OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in,
                                                split->dev, T, w);
@@ -826,16 +827,17 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
                                else
                                    OVTK_LAUNCH(ws.marks, "lookup_pieces", lookup_kernel<kPieces>, grid, kBlockThreads, s, d_in,
                                                SplitDev{}, T, w);
+                               if (!(w.launch_mask & kLaunchMerge)) return;   // (the short path: nothing is expected to be left to merge)
                                const int tail_rows = w.fold_tail ? d_in.n_rows : 0;
                                if (bpe->narrow_ids) {
                                    static const int per_cu = resident_blocks_per_cu(merge_kernel<true>);
                                    OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<true>,
-                                               dim3(kShards, grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * per_cu / kShards)),
+                                               dim3(kShards, grid_deferred_hinted(grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * per_cu / kShards), w.span_sums, w.merge_hint)),
                                                kBlockThreads, s, d_in, T, w, tail_rows, w.out_cap);
                                } else {
                                    static const int per_cu = resident_blocks_per_cu(merge_kernel<false>);
                                    OVTK_LAUNCH(ws.marks, "bpe_merge", merge_kernel<false>,
-                                               dim3(kShards, grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * per_cu / kShards)),
+                                               dim3(kShards, grid_deferred_hinted(grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * per_cu / kShards), w.span_sums, w.merge_hint)),
                                                kBlockThreads, s, d_in, T, w, tail_rows, w.out_cap);
                                }
                                if (!w.fold_tail) OVTK_LAUNCH(ws.marks, "bpe_exact", exact_kernel, 64, kBlockThreads, s, d_in, T, w);
@@ -874,28 +876,25 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
     else if (device_inputs)
         r->input_on_device(device_inputs);
     const bool has_store = T.store.slots != nullptr;
-    // The short path: span -> compact.  Where the call's first kernel is lookup_span_kernel and the handle's last attempts do not say
-    // otherwise.
-    bool short_path = split && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3 || split->dev.family != kFamNone) && T.pieces.slots &&
-                      !row_tickets().load(std::memory_order_relaxed) && short_path_mode().load(std::memory_order_relaxed) != 0;
-    if (short_path && short_path_mode().load(std::memory_order_relaxed) == 1) {
-        if (!has_store) short_path = false;   // (every miss of the memo would be an inexact wave)
-        else if (bpe->short_skip.load(std::memory_order_relaxed) > 0) {
-            bpe->short_skip.fetch_sub(1, std::memory_order_relaxed);
-            short_path = false;
-        }
-    }
-    if (short_path) r->enable_short_path();
+    // The short path (span_kernel.hpp): where the call's first kernel is lookup_span_kernel, the kernels behind it are launched only when
+    // the handle's last calls had work for them.
+    const bool short_path = split && (split->dev.kind <= kSplitGpt2Digits || split->dev.kind == kSplitLlama3 || split->dev.family != kFamNone) && T.pieces.slots &&
+                            !row_tickets().load(std::memory_order_relaxed) && short_path_mode().load(std::memory_order_relaxed) != 0;
+    if (short_path)
+        r->enable_short_path(bpe->expect_pending.load(std::memory_order_relaxed) > 0, bpe->expect_merge.load(std::memory_order_relaxed) > 0 || !has_store,
+                             has_store ? bpe->last_unresolved.load(std::memory_order_relaxed) : -1);
     if (has_store || dense_width || short_path)   // what the store did for this call decides whether the next ones ask it at all
         r->on_status([bpe, has_store, dense_width](const RunStatus& st) {
             if (dense_width) *dense_width = st.width;
-            if (st.short_path) {   // the call was launched as span -> compact
-                if (st.n_inexact > 0) {
-                    const int b = std::min(64, std::max(1, 2 * bpe->short_backoff.load(std::memory_order_relaxed)));
-                    bpe->short_backoff.store(b, std::memory_order_relaxed);
-                    bpe->short_skip.store(b, std::memory_order_relaxed);
-                } else {
-                    bpe->short_backoff.store(0, std::memory_order_relaxed);
+            if (st.short_path) {   // the span kernel counted: what this call's text left to the kernels of the middle
+                auto note = [](std::atomic<int>& expect, bool had_work) {
+                    if (had_work) expect.store(16, std::memory_order_relaxed);
+                    else if (expect.load(std::memory_order_relaxed) > 0) expect.fetch_sub(1, std::memory_order_relaxed);
+                };
+                note(bpe->expect_pending, st.n_pending > 0);
+                if (st.short_path != 3) {   // (3: the long way, nothing was counted)
+                    note(bpe->expect_merge, st.n_unresolved > 0);
+                    bpe->last_unresolved.store(st.n_unresolved, std::memory_order_relaxed);
                 }
             }
             if (!has_store) return;

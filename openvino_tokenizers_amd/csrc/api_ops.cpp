@@ -99,6 +99,7 @@ struct ovtk_wordpiece {
     int32_t store_capacity = 0;
     PieceTableDev memo{nullptr, 30, nullptr, 0, 0};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
     int64_t n_vocab = 0;   // ids are vocabulary indices: below 65535 (and unk_token_id too), a call stages u16 entries
+    std::atomic<int> expect_pending{0}, expect_merge{16}, last_unresolved{-1};   // the short path's predictors (api_encode.cpp ovtk_bpe says how they count)
 };
 
 struct ovtk_vocab_encoder {
@@ -229,7 +230,9 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
     sp.drop = 1;
     BpeDev memo_only{};        // the lookup kernel reads nothing but the memo and the (absent) end suffix
     memo_only.pieces = h->memo;
+    memo_only.store = h->dev.store;   // (the short path: lookup_span_kernel looks the words the memo does not hold up in the word store itself)
     memo_only.suffix_len = 0;
+    memo_only.unk_id = unk_token_id;   // (what a word-store entry without a segmentation comes back as)
     const int dev = h->device;
     const WordpieceDev wdev = h->dev;
     auto r = make_rows_run(dev, "WordpieceTokenizer", in, nullptr, 1, out, mem, s,
@@ -241,7 +244,8 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                const int grid1 = rows_grid(d_in.n_rows, grid, w1.rows_per_wave);
                                if (!w.rows_per_ticket) {
                                    // several rows per scan block (span_kernel.hpp) where there is a word memo to probe
-                                   if (memo_only.pieces.slots && w1.stage16)
+                                   if (!(w.launch_mask & kLaunchSpan)) {}   // (the short path's second set of launches: the span kernel has run)
+                                   else if (memo_only.pieces.slots && w1.stage16)
                                        OVTK_LAUNCH(ws.marks, "lookup_words", (lookup_span_kernel<kSpanBertWords, true>), grid1, kBlockThreads, s, d_in, sp,
                                                    memo_only, w1);
                                    else if (memo_only.pieces.slots)
@@ -252,11 +256,13 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                                                    memo_only, w1);
                                    EncodeWork w2 = w;
                                    w2.only_pending = 1;
-                                   OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp, memo_only, w2);
+                                   if (w.launch_mask & kLaunchPending)
+                                       OVTK_LAUNCH(ws.marks, "lookup_fused", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp, memo_only, w2);
                                } else {
                                    OVTK_LAUNCH(ws.marks, "lookup_words", lookup_kernel<kFused>, grid, kBlockThreads, s, d_in, sp, memo_only, w);
                                }
-                               const dim3 dgrid(grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * 8 / kShards), kShards);
+                               if (!(w.launch_mask & kLaunchMerge)) return;   // (the short path: no word is expected to be left for the tries)
+                               const dim3 dgrid(grid_deferred_hinted(grid_deferred_per_shard(d_in.n_chars, d_in.n_strings, device_cu_count(dev) * 8 / kShards), w.span_sums, w.merge_hint), kShards);
                                if (w.stage16)
                                    OVTK_LAUNCH(ws.marks, "wordpiece_deferred", wordpiece_deferred_kernel<true>, dgrid, kBlockThreads, s, d_in, wdev,
                                                unk_token_id, w, w.fold_tail ? d_in.n_rows : 0, w.out_cap);
@@ -269,6 +275,24 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
                            /*tail_in_middle=*/true);
     if (h->n_vocab > 0 && h->n_vocab <= 65535 && unk_token_id >= 0 && unk_token_id <= 65534) r->enable_stage16();
     if (memo_only.pieces.slots) r->stage_twice();   // (lookup_span_kernel in front of the generic kernel)
+    // The short path (span_kernel.hpp): lookup_kernel<kFused> / wordpiece_deferred_kernel only when the handle's last calls had rows /
+    // words for them (as a BPE handle does: api_encode.cpp).
+    if (memo_only.pieces.slots && !row_tickets().load(std::memory_order_relaxed) && short_path_mode().load(std::memory_order_relaxed) != 0) {
+        r->enable_short_path(h->expect_pending.load(std::memory_order_relaxed) > 0, h->expect_merge.load(std::memory_order_relaxed) > 0 || !memo_only.store.slots,
+                             memo_only.store.slots ? h->last_unresolved.load(std::memory_order_relaxed) : -1);
+        r->on_status([h](const RunStatus& st) {
+            if (!st.short_path) return;
+            auto note = [](std::atomic<int>& expect, bool had_work) {
+                if (had_work) expect.store(16, std::memory_order_relaxed);
+                else if (expect.load(std::memory_order_relaxed) > 0) expect.fetch_sub(1, std::memory_order_relaxed);
+            };
+            note(h->expect_pending, st.n_pending > 0);
+            if (st.short_path != 3) {   // (3: the long way, nothing was counted)
+                note(h->expect_merge, st.n_unresolved > 0);
+                h->last_unresolved.store(st.n_unresolved, std::memory_order_relaxed);
+            }
+        });
+    }
     if (int rc = r->start()) return rc;
     run = std::move(r);
     return OVTK_OK;

@@ -36,10 +36,9 @@ struct RunStatus {
     int32_t n_store_hit;   // ... and found there
     int32_t width;         // dense output (ovtk_encode_dense_*): the row width row_width_kernel settled on
     uint32_t width_ticket; // ... and its "last block done" ticket
-    int32_t n_inexact;     // the short path (EncodeWork::short_path): waves of lookup_span_kernel that left something to the kernels that were
-                           // not launched -- a piece neither the memo nor the store holds, a row for the generic kernel; > 0: compact_kernel
-                           // wrote nothing and the host launches lookup_kernel<kFused> / merge_kernel / compact_kernel after all
-    int32_t short_path;    // (host side: the attempt that completed the call was the short path's)
+    int32_t n_unresolved;  // the short path (EncodeWork::span_sums): pieces filed for merge_kernel / wordpiece_deferred_kernel -- what neither the memo
+                           // nor the piece store holds (the span kernel looks its misses up in the store itself)
+    int32_t short_path;    // (host side, for the handle's predictors: 1 the call's first set of launches did it, 2 a second set was needed, 3 started over the long way)
     int32_t pad[16];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s
     int32_t stage_top[kShards * kCounterStride];    // [s * kCounterStride] = staging entries handed out in region s

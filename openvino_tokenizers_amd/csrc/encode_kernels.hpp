@@ -104,14 +104,20 @@ struct EncodeWork {
     uint8_t* scratch;
     uint32_t scratch_cap;
     RunStatus* status;
-    // ---- the short path (round 6; span_kernel.hpp "the short path"): lookup_span_kernel looks the pieces the memo does not hold up in
-    // the piece store itself and sums its rows' counts into tile_cnt; compact_kernel follows at once -- no lookup_kernel<kFused>, no
-    // merge_kernel launch unless a wave reports that it could not (RunStatus::n_inexact: compact_kernel then writes nothing)
-    int32_t short_path;
-    int32_t phase2;          // (host side, the middle's launches) the span kernel has run and left inexact waves: launch what follows it
+    // ---- the short path (round 6; span_kernel.hpp "the short path")
+    int32_t span_sums;       // lookup_span_kernel looks the pieces the memo does not hold up in the piece store itself, counts what is left
+                             // (RunStatus::n_unresolved) and sums its rows' ids into tile_cnt; the kernels behind it add to these (lookup_kernel
+                             // with only_pending: its rows' counts, its misses) instead of summing row_emit once more
+    int32_t skip_mask;       // kernels of the middle that were not launched: kSkipPending lookup_kernel<kFused> for left-over rows, kSkipMerge
+                             // merge_kernel / wordpiece_deferred_kernel -- compact_kernel writes nothing when one of them had work
+    int32_t merge_hint;      // (host side) pieces the last call of the handle left for merge_kernel / wordpiece_deferred_kernel, < 0: unknown
+    int32_t launch_mask;     // (host side) what the middle launches now: kLaunchSpan its first kernel, kLaunchPending lookup_kernel<kFused> for the
+                             // rows that one leaves, kLaunchMerge merge_kernel / wordpiece_deferred_kernel
 };
 
 constexpr uint32_t kFatalFlags = kFlagRange | kFlagStageOverflow;
+constexpr int kSkipPending = 1, kSkipMerge = 2;   // EncodeWork::skip_mask
+constexpr int kLaunchSpan = 1, kLaunchPending = 2, kLaunchMerge = 4, kLaunchAll = 7;   // EncodeWork::launch_mask
 
 // One staging entry (w.stage16 is a kernel argument: the branch is scalar).
 __device__ __forceinline__ void stage_put(const EncodeWork& w, int pos, int32_t id) {
@@ -480,7 +486,10 @@ __device__ __forceinline__ void flush_misses(WaveMiss& mb, int& n_miss, int n, c
     const int l = lane_id();
     const int shard = w.small ? 0 : int(blockIdx.x) % kShards;  // (a small batch: one dense list for the one block that merges)
     int idx = 0;
-    if (l == 0) idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
+    if (l == 0) {
+        idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
+        if (w.span_sums) atomicAdd(&w.status->n_unresolved, n);   // (the short path: this kernel runs for the rows the span kernel left)
+    }
     idx = wave_readlane(idx, 0);
     if (l < n) {
         if (idx + l < w.shard_cap) w.deferred[(long long)shard * w.shard_cap + idx + l] = mb.e[l];
@@ -743,6 +752,7 @@ __device__ __forceinline__ void lookup_body(const RowsIn& in, const SplitDev& sp
             w.row_cnt[row] = st.emitted;
             if (w.row_emit) w.row_emit[row] = st.emitted;  // (an atomic into tile_cnt here would stall every row: vmcnt is in order)
             w.row_used[row] = st.used;
+            if (w.span_sums && st.emitted) atomicAdd(&w.tile_cnt[row / kRowTile], st.emitted);   // (the short path: the few rows the span kernel left)
         }
         cursor += st.used;
         if (listed) {
@@ -1035,7 +1045,7 @@ __device__ __forceinline__ void merge_body(const RowsIn& in, const BpeDev& T, co
     __syncthreads();
     PROBE(0);
     if (flags0 & (kFatalFlags | kFlagDeferOverflow)) return;
-    if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows, solo);
+    if (tail_rows > 0 && !w.span_sums) fold_emitted_tile_sums(w, tail_rows, solo);   // (span_sums: the lookup kernels have summed their rows themselves)
     PROBE(1);
     uint64_t* key = lds_all[wave_in_block()];                                 // path W
     uint32_t* id = reinterpret_cast<uint32_t*>(key + kChunkSyms);             // path W
@@ -1633,7 +1643,8 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
     if ((w.status->flags | more_flags) & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
                                          kFlagTailPending))
         return;
-    if (w.short_path && w.status->n_inexact != 0) return;   // (the short path: a wave of the span kernel left pieces or rows to the kernels that were not launched)
+    // the short path: rows or pieces were left to a kernel that was not launched (the host launches it, and this kernel again)
+    if (((w.skip_mask & kSkipPending) && w.status->n_pending != 0) || ((w.skip_mask & kSkipMerge) && w.status->n_unresolved != 0)) return;
     sink.start(w.status);
     const int l = lane_id();
     const int n_waves = (solo ? 1 : int(gridDim.x)) * kWavesPerBlock;

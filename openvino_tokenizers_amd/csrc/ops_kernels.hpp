@@ -45,9 +45,11 @@ struct StageSlot {
         return w.stage[pos + k];
     }
 };
+// *is_unk (optional): the word has no segmentation and came out as unk_token_id -- as opposed to a word whose one token happens to be that id.
 template <class GetByte, class Slot>
 __device__ __forceinline__ int wordpiece_word(const WordpieceDev& T, const I2* root_lds, const I2* sub_lds, GetByte&& getb,
-                                              int len, int32_t unk_id, const Slot& slot) {
+                                              int len, int32_t unk_id, const Slot& slot, bool* is_unk = nullptr) {
+    if (is_unk) *is_unk = true;
     if (len > T.max_bytes || len <= 0) {  // strict > (:100-103); an empty word is undefined in the reference
         slot.put(0, unk_id);
         return 1;
@@ -67,6 +69,7 @@ __device__ __forceinline__ int wordpiece_word(const WordpieceDev& T, const I2* r
         }
         slot.put(cnt++, tok);
     }
+    if (is_unk) *is_unk = false;
     return cnt;
 }
 
@@ -143,7 +146,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
     __syncthreads();
     PROBE(1);
     if (flags0 & (kFatalFlags | kFlagDeferOverflow)) return;
-    if (tail_rows > 0) fold_emitted_tile_sums(w, tail_rows);
+    if (tail_rows > 0 && !w.span_sums) fold_emitted_tile_sums(w, tail_rows);   // (span_sums: the lookup kernels have summed their rows themselves)
     PROBE(2);
     if (count > w.shard_cap) count = w.shard_cap;
     const DeferredPiece* list = w.deferred + (long long)shard * w.shard_cap;
@@ -162,8 +165,9 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
         if (valid) e = list[base + l];
         int cnt = 0;
         // The word store first (the piece store of tables.hpp, keyed by the word): a word it holds is one probe instead of a
-        // trie walk of one dependent load per byte.  What is filed there never depends on unk_token_id -- a word that came out
-        // as unk is not stored --, so the table stays valid whatever input 8 says on the next call.
+        // trie walk of one dependent load per byte.  What is filed there never depends on unk_token_id -- a word without a
+        // segmentation is filed as one id kStoreUnk16 / kStoreUnk32 (no vocabulary index) and comes back as THIS call's input 8 --,
+        // so the table stays valid whatever input 8 says on the next call.
         PROBE(3);   // (the batch's entries are here)
         const StageSlot<S16> out{w, e.stage_pos};
         uint32_t skey[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -183,39 +187,41 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
                 if (T.store.narrow) {
 #pragma unroll
                     for (int k = 0; k < kStoreIds16; ++k)
-                        if (k < c) out.put(k, store_id<true>(pay, k));
+                        if (k < c) out.put(k, k == 0 && store_id<true>(pay, 0) == kStoreUnk16 ? unk_id : store_id<true>(pay, k));
                 } else {
 #pragma unroll
                     for (int k = 0; k < kStoreIds32; ++k)
-                        if (k < c) out.put(k, store_id<false>(pay, k));
+                        if (k < c) out.put(k, k == 0 && store_id<false>(pay, 0) == kStoreUnk32 ? unk_id : store_id<false>(pay, k));
                 }
                 for (int k = c; k < e.len; ++k) out.clear(k);
             }
         }
         PROBE(4);   // (the store has answered)
+        bool is_unk = false;   // the word has no segmentation (as opposed to: its one token is the id input 8 names)
         if (valid && !stored) {
             if (e.len >= 1 && e.len <= kPieceKeyBytes) {
                 const uint64_t k0 = e.k0, k1 = e.k1;
                 cnt = wordpiece_word(
                     T, root_lds, sub_lds,
                     [&](int i) -> uint32_t { return uint32_t((i < 8 ? k0 >> (8 * i) : k1 >> (8 * (i - 8))) & 0xFF); }, e.len,
-                    unk_id, out);
+                    unk_id, out, &is_unk);
             } else {
                 const uint8_t* s = in.chars + e.begin;
-                cnt = wordpiece_word(T, root_lds, sub_lds, [&](int i) -> uint32_t { return s[i]; }, e.len, unk_id, out);
+                cnt = wordpiece_word(T, root_lds, sub_lds, [&](int i) -> uint32_t { return s[i]; }, e.len, unk_id, out, &is_unk);
             }
             for (int k = cnt; k < e.len; ++k) out.clear(k);
         }
         if (store_budget > 0) {  // file what was walked: its ids come back from the lane's own staging entries
             const int max_ids = T.store.narrow ? kStoreIds16 : kStoreIds32;
-            const bool want = keyed && !stored && cnt <= max_ids && !(cnt == 1 && out.get(0) == unk_id);
+            const bool want = keyed && !stored && cnt <= max_ids;
             if (__ballot(want)) {
                 bool added = false;
                 if (want) {
                     uint32_t pay[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
                     for (int k = 0; k < kStoreIds16; ++k) {
-                        const uint32_t v = k < cnt ? uint32_t(out.get(k)) : 0u;
+                        uint32_t v = k < cnt ? uint32_t(out.get(k)) : 0u;
+                        if (k == 0 && is_unk) v = T.store.narrow ? uint32_t(kStoreUnk16) : uint32_t(kStoreUnk32);
                         if (T.store.narrow) pay[k >> 1] |= v << (16 * (k & 1));
                         else if (k < kStoreIds32) pay[k] = v;
                     }
@@ -232,8 +238,7 @@ static __global__ __launch_bounds__(kBlockThreads) void wordpiece_deferred_kerne
         if (my_room) {
             // (not the words the store knew: they were offered to the memo when they were walked, and found their slot taken)
             const int memo_ids = T.memo.packed6 ? kPieceMaxIds6 : kPieceMaxIds;
-            const bool keep = valid && !stored && e.len >= 1 && e.len <= kPieceKeyBytes && cnt >= 1 && cnt <= memo_ids &&
-                              !(cnt == 1 && out.get(0) == unk_id);
+            const bool keep = valid && !stored && e.len >= 1 && e.len <= kPieceKeyBytes && cnt >= 1 && cnt <= memo_ids && !is_unk;   // (the memo has no "input 8" entry)
             const unsigned long long km = __ballot(keep);
             if (km) {
                 int left = 0;

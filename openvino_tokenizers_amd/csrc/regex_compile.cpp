@@ -136,6 +136,12 @@ struct Node {
 struct Unsupported {
     std::string what;
 };
+// What PCRE2 itself rejects (pcre2_compile returns NULL): the reference then keeps a null pattern and every match "fails"
+// (src/utils.cpp:264-271, 397-399) -- RegexSplit passes every string through unsplit.  Only the errors that are certain are thrown
+// as Invalid; whatever PCRE2 might accept (a property name this table does not know, a group option it does) stays Unsupported.
+struct Invalid {
+    std::string what;
+};
 
 struct Flags {
     bool caseless = false, dotall = false;
@@ -148,11 +154,11 @@ public:
         for (size_t i = 0; i < utf8.size();) {
             const uint8_t b = uint8_t(utf8[i]);
             int n = b < 0x80 ? 1 : (b >= 0xF0 ? 4 : (b >= 0xE0 ? 3 : (b >= 0xC0 ? 2 : 0)));
-            if (n == 0 || i + size_t(n) > utf8.size()) throw Unsupported{"pattern is not valid UTF-8"};
+            if (n == 0 || i + size_t(n) > utf8.size()) throw Invalid{"pattern is not valid UTF-8"};
             uint32_t cp = n == 1 ? b : (b & (0xFFu >> (n + 1)));
             for (int k = 1; k < n; ++k) {
                 const uint8_t c = uint8_t(utf8[i + size_t(k)]);
-                if ((c & 0xC0) != 0x80) throw Unsupported{"pattern is not valid UTF-8"};
+                if ((c & 0xC0) != 0x80) throw Invalid{"pattern is not valid UTF-8"};
                 cp = (cp << 6) | (c & 0x3F);
             }
             p_.push_back(cp);
@@ -162,7 +168,7 @@ public:
     int parse() {
         Flags f;
         const int root = parse_alt(f);
-        if (pos_ != p_.size()) throw Unsupported{"unmatched ')'"};
+        if (pos_ != p_.size()) throw Invalid{"unmatched ')'"};
         return root;
     }
 
@@ -170,6 +176,7 @@ private:
     std::vector<Node>& nodes_;
     std::vector<uint32_t> p_;
     size_t pos_ = 0;
+    std::vector<std::string> group_names_;   // named groups seen so far (PCRE2 rejects a second use of a name)
 
     bool more() const { return pos_ < p_.size(); }
     uint32_t peek(size_t k = 0) const { return pos_ + k < p_.size() ? p_[pos_ + k] : 0xFFFFFFFFu; }
@@ -254,7 +261,7 @@ private:
             long long x = 0;
             while (q < p_.size() && p_[q] >= '0' && p_[q] <= '9') {
                 x = x * 10 + (p_[q] - '0');
-                if (x > 65535) throw Unsupported{"repeat count too large"};
+                if (x > 65535) throw Invalid{"number too big in {} quantifier"};
                 ++q;
             }
             v = int(x);
@@ -277,7 +284,7 @@ private:
             if (!number(mx)) mx = -1;
         }
         if (!(q < p_.size() && p_[q] == '}')) return false;
-        if (mx >= 0 && mx < mn) throw Unsupported{"{m,n} with n < m"};
+        if (mx >= 0 && mx < mn) throw Invalid{"numbers out of order in {} quantifier"};
         pos_ = q + 1;
         return true;
     }
@@ -290,8 +297,11 @@ private:
             else if (eat('?')) { mn = 0; mx = 1; }
             else if (peek() == '{' && parse_braces(mn, mx)) {}
             else return atom;
-            if (count) throw Unsupported{"quantifier on a quantifier"};
-            if (nodes_[size_t(atom)].kind == kAssert) throw Unsupported{"quantifier on an assertion"};
+            if (count) throw Invalid{"quantifier does not follow a repeatable item"};
+            if (nodes_[size_t(atom)].kind == kAssert) {
+                if (nodes_[size_t(atom)].akind == kAhead || nodes_[size_t(atom)].akind == kBehind) throw Unsupported{"quantifier on a look-around group"};
+                throw Invalid{"quantifier does not follow a repeatable item"};   // (^* $* \\b*)
+            }
             Node n;
             n.kind = kRepeat;
             n.kids = {atom};
@@ -319,7 +329,7 @@ private:
         if (eat('{')) {
             if (eat('^')) negate = !negate;
             while (more() && peek() != '}') name.push_back(char(p_[pos_++]));
-            if (!eat('}')) throw Unsupported{"unterminated \\p{"};
+            if (!eat('}')) throw Invalid{"malformed \\P or \\p sequence"};
         } else if (more()) {
             name.push_back(char(p_[pos_++]));
         }
@@ -372,7 +382,7 @@ private:
     // An escape (pos_ behind the backslash).  Returns true and fills `set` for a character-type escape; returns false
     // and fills `cp` for a single character.  in_class: inside [...].
     bool parse_escape(bool in_class, CharSet& set, uint32_t& cp, bool caseless = false) {
-        if (!more()) throw Unsupported{"pattern ends with a backslash"};
+        if (!more()) throw Invalid{"\\ at end of pattern"};
         const uint32_t c = p_[pos_++];
         switch (c) {
             case 'd': set = gc_set(gc_bit(Nd)); return true;
@@ -413,11 +423,11 @@ private:
                         v = v * 16 + uint32_t(hex(p_[pos_++]));
                         if (++digits > 6) throw Unsupported{"\\x{...} too long"};
                     }
-                    if (!eat('}') || digits == 0) throw Unsupported{"malformed \\x{...}"};
+                    if (!eat('}') || digits == 0) throw Invalid{"malformed \\x{...}"};
                 } else {
                     for (int k = 0; k < 2 && more() && hex(peek()) >= 0; ++k) v = v * 16 + uint32_t(hex(p_[pos_++]));
                 }
-                if (v > kMaxCp) throw Unsupported{"\\x beyond U+10FFFF"};
+                if (v > kMaxCp) throw Invalid{"code point value in \\x{} is too large"};
                 cp = v;
                 return false;
             }
@@ -437,12 +447,12 @@ private:
         CharSet explicit_chars, props;
         bool first = true, after_class_item = false;
         for (;;) {
-            if (!more()) throw Unsupported{"unterminated character class"};
+            if (!more()) throw Invalid{"missing terminating ] for character class"};
             uint32_t c = p_[pos_];
             if (c == ']' && !first) { ++pos_; break; }
             first = false;
             // "[\d-x]": PCRE2 rejects a range that starts at a class escape / POSIX class (only "-]" is a literal hyphen there)
-            if (c == '-' && after_class_item && peek(1) != ']') throw Unsupported{"hyphen behind a class escape"};
+            if (c == '-' && after_class_item && peek(1) != ']') throw Invalid{"invalid range in character class"};
             after_class_item = false;
             if (c == '[' && peek(1) == ':') {  // POSIX class; under UCP: Unicode properties
                 size_t q = pos_ + 2;
@@ -460,13 +470,15 @@ private:
                 else if (name == "digit") s = gc_set(gc_bit(Nd));
                 else if (name == "space") s = space_set();
                 else if (name == "word") s = word_set();
-                else throw Unsupported{"POSIX class [:" + name + ":]"};
+                else if (name == "ascii" || name == "blank" || name == "cntrl" || name == "graph" || name == "print" || name == "punct" || name == "xdigit")
+                    throw Unsupported{"POSIX class [:" + name + ":]"};
+                else throw Invalid{"unknown POSIX class name"};
                 if ((name == "lower" || name == "upper") && f.caseless) throw Unsupported{"(?i) with [:lower:] / [:upper:]"};
                 props.add(neg ? s.negated() : s);
                 after_class_item = true;
                 continue;
             }
-            if (c == '[' && (peek(1) == '.' || peek(1) == '=')) throw Unsupported{"POSIX collating element"};
+            if (c == '[' && (peek(1) == '.' || peek(1) == '=')) throw Invalid{"POSIX collating elements are not supported"};
             uint32_t lo;
             ++pos_;
             if (c == '\\') {
@@ -486,13 +498,13 @@ private:
                 uint32_t c2 = p_[pos_++];
                 if (c2 == '\\') {
                     CharSet s;
-                    if (parse_escape(true, s, hi, f.caseless)) throw Unsupported{"class range that ends at a class escape"};
+                    if (parse_escape(true, s, hi, f.caseless)) throw Invalid{"invalid range in character class"};
                 } else if (c2 == '[' && peek() == ':') {
                     throw Unsupported{"class range that ends at a POSIX class"};
                 } else {
                     hi = c2;
                 }
-                if (hi < lo) throw Unsupported{"class range out of order"};
+                if (hi < lo) throw Invalid{"range out of order in character class"};
             }
             explicit_chars.add(lo, hi);
         }
@@ -531,7 +543,7 @@ private:
             } else if (peek() == '=' || peek() == '!') {
                 const bool neg = p_[pos_++] == '!';
                 const int body = parse_alt(f);
-                if (!eat(')')) throw Unsupported{"unterminated group"};
+                if (!eat(')')) throw Invalid{"missing closing parenthesis"};
                 CharSet s;
                 if (!single_char_set(body, s)) throw Unsupported{"look-ahead on more than one character"};
                 return assert_node(kAhead, neg, s);
@@ -539,14 +551,27 @@ private:
                 const bool neg = peek(1) == '!';
                 pos_ += 2;
                 const int body = parse_alt(f);
-                if (!eat(')')) throw Unsupported{"unterminated group"};
+                if (!eat(')')) throw Invalid{"missing closing parenthesis"};
                 CharSet s;
                 if (!single_char_set(body, s)) throw Unsupported{"look-behind on more than one character"};
                 return assert_node(kBehind, neg, s);
             } else if (peek() == '<' || looking_at("P<") || peek() == '\'') {  // named capture: a plain group here
                 const uint32_t close = peek() == '\'' ? '\'' : '>';
-                while (more() && peek() != close) ++pos_;
-                if (!eat(close)) throw Unsupported{"malformed group name"};
+                if (looking_at("P<")) pos_ += 2;
+                else ++pos_;
+                std::string name;
+                while (more() && peek() != close) {
+                    const uint32_t ch = p_[pos_++];
+                    if (ch >= 0x80) throw Unsupported{"group name outside ASCII"};
+                    name.push_back(char(ch));
+                }
+                // PCRE2: a name is word characters, not starting with a digit, at most 32 of them, and not used twice (error 142 / 144 / 143)
+                bool ok = eat(close) && !name.empty() && name.size() <= 32 && !(name[0] >= '0' && name[0] <= '9');
+                for (char ch : name) ok = ok && ((ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || (ch >= '0' && ch <= '9') || ch == '_');
+                if (!ok) throw Invalid{"syntax error in subpattern name"};
+                for (const std::string& seen : group_names_)
+                    if (seen == name) throw Invalid{"two named subpatterns have the same name"};
+                group_names_.push_back(name);
             } else {
                 // flag settings: (?i) (?s) (?is) (?-i) ... and the scoped form (?i: ... )
                 bool on = true, any = false;
@@ -564,14 +589,25 @@ private:
                     outer = g;
                     return -1;
                 }
-                if (!eat(':')) throw Unsupported{"malformed group options"};
+                if (!eat(':')) throw Invalid{"missing closing parenthesis"};   // (the loop above stops at `)`, `:` or the pattern's end)
                 f = g;
             }
         } else if (peek() == '*') {
-            throw Unsupported{"(*VERB)"};
+            // (*VERB), (*VERB:NAME), (*alpha_assertion:...): what PCRE2 knows is outside the subset; anything else it rejects (error 160 / 195)
+            static const char* const known[] = {"UTF", "UCP", "ANY", "ANYCRLF", "CR", "LF", "CRLF", "NUL", "BSR_ANYCRLF", "BSR_UNICODE", "NO_AUTO_POSSESS",
+                                                "NO_DOTSTAR_ANCHOR", "NO_JIT", "NO_START_OPT", "NOTEMPTY", "NOTEMPTY_ATSTART", "LIMIT_HEAP", "LIMIT_MATCH",
+                                                "LIMIT_DEPTH", "LIMIT_RECURSION", "ACCEPT", "COMMIT", "FAIL", "F", "PRUNE", "SKIP", "THEN", "MARK", "",
+                                                "pla", "plb", "nla", "nlb", "napla", "naplb", "positive_lookahead", "positive_lookbehind", "negative_lookahead",
+                                                "negative_lookbehind", "non_atomic_positive_lookahead", "non_atomic_positive_lookbehind", "atomic", "sr",
+                                                "asr", "script_run", "atomic_script_run", "scan_substring", "scs"};
+            std::string name;
+            for (size_t q = pos_ + 1; q < p_.size() && ((p_[q] >= 'A' && p_[q] <= 'Z') || (p_[q] >= 'a' && p_[q] <= 'z') || p_[q] == '_'); ++q) name.push_back(char(p_[q]));
+            for (const char* k : known)
+                if (name == k) throw Unsupported{"(*VERB)"};
+            throw Invalid{"(*VERB) not recognized"};
         }
         const int body = parse_alt(f);
-        if (!eat(')')) throw Unsupported{"unterminated group"};
+        if (!eat(')')) throw Invalid{"missing closing parenthesis"};
         return body;
     }
 
@@ -595,7 +631,7 @@ private:
             }
             case '^': return assert_node(kBot);
             case '$': return assert_node(kEotNl);
-            case '*': case '+': case '?': throw Unsupported{"quantifier without an operand"};
+            case '*': case '+': case '?': throw Invalid{"quantifier does not follow a repeatable item"};
             case '\\': {
                 if (eat('Q')) {  // \Q ... \E: literal text
                     std::vector<int> items;
@@ -620,6 +656,8 @@ private:
                     case 'B': ++pos_; return assert_node(kNotWordB);
                     case 'G': case 'K': case 'R': case 'X': case 'C': case 'g': case 'k':
                         throw Unsupported{std::string("escape \\") + char(peek())};
+                    case 'L': case 'l': case 'U': case 'u': case 'F':
+                        throw Invalid{"PCRE2 does not support \\F, \\L, \\l, \\U, or \\u"};
                     default: break;
                 }
                 if (peek() >= '1' && peek() <= '9') throw Unsupported{"back-reference"};
@@ -942,6 +980,20 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
     } catch (const Unsupported& u) {
         err = "RegexSplit: pattern outside the subset compiled for the GPU (" + u.what + "); PCRE2 is not executed on the device";
         return OVTK_E_UNSUPPORTED;
+    } catch (const Invalid& v) {
+        // The reference keeps a null pattern (src/utils.cpp:264-271): nothing ever matches.  One dead state, one class.
+        out = RegexProgram{};
+        out.invalid = true;
+        out.invalid_why = v.what;
+        out.n_classes = 1;
+        out.sym_eot = 1;
+        out.n_syms = 2;
+        out.n_states = 1;
+        out.trans.assign(2, 0);
+        out.ctx_of_class.assign(1, 0);
+        out.cp_index.assign((size_t(kMaxCp) + 1) >> 7, 0);
+        out.cp_blocks.assign(128, 0);
+        return OVTK_OK;
     }
 }
 

@@ -51,9 +51,12 @@ struct RegexProgram {
     std::vector<uint16_t> cp_index;      // [0x110000 >> 7]
     std::vector<uint8_t> cp_blocks;      // [n_blocks * 128]
     bool can_match_empty = false;        // some start state accepts before consuming anything
+    bool invalid = false;                // PCRE2 itself rejects the pattern: the program never matches (the reference's null pattern,
+    std::string invalid_why;             // src/utils.cpp:264-271, 397-399: every string passes through unsplit)
 };
 
-// 0, or OVTK_E_UNSUPPORTED with `err` naming what is outside the subset.
+// 0, or OVTK_E_UNSUPPORTED with `err` naming what is outside the subset.  A pattern that PCRE2 itself rejects (an unmatched parenthesis,
+// a quantifier without an operand, a range out of order ...) compiles -- to a program that never matches, RegexProgram::invalid.
 int compile_regex(const std::string& pattern, RegexProgram& out, std::string& err);
 
 // General_Category of every code point, as its index in unicode_gc.inc's order (Cn Lu Ll Lt Lm Lo Mn Mc Me Nd Nl No Pc Pd Ps Pe Pi Pf Po

@@ -37,14 +37,17 @@ constexpr int kSpanDwords = kSpanLane / 4;
 constexpr int kSpanBytes = kWave * kSpanLane;    // bytes per block
 // an entry of the piece list (BERT words; the GPT-2 family's entries are positions and nothing else)
 constexpr uint32_t kSpanPosMask = 0x0FFFu, kSpanOneBefore = 0x4000u, kSpanDropped = 0x8000u;
-constexpr int kSpanMiss = 48;                    // misses noted per wave before they are written out
+constexpr int kSpanMiss = 48;                    // misses noted per wave before they are written out: the kernels that run five blocks per CU ...
+constexpr int kSpanMissWide = 112;               // ... and the ones that run four (the Llama-3 family, span_fam.hpp's: 39 KB of LDS per block) -- mixed-script
+                                                 // text under a 128 K vocabulary leaves ~80 pieces per wave to the store
 
 struct SpanMiss {
     uint4 key;    // the piece's memo key (zero for pieces longer than one)
     uint4 info;   // {staging position, begin in chars, length, byte position among the wave's rows (-> the row, at flush time)}
 };
-struct SpanWave {
-    SpanMiss miss[kSpanMiss];
+template <int NM>
+struct SpanWaveT {
+    SpanMiss miss[NM];
     uint32_t text[1 + kSpanBytes / 4 + 8];       // one dword of padding (the window views of the ballot scanner), the block's text,
                                                  // 32 bytes behind it (the 16-byte key read of a piece at its end)
     uint16_t pstart[kSpanBytes + 4];             // piece starts, block-relative, np + 1 of them (every byte may start one); between two
@@ -163,14 +166,18 @@ __device__ __forceinline__ int bert_match_end(const SplitDev& sp, const uint8_t*
     return q;
 }
 
-// Writes the n (<= kSpanMiss) noted misses of the wave to its shard of the deferred list.  incl32: bytes of the wave's rows 0..l
-// (the row of a miss is the first one whose sum lies behind the piece's position).
-__device__ __forceinline__ void span_flush(const SpanWave& sw, int n, const EncodeWork& w, int row0, int incl32) {
+// Writes the noted misses [first, first + n) of the wave (n <= 64: a lane each) to its shard of the deferred list.  incl32: bytes of the
+// wave's rows 0..l (the row of a miss is the first one whose sum lies behind the piece's position).
+template <class SW>
+__device__ __forceinline__ void span_flush(const SW& sw, int first, int n, const EncodeWork& w, int row0, int incl32) {
     const int l = lane_id();
     const int shard = int(blockIdx.x) % kShards;
     int idx = 0;
-    if (l == 0) idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
-    const SpanMiss e = sw.miss[l < n ? l : 0];
+    if (l == 0) {
+        idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
+        if (w.span_sums) atomicAdd(&w.status->n_unresolved, n);   // (the short path: pieces that need merge_kernel / wordpiece_deferred_kernel)
+    }
+    const SpanMiss e = sw.miss[first + (l < n ? l : 0)];
     int row = 0;   // = rows whose bytes end at or before the piece
 #pragma unroll
     for (int step = kWave / 2; step >= 1; step >>= 1) {
@@ -201,18 +208,19 @@ constexpr int kSpanHalo = 8;          // bytes at the end of a block that is not
 constexpr int kSpanWindow = 16 * kWave;   // the ballot form's window (its masks travel inside a DPP row of 16 lanes)
 constexpr int kSpanWindowHalo = 16;
 
-// ---- the short path (round 6): span -> compact ------------------------------------------------------------------------------------
+// ---- the short path (round 6): span -> [left-over rows] -> [merge] -> compact, the two in the middle only when they are needed ----------
 // Until round 5 every call was four launches: this kernel, lookup_kernel<kFused> for the rows it leaves (none, as a rule: 5 us of a
-// kernel that finds nothing), merge_kernel for the pieces the memo does not hold (once the tables have learned a text: a few thousand
-// pieces that merge_kernel finds in the piece store, nothing to merge -- 13 us of launch, list, store probe and tile sums) and
-// compact_kernel.  With EncodeWork::short_path the span kernel does what is left of the two in the middle itself:
+// kernel that finds nothing), merge_kernel (wordpiece_deferred_kernel) for the pieces the memo does not hold -- once the tables have
+// learned a text these are pieces it finds in the piece store, nothing to merge: 13-70 us of launch, list, store probes and tile sums --
+// and compact_kernel.  With EncodeWork::span_sums the span kernel does the middle's bookkeeping itself:
 //   * at its end a wave looks its noted misses up in the piece store (the memo's second level: one round trip, a lane per miss;
-//     store_lookup) and writes their ids into the staging entries it had reserved for them; what the store does not hold either is
-//     filed for merge_kernel as ever, and the wave is INEXACT -- as is a wave with a row it left to the generic kernel;
-//   * it adds its rows' id counts to their tiles' sums (tile_cnt: merge_kernel's fold_emitted_tile_sums);
-// and compact_kernel follows at once.  RunStatus::n_inexact > 0 makes that compact_kernel write nothing, and the host launches
-// lookup_kernel<kFused> / merge_kernel / compact_kernel after all (RowsRun::launch_phase2): the staging buffer, the row records and
-// the deferred list are as the four-launch form's span kernel leaves them.  Results are the same either way.
+//     store_lookup) and writes their ids into the staging entries it had reserved for them; only what the store does not hold either
+//     is filed for merge_kernel, and counted (RunStatus::n_unresolved);
+//   * it adds its rows' id counts to their tiles' sums (tile_cnt: what merge_kernel's fold_emitted_tile_sums did for every launch);
+// and the host launches the kernels in the middle only when the handle's last calls say they will find work (EncodeWork::skip_mask says
+// which were left out).  compact_kernel checks: rows left over (n_pending) without their kernel, or unresolved pieces without theirs,
+// and it writes nothing -- the host then launches what was left out, and compact_kernel again (RowsRun::launch_phase2).  Results are
+// the same either way: the piece store is the reference's piece cache (src/bpe_tokenizer.cpp:197-205, 331-338), pure memoisation.
 // (Tried first and dropped, profiles/r06/a_one_pass_*: ONE launch -- a wave takes its output offset from a decoupled look-back over the
 // waves in front of it and copies its own staging stretch to the final ids.  A persistent grid's waves all end together, so every
 // wave waits for the slowest one in front of it, and waiting is not free: the waves that wait are the older waves of their SIMDs and
@@ -222,7 +230,9 @@ constexpr int kSpanWindowHalo = 16;
 
 // The store's answer for one noted miss: its ids into the staging entries the piece had reserved, the rest of them cleared.
 // -> the id count, or -1 (not in the store, or no key of it fits one).
-template <bool NARROW, bool S16>
+// WORDS: the store is a WordPiece handle's word store -- an entry of the one id kStoreUnk16 / kStoreUnk32 is a word without a segmentation
+// and comes back as the call's unk_token_id (T.unk_id).
+template <bool NARROW, bool S16, bool WORDS>
 __device__ __forceinline__ int span_resolve_miss(const RowsIn& in, const BpeDev& T, const EncodeWork& w, const SpanMiss& e, int SL) {
     const int len = int(e.info.z);
     if (len < 1 || len > kStoreKeyBytes) return -1;
@@ -239,8 +249,10 @@ __device__ __forceinline__ int span_resolve_miss(const RowsIn& in, const BpeDev&
 #pragma unroll
     for (int k = 0; k < kIds; ++k)
         if (k < c) {
-            if (S16) reinterpret_cast<uint16_t*>(w.stage)[pos + k] = uint16_t(store_id<NARROW>(pay, k));
-            else w.stage[pos + k] = store_id<NARROW>(pay, k);
+            int32_t id = store_id<NARROW>(pay, k);
+            if (WORDS && k == 0 && id == (NARROW ? kStoreUnk16 : kStoreUnk32)) id = T.unk_id;
+            if (S16) reinterpret_cast<uint16_t*>(w.stage)[pos + k] = uint16_t(id);
+            else w.stage[pos + k] = id;
         }
     for (int k = c; k < need; ++k) {
         if (S16) reinterpret_cast<uint16_t*>(w.stage)[pos + k] = uint16_t(0xFFFFu);
@@ -263,6 +275,8 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
     constexpr bool BERT = SCAN == kSpanBertWords;
     constexpr bool L3 = SCAN == kSpanLlama3;   // the Llama-3 family (span_l3.hpp)
     constexpr int FAM = SCAN == kSpanDs3 ? int(kFamDs3) : (SCAN == kSpanO200k ? int(kFamO200k) : 0);   // DeepSeek-V3's pattern, o200k_base (span_fam.hpp)
+    constexpr int NM = (L3 || FAM != 0) ? kSpanMissWide : kSpanMiss;   // (noted misses per wave)
+    using SpanWave = SpanWaveT<NM>;
     __shared__ SpanWave sw_all[kWavesPerBlock];
     __shared__ uint4 mask_tab[16];   // [n]: byte masks of the four key dwords of an n-byte piece (n = 0: nothing)
     const int l = lane_id();
@@ -380,15 +394,14 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         const int add = __popcll(mm);
         const int rank = rank_below(mm);
         for (int done = 0; done < add;) {
-            if (n_miss + (add - done) > kSpanMiss && n_miss > 0) {
+            if (n_miss + (add - done) > NM && n_miss > 0) {
+                // (more than the wave can note: these go to merge_kernel / wordpiece_deferred_kernel as they are -- span_flush counts them as unresolved)
                 wave_sync();
-                span_flush(sw, n_miss, w, row0, incl32);
+                for (int f0 = 0; f0 < n_miss; f0 += kWave) span_flush(sw, f0, n_miss - f0 < kWave ? n_miss - f0 : kWave, w, row0, incl32);
                 wave_sync();
                 n_miss = 0;
-                // (the short path: these go to merge_kernel -- the call is inexact, said at once: nothing else has to remember it)
-                if (!BERT && w.short_path && l == 0) atomicAdd(&w.status->n_inexact, 1);
             }
-            const int take = add - done < kSpanMiss - n_miss ? add - done : kSpanMiss - n_miss;
+            const int take = add - done < NM - n_miss ? add - done : NM - n_miss;
             if (mine && rank >= done && rank < done + take)
                 sw.miss[n_miss + rank - done] = SpanMiss{uint4{ka, kb, kc, kd}, uint4{uint32_t(at), uint32_t(begin), uint32_t(len), uint32_t(wpos)}};
             n_miss += take;
@@ -776,44 +789,47 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         have_chain = next_chain(cj);
     }
     PROBE(1);
-    bool exact = !dead;   // (the short path) every id of my rows stands in my staging stretch
-    if (!BERT && w.short_path && n_miss > 0 && T.store.slots && !dead) {
-        // ---- the short path: the noted misses through the piece store, a lane each
+    if (w.span_sums && n_miss > 0 && T.store.slots && !dead) {
+        // ---- the short path: the noted misses through the piece store, a lane each, 64 at a time
+        uint32_t* radd = reinterpret_cast<uint32_t*>(sw.pstart);   // the rows' id counts go through LDS (the piece list's room is free)
         wave_sync();
-        const SpanMiss e = sw.miss[l < n_miss ? l : 0];
-        int row = 0;   // the row of my miss (span_flush's search)
-#pragma unroll
-        for (int step = kWave / 2; step >= 1; step >>= 1) {
-            const int t = row + step;
-            if (__shfl(incl32, t - 1) <= int(e.info.w)) row = t;
-        }
-        int c = -1;
-        if (l < n_miss) {
-            if (S16) c = span_resolve_miss<true, S16>(in, T, w, e, SL);
-            else if (T.store.narrow) c = span_resolve_miss<true, S16>(in, T, w, e, SL);
-            else c = span_resolve_miss<false, S16>(in, T, w, e, SL);
-        }
-        // the rows' id counts: through LDS (the piece list's room is free)
-        uint32_t* radd = reinterpret_cast<uint32_t*>(sw.pstart);
         radd[l] = 0;
-        wave_sync();
-        if (c > 0) atomicAdd(&radd[row], uint32_t(c));
+        int n_left = 0;   // entries [0, n_left) of the list: what the store does not hold
+        for (int f0 = 0; f0 < n_miss; f0 += kWave) {
+            const int n = n_miss - f0 < kWave ? n_miss - f0 : kWave;
+            wave_sync();
+            const SpanMiss e = sw.miss[f0 + (l < n ? l : 0)];
+            int row = 0;   // the row of my miss (span_flush's search)
+#pragma unroll
+            for (int step = kWave / 2; step >= 1; step >>= 1) {
+                const int t = row + step;
+                if (__shfl(incl32, t - 1) <= int(e.info.w)) row = t;
+            }
+            int c = -1;
+            if (l < n) {
+                if (S16) c = span_resolve_miss<true, S16, BERT>(in, T, w, e, SL);
+                else if (T.store.narrow) c = span_resolve_miss<true, S16, BERT>(in, T, w, e, SL);
+                else c = span_resolve_miss<false, S16, BERT>(in, T, w, e, SL);
+            }
+            if (c > 0) atomicAdd(&radd[row], uint32_t(c));
+            const unsigned long long um = __ballot(l < n && c < 0);
+            // what the store did for this call decides whether the next ones ask it at all (api_encode.cpp store_pause): a SAMPLE of the
+            // waves counts, as in merge_kernel -- which now sees only what the store does not hold
+            if ((wave & 63) == 0 && l == 0) {
+                atomicAdd(&w.status->n_store_probe, n);
+                if (n - int(__popcll(um)) > 0) atomicAdd(&w.status->n_store_hit, n - int(__popcll(um)));
+            }
+            wave_sync();   // (every lane holds its entry in registers: what is moved to the front overwrites nothing unread)
+            if (l < n && c < 0) sw.miss[n_left + rank_below(um)] = e;
+            n_left += __popcll(um);
+        }
         wave_sync();
         rec_cnt += int(radd[l]);
-        // what the store does not hold: to the front of the list, and out to merge_kernel
-        const unsigned long long um = __ballot(l < n_miss && c < 0);
-        if (um) {
-            if (l < n_miss && c < 0) sw.miss[rank_below(um)] = e;   // (every lane holds its entry in registers: nothing is overwritten unread)
-            wave_sync();
-            span_flush(sw, __popcll(um), w, row0, incl32);
-            exact = false;
-        }
-        n_miss = 0;
+        n_miss = n_left;
     }
     if (n_miss > 0) {
         wave_sync();
-        span_flush(sw, n_miss, w, row0, incl32);
-        exact = false;
+        for (int f0 = 0; f0 < n_miss; f0 += kWave) span_flush(sw, f0, n_miss - f0 < kWave ? n_miss - f0 : kWave, w, row0, incl32);
     }
     PROBE(2);
     const bool is_pending = l < nr && ((pending_m >> l) & 1ull);
@@ -832,18 +848,14 @@ static __global__ __launch_bounds__(kBlockThreads, 4) void lookup_span_kernel(Ro
         base = wave_readlane(base, 0);
         if (w.pending_rows && is_pending) w.pending_rows[base + rank_below(pm)] = row0 + l;
     }
-    if constexpr (!BERT) {
-        if (w.short_path) {
-            // ---- the short path: my rows' id counts to their tiles' sums (R <= 64 consecutive rows: two tiles at most), and whether
-            // compact_kernel may go ahead
-            const int my_cnt = l < nr && !is_pending ? rec_cnt : 0;
-            const int t0 = row0 / kRowTile;
-            const int all = wave_sum(my_cnt), first = wave_sum((row0 + l) / kRowTile == t0 ? my_cnt : 0);
-            if (l == 0) {
-                if (first) atomicAdd(&w.tile_cnt[t0], first);
-                if (all - first) atomicAdd(&w.tile_cnt[t0 + 1], all - first);
-                if (!exact || pm) atomicAdd(&w.status->n_inexact, 1);
-            }
+    if (w.span_sums) {
+        // ---- the short path: my rows' id counts to their tiles' sums (R <= 64 consecutive rows: two tiles at most)
+        const int my_cnt = l < nr && !is_pending ? rec_cnt : 0;
+        const int t0 = row0 / kRowTile;
+        const int all = wave_sum(my_cnt), first = wave_sum((row0 + l) / kRowTile == t0 ? my_cnt : 0);
+        if (l == 0) {
+            if (first) atomicAdd(&w.tile_cnt[t0], first);
+            if (all - first) atomicAdd(&w.tile_cnt[t0 + 1], all - first);
         }
     }
 }

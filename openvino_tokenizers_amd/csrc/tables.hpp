@@ -103,6 +103,9 @@ constexpr int kRoomShards = 16, kRoomStride = 32;
 // bytes match and whose payload carries the valid bit and the checksum of its own ids).
 constexpr int kStoreKeyBytes = 31;
 constexpr int kStoreIds16 = 15, kStoreIds32 = 7;
+// The word store's entry for a word without a WordPiece segmentation: one id that is no vocabulary index (a narrow store belongs to a
+// vocabulary of at most 65 535 words), read back as the call's unk_token_id (input 8 may differ from call to call).
+constexpr int32_t kStoreUnk16 = 0xFFFF, kStoreUnk32 = 0x7FFFFFFF;
 struct alignas(64) StoreEntry {
     uint32_t key[8];  // piece bytes 0..30 (little endian, zero padded), byte 31 = length; key[7] == 0: free (length >= 1)
     uint32_t pay[8];  // narrow: u16 ids[15], u16 tag   wide: i32 ids[7], u32 tag

@@ -173,6 +173,9 @@ extern "C" int orc_regex_split_create(const char* pattern, int64_t pattern_len, 
     return ORC_OK;
 }
 
+// Did pcre2_compile accept the pattern?  (Tests of the null-pattern behaviour, utils.cpp:264-271, name their patterns by this.)
+extern "C" int orc_regex_compiled(const orc_regex* r) { return r && r->code ? 1 : 0; }
+
 extern "C" void orc_regex_split_destroy(orc_regex* r) {
     if (!r) return;
     if (r->code) Pcre2::get().code_free(r->code);

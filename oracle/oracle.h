@@ -45,6 +45,8 @@ typedef struct orc_regex orc_regex;
 int orc_regex_split_create(const char* pattern, int64_t pattern_len, const char* behaviour,
                            int invert, int max_splits, orc_regex** out);
 void orc_regex_split_destroy(orc_regex*);
+/* 1 when PCRE2 compiled the pattern, 0 when it rejected it (the handle then never matches: src/utils.cpp:264-271, 397-399). */
+int orc_regex_compiled(const orc_regex*);
 /* skips may be NULL (6-input form).  Outputs: out_rb/out_re sized B (or 1 when nchars == 0:
  * *n_rows_out tells), out_begins/out_ends/out_skips sized `cap` (reference bound: nchars + N). */
 int orc_regex_split_run(const orc_regex*, const int32_t* rb, const int32_t* re, int64_t B,

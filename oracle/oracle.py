@@ -81,6 +81,11 @@ def unpack_strings(begins, ends, chars):
 
 
 # --------------------------------------------------------------------------- RegexSplit
+def pcre2_compiles(pattern) -> bool:
+    """True when the image's PCRE2 (PCRE2_UTF | PCRE2_UCP) accepts `pattern`."""
+    return RegexSplit(pattern, "isolate").compiled()
+
+
 class RegexSplit:
     def __init__(self, pattern, behaviour="remove", invert=False, max_splits=-1):
         p = pattern.encode("utf-8") if isinstance(pattern, str) else bytes(pattern)
@@ -95,6 +100,10 @@ class RegexSplit:
                 self._h = None
         except Exception:  # interpreter shutdown
             pass
+
+    def compiled(self) -> bool:
+        """Did PCRE2 accept the pattern?  (A rejected one never matches: src/utils.cpp:264-271, 397-399.)"""
+        return bool(lib().orc_regex_compiled(self._h))
 
     def match(self, s: bytes, start: int):
         m = (C.c_int64 * 2)()

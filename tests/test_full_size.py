@@ -262,3 +262,74 @@ def test_many_short_rows(hip_lib, rows):
     k = 3000
     ref = tok.oracle()(*O.RegexSplit(tok.pattern, "isolate")(rb[:k], re_[:k], b[:k], e[:k], c)[:5])
     assert np.array_equal(ref[1], whole[1][:k].cpu().numpy()) and np.array_equal(ref[2], whole[2][: int(ref[1][-1])].cpu().numpy())
+
+
+def test_config4_as_stated_eight_shards_on_one_gpu(hip_lib):
+    """BASELINE config 4 at its stated size -- 1 048 576 x ~512-byte mixed-script rows, Llama-3-shaped BPE (V = 128 256), sharded
+    eight ways with a gather of the per-shard ragged ids -- on ONE GPU: the eight byte-balanced shards (shard_rows_by_bytes) are
+    encoded straight to their wires one after the other (ovtk_encode_enqueue_wire: what each rank of an 8-GPU node does), one
+    shard_unpack_kernel rebuilds the global tensor from the eight wires (what every rank does behind the all-gather), and the
+    result equals the whole batch encoded in one ovtk_encode_run call -- begins, ends and ids bit for bit -- plus the oracle on a
+    prefix of every shard.  Only the transport (RCCL over xGMI) is missing; `tests/test_distributed.py` covers it on gloo."""
+    import ctypes as C
+
+    import torch
+
+    from openvino_tokenizers_amd import _lib as L
+    from openvino_tokenizers_amd.distributed import shard_rows_by_bytes
+    world, rows = 8, 1 << 20
+    tok = BpeTok.load("llama3")
+    b, e, c = TextModel(1234, "mixed").batch(rows, 512, seed=91)
+    rb, re_ = ragged_rows(rows)
+    pat = tok.pattern_u8()
+    fused = FusedSplitBPE(RegexSplit("isolate", lib=hip_lib), BPETokenizer(**tok.attrs, lib=hip_lib))
+    d_rb, d_re, d_b, d_e = dev([rb, re_, b, e])
+    d_c = torch.as_tensor(c, device="cuda")
+    whole = fused.evaluate([d_rb, d_re, d_b, d_e, d_c, pat], tok.consts)
+    n_ids = whole[2].numel()
+    check_offsets(whole[0], whole[1], n_ids)
+    w_ends = whole[1].cpu().numpy()
+    shards = shard_rows_by_bytes(b, e, world)
+    assert shards[0][0] == 0 and shards[-1][1] == rows and all(shards[r][1] == shards[r + 1][0] for r in range(world - 1))
+    text_per_shard = [int(e[hi - 1] - b[lo]) for lo, hi in shards]
+    assert max(text_per_shard) - min(text_per_shard) <= 2 * 1024, "shards are not balanced by bytes"
+    ids_per_shard = [int(w_ends[hi - 1]) - (int(w_ends[lo - 1]) if lo else 0) for lo, hi in shards]
+    pad = (max(ids_per_shard) + 7) // 8 * 8
+    h = C.c_void_p()
+    L.check(hip_lib, hip_lib.ovtk_shard_exchange_create(world, C.c_int64(rows), 4, C.c_int64(max(hi - lo for lo, hi in shards)), 0, C.byref(h)))
+    try:
+        max_rows = int(hip_lib.ovtk_shard_max_rows(h))
+        wire_bytes = int(hip_lib.ovtk_shard_wire_bytes(h, C.c_int64(pad)))
+        wires = torch.zeros(world * wire_bytes, dtype=torch.uint8, device="cuda")
+        for r, (lo, hi) in enumerate(shards):
+            # the shard's rows keep their string indices: the strings tensor is the whole batch's, as on a rank that holds it
+            rs = L.RaggedStrings(C.c_void_p(d_rb[lo:hi].data_ptr()), C.c_void_p(d_re[lo:hi].data_ptr()), hi - lo,
+                                 L.Strings(C.c_void_p(d_b.data_ptr()), C.c_void_p(d_e.data_ptr()), C.c_void_p(d_c.data_ptr()), rows, len(c)))
+            pending = C.c_void_p()
+            L.check(hip_lib, hip_lib.ovtk_encode_enqueue_wire(fused.split._h, fused.bpe._h, C.byref(rs), None,
+                                                              C.c_void_p(wires[r * wire_bytes:].data_ptr()), C.c_int64(max_rows), C.c_int64(pad), 4,
+                                                              None, C.byref(pending)))
+            out = L.RaggedI32Out(None, None, None, 0, 0, 0)
+            L.check(hip_lib, hip_lib.ovtk_encode_finish(pending, C.byref(out)))
+            assert out.n_data == ids_per_shard[r], f"shard {r}: {out.n_data} ids on the wire, {ids_per_shard[r]} in the whole batch"
+        g_b = torch.empty(rows, dtype=torch.int32, device="cuda")
+        g_e = torch.empty(rows, dtype=torch.int32, device="cuda")
+        g_ids = torch.empty(n_ids, dtype=torch.int32, device="cuda")
+        res = torch.zeros(4, dtype=torch.int64, device="cuda")
+        L.check(hip_lib, hip_lib.ovtk_shard_unpack(h, C.c_void_p(wires.data_ptr()), C.c_int64(pad), C.c_void_p(g_b.data_ptr()), C.c_void_p(g_e.data_ptr()),
+                                                   C.c_void_p(g_ids.data_ptr()), C.c_int64(n_ids), C.c_void_p(res.data_ptr()), L.MEM_DEVICE, None))
+        torch.cuda.synchronize()
+        r_ids, r_max, r_status, _ = (int(x) for x in res.cpu())
+        assert r_status == 0 and r_ids == n_ids and r_max == max(ids_per_shard)
+        assert torch.equal(g_b, whole[0]) and torch.equal(g_e, whole[1]) and torch.equal(g_ids, whole[2]), "the eight shards' wires do not give the whole batch"
+    finally:
+        hip_lib.ovtk_shard_exchange_destroy(h)
+    # the oracle on the first rows of every shard
+    orc, rs_o = tok.oracle(), O.RegexSplit(tok.pattern, "isolate")
+    w_ids = whole[2]
+    for lo, hi in shards:
+        k = 250
+        ref = orc(*rs_o(rb[:k], re_[:k], b[lo:lo + k], e[lo:lo + k], c)[:5])
+        first = int(w_ends[lo - 1]) if lo else 0
+        assert np.array_equal(ref[1] + first, w_ends[lo:lo + k]), f"rows {lo}..: ends differ from the oracle's"
+        assert np.array_equal(ref[2], w_ids[first:first + int(ref[1][-1])].cpu().numpy()), f"rows {lo}..: ids differ from the oracle's"

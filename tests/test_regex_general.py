@@ -127,13 +127,36 @@ def test_fuzzed_patterns(backend):
 
 
 @pytest.mark.parametrize("pattern", [r"(a)\1", r"(?>a+)b", r"\p{Hann}+", r"\p{foo:Greek}", r"a(?=bc)", r"(?<=ab)c", r"(?m)^a", r"(?x) a b", r"\R",
-                                     r"\X", r"a\Kb", r"(?|a|b)", r"(?R)", r"(?(1)a|b)", r"(?i)é", r"(?i)[à-ý]", r"(a|b)++c", r"a**",
-                                     r"(?i)\p{Lu}x", r"[[:punct:]]", r"(*UTF)a", r"(", r"a)", r"[a", r"\p{Foo}", "\\"])
+                                     r"\X", r"a\Kb", r"(?|a|b)", r"(?R)", r"(?(1)a|b)", r"(?i)é", r"(?i)[à-ý]", r"(a|b)++c",
+                                     r"(?i)\p{Lu}x", r"[[:punct:]]", r"(*UTF)a", r"\p{Foo}", r"(?=a)*b"])
 def test_outside_the_subset_is_refused(backend, pattern):
+    """Patterns PCRE2 accepts (or may accept: a property name outside this library's tables) and the compiled subset does not cover."""
     # (?i)\p{Lu} is accepted by the parser but means something else under PCRE2's caseless rules: refuse
     with pytest.raises(L.OvtkError) as ei:
         RegexSplit("isolate", lib=backend.lib).evaluate(backend.data(one_string_per_row(["ab"])) + [np.frombuffer(pattern.encode(), np.uint8)])
     assert ei.value.code == L.E_UNSUPPORTED
+
+
+# Patterns pcre2_compile itself rejects (checked below against the oracle's PCRE2): the reference keeps a null pattern and every match
+# "fails" (src/utils.cpp:264-271, 397-399; SURVEY A.1 R9) -- every string is handed on as one piece, whatever the behaviour.
+INVALID_PATTERNS = ["a)", "abc\\", "[abc", "(abc", "(?:ab", "*a", "+a", "a|*b", "a{3,1}", "[z-a]", "a**", "a{2}*", "a+++", "^*", "$*", "\\b*",
+                    "\\x{110000}", "\\x{}", "\\x{12", "[[:foo:]]", "[[.a.]]", "[[=a=]]", "\\p{L", "a{65536}", "a{70000}", "(?<n", "(?<n>a",
+                    "[\\d-z]", "[a-\\d]", "\\L", "\\u0041", "\\U", "[]", "[^]", "(?i", "(", b"\xff", b"a\xc3"]
+
+
+@pytest.mark.parametrize("behaviour,invert", [("isolate", False), ("remove", False), ("remove", True), ("mergedwithnext", False), ("contiguous", False)])
+def test_invalid_patterns_split_nothing(backend, behaviour, invert):
+    """A pattern PCRE2 rejects splits nothing, as in the reference; judged by the oracle, which hands the pattern to the real PCRE2."""
+    strings = ["hello world", "a)b [abc", "", "x", "\x5c", "ÄÖ 漢字 *+?"]
+    inputs = one_string_per_row(strings)
+    for pattern in INVALID_PATTERNS:
+        raw = pattern if isinstance(pattern, bytes) else pattern.encode()
+        assert not O.pcre2_compiles(raw), f"{pattern!r}: the oracle's PCRE2 accepts it -- not a test of the null pattern"
+        if behaviour == "contiguous" and raw.endswith(b"+"):
+            continue   # (regex_split.cpp:33-37 leaves such a pattern as it is: covered by "isolate")
+        ref = O.RegexSplit(raw, behaviour, invert=invert)(*inputs)
+        got = RegexSplit(behaviour, invert=invert, lib=backend.lib).evaluate(backend.data(inputs) + [np.frombuffer(raw, np.uint8)])
+        assert_same(ref[:5], got[:5], backend.host, f"{pattern!r} {behaviour} invert={invert}")
 
 
 def _spelled(mask_fn, names):

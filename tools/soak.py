@@ -1,6 +1,7 @@
 """Soak: many batches through every calling mode of the fused encode on one handle (device-resident on three streams,
 pinned host buffers on four, straight to an exchange wire), each result compared with the first (blocking, device) result
-of the same batch.  python tools/soak.py [rounds]"""
+of the same batch.  python tools/soak.py [rounds] [modes] [cache_capacity] [short path mode: ovtk_set_short_path, default 1;
+2 = every call leaves out the kernels of the middle first and takes the second set of launches when they had work]"""
 import ctypes as C
 import sys
 from pathlib import Path
@@ -35,6 +36,7 @@ def report(name, r, j, ref, got, mode):
                 msg.append(f"out{q} {len(d)} diffs, first at {d[0]}: {a[d[0]:d[0]+6].tolist()} vs {b[d[0]:d[0]+6].tolist()}")
     print(" ".join(msg), flush=True)
 lib = L.load()
+L.check(lib, lib.ovtk_set_short_path(int(sys.argv[4]) if len(sys.argv) > 4 else 1))
 dev = torch.device("cuda", 0)
 for name, kinds in (("gpt2", ("zipf", "uniform", "mixed")), ("llama3", ("mixed", "zipf"))):
     if not on(name):
