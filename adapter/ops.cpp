@@ -116,6 +116,13 @@ bool RegexSplit::visit_attributes(ov::AttributeVisitor& visitor) {
     visitor.on_attribute("max_splits", m_max_splits);
     return true;
 }
+ovtk_regex_split* RegexSplit::handle(const ov::Tensor& pattern) const {
+    return ensure(*m_state, ovtk_regex_split_destroy, [&](ovtk_regex_split** out) {
+        const std::string pat = text_of(pattern);
+        const ovtk_regex_split_params p{pat.data(), int64_t(pat.size()), m_behaviour.c_str(), m_invert ? 1 : 0, m_max_splits, device()};
+        check(ovtk_regex_split_create(&p, out), "RegexSplit (pattern compilation)");
+    });
+}
 bool RegexSplit::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
     const bool has_skips = inputs.size() == 7;
     // The 9-input form of old IRs (regex_split.cpp:102,164-179,235-238): a string that equals one of the "skip tokens"
@@ -134,12 +141,7 @@ bool RegexSplit::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inp
         check(ovtk_vocab_encoder_run(set, &strings, &none, flags.data(), OVTK_MEM_HOST, nullptr), "RegexSplit (skip tokens)");
         legacy_skips.assign(flags.begin(), flags.end());
     }
-    const ov::Tensor& pattern = inputs[5 + has_skips];
-    ovtk_regex_split* h = ensure(*m_state, ovtk_regex_split_destroy, [&](ovtk_regex_split** out) {
-        const std::string pat = text_of(pattern);
-        const ovtk_regex_split_params p{pat.data(), int64_t(pat.size()), m_behaviour.c_str(), m_invert ? 1 : 0, m_max_splits, device()};
-        check(ovtk_regex_split_create(&p, out), "RegexSplit (pattern compilation)");
-    });
+    ovtk_regex_split* h = handle(inputs[5 + has_skips]);
     const ovtk_ragged_strings in = ragged_at(inputs);
     const size_t rows = inputs[0].get_size();
     const size_t cap = inputs[4].get_size() + inputs[2].get_size();  // regex_split.cpp:182
@@ -183,13 +185,15 @@ std::shared_ptr<ov::Node> SpecialTokensSplit::clone_with_new_inputs(const ov::Ou
     c->m_state = m_state;
     return c;
 }
-bool SpecialTokensSplit::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
-    const bool has_skips = inputs.size() == 7;
-    const ov::Tensor& pattern = inputs[5 + has_skips];
-    ovtk_special_tokens_split* h = ensure(*m_state, ovtk_special_tokens_split_destroy, [&](ovtk_special_tokens_split** out) {
+ovtk_special_tokens_split* SpecialTokensSplit::handle(const ov::Tensor& pattern) const {
+    return ensure(*m_state, ovtk_special_tokens_split_destroy, [&](ovtk_special_tokens_split** out) {
         const std::string pat = text_of(pattern);
         check(ovtk_special_tokens_split_create(pat.data(), int64_t(pat.size()), device(), out), "SpecialTokensSplit (pattern)");
     });
+}
+bool SpecialTokensSplit::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
+    const bool has_skips = inputs.size() == 7;
+    ovtk_special_tokens_split* h = handle(inputs[5 + has_skips]);
     const ovtk_ragged_strings in = ragged_at(inputs);
     const size_t rows = inputs[0].get_size(), cap = inputs[4].get_size() + inputs[2].get_size();
     outputs[0].set_shape(one_dim(rows));
@@ -237,16 +241,16 @@ bool BPETokenizer::visit_attributes(ov::AttributeVisitor& visitor) {
     visitor.on_attribute("cache_capacity", m_cache_capacity);
     return true;
 }
-bool BPETokenizer::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
-    const size_t n = inputs.size();
-    ovtk_bpe* h = ensure(*m_state, ovtk_bpe_destroy, [&](ovtk_bpe** out) {
+ovtk_bpe* BPETokenizer::handle(const ov::TensorVector& t, size_t first, size_t n) const {
+    // t[first ..] = the op's inputs 5 ..; n = the op's input count (which constants there are)
+    return ensure(*m_state, ovtk_bpe_destroy, [&](ovtk_bpe** out) {
         ovtk_bpe_params p{};
-        p.vocab = strings_at(inputs, 5);
-        p.merges = strings_at(inputs, 8);  // "left right" lines (11 / 15 inputs) or the left halves (14 / 18)
-        if (n == 14 || n == 18) p.merges_right = strings_at(inputs, 11);
+        p.vocab = strings_at(t, first);
+        p.merges = strings_at(t, first + 3);  // "left right" lines (11 / 15 inputs) or the left halves (14 / 18)
+        if (n == 14 || n == 18) p.merges_right = strings_at(t, first + 6);
         if (n == 15 || n == 18) {
-            p.added_tokens = strings_at(inputs, n - 4);
-            p.added_ids = i32(inputs[n - 1]);
+            p.added_tokens = strings_at(t, first + n - 9);
+            p.added_ids = i32(t[first + n - 6]);
         }
         p.unk_token = m_unk_token.data();
         p.unk_token_len = int64_t(m_unk_token.size());
@@ -260,6 +264,9 @@ bool BPETokenizer::evaluate(ov::TensorVector& outputs, const ov::TensorVector& i
         p.device = device();
         check(ovtk_bpe_create(&p, out), "BPETokenizer (table construction)");
     });
+}
+bool BPETokenizer::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
+    ovtk_bpe* h = handle(inputs, 5, inputs.size());
     const ovtk_ragged_strings in = ragged_at(inputs);
     // the reference sizes the ids to the chars tensor (bpe_tokenizer.cpp:135); an end_suffix adds up to its length per piece
     const size_t cap = (inputs[4].get_size() + inputs[2].get_size()) * (1 + m_end_suffix.size());
@@ -293,12 +300,15 @@ bool WordpieceTokenizer::visit_attributes(ov::AttributeVisitor& visitor) {
     visitor.on_attribute("max_bytes_per_word", m_max_bytes_per_word);
     return true;
 }
-bool WordpieceTokenizer::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
-    ovtk_wordpiece* h = ensure(*m_state, ovtk_wordpiece_destroy, [&](ovtk_wordpiece** out) {
-        const ovtk_wordpiece_params p{strings_at(inputs, 5), m_suffix_indicator.data(), int64_t(m_suffix_indicator.size()),
+ovtk_wordpiece* WordpieceTokenizer::handle(const ov::TensorVector& t, size_t vocab_at) const {
+    return ensure(*m_state, ovtk_wordpiece_destroy, [&](ovtk_wordpiece** out) {
+        const ovtk_wordpiece_params p{strings_at(t, vocab_at), m_suffix_indicator.data(), int64_t(m_suffix_indicator.size()),
                                       m_max_bytes_per_word, device()};
         check(ovtk_wordpiece_create(&p, out), "WordpieceTokenizer (trie construction)");
     });
+}
+bool WordpieceTokenizer::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
+    ovtk_wordpiece* h = handle(inputs, 5);
     const ovtk_ragged_strings in = ragged_at(inputs);
     const int32_t unk = i32(inputs[8])[0];  // read every call (wordpiece_tokenizer.cpp:74)
     const size_t cap = inputs[4].get_size() + inputs[2].get_size();
@@ -411,12 +421,15 @@ bool VocabDecoder::visit_attributes(ov::AttributeVisitor& visitor) {
     visitor.on_attribute("skip_tokens", m_skip_tokens);
     return true;
 }
-bool VocabDecoder::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
-    ovtk_vocab_decoder* h = ensure(*m_state, ovtk_vocab_decoder_destroy, [&](ovtk_vocab_decoder** out) {
+ovtk_vocab_decoder* VocabDecoder::handle(const ov::TensorVector& inputs) const {
+    return ensure(*m_state, ovtk_vocab_decoder_destroy, [&](ovtk_vocab_decoder** out) {
         std::vector<int32_t> skip(m_skip_tokens.begin(), m_skip_tokens.end());
         const ovtk_vocab_decoder_params p{strings_at(inputs, 1), skip.data(), int64_t(skip.size()), device()};
         check(ovtk_vocab_decoder_create(&p, out), "VocabDecoder (table construction)");
     });
+}
+bool VocabDecoder::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
+    ovtk_vocab_decoder* h = handle(inputs);
     const ov::Shape ids = inputs[0].get_shape();
     OPENVINO_ASSERT(ids.size() == 2, "VocabDecoder: ids must be [batch, seq_len]");
     const size_t batch = ids[0], seq = ids[1], tokens = batch * std::max<size_t>(seq, 1);
@@ -656,6 +669,104 @@ std::shared_ptr<ov::Node> StringTensorPack::clone_with_new_inputs(const ov::Outp
 }
 bool StringTensorPack::visit_attributes(ov::AttributeVisitor& visitor) {
     visitor.on_attribute("mode", m_mode);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ the fused nodes (fuse_pass.cpp)
+FusedSplitBPE::FusedSplitBPE(const ov::OutputVector& arguments, std::shared_ptr<const SpecialTokensSplit> special, std::shared_ptr<const RegexSplit> split,
+                             std::shared_ptr<const BPETokenizer> bpe, bool has_skips, size_t bpe_inputs)
+    : Base(arguments), m_special(std::move(special)), m_split(std::move(split)), m_bpe(std::move(bpe)), m_has_skips(has_skips), m_bpe_inputs(bpe_inputs) {
+    constructor_validate_and_infer_types();
+}
+void FusedSplitBPE::validate_and_infer_types() {
+    expect_ragged_strings(this, "OvtkFusedSplitBPE");
+    ragged_i32_outputs(this, get_input_partial_shape(0));
+}
+std::shared_ptr<ov::Node> FusedSplitBPE::clone_with_new_inputs(const ov::OutputVector& inputs) const {
+    return std::make_shared<FusedSplitBPE>(inputs, m_special, m_split, m_bpe, m_has_skips, m_bpe_inputs);
+}
+bool FusedSplitBPE::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
+    size_t at = 5 + (m_has_skips ? 1 : 0);
+    ovtk_special_tokens_split* special = m_special ? m_special->handle(inputs[at++]) : nullptr;
+    ovtk_regex_split* split = m_split->handle(inputs[at++]);
+    ovtk_bpe* bpe = m_bpe->handle(inputs, at, m_bpe_inputs);
+    const ovtk_ragged_strings in = ragged_at(inputs);
+    const size_t cap = (inputs[4].get_size() + inputs[2].get_size()) * (1 + m_bpe->end_suffix_size());   // bpe_tokenizer.cpp:135
+    outputs[0].set_shape(inputs[0].get_shape());
+    outputs[1].set_shape(inputs[0].get_shape());
+    outputs[2].set_shape(one_dim(std::max<size_t>(cap, 1)));
+    ovtk_ragged_i32_out out{i32(outputs[0]), i32(outputs[1]), i32(outputs[2]), int64_t(cap), 0, 0};
+    const uint8_t* skips = m_has_skips ? u8(inputs[5]) : nullptr;
+    if (special) check(ovtk_encode_special_run(special, split, bpe, &in, skips, &out, OVTK_MEM_HOST, nullptr), "OvtkFusedSplitBPE");
+    else check(ovtk_encode_run(split, bpe, &in, skips, &out, OVTK_MEM_HOST, nullptr), "OvtkFusedSplitBPE");
+    outputs[0].set_shape(one_dim(size_t(out.n_rows)));
+    outputs[1].set_shape(one_dim(size_t(out.n_rows)));
+    outputs[2].set_shape(one_dim(size_t(out.n_data)));
+    return true;
+}
+
+FusedSplitWordpiece::FusedSplitWordpiece(const ov::OutputVector& arguments, std::shared_ptr<const RegexSplit> whitespace,
+                                         std::shared_ptr<const RegexSplit> delimiters, std::shared_ptr<const WordpieceTokenizer> wordpiece)
+    : Base(arguments), m_whitespace(std::move(whitespace)), m_delimiters(std::move(delimiters)), m_wordpiece(std::move(wordpiece)) {
+    constructor_validate_and_infer_types();
+}
+void FusedSplitWordpiece::validate_and_infer_types() {
+    OPENVINO_ASSERT(get_input_size() == 11, "OvtkFusedSplitWordpiece: ragged strings (5), two patterns, vocabulary (3), unk_token_id expected");
+    expect_ragged_strings(this, "OvtkFusedSplitWordpiece");
+    ragged_i32_outputs(this, get_input_partial_shape(0));
+}
+std::shared_ptr<ov::Node> FusedSplitWordpiece::clone_with_new_inputs(const ov::OutputVector& inputs) const {
+    return std::make_shared<FusedSplitWordpiece>(inputs, m_whitespace, m_delimiters, m_wordpiece);
+}
+bool FusedSplitWordpiece::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
+    ovtk_regex_split* ws = m_whitespace->handle(inputs[5]);
+    ovtk_regex_split* pu = m_delimiters->handle(inputs[6]);
+    ovtk_wordpiece* wp = m_wordpiece->handle(inputs, 7);
+    const ovtk_ragged_strings in = ragged_at(inputs);
+    const int32_t unk = i32(inputs[10])[0];   // read every call (wordpiece_tokenizer.cpp:74)
+    const size_t cap = inputs[4].get_size() + inputs[2].get_size();
+    outputs[0].set_shape(inputs[0].get_shape());
+    outputs[1].set_shape(inputs[0].get_shape());
+    outputs[2].set_shape(one_dim(std::max<size_t>(cap, 1)));
+    ovtk_ragged_i32_out out{i32(outputs[0]), i32(outputs[1]), i32(outputs[2]), int64_t(cap), 0, 0};
+    check(ovtk_wordpiece_encode_run(wp, ws, pu, &in, unk, &out, OVTK_MEM_HOST, nullptr), "OvtkFusedSplitWordpiece");
+    outputs[0].set_shape(one_dim(size_t(out.n_rows)));
+    outputs[1].set_shape(one_dim(size_t(out.n_rows)));
+    outputs[2].set_shape(one_dim(size_t(out.n_data)));
+    return true;
+}
+
+FusedDetokenize::FusedDetokenize(const ov::OutputVector& arguments, std::shared_ptr<const VocabDecoder> decoder, bool byte_fallback)
+    : Base(arguments), m_decoder(std::move(decoder)), m_byte_fallback(byte_fallback) {
+    constructor_validate_and_infer_types();
+}
+void FusedDetokenize::validate_and_infer_types() {
+    OPENVINO_ASSERT(get_input_size() == 4 || get_input_size() == 5, "OvtkFusedDetokenize: VocabDecoder's inputs expected");
+    string_outputs(this, 0, ov::PartialShape{ov::Dimension()});
+}
+std::shared_ptr<ov::Node> FusedDetokenize::clone_with_new_inputs(const ov::OutputVector& inputs) const {
+    return std::make_shared<FusedDetokenize>(inputs, m_decoder, m_byte_fallback);
+}
+bool FusedDetokenize::evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const {
+    ovtk_vocab_decoder* h = m_decoder->handle(inputs);
+    const ov::Shape ids = inputs[0].get_shape();
+    OPENVINO_ASSERT(ids.size() == 2, "OvtkFusedDetokenize: ids must be [batch, seq_len]");
+    const size_t batch = ids[0], seq = ids[1];
+    const ovtk_strings vocab = strings_at(inputs, 1);
+    int32_t longest = 0;
+    for (int64_t k = 0; k < vocab.n; ++k) longest = std::max(longest, vocab.ends[k] - vocab.begins[k]);
+    const size_t cap = std::min<size_t>(batch * seq * size_t(longest), size_t(INT32_MAX) - 1);
+    outputs[0].set_shape(one_dim(batch));
+    outputs[1].set_shape(one_dim(batch));
+    outputs[2].set_shape(one_dim(std::max<size_t>(cap, 1)));
+    ovtk_strings_out out{i32(outputs[0]), i32(outputs[1]), u8(outputs[2]), int64_t(cap), 0};
+    const bool skip_input = inputs.size() == 5;   // input 4 overrides the attribute, an empty one too (vocab_decoder.cpp:36-41)
+    static const int32_t none = 0;
+    const int32_t* skip = skip_input ? (inputs[4].get_size() ? i32(inputs[4]) : &none) : nullptr;
+    check(ovtk_detokenize_run(h, i32(inputs[0]), int64_t(batch), int64_t(seq), skip, skip_input ? int64_t(inputs[4].get_size()) : 0,
+                              m_byte_fallback ? 1 : 0, &out, OVTK_MEM_HOST, nullptr),
+          "OvtkFusedDetokenize");
+    outputs[2].set_shape(one_dim(size_t(out.n_chars)));
     return true;
 }
 

@@ -58,6 +58,8 @@ public:
     std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
     bool visit_attributes(ov::AttributeVisitor& visitor) override;
     bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+    // the device tables of this node (built on first use, shared by its clones): for the fused nodes of fuse_pass.hpp
+    ovtk_regex_split* handle(const ov::Tensor& pattern) const;
 
 private:
     std::string m_behaviour = "remove";
@@ -77,6 +79,7 @@ public:
     std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
     bool visit_attributes(ov::AttributeVisitor&) override { return true; }
     bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+    ovtk_special_tokens_split* handle(const ov::Tensor& pattern) const;
 
 private:
     mutable std::shared_ptr<Lazy<ovtk_special_tokens_split>> m_state = std::make_shared<Lazy<ovtk_special_tokens_split>>();
@@ -93,6 +96,9 @@ public:
     std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
     bool visit_attributes(ov::AttributeVisitor& visitor) override;
     bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+    // `consts`: inputs 5.. of the op (vocab, merges, [added tokens]), `first`: where they start in `consts`
+    ovtk_bpe* handle(const ov::TensorVector& consts, size_t first, size_t n_inputs) const;
+    size_t end_suffix_size() const { return m_end_suffix.size(); }
 
 private:
     std::string m_unk_token, m_suffix_indicator, m_end_suffix;
@@ -110,6 +116,7 @@ public:
     std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
     bool visit_attributes(ov::AttributeVisitor& visitor) override;
     bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+    ovtk_wordpiece* handle(const ov::TensorVector& tensors, size_t vocab_at) const;
 
 private:
     std::string m_suffix_indicator = "##";
@@ -154,6 +161,7 @@ public:
     std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
     bool visit_attributes(ov::AttributeVisitor& visitor) override;
     bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+    ovtk_vocab_decoder* handle(const ov::TensorVector& inputs) const;
 
 private:
     std::vector<int> m_skip_tokens;
@@ -255,6 +263,65 @@ public:
 
 private:
     std::string m_mode = "begins_ends";
+};
+
+// ---- the fused nodes fuse_pass.cpp puts in place of the chains it recognises (python mirror: openvino_tokenizers_amd/pipeline.py) ------
+// Each holds the nodes it replaces -- their attributes and their device tables -- and forwards ONE evaluate() to the library's fused
+// entry point, host tensors in and out (OVTK_MEM_HOST: staged over PCIe once per chain instead of once per op).
+
+// [SpecialTokensSplit ->] RegexSplit -> BPETokenizer  =>  ovtk_encode_run / ovtk_encode_special_run.
+// Inputs: the chain's ragged strings 0-4 [, skips], [the special pattern], the split pattern, then BPETokenizer's inputs 5...
+class FusedSplitBPE : public Base {
+public:
+    OPENVINO_OP("OvtkFusedSplitBPE");
+    FusedSplitBPE() = default;
+    FusedSplitBPE(const ov::OutputVector& arguments, std::shared_ptr<const SpecialTokensSplit> special, std::shared_ptr<const RegexSplit> split,
+                  std::shared_ptr<const BPETokenizer> bpe, bool has_skips, size_t bpe_inputs);
+    void validate_and_infer_types() override;
+    std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
+    bool visit_attributes(ov::AttributeVisitor&) override { return true; }
+    bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+
+private:
+    std::shared_ptr<const SpecialTokensSplit> m_special;
+    std::shared_ptr<const RegexSplit> m_split;
+    std::shared_ptr<const BPETokenizer> m_bpe;
+    bool m_has_skips = false;
+    size_t m_bpe_inputs = 0;   // input count of the BPETokenizer node (11 / 14 / 15 / 18: which constants follow)
+};
+
+// RegexSplit(\\s+, remove) -> RegexSplit(BERT delimiters, isolate) -> WordpieceTokenizer  =>  ovtk_wordpiece_encode_run.
+// Inputs: ragged strings 0-4, the two patterns, the vocabulary (3), unk_token_id.
+class FusedSplitWordpiece : public Base {
+public:
+    OPENVINO_OP("OvtkFusedSplitWordpiece");
+    FusedSplitWordpiece() = default;
+    FusedSplitWordpiece(const ov::OutputVector& arguments, std::shared_ptr<const RegexSplit> whitespace, std::shared_ptr<const RegexSplit> delimiters,
+                        std::shared_ptr<const WordpieceTokenizer> wordpiece);
+    void validate_and_infer_types() override;
+    std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
+    bool visit_attributes(ov::AttributeVisitor&) override { return true; }
+    bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+
+private:
+    std::shared_ptr<const RegexSplit> m_whitespace, m_delimiters;
+    std::shared_ptr<const WordpieceTokenizer> m_wordpiece;
+};
+
+// VocabDecoder -> [ByteFallback] -> FuzeRagged  =>  ovtk_detokenize_run.  Inputs: VocabDecoder's; outputs: begins, ends, chars of the rows.
+class FusedDetokenize : public Base {
+public:
+    OPENVINO_OP("OvtkFusedDetokenize");
+    FusedDetokenize() = default;
+    FusedDetokenize(const ov::OutputVector& arguments, std::shared_ptr<const VocabDecoder> decoder, bool byte_fallback);
+    void validate_and_infer_types() override;
+    std::shared_ptr<ov::Node> clone_with_new_inputs(const ov::OutputVector& inputs) const override;
+    bool visit_attributes(ov::AttributeVisitor&) override { return true; }
+    bool evaluate(ov::TensorVector& outputs, const ov::TensorVector& inputs) const override;
+
+private:
+    std::shared_ptr<const VocabDecoder> m_decoder;
+    bool m_byte_fallback = false;
 };
 
 }  // namespace ovtk_adapter

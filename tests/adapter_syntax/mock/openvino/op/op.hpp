@@ -2,6 +2,7 @@
 #pragma once
 #include <cstdint>
 #include <memory>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -11,12 +12,17 @@ namespace ov {
 class Node;
 template <class T>
 class Output;
+template <class T>
+class Input;
 template <>
 class Output<Node> {
 public:
     Output() = default;
     Output(const std::shared_ptr<Node>&) {}
     std::shared_ptr<Node> get_node_shared_ptr() const;
+    size_t get_index() const;
+    std::set<Input<Node>> get_target_inputs() const;
+    void replace(const Output<Node>& replacement);
     const element::Type& get_element_type() const;
     const PartialShape& get_partial_shape() const;
 };
@@ -49,6 +55,11 @@ public:
     void set_output_type(size_t i, const element::Type& type, const PartialShape& shape);
     void set_output_size(size_t n);
     OutputVector outputs();
+    size_t get_output_size() const;
+    Output<Node> input_value(size_t i) const;
+    Output<Node> output(size_t i);
+    const std::string& get_friendly_name() const;
+    void set_friendly_name(const std::string& name);
 };
 namespace op {
 class Op : public Node {
