@@ -220,7 +220,7 @@ int ovtk_set_row_tickets(int rows_per_ticket);
  * lookup_kernel for the rows it leaves (rows of several strings, skipped strings: rare), merge_kernel / wordpiece_deferred_kernel for the
  * pieces the memo does not hold, compact_kernel.  Now the span kernel looks those pieces up in the handle's piece store itself and
  * counts what is in neither table, and the two kernels in the middle are launched only when the handle's last calls had work for them
- * (every call that had sets a count of 16 calls, every call that had not takes one off; a new handle starts with merging expected).
+ * (every call that had sets a count of 4 calls, every call that had not takes one off; a new handle starts with merging expected).
  * When a kernel was left out and had work after all, compact_kernel writes nothing and the kernel follows, with compact_kernel again,
  * from ovtk_encode_finish / inside ovtk_encode_run.  Results are identical either way.
  * 0: never (every call launches all four, round 5's form); 1 (default): as described; 2: every call leaves out both kernels of the

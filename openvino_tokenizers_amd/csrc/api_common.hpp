@@ -274,6 +274,10 @@ inline std::atomic<int>& short_path_mode() {
     return v;
 }
 
+// Calls for which a kernel of the middle is still launched after a call that had work for it (the handles' predictors: api_encode.cpp
+// ovtk_bpe).  A wrong guess costs one more round of launches (~0.1 ms), a needless launch a few microseconds: four calls without work
+// and the kernel is left out -- the driver's bench line (8 priming + 5 warm-up calls in front of 20 timed ones) then times the steady form.
+constexpr int kShortPathKeep = 4;
 // ovtk_short_path_stats(): calls launched as span -> compact / of them, calls that needed no other kernel.
 struct ShortPathCounts { std::atomic<int64_t> tried{0}, exact{0}; };
 inline ShortPathCounts& short_path_counts() {

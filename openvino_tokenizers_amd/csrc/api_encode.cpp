@@ -109,9 +109,9 @@ struct ovtk_bpe {
     // hit (then the store is asked again, and so on -- text changes)
     mutable std::atomic<int> store_pause{0}, store_low{0};  // store_low: calls in a row with that little use of it
     // The short path (span_kernel.hpp): calls during which the kernels of the middle are still launched whatever the last call said --
-    // lookup_kernel<kFused> for left-over rows, merge_kernel for pieces in neither table.  Set to 16 by every call that had such rows /
-    // pieces, counted down by every call that had none; a new handle's tables are empty: its first calls merge.
-    mutable std::atomic<int> expect_pending{0}, expect_merge{16};
+    // lookup_kernel<kFused> for left-over rows, merge_kernel for pieces in neither table.  Set to kShortPathKeep by every call that had such
+    // rows / pieces, counted down by every call that had none; a new handle's tables are empty: its first calls merge.
+    mutable std::atomic<int> expect_pending{0}, expect_merge{kShortPathKeep};
     mutable std::atomic<int> last_unresolved{-1};   // pieces the last such call left for merge_kernel (sizes its launch)
 };
 
@@ -888,7 +888,7 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
             if (dense_width) *dense_width = st.width;
             if (st.short_path) {   // the span kernel counted: what this call's text left to the kernels of the middle
                 auto note = [](std::atomic<int>& expect, bool had_work) {
-                    if (had_work) expect.store(16, std::memory_order_relaxed);
+                    if (had_work) expect.store(kShortPathKeep, std::memory_order_relaxed);
                     else if (expect.load(std::memory_order_relaxed) > 0) expect.fetch_sub(1, std::memory_order_relaxed);
                 };
                 note(bpe->expect_pending, st.n_pending > 0);

@@ -99,7 +99,7 @@ struct ovtk_wordpiece {
     int32_t store_capacity = 0;
     PieceTableDev memo{nullptr, 30, nullptr, 0, 0};  // word -> ids of every vocabulary word (the fused path's first-level lookup)
     int64_t n_vocab = 0;   // ids are vocabulary indices: below 65535 (and unk_token_id too), a call stages u16 entries
-    std::atomic<int> expect_pending{0}, expect_merge{16}, last_unresolved{-1};   // the short path's predictors (api_encode.cpp ovtk_bpe says how they count)
+    std::atomic<int> expect_pending{0}, expect_merge{kShortPathKeep}, last_unresolved{-1};   // the short path's predictors (api_encode.cpp ovtk_bpe says how they count)
 };
 
 struct ovtk_vocab_encoder {
@@ -283,7 +283,7 @@ int start_wordpiece_encode(ovtk_wordpiece* h, ovtk_regex_split* whitespace, ovtk
         r->on_status([h](const RunStatus& st) {
             if (!st.short_path) return;
             auto note = [](std::atomic<int>& expect, bool had_work) {
-                if (had_work) expect.store(16, std::memory_order_relaxed);
+                if (had_work) expect.store(kShortPathKeep, std::memory_order_relaxed);
                 else if (expect.load(std::memory_order_relaxed) > 0) expect.fetch_sub(1, std::memory_order_relaxed);
             };
             note(h->expect_pending, st.n_pending > 0);
