@@ -17,10 +17,10 @@
 // and their negations, \p{..} \P{..} \pL by General_Category and (round 5) by script -- \p{Han} \p{Hira} = Script_Extensions as in
 // PCRE2 >= 10.40, \p{sc:Han} \p{script=Han} = Script, \p{scx:Han}; names matched loosely -- (Unicode 16.0, the version of the
 // PCRE2 10.46 the reference pins; UCP meanings: \d = Nd, \s = Z + \h + \v, \w = L | N | Mn | Pc), groups ( ) (?: ) (?<name> ),
-// (?i) (?s) (?i: ) (?s: ) -- caseless on ASCII letters incl. U+017F / U+212A --, alternation, * + ? {m} {m,} {m,n}
+// (?i) (?s) (?m) (?i: ) (?s: ) -- caseless on ASCII letters incl. U+017F / U+212A; (?m): `^` / `$` at every line break --, alternation, * + ? {m} {m,} {m,n} {,n}
 // greedy / lazy, possessive on single-character atoms, ^ $ \A \z \Z \b \B, look-ahead / look-behind (?= ) (?! ) (?<= )
 // (?<! ) on one character.  Not supported: back-references, recursion, atomic groups, conditionals, look-around over more than
-// one character, (?m) (?x), \R \X \K \G, binary properties (\p{Alphabetic} ...).
+// one character, (?x), \R \X \K \G, binary properties (\p{Alphabetic} ...).
 #pragma once
 
 #include <stdint.h>

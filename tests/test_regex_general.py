@@ -43,7 +43,8 @@ def strings_for(backend, alphabet, seed, n_emu=900, n_gpu=40000):
 
 # \w under UCP is L | N | Mn | Pc from PCRE2 10.43 on (the reference pins 10.46); the oracle's 10.39 has L | N | '_'
 W1046 = r"\p{L}\p{N}\p{Mn}\p{Pc}"
-REF_PATTERN = {r"\w+|[^\w\s]+": "[" + W1046 + "]+|[^" + W1046 + r"\s]+"}
+# ... and reads `{,n}` and blanks inside the braces as a quantifier, where 10.39 sees literal text
+REF_PATTERN = {r"\w+|[^\w\s]+": "[" + W1046 + "]+|[^" + W1046 + r"\s]+", r"a{,3}": r"a{0,3}", r"[ab]{ 1 , 2 }c": r"[ab]{1,2}c", r"a{ ,2}b": r"a{0,2}b"}
 
 
 @pytest.mark.parametrize("name", list(MODEL_PATTERNS))
@@ -67,13 +68,14 @@ def test_behaviours(backend, name, behaviour, invert):
 
 SEMANTICS = [
     r"a|ab", r"(a|ab)(c|bcd)", r"(?:ab|a)(?:c|bcd)?", r"a*", r"(a*)+", r"(a|b)*?b", r"a+?", r"a+?b", r"a??b", r"a{2,3}", r"a{2}", r"a{2,}",
-    r"a{,3}", r"x{", r"a{2,3}?", r"a?+a", r"a*+a", r"[ab]++b", r"a{1,2}+", r"\d+|\D", r"^a", r"^", r"a$", r"$", r"\s+$", r"\s++$", r"\Aa", r"b\z",
+    r"a{,3}", r"[ab]{ 1 , 2 }c", r"a{ ,2}b", r"a{,}", r"a{ }", r"x{", r"a{2,3}?", r"a?+a", r"a*+a", r"[ab]++b", r"a{1,2}+", r"\d+|\D", r"^a", r"^", r"a$", r"$", r"\s+$", r"\s++$", r"\Aa", r"b\z",
     r"b\Z", r"\bs\b", r"\Bs", r"s\B", r"(?<=a)b", r"(?<!a)b", r"(?<![ab])\s", r"b(?=a)", r"b(?!a)", r"b(?=[a\n])", r"(?i)Ab", r"(?i:a)b",
     r"a(?i)b|S", r"(?i)[a-c]", r"(?i)[^a-c]", r"(?i)s+", r"(?i)k", r".", r".+", r"(?s).", r"(?s:.)a", r"\N+", r"[^a]", r"[]a]+", r"[^]a]+",
     r"[a\-b]+", r"[a-]+", r"[-a]+", r"[\]]", r"[\\]", r"[[:alpha:]]+", r"[[:digit:][:space:]]+", r"[[:^alpha:]]+", r"[\d\s]+", r"[^\d\s]+",
     r"[\x41-\x{5A}]+", r"\x61\x{62}", r"\Qa.b\E", r"\Q[a]\E|b", r"a\.b", r"\p{Lu}\p{Ll}+", r"\pL+", r"\PL+", r"\p{^L}+", r"[\p{L}--a]",
     r"\p{L&}+", r"\p{Lt}", r"\p{Xan}+", r"\p{Xsp}+", r"\h+", r"\v+", r"\H\V", r"\t|\n|\r|\f|\e|\a|\0", r"(?<w>a+)b", r"(?P<w>a+)b", r"(a)|b|",
     r"|a", r"a||b", r"()", r"(?:)", r"a(?:)b", r"é+", r"[é元]+", r"元|，", r"😀+", r"[^\x00-\x7F]+", r"[\x{80}-\x{10FFFF}]",
+    r"(?m)^a", r"(?m)a$", r"(?m)^", r"(?m)$", r"(?m)^\s+$", r"(?m)^.+$", r"(?m:^a)|b$", r"(?ms)^.+?$", r"a(?m)^b|^c", r"(?m)\s*$", r"(?m)^$",
     r"(?:a|b)+?(?:ab)", r"(a+|b+)*c", r"(?:(?:a?)b?)*", r"(a|b|ab)*", r"(?:a{0,2}b){1,2}", r"\s*[\r\n]+|\s+(?!\S)|\s+", r"'(?i:[sdmt]|ll|ve|re)",
 ]
 SEM_ALPHABET = ["a", "b", "c", "d", "A", "B", "S", "s", "k", " ", "\n", "\r", "1", ".", "-", "]", "[", "\\", "é", "元", "，", "😀", "ſ", "K",
@@ -85,10 +87,10 @@ def test_pcre2_semantics(backend, pattern):
     strs = strings_for(backend, SEM_ALPHABET, 3, n_emu=500, n_gpu=6000)
     strs += ["a.b", "[a]", "abcd", "aab", "abab", "ab\n", "b\n", "b\n\n", "  \n", "sass s", "s", "a-b", "\x1b\x07\x00\t", "aaa", "ABC abc"]
     try:
-        check(backend, pattern, strs)
+        check(backend, pattern, strs, ref_pattern=REF_PATTERN.get(pattern))
     except L.OvtkError as err:
         # a refused pattern is fine (never a wrong answer) -- but only for the constructs documented as unsupported
-        assert err.code == L.E_UNSUPPORTED and pattern in (r"a{,3}", r"[\p{L}--a]"), pattern
+        assert err.code == L.E_UNSUPPORTED and pattern in (r"[\p{L}--a]",), pattern
 
 
 # Repeats whose body can match the empty string: PCRE2 ends a repeat at the first round that consumed nothing, and what
@@ -126,7 +128,7 @@ def test_fuzzed_patterns(backend):
     assert compared >= 20
 
 
-@pytest.mark.parametrize("pattern", [r"(a)\1", r"(?>a+)b", r"\p{Hann}+", r"\p{foo:Greek}", r"a(?=bc)", r"(?<=ab)c", r"(?m)^a", r"(?x) a b", r"\R",
+@pytest.mark.parametrize("pattern", [r"(a)\1", r"(?>a+)b", r"\p{Hann}+", r"\p{foo:Greek}", r"a(?=bc)", r"(?<=ab)c", r"(?x) a b", r"\R",
                                      r"\X", r"a\Kb", r"(?|a|b)", r"(?R)", r"(?(1)a|b)", r"(?i)é", r"(?i)[à-ý]", r"(a|b)++c",
                                      r"(?i)\p{Lu}x", r"[[:punct:]]", r"(*UTF)a", r"\p{Foo}", r"(?=a)*b"])
 def test_outside_the_subset_is_refused(backend, pattern):
