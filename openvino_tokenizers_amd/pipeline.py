@@ -203,7 +203,9 @@ class FusedSplitBPEStep(Step):
 
 
 class FusedEncodeDenseStep(Step):
-    """... -> Truncate -> CombineSegments -> Padding as the sink of the encode's last pass: ovtk_encode_dense_enqueue / _finish."""
+    """... -> Truncate -> CombineSegments -> Padding as the sink of the encode's last pass: ovtk_encode_dense_enqueue / _finish (device tensors).
+    Host arrays (a CPU-plugin style caller) take the two-call form instead -- ovtk_encode_run / ovtk_encode_special_run, then
+    ovtk_encode_tail_run --, both of which stage host memory themselves."""
 
     def __init__(self, special, split, bpe, trunc, comb, pad):
         self.special, self.split, self.bpe, self.pad = special, split, bpe, pad
@@ -211,9 +213,14 @@ class FusedEncodeDenseStep(Step):
                                      max_length=trunc.max_length if trunc is not None else 2**31 - 1, trunc_side=trunc.side if trunc is not None else "right",
                                      pad_right=pad.pad_right, pad_value=pad.pad_value, prefix=comb.prefix if comb is not None else (),
                                      suffix=comb.suffix if comb is not None else ())
+        self.host_form = [FusedSplitBPEStep(special, split, bpe), FusedEncodeTailStep(trunc, comb, pad, lib=pad.op._lib)]
 
     def apply(self, kind, vals):
         assert kind == "strings"
+        if not _is_torch(vals[4]) and not hasattr(self.bpe.op._lib, "ovtk_emulator_build"):
+            for s in self.host_form:
+                kind, vals = s.apply(kind, vals)
+            return kind, vals
         ins = list(vals[:5]) + ([vals[5]] if vals[5] is not None else [])
         return "dense", self.op.evaluate(ins, _u8(self.split.pattern), self.bpe.consts,
                                          special_pattern=self.special.pattern if self.special is not None else None, target_dim=self.pad.target_dim)
