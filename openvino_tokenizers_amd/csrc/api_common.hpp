@@ -422,7 +422,12 @@ public:
             OVTK_HIP(hipGetLastError());
             if (front_check_)
                 if (int rc = front_check_()) return rc;
-            const RunStatus& st = *ws_->host_status;
+            RunStatus& st = *ws_->host_status;
+            if (phase_ != 0) {   // (the short path: every entry of the deferred list is a piece in neither table)
+                long long unresolved = 0;
+                for (int k = 0; k < kShards; ++k) unresolved += st.shard_count[k * kCounterStride];
+                st.n_unresolved = int32_t(std::min<long long>(unresolved, INT32_MAX));
+            }
             static const bool debug_status = std::getenv("OVTK_DEBUG_STATUS") != nullptr;
             if (debug_status) {   // (a debugging aid: what the kernels reported, one line per attempt)
                 long long deferred = 0;

@@ -36,8 +36,9 @@ struct RunStatus {
     int32_t n_store_hit;   // ... and found there
     int32_t width;         // dense output (ovtk_encode_dense_*): the row width row_width_kernel settled on
     uint32_t width_ticket; // ... and its "last block done" ticket
-    int32_t n_unresolved;  // the short path (EncodeWork::span_sums): pieces filed for merge_kernel / wordpiece_deferred_kernel -- what neither the memo
-                           // nor the piece store holds (the span kernel looks its misses up in the store itself)
+    int32_t n_unresolved;  // the short path, HOST SIDE (RowsRun::finish sums the shards' deferred counts into it for the handle's predictors): pieces
+                           // filed for merge_kernel / wordpiece_deferred_kernel -- with EncodeWork::span_sums what neither the memo nor the
+                           // piece store holds (the span kernel looks its misses up in the store itself)
     int32_t short_path;    // (host side, for the handle's predictors: 1 the call's first set of launches did it, 2 a second set was needed, 3 started over the long way)
     int32_t pad[16];
     int32_t shard_count[kShards * kCounterStride];  // [s * kCounterStride] = deferred pieces pushed to shard s

@@ -106,7 +106,7 @@ struct EncodeWork {
     RunStatus* status;
     // ---- the short path (round 6; span_kernel.hpp "the short path")
     int32_t span_sums;       // lookup_span_kernel looks the pieces the memo does not hold up in the piece store itself, counts what is left
-                             // (RunStatus::n_unresolved) and sums its rows' ids into tile_cnt; the kernels behind it add to these (lookup_kernel
+                             // (the deferred list's counters) and sums its rows' ids into tile_cnt; the kernels behind it add to these (lookup_kernel
                              // with only_pending: its rows' counts, its misses) instead of summing row_emit once more
     int32_t skip_mask;       // kernels of the middle that were not launched: kSkipPending lookup_kernel<kFused> for left-over rows, kSkipMerge
                              // merge_kernel / wordpiece_deferred_kernel -- compact_kernel writes nothing when one of them had work
@@ -486,10 +486,7 @@ __device__ __forceinline__ void flush_misses(WaveMiss& mb, int& n_miss, int n, c
     const int l = lane_id();
     const int shard = w.small ? 0 : int(blockIdx.x) % kShards;  // (a small batch: one dense list for the one block that merges)
     int idx = 0;
-    if (l == 0) {
-        idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
-        if (w.span_sums) atomicAdd(&w.status->n_unresolved, n);   // (the short path: this kernel runs for the rows the span kernel left)
-    }
+    if (l == 0) idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
     idx = wave_readlane(idx, 0);
     if (l < n) {
         if (idx + l < w.shard_cap) w.deferred[(long long)shard * w.shard_cap + idx + l] = mb.e[l];
@@ -1643,8 +1640,14 @@ __device__ __forceinline__ void compact_body(int n_rows, const EncodeWork& w, Si
     if ((w.status->flags | more_flags) & (kFatalFlags | kFlagOutCapacity | kFlagDeferOverflow | kFlagExactOverflow | kFlagScratchOverflow |
                                          kFlagTailPending))
         return;
-    // the short path: rows or pieces were left to a kernel that was not launched (the host launches it, and this kernel again)
-    if (((w.skip_mask & kSkipPending) && w.status->n_pending != 0) || ((w.skip_mask & kSkipMerge) && w.status->n_unresolved != 0)) return;
+    // the short path: rows or pieces were left to a kernel that was not launched (the host launches it, and this kernel again).
+    // Unresolved pieces = entries of the deferred list: with span_sums nothing else is filed there (a counter of its own, one more add
+    // per flush on ONE address, cost text that misses everywhere half its rate: 135 000 flushes per batch of uniform-random text).
+    if ((w.skip_mask & kSkipPending) && w.status->n_pending != 0) return;
+    if (w.skip_mask & kSkipMerge) {
+        const int mine = lane_id() < kShards ? __hip_atomic_load(&w.status->shard_count[lane_id() * kCounterStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        if (__ballot(mine != 0)) return;
+    }
     sink.start(w.status);
     const int l = lane_id();
     const int n_waves = (solo ? 1 : int(gridDim.x)) * kWavesPerBlock;

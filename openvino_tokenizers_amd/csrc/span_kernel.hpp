@@ -173,10 +173,7 @@ __device__ __forceinline__ void span_flush(const SW& sw, int first, int n, const
     const int l = lane_id();
     const int shard = int(blockIdx.x) % kShards;
     int idx = 0;
-    if (l == 0) {
-        idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);
-        if (w.span_sums) atomicAdd(&w.status->n_unresolved, n);   // (the short path: pieces that need merge_kernel / wordpiece_deferred_kernel)
-    }
+    if (l == 0) idx = atomicAdd(&w.status->shard_count[shard * kCounterStride], n);   // (with span_sums these are the unresolved pieces: compact_body reads the counters)
     const SpanMiss e = sw.miss[first + (l < n ? l : 0)];
     int row = 0;   // = rows whose bytes end at or before the piece
 #pragma unroll
@@ -215,7 +212,7 @@ constexpr int kSpanWindowHalo = 16;
 // and compact_kernel.  With EncodeWork::span_sums the span kernel does the middle's bookkeeping itself:
 //   * at its end a wave looks its noted misses up in the piece store (the memo's second level: one round trip, a lane per miss;
 //     store_lookup) and writes their ids into the staging entries it had reserved for them; only what the store does not hold either
-//     is filed for merge_kernel, and counted (RunStatus::n_unresolved);
+//     is filed for merge_kernel: with span_sums the deferred list holds exactly the unresolved pieces (its per-shard counters say how many);
 //   * it adds its rows' id counts to their tiles' sums (tile_cnt: what merge_kernel's fold_emitted_tile_sums did for every launch);
 // and the host launches the kernels in the middle only when the handle's last calls say they will find work (EncodeWork::skip_mask says
 // which were left out).  compact_kernel checks: rows left over (n_pending) without their kernel, or unresolved pieces without theirs,
