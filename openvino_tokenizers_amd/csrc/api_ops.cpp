@@ -837,19 +837,39 @@ int ovtk_trie_tokenizer_run(ovtk_trie_tokenizer* h, const ovtk_ragged_strings* i
     if (int rc = out_target(ws->out_a, out->begins, size_t(in->n_rows) * 4, mem, &d_b)) return rc;
     if (int rc = out_target(ws->out_b, out->ends, size_t(in->n_rows) * 4, mem, &d_e)) return rc;
     if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_i)) return rc;
-    // count walk (a lane per row) -> scan of the filed lengths -> write walk from the row's offset
+    // the rows' bytes -> scan: staging offsets; ONE walk (a lane per row): ids into the row's stretch, its count filed; scan of the counts:
+    // the rows' offsets in the output; a wave per row copies its stretch there
     if (int rc = ws->gen[6].ensure(size_t(in->n_rows) * 4)) return rc;
+    if (int rc = ws->gen[7].ensure(size_t(in->n_rows) * 8)) return rc;
     int32_t* lens = ws->gen[6].as<int32_t>();
+    long long* stage_off = ws->gen[7].as<long long>();
     const int each_grid = int((in->n_rows + kTileThreads - 1) / kTileThreads);
-    OVTK_LAUNCH(ws->marks, "trie_count", each_kernel<TrieCount>, each_grid, kTileThreads, s, (long long)in->n_rows, TrieCount{r, lens},
-                (const RunStatus*)nullptr, 0u);
-    if (int rc = scan_and_apply(*ws.ws, s, in->n_rows, FiledLen{lens}, RowOffsets{d_b, d_e, 0},
-                                (long long)std::min<int64_t>(out->data_capacity, INT32_MAX - 1), st, "trie_tokenizer"))
-        return rc;
-    OVTK_LAUNCH(ws->marks, "trie_write", each_kernel<TrieWrite>, each_grid, kTileThreads, s, (long long)in->n_rows,
-                TrieWrite{r, d_b, d_i}, (const RunStatus*)st, kFlagOutCapacity | kFlagRange | kFlagItemsOverflow);
-    if (int rc = finish_status(*ws.ws, s)) return rc;
-    const uint32_t f = ws->host_status->flags;
+    const int wave_grid = int(std::min<long long>((in->n_rows + kTileThreads / kWave - 1) / (kTileThreads / kWave), (long long)device_cu_count(h->device) * 32));
+    int64_t stage_cap = std::max<int64_t>(in->strings.n_chars, 1);   // (a token takes at least a byte; rows that share strings need more: second attempt)
+    uint32_t f = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (attempt) {
+            if (int rc = begin_status(*ws.ws, s, &st)) return rc;
+            r.status = st;
+        }
+        if (int rc = ws->stage.ensure(size_t(stage_cap) * 4)) return rc;
+        int32_t* stage = ws->stage.as<int32_t>();
+        if ((in->n_rows + kTileElems - 1) / kTileElems > INT32_MAX) return set_error(OVTK_E_UNSUPPORTED, "too many rows for one call; split it");
+        if (int rc = ws->tiles.ensure(scan_tiles_bytes(in->n_rows))) return rc;
+        launch_scan(ws->marks, "trie_tokenizer", s, in->n_rows, TrieRowBytes{r}, TrieStageOffsets{stage_off}, TrieStageFin{st, (long long)stage_cap},
+                    ws->tiles.as<long long>(), st, kFlagRange);
+        OVTK_LAUNCH(ws->marks, "trie_walk", trie_walk_kernel, each_grid, kTileThreads, s, (long long)in->n_rows, r, (const long long*)stage_off, stage, lens);
+        if (int rc = scan_and_apply(*ws.ws, s, in->n_rows, FiledLen{lens}, RowOffsets{d_b, d_e, 0},
+                                    (long long)std::min<int64_t>(out->data_capacity, INT32_MAX - 1), st, "trie_tokenizer"))
+            return rc;
+        OVTK_LAUNCH(ws->marks, "trie_copy", each_wave_kernel<TrieCopy>, wave_grid, kTileThreads, s, (long long)in->n_rows,
+                    TrieCopy{stage_off, stage, lens, d_b, d_i}, (const RunStatus*)st, kFlagOutCapacity | kFlagRange | kFlagItemsOverflow | kFlagStageOverflow);
+        if (int rc = finish_status(*ws.ws, s)) return rc;
+        f = ws->host_status->flags;
+        if (!(f & kFlagStageOverflow) || (f & kFlagRange)) break;
+        if (ws->host_status->stage_need >= INT32_MAX - 1) return set_error(OVTK_E_UNSUPPORTED, "TrieTokenizer: the rows' strings add up to 2^31 bytes or more; split the call");
+        stage_cap = ws->host_status->stage_need;
+    }
     if (f & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
     if (f & kFlagItemsOverflow)
         return set_error(OVTK_E_VOCAB, "TrieTokenizer: no vocabulary entry matches at some byte (the reference does not terminate on this input)");

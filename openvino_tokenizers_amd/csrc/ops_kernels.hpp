@@ -811,8 +811,12 @@ static __global__ __launch_bounds__(kBlockThreads) void fuze_kernel(const int32_
 }
 
 // ------------------------------------------------------------------------------- TrieTokenizer
-// src/trie_tokenizer.cpp:66-78, one lane per ragged row: a counting walk sizes the row (device scan = the reference's
-// running ragged_offset), a second walk writes the ids.  emit(token) per match; returns false where nothing matches.
+// src/trie_tokenizer.cpp:66-78, one lane per ragged row.  Round 6: ONE walk per row -- the ids go to a staging stretch of the row's
+// own (a token takes at least one byte: the row's bytes bound its ids; the stretches' offsets are a scan of the rows' bytes), the scan
+// of the filed counts is the reference's running ragged_offset, a wave per row copies the stretch to its place.  Until then: a counting
+// walk, the scan, a second walk that wrote (2.85 ms for a config-2 batch; the walk is a chain of dependent loads, one per byte).  And
+// the text comes sixteen bytes at a time into registers: the byte load in front of every trie step was a dependent load of its own.
+struct __attribute__((packed, aligned(1))) TrieBytes16 { uint32_t x, y, z, w; };
 struct TrieRows {
     const int32_t* ragged_begins;
     const int32_t* ragged_ends;
@@ -823,44 +827,129 @@ struct TrieRows {
     TrieDev trie;
     RunStatus* status;
 
+    // bytes of the row's strings (its staging stretch), -1 for offsets outside their tensors
+    __device__ long long row_bytes(long long row) const {
+        const long long cb = ragged_begins[row], ce = ragged_ends[row];
+        if (cb < 0 || ce < cb || ce > n_strings) return -1;
+        long long sum = 0;
+        for (long long col = cb; col < ce; ++col) {
+            const long long b = begins[col], e = ends[col];
+            if (b < 0 || e < b || e > n_chars) return -1;
+            sum += e - b;
+        }
+        return sum;
+    }
+
+    // The greedy walk of one row as a FLAT loop: every turn of it is one trie step of the lane's current token -- the first byte through
+    // the root table (`root`: a copy in LDS), then one edge per turn -- and a token's end (emit, back to the root) is part of the turn that
+    // finds it.  Written as the reference writes it -- a loop over tokens round a loop over steps (src/utils.cpp:517-538) -- a WAVE ran,
+    // for the k-th token of its 64 rows, as many inner turns as the longest of those 64 tokens: 1.5 ms per batch where this form takes
+    // as many turns as its longest ROW has steps.
     template <class Emit>
-    __device__ void walk(long long row, Emit&& emit) const {
+    __device__ void walk(long long row, const I2* root, Emit&& emit) const {
         const long long cb = ragged_begins[row], ce = ragged_ends[row];
         if (cb < 0 || ce < cb || ce > n_strings) {
             atomicOr(&status->flags, kFlagRange);
             return;
         }
+        TrieBytes16 win{0, 0, 0, 0};
+        long long win_at = -1;   // chars offset of the window (a multiple of 16), -1: none
         for (long long col = cb; col < ce; ++col) {
             const long long b = begins[col], e = ends[col];
             if (b < 0 || e < b || e > n_chars) {
                 atomicOr(&status->flags, kFlagRange);
                 return;
             }
-            const uint8_t* s = chars + b;
             const int n = int(e - b);
-            int idx = 0;
-            while (idx < n) {
-                const int tok = trie_longest(trie, trie.root, [&](int i) -> uint32_t { return s[i]; }, n, idx);
-                if (tok == -1) {  // the reference spins here forever (:72-75)
-                    atomicOr(&status->flags, kFlagItemsOverflow);
-                    return;
+            auto getb = [&](int i) -> uint32_t {
+                const long long at = b + i, base = at & ~15ll;
+                if (base != win_at) {
+                    if (base + 16 <= n_chars) {
+                        win = *reinterpret_cast<const TrieBytes16*>(chars + base);
+                    } else {   // the chars tensor's last bytes
+                        uint32_t v[4] = {0, 0, 0, 0};
+                        for (long long k = base; k < n_chars; ++k) v[(k - base) >> 2] |= uint32_t(chars[k]) << (8 * ((k - base) & 3));
+                        win = TrieBytes16{v[0], v[1], v[2], v[3]};
+                    }
+                    win_at = base;
                 }
-                emit(tok);
+                const int k = int(at & 15);
+                const uint32_t word = k < 8 ? (k < 4 ? win.x : win.y) : (k < 12 ? win.z : win.w);
+                return (word >> (8 * (k & 3))) & 0xFFu;
+            };
+            int idx = 0;                       // where the current token starts
+            int i = 0, cur = -1, best = -1, best_end = 0;   // cur < 0: at the root
+            bool stop = false;
+            while (idx < n) {
+                if (cur < 0) {   // Trie::find_longest's first step (src/utils.cpp:517-538)
+                    const I2 r = root[getb(idx)];
+                    best = r.y < 0 ? -1 : r.x;
+                    best_end = idx + 1;
+                    i = idx + 1;
+                    cur = r.y < 0 ? 0 : (r.y & ~kLeafBit);
+                    stop = r.y < 0 || (r.y & kLeafBit) != 0 || i >= n;
+                } else {
+                    TrieEdge ed;
+                    if (trie_step(trie, cur, getb(i), ed)) {
+                        cur = ed.child;
+                        ++i;
+                        if (ed.value != -1) {
+                            best = ed.value;
+                            best_end = i;
+                        }
+                        stop = ed.has_kids == 0 || i >= n;
+                    } else {
+                        stop = true;
+                    }
+                }
+                if (stop) {
+                    if (best == -1) {  // the reference spins here forever (src/trie_tokenizer.cpp:72-75)
+                        atomicOr(&status->flags, kFlagItemsOverflow);
+                        return;
+                    }
+                    emit(best);
+                    idx = best_end;
+                    cur = -1;
+                }
             }
         }
     }
 };
-// A lane per row, every row its own lane (each_kernel): the count walk files the row's length, the scan runs over the filed
-// lengths, the write walk starts at the row's offset -- two walks per row instead of the three the tile kernels made of it.
-struct TrieCount {
+struct TrieRowBytes {
     TrieRows r;
-    int32_t* lens;
-    __device__ void operator()(long long row) const {
-        int32_t n = 0;
-        r.walk(row, [&](int) { ++n; });
-        lens[row] = n;
+    __device__ long long operator()(long long row) const {
+        const long long n = r.row_bytes(row);
+        if (n < 0) atomicOr(&r.status->flags, kFlagRange);
+        return n < 0 ? 0 : n;
     }
 };
+struct TrieStageOffsets {
+    long long* off;
+    __device__ void operator()(long long i, long long o, long long) const { off[i] = o; }
+};
+// the staging entries the batch needs (rows may share strings: then more than the chars tensor has bytes) -> stage_need, and the flag when
+// the buffer at hand is smaller: the host grows it and runs the call again
+struct TrieStageFin {
+    RunStatus* status;
+    long long cap;
+    __device__ void operator()(long long total) const {
+        status->stage_need = total > INT32_MAX ? INT32_MAX : int32_t(total);
+        if (total > cap) atomicOr(&status->flags, kFlagStageOverflow);
+    }
+};
+// the walk: a lane per row, ids to the row's staging stretch, the count filed
+static __global__ __launch_bounds__(kTileThreads) void trie_walk_kernel(long long n_rows, TrieRows r, const long long* stage_off, int32_t* stage, int32_t* lens) {
+    __shared__ I2 root_lds[256];
+    for (int k = int(threadIdx.x); k < 256; k += kTileThreads) root_lds[k] = r.trie.root[k];
+    __syncthreads();
+    if (r.status->flags & (kFlagRange | kFlagStageOverflow)) return;
+    const long long row = (long long)blockIdx.x * kTileThreads + threadIdx.x;
+    if (row >= n_rows) return;
+    int32_t* dst = stage + stage_off[row];
+    int32_t n = 0;
+    r.walk(row, root_lds, [&](int tok) { dst[n++] = tok; });
+    lens[row] = n;
+}
 struct FiledLen {
     const int32_t* lens;
     __device__ long long operator()(long long i) const { return lens[i]; }
@@ -874,13 +963,18 @@ struct RowOffsets {
         out_ends[i] = int32_t(base + off + len);
     }
 };
-struct TrieWrite {
-    TrieRows r;
+// a wave per row: the staging stretch to its place in the output
+struct TrieCopy {
+    const long long* stage_off;
+    const int32_t* stage;
+    const int32_t* lens;
     const int32_t* out_begins;
     int32_t* out_ids;
     __device__ void operator()(long long row) const {
+        const int32_t* src = stage + stage_off[row];
         int32_t* dst = out_ids + out_begins[row];
-        r.walk(row, [&](int tok) { *dst++ = tok; });
+        const int n = lens[row];
+        for (int k = lane_id(); k < n; k += kWave) dst[k] = src[k];
     }
 };
 

@@ -84,3 +84,25 @@ def test_errors(backend):
         TrieTokenizer(lib=backend.lib).evaluate([one, one + 1, b, e, c, vb, ve, vc, idx[:1]])
     ok = TrieTokenizer(lib=backend.lib).evaluate([one, one + 1, b, np.array([2], np.int32), c, vb, ve, vc, idx])
     assert backend.host(ok[2]).tolist() == [9]
+
+
+def test_rows_that_share_strings(backend):
+    """Rows may name the same strings again (the reference only dereferences offsets): the rows' bytes then outnumber the chars tensor's and
+    the staging buffer of the one-walk form is grown for a second attempt; window edges of the 16-byte text loads at every offset."""
+    rng = np.random.default_rng(4)
+    vocab, indices = rwkv_like_vocab(rng, 800)
+    words = vocab[256:]
+    strings = [b"".join(words[int(k)] for k in rng.integers(0, len(words), int(rng.integers(1, 14)))) for _ in range(60)] + [b"a" * k for k in range(1, 20)]
+    b, e, c = O.pack_strings(strings)
+    n = len(strings)
+    # every string a row, a third of them once more, and one row of many strings: the rows' bytes exceed the chars tensor's (the staging
+    # buffer's first size), the ids do not (the reference sizes its output by the chars tensor, trie_tokenizer.cpp:57-59)
+    rb = np.concatenate([np.arange(n), np.arange(n // 3), [n // 2]]).astype(np.int32)
+    re_ = np.concatenate([np.arange(n) + 1, np.arange(n // 3) + 1, [n // 2 + 9]]).astype(np.int32)
+    ref = O.TrieTokenizer(vocab, indices)(rb, re_, b, e, c)
+    assert int((e - b)[rb[n:n + n // 3]].sum()) > 0 and len(ref[2]) <= len(c)
+    vb, ve, vc = O.pack_strings(vocab)
+    op = TrieTokenizer(lib=backend.lib)
+    for call in range(2):
+        got = op.evaluate(backend.data([rb, re_, b, e, c]) + [vb, ve, vc, indices])
+        assert_same(list(ref), got, backend.host, f"shared strings, call {call}")
