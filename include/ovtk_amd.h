@@ -86,9 +86,11 @@ typedef struct ovtk_ragged_i32_out {
  * reference's converter emits (python/openvino_tokenizers/tokenizer_pipeline.py:392-457) and selects a
  * hand-written gfx950 scanner with identical results; any other pattern is compiled into a leftmost-first DFA
  * (csrc/regex_compile.cpp: the PCRE2 subset listed in regex_compile.hpp -- classes, \p{..} by General_Category,
- * groups, alternation, greedy / lazy / possessive repeats, anchors, one-character look-around) and run one lane
- * per row; only constructs outside that subset (back-references, atomic groups, recursion, script properties ...)
- * are OVTK_E_UNSUPPORTED -- never an approximation, never a CPU fallback.  The GPT-2 family, the Llama-3 family
+ * and script, groups, alternation, greedy / lazy / possessive repeats, atomic groups, anchors, look-ahead over
+ * anything that is decided within 7 characters of a match's end, look-behind over up to 8 characters) and run one
+ * lane per row; only constructs outside that subset (back-references, recursion, conditions, \X, \K ...) are
+ * OVTK_E_UNSUPPORTED -- never an approximation, never a CPU fallback; a pattern pcre2_compile itself rejects
+ * splits nothing, as the reference's null pattern (src/utils.cpp:264-271).  The GPT-2 family, the Llama-3 family
  * (Llama-3's own pattern, Qwen2's, tiktoken's cl100k_base) are scanned inside the fused encode's lookup kernels; a
  * compiled DFA runs as one pass of its own in front of them on the same stream (no host wait: ovtk_encode_enqueue
  * returns before the split has finished); only the class patterns (\s+, the BERT delimiters) in front of a BPETokenizer,

@@ -309,7 +309,7 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
         e = e ? e : h->r_ascii.upload(prog.ascii_class, sizeof prog.ascii_class);
         e = e ? e : h->r_index.upload(prog.cp_index.data(), prog.cp_index.size() * sizeof(uint16_t));
         e = e ? e : h->r_blocks.upload(prog.cp_blocks.data(), prog.cp_blocks.size());
-        e = e ? e : h->r_ctx.upload(prog.ctx_of_class.data(), prog.ctx_of_class.size());
+        e = e ? e : h->r_ctx.upload(prog.ctx_next.data(), std::max<size_t>(prog.ctx_next.size(), 1));
         if (e) return e;
         OVTK_HIP(hipStreamSynchronize(nullptr));
         RegexDev& r = h->regex;
@@ -317,12 +317,13 @@ int ovtk_regex_split_create(const ovtk_regex_split_params* p, ovtk_regex_split**
         r.ascii_class = h->r_ascii.as<uint8_t>();
         r.cp_index = h->r_index.as<uint16_t>();
         r.cp_blocks = h->r_blocks.as<uint8_t>();
-        r.ctx_of_class = h->r_ctx.as<uint8_t>();
+        r.ctx_next = h->r_ctx.as<uint8_t>();
         r.n_syms = prog.n_syms;
         r.n_states = prog.n_states;
         r.sym_eot = prog.sym_eot;
         r.sym_final_nl = prog.sym_final_nl;
         r.n_ctx = prog.n_ctx;
+        r.behind_chars = prog.behind_chars;
         r.cp_blocks_bytes = int32_t(prog.cp_blocks.size());
         std::memcpy(r.start, prog.start, sizeof r.start);
         r.mode = h->mode;

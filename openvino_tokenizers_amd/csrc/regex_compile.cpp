@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <climits>
 #include <set>
+#include <tuple>
 #include <utility>
 
 #include "../../include/ovtk_amd.h"
@@ -59,6 +61,19 @@ struct CharSet {
         for (const auto& x : r)
             if (cp >= x.first && cp <= x.second) return true;
         return false;
+    }
+    CharSet intersected(CharSet o) const {   // a & b = ~(~a | ~b)
+        CharSet a = *this;
+        a.normalize();
+        o.normalize();
+        CharSet u = a.negated();
+        u.add(o.negated());
+        u.normalize();
+        return u.negated();
+    }
+    CharSet minus(CharSet o) const {
+        o.normalize();
+        return intersected(o.negated());
     }
 };
 
@@ -121,7 +136,8 @@ CharSet word_set() {  // \w under UCP in PCRE2 >= 10.43 (the reference pins 10.4
 }
 
 // ---------------------------------------------------------------------------------------------- syntax tree
-enum NodeKind { kEmpty, kSet, kCat, kAlt, kRepeat, kAssert };
+enum NodeKind { kEmpty, kSet, kCat, kAlt, kRepeat, kAssert, kLookNode, kAtomic };   // kLookNode: (?=X) / (?!X) over more than one character, kids = {X};
+                                                                                     // kAtomic: (?>X) that Parser::atomize could not spell in plain syntax, kids = {X}
 enum AssertKind { kBot, kEot, kEotNl, kWordB, kNotWordB, kAhead, kBehind };
 struct Node {
     NodeKind kind = kEmpty;
@@ -130,7 +146,8 @@ struct Node {
     int min = 0, max = 0;   // kRepeat; max < 0: unbounded
     int mode = 0;           // kRepeat: 0 greedy, 1 lazy, 2 possessive
     int akind = 0;
-    bool aneg = false;
+    bool aneg = false;      // kAssert, kLookNode: negative
+    std::vector<std::vector<CharSet>> behind;   // kAssert kBehind over more than one character: the alternatives, each a sequence of sets
 };
 
 struct Unsupported {
@@ -144,7 +161,7 @@ struct Invalid {
 };
 
 struct Flags {
-    bool caseless = false, dotall = false, multiline = false;
+    bool caseless = false, dotall = false, multiline = false, extended = false;
 };
 
 class Parser {
@@ -167,6 +184,11 @@ public:
     }
     int parse() {
         Flags f;
+        for (;;) {   // leading option settings that ask for what the reference sets anyway (PCRE2_UTF | PCRE2_UCP, src/utils.cpp:256-262)
+            if (looking_at("(*UTF)")) pos_ += 6;
+            else if (looking_at("(*UCP)")) pos_ += 6;
+            else break;
+        }
         const int root = parse_alt(f);
         if (pos_ != p_.size()) throw Invalid{"unmatched ')'"};
         return root;
@@ -240,10 +262,13 @@ private:
 
     int parse_cat(Flags& f) {
         std::vector<int> items;
-        while (more() && peek() != '|' && peek() != ')') {
+        for (;;) {
+            skip_extended(f);
+            if (!(more() && peek() != '|' && peek() != ')')) break;
+            const bool group = peek() == '(';
             int atom = parse_atom(f);
             if (atom < 0) continue;  // a flag setting (?i)
-            atom = parse_quantifier(atom);
+            atom = parse_quantifier(atom, group, f);
             items.push_back(atom);
         }
         if (items.empty()) return add(Node{});
@@ -295,18 +320,34 @@ private:
         return true;
     }
 
-    int parse_quantifier(int atom) {
+    void skip_extended(const Flags& f) {   // (?x): white space and `#` comments between the items are not part of the pattern (inside a class they are)
+        if (!f.extended) return;
+        for (;;) {
+            while (more() && (peek() == ' ' || (peek() >= 0x09 && peek() <= 0x0D))) ++pos_;
+            if (peek() != '#') break;
+            while (more() && peek() != '\n') ++pos_;
+        }
+    }
+
+    int parse_quantifier(int atom, bool from_group, const Flags& f) {
         for (int count = 0;; ++count) {
             int mn, mx;
+            skip_extended(f);
             if (eat('*')) { mn = 0; mx = -1; }
             else if (eat('+')) { mn = 1; mx = -1; }
             else if (eat('?')) { mn = 0; mx = 1; }
             else if (peek() == '{' && parse_braces(mn, mx)) {}
             else return atom;
             if (count) throw Invalid{"quantifier does not follow a repeatable item"};
-            if (nodes_[size_t(atom)].kind == kAssert) {
-                if (nodes_[size_t(atom)].akind == kAhead || nodes_[size_t(atom)].akind == kBehind) throw Unsupported{"quantifier on a look-around group"};
-                throw Invalid{"quantifier does not follow a repeatable item"};   // (^* $* \\b*)
+            if (nodes_[size_t(atom)].kind == kLookNode || nodes_[size_t(atom)].kind == kAssert) {
+                const Node& a = nodes_[size_t(atom)];
+                if (!(from_group || a.kind == kLookNode || a.akind == kAhead || a.akind == kBehind))
+                    throw Invalid{"quantifier does not follow a repeatable item"};   // (^* $* \\b*)
+                // a quantified assertion group -- (?=a)*, (^){1,2} --: tried once where the minimum is not zero, and free to fail where it is:
+                // nothing is consumed either way and there are no captures to tell the difference
+                if (!eat('?')) eat('+');
+                atom = mn == 0 ? add(Node{}) : atom;
+                continue;
             }
             Node n;
             n.kind = kRepeat;
@@ -315,10 +356,11 @@ private:
             n.max = mx;
             if (eat('?')) n.mode = 1;
             else if (eat('+')) n.mode = 2;
-            if (n.mode == 2 && nodes_[size_t(atom)].kind != kSet)
-                throw Unsupported{"possessive quantifier on something longer than one character"};
             if (n.max > 1000 || n.min > 1000) throw Unsupported{"repeat count too large"};
+            const bool possessive_group = n.mode == 2 && nodes_[size_t(atom)].kind != kSet;
+            if (possessive_group) n.mode = 0;   // X*+ is (?>X*)
             atom = add(std::move(n));
+            if (possessive_group) atom = atomize(atom);
         }
     }
 
@@ -476,10 +518,30 @@ private:
                 else if (name == "digit") s = gc_set(gc_bit(Nd));
                 else if (name == "space") s = space_set();
                 else if (name == "word") s = word_set();
-                else if (name == "ascii" || name == "blank" || name == "cntrl" || name == "graph" || name == "print" || name == "punct" || name == "xdigit")
-                    throw Unsupported{"POSIX class [:" + name + ":]"};
+                else if (name == "ascii") s.add(0, 0x7F);
+                else if (name == "blank") s = hspace_set();
+                else if (name == "cntrl") s = gc_set(gc_bit(Cc));
+                else if (name == "xdigit") { s.add('0', '9'); s.add('a', 'f'); s.add('A', 'F'); }
+                else if (name == "graph" || name == "print") {
+                    // PCRE2 under UCP (pcre2pattern, "POSIX character classes"): what marks the page -- L, M, N, P, S, Cf without the
+                    // invisible format characters U+061C, U+180E, U+2066-2069; [:print:] adds the Zs spaces
+                    CharSet hidden;
+                    hidden.add(0x61C, 0x61C);
+                    hidden.add(0x180E, 0x180E);
+                    hidden.add(0x2066, 0x2069);
+                    hidden.normalize();
+                    s = gc_set(kMaskL | kMaskN | kMaskP | kMaskS | gc_bit(Mn) | gc_bit(Mc) | gc_bit(Me) | gc_bit(Cf));
+                    s = s.minus(hidden);
+                    if (name == "print") s.add(gc_set(gc_bit(Zs)));
+                } else if (name == "punct") {   // P, and the S characters below 128
+                    s = gc_set(kMaskP);
+                    CharSet sym = gc_set(kMaskS), low;
+                    low.add(0, 0x7F);
+                    s.add(sym.intersected(low));
+                }
                 else throw Invalid{"unknown POSIX class name"};
                 if ((name == "lower" || name == "upper") && f.caseless) throw Unsupported{"(?i) with [:lower:] / [:upper:]"};
+                s.normalize();
                 props.add(neg ? s.negated() : s);
                 after_class_item = true;
                 continue;
@@ -542,25 +604,131 @@ private:
         return false;
     }
 
+    // `node` as a sequence of character sets (a literal string, classes, counted repeats of those): the only thing it can match is one
+    // character of each, in order.
+    bool fixed_sets(int node, std::vector<CharSet>& out) const {
+        const Node& n = nodes_[size_t(node)];
+        switch (n.kind) {
+            case kEmpty: return true;
+            case kSet: out.push_back(n.set); return true;
+            case kCat:
+                for (int k : n.kids)
+                    if (!fixed_sets(k, out)) return false;
+                return true;
+            case kRepeat:
+                if (n.min != n.max || n.min > 64) return false;
+                for (int k = 0; k < n.min; ++k)
+                    if (!fixed_sets(n.kids[0], out)) return false;
+                return true;
+            default: return false;
+        }
+    }
+    // One way to match at most (no alternative to fall back on inside): sets, assertions, look-arounds, counted repeats and sequences of those.
+    bool single_path(int node) const {
+        const Node& n = nodes_[size_t(node)];
+        switch (n.kind) {
+            case kEmpty: case kSet: case kAssert: case kLookNode: case kAtomic: return true;
+            case kCat:
+                for (int k : n.kids)
+                    if (!single_path(k)) return false;
+                return true;
+            case kRepeat: return n.min == n.max && single_path(n.kids[0]);
+            default: return false;
+        }
+    }
+    int look_node(bool neg, int body) {
+        CharSet s;
+        if (single_char_set(body, s)) return assert_node(kAhead, neg, s);
+        Node n;
+        n.kind = kLookNode;
+        n.aneg = neg;
+        n.kids = {body};
+        return add(std::move(n));
+    }
+    // (?>X): X matched the FIRST way its alternatives and repeats allow (in PCRE2's order) and never re-entered -- rewritten into plain
+    // syntax where that first way can be told by looking ahead:
+    //   one way to match at most            X itself
+    //   A1|A2|...                           (?>A1) | (?!A1)(?>A2) | (?!A1)(?!A2)(?>A3) ...  (A2 is tried only where A1 does not match at all)
+    //   F{n,m} greedy, F a fixed sequence   F{n,m} whose every early way out is taken only where no further F follows (the possessive form)
+    //   F{n,m}? lazy                        F{n}
+    //   P X, P with one way to match        P (?>X)
+    // Anything else (a repeat in front of something that could make it give characters back inside the group) stays a group of its own kind,
+    // kAtomic, for the table builder: the threads inside it are told apart by the entry they came from, and the first of an entry's threads
+    // to leave the group ends the ones behind it (compile_regex).
+    int atomize(int node) {
+        if (single_path(node)) return node;
+        const Node n = nodes_[size_t(node)];   // (copy: nodes_ grows below)
+        if (n.kind == kAlt) {
+            Node alt;
+            alt.kind = kAlt;
+            for (size_t k = 0; k < n.kids.size(); ++k) {
+                const int body = atomize(n.kids[k]);
+                if (k == 0) { alt.kids.push_back(body); continue; }
+                Node cat;
+                cat.kind = kCat;
+                for (size_t j = 0; j < k; ++j) cat.kids.push_back(look_node(true, n.kids[j]));
+                cat.kids.push_back(body);
+                alt.kids.push_back(add(std::move(cat)));
+            }
+            return add(std::move(alt));
+        }
+        if (n.kind == kRepeat) {
+            std::vector<CharSet> seq;
+            if (!fixed_sets(n.kids[0], seq) || seq.empty()) return atomic_node(node);
+            Node r = n;
+            if (n.mode == 1) r.max = r.min;
+            else r.mode = 2;
+            return add(std::move(r));
+        }
+        if (n.kind == kCat) {
+            for (size_t k = 0; k + 1 < n.kids.size(); ++k)
+                if (!single_path(n.kids[k])) return atomic_node(node);
+            Node cat = n;
+            cat.kids.back() = atomize(n.kids.back());
+            return add(std::move(cat));
+        }
+        return atomic_node(node);
+    }
+    int atomic_node(int body) {
+        Node n;
+        n.kind = kAtomic;
+        n.kids = {body};
+        return add(std::move(n));
+    }
+
     int parse_group(Flags& outer) {  // pos_ behind '('
         Flags f = outer;
         if (eat('?')) {
-            if (eat(':')) {
+            if (eat(':') || eat('|')) {   // (?|...): the branches number their groups alike -- nothing here looks at group numbers
             } else if (peek() == '=' || peek() == '!') {
                 const bool neg = p_[pos_++] == '!';
                 const int body = parse_alt(f);
                 if (!eat(')')) throw Invalid{"missing closing parenthesis"};
-                CharSet s;
-                if (!single_char_set(body, s)) throw Unsupported{"look-ahead on more than one character"};
-                return assert_node(kAhead, neg, s);
+                return look_node(neg, body);   // one character: an assertion on the next class; anything longer: decided while the characters go by
             } else if (peek() == '<' && (peek(1) == '=' || peek(1) == '!')) {
                 const bool neg = peek(1) == '!';
                 pos_ += 2;
                 const int body = parse_alt(f);
                 if (!eat(')')) throw Invalid{"missing closing parenthesis"};
                 CharSet s;
-                if (!single_char_set(body, s)) throw Unsupported{"look-behind on more than one character"};
-                return assert_node(kBehind, neg, s);
+                if (single_char_set(body, s)) return assert_node(kBehind, neg, s);
+                // alternatives of fixed sequences of sets, kRegexMaxBehind characters at most (PCRE2 wants every alternative of a
+                // fixed length; anything else here is its error 125 or outside this subset)
+                std::vector<std::vector<CharSet>> alts;
+                const Node& b = nodes_[size_t(body)];
+                for (int k : b.kind == kAlt ? b.kids : std::vector<int>{body}) {
+                    std::vector<CharSet> seq;
+                    if (!fixed_sets(k, seq) || seq.empty()) throw Unsupported{"look-behind on something other than fixed sequences of characters"};
+                    if (seq.size() > size_t(kRegexMaxBehind)) throw Unsupported{"look-behind over more than 8 characters"};
+                    alts.push_back(std::move(seq));
+                }
+                const int a = assert_node(kBehind, neg);
+                nodes_[size_t(a)].behind = std::move(alts);
+                return a;
+            } else if (eat('>')) {   // atomic group
+                const int body = parse_alt(f);
+                if (!eat(')')) throw Invalid{"missing closing parenthesis"};
+                return atomize(body);
             } else if (peek() == '<' || looking_at("P<") || peek() == '\'') {  // named capture: a plain group here
                 const uint32_t close = peek() == '\'' ? '\'' : '>';
                 if (looking_at("P<")) pos_ += 2;
@@ -588,6 +756,7 @@ private:
                     else if (c == 'i') g.caseless = on;
                     else if (c == 's') g.dotall = on;
                     else if (c == 'm') g.multiline = on;
+                    else if (c == 'x') g.extended = on;
                     // a letter PCRE2 has no option for is its error 111; anything else here -- `>` `|` `(` `R` digits `&` `#` `C` `+` ...: atomic
                     // groups, branch reset, conditions, recursion, comments, callouts -- is syntax it knows and this subset does not cover
                     else if (((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) && !std::strchr("imnsxJUarRPC", int(c))) throw Invalid{"unrecognized character after (? or (?-"};
@@ -682,7 +851,20 @@ private:
                     case 'Z': ++pos_; return assert_node(kEotNl);
                     case 'b': ++pos_; return assert_node(kWordB);
                     case 'B': ++pos_; return assert_node(kNotWordB);
-                    case 'G': case 'K': case 'R': case 'X': case 'C': case 'g': case 'k':
+                    case 'R': {   // (?>\r\n|\n|\x0b|\f|\r|\x85|\x{2028}|\x{2029}): any Unicode newline sequence, \r\n never split
+                        ++pos_;
+                        Node crlf;
+                        crlf.kind = kCat;
+                        CharSet cr, lf;
+                        cr.add('\r', '\r');
+                        lf.add('\n', '\n');
+                        crlf.kids = {set_node(cr), set_node(lf)};
+                        Node alt;
+                        alt.kind = kAlt;
+                        alt.kids = {add(std::move(crlf)), set_node(vspace_set())};
+                        return atomize(add(std::move(alt)));
+                    }
+                    case 'G': case 'K': case 'X': case 'C': case 'g': case 'k':
                         throw Unsupported{std::string("escape \\") + char(peek())};
                     case 'L': case 'l': case 'U': case 'u': case 'F':
                         throw Invalid{"PCRE2 does not support \\F, \\L, \\l, \\U, or \\u"};
@@ -700,19 +882,22 @@ private:
 };
 
 // ---------------------------------------------------------------------------------------------- backtracking automaton
-enum Op : uint8_t { kChar, kSplit, kJmp, kAssertOp, kMatch };
+enum Op : uint8_t { kChar, kSplit, kJmp, kAssertOp, kMatch, kLook, kLookAccept, kAtomEnter, kAtomExit };
 struct Inst {
     Op op;
-    int x = 0, y = 0;  // kChar: x = set id, y = next; kSplit: x preferred, y other; kJmp: x; kAssertOp: x = assert id, y = next
+    int x = 0, y = 0;  // kChar: x = set id, y = next; kSplit: x preferred, y other; kJmp: x; kAssertOp: x = assert id, y = next;
+                       // kLook: x = entry of the looked-for X (which ends in kLookAccept), y = next; kAtomEnter / kAtomExit: x = next
     // kSplit at the head of a greedy / possessive unbounded repeat (x = one more round of the body, y = the way out).  When
     // the body gets back here without having consumed a character, PCRE2 ends the repeat THERE -- what follows the repeat is
     // tried before the body's remaining alternatives ((a??)+ on "a" matches the empty string, not "a").
     bool loop = false;
+    bool neg = false;   // kLook
 };
 struct AssertInfo {
     int kind;
     bool neg;
     int set;  // index into sets, or -1
+    std::vector<std::vector<int>> behind;   // kBehind over sequences: per alternative the set ids, first character first
 };
 
 struct Builder {
@@ -733,8 +918,15 @@ struct Builder {
         return int(prog.size()) - 1;
     }
     int emit_assert(int kind, bool neg, const CharSet* s, int next) {
-        asserts.push_back(AssertInfo{kind, neg, s ? set_id(*s) : -1});
+        asserts.push_back(AssertInfo{kind, neg, s ? set_id(*s) : -1, {}});
         return emit(Inst{kAssertOp, int(asserts.size()) - 1, next});
+    }
+    int emit_look(bool neg, int body, int next) {
+        const int accept = emit(Inst{kLookAccept});
+        const int entry = gen(body, accept);
+        Inst in{kLook, entry, next};
+        in.neg = neg;
+        return emit(in);
     }
     // Code that matches node `n` and continues at `next`; returns its entry.
     int gen(int n, int next) {
@@ -754,14 +946,32 @@ struct Builder {
                 for (size_t k = entries.size() - 1; k-- > 0;) e = emit(Inst{kSplit, entries[k], e});
                 return e;
             }
-            case kAssert: return emit_assert(nd.akind, nd.aneg, (nd.akind == kAhead || nd.akind == kBehind) ? &nd.set : nullptr, next);
+            case kAssert: {
+                if (nd.akind == kBehind && !nd.behind.empty()) {
+                    AssertInfo a{kBehind, nd.aneg, -1, {}};
+                    for (const auto& seq : nd.behind) {
+                        a.behind.emplace_back();
+                        for (const CharSet& cs : seq) a.behind.back().push_back(set_id(cs));
+                    }
+                    asserts.push_back(std::move(a));
+                    return emit(Inst{kAssertOp, int(asserts.size()) - 1, next});
+                }
+                return emit_assert(nd.akind, nd.aneg, (nd.akind == kAhead || nd.akind == kBehind) ? &nd.set : nullptr, next);
+            }
+            case kLookNode: return emit_look(nd.aneg, nd.kids[0], next);
+            case kAtomic: {
+                const int leave = emit(Inst{kAtomExit, next, 0});
+                const int body = gen(nd.kids[0], leave);
+                return emit(Inst{kAtomEnter, body, 0});
+            }
             case kRepeat: {
                 const int child = nd.kids[0];
                 // where the "no further repetition" edge goes: straight on, or (possessive X: never give a character
                 // back) through "the next character is not an X"
                 auto skip_target = [&](int to) {
                     if (nd.mode != 2) return to;
-                    return emit_assert(kAhead, true, &nodes[size_t(child)].set, to);
+                    if (nodes[size_t(child)].kind == kSet) return emit_assert(kAhead, true, &nodes[size_t(child)].set, to);
+                    return emit_look(true, child, to);   // (a fixed sequence of sets: Parser::atomize)
                 };
                 auto split = [&](int body, int skip) {
                     return nd.mode == 1 ? emit(Inst{kSplit, skip, body}) : emit(Inst{kSplit, body, skip});
@@ -798,17 +1008,34 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
         const int match_pc = b.emit(Inst{kMatch});
         const int entry = b.gen(root, match_pc);
 
-        // ---- which contexts the assertions look at
+        // ---- what the assertions look at behind a position: sequences of sets (one set long for `\b`, one-character look-behind and
+        // (?m)^; up to kRegexMaxBehind for (?<=abc)), first character first
         bool uses_bot = false, uses_word = false, uses_final_nl = false;
-        std::vector<int> behind_sets;
-        for (const AssertInfo& a : b.asserts) {
-            if (a.kind == kBot) uses_bot = true;
+        std::vector<std::vector<int>> seqs;
+        auto seq_id = [&](const std::vector<int>& q) {
+            for (size_t i = 0; i < seqs.size(); ++i)
+                if (seqs[i] == q) return int(i);
+            seqs.push_back(q);
+            return int(seqs.size()) - 1;
+        };
+        int word_set_id = -1, word_seq = -1;
+        for (const AssertInfo& a : b.asserts)
             if (a.kind == kWordB || a.kind == kNotWordB) uses_word = true;
-            if (a.kind == kEotNl) uses_final_nl = true;
-            if (a.kind == kBehind) behind_sets.push_back(a.set);
+        if (uses_word) {
+            word_set_id = b.set_id(word_set());
+            word_seq = seq_id({word_set_id});
         }
-        int word_set_id = -1;
-        if (uses_word) word_set_id = b.set_id(word_set());
+        std::vector<std::vector<int>> seqs_of_assert(b.asserts.size());
+        for (size_t i = 0; i < b.asserts.size(); ++i) {
+            const AssertInfo& a = b.asserts[i];
+            if (a.kind == kBot) uses_bot = true;
+            if (a.kind == kEotNl) uses_final_nl = true;
+            if (a.kind != kBehind) continue;
+            if (a.behind.empty()) seqs_of_assert[i].push_back(seq_id({a.set}));
+            for (const auto& q : a.behind) seqs_of_assert[i].push_back(seq_id(q));
+        }
+        int behind_chars = 0;
+        for (const auto& q : seqs) behind_chars = std::max(behind_chars, int(q.size()));
 
         // ---- partition of the code points: signature = membership in every set
         const size_t n_sets = b.sets.size();
@@ -841,38 +1068,138 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
         const int nl_class = cls['\n'];
         auto sym_class = [&](int sym) { return sym == sym_final_nl ? nl_class : (sym < n_classes ? sym : -1); };
 
-        // ---- "previous character" contexts: 0 = start of subject, else 1 + signature over the sets looked at behind
-        std::vector<int> ctx_sets = behind_sets;
-        if (uses_word) ctx_sets.push_back(word_set_id);
-        std::sort(ctx_sets.begin(), ctx_sets.end());
-        ctx_sets.erase(std::unique(ctx_sets.begin(), ctx_sets.end()), ctx_sets.end());
-        const bool track_ctx = uses_bot || !ctx_sets.empty();
-        std::vector<uint8_t> ctx_of_class(size_t(n_classes), 0);
-        std::vector<std::vector<bool>> ctx_sig{std::vector<bool>(ctx_sets.size(), false)};  // ctx 0: nothing behind
+        // ---- contexts: a small automaton over the classes that knows, for every sequence, which of its prefixes the text behind the
+        // position ends in (bit l-1 of its mask: the last l characters are the sequence's first l).  Context 0 = start of the subject,
+        // context 1 = nothing known to match (also where the kernels start when they re-read the kRegexMaxBehind characters behind a
+        // position in the middle of a string: a prefix of l characters depends on the last l characters only).
+        const bool track_ctx = uses_bot || !seqs.empty();
+        std::vector<std::vector<uint16_t>> ctx_masks{std::vector<uint16_t>(seqs.size(), 0)};
+        std::vector<uint8_t> ctx_next;
         int n_ctx = 1;
+        if (!track_ctx) ctx_next.assign(size_t(n_classes), 0);
         if (track_ctx) {
-            std::map<std::vector<bool>, int> ids;
-            for (int c = 0; c < n_classes; ++c) {
-                std::vector<bool> sig(ctx_sets.size());
-                for (size_t k = 0; k < ctx_sets.size(); ++k) sig[k] = sig_of_class[size_t(c)][size_t(ctx_sets[k])];
-                auto it = ids.find(sig);
-                if (it == ids.end()) {
-                    if (n_ctx >= kRegexMaxCtx) throw Unsupported{"too many look-behind contexts"};
-                    it = ids.emplace(sig, n_ctx++).first;
-                    ctx_sig.push_back(sig);
+            std::map<std::vector<uint16_t>, int> ids;
+            ctx_masks.push_back(ctx_masks[0]);
+            ids.emplace(ctx_masks[1], 1);
+            n_ctx = 2;
+            for (int x = 0; x < n_ctx; ++x) {
+                ctx_next.resize(size_t(x + 1) * size_t(n_classes));
+                for (int c = 0; c < n_classes; ++c) {
+                    std::vector<uint16_t> m(seqs.size());
+                    for (size_t j = 0; j < seqs.size(); ++j) {
+                        uint16_t fits = 0;
+                        for (size_t l = 0; l < seqs[j].size(); ++l)
+                            if (sig_of_class[size_t(c)][size_t(seqs[j][l])]) fits |= uint16_t(1u << l);
+                        m[j] = uint16_t(((ctx_masks[size_t(x)][j] << 1) | 1u) & fits);
+                    }
+                    auto it = ids.find(m);
+                    if (it == ids.end()) {
+                        if (n_ctx >= kRegexMaxCtx) throw Unsupported{"too many look-behind contexts"};
+                        it = ids.emplace(m, n_ctx++).first;
+                        ctx_masks.push_back(m);
+                    }
+                    ctx_next[size_t(x) * size_t(n_classes) + size_t(c)] = uint8_t(it->second);
                 }
-                ctx_of_class[size_t(c)] = uint8_t(it->second);
             }
         }
-        auto ctx_has = [&](int ctx, int set) {
-            if (ctx == 0) return false;
-            for (size_t k = 0; k < ctx_sets.size(); ++k)
-                if (ctx_sets[k] == set) return bool(ctx_sig[size_t(ctx)][k]);
+        auto ctx_ends_in = [&](int ctx, int seq) { return ((ctx_masks[size_t(ctx)][size_t(seq)] >> (seqs[size_t(seq)].size() - 1)) & 1u) != 0; };
+        auto assert_ok = [&](int id, int ctx, int sym, int c) {
+            const AssertInfo& a = b.asserts[size_t(id)];
+            switch (a.kind) {
+                case kBot: return ctx == 0;
+                case kEot: return sym == sym_eot;
+                case kEotNl: return sym == sym_eot || sym == sym_final_nl;
+                case kAhead: return (c >= 0 && sig_of_class[size_t(c)][size_t(a.set)]) != a.neg;
+                case kBehind: {
+                    bool any = false;
+                    for (int q : seqs_of_assert[size_t(id)]) any = any || ctx_ends_in(ctx, q);
+                    return any != a.neg;
+                }
+                case kWordB:
+                case kNotWordB: {
+                    const bool wp = ctx_ends_in(ctx, word_seq);
+                    const bool wn = c >= 0 && sig_of_class[size_t(c)][size_t(word_set_id)];
+                    return (wp != wn) == (a.kind == kWordB);
+                }
+            }
             return false;
         };
 
-        // ---- subset construction over ordered position lists
-        using Key = std::pair<int, std::vector<int>>;  // (context, positions in priority order)
+        // ---- subset construction over ordered lists of threads.  A thread is a position of the backtracking automaton; behind a
+        // look-ahead over more than one character it carries that look-ahead as a CONDITION -- the set of positions of the looked-for
+        // X that the characters read since have led to -- which travels with it, character by character, until X has matched (positive:
+        // the condition is dropped; negative: the thread dies) or cannot any more (the other way round).  A thread that reaches the
+        // pattern's end while it still carries conditions is a TENTATIVE match: it stays in the list, ages by one per character, cuts
+        // nothing yet; when its last condition is dropped the transition reports the match with that age as the delay (the match ended
+        // `age` characters back) and everything of lower priority is cut, as for an immediate match.
+        //   An atomic group the parser could not rewrite (kAtomEnter .. kAtomExit) gives every thread that enters it a TAG of its own,
+        // inherited by the threads that come of it.  When one of them leaves the group, the threads with the same tag BEHIND it in the
+        // list (the ways PCRE2 would only try by backtracking into the group) end; the ones in FRONT of it might still leave the group
+        // later, and then this one must not have been: it carries them as a negative condition -- "none of these positions reaches the
+        // group's exit".
+        struct Cond {
+            bool neg;
+            int accept;             // -1: the looked-for X ends in its own kLookAccept; else the kAtomExit that counts
+            std::vector<int> pcs;   // sorted
+            bool operator<(const Cond& o) const { return neg != o.neg ? neg < o.neg : (accept != o.accept ? accept < o.accept : pcs < o.pcs); }
+            bool operator==(const Cond& o) const { return neg == o.neg && accept == o.accept && pcs == o.pcs; }
+        };
+        using Conds = std::vector<Cond>;   // sorted, no duplicates
+        struct Item {
+            int pc;    // >= 0: a thread about to run from this position; -1: a tentative match
+            int age;   // tentative match: characters read since its end
+            Conds conds;
+            std::vector<int> tags;   // the atomic groups the thread is inside, outermost first (numbers of no meaning beyond "same entry")
+            bool operator==(const Item& o) const { return pc == o.pc && age == o.age && conds == o.conds && tags == o.tags; }
+        };
+        // a state's key: the context and the items flattened (a plain thread is its position alone, as before look-aheads had conditions)
+        using Key = std::pair<int, std::vector<int>>;
+        auto flatten = [](const std::vector<Item>& items) {
+            std::vector<int> v;
+            std::vector<int> seen_tags;   // tags renumbered in the order they appear: equal states get equal keys
+            for (const Item& it : items) {
+                if (it.pc >= 0 && it.conds.empty() && it.tags.empty()) { v.push_back(it.pc); continue; }
+                v.push_back(-1);
+                v.push_back(it.pc);
+                v.push_back(it.age);
+                v.push_back(int(it.conds.size()));
+                for (const Cond& cd : it.conds) {
+                    v.push_back(cd.neg ? 1 : 0);
+                    v.push_back(cd.accept);
+                    v.push_back(int(cd.pcs.size()));
+                    v.insert(v.end(), cd.pcs.begin(), cd.pcs.end());
+                }
+                v.push_back(int(it.tags.size()));
+                for (int t : it.tags) {
+                    size_t k = 0;
+                    while (k < seen_tags.size() && seen_tags[k] != t) ++k;
+                    if (k == seen_tags.size()) seen_tags.push_back(t);
+                    v.push_back(int(k));
+                }
+            }
+            return v;
+        };
+        auto unflatten = [](const std::vector<int>& v) {
+            std::vector<Item> items;
+            for (size_t i = 0; i < v.size();) {
+                if (v[i] >= 0) { items.push_back(Item{v[i++], 0, {}, {}}); continue; }
+                Item it{v[i + 1], v[i + 2], {}, {}};
+                const int n = v[i + 3];
+                i += 4;
+                for (int k = 0; k < n; ++k) {
+                    Cond cd{v[i] != 0, v[i + 1], {}};
+                    const int m = v[i + 2];
+                    cd.pcs.assign(v.begin() + long(i) + 3, v.begin() + long(i) + 3 + m);
+                    i += 3 + size_t(m);
+                    it.conds.push_back(std::move(cd));
+                }
+                const int nt = v[i++];
+                it.tags.assign(v.begin() + long(i), v.begin() + long(i) + nt);
+                i += size_t(nt);
+                items.push_back(std::move(it));
+            }
+            return items;
+        };
         std::map<Key, int> ids;
         std::vector<Key> states;
         states.push_back(Key{0, {}});  // state 0: dead
@@ -891,90 +1218,283 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
         for (int c = 0; c < n_ctx; ++c) out.start[c] = uint16_t(intern(Key{c, {entry}}));
         std::vector<uint16_t> trans;
         std::vector<uint8_t> open(b.prog.size());
-        std::set<std::pair<int, uint64_t>> visited;
+        std::set<std::tuple<int, uint64_t, int, int>> visited;
         long long closure_steps = 0;
         constexpr long long kMaxClosureSteps = 50'000'000;
-        std::vector<int> pending;
+        auto count_step = [&]() {
+            if (++closure_steps > kMaxClosureSteps) throw Unsupported{"pattern too intricate for the table builder"};
+        };
+
+        // The looked-for X from the raw positions `raw`, at a position whose context and next symbol are known: has it matched
+        // (`accept`), and which character positions wait for the next character (`chars`, sorted).
+        auto look_close = [&](const std::vector<int>& raw, int accept_pc, int ctx, int sym, int c, bool& accept, std::vector<int>& chars) {
+            accept = false;
+            chars.clear();
+            std::vector<int> st(raw.rbegin(), raw.rend());
+            std::set<int> seen;
+            while (!st.empty()) {
+                const int pc = st.back();
+                st.pop_back();
+                if (!seen.insert(pc).second) continue;
+                count_step();
+                const Inst& in = b.prog[size_t(pc)];
+                switch (in.op) {
+                    case kJmp: st.push_back(in.x); break;
+                    case kSplit: st.push_back(in.y); st.push_back(in.x); break;
+                    case kChar: chars.push_back(pc); break;
+                    case kLookAccept: accept = true; break;
+                    case kAssertOp: if (assert_ok(in.x, ctx, sym, c)) st.push_back(in.y); break;
+                    case kLook: throw Unsupported{"look-around inside a look-ahead of more than one character, or inside an atomic group that can give characters back"};
+                    case kAtomExit:
+                        if (pc == accept_pc) { accept = true; break; }
+                        [[fallthrough]];
+                    case kAtomEnter: throw Unsupported{"atomic group that can give characters back, inside a look-ahead or another such group"};
+                    case kMatch: break;
+                }
+            }
+            std::sort(chars.begin(), chars.end());
+        };
+        // ... from raw positions, before the next symbol is known: reached the end through jumps alone?
+        auto look_done = [&](const std::vector<int>& raw, int accept_pc) {
+            std::vector<int> st(raw);
+            std::set<int> seen;
+            while (!st.empty()) {
+                const int pc = st.back();
+                st.pop_back();
+                if (!seen.insert(pc).second) continue;
+                const Inst& in = b.prog[size_t(pc)];
+                if (in.op == kLookAccept || pc == accept_pc) return true;
+                if (in.op == kJmp) st.push_back(in.x);
+                if (in.op == kSplit) { st.push_back(in.y); st.push_back(in.x); }
+            }
+            return false;
+        };
+        // conditions at a position (context, next symbol): false = the thread that carries them dies
+        auto close_conds = [&](const Conds& in, int ctx, int sym, int c, Conds& res) {
+            res.clear();
+            bool accept = false;
+            std::vector<int> chars;
+            for (const Cond& cd : in) {
+                look_close(cd.pcs, cd.accept, ctx, sym, c, accept, chars);
+                if (accept) {
+                    if (cd.neg) return false;
+                } else if (chars.empty() || c < 0) {
+                    if (!cd.neg) return false;
+                } else {
+                    res.push_back(Cond{cd.neg, cd.accept, chars});
+                }
+            }
+            std::sort(res.begin(), res.end());
+            res.erase(std::unique(res.begin(), res.end()), res.end());
+            return true;
+        };
+        // ... over the character of class c
+        auto step_conds = [&](const Conds& in, int c, Conds& res) {
+            res.clear();
+            for (const Cond& cd : in) {
+                std::vector<int> raw;
+                for (int pc : cd.pcs) {
+                    const Inst& q = b.prog[size_t(pc)];
+                    if (sig_of_class[size_t(c)][size_t(q.x)]) raw.push_back(q.y);
+                }
+                std::sort(raw.begin(), raw.end());
+                raw.erase(std::unique(raw.begin(), raw.end()), raw.end());
+                if (raw.empty()) {
+                    if (!cd.neg) return false;
+                } else if (look_done(raw, cd.accept)) {
+                    if (cd.neg) return false;
+                } else {
+                    res.push_back(Cond{cd.neg, cd.accept, std::move(raw)});
+                }
+            }
+            std::sort(res.begin(), res.end());
+            res.erase(std::unique(res.begin(), res.end()), res.end());
+            return true;
+        };
+
+        struct Entry { int pc, cid, age, tid; };   // pc == INT_MIN: a tentative match of the state; pc < 0 otherwise: "the body of repeat -pc - 1 has been walked"
+        struct Found { int pc, cid, age, tid; };   // pc >= 0: a thread waiting at a character position; -1: a tentative match
         for (size_t s = 0; s < states.size(); ++s) {
             trans.resize((s + 1) * size_t(n_syms), 0);
             if (s == 0) continue;
-            const Key st = states[s];  // copy: `states` grows below
+            const int st_ctx = states[s].first;
+            const std::vector<Item> st_items = unflatten(states[s].second);
             for (int sym = 0; sym < n_syms; ++sym) {
                 const int c = sym_class(sym);
-                pending.clear();
+                std::vector<Conds> cl{Conds{}};   // the condition lists at hand in this transition; 0 = none
+                auto cond_id = [&](const Conds& x) {
+                    for (size_t i = 0; i < cl.size(); ++i)
+                        if (cl[i] == x) return int(i);
+                    cl.push_back(x);
+                    return int(cl.size()) - 1;
+                };
+                std::vector<std::vector<int>> tl{std::vector<int>{}};   // ... and the tag lists; 0 = outside every atomic group
+                auto tags_id = [&](const std::vector<int>& x) {
+                    for (size_t i = 0; i < tl.size(); ++i)
+                        if (tl[i] == x) return int(i);
+                    tl.push_back(x);
+                    return int(tl.size()) - 1;
+                };
+                int fresh_tag = 0;
+                for (const Item& it : st_items)
+                    for (int t : it.tags) fresh_tag = std::max(fresh_tag, t + 1);
+                std::vector<int> ended_tags;   // entries of atomic groups one of whose threads has left the group in this transition
+                auto ended = [&](int tid) {
+                    for (int t : tl[size_t(tid)])
+                        if (std::find(ended_tags.begin(), ended_tags.end(), t) != ended_tags.end()) return true;
+                    return false;
+                };
                 bool matched = false;
-                // the closure at this position: previous character = st.first, next symbol = sym
-                std::vector<int> stack;
-                for (size_t k = st.second.size(); k-- > 0;) stack.push_back(st.second[k]);
+                int delay = 0;
+                std::vector<Found> found;
+                auto have = [&](int pc, int cid, int age, int tid) {
+                    for (const Found& f : found)
+                        if (f.pc == pc && f.age == age && f.tid == tid && (f.cid == cid || (pc >= 0 && f.cid == 0))) return true;   // (the same position without conditions, earlier: all this one could do)
+                    return false;
+                };
+                // the closure at this position: context st_ctx behind it, symbol sym next
+                std::vector<Entry> stack;
+                {
+                    std::vector<Entry> first;
+                    Conds res;
+                    for (const Item& it : st_items) {
+                        if (!close_conds(it.conds, st_ctx, sym, c, res)) continue;
+                        first.push_back(Entry{it.pc >= 0 ? it.pc : INT_MIN, cond_id(res), it.age, tags_id(it.tags)});
+                    }
+                    stack.assign(first.rbegin(), first.rend());
+                }
                 std::fill(open.begin(), open.end(), 0);
                 visited.clear();
                 uint64_t open_sig = 0;  // which repeats are open on the way to the node at hand (order-independent sum)
                 auto sig_of = [](int loop_pc) { return (uint64_t(loop_pc) + 1) * 0x9E3779B97F4A7C15ull; };
                 while (!stack.empty() && !matched) {
-                    const int pc = stack.back();
+                    const Entry e = stack.back();
                     stack.pop_back();
+                    const int pc = e.pc;
+                    if (pc == INT_MIN) {  // a tentative match from the characters before
+                        if (cl[size_t(e.cid)].empty()) {
+                            matched = true;
+                            delay = e.age;
+                        } else if (!have(-1, e.cid, e.age, 0)) {
+                            found.push_back(Found{-1, e.cid, e.age, 0});
+                        }
+                        continue;
+                    }
                     if (pc < 0) {  // the body of repeat -pc - 1 has been walked
                         open[size_t(-pc - 1)] = 0;
                         open_sig -= sig_of(-pc - 1);
                         continue;
                     }
+                    if (ended(e.tid)) continue;   // a way into an atomic group that a thread in front of this one has left
                     if (open[size_t(pc)]) {  // an empty round of an open repeat: PCRE2 leaves the repeat here
-                        stack.push_back(b.prog[size_t(pc)].y);
+                        stack.push_back(Entry{b.prog[size_t(pc)].y, e.cid, 0, e.tid});
                         continue;
                     }
-                    // A node reached again is the same thread only if the same repeats are open: what follows an empty round
-                    // depends on them.  (Character threads are told apart by `pending` below: the first one wins.)
-                    if (!visited.insert({pc, open_sig}).second) continue;
-                    if (++closure_steps > kMaxClosureSteps) throw Unsupported{"pattern too intricate for the table builder"};
+                    // A node reached again is the same thread only if the same repeats are open (what follows an empty round
+                    // depends on them) and it carries the same conditions.  (Character threads are told apart by `found` below: the first one wins.)
+                    if (!visited.insert(std::make_tuple(pc, open_sig, e.cid, e.tid)).second) continue;
+                    count_step();
                     const Inst& in = b.prog[size_t(pc)];
                     switch (in.op) {
-                        case kJmp: stack.push_back(in.x); break;
+                        case kJmp: stack.push_back(Entry{in.x, e.cid, 0, e.tid}); break;
                         case kSplit:
-                            stack.push_back(in.y);
+                            stack.push_back(Entry{in.y, e.cid, 0, e.tid});
                             if (in.loop) {
-                                stack.push_back(-pc - 1);
+                                stack.push_back(Entry{-pc - 1, 0, 0, 0});
                                 open[size_t(pc)] = 1;
                                 open_sig += sig_of(pc);
                             }
-                            stack.push_back(in.x);
+                            stack.push_back(Entry{in.x, e.cid, 0, e.tid});
                             break;
                         case kChar:
-                            if (std::find(pending.begin(), pending.end(), pc) == pending.end()) pending.push_back(pc);
+                            if (!have(pc, e.cid, 0, e.tid)) found.push_back(Found{pc, e.cid, 0, e.tid});
                             break;
-                        case kMatch: matched = true; break;  // everything of lower priority is cut
-                        case kAssertOp: {
-                            const AssertInfo& a = b.asserts[size_t(in.x)];
-                            bool ok = false;
-                            switch (a.kind) {
-                                case kBot: ok = st.first == 0; break;
-                                case kEot: ok = sym == sym_eot; break;
-                                case kEotNl: ok = sym == sym_eot || sym == sym_final_nl; break;
-                                case kAhead: ok = (c >= 0 && sig_of_class[size_t(c)][size_t(a.set)]) != a.neg; break;
-                                case kBehind: ok = ctx_has(st.first, a.set) != a.neg; break;
-                                case kWordB:
-                                case kNotWordB: {
-                                    const bool wp = ctx_has(st.first, word_set_id);
-                                    const bool wn = c >= 0 && sig_of_class[size_t(c)][size_t(word_set_id)];
-                                    ok = (wp != wn) == (a.kind == kWordB);
-                                    break;
-                                }
-                            }
-                            if (ok) stack.push_back(in.y);
+                        case kMatch:
+                            if (cl[size_t(e.cid)].empty()) matched = true;   // everything of lower priority is cut
+                            else if (!have(-1, e.cid, 0, 0)) found.push_back(Found{-1, e.cid, 0, 0});
+                            break;
+                        case kAssertOp:
+                            if (assert_ok(in.x, st_ctx, sym, c)) stack.push_back(Entry{in.y, e.cid, 0, e.tid});
+                            break;
+                        case kAtomEnter: {
+                            std::vector<int> tags = tl[size_t(e.tid)];
+                            tags.push_back(fresh_tag++);
+                            stack.push_back(Entry{in.x, e.cid, 0, tags_id(tags)});
                             break;
                         }
+                        case kAtomExit: {
+                            std::vector<int> tags = tl[size_t(e.tid)];
+                            const int tag = tags.back();
+                            tags.pop_back();
+                            // the threads of the same entry in front of this one, still inside the group: this exit holds only if none of them gets here
+                            std::vector<int> ahead;
+                            for (const Found& f : found) {
+                                const std::vector<int>& ft = tl[size_t(f.tid)];
+                                if (std::find(ft.begin(), ft.end(), tag) == ft.end()) continue;
+                                if (ft.back() != tag || f.cid != e.cid)
+                                    throw Unsupported{"atomic group that can give characters back, with a look-ahead or another such group inside it"};
+                                if (c >= 0 && sig_of_class[size_t(c)][size_t(b.prog[size_t(f.pc)].x)]) ahead.push_back(f.pc);   // (the others end at this character)
+                            }
+                            ended_tags.push_back(tag);   // ... and the ones behind it end here
+                            int cid = e.cid;
+                            if (!ahead.empty() && !tags.empty()) throw Unsupported{"atomic group that can give characters back, with a look-ahead or another such group inside it"};
+                            if (!ahead.empty()) {
+                                std::sort(ahead.begin(), ahead.end());
+                                ahead.erase(std::unique(ahead.begin(), ahead.end()), ahead.end());
+                                Conds with = cl[size_t(e.cid)];
+                                with.push_back(Cond{true, pc, ahead});
+                                std::sort(with.begin(), with.end());
+                                with.erase(std::unique(with.begin(), with.end()), with.end());
+                                cid = cond_id(with);
+                            }
+                            stack.push_back(Entry{in.x, cid, 0, tags_id(tags)});
+                            break;
+                        }
+                        case kLook: {
+                            bool accept = false;
+                            std::vector<int> chars;
+                            look_close({in.x}, -1, st_ctx, sym, c, accept, chars);
+                            if (accept) {
+                                if (!in.neg) stack.push_back(Entry{in.y, e.cid, 0, e.tid});
+                            } else if (chars.empty() || c < 0) {
+                                if (in.neg) stack.push_back(Entry{in.y, e.cid, 0, e.tid});
+                            } else {
+                                // (inside such an atomic group the thread would leave the group -- and end the ways behind it -- before the
+                                // look-ahead is decided)
+                                if (!tl[size_t(e.tid)].empty()) throw Unsupported{"atomic group that can give characters back, with a look-ahead or another such group inside it"};
+                                Conds with = cl[size_t(e.cid)];
+                                with.push_back(Cond{in.neg, -1, chars});
+                                std::sort(with.begin(), with.end());
+                                with.erase(std::unique(with.begin(), with.end()), with.end());
+                                stack.push_back(Entry{in.y, cond_id(with), 0, e.tid});
+                            }
+                            break;
+                        }
+                        case kLookAccept: break;
                     }
                 }
-                Key next{0, {}};
+                // ... and over the character: the threads whose set holds it move on, conditions and tentative matches with them
+                std::vector<Item> next;
                 if (c >= 0) {
-                    next.first = ctx_of_class[size_t(c)];
-                    for (int pc : pending) {
-                        const Inst& in = b.prog[size_t(pc)];
-                        if (sig_of_class[size_t(c)][size_t(in.x)] &&
-                            std::find(next.second.begin(), next.second.end(), in.y) == next.second.end())
-                            next.second.push_back(in.y);
+                    Conds res;
+                    for (const Found& f : found) {
+                        if (f.pc >= 0 && !sig_of_class[size_t(c)][size_t(b.prog[size_t(f.pc)].x)]) continue;
+                        if (!step_conds(cl[size_t(f.cid)], c, res)) continue;
+                        Item it{f.pc >= 0 ? b.prog[size_t(f.pc)].y : -1, f.pc >= 0 ? 0 : f.age + 1, res, tl[size_t(f.tid)]};
+                        if (f.pc < 0 && res.empty()) {   // decided by this very character: a match that ended f.age characters back
+                            matched = true;               // (of higher priority than one the closure found: that one came later in the list)
+                            delay = f.age;
+                            break;
+                        }
+                        if (it.age > kRegexMaxDelay) throw Unsupported{"a look-ahead that stays undecided for more than 7 characters behind the end of a match"};
+                        bool dup = false;
+                        for (const Item& o : next) dup = dup || o == it || (it.pc >= 0 && o.pc == it.pc && o.conds.empty() && o.tags == it.tags);
+                        if (!dup) next.push_back(std::move(it));
                     }
                 }
-                trans[s * size_t(n_syms) + size_t(sym)] = uint16_t(intern(std::move(next))) | (matched ? kRegexMatchBit : 0);
+                const int next_ctx = c >= 0 && track_ctx ? int(ctx_next[size_t(st_ctx) * size_t(n_classes) + size_t(c)]) : 0;
+                trans[s * size_t(n_syms) + size_t(sym)] =
+                    uint16_t(intern(Key{next_ctx, flatten(next)})) | (matched ? uint16_t(kRegexMatchBit | (delay << kRegexDelayShift)) : uint16_t(0));
             }
         }
         out.trans = std::move(trans);
@@ -984,7 +1504,8 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
         out.sym_eot = sym_eot;
         out.sym_final_nl = sym_final_nl;
         out.n_ctx = n_ctx;
-        out.ctx_of_class = std::move(ctx_of_class);
+        out.ctx_next = std::move(ctx_next);
+        out.behind_chars = behind_chars;
         out.can_match_empty = false;
         for (int c = 0; c < n_ctx; ++c)
             for (int sym = 0; sym < n_syms; ++sym)
@@ -1018,7 +1539,7 @@ int compile_regex(const std::string& pattern, RegexProgram& out, std::string& er
         out.n_syms = 2;
         out.n_states = 1;
         out.trans.assign(2, 0);
-        out.ctx_of_class.assign(1, 0);
+        out.ctx_next.assign(1, 0);
         out.cp_index.assign((size_t(kMaxCp) + 1) >> 7, 0);
         out.cp_blocks.assign(128, 0);
         return OVTK_OK;

@@ -18,8 +18,8 @@ struct RegexDev {
     const uint8_t* ascii_class;   // [128]
     const uint16_t* cp_index;     // [0x110000 >> 7]
     const uint8_t* cp_blocks;     // [n_blocks * 128]
-    const uint8_t* ctx_of_class;  // [n_classes]
-    int32_t n_syms, n_states, sym_eot, sym_final_nl, n_ctx;
+    const uint8_t* ctx_next;      // [n_ctx * n_classes]: the context automaton (RegexProgram::ctx_next)
+    int32_t n_syms, n_states, sym_eot, sym_final_nl, n_ctx, behind_chars;
     int32_t cp_blocks_bytes;      // size of cp_blocks
     uint16_t start[kRegexMaxCtx];
     int32_t mode;                 // 0 removed, 1 isolated, 2 merged-with-previous, 3 merged-with-next
@@ -54,15 +54,36 @@ __device__ __forceinline__ int regex_symbol(const RegexDev& R, const RegexTables
     return R.cp_blocks[uint32_t(R.cp_index[cp >> 7]) * 128u + (cp & 127u)];
 }
 
-// "Previous character" context of start position p (patterns with ^, \b or look-behind only).
+// The character boundary `chars` characters in front of position i (not before `lo`).
+__device__ __forceinline__ int regex_step_back(const uint8_t* s, int lo, int i, int chars) {
+    for (; chars > 0 && i > lo; --chars) {
+        const int e = i;
+        --i;
+        while (i > lo && e - i < 4 && (s[i] & 0xC0u) == 0x80u) --i;
+    }
+    return i;
+}
+
+// Context of start position p -- what the pattern's `^`, `\b` and look-behinds need to know of the text in front of it: the
+// context automaton run over the last behind_chars characters (patterns with such assertions only).
 __device__ __forceinline__ int regex_context(const RegexDev& R, const RegexTables& T, const uint8_t* s, int slen, int p) {
     if (R.n_ctx <= 1 || p <= 0) return 0;
-    int q = p - 1;
-    while (q > 0 && p - q < 4 && (s[q] & 0xC0u) == 0x80u) --q;
-    int len = 0;
-    int sym = regex_symbol(R, T, s, slen, q, len);
-    if (sym == R.sym_final_nl) sym = T.ascii_class['\n'];
-    return R.ctx_of_class[sym];
+    int q = regex_step_back(s, 0, p, R.behind_chars > 0 ? R.behind_chars : 1);
+    int ctx = q == 0 ? 0 : 1;
+    while (q < p) {
+        int len = 0;
+        int sym = regex_symbol(R, T, s, slen, q, len);
+        if (sym == R.sym_final_nl) sym = T.ascii_class['\n'];
+        ctx = R.ctx_next[ctx * R.sym_eot + sym];   // (sym_eot = the number of classes)
+        q += len;
+    }
+    return ctx;
+}
+
+// Where the match that transition t reports at position i ended: i, or some characters back (a look-ahead decided late).
+__device__ __forceinline__ int regex_match_end(uint32_t t, const uint8_t* s, int p, int i) {
+    const int d = int((t >> kRegexDelayShift) & kRegexDelayMask);
+    return d == 0 ? i : regex_step_back(s, p, i, d);
 }
 
 // The match PCRE2 finds at or after `start` (PCRE2Wrapper::match, src/utils.cpp:396-420): leftmost start position, at
@@ -78,7 +99,7 @@ __device__ __forceinline__ bool regex_next_match(const RegexDev& R, const RegexT
             const int sym = i < slen ? regex_symbol(R, T, s, slen, i, len) : R.sym_eot;
             if (i == p) first_len = len;
             const uint32_t t = T.trans[state * R.n_syms + sym];
-            if (t & kRegexMatchBit) last = i;
+            if (t & kRegexMatchBit) last = regex_match_end(t, s, p, i);
             state = int(t & kRegexStateMask);
             if (state == 0 || i >= slen) break;
             i += len;
@@ -389,7 +410,7 @@ static __global__ __launch_bounds__(kBlockThreads) void regex_sparse_kernel(Rows
         }
         if (i == p) first_len = clen;
         const uint32_t t = T.trans[state * R.n_syms + sym];
-        if (t & kRegexMatchBit) last = i;
+        if (t & kRegexMatchBit) last = regex_match_end(t, s, p, i);
         state = int(t & kRegexStateMask);
         if (state == 0 || i >= len) {   // the attempt at p is over
             if (last >= 0 && last != p) {   // a match [p, last): the gap in front of it, then the match (regex_split.cpp:286-301)

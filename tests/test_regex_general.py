@@ -128,11 +128,47 @@ def test_fuzzed_patterns(backend):
     assert compared >= 20
 
 
-@pytest.mark.parametrize("pattern", [r"(a)\1", r"(?>a+)b", r"\p{Hann}+", r"\p{foo:Greek}", r"a(?=bc)", r"(?<=ab)c", r"(?x) a b", r"\R",
-                                     r"\X", r"a\Kb", r"(?|a|b)", r"(?R)", r"(?(1)a|b)", r"(?i)é", r"(?i)[à-ý]", r"(a|b)++c",
-                                     r"(?i)\p{Lu}x", r"[[:punct:]]", r"(*UTF)a", r"\p{Foo}", r"(?=a)*b"])
+# Look-around over more than one character, atomic groups, possessive groups, \R, (?x), (?|...), the POSIX classes with a meaning of
+# their own under UCP (round 6: VERDICT r05 item 7).  A look-ahead travels with the thread that met it as a condition until the
+# characters behind it have decided it (a match whose look-ahead is still open is reported late, with the number of characters it
+# ended back: RegexProgram bits 12..14); a look-behind reads a context automaton over the last <= 8 characters; an atomic group is
+# rewritten where its first way to match can be told by looking ahead (regex_compile.cpp Parser::atomize), and otherwise its threads
+# carry the entry they came from: the first of them to leave the group ends the ones behind it.
+LOOK_AROUND = [
+    r"a(?=bc)", r"a(?!bc)", r"(?=ab)a|b", r"\w+(?=ing\b)", r"\s+(?!\S\S)|\s", r"(?=..b)a", r"x?(?!ab|a$)a", r"a(?=b(?!c))", r"(?=a)*b", r"(?!a){0,2}.",
+    r"(?=ab)", r"(?!ab)\w\w", r"a*(?=b\z)", r"(?:a(?=bb)|b)+", r"(?i)s(?=SK)", r"\d(?=\d\d\d\b)", r"a(?=[^b]c)|1", r"(?=\s\S)\s+",
+    r"(?<=ab)c", r"(?<!ab)c", r"(?<=ab|c)d", r"(?<!ab|c)d", r"(?<=\d{3})a", r"(?<![a-c]{2}) ", r"(?<=\p{L}\d)\s|b", r"(?<=a\n)b", r"(?<=é元)a",
+    r"\b(?<=ab)\s", r"(?<=ab)(?=cd)", r"(?<=a)(?<!ba)c",
+    r"(?>a+)b", r"(?>a+)ab", r"(?>a|ab)c", r"(?>ab|a)c", r"(?>foo|foobar)x|\w", r"(?>a*?)b", r"(?>\d+)\d|a", r"(?>(?:ab)+)a|c", r"(?:ab)++a|c", r"(?:ab)*+c|a",
+    r"(?>a|b)+c", r"(?>a{1,3})a", r"(?:a[bc]){1,2}+a", r"(?>\s+)(?!\S)|\s", r"(?>ab?|a)c", r"(?>(?>a)b|a)c",
+    r"(a|b)++c", r"(?>a+b)c", r"(?>\w+\s)\w|x", r"(?>a+?b?)c", r"(?>(?:a|ab)+)c", r"(?>(?>a+b)+c)d", r"(?:a|ab)*+c|b", r"(?>[ab]+c?)+d", r"x(?>a|b\d?)++1",
+    r"\R", r"a\R+b|\R", "(?x) a b + # two b\n c", "(?x)a [ ]b", r"(?x: a b ) c", r"(?|a|b)+c", r"(*UTF)(*UCP)\w+", r"(^){1,2}a", r"(\b)?s",
+    r"[[:punct:]]+", r"[[:^punct:]]+", r"[[:graph:]]+", r"[[:print:]]+", r"[[:blank:][:cntrl:]]+", r"[[:xdigit:]]+|[[:ascii:]]",
+]
+LOOK_ALPHABET = ["a", "b", "c", "d", "S", "s", "K", "k", "i", "n", "g", "x", "f", "o", "r", " ", "\n", "\r", "1", "2", ".", "$", "é", "元", "\u2028", "\t", "\x85", "\x0c", ""]
+
+
+@pytest.mark.parametrize("pattern", LOOK_AROUND)
+def test_look_around_and_atomic_groups(backend, pattern):
+    strs = strings_for(backend, LOOK_ALPHABET, 7, n_emu=500, n_gpu=8000)
+    strs += ["abc", "abd", "ab", "abcabc", "singing ringing sing", "foobarx foox", "aaab", "aaa", "ababa", "abab c", "1234567", "12345", "a\r\nb\n\rc\r", "\r\n\r\n",
+             "a\r\n\nb", "abcd", "cabcd", "a1 b2", "ab  c", "  a", "a!b$c+d~e«f»g€h", "ab \tcG9\u3000z", "a\u200bb\u061cc", "sSK sk", "a\nb", "é元a", "abbc ab c", "a b ab"]
+    check(backend, pattern, strs)
+    for behaviour, invert in (("remove", True), ("mergedwithnext", False), ("contiguous", False)):
+        try:
+            check(backend, pattern, strs[-60:], behaviour, invert)
+        except L.OvtkError as err:
+            # "contiguous" compiles (?:pattern)+ (regex_split.cpp:33-37): an atomic group inside a repeat can need more states than the table holds
+            assert err.code == L.E_UNSUPPORTED and behaviour == "contiguous" and "(?>" in pattern, pattern
+
+
+@pytest.mark.parametrize("pattern", [r"(a)\1", r"\p{foo:Greek}", r"\X", r"a\Kb", r"(?R)", r"(?(1)a|b)", r"(?i)é", r"(?i)[à-ý]", r"(?>a+(?=bc)b?)c", r"(?=(?>a+b)c)a", r"(?>a*b|a)a",
+                                     r"(?i)\p{Lu}x", r"\p{Foo}", r"\p{Hann}+", r"(*ANYCRLF)a", r"a(?=\d+b)", r"(?=a(?=bc))a", r"(?<=a+)b", r"(?<=a{9})b", r"(?<=^a)b", r"(?=a+b)a|b"])
 def test_outside_the_subset_is_refused(backend, pattern):
-    """Patterns PCRE2 accepts (or may accept: a property name outside this library's tables) and the compiled subset does not cover."""
+    """Patterns PCRE2 accepts (or may accept: a property name outside this library's tables) and the compiled subset does not cover:
+    back-references, \\X, \\K, recursion, conditions, caseless matching beyond ASCII, an atomic group that can give characters back inside itself AND
+    holds a look-ahead of more than one character (or stands inside one), a look-ahead (or an atomic group's "no earlier way out") that can stay undecided for more than 7 characters behind a match's end, look-around
+    nested in a look-ahead of more than one character, look-behind over repeats or more than 8 characters, option verbs."""
     # (?i)\p{Lu} is accepted by the parser but means something else under PCRE2's caseless rules: refuse
     with pytest.raises(L.OvtkError) as ei:
         RegexSplit("isolate", lib=backend.lib).evaluate(backend.data(one_string_per_row(["ab"])) + [np.frombuffer(pattern.encode(), np.uint8)])

@@ -41,10 +41,18 @@ def gen(rng, depth=0):
         return "(?:" + gen(rng, depth + 1) + "|" + gen(rng, depth + 1) + ")" + QUANT[rng.integers(len(QUANT))]
     if r < 0.88:
         return "(" + gen(rng, depth + 1) + ")" + QUANT[rng.integers(len(QUANT))]
-    if r < 0.94:
+    if r < 0.91:
         kind = ["(?=", "(?!", "(?<=", "(?<!"][rng.integers(4)]
         inner = ATOMS[rng.integers(18)]  # single-character atoms only (fixed-width look-behind)
         return kind + inner + ")"
+    if r < 0.94:   # round 6: look-ahead over anything, look-behind over alternatives of fixed sequences, atomic groups
+        k = rng.integers(3)
+        if k == 0:
+            return ["(?=", "(?!"][rng.integers(2)] + gen(rng, depth + 1) + ")"
+        if k == 1:
+            alts = "|".join("".join(ATOMS[rng.integers(18)] for _ in range(int(rng.integers(1, 4)))) for _ in range(int(rng.integers(1, 3))))
+            return ["(?<=", "(?<!"][rng.integers(2)] + alts + ")"
+        return "(?>" + gen(rng, depth + 1) + ")" + QUANT[rng.integers(len(QUANT))]
     return "(?i:" + gen(rng, depth + 1) + ")"
 
 
