@@ -837,33 +837,47 @@ int ovtk_trie_tokenizer_run(ovtk_trie_tokenizer* h, const ovtk_ragged_strings* i
     if (int rc = out_target(ws->out_a, out->begins, size_t(in->n_rows) * 4, mem, &d_b)) return rc;
     if (int rc = out_target(ws->out_b, out->ends, size_t(in->n_rows) * 4, mem, &d_e)) return rc;
     if (int rc = out_target(ws->out_c, out->data, size_t(out->data_capacity) * 4, mem, &d_i)) return rc;
-    // the rows' bytes -> scan: staging offsets; ONE walk (a lane per row): ids into the row's stretch, its count filed; scan of the counts:
-    // the rows' offsets in the output; a wave per row copies its stretch there
+    // the rows' bytes in whole segments -> scan: staging offsets, the segments' rows; a lane per segment walks its guess; a lane per row
+    // stitches them and files the count; scan of the counts: the rows' offsets in the output; a wave per row gathers its kept entries
     if (int rc = ws->gen[6].ensure(size_t(in->n_rows) * 4)) return rc;
     if (int rc = ws->gen[7].ensure(size_t(in->n_rows) * 8)) return rc;
     int32_t* lens = ws->gen[6].as<int32_t>();
     long long* stage_off = ws->gen[7].as<long long>();
-    const int each_grid = int((in->n_rows + kTileThreads - 1) / kTileThreads);
+    const int row_grid = int((in->n_rows + kTileThreads - 1) / kTileThreads);
     const int wave_grid = int(std::min<long long>((in->n_rows + kTileThreads / kWave - 1) / (kTileThreads / kWave), (long long)device_cu_count(h->device) * 32));
-    int64_t stage_cap = std::max<int64_t>(in->strings.n_chars, 1);   // (a token takes at least a byte; rows that share strings need more: second attempt)
+    // (a token takes at least a byte, a row's stretch is its bytes in whole segments; rows that share strings need more: second attempt)
+    int64_t stage_cap = (std::max<int64_t>(in->strings.n_chars, 1) + int64_t(kTrieSeg) * in->n_rows + kTrieSeg - 1) / kTrieSeg * kTrieSeg;
     uint32_t f = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (attempt) {
             if (int rc = begin_status(*ws.ws, s, &st)) return rc;
             r.status = st;
         }
+        if (stage_cap / kTrieSeg > INT32_MAX / 2) return set_error(OVTK_E_UNSUPPORTED, "TrieTokenizer: too much text for one call; split it");
+        const size_t n_seg_cap = size_t(stage_cap / kTrieSeg);
         if (int rc = ws->stage.ensure(size_t(stage_cap) * 4)) return rc;
+        if (int rc = ws->gen[3].ensure(n_seg_cap * 4)) return rc;
+        if (int rc = ws->gen[4].ensure(n_seg_cap * 8)) return rc;
+        if (int rc = ws->gen[5].ensure(n_seg_cap * 4)) return rc;
         int32_t* stage = ws->stage.as<int32_t>();
+        int32_t* seg_row = ws->gen[3].as<int32_t>();
+        unsigned long long* seg_bits = ws->gen[4].as<unsigned long long>();
+        int32_t* seg_exit = ws->gen[5].as<int32_t>();
         if ((in->n_rows + kTileElems - 1) / kTileElems > INT32_MAX) return set_error(OVTK_E_UNSUPPORTED, "too many rows for one call; split it");
         if (int rc = ws->tiles.ensure(scan_tiles_bytes(in->n_rows))) return rc;
-        launch_scan(ws->marks, "trie_tokenizer", s, in->n_rows, TrieRowBytes{r}, TrieStageOffsets{stage_off}, TrieStageFin{st, (long long)stage_cap},
-                    ws->tiles.as<long long>(), st, kFlagRange);
-        OVTK_LAUNCH(ws->marks, "trie_walk", trie_walk_kernel, each_grid, kTileThreads, s, (long long)in->n_rows, r, (const long long*)stage_off, stage, lens);
+        launch_scan(ws->marks, "trie_tokenizer", s, in->n_rows, TrieRowStretch{r}, TrieStageOffsets{stage_off, seg_row, (long long)stage_cap},
+                    TrieStageFin{st, (long long)stage_cap}, ws->tiles.as<long long>(), st, kFlagRange);
+        const unsigned seg_grid = unsigned((n_seg_cap + kTileThreads - 1) / kTileThreads);
+        OVTK_LAUNCH(ws->marks, "trie_segments", trie_segments_kernel, seg_grid, kTileThreads, s, r, (const long long*)stage_off, (const int32_t*)seg_row, stage, seg_bits,
+                    seg_exit);
+        OVTK_LAUNCH(ws->marks, "trie_rows", trie_rows_kernel, row_grid, kTileThreads, s, (long long)in->n_rows, r, (const long long*)stage_off, stage, seg_bits,
+                    (const int32_t*)seg_exit, lens);
         if (int rc = scan_and_apply(*ws.ws, s, in->n_rows, FiledLen{lens}, RowOffsets{d_b, d_e, 0},
                                     (long long)std::min<int64_t>(out->data_capacity, INT32_MAX - 1), st, "trie_tokenizer"))
             return rc;
-        OVTK_LAUNCH(ws->marks, "trie_copy", each_wave_kernel<TrieCopy>, wave_grid, kTileThreads, s, (long long)in->n_rows,
-                    TrieCopy{stage_off, stage, lens, d_b, d_i}, (const RunStatus*)st, kFlagOutCapacity | kFlagRange | kFlagItemsOverflow | kFlagStageOverflow);
+        OVTK_LAUNCH(ws->marks, "trie_gather", each_wave_kernel<TrieGather>, wave_grid, kTileThreads, s, (long long)in->n_rows,
+                    TrieGather{stage_off, stage, seg_bits, lens, d_b, d_i, st, (long long)in->n_rows}, (const RunStatus*)st,
+                    kFlagOutCapacity | kFlagRange | kFlagItemsOverflow | kFlagStageOverflow);
         if (int rc = finish_status(*ws.ws, s)) return rc;
         f = ws->host_status->flags;
         if (!(f & kFlagStageOverflow) || (f & kFlagRange)) break;

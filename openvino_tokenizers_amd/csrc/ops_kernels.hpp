@@ -811,12 +811,45 @@ static __global__ __launch_bounds__(kBlockThreads) void fuze_kernel(const int32_
 }
 
 // ------------------------------------------------------------------------------- TrieTokenizer
-// src/trie_tokenizer.cpp:66-78, one lane per ragged row.  Round 6: ONE walk per row -- the ids go to a staging stretch of the row's
-// own (a token takes at least one byte: the row's bytes bound its ids; the stretches' offsets are a scan of the rows' bytes), the scan
-// of the filed counts is the reference's running ragged_offset, a wave per row copies the stretch to its place.  Until then: a counting
-// walk, the scan, a second walk that wrote (2.85 ms for a config-2 batch; the walk is a chain of dependent loads, one per byte).  And
-// the text comes sixteen bytes at a time into registers: the byte load in front of every trie step was a dependent load of its own.
+// src/trie_tokenizer.cpp:66-78: per string the greedy chain of longest matches (Trie::find_longest, src/utils.cpp:517-538).
+// A chain is a run of dependent table reads -- 1.4 us per step on this chip whatever the occupancy (a lane per row: 1.14 ms for a
+// config-2 batch; the same rows spread over eight times the waves: 0.97) --, so the row is cut into SEGMENTS of 64 bytes, a lane each
+// (round 6):
+//   * trie_segments_kernel: every segment's lane walks the chain that STARTS AT ITS FIRST BYTE -- a guess for every segment but a
+//     string's first -- until a token ends behind the segment; the token that starts at byte p of the row goes to entry p of the row's
+//     staging stretch (a token takes at least a byte), bit p % 64 of the segment's mask says so, and the position behind the segment's
+//     last token is filed;
+//   * trie_rows_kernel, a lane per row: the true chain enters segment k where segment k - 1's true chain left it.  Greedy chains that
+//     meet stay together, and they meet soon (a guess that starts inside a word ends with that word): where the entry is a token start
+//     of the segment's guess, the guess from there on IS the true chain (the mask's lower bits are dropped); where not, the lane walks
+//     on from the entry until it steps on a token start of the guess or leaves the segment.  The row's count is the kept bits;
+//   * the scan of the counts is the reference's running ragged_offset; trie_gather_kernel, a wave per row, moves the kept entries to
+//     their places.
+// Rows of several strings (the guess would have to know where the strings start) are walked whole by their lane of trie_rows_kernel,
+// into the same masks.  Until round 6: one walk per row (1.14 ms), before that a counting walk, the scan, a writing walk (2.85 ms).
 struct __attribute__((packed, aligned(1))) TrieBytes16 { uint32_t x, y, z, w; };
+constexpr int kTrieSeg = 64;
+constexpr int32_t kTrieBroken = INT32_MIN;   // in a segment's filed exit: no token matches at the position in the lower bits
+struct TrieWindow {   // sixteen bytes of the chars tensor in registers: the byte load in front of every trie step was a dependent load of its own
+    TrieBytes16 win{0, 0, 0, 0};
+    long long at = -1;   // chars offset of the window (a multiple of 16), -1: none
+    __device__ uint32_t byte(const uint8_t* chars, long long n_chars, long long pos) {
+        const long long base = pos & ~15ll;
+        if (base != at) {
+            if (base + 16 <= n_chars) {
+                win = *reinterpret_cast<const TrieBytes16*>(chars + base);
+            } else {   // the chars tensor's last bytes
+                uint32_t v[4] = {0, 0, 0, 0};
+                for (long long k = base; k < n_chars; ++k) v[(k - base) >> 2] |= uint32_t(chars[k]) << (8 * ((k - base) & 3));
+                win = TrieBytes16{v[0], v[1], v[2], v[3]};
+            }
+            at = base;
+        }
+        const int k = int(pos & 15);
+        const uint32_t word = k < 8 ? (k < 4 ? win.x : win.y) : (k < 12 ? win.z : win.w);
+        return (word >> (8 * (k & 3))) & 0xFFu;
+    }
+};
 struct TrieRows {
     const int32_t* ragged_begins;
     const int32_t* ragged_ends;
@@ -827,7 +860,7 @@ struct TrieRows {
     TrieDev trie;
     RunStatus* status;
 
-    // bytes of the row's strings (its staging stretch), -1 for offsets outside their tensors
+    // bytes of the row's strings, -1 for offsets outside their tensors
     __device__ long long row_bytes(long long row) const {
         const long long cb = ragged_begins[row], ce = ragged_ends[row];
         if (cb < 0 || ce < cb || ce > n_strings) return -1;
@@ -840,92 +873,69 @@ struct TrieRows {
         return sum;
     }
 
-    // The greedy walk of one row as a FLAT loop: every turn of it is one trie step of the lane's current token -- the first byte through
-    // the root table (`root`: a copy in LDS), then one edge per turn -- and a token's end (emit, back to the root) is part of the turn that
-    // finds it.  Written as the reference writes it -- a loop over tokens round a loop over steps (src/utils.cpp:517-538) -- a WAVE ran,
-    // for the k-th token of its 64 rows, as many inner turns as the longest of those 64 tokens: 1.5 ms per batch where this form takes
-    // as many turns as its longest ROW has steps.
-    template <class Emit>
-    __device__ void walk(long long row, const I2* root, Emit&& emit) const {
-        const long long cb = ragged_begins[row], ce = ragged_ends[row];
-        if (cb < 0 || ce < cb || ce > n_strings) {
-            atomicOr(&status->flags, kFlagRange);
-            return;
-        }
-        TrieBytes16 win{0, 0, 0, 0};
-        long long win_at = -1;   // chars offset of the window (a multiple of 16), -1: none
-        for (long long col = cb; col < ce; ++col) {
-            const long long b = begins[col], e = ends[col];
-            if (b < 0 || e < b || e > n_chars) {
-                atomicOr(&status->flags, kFlagRange);
-                return;
-            }
-            const int n = int(e - b);
-            auto getb = [&](int i) -> uint32_t {
-                const long long at = b + i, base = at & ~15ll;
-                if (base != win_at) {
-                    if (base + 16 <= n_chars) {
-                        win = *reinterpret_cast<const TrieBytes16*>(chars + base);
-                    } else {   // the chars tensor's last bytes
-                        uint32_t v[4] = {0, 0, 0, 0};
-                        for (long long k = base; k < n_chars; ++k) v[(k - base) >> 2] |= uint32_t(chars[k]) << (8 * ((k - base) & 3));
-                        win = TrieBytes16{v[0], v[1], v[2], v[3]};
+    // The greedy chain over the string chars[b, b + n) from position `from`, as a FLAT loop: every turn of it is one trie step of the
+    // lane's current token -- the first byte through the root table (`root`: a copy in LDS), then one edge per turn -- and a token's end
+    // (emit, back to the root) is part of the turn that finds it.  Written as the reference writes it -- a loop over tokens round a loop
+    // over steps (src/utils.cpp:517-538) -- a WAVE ran, for the k-th token of its 64 lanes, as many inner turns as the longest of those
+    // 64 tokens.  The chain goes on while `more(position)` says so for the position behind a token (and the string has bytes left);
+    // returns that position, or kTrieBroken | position where no token matches (the reference spins there forever, :72-75).
+    template <class Emit, class More>
+    __device__ int32_t chain(long long b, int n, int from, const I2* root, TrieWindow& tw, Emit&& emit, More&& more) const {
+        int idx = from;                    // where the current token starts
+        int i = 0, cur = -1, best = -1, best_end = 0;   // cur < 0: at the root
+        bool stop = false;
+        while (idx < n) {
+            if (cur < 0) {   // Trie::find_longest's first step
+                const I2 r = root[tw.byte(chars, n_chars, b + idx)];
+                best = r.y < 0 ? -1 : r.x;
+                best_end = idx + 1;
+                i = idx + 1;
+                cur = r.y < 0 ? 0 : (r.y & ~kLeafBit);
+                stop = r.y < 0 || (r.y & kLeafBit) != 0 || i >= n;
+            } else {
+                TrieEdge ed;
+                if (trie_step(trie, cur, tw.byte(chars, n_chars, b + i), ed)) {
+                    cur = ed.child;
+                    ++i;
+                    if (ed.value != -1) {
+                        best = ed.value;
+                        best_end = i;
                     }
-                    win_at = base;
-                }
-                const int k = int(at & 15);
-                const uint32_t word = k < 8 ? (k < 4 ? win.x : win.y) : (k < 12 ? win.z : win.w);
-                return (word >> (8 * (k & 3))) & 0xFFu;
-            };
-            int idx = 0;                       // where the current token starts
-            int i = 0, cur = -1, best = -1, best_end = 0;   // cur < 0: at the root
-            bool stop = false;
-            while (idx < n) {
-                if (cur < 0) {   // Trie::find_longest's first step (src/utils.cpp:517-538)
-                    const I2 r = root[getb(idx)];
-                    best = r.y < 0 ? -1 : r.x;
-                    best_end = idx + 1;
-                    i = idx + 1;
-                    cur = r.y < 0 ? 0 : (r.y & ~kLeafBit);
-                    stop = r.y < 0 || (r.y & kLeafBit) != 0 || i >= n;
+                    stop = ed.has_kids == 0 || i >= n;
                 } else {
-                    TrieEdge ed;
-                    if (trie_step(trie, cur, getb(i), ed)) {
-                        cur = ed.child;
-                        ++i;
-                        if (ed.value != -1) {
-                            best = ed.value;
-                            best_end = i;
-                        }
-                        stop = ed.has_kids == 0 || i >= n;
-                    } else {
-                        stop = true;
-                    }
-                }
-                if (stop) {
-                    if (best == -1) {  // the reference spins here forever (src/trie_tokenizer.cpp:72-75)
-                        atomicOr(&status->flags, kFlagItemsOverflow);
-                        return;
-                    }
-                    emit(best);
-                    idx = best_end;
-                    cur = -1;
+                    stop = true;
                 }
             }
+            if (stop) {
+                if (best == -1) return kTrieBroken | idx;
+                emit(idx, best);
+                idx = best_end;
+                cur = -1;
+                if (!more(idx)) break;
+            }
         }
+        return idx;
     }
 };
-struct TrieRowBytes {
+// a row's staging stretch: its bytes rounded up to whole segments (so that stretch offset / 64 numbers the segments of the batch)
+struct TrieRowStretch {
     TrieRows r;
     __device__ long long operator()(long long row) const {
         const long long n = r.row_bytes(row);
         if (n < 0) atomicOr(&r.status->flags, kFlagRange);
-        return n < 0 ? 0 : n;
+        return n < 0 ? 0 : (n + kTrieSeg - 1) / kTrieSeg * kTrieSeg;
     }
 };
+// ... its offset filed, and the row's number with each of its segments
 struct TrieStageOffsets {
     long long* off;
-    __device__ void operator()(long long i, long long o, long long) const { off[i] = o; }
+    int32_t* seg_row;
+    long long cap;
+    __device__ void operator()(long long i, long long o, long long len) const {
+        off[i] = o;
+        if (o + len > cap) return;   // (TrieStageFin raises the flag: the host grows the buffers and runs the call again)
+        for (long long k = 0; k < len / kTrieSeg; ++k) seg_row[o / kTrieSeg + k] = int32_t(i);
+    }
 };
 // the staging entries the batch needs (rows may share strings: then more than the chars tensor has bytes) -> stage_need, and the flag when
 // the buffer at hand is smaller: the host grows it and runs the call again
@@ -937,18 +947,127 @@ struct TrieStageFin {
         if (total > cap) atomicOr(&status->flags, kFlagStageOverflow);
     }
 };
-// the walk: a lane per row, ids to the row's staging stretch, the count filed
-static __global__ __launch_bounds__(kTileThreads) void trie_walk_kernel(long long n_rows, TrieRows r, const long long* stage_off, int32_t* stage, int32_t* lens) {
+// A lane per segment: the chain that starts at the segment's first byte.
+static __global__ __launch_bounds__(kTileThreads) void trie_segments_kernel(TrieRows r, const long long* stage_off, const int32_t* seg_row, int32_t* stage,
+                                                                            unsigned long long* seg_bits, int32_t* seg_exit) {
+    __shared__ I2 root_lds[256];
+    for (int k = int(threadIdx.x); k < 256; k += kTileThreads) root_lds[k] = r.trie.root[k];
+    __syncthreads();
+    if (r.status->flags & (kFlagRange | kFlagStageOverflow)) return;
+    const long long g = (long long)blockIdx.x * kTileThreads + threadIdx.x;
+    if (g >= r.status->stage_need / kTrieSeg) return;
+    const long long row = seg_row[g];
+    const long long so = stage_off[row];
+    const long long cb = r.ragged_begins[row];
+    unsigned long long bits = 0;
+    int32_t exit = 0;
+    if (r.ragged_ends[row] - cb == 1) {
+        const long long b = r.begins[cb];
+        const int n = int(r.ends[cb] - b);
+        const int base = int(g - so / kTrieSeg) * kTrieSeg;
+        const int until = base + kTrieSeg;
+        TrieWindow tw;
+        int32_t* dst = stage + so;
+        exit = r.chain(b, n, base, root_lds, tw,
+                       [&](int at, int tok) {
+                           dst[at] = tok;
+                           bits |= 1ull << (at - base);
+                       },
+                       [&](int at) { return at < until; });
+    }
+    seg_bits[g] = bits;
+    seg_exit[g] = exit;
+}
+// A lane per row: the true chain through the row's segments (rows of one string), or the whole walk (rows of several); the count filed.
+static __global__ __launch_bounds__(kTileThreads) void trie_rows_kernel(long long n_rows, TrieRows r, const long long* stage_off, int32_t* stage,
+                                                                        unsigned long long* seg_bits, const int32_t* seg_exit, int32_t* lens) {
     __shared__ I2 root_lds[256];
     for (int k = int(threadIdx.x); k < 256; k += kTileThreads) root_lds[k] = r.trie.root[k];
     __syncthreads();
     if (r.status->flags & (kFlagRange | kFlagStageOverflow)) return;
     const long long row = (long long)blockIdx.x * kTileThreads + threadIdx.x;
     if (row >= n_rows) return;
-    int32_t* dst = stage + stage_off[row];
-    int32_t n = 0;
-    r.walk(row, root_lds, [&](int tok) { dst[n++] = tok; });
-    lens[row] = n;
+    const long long so = stage_off[row];
+    const long long g0 = so / kTrieSeg;
+    int32_t* dst = stage + so;
+    const long long cb = r.ragged_begins[row], ce = r.ragged_ends[row];
+    TrieWindow tw;
+    int32_t count = 0;
+    if (ce - cb == 1) {
+        const long long b = r.begins[cb];
+        const int n = int(r.ends[cb] - b);
+        const int n_seg = (n + kTrieSeg - 1) / kTrieSeg;
+        int t = 0;   // where the true chain enters the segment at hand
+        for (int k = 0; k < n_seg; ++k) {
+            const int base = k * kTrieSeg;
+            if (t >= base + kTrieSeg) {   // a token that covers the whole segment
+                seg_bits[g0 + k] = 0;
+                continue;
+            }
+            const unsigned long long guess = seg_bits[g0 + k];
+            int32_t exit = seg_exit[g0 + k];
+            unsigned long long keep;
+            if ((guess >> (t - base)) & 1ull) {
+                keep = guess & (~0ull << (t - base));
+            } else {
+                keep = 0;
+                int met = -1;   // the guess's token start the walk stepped on
+                const int32_t e = r.chain(b, n, t, root_lds, tw,
+                                          [&](int at, int tok) {
+                                              dst[at] = tok;
+                                              keep |= 1ull << (at - base);
+                                          },
+                                          [&](int at) {
+                                              if (at >= base + kTrieSeg) return false;
+                                              if ((guess >> (at - base)) & 1ull) {
+                                                  met = at;
+                                                  return false;
+                                              }
+                                              return true;
+                                          });
+                if (met >= 0) keep |= guess & (~0ull << (met - base));
+                else exit = e;
+            }
+            seg_bits[g0 + k] = keep;
+            count += __popcll(keep);
+            if (exit < 0) {  // the reference spins here forever (src/trie_tokenizer.cpp:72-75)
+                atomicOr(&r.status->flags, kFlagItemsOverflow);
+                break;
+            }
+            t = exit;
+        }
+    } else if (cb >= 0 && ce >= cb && ce <= r.n_strings) {
+        // several strings: every string's chain from its first byte, positions counted through the row's strings
+        int at0 = 0;   // bytes of the strings before
+        unsigned long long bits = 0;
+        long long seg = 0;
+        bool broken = false;
+        for (long long col = cb; col < ce && !broken; ++col) {
+            const long long b = r.begins[col];
+            const int n = int(r.ends[col] - b);
+            const int32_t e = r.chain(b, n, 0, root_lds, tw,
+                                      [&](int at, int tok) {
+                                          const int p = at0 + at;
+                                          if (p / kTrieSeg != seg) {
+                                              seg_bits[g0 + seg] = bits;
+                                              for (long long q = seg + 1; q < p / kTrieSeg; ++q) seg_bits[g0 + q] = 0;
+                                              seg = p / kTrieSeg;
+                                              bits = 0;
+                                          }
+                                          dst[p] = tok;
+                                          bits |= 1ull << (p % kTrieSeg);
+                                          ++count;
+                                      },
+                                      [&](int) { return true; });
+            broken = e < 0;
+            at0 += n;
+        }
+        const long long n_seg = (at0 + kTrieSeg - 1) / kTrieSeg;
+        if (seg < n_seg) seg_bits[g0 + seg] = bits;
+        for (long long q = seg + 1; q < n_seg; ++q) seg_bits[g0 + q] = 0;
+        if (broken) atomicOr(&r.status->flags, kFlagItemsOverflow);
+    }
+    lens[row] = count;
 }
 struct FiledLen {
     const int32_t* lens;
@@ -963,18 +1082,28 @@ struct RowOffsets {
         out_ends[i] = int32_t(base + off + len);
     }
 };
-// a wave per row: the staging stretch to its place in the output
-struct TrieCopy {
+// a wave per row: the kept entries of the row's stretch, segment by segment, to their places in the output
+struct TrieGather {
     const long long* stage_off;
     const int32_t* stage;
+    const unsigned long long* seg_bits;
     const int32_t* lens;
     const int32_t* out_begins;
     int32_t* out_ids;
+    const RunStatus* status;
+    long long n_rows;
     __device__ void operator()(long long row) const {
-        const int32_t* src = stage + stage_off[row];
+        const long long so = stage_off[row];
+        const long long end = row + 1 < n_rows ? stage_off[row + 1] : status->stage_need;
         int32_t* dst = out_ids + out_begins[row];
+        const int l = lane_id();
+        int done = 0;
         const int n = lens[row];
-        for (int k = lane_id(); k < n; k += kWave) dst[k] = src[k];
+        for (long long g = so / kTrieSeg; g < end / kTrieSeg && done < n; ++g) {
+            const unsigned long long bits = seg_bits[g];
+            if ((bits >> l) & 1ull) dst[done + __popcll(bits & ((1ull << l) - 1))] = stage[g * kTrieSeg + l];
+            done += __popcll(bits);
+        }
     }
 };
 

@@ -101,8 +101,54 @@ def test_rows_that_share_strings(backend):
     re_ = np.concatenate([np.arange(n) + 1, np.arange(n // 3) + 1, [n // 2 + 9]]).astype(np.int32)
     ref = O.TrieTokenizer(vocab, indices)(rb, re_, b, e, c)
     assert int((e - b)[rb[n:n + n // 3]].sum()) > 0 and len(ref[2]) <= len(c)
+    _run_shared(backend, vocab, indices, rb, re_, b, e, c, ref)
+    # round 6: a row's stretch is its bytes in whole 64-byte segments and the first size has room for that -- three rows that each name
+    # EVERY string, and a few of one string, outgrow it
+    rb = np.array([0, 0, 0, 3, 4, 50], np.int32)
+    re_ = np.array([n, n, n, 4, 5, 51], np.int32)
+    ref = O.TrieTokenizer(vocab, indices)(rb, re_, b, e, c)
+    assert 3 * len(c) > len(c) + 64 * (len(rb) + 1) and len(ref[2]) <= len(c)
+    _run_shared(backend, vocab, indices, rb, re_, b, e, c, ref)
+
+
+def _run_shared(backend, vocab, indices, rb, re_, b, e, c, ref):
     vb, ve, vc = O.pack_strings(vocab)
     op = TrieTokenizer(lib=backend.lib)
     for call in range(2):
         got = op.evaluate(backend.data([rb, re_, b, e, c]) + [vb, ve, vc, indices])
         assert_same(list(ref), got, backend.host, f"shared strings, call {call}")
+
+
+def test_rows_of_many_segments(backend):
+    """The segmented walk (round 6: a lane per 64-byte segment walks the chain that starts at the segment's first byte, a lane per row stitches
+    them): tokens across segment borders, a token longer than a segment (and than two), chains that never meet the guess ({a, aaa} on a run of
+    a's: 64 is not a multiple of 3), a guess that starts on a byte no token starts with (`z` only ever inside `az`: the guess breaks there,
+    the true chain never starts a token there -- no error), every length around the segment size, rows of several strings among them."""
+    rng = np.random.default_rng(5)
+    vocab = [bytes([b]) for b in range(256) if b != ord("z")] + [b"aaa", b"az", b"ab" * 40, b"c" * 150, b"hello", b" world", b" wor", b"ld", b"lo w", b"the quick", b" brown fox"]
+    vocab += [bytes(rng.choice(list(b"abc dehlorw"), size=int(rng.integers(2, 12))).tolist()) for _ in range(400)]
+    vocab = list(dict.fromkeys(vocab))
+    indices = np.arange(10, 10 + len(vocab), dtype=np.int32)
+    strings = [b"a" * k for k in (1, 2, 3, 63, 64, 65, 127, 128, 129, 191, 200, 700)]
+    strings += [b"x" * k + b"az" * 5 + b"x" * 70 for k in range(60, 68)]   # `z` on either side of a border
+    strings += [b"x" * k + b"ab" * 45 + b"c" * 320 + b"hello world" * 9 for k in range(0, 70, 7)]
+    words = [b"hello", b" world", b"the quick", b" brown fox", b"aaa", b" ", b"lo w", b"c" * 150, b"ab" * 40] + vocab[-60:]
+    n = 40 if backend.name == "emu" else 6000
+    strings += [b"".join(words[int(k)] for k in rng.integers(0, len(words), int(rng.integers(1, 120)))) for _ in range(n)]
+    strings += [bytes(rng.choice(list(b"abc dehlorw"), size=int(k)).tolist()) for k in rng.integers(0, 600, n)]
+    strings.append(b"")
+    b, e, c = O.pack_strings(strings)
+    m = len(strings)
+    cuts = np.unique(np.concatenate([[0, m], np.arange(0, 30), rng.integers(0, m, m - m // 6)])).astype(np.int32)   # mostly one string per row, some 2-4
+    rb, re_ = cuts[:-1], cuts[1:]
+    ref = O.TrieTokenizer(vocab, indices)(rb, re_, b, e, c)
+    vb, ve, vc = O.pack_strings(vocab)
+    op = TrieTokenizer(lib=backend.lib)
+    got = op.evaluate(backend.data([rb, re_, b, e, c]) + [vb, ve, vc, indices])
+    assert_same(list(ref), got, backend.host, "rows of many segments")
+    # ... and where the TRUE chain starts a token on `z`, the error is raised wherever the segment borders fall
+    for k in (0, 63, 64, 65, 200):
+        bb, ee, cc = O.pack_strings([b"a" * 300, b"b" * k + b"z" + b"a" * 100])
+        with pytest.raises(L.OvtkError) as ei:
+            op.evaluate(backend.data([np.array([0, 1], np.int32), np.array([1, 2], np.int32), bb, ee, cc]) + [vb, ve, vc, indices])
+        assert ei.value.code == L.E_VOCAB

@@ -136,7 +136,7 @@ def main():
     ref_tr = O.TrieTokenizer(tok.vocab, idx)(*head)
     tr_out = timed("TrieTokenizer", lambda: tr.evaluate(d + [vb, ve, vc, idx]), n_c + 16 * n + 4 * (n_c // 3),
                    lambda out: same(ref_tr[:2], [to_np(out[0])[:k], to_np(out[1])[:k]]) and same([ref_tr[2]], [to_np(out[2])], upto=len(ref_tr[2])),
-                   f"V = {len(tok.vocab)} (the GPT-2-shaped vocabulary's strings), one lane per row")
+                   f"V = {len(tok.vocab)} (the GPT-2-shaped vocabulary's strings), a lane per 64-byte segment + a lane per row that stitches them")
     del tr_out
     # ---- the ids of the batch (the fused encode), then the ops behind the tokenizer
     fused = FusedSplitBPE(RegexSplit("isolate", lib=lib), BPETokenizer(**tok.attrs, lib=lib))
