@@ -786,8 +786,8 @@ int ovtk_fuze_ragged(const int32_t* ragged_begins, const int32_t* ragged_ends, i
 // ------------------------------------------------------------------------------- TrieTokenizer
 struct ovtk_trie_tokenizer {
     int device = 0;
-    TrieDev dev{};
-    TrieBufs bufs;
+    TrieBucketsDev dev{};
+    DevBuf root, buckets;
 };
 
 int ovtk_trie_tokenizer_create(const ovtk_strings* vocab, const int32_t* indices, int device, ovtk_trie_tokenizer** out) {
@@ -802,8 +802,11 @@ int ovtk_trie_tokenizer_create(const ovtk_strings* vocab, const int32_t* indices
         if (b < 0 || e < b || e > vocab->n_chars) return set_error(OVTK_E_RANGE, "trie tokenizer: vocab begins/ends outside the chars tensor");
         t.add(vocab->chars + b, size_t(e - b), indices[i]);
     }
-    t.finalize();
-    if (int rc = h->bufs.upload(t, h->dev)) return rc;
+    TrieBucketsHost tb;
+    if (!tb.build(t)) return set_error(OVTK_E_UNSUPPORTED, "trie tokenizer: the vocabulary's trie has more than 8 million nodes");
+    if (int rc = h->root.upload(tb.root.data(), tb.root.size() * sizeof(I2))) return rc;
+    if (int rc = h->buckets.upload(tb.buckets.data(), tb.buckets.size() * sizeof(TrieBucket))) return rc;
+    h->dev = TrieBucketsDev{h->root.as<I2>(), h->buckets.as<TrieBucket>(), tb.bucket_mask, tb.bucket_shift};
     OVTK_HIP(hipStreamSynchronize(nullptr));
     *out = h.release();
     return OVTK_OK;
@@ -843,7 +846,6 @@ int ovtk_trie_tokenizer_run(ovtk_trie_tokenizer* h, const ovtk_ragged_strings* i
     if (int rc = ws->gen[7].ensure(size_t(in->n_rows) * 8)) return rc;
     int32_t* lens = ws->gen[6].as<int32_t>();
     long long* stage_off = ws->gen[7].as<long long>();
-    const int row_grid = int((in->n_rows + kTileThreads - 1) / kTileThreads);
     const int wave_grid = int(std::min<long long>((in->n_rows + kTileThreads / kWave - 1) / (kTileThreads / kWave), (long long)device_cu_count(h->device) * 32));
     // (a token takes at least a byte, a row's stretch is its bytes in whole segments; rows that share strings need more: second attempt)
     int64_t stage_cap = (std::max<int64_t>(in->strings.n_chars, 1) + int64_t(kTrieSeg) * in->n_rows + kTrieSeg - 1) / kTrieSeg * kTrieSeg;
@@ -870,8 +872,11 @@ int ovtk_trie_tokenizer_run(ovtk_trie_tokenizer* h, const ovtk_ragged_strings* i
         const unsigned seg_grid = unsigned((n_seg_cap + kTileThreads - 1) / kTileThreads);
         OVTK_LAUNCH(ws->marks, "trie_segments", trie_segments_kernel, seg_grid, kTileThreads, s, r, (const long long*)stage_off, (const int32_t*)seg_row, stage, seg_bits,
                     seg_exit);
-        OVTK_LAUNCH(ws->marks, "trie_rows", trie_rows_kernel, row_grid, kTileThreads, s, (long long)in->n_rows, r, (const long long*)stage_off, stage, seg_bits,
-                    (const int32_t*)seg_exit, lens);
+        int spread = 1;   // rows on every spread-th lane (trie_rows_kernel): as many waves as give every SIMD four
+        while (spread < 8 && (long long)in->n_rows * spread < 4ll * 4 * device_cu_count(h->device) * kWave) spread *= 2;
+        const unsigned rows_grid_n = unsigned(((long long)in->n_rows * spread + kTileThreads - 1) / kTileThreads);
+        OVTK_LAUNCH(ws->marks, "trie_rows", trie_rows_kernel, rows_grid_n, kTileThreads, s, (long long)in->n_rows, r, (const long long*)stage_off, stage, seg_bits,
+                    (const int32_t*)seg_exit, lens, spread);
         if (int rc = scan_and_apply(*ws.ws, s, in->n_rows, FiledLen{lens}, RowOffsets{d_b, d_e, 0},
                                     (long long)std::min<int64_t>(out->data_capacity, INT32_MAX - 1), st, "trie_tokenizer"))
             return rc;

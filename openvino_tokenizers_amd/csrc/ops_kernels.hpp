@@ -827,28 +827,24 @@ static __global__ __launch_bounds__(kBlockThreads) void fuze_kernel(const int32_
 //     their places.
 // Rows of several strings (the guess would have to know where the strings start) are walked whole by their lane of trie_rows_kernel,
 // into the same masks.  Until round 6: one walk per row (1.14 ms), before that a counting walk, the scan, a writing walk (2.85 ms).
-struct __attribute__((packed, aligned(1))) TrieBytes16 { uint32_t x, y, z, w; };
 constexpr int kTrieSeg = 64;
 constexpr int32_t kTrieBroken = INT32_MIN;   // in a segment's filed exit: no token matches at the position in the lower bits
-struct TrieWindow {   // sixteen bytes of the chars tensor in registers: the byte load in front of every trie step was a dependent load of its own
-    TrieBytes16 win{0, 0, 0, 0};
-    long long at = -1;   // chars offset of the window (a multiple of 16), -1: none
-    __device__ uint32_t byte(const uint8_t* chars, long long n_chars, long long pos) {
-        const long long base = pos & ~15ll;
-        if (base != at) {
-            if (base + 16 <= n_chars) {
-                win = *reinterpret_cast<const TrieBytes16*>(chars + base);
-            } else {   // the chars tensor's last bytes
-                uint32_t v[4] = {0, 0, 0, 0};
-                for (long long k = base; k < n_chars; ++k) v[(k - base) >> 2] |= uint32_t(chars[k]) << (8 * ((k - base) & 3));
-                win = TrieBytes16{v[0], v[1], v[2], v[3]};
-            }
-            at = base;
-        }
-        const int k = int(pos & 15);
-        const uint32_t word = k < 8 ? (k < 4 ? win.x : win.y) : (k < 12 ? win.z : win.w);
-        return (word >> (8 * (k & 3))) & 0xFFu;
+// the chars tensor's last bytes, fewer than sixteen: byte by byte (out of line: a path of a few lanes per batch, kept out of the walk's loop)
+__device__ __attribute__((noinline)) static uint4 trie_window_tail(const uint8_t* chars, long long n_chars, long long base) {
+    uint64_t lo = 0, hi = 0;
+    for (long long k = base; k < n_chars; ++k) {
+        const uint64_t v = uint64_t(chars[k]) << (8 * ((k - base) & 7));
+        if (k - base < 8) lo |= v;
+        else hi |= v;
     }
+    return uint4{uint32_t(lo), uint32_t(lo >> 32), uint32_t(hi), uint32_t(hi >> 32)};
+}
+struct __attribute__((packed, aligned(1))) TrieBytes16 { uint32_t d[4]; };
+// Sixteen bytes of the chars tensor per lane, in LDS: a step reads its byte with one ds_read_u8 (the byte load from global memory in front of
+// every trie step was a dependent load of its own; the window in registers, a 64-bit shift per byte).
+struct TrieWindow {
+    uint8_t* mine;       // the lane's sixteen bytes (LDS)
+    long long at = -1;   // chars offset of the window (a multiple of 16), -1: none
 };
 struct TrieRows {
     const int32_t* ragged_begins;
@@ -857,7 +853,7 @@ struct TrieRows {
     const int32_t* ends;
     const uint8_t* chars;
     long long n_strings, n_chars;
-    TrieDev trie;
+    TrieBucketsDev trie;
     RunStatus* status;
 
     // bytes of the row's strings, -1 for offsets outside their tensors
@@ -873,48 +869,91 @@ struct TrieRows {
         return sum;
     }
 
-    // The greedy chain over the string chars[b, b + n) from position `from`, as a FLAT loop: every turn of it is one trie step of the
-    // lane's current token -- the first byte through the root table (`root`: a copy in LDS), then one edge per turn -- and a token's end
-    // (emit, back to the root) is part of the turn that finds it.  Written as the reference writes it -- a loop over tokens round a loop
-    // over steps (src/utils.cpp:517-538) -- a WAVE ran, for the k-th token of its 64 lanes, as many inner turns as the longest of those
-    // 64 tokens.  The chain goes on while `more(position)` says so for the position behind a token (and the string has bytes left);
-    // returns that position, or kTrieBroken | position where no token matches (the reference spins there forever, :72-75).
+    // The greedy chain over the string chars[b, b + n) from position `from` (Trie::find_longest, src/utils.cpp:517-538, token after token),
+    // as a FLAT loop of ONE 16-BYTE READ PER TURN, whatever the lane is at:
+    //   * the sixteen bytes of text round the byte at hand, when the lane's window does not hold it (a turn in sixteen), or
+    //   * half a bucket of the edge table: the edge (node, byte) is there -- on to the next byte --, or an entry of the half is free -- the
+    //     node has no such edge: the token found so far ends (emit, back to the root: part of the same turn) --, or the half is full of
+    //     other edges: the next turn reads the other half / the next bucket.
+    // The root is a node of the bucket table like the others (kTrieRoot): no branch for a token's first byte.
+    // Measured on a config-2 batch's 590 000 segments (profiles/r06/n_trie_*): the open-addressed 16-byte edges with the root table in LDS
+    // and the text window in registers 444 us (103 vector + 102 scalar instructions per turn of a wave: both branches, the window's
+    // refill, the probe loop); buckets read whole 470; buckets by halves, the second half and the refill out of line 343; this form 359
+    // -- same time, a third of the code.  72 M vector + 61 M scalar instructions per launch either way: a wave's turn is ~160
+    // instructions for one table read, most of them the bookkeeping of lanes that are at different points of their tokens.
+    // The chain goes on while `more(position)` says so for the position behind a token (and the string has bytes left); returns that
+    // position, or kTrieBroken | position where no token matches (the reference spins there forever, src/trie_tokenizer.cpp:72-75).
     template <class Emit, class More>
-    __device__ int32_t chain(long long b, int n, int from, const I2* root, TrieWindow& tw, Emit&& emit, More&& more) const {
-        int idx = from;                    // where the current token starts
-        int i = 0, cur = -1, best = -1, best_end = 0;   // cur < 0: at the root
-        bool stop = false;
-        while (idx < n) {
-            if (cur < 0) {   // Trie::find_longest's first step
-                const I2 r = root[tw.byte(chars, n_chars, b + idx)];
-                best = r.y < 0 ? -1 : r.x;
-                best_end = idx + 1;
-                i = idx + 1;
-                cur = r.y < 0 ? 0 : (r.y & ~kLeafBit);
-                stop = r.y < 0 || (r.y & kLeafBit) != 0 || i >= n;
+    __device__ __forceinline__ int32_t chain(long long b, int n, int from, TrieWindow& tw, Emit&& emit, More&& more) const {
+        if (from >= n) return from;
+        int idx = from;   // where the current token starts
+        int i = from;     // the position of the byte at hand
+        int cur = kTrieRoot, best = -1, best_end = 0;
+        uint32_t key = 0, bk = 0, half = 0;
+        bool text = true;   // this turn reads text
+        // the byte at position i is in the window: its edge's key and bucket
+        auto aim = [&]() {
+            const uint32_t byte = tw.mine[(b + i) & 15];
+            key = (uint32_t(cur) << 8) | byte;
+#ifdef OVTK_SIMT_EMULATOR
+            bk = trie_bucket_of(uint32_t(cur), byte, trie.bucket_mask);
+#else
+            const uint32_t h = __umul24(uint32_t(cur), 0x9E3779u) + __umul24(byte, 0x85EBCBu);   // trie_bucket_of()
+            bk = ((h >> 9) ^ h) & trie.bucket_mask;
+#endif
+            half = 0;
+        };
+        if (((b + i) & ~15ll) == tw.at) {
+            text = false;
+            aim();
+        }
+        for (;;) {
+            const long long base = (b + i) & ~15ll;
+            uint4 v;
+            if (text && base + 16 > n_chars) {   // the chars tensor's last bytes (a lane or two per batch)
+                v = trie_window_tail(chars, n_chars, base);
             } else {
-                TrieEdge ed;
-                if (trie_step(trie, cur, tw.byte(chars, n_chars, b + i), ed)) {
-                    cur = ed.child;
-                    ++i;
-                    if (ed.value != -1) {
-                        best = ed.value;
-                        best_end = i;
-                    }
-                    stop = ed.has_kids == 0 || i >= n;
-                } else {
-                    stop = true;
+                const char* at = text ? reinterpret_cast<const char*>(chars) + base : reinterpret_cast<const char*>(trie.buckets) + ((size_t(bk) << 5) | (half << 4));
+                const TrieBytes16 w = *reinterpret_cast<const TrieBytes16*>(at);   // (the text may start at any address: gfx950 reads 16 bytes at any alignment)
+                v = uint4{w.d[0], w.d[1], w.d[2], w.d[3]};
+            }
+#ifndef OVTK_SIMT_EMULATOR
+            asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));   // (one 16-byte read: left alone, the compiler fetches an entry's value in a second round trip)
+#endif
+            if (text) {
+                *reinterpret_cast<uint4*>(tw.mine) = v;
+                tw.at = base;
+                text = false;
+                aim();
+                continue;
+            }
+            const bool m0 = (v.x & ~kTrieKids) == key, m1 = (v.z & ~kTrieKids) == key;
+            bool stop = true;
+            if (m0 | m1) {
+                const int value = int(m0 ? v.y : v.w);
+                cur = int(4u * bk + 2u * half + (m0 ? 0u : 1u));
+                ++i;
+                if (value != -1) {
+                    best = value;
+                    best_end = i;
                 }
+                stop = (((m0 ? v.x : v.z) & kTrieKids) == 0) || i >= n;
+            } else if (v.x != kTrieFree && v.z != kTrieFree) {   // a full half: the edge may be behind it
+                bk = (bk + half) & trie.bucket_mask;
+                half ^= 1u;
+                continue;
             }
             if (stop) {
                 if (best == -1) return kTrieBroken | idx;
                 emit(idx, best);
-                idx = best_end;
-                cur = -1;
-                if (!more(idx)) break;
+                idx = i = best_end;
+                cur = kTrieRoot;
+                best = -1;
+                if (idx >= n || !more(idx)) return idx;
             }
+            if (((b + i) & ~15ll) != tw.at) text = true;
+            else aim();
         }
-        return idx;
     }
 };
 // a row's staging stretch: its bytes rounded up to whole segments (so that stretch offset / 64 numbers the segments of the batch)
@@ -950,9 +989,7 @@ struct TrieStageFin {
 // A lane per segment: the chain that starts at the segment's first byte.
 static __global__ __launch_bounds__(kTileThreads) void trie_segments_kernel(TrieRows r, const long long* stage_off, const int32_t* seg_row, int32_t* stage,
                                                                             unsigned long long* seg_bits, int32_t* seg_exit) {
-    __shared__ I2 root_lds[256];
-    for (int k = int(threadIdx.x); k < 256; k += kTileThreads) root_lds[k] = r.trie.root[k];
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) uint8_t win_lds[kTileThreads][16];
     if (r.status->flags & (kFlagRange | kFlagStageOverflow)) return;
     const long long g = (long long)blockIdx.x * kTileThreads + threadIdx.x;
     if (g >= r.status->stage_need / kTrieSeg) return;
@@ -966,9 +1003,9 @@ static __global__ __launch_bounds__(kTileThreads) void trie_segments_kernel(Trie
         const int n = int(r.ends[cb] - b);
         const int base = int(g - so / kTrieSeg) * kTrieSeg;
         const int until = base + kTrieSeg;
-        TrieWindow tw;
+        TrieWindow tw{win_lds[threadIdx.x]};
         int32_t* dst = stage + so;
-        exit = r.chain(b, n, base, root_lds, tw,
+        exit = r.chain(b, n, base, tw,
                        [&](int at, int tok) {
                            dst[at] = tok;
                            bits |= 1ull << (at - base);
@@ -979,19 +1016,21 @@ static __global__ __launch_bounds__(kTileThreads) void trie_segments_kernel(Trie
     seg_exit[g] = exit;
 }
 // A lane per row: the true chain through the row's segments (rows of one string), or the whole walk (rows of several); the count filed.
+// (`spread`: only every spread-th lane has a row -- the lanes wait for one table read after the other, and 65 536 rows on every lane are one
+// wave per SIMD with nothing to switch to)
 static __global__ __launch_bounds__(kTileThreads) void trie_rows_kernel(long long n_rows, TrieRows r, const long long* stage_off, int32_t* stage,
-                                                                        unsigned long long* seg_bits, const int32_t* seg_exit, int32_t* lens) {
-    __shared__ I2 root_lds[256];
-    for (int k = int(threadIdx.x); k < 256; k += kTileThreads) root_lds[k] = r.trie.root[k];
-    __syncthreads();
+                                                                        unsigned long long* seg_bits, const int32_t* seg_exit, int32_t* lens, int spread) {
+    __shared__ __attribute__((aligned(16))) uint8_t win_lds[kTileThreads][16];
     if (r.status->flags & (kFlagRange | kFlagStageOverflow)) return;
-    const long long row = (long long)blockIdx.x * kTileThreads + threadIdx.x;
+    const long long t0 = (long long)blockIdx.x * kTileThreads + threadIdx.x;
+    if (t0 % spread != 0) return;
+    const long long row = t0 / spread;
     if (row >= n_rows) return;
     const long long so = stage_off[row];
     const long long g0 = so / kTrieSeg;
     int32_t* dst = stage + so;
     const long long cb = r.ragged_begins[row], ce = r.ragged_ends[row];
-    TrieWindow tw;
+    TrieWindow tw{win_lds[threadIdx.x]};
     int32_t count = 0;
     if (ce - cb == 1) {
         const long long b = r.begins[cb];
@@ -1012,7 +1051,7 @@ static __global__ __launch_bounds__(kTileThreads) void trie_rows_kernel(long lon
             } else {
                 keep = 0;
                 int met = -1;   // the guess's token start the walk stepped on
-                const int32_t e = r.chain(b, n, t, root_lds, tw,
+                const int32_t e = r.chain(b, n, t, tw,
                                           [&](int at, int tok) {
                                               dst[at] = tok;
                                               keep |= 1ull << (at - base);
@@ -1045,7 +1084,7 @@ static __global__ __launch_bounds__(kTileThreads) void trie_rows_kernel(long lon
         for (long long col = cb; col < ce && !broken; ++col) {
             const long long b = r.begins[col];
             const int n = int(r.ends[col] - b);
-            const int32_t e = r.chain(b, n, 0, root_lds, tw,
+            const int32_t e = r.chain(b, n, 0, tw,
                                       [&](int at, int tok) {
                                           const int p = at0 + at;
                                           if (p / kTrieSeg != seg) {
@@ -1097,12 +1136,28 @@ struct TrieGather {
         const long long end = row + 1 < n_rows ? stage_off[row + 1] : status->stage_need;
         int32_t* dst = out_ids + out_begins[row];
         const int l = lane_id();
+        const long long g0 = so / kTrieSeg, n_seg = (end - so) / kTrieSeg;
         int done = 0;
-        const int n = lens[row];
-        for (long long g = so / kTrieSeg; g < end / kTrieSeg && done < n; ++g) {
-            const unsigned long long bits = seg_bits[g];
-            if ((bits >> l) & 1ull) dst[done + __popcll(bits & ((1ull << l) - 1))] = stage[g * kTrieSeg + l];
-            done += __popcll(bits);
+        // the masks of 64 segments at a time, a lane each; then eight segments' entries in flight at once
+        for (long long s0 = 0; s0 < n_seg; s0 += kWave) {
+            const unsigned long long mine = s0 + l < n_seg ? seg_bits[g0 + s0 + l] : 0ull;
+            const int here = int(n_seg - s0 < kWave ? n_seg - s0 : kWave);
+            for (int k0 = 0; k0 < here; k0 += 8) {
+                int32_t v[8];
+                unsigned long long bits[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    bits[k] = (unsigned long long)(uint32_t)wave_readlane(int(uint32_t(mine)), (k0 + k) & (kWave - 1)) |
+                              ((unsigned long long)(uint32_t)wave_readlane(int(uint32_t(mine >> 32)), (k0 + k) & (kWave - 1)) << 32);
+                    if (k0 + k >= here) bits[k] = 0;
+                    v[k] = ((bits[k] >> l) & 1ull) ? stage[(g0 + s0 + k0 + k) * kTrieSeg + l] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if ((bits[k] >> l) & 1ull) dst[done + __popcll(bits[k] & ((1ull << l) - 1))] = v[k];
+                    done += __popcll(bits[k]);
+                }
+            }
         }
     }
 };

@@ -79,6 +79,42 @@ void TrieHost::finalize() {
         }
 }
 
+bool TrieBucketsHost::build(const TrieHost& t) {
+    const auto& kids = t.b.kids;
+    const auto& value = t.b.value;
+    size_t n_edges = 0;
+    for (size_t i = 0; i < kids.size(); ++i) n_edges += kids[i].size();
+    const uint32_t n_buckets = std::max<uint32_t>(2, pow2_at_least(uint64_t(n_edges) / 2 + 1));   // one to two entries of four taken
+    if (4ull * n_buckets > uint64_t(kTrieMaxNodes)) return false;
+    bucket_mask = n_buckets - 1;
+    bucket_shift = 32 - log2u(n_buckets);
+    TrieBucket free_bucket;
+    for (int k = 0; k < 8; ++k) free_bucket.kv[k] = kTrieFree;
+    buckets.assign(n_buckets, free_bucket);
+    root.assign(256, I2{-1, -1});
+    // breadth first: an edge's key holds its parent's number, which is the place the parent's own edge was given
+    std::vector<std::pair<int, int>> queue{{0, kTrieRoot}};   // (host node, its number here)
+    for (size_t q = 0; q < queue.size(); ++q) {
+        const int host = queue[q].first, node = queue[q].second;
+        for (const auto& k : kids[size_t(host)]) {
+            const uint32_t key = (uint32_t(node) << 8) | k.first;
+            uint32_t bk = trie_bucket_of(uint32_t(node), k.first, bucket_mask);
+            int slot = -1;
+            for (;; bk = (bk + 1) & bucket_mask) {
+                for (int j = 0; j < 4 && slot < 0; ++j)
+                    if (buckets[bk].kv[2 * j] == kTrieFree) slot = j;
+                if (slot >= 0) break;
+            }
+            const int child = k.second;
+            buckets[bk].kv[2 * slot] = key | (kids[size_t(child)].empty() ? 0u : kTrieKids);
+            buckets[bk].kv[2 * slot + 1] = uint32_t(value[size_t(child)]);
+            queue.emplace_back(child, int(4u * bk + uint32_t(slot)));
+            if (host == 0) root[k.first] = I2{value[size_t(child)], int(4u * bk + uint32_t(slot)) | (kids[size_t(child)].empty() ? kLeafBit : 0)};
+        }
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------- BPE
 namespace {
 // Cuckoo insertion by random walk (deterministic xorshift): `choices(item, idx)` fills the candidate slot

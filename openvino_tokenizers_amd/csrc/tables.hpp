@@ -55,6 +55,31 @@ struct TrieDev {
     uint32_t edge_shift;     // 32 - log2(capacity)
 };
 
+// TrieTokenizer's own form of the edges (round 6): BUCKETS of four 8-byte entries, one 32-byte sector per step whether the edge exists or
+// not (the open-addressed 16-byte TrieEdge costs 1.5 reads when it does and 2.5 when it does not, and the walk is bound by the rate of
+// exactly these reads), half the bytes per edge.  An entry: key = has_kids << 31 | parent node << 8 | byte (all ones: free), value = the
+// token that ends here or -1.  The node an entry leads to is the entry's own index, 4 * bucket + slot (the root's edges are entries like the
+// others, parent kTrieRoot, and once more a 256-entry table for the kernels' LDS).  A bucket that is full sends its surplus to the next
+// one: a lookup goes on only from a bucket without a free entry.
+struct alignas(32) TrieBucket {
+    uint32_t kv[8];   // key0, value0, key1, value1, ...
+};
+constexpr uint32_t kTrieFree = 0xFFFFFFFFu;
+constexpr uint32_t kTrieKids = 0x80000000u;
+// the bucket of the edge (node, byte): two 24-bit multiplies (full rate on gfx950; a 32-bit one is a quarter) -- nodes are entry indices,
+// spread by the hash that placed them
+__host__ __device__ inline uint32_t trie_bucket_of(uint32_t node, uint32_t byte, uint32_t mask) {
+    const uint32_t h = (node & 0xFFFFFFu) * 0x9E3779u + byte * 0x85EBCBu;   // (both products below 2^48: the low 32 bits, as v_mul_u32_u24 gives them)
+    return ((h >> 9) ^ h) & mask;
+}
+constexpr int kTrieRoot = (1 << 23) - 2;    // (a key, node << 8 | byte, stays below 2^31 - 1: never a free entry's all-ones less the kids bit)
+constexpr int kTrieMaxNodes = kTrieRoot - 1;
+struct TrieBucketsDev {
+    const I2* root;   // [256] x = token id ending at this byte or -1; y = node | kLeafBit when nothing goes on from it, or -1 (no token starts with this byte)
+    const TrieBucket* buckets;
+    uint32_t bucket_mask, bucket_shift;
+};
+
 struct alignas(16) MergeSlot {
     uint64_t kr;   // merge_key(left, right) << kMaxRankBits | rank; kEmptySlot = free
     uint64_t nid;  // id of the merged token
@@ -253,6 +278,14 @@ struct TrieHost {
     TrieHost();
     void add(const uint8_t* s, size_t n, int32_t value);  // later add of the same string overwrites
     void finalize();                                      // flattens b -> root/node/edges
+};
+
+// TrieHost's nodes as TrieBucketsDev's tables; false: more nodes than an entry's key can name
+struct TrieBucketsHost {
+    std::vector<I2> root;
+    std::vector<TrieBucket> buckets;
+    uint32_t bucket_mask = 0, bucket_shift = 32;
+    bool build(const TrieHost& t);
 };
 
 struct BpeHost {
