@@ -10,6 +10,8 @@
 #include <openvino/core/op_extension.hpp>
 #include <openvino/core/any.hpp>
 
+#include <cstdlib>
+
 #include "ops.hpp"
 
 using namespace ovtk_adapter;
@@ -36,6 +38,18 @@ OPENVINO_CREATE_EXTENSIONS(
 // clang-format on
 
 namespace {
+// Device memory per tokenizer node: every BPETokenizer / WordpieceTokenizer handle owns a piece store sized by the library's default
+// (include/ovtk_amd.h ovtk_set_memo_store: GPT-2 64 MB, Llama-3 128 MB) -- the nodes are created with memo_store = 0 --, and a graph that
+// is cloned per infer request multiplies it.  OVTK_AMD_MEMO_STORE=<entries> (0 or less: no store) sets that default once, when this
+// library is loaded; it changes no result, only what a repeated text costs.
+const bool memo_store_from_env = [] {
+    if (const char* e = std::getenv("OVTK_AMD_MEMO_STORE")) {
+        const long long n = std::atoll(e);
+        ovtk_set_memo_store(n > 0 ? n : -1);
+    }
+    return true;
+}();
+
 template <typename T>
 T attr(const ov::AnyMap& attributes, const std::string& name, const T& fallback) {
     auto it = attributes.find(name);
