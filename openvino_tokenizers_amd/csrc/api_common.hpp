@@ -218,6 +218,11 @@ inline int grid_lookup(int device, int n_rows) { return grid_rows(device, n_rows
 // ceil(n_rows / waves) rows per wave -- or, where that would be more than the 64 a wave's lanes can hold headers for (hundreds of
 // thousands of short rows), 64 rows per wave and as many blocks as that takes: the surplus runs as later rounds.
 inline int rows_grid(int n_rows, int persistent_grid, int32_t& rows_per_wave) {
+    static const int rows_env = [] { const char* e = std::getenv("OVTK_SPAN_ROWS"); return e ? std::atoi(e) : 0; }();   // (measurements: rows per wave, any grid)
+    if (rows_env >= 1 && rows_env <= kWave) {
+        rows_per_wave = rows_env;
+        return std::max(1, (n_rows + rows_env * kWavesPerBlock - 1) / (rows_env * kWavesPerBlock));
+    }
     const int waves = persistent_grid * kWavesPerBlock;
     rows_per_wave = (n_rows + waves - 1) / waves;
     // A multiple of compact_kernel's work item (kCompactRows = 4 rows) where a wave owns more than that: an item whose rows were staged by
