@@ -1131,10 +1131,13 @@ def main():
     run_steps(0, args.warmup)
     lib.ovtk_profile_enable(0)   # the timed region runs without the library's per-kernel event brackets
     barrier()
+    timed_stamps = [] if os.environ.get("OVTK_BENCH_STAMPS") else None   # (a diagnostic: when each of the K batches completed, to stderr)
     t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)   # every one of the K batches is complete (and, N > 1, gathered on every rank) when it returns
+    run_steps(args.warmup, args.steps, timed_stamps)   # every one of the K batches is complete (and, N > 1, gathered on every rank) when it returns
     barrier()
     dt = time.perf_counter() - t0
+    if timed_stamps:
+        print("timed region: completions at (us)", [round((x - t0) * 1e6) for x in timed_stamps], "end", round(dt * 1e6), file=sys.stderr)
     # The same loop for 200 further steps: the K steps above are the reported region -- 1.3 ms of wall time at K = 20,
     # of which one fill of the three-stream pipeline is a visible part --, this leg says what the loop settles at, and how evenly the
     # batches complete (the host-side interval between two completions: its median, and the 90th percentile).

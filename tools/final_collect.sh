@@ -2,6 +2,7 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r06; T=${TAG:-e}; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -x -q > $O/${T}_gpu_tests.log 2>&1; tail -2 $O/${T}_gpu_tests.log
 timeout 300 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --short-path 0 > $O/${T}_bench_c2_four_launches.json 2>/dev/null
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/${T}_bench_c2_driver_form.json 2>/dev/null; timeout 600 python bench.py --steps 20 --warmup 5 --short-path 0 > $O/${T}_bench_c2_driver_form_four_launches.json 2>/dev/null
 for c in 2 3 4 5 pipeline r2d vocab_encoder 1; do timeout 600 python bench.py --config $c > $O/${T}_bench_c$c.json 2> $O/${T}_bench_c$c.err; done
 for p in qwen2 cl100k o200k deepseek-v3; do timeout 300 python bench.py --config 4 --pattern $p --no-cpu-baseline --no-extras > $O/${T}_bench_c4_$p.json 2>/dev/null; done
 timeout 300 python bench.py --config 2 --steps 200 --warmup 10 --no-cpu-baseline --no-extras > $O/${T}_bench_c2_200steps.json 2>/dev/null
