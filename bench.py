@@ -999,7 +999,7 @@ def main():
     ap.add_argument("--lib", default=None, help="debug: load this build of libovtk_amd.so")
     ap.add_argument("--no-alone-leg", action="store_true", help="skip the one-stream leg behind `roofline` (profile runs of the "
                     "overlapped loop: rocprofv3's per-kernel average then covers the overlapped launches only)")
-    ap.add_argument("--depth", type=int, default=2, help="batches launched ahead of the one being completed (two-half calls)")
+    ap.add_argument("--depth", type=int, default=3, help="batches launched ahead of the one being completed (two-half calls); 3 since round 6: the same rate over 200 steps as 2, a shorter way into the pipeline for the first batches of a 20-step window (profiles/r06/x_depth_ab.txt)")
     ap.add_argument("--exchange", default="allgather", choices=["allgather", "p2p"],
                     help="N > 1: one RCCL all-gather of the wires, or grouped direct sends / receives (one xGMI link per pair)")
     ap.add_argument("--wire", type=int, default=1,
