@@ -562,7 +562,14 @@ bool fusable(const ovtk_regex_split* split, const ovtk_bpe* bpe = nullptr) {
 struct SparseRowLen {
     const int32_t* rb;
     const int32_t* re;
-    __device__ long long operator()(long long i) const { return re[i] - rb[i]; }
+    RunStatus* status;   // regex_sparse_kernel marks a row of bad offsets with a begin of -1: the range error is raised here (nullptr: no such rows)
+    __device__ long long operator()(long long i) const {
+        if (rb[i] < 0) {
+            if (status) atomicOr(&status->flags, kFlagRange);
+            return 0;
+        }
+        return re[i] - rb[i];
+    }
 };
 struct SparseRowGather {
     const int32_t* rb;
@@ -578,10 +585,33 @@ struct SparseRowGather {
         for (long long k = 0; k < len; ++k) {
             o_b[off + k] = b[src + k];
             o_e[off + k] = e[src + k];
-            o_sk[off + k] = sk[src + k];
+            if (o_sk) o_sk[off + k] = sk[src + k];
         }
     }
 };
+// ... the same for rows of many strings (RegexSplit: a row's pieces): the scan files the offsets, a WAVE per row moves the strings
+struct SparseRowOffsets {
+    int32_t *o_rb, *o_re;
+    __device__ void operator()(long long i, long long off, long long len) const {
+        o_rb[i] = int32_t(off);
+        o_re[i] = int32_t(off + len);
+    }
+};
+static __global__ __launch_bounds__(kBlockThreads) void sparse_gather_kernel(int n_rows, const int32_t* rb, const int32_t* b, const int32_t* e, const uint8_t* sk,
+                                                                             const int32_t* o_rb, const int32_t* o_re, int32_t* o_b, int32_t* o_e, uint8_t* o_sk,
+                                                                             const RunStatus* status, uint32_t skip_flags) {
+    if (status->flags & skip_flags) return;
+    const int l = lane_id();
+    const int n_waves = int(gridDim.x) * kWavesPerBlock;
+    for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < n_rows; row += n_waves) {
+        const int src = rb[row], off = o_rb[row], len = o_re[row] - off;
+        for (int k = l; k < len; k += kWave) {
+            o_b[off + k] = b[src + k];
+            o_e[off + k] = e[src + k];
+            if (o_sk) o_sk[off + k] = sk[src + k];
+        }
+    }
+}
 struct SparseFin {   // total -> status->n_out (special_sparse_kernel used the word as its region counter) + capacity flag
     RunStatus* status;
     long long cap;
@@ -590,6 +620,47 @@ struct SparseFin {   // total -> status->n_out (special_sparse_kernel used the w
         if (total > cap) atomicOr(&status->flags, kFlagOutCapacity);
     }
 };
+// RegexSplit, the op alone, for a COMPILED pattern (the DFA): regex_sparse_kernel -- the fused encode's one-pass form, a lane per row, a
+// character per turn -- into buffers of the reference's capacity, the scan of the rows' counts, the gather.  Until round 6 the automaton ran
+// twice (regex_split_kernel<0 / 1>, split_on_device).  The hand-written scanners keep their count and write passes.
+int regex_one_pass(const ovtk_regex_split* h, Workspace& sw, const RowsIn& d_in, hipStream_t s, int32_t* d_rb, int32_t* d_re, int32_t* d_b,
+                   int32_t* d_e, uint8_t* d_sk, long long capacity) {
+    const int n_rows = d_in.n_rows;
+    const long long cap = (long long)d_in.n_chars + d_in.n_strings;   // src/regex_split.cpp:182
+    int e = 0;
+    e = e ? e : sw.gen[0].ensure(size_t(n_rows) * 4);
+    e = e ? e : sw.gen[1].ensure(size_t(n_rows) * 4);
+    e = e ? e : sw.gen[2].ensure(size_t(cap) * 4);
+    e = e ? e : sw.gen[3].ensure(size_t(cap) * 4);
+    e = e ? e : sw.gen[4].ensure(size_t(cap));
+    e = e ? e : sw.tiles.ensure(scan_tiles_bytes(n_rows));
+    e = e ? e : sw.status.ensure(sizeof(RunStatus));
+    if (e) return e;
+    RunStatus* st = sw.status.as<RunStatus>();
+    OVTK_HIP(hipMemsetAsync(st, 0, sizeof(RunStatus), s));
+    int32_t *t_rb = sw.gen[0].as<int32_t>(), *t_re = sw.gen[1].as<int32_t>(), *t_b = sw.gen[2].as<int32_t>(), *t_e = sw.gen[3].as<int32_t>();
+    uint8_t* t_sk = sw.gen[4].as<uint8_t>();
+    const int lane_grid = (n_rows + kBlockThreads - 1) / kBlockThreads;
+    const RegexSparseLds lay = regex_sparse_layout(h->regex.n_states * h->regex.n_syms, h->regex.cp_blocks_bytes);
+    note_launch(sw.marks, s);
+    Profiler& pf = Profiler::get();
+    if (pf.enabled()) pf.begin("regex_split", s, sw.marks);
+    if (h->mode == 1 && h->max_splits == -1)
+        hipLaunchKernelGGL(regex_sparse_kernel<true>, dim3(lane_grid), dim3(kBlockThreads), size_t(lay.total), s, d_in, h->regex, st, cap, t_rb, t_re, t_b, t_e,
+                           t_sk);
+    else
+        hipLaunchKernelGGL(regex_sparse_kernel<false>, dim3(lane_grid), dim3(kBlockThreads), size_t(lay.total), s, d_in, h->regex, st, cap, t_rb, t_re, t_b, t_e,
+                           t_sk);
+    if (pf.enabled()) pf.end(s, sw.marks);
+    // (a row of bad offsets has begin -1 / end 0 there: SparseBadRows turns that into the range error the count pass used to raise)
+    launch_scan(sw.marks, "regex_split", s, (long long)n_rows, SparseRowLen{t_rb, t_re, st}, SparseRowOffsets{d_rb, d_re}, SparseFin{st, capacity},
+                sw.tiles.as<long long>(), st, kFlagOutCapacity | kFlagRange);
+    OVTK_LAUNCH(sw.marks, "regex_split", sparse_gather_kernel, grid_lookup(h->device, n_rows), kBlockThreads, s, n_rows, (const int32_t*)t_rb, (const int32_t*)t_b,
+                (const int32_t*)t_e, (const uint8_t*)t_sk, (const int32_t*)d_rb, (const int32_t*)d_re, d_b, d_e, d_sk, (const RunStatus*)st,
+                uint32_t(kFlagOutCapacity | kFlagRange));
+    return OVTK_OK;
+}
+
 // SpecialTokensSplit, the op alone, in ONE pass over the text: special_sparse_kernel (the fused encode's: a sweep of the text for the tokens'
 // first bytes, only the rows in which one turns up are walked) into buffers of the reference's capacity, the scan of the rows' counts, the
 // gather.  Until round 6: count pass, scan, write pass, a lane walking each row twice (special_on_device below: 0.24 ms for a config-2 batch).
@@ -613,7 +684,7 @@ int special_one_pass(const ovtk_special_tokens_split* h, Workspace& sw, const Ro
     uint8_t* t_sk = sw.gen[4].as<uint8_t>();
     OVTK_LAUNCH(sw.marks, "special_split", special_sparse_kernel, (n_rows + kWave - 1) / kWave, kBlockThreads, s, d_in, h->dev, st, cap_extra, t_rb, t_re, t_b,
                 t_e, t_sk);
-    launch_scan(sw.marks, "special_split", s, (long long)n_rows, SparseRowLen{t_rb, t_re}, SparseRowGather{t_rb, t_b, t_e, t_sk, d_rb, d_re, d_b, d_e, d_sk},
+    launch_scan(sw.marks, "special_split", s, (long long)n_rows, SparseRowLen{t_rb, t_re, nullptr}, SparseRowGather{t_rb, t_b, t_e, t_sk, d_rb, d_re, d_b, d_e, d_sk},
                 SparseFin{st, capacity}, sw.tiles.as<long long>(), st, kFlagOutCapacity | kFlagRange);
     return OVTK_OK;
 }
@@ -758,11 +829,11 @@ int start_encode(const ovtk_regex_split* split_in, const ovtk_bpe* bpe, const ov
             if (split->mode == 1 && split->max_splits == -1)
                 hipLaunchKernelGGL(regex_sparse_kernel<true>, dim3(lane_grid), dim3(kBlockThreads), size_t(lay.total), s, d_in, split->regex,
                                    sw.status.as<RunStatus>(), (long long)cap, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
-                                   sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>());
+                                   sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>(), (uint8_t*)nullptr);
             else
                 hipLaunchKernelGGL(regex_sparse_kernel<false>, dim3(lane_grid), dim3(kBlockThreads), size_t(lay.total), s, d_in, split->regex,
                                    sw.status.as<RunStatus>(), (long long)cap, sw.gen[0].as<int32_t>(), sw.gen[1].as<int32_t>(),
-                                   sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>());
+                                   sw.gen[2].as<int32_t>(), sw.gen[3].as<int32_t>(), (uint8_t*)nullptr);
             if (pf.enabled()) pf.end(s, sw.marks);
             OVTK_HIP(hipMemcpyAsync(sw.host_status, sw.status.as<RunStatus>(), sizeof(RunStatus), hipMemcpyDeviceToHost, s));   // (read at finish)
             sparse_status = true;
@@ -1264,7 +1335,21 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
     if (out->skips) e = e ? e : out_target(ws->out_e, out->skips, size_t(out->capacity), mem, &d_sk);
     if (e) return e;
     int64_t n_out = 0;
-    if (int rc = split_on_device(h, *ws.ws, d_in, s, d_rb, d_re, d_b, d_e, d_sk, out->capacity, &n_out)) return rc;
+    bool done = false;
+    if (h->dev.kind == kSplitGeneral && (long long)d_in.n_chars + d_in.n_strings < INT32_MAX) {   // a compiled pattern: the automaton runs once
+        if (int rc = regex_one_pass(h, *ws.ws, d_in, s, d_rb, d_re, d_b, d_e, d_sk, (long long)out->capacity)) return rc;
+        if (int rc = finish_status(*ws.ws, s)) return rc;
+        const RunStatus& st = *ws->host_status;
+        if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
+        // (the capacity flag may also mean the one-pass form's own buffers -- strings that overlap ask for more than n_chars + n_strings --: the
+        // count and write passes below have the last word)
+        if (!(st.flags & kFlagOutCapacity)) {
+            n_out = st.n_out;
+            done = true;
+        }
+    }
+    if (!done)
+        if (int rc = split_on_device(h, *ws.ws, d_in, s, d_rb, d_re, d_b, d_e, d_sk, out->capacity, &n_out)) return rc;
     out->n = n_out;
     if (mem == OVTK_MEM_HOST) {
         OVTK_HIP(hipMemcpyAsync(out->ragged_begins, d_rb, size_t(n_rows) * 4, hipMemcpyDeviceToHost, s));

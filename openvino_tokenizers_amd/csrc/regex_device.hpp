@@ -240,7 +240,8 @@ __host__ __device__ inline RegexSparseLds regex_sparse_layout(int n_trans, int c
 template <bool PLAIN>
 static __global__ __launch_bounds__(kBlockThreads) void regex_sparse_kernel(RowsIn in, RegexDev R, RunStatus* status, long long capacity,
                                                                             int32_t* out_rb, int32_t* out_re, int32_t* out_begins,
-                                                                            int32_t* out_ends) {
+                                                                            int32_t* out_ends, uint8_t* out_skips) {
+    // (out_skips: the RegexSplit op's third output -- a piece of a skipped string carries the flag, regex_split.cpp:231-234 -- or nullptr)
     int* bump = &status->n_out;
     // dynamic LDS (regex_sparse_lds_bytes): transitions | ASCII classes | code-point index | code-point blocks -- whatever of it
     // fits; with two waves per SIMD (a lane per row) every table read is on the critical path, and a non-ASCII character is two
@@ -308,9 +309,10 @@ static __global__ __launch_bounds__(kBlockThreads) void regex_sparse_kernel(Rows
         return;
     }
     int count = 0;
-    auto put = [&](int b, int e) {
+    auto put = [&](int b, int e, int skip = 0) {
         out_begins[base + count] = b;
         out_ends[base + count] = e;
+        if (out_skips) out_skips[base + count] = uint8_t(skip);
         ++count;
     };
     // ---- one loop: a character per turn
@@ -368,7 +370,7 @@ static __global__ __launch_bounds__(kBlockThreads) void regex_sparse_kernel(Rows
             sb = in.begins[col];
             len = in.ends[col] - sb;
             if (in.skips && in.skips[col]) {  // regex_split.cpp:231-234 (BPETokenizer has no skips input: the string is one piece)
-                put(sb, sb + len);
+                put(sb, sb + len, 1);
                 ++col;
                 continue;
             }
