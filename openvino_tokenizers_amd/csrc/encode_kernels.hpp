@@ -1828,6 +1828,8 @@ static __global__ __launch_bounds__(kBlockThreads) void encode_small_kernel(Rows
 
 // ---- RegexSplit as its own op: count pass, then write pass (the scan is cheap enough to run twice).
 // mode 0: row_cnt[row] = number of pieces.  mode 1: write begins/ends/skips at row_out[row].
+// mode 2 (round 6, the op in one pass): write at w.row_stage[row] -- the row's region in buffers of the reference's capacity, a slot per byte and
+// one per string, the offsets a scan of those bounds -- and file the count in row_cnt[row]; the caller scans the counts and gathers.
 template <int WRITE, bool LLAMA3 = false>
 static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, SplitDev sp, int max_splits, EncodeWork w,
                                                                      int32_t* out_rb, int32_t* out_re,
@@ -1841,8 +1843,8 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
     for (int row = int(blockIdx.x) * kWavesPerBlock + wave_in_block(); row < in.n_rows; row += n_waves) {
         int count = 0;
         int total = 0;
-        const int o = WRITE ? int(row_output_offset(w, in.n_rows, row, total)) : 0;
-        if (WRITE && l == 0) {
+        const int o = WRITE == 2 ? w.row_stage[row] : (WRITE ? int(row_output_offset(w, in.n_rows, row, total)) : 0);
+        if (WRITE == 1 && l == 0) {
             out_rb[row] = o;
             out_re[row] = o + total;
         }
@@ -1885,7 +1887,7 @@ static __global__ __launch_bounds__(kBlockThreads) void split_kernel(RowsIn in, 
                 });
             count += in_string;
         }
-        if (!WRITE && l == 0) w.row_cnt[row] = count;
+        if (WRITE != 1 && l == 0) w.row_cnt[row] = count;
     }
 }
 
