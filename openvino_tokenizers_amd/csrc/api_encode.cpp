@@ -1420,10 +1420,10 @@ int ovtk_regex_split_run(ovtk_regex_split* h, const ovtk_ragged_strings* in, con
         }
         if (int rc = finish_status(*ws.ws, s)) return rc;
         const RunStatus& st = *ws->host_status;
-        if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
-        // (the capacity flag may also mean the one-pass form's own buffers -- strings that overlap ask for more than n_chars + n_strings --: the
-        // count and write passes below have the last word)
+        // (the capacity flag may also mean the one-pass form's own buffers -- strings that overlap ask for more than n_chars + n_strings, and
+        // the rows that found no room there look like rows of bad offsets --: the count and write passes below have the last word)
         if (!(st.flags & kFlagOutCapacity)) {
+            if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
             n_out = st.n_out;
             done = true;
         }
@@ -1465,12 +1465,18 @@ int ovtk_special_tokens_split_run(ovtk_special_tokens_split* h, const ovtk_ragge
     e = e ? e : out_target(ws->out_d, out->ends, size_t(out->capacity) * 4, mem, &d_e);
     e = e ? e : out_target(ws->out_e, out->skips, size_t(out->capacity), mem, &d_sk);
     if (e) return e;
-    if ((long long)d_in.n_rows + d_in.n_chars + d_in.n_strings >= INT32_MAX) {   // (the one-pass form's buffers: the three-pass form has none)
-        if (int rc = special_on_device(h, *ws.ws, d_in, s, d_rb, d_re, d_b, d_e, d_sk, (long long)out->capacity)) return rc;
-    } else {
+    bool one_pass = (long long)d_in.n_rows + d_in.n_chars + d_in.n_strings < INT32_MAX;   // (the one-pass form's buffers: the three-pass form has none)
+    if (one_pass) {
         if (int rc = special_one_pass(h, *ws.ws, d_in, s, d_rb, d_re, d_b, d_e, d_sk, (long long)out->capacity)) return rc;
+        if (int rc = finish_status(*ws.ws, s)) return rc;
+        // (the capacity flag may also mean the one-pass form's own buffers -- rows that name the same strings again ask for more than
+        // n_chars + n_strings --: the count and write passes have the last word)
+        if (ws->host_status->flags & kFlagOutCapacity) one_pass = false;
     }
-    if (int rc = finish_status(*ws.ws, s)) return rc;
+    if (!one_pass) {
+        if (int rc = special_on_device(h, *ws.ws, d_in, s, d_rb, d_re, d_b, d_e, d_sk, (long long)out->capacity)) return rc;
+        if (int rc = finish_status(*ws.ws, s)) return rc;
+    }
     const RunStatus& st = *ws->host_status;
     if (st.flags & kFlagRange) return set_error(OVTK_E_RANGE, "input begins/ends index outside their tensors");
     if (st.flags & kFlagOutCapacity) return set_error(OVTK_E_CAPACITY, "SpecialTokensSplit: output begins/ends too small");

@@ -286,6 +286,30 @@ def test_rows_with_several_strings_and_skips(backend):
         assert_same(ref[:4] + [ref[5]], list(got[:4]) + [got[5]], backend.host, pat)
 
 
+def test_rows_that_name_the_same_strings_again(backend):
+    """The one-pass forms of the split ops (round 6) write a row's pieces into a region of buffers of the reference's capacity,
+    n_chars + n_strings (regex_split.cpp:182, special_tokens_split.cpp:88-92); rows / strings that alias the same text ask for more than
+    that: the ops then fall back to their count and write passes, and the result is the oracle's either way.  A compiled pattern, a
+    hand-written scanner (GPT-2's), SpecialTokensSplit."""
+    from openvino_tokenizers_amd.ops import SpecialTokensSplit
+    words = ["helloworld itsalongword", "<|endoftext|> 1234567890 tailtailtail", "xxxxxxxx<|endoftext|>yyyyyyyy zzzzzzzz", "abcdefgh ijklmnopqrstuvw"]
+    b0, e0, c = O.pack_strings(words)
+    reps = 2   # (twice the bytes: more than the capacity's n_chars + n_strings of bounds, fewer pieces than it -- the reference's own limit)
+    b, e = np.tile(b0, reps), np.tile(e0, reps)   # 8 strings over the same 120-odd bytes
+    n = len(b)
+    rb = np.arange(0, n, 2, dtype=np.int32)
+    re_ = rb + 2
+    assert int((e - b).sum()) + n > len(c) + n
+    for pat in (r"\w+|[^\w\s]+", GPT2_PATTERN):
+        ref = O.RegexSplit(pat, "isolate")(rb, re_, b, e, c)
+        got = RegexSplit("isolate", lib=backend.lib).evaluate(backend.data([rb, re_, b, e, c]) + [np.frombuffer(pat.encode(), np.uint8)])
+        assert_same(ref[:5], got[:5], backend.host, pat)
+    sp_pat = O.special_tokens_pattern([("<|endoftext|>", False, False)])
+    ref = O.SpecialTokensSplit(sp_pat)(rb, re_, b, e, c)
+    got = SpecialTokensSplit(lib=backend.lib).evaluate(backend.data([rb, re_, b, e, c]) + [np.frombuffer(sp_pat.encode(), np.uint8)])
+    assert_same(list(ref), got, backend.host, "SpecialTokensSplit over aliased strings")
+
+
 @pytest.mark.parametrize("name", ["qwen2", "cl100k-tiktoken", "o200k", "deepseek-v3", "clip"])
 def test_fused_encode_with_compiled_pattern(backend, name):
     """ovtk_encode_run with a pattern that has no scanner: RegexSplit (DFA) -> BPETokenizer inside one call = the oracle
